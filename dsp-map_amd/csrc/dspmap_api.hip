@@ -1,0 +1,948 @@
+// dspmap_api.hip -- host runtime + C ABI (include/dspmap.h) of libdspmap_hip.so.
+// Host logic restates DSPMap::update's gating / delta-pose preamble
+// (reference include/dsp_dynamic.h:187-218) and owns the device state; all
+// per-particle / per-voxel work is in dspmap_kernels.hip.  There is no CPU
+// compute path here: without a usable HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/dspmap.h"
+#include "dspmap_kernels.h"
+#include "velocity_estimator.h"
+
+struct dspmap {
+    dspmap_config cfg;
+    MapDims d;
+    FilterParams fp;
+    DevState s;
+    KernelScratch k;
+    bool device_ready = false;
+    bool own_stream = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    int device = -1;
+    std::string err;
+    // parameters
+    float p_stddev = 0.2f, v_stddev = 0.1f;  // :154-155
+    float voxel_filter_res = 0.15f;          // :132
+    bool use_vel_est = false;
+    bool regen_tables = false;
+    bool nb_frozen = false;                  // function statics of the birth stage (:808-811)
+    // tables (host copies kept until upload)
+    std::vector<float> h_ptab, h_vtab;
+    std::vector<int> h_rtab;
+    bool tables_injected = false, rtab_injected = false;
+    int pend_cursor[3] = {0, 0, 0};
+    // function statics of update() (:187-190)
+    bool have_last = false;
+    float last_p[3] = {0, 0, 0};
+    double last_stamp = 0.0;
+    float cur_pos[3] = {0, 0, 0};
+    float quat[4] = {1, 0, 0, 0};
+    float dt_last = 0.f;
+    // capacities
+    int pt_cap = 0, birth_cap = 0;
+    float* pts_dev = nullptr;        // staging for host-fed clouds
+    float* pts_pin = nullptr; int pts_pin_cap = 0;
+    BirthSrc* birth_pin = nullptr; int birth_pin_cap = 0;
+    // birth cloud supplied by the caller (estimator off) / produced by the estimator
+    std::vector<dspmap_vpoint> h_birth;
+    bool h_birth_valid = false;
+    int last_n_birth = 0;            // entries of s.birth used by the last frame
+    bool last_birth_static = false;
+    int vz_frames = 0;
+    int last_n_points = 0;
+    VelocityEstimator vel;
+};
+
+static int fail(dspmap* m, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (m) m->err = buf;
+    return code;
+}
+#define HIPCHK(m, call)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail((m), DSPMAP_E_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+static LaunchCtx ctx_of(dspmap* m) {
+    LaunchCtx c;
+    c.d = m->d; c.fp = m->fp; c.s = m->s; c.k = m->k; c.stream = m->stream;
+    c.pt_cap = m->pt_cap; c.birth_cap = m->birth_cap;
+    return c;
+}
+
+extern "C" void dspmap_default_config(dspmap_config* c) {  // dsp_dynamic.h:38-50
+    memset(c, 0, sizeof(*c));
+    c->nx = 66; c->ny = 66; c->nz = 40;
+    c->voxel_resolution = 0.15f;
+    c->angle_resolution = 3;
+    c->max_particle_num_voxel = 9;
+    c->half_fov_h = 42; c->half_fov_v = 24;
+    c->prediction_times = 6;
+    const float t[6] = {0.05f, 0.2f, 0.5f, 1.f, 1.5f, 2.f};
+    memcpy(c->prediction_future_time, t, sizeof(t));
+    c->device = -1;
+}
+
+static void derive_dims(dspmap* m) {
+    const dspmap_config& c = m->cfg;
+    MapDims& d = m->d;
+    memset(&d, 0, sizeof(d));
+    d.nx = c.nx; d.ny = c.ny; d.nz = c.nz;
+    d.z_lo = c.z_lo; d.z_hi = c.z_hi;
+    if (d.z_lo == 0 && d.z_hi == 0) d.z_hi = c.nz;
+    d.v_loc = c.nx * c.ny * (d.z_hi - d.z_lo);
+    d.v_base = d.z_lo * c.nx * c.ny;
+    d.v_glob = c.nx * c.ny * c.nz;                                     // :62
+    d.M = c.max_particle_num_voxel;
+    d.slots = 2 * d.M;                                                 // :65
+    d.mw = (d.slots + 63) / 64;
+    const int A = c.angle_resolution;
+    d.np_h = c.half_fov_h * 2 / A;                                     // :58
+    d.np_v = c.half_fov_v * 2 / A;                                     // :59
+    d.np = d.np_h * d.np_v;                                            // :60
+    const int pyramid_num = 360 * 180 / A / A;                         // :63
+    const int safe_particle_num = (int)((double)d.v_glob * d.M + 1e5); // :64
+    d.capp = safe_particle_num / pyramid_num * 2;                      // :66
+    d.T = c.prediction_times;
+    d.res = c.voxel_resolution;
+    d.half_x = (d.res * (float)c.nx) * 0.5f;                           // :528-530
+    d.half_y = (d.res * (float)c.ny) * 0.5f;
+    d.half_z = (d.res * (float)c.nz) * 0.5f;
+    for (int i = 0; i < d.T; ++i) d.pred_t[i] = c.prediction_future_time[i];
+}
+
+static void refresh_fp(dspmap* m) {
+    FilterParams& f = m->fp;
+    f.inv_sigma_ob = 1.f / f.sigma_ob;
+    const float pi_2 = 1.57079632679489661923f;
+    f.pdf_c = 1.f / sqrtf(2.f * pi_2);  // standardNormalPDF :1284 at 0
+    f.pdf_c3 = f.pdf_c * f.pdf_c * f.pdf_c;
+}
+
+extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
+    if (!cfg) return nullptr;
+    if (cfg->nx <= 0 || cfg->ny <= 0 || cfg->nz <= 0 || cfg->voxel_resolution <= 0.f) return nullptr;
+    if (cfg->angle_resolution <= 0 || cfg->max_particle_num_voxel <= 0 || cfg->max_particle_num_voxel > 64) return nullptr;
+    if (cfg->prediction_times < 0 || cfg->prediction_times > DSPMAP_MAX_PRED_TIMES) return nullptr;
+    if (cfg->z_lo < 0 || cfg->z_hi > cfg->nz || cfg->z_lo > cfg->z_hi) return nullptr;
+    dspmap* m = new dspmap();
+    m->cfg = *cfg;
+    derive_dims(m);
+    if (m->d.np_h + 1 > DSP_MAX_PLANES_H || m->d.np_v + 1 > DSP_MAX_PLANES_V || m->d.np <= 0) { delete m; return nullptr; }
+    memset(&m->s, 0, sizeof(m->s));
+    memset(&m->k, 0, sizeof(m->k));
+    FilterParams& f = m->fp;
+    memset(&f, 0, sizeof(f));
+    f.sigma_ob = 0.2f; f.kappa = 0.01f; f.p_det = 0.95f;  // :156-158
+    f.nb_weight = 0.04f; f.nb_num = 20;                   // :162-163
+    f.occl_margin = 0.3f;                                 // :70
+    f.tab_n = 1; f.rtab_n = 1;
+    refresh_fp(m);
+    m->device = cfg->device;
+    m->vel.configure(cfg->half_fov_h, cfg->half_fov_v, cfg->angle_resolution);
+    return m;
+}
+
+static void free_dev(dspmap* m) {
+    if (!m->device_ready) return;
+    DevState& s = m->s;
+    void* ptrs[] = {s.mask, s.nbmask, s.px, s.py, s.pz, s.vx, s.vy, s.w, s.vz0, s.res4, s.fut, s.obs, s.obs_ck,
+                    s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
+                    s.birth, s.plan, s.nstatic, s.fov_rec, s.fov_slot, s.pyr_cnt, s.mv_rec, s.exp_up, s.exp_down,
+                    s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mvmask, m->k.expmask,
+                    m->k.part_predict, m->k.part_claim, m->k.part_resample, m->pts_dev};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (m->pts_pin) (void)hipHostFree(m->pts_pin);
+    if (m->birth_pin) (void)hipHostFree(m->birth_pin);
+    if (m->ev0) (void)hipEventDestroy(m->ev0);
+    if (m->ev1) (void)hipEventDestroy(m->ev1);
+    if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
+    m->device_ready = false;
+}
+
+extern "C" void dspmap_destroy(dspmap_t* m) {
+    if (!m) return;
+    free_dev(m);
+    delete m;
+}
+
+extern "C" const char* dspmap_last_error(const dspmap_t* m) { return m ? m->err.c_str() : "null handle"; }
+
+template <typename T>
+static hipError_t dalloc(T** p, size_t n) {
+    return hipMalloc((void**)p, sizeof(T) * (n ? n : 1));
+}
+
+// generateGaussianRandomsVectorZeroCenter :1150-1160 (same engine/distribution as the reference)
+static void gen_gauss_tables(dspmap* m, unsigned seed) {
+    const int n = m->cfg.gaussian_table_size > 0 ? m->cfg.gaussian_table_size : 10000000;  // :72
+    m->h_ptab.resize(n); m->h_vtab.resize(n);
+    std::default_random_engine random(seed);
+    std::normal_distribution<double> n1(0, m->p_stddev);
+    std::normal_distribution<double> n2(0, m->v_stddev);
+    for (int i = 0; i < n; i++) { m->h_ptab[i] = (float)n1(random); m->h_vtab[i] = (float)n2(random); }
+}
+static void gen_rand_table(dspmap* m, unsigned seed) {
+    // the reference draws uniforms with libc rand() after srand(time(0)) (:586,1551-1553);
+    // a private random_r stream of the same generator is tabulated instead
+    const int n = 1 << 22;
+    m->h_rtab.resize(n);
+    struct random_data rd;
+    memset(&rd, 0, sizeof(rd));
+    char state[128];
+    initstate_r(seed, state, sizeof(state), &rd);
+    for (int i = 0; i < n; i++) { int32_t r; random_r(&rd, &r); m->h_rtab[i] = r; }
+}
+
+static int upload_tables(dspmap* m) {
+    DevState& s = m->s;
+    if (s.p_tab) { (void)hipFree(s.p_tab); s.p_tab = nullptr; }
+    if (s.v_tab) { (void)hipFree(s.v_tab); s.v_tab = nullptr; }
+    const size_t n = m->h_ptab.size();
+    HIPCHK(m, dalloc(&s.p_tab, n));
+    HIPCHK(m, dalloc(&s.v_tab, n));
+    HIPCHK(m, hipMemcpy(s.p_tab, m->h_ptab.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+    HIPCHK(m, hipMemcpy(s.v_tab, m->h_vtab.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+    m->fp.tab_n = (int)n;
+    return DSPMAP_OK;
+}
+static int upload_rtab(dspmap* m) {
+    DevState& s = m->s;
+    if (s.r_tab) { (void)hipFree(s.r_tab); s.r_tab = nullptr; }
+    const size_t n = m->h_rtab.size();
+    HIPCHK(m, dalloc(&s.r_tab, n));
+    HIPCHK(m, hipMemcpy(s.r_tab, m->h_rtab.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    m->fp.rtab_n = (int)n;
+    return DSPMAP_OK;
+}
+
+static int ensure_point_cap(dspmap* m, int n) {
+    if (n <= m->pt_cap) return DSPMAP_OK;
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    DevState& s = m->s;
+    const int cap = n + n / 2 + 1024;
+    void* olds[] = {s.pt_rot, s.pt_pyr, s.birth, s.plan, s.nstatic, m->pts_dev};
+    for (void* p : olds) if (p) (void)hipFree(p);
+    HIPCHK(m, dalloc(&s.pt_rot, (size_t)cap));
+    HIPCHK(m, dalloc(&s.pt_pyr, (size_t)cap));
+    HIPCHK(m, dalloc(&s.birth, (size_t)cap));
+    HIPCHK(m, dalloc(&s.plan, (size_t)cap));
+    HIPCHK(m, dalloc(&s.nstatic, (size_t)cap));
+    HIPCHK(m, dalloc(&m->pts_dev, (size_t)cap * 3));
+    m->pt_cap = cap; m->birth_cap = cap;
+    return DSPMAP_OK;
+}
+
+extern "C" int dspmap_init_device(dspmap_t* m) {
+    if (!m) return DSPMAP_E_ARG;
+    if (m->device_ready) return DSPMAP_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(m, DSPMAP_E_DEVICE, "no HIP device available (libdspmap_hip has no CPU fallback)");
+    if (m->device >= 0) HIPCHK(m, hipSetDevice(m->device));
+    else HIPCHK(m, hipGetDevice(&m->device));
+    if (!m->stream) { HIPCHK(m, hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
+    HIPCHK(m, hipEventCreate(&m->ev0));
+    HIPCHK(m, hipEventCreate(&m->ev1));
+    const MapDims& d = m->d;
+    DevState& s = m->s;
+    const size_t S = (size_t)d.v_loc * d.slots, W = (size_t)d.v_loc * d.mw;
+    HIPCHK(m, dalloc(&s.mask, W)); HIPCHK(m, dalloc(&s.nbmask, W));
+    HIPCHK(m, dalloc(&s.px, S)); HIPCHK(m, dalloc(&s.py, S)); HIPCHK(m, dalloc(&s.pz, S));
+    HIPCHK(m, dalloc(&s.vx, S)); HIPCHK(m, dalloc(&s.vy, S)); HIPCHK(m, dalloc(&s.w, S));
+    HIPCHK(m, dalloc(&s.res4, (size_t)d.v_loc));
+    HIPCHK(m, dalloc(&s.fut, (size_t)d.v_loc * (d.T ? d.T : 1)));
+    HIPCHK(m, dalloc(&s.obs, (size_t)d.np * DSP_OBS_CAP));
+    HIPCHK(m, dalloc(&s.obs_ck, (size_t)d.np * DSP_OBS_CAP));
+    HIPCHK(m, dalloc(&s.obs_cnt, (size_t)d.np));
+    HIPCHK(m, dalloc(&s.obs_maxlen, (size_t)d.np));
+    HIPCHK(m, dalloc(&s.planes_h, (size_t)(d.np_h + 1) * 3)); HIPCHK(m, dalloc(&s.planes_v, (size_t)(d.np_v + 1) * 3));
+    HIPCHK(m, dalloc(&s.planes_h0, (size_t)(d.np_h + 1) * 3)); HIPCHK(m, dalloc(&s.planes_v0, (size_t)(d.np_v + 1) * 3));
+    HIPCHK(m, dalloc(&s.fov_rec, (size_t)d.np * d.capp));
+    HIPCHK(m, dalloc(&s.fov_slot, (size_t)d.np * d.capp));
+    HIPCHK(m, dalloc(&s.pyr_cnt, (size_t)d.np));
+    HIPCHK(m, dalloc(&s.fs, (size_t)1));
+    KernelScratch& k = m->k;
+    k.tpb_sweep = sweep_geometry(d.slots, &k.vpw_sweep);
+    k.nblk_sweep = (d.v_loc + k.vpw_sweep - 1) / k.vpw_sweep;
+    k.nblk_resample = (d.v_loc + 255) / 256;
+    HIPCHK(m, dalloc(&k.mvmask, W));
+    const bool slab = !(d.z_lo == 0 && d.z_hi == d.nz);
+    if (slab) HIPCHK(m, dalloc(&k.expmask, W));
+    HIPCHK(m, dalloc(&k.part_predict, (size_t)k.nblk_sweep * 4));
+    HIPCHK(m, dalloc(&k.part_claim, (size_t)k.nblk_sweep * 2));
+    HIPCHK(m, dalloc(&k.part_resample, (size_t)k.nblk_resample * 4));
+    HIPCHK(m, dalloc(&s.blk_cnt, (size_t)k.nblk_resample + 1));
+    HIPCHK(m, hipMemset(s.mask, 0, sizeof(u64) * W)); HIPCHK(m, hipMemset(s.nbmask, 0, sizeof(u64) * W));
+    HIPCHK(m, hipMemset(k.mvmask, 0, sizeof(u64) * W));
+    if (k.expmask) HIPCHK(m, hipMemset(k.expmask, 0, sizeof(u64) * W));
+    HIPCHK(m, hipMemset(s.res4, 0, sizeof(float4) * (size_t)d.v_loc));
+    HIPCHK(m, hipMemset(s.fut, 0, sizeof(float) * (size_t)d.v_loc * (d.T ? d.T : 1)));
+    HIPCHK(m, hipMemset(s.fs, 0, sizeof(FrameScalars)));
+    HIPCHK(m, hipMemset(s.obs_cnt, 0, sizeof(int) * d.np));
+    HIPCHK(m, hipMemset(s.obs_ck, 0, sizeof(float) * d.np * DSP_OBS_CAP));
+    HIPCHK(m, hipMemset(s.pyr_cnt, 0, sizeof(int) * d.np));
+    HIPCHK(m, hipMemset(k.part_predict, 0, sizeof(int) * (size_t)k.nblk_sweep * 4));
+    HIPCHK(m, hipMemset(k.part_claim, 0, sizeof(int) * (size_t)k.nblk_sweep * 2));
+    HIPCHK(m, hipMemset(k.part_resample, 0, sizeof(int) * (size_t)k.nblk_resample * 4));
+    {   // boundary-plane normals, sensor frame (:563-578; float sin/cos like the C++ overloads)
+        std::vector<float> h((size_t)(d.np_h + 1) * 3), v((size_t)(d.np_v + 1) * 3);
+        const float pi_f = 3.14159265358979323846f;
+        const int A = m->cfg.angle_resolution;
+        const float ang = (float)A / 180.f * pi_f;  // :543
+        const int he = m->cfg.half_fov_h / A, ve = m->cfg.half_fov_v / A;
+        for (int i = -he; i <= he; i++) { h[(i + he) * 3] = -sinf((float)i * ang); h[(i + he) * 3 + 1] = cosf((float)i * ang); h[(i + he) * 3 + 2] = 0.f; }
+        for (int i = -ve; i <= ve; i++) { v[(i + ve) * 3] = sinf((float)i * ang); v[(i + ve) * 3 + 1] = 0.f; v[(i + ve) * 3 + 2] = cosf((float)i * ang); }
+        HIPCHK(m, hipMemcpy(s.planes_h0, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
+        HIPCHK(m, hipMemcpy(s.planes_v0, v.data(), sizeof(float) * v.size(), hipMemcpyHostToDevice));
+        HIPCHK(m, hipMemcpy(s.planes_h, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
+        HIPCHK(m, hipMemcpy(s.planes_v, v.data(), sizeof(float) * v.size(), hipMemcpyHostToDevice));
+    }
+    m->device_ready = true;  // from here on free_dev() releases everything
+    unsigned seed = m->cfg.seed ? m->cfg.seed : (unsigned)time(nullptr);  // :586,1151
+    if (!m->tables_injected) gen_gauss_tables(m, seed);
+    if (!m->rtab_injected) gen_rand_table(m, seed);
+    int rc = upload_tables(m);
+    if (rc != DSPMAP_OK) return rc;
+    rc = upload_rtab(m);
+    if (rc != DSPMAP_OK) return rc;
+    {   // cursors
+        FrameScalars fs;
+        memset(&fs, 0, sizeof(fs));
+        fs.p_cur = m->pend_cursor[0]; fs.v_cur = m->pend_cursor[1]; fs.r_cur = m->pend_cursor[2];
+        HIPCHK(m, hipMemcpy(s.fs, &fs, sizeof(fs), hipMemcpyHostToDevice));
+    }
+    rc = ensure_point_cap(m, 8192);
+    if (rc != DSPMAP_OK) return rc;
+    HIPCHK(m, hipDeviceSynchronize());
+    return DSPMAP_OK;
+}
+
+#define READY(m)                                       \
+    do {                                               \
+        if (!(m)) return DSPMAP_E_ARG;                 \
+        if (!(m)->device_ready) {                      \
+            int rc_ = dspmap_init_device(m);           \
+            if (rc_ != DSPMAP_OK) return rc_;          \
+        } else if ((m)->device >= 0) {                 \
+            (void)hipSetDevice((m)->device);           \
+        }                                              \
+    } while (0)
+
+extern "C" int dspmap_sync(dspmap_t* m) {
+    if (!m) return DSPMAP_E_ARG;
+    if (!m->device_ready) return DSPMAP_OK;
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}
+
+extern "C" int dspmap_set_stream(dspmap_t* m, void* hip_stream) {
+    if (!m) return DSPMAP_E_ARG;
+    if (m->device_ready) HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (m->own_stream && m->stream) { (void)hipStreamDestroy(m->stream); m->own_stream = false; }
+    m->stream = (hipStream_t)hip_stream;
+    return DSPMAP_OK;
+}
+
+// ------------------------------------------------------------------ setters
+extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
+    if (!m) return DSPMAP_E_ARG;
+    switch (key) {
+        case DSPMAP_P_POSITION_STDDEV: m->p_stddev = (float)v; break;
+        case DSPMAP_P_VELOCITY_STDDEV: m->v_stddev = (float)v; break;
+        case DSPMAP_P_OBSERVATION_STDDEV: m->fp.sigma_ob = (float)v; refresh_fp(m); break;
+        case DSPMAP_P_NEWBORN_WEIGHT: m->fp.nb_weight = (float)v; break;
+        case DSPMAP_P_NEWBORN_NUMBER:
+            if (v < 1 || v > 32) return fail(m, DSPMAP_E_ARG, "newborn number must be in [1,32]");
+            m->fp.nb_num = (int)v; break;
+        case DSPMAP_P_VOXEL_FILTER_RES: m->voxel_filter_res = (float)v; break;
+        case DSPMAP_P_KAPPA: m->fp.kappa = (float)v; break;
+        case DSPMAP_P_DETECTION: m->fp.p_det = (float)v; break;
+        case DSPMAP_P_VELOCITY_ESTIMATOR: m->use_vel_est = v != 0; break;
+        case DSPMAP_P_REGENERATE_TABLES:
+            // setPredictionVariance regenerates both tables with a fresh seed (:355-360)
+            if (v != 0 && !m->tables_injected) {
+                gen_gauss_tables(m, m->cfg.seed ? m->cfg.seed + 1 : (unsigned)time(nullptr));
+                if (m->device_ready) { HIPCHK(m, hipStreamSynchronize(m->stream)); return upload_tables(m); }
+            }
+            break;
+        default: return fail(m, DSPMAP_E_ARG, "unknown parameter key %d", key);
+    }
+    return DSPMAP_OK;
+}
+extern "C" double dspmap_get_param(const dspmap_t* m, int key) {
+    if (!m) return 0;
+    switch (key) {
+        case DSPMAP_P_POSITION_STDDEV: return m->p_stddev;
+        case DSPMAP_P_VELOCITY_STDDEV: return m->v_stddev;
+        case DSPMAP_P_OBSERVATION_STDDEV: return m->fp.sigma_ob;
+        case DSPMAP_P_NEWBORN_WEIGHT: return m->fp.nb_weight;
+        case DSPMAP_P_NEWBORN_NUMBER: return m->fp.nb_num;
+        case DSPMAP_P_VOXEL_FILTER_RES: return m->voxel_filter_res;
+        case DSPMAP_P_KAPPA: return m->fp.kappa;
+        case DSPMAP_P_DETECTION: return m->fp.p_det;
+        case DSPMAP_P_VELOCITY_ESTIMATOR: return m->use_vel_est ? 1 : 0;
+        default: return 0;
+    }
+}
+
+extern "C" int dspmap_set_gaussian_tables(dspmap_t* m, const float* p, const float* v, int n) {
+    if (!m || !p || !v || n <= 0) return DSPMAP_E_ARG;
+    m->h_ptab.assign(p, p + n);
+    m->h_vtab.assign(v, v + n);
+    m->tables_injected = true;
+    if (m->device_ready) {
+        HIPCHK(m, hipStreamSynchronize(m->stream));
+        int rc = upload_tables(m);
+        if (rc != DSPMAP_OK) return rc;
+        return dspmap_set_cursors(m, 0, 0, -1);
+    }
+    m->pend_cursor[0] = m->pend_cursor[1] = 0;
+    return DSPMAP_OK;
+}
+extern "C" int dspmap_set_rand_table(dspmap_t* m, const int* r, int n) {
+    if (!m || !r || n <= 0) return DSPMAP_E_ARG;
+    m->h_rtab.assign(r, r + n);
+    m->rtab_injected = true;
+    if (m->device_ready) {
+        HIPCHK(m, hipStreamSynchronize(m->stream));
+        int rc = upload_rtab(m);
+        if (rc != DSPMAP_OK) return rc;
+        return dspmap_set_cursors(m, -1, -1, 0);
+    }
+    m->pend_cursor[2] = 0;
+    return DSPMAP_OK;
+}
+extern "C" int dspmap_set_cursors(dspmap_t* m, int pc, int vc, int rc) {  // negative = leave unchanged
+    if (!m) return DSPMAP_E_ARG;
+    if (!m->device_ready) {
+        if (pc >= 0) m->pend_cursor[0] = pc;
+        if (vc >= 0) m->pend_cursor[1] = vc;
+        if (rc >= 0) m->pend_cursor[2] = rc;
+        return DSPMAP_OK;
+    }
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    FrameScalars fs;
+    HIPCHK(m, hipMemcpy(&fs, m->s.fs, sizeof(fs), hipMemcpyDeviceToHost));
+    if (pc >= 0) fs.p_cur = pc;
+    if (vc >= 0) fs.v_cur = vc;
+    if (rc >= 0) fs.r_cur = rc;
+    HIPCHK(m, hipMemcpy(m->s.fs, &fs, sizeof(fs), hipMemcpyHostToDevice));
+    return DSPMAP_OK;
+}
+extern "C" int dspmap_get_cursors(dspmap_t* m, int* pc, int* vc, int* rc) {
+    READY(m);
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    FrameScalars fs;
+    HIPCHK(m, hipMemcpy(&fs, m->s.fs, sizeof(fs), hipMemcpyDeviceToHost));
+    if (pc) *pc = fs.p_cur;
+    if (vc) *vc = fs.v_cur;
+    if (rc) *rc = fs.r_cur;
+    return DSPMAP_OK;
+}
+
+// --------------------------------------------------------------- the frame
+static void freeze_birth_statics(dspmap* m) {
+    if (m->nb_frozen) return;  // function statics initialised at first call (:808-811)
+    m->fp.min_static_nb = (int)((float)m->fp.nb_num * 0.15f);
+    m->fp.model_nb = (int)((float)m->fp.nb_num * 0.8f);
+    m->nb_frozen = true;
+}
+
+// C0 gate + deltas, update() :187-218.  returns 1 (accepted) / 0 (rejected)
+static int gate_and_delta(dspmap* m, const float pos[3], double stamp, const float q[4], float dp[3], float* dt) {
+    if (!m->have_last) {
+        m->last_p[0] = pos[0]; m->last_p[1] = pos[1]; m->last_p[2] = pos[2];
+        m->last_stamp = stamp;
+        m->have_last = true;
+    }
+    if (fabsf(q[0]) > 1.001f || fabsf(q[1]) > 1.001f || fabsf(q[2]) > 1.001f || fabsf(q[3]) > 1.001f) {
+        printf("Invalid quaternion.\n");  // :194
+        return 0;
+    }
+    dp[0] = pos[0] - m->last_p[0]; dp[1] = pos[1] - m->last_p[1]; dp[2] = pos[2] - m->last_p[2];
+    *dt = (float)(stamp - m->last_stamp);
+    if (fabsf(dp[0]) > 10.f || fabsf(dp[1]) > 10.f || fabsf(dp[2]) > 10.f || *dt < 0.f || *dt > 10.f) {
+        printf("!!! delt_t = %f\n", *dt);  // :204-206
+        return 0;
+    }
+    for (int i = 0; i < 3; i++) m->cur_pos[i] = m->last_p[i] = pos[i];
+    m->last_stamp = stamp;
+    m->dt_last = *dt;
+    for (int i = 0; i < 4; i++) m->quat[i] = q[i];
+    return 1;
+}
+
+// enqueue the stages after binning; birth source already selected in c.s.birth
+static void enqueue_filter(dspmap* m, LaunchCtx& c, const float dp[3], float dt, int n_birth) {
+    launch_predict(c, -dp[0], -dp[1], -dp[2], dt);  // particles move opposite to the sensor (:300)
+    launch_ck_partial(c);
+    launch_ck_finalize(c);
+    launch_weight_update(c);
+    launch_birth(c, n_birth, false);
+    launch_resample(c);
+    if (m->vz_frames > 0 && --m->vz_frames == 0) { /* vz0 stays allocated but is no longer consulted */ }
+}
+
+extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* points_dev, int n_birth,
+                                    const dspmap_vpoint* birth_dev, const float pos[3], double stamp,
+                                    const float q[4]) {
+    READY(m);
+    if (n_points < 0 || (n_points > 0 && !points_dev) || !pos || !q) return fail(m, DSPMAP_E_ARG, "bad arguments");
+    float dp[3], dt;
+    if (!gate_and_delta(m, pos, stamp, q, dp, &dt)) return DSPMAP_REJECTED;
+    int rc = ensure_point_cap(m, n_points > n_birth ? n_points : n_birth);
+    if (rc != DSPMAP_OK) return rc;
+    freeze_birth_statics(m);
+    LaunchCtx c = ctx_of(m);
+    if (m->vz_frames <= 0) c.s.vz0 = nullptr;
+    const bool static_birth = birth_dev == nullptr;
+    if (!static_birth) c.s.birth = (BirthSrc*)birth_dev;
+    const int nb = static_birth ? n_points : n_birth;
+    HIPCHK(m, hipEventRecord(m->ev0, m->stream));
+    launch_frame_setup(c, m->quat, m->cur_pos, true);
+    launch_obs_bin(c, n_points, points_dev, m->quat, static_birth);
+    enqueue_filter(m, c, dp, dt, nb);
+    HIPCHK(m, hipEventRecord(m->ev1, m->stream));
+    m->ev_valid = true;
+    m->last_n_points = n_points;
+    m->last_n_birth = nb;
+    m->last_birth_static = static_birth;
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}
+
+static int stage_points(dspmap* m, int n, int stride, const float* pts) {
+    int rc = ensure_point_cap(m, n);
+    if (rc != DSPMAP_OK) return rc;
+    if (n > m->pts_pin_cap) {
+        if (m->pts_pin) (void)hipHostFree(m->pts_pin);
+        m->pts_pin_cap = n + n / 2 + 1024;
+        HIPCHK(m, hipHostMalloc((void**)&m->pts_pin, sizeof(float) * 3 * (size_t)m->pts_pin_cap));
+    }
+    for (int i = 0; i < n; i++) {  // xyz are the first three floats of each point (:247,289)
+        m->pts_pin[3 * i] = pts[(size_t)i * stride];
+        m->pts_pin[3 * i + 1] = pts[(size_t)i * stride + 1];
+        m->pts_pin[3 * i + 2] = pts[(size_t)i * stride + 2];
+    }
+    if (n > 0) HIPCHK(m, hipMemcpyAsync(m->pts_dev, m->pts_pin, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, m->stream));
+    return DSPMAP_OK;
+}
+
+static int upload_birth(dspmap* m, const dspmap_vpoint* pts, int n) {
+    int rc = ensure_point_cap(m, n);
+    if (rc != DSPMAP_OK) return rc;
+    if (n > m->birth_pin_cap) {
+        if (m->birth_pin) (void)hipHostFree(m->birth_pin);
+        m->birth_pin_cap = n + n / 2 + 1024;
+        HIPCHK(m, hipHostMalloc((void**)&m->birth_pin, sizeof(BirthSrc) * (size_t)m->birth_pin_cap));
+    }
+    static_assert(sizeof(BirthSrc) == sizeof(dspmap_vpoint), "layout");
+    if (n > 0) {
+        memcpy(m->birth_pin, pts, sizeof(BirthSrc) * (size_t)n);
+        HIPCHK(m, hipMemcpyAsync(m->s.birth, m->birth_pin, sizeof(BirthSrc) * (size_t)n, hipMemcpyHostToDevice, m->stream));
+    }
+    return DSPMAP_OK;
+}
+
+// host copy of the rotation used for the estimator's input cloud (same operation order as the kernel)
+static void rotate_host(const float v[3], const float q[4], float out[3]) {
+    const float vq[4] = {0.f, v[0], v[1], v[2]};
+    const float n2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + q[0] * q[0];
+    const float inv[4] = {q[0] / n2, -q[1] / n2, -q[2] / n2, -q[3] / n2};
+    auto mul = [](const float a[4], const float b[4], float r[4]) {
+        r[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+        r[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+        r[2] = a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3];
+        r[3] = a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1];
+    };
+    float t[4], r[4];
+    mul(q, vq, t);
+    mul(t, inv, r);
+    out[0] = r[1]; out[1] = r[2]; out[2] = r[3];
+}
+
+extern "C" int dspmap_update(dspmap_t* m, int n, int stride, const float* pts, float sx, float sy, float sz,
+                             double stamp, float qw, float qx, float qy, float qz) {
+    READY(m);
+    if (n > 0 && (!pts || stride < 3)) return fail(m, DSPMAP_E_ARG, "bad point cloud arguments");
+    const float pos[3] = {sx, sy, sz};
+    const float q[4] = {qw, qx, qy, qz};
+    float dp[3], dt;
+    if (!gate_and_delta(m, pos, stamp, q, dp, &dt)) return DSPMAP_REJECTED;
+    const int np = n > 0 ? n : 0;
+    int rc = stage_points(m, np, stride, pts);
+    if (rc != DSPMAP_OK) return rc;
+    freeze_birth_statics(m);
+    LaunchCtx c = ctx_of(m);
+    if (m->vz_frames <= 0) c.s.vz0 = nullptr;
+    const bool have_cloud = m->use_vel_est || m->h_birth_valid;
+    HIPCHK(m, hipEventRecord(m->ev0, m->stream));
+    launch_frame_setup(c, m->quat, m->cur_pos, true);
+    launch_obs_bin(c, np, m->pts_dev, m->quat, !have_cloud);
+    launch_predict(c, -dp[0], -dp[1], -dp[2], dt);
+    launch_ck_partial(c);
+    launch_ck_finalize(c);
+    launch_weight_update(c);
+    int nb = np;
+    if (m->use_vel_est) {
+        // the reference forks velocityEstimationThread before prediction and joins before the birth
+        // stage (:297,311); here the host estimator overlaps with the kernels queued above
+        std::vector<float> view;
+        view.reserve((size_t)np * 3);
+        m->vel.rotate_and_filter(m->pts_pin, np, q, view);
+        m->vel.run(view, m->cur_pos, dt, m->voxel_filter_res, m->h_birth);
+        m->h_birth_valid = true;
+    }
+    if (have_cloud) {
+        nb = (int)m->h_birth.size();
+        rc = upload_birth(m, m->h_birth.data(), nb);
+        if (rc != DSPMAP_OK) return rc;
+        c.s = m->s;  // pointers may have been re-allocated
+        if (m->vz_frames <= 0) c.s.vz0 = nullptr;
+    }
+    if (n >= 0) launch_birth(c, nb, false);  // :314-316
+    launch_resample(c);
+    if (m->vz_frames > 0) --m->vz_frames;
+    HIPCHK(m, hipEventRecord(m->ev1, m->stream));
+    m->ev_valid = true;
+    m->last_n_points = np;
+    m->last_n_birth = nb;
+    m->last_birth_static = !have_cloud;
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}
+
+extern "C" int dspmap_set_birth_cloud(dspmap_t* m, const dspmap_vpoint* pts, int n) {
+    if (!m || n < 0 || (n > 0 && !pts)) return DSPMAP_E_ARG;
+    m->h_birth.assign(pts, pts + n);
+    m->h_birth_valid = true;
+    return DSPMAP_OK;
+}
+extern "C" int dspmap_get_birth_cloud(dspmap_t* m, dspmap_vpoint* out, int cap, int* n_out) {
+    READY(m);
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (m->last_birth_static) {
+        std::vector<BirthSrc> tmp((size_t)m->last_n_birth);
+        if (m->last_n_birth) HIPCHK(m, hipMemcpy(tmp.data(), m->s.birth, sizeof(BirthSrc) * tmp.size(), hipMemcpyDeviceToHost));
+        int k = 0;
+        for (auto& b : tmp)
+            if (b.intensity > -1.5f) { if (out && k < cap) memcpy(&out[k], &b, sizeof(b)); ++k; }
+        if (n_out) *n_out = k;
+    } else {
+        const int n = (int)m->h_birth.size();
+        for (int i = 0; i < n && i < cap && out; i++) out[i] = m->h_birth[i];
+        if (n_out) *n_out = n;
+    }
+    return DSPMAP_OK;
+}
+
+// ----------------------------------------------------------------- readout
+static int readout(dspmap* m, float thr, float* xyz, int cap, int* n_out, float* fut_out, bool want_occ) {
+    READY(m);
+    LaunchCtx c = ctx_of(m);
+    const MapDims& d = m->d;
+    int n = 0;
+    if (want_occ) {
+        if (!m->s.occ_xyz) { HIPCHK(m, dalloc(&m->s.occ_xyz, (size_t)d.v_loc * 3)); c.s = m->s; }
+        launch_occupied_compact(c, thr);
+        HIPCHK(m, hipMemcpyAsync(&n, &m->s.fs->occupied_count, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(m, hipStreamSynchronize(m->stream));
+        const int ncopy = n < cap ? n : cap;
+        if (xyz && ncopy > 0) HIPCHK(m, hipMemcpyAsync(xyz, m->s.occ_xyz, sizeof(float) * 3 * (size_t)ncopy, hipMemcpyDeviceToHost, m->stream));
+    }
+    if (fut_out && d.T > 0)
+        HIPCHK(m, hipMemcpyAsync(fut_out, m->s.fut, sizeof(float) * (size_t)d.v_loc * d.T, hipMemcpyDeviceToHost, m->stream));
+    launch_clear_future(c);  // :397-400, :420-424
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (n_out) *n_out = n;
+    return DSPMAP_OK;
+}
+extern "C" int dspmap_get_occupancy(dspmap_t* m, float thr, float* xyz, int cap, int* n_out) {
+    return readout(m, thr, xyz, cap, n_out, nullptr, true);
+}
+extern "C" int dspmap_get_occupancy_with_future(dspmap_t* m, float thr, float* xyz, int cap, int* n_out, float* fut) {
+    return readout(m, thr, xyz, cap, n_out, fut, true);
+}
+extern "C" int dspmap_get_future(dspmap_t* m, float* fut) { return readout(m, 0.f, nullptr, 0, nullptr, fut, false); }
+extern "C" int dspmap_clear_future(dspmap_t* m) {
+    READY(m);
+    LaunchCtx c = ctx_of(m);
+    launch_clear_future(c);
+    return DSPMAP_OK;
+}
+extern "C" int dspmap_get_results(dspmap_t* m, float* out) {
+    READY(m);
+    HIPCHK(m, hipMemcpyAsync(out, m->s.res4, sizeof(float4) * (size_t)m->d.v_loc, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    return DSPMAP_OK;
+}
+extern "C" const float* dspmap_results_device(dspmap_t* m) { return (m && m->device_ready) ? (const float*)m->s.res4 : nullptr; }
+extern "C" const float* dspmap_future_device(dspmap_t* m) { return (m && m->device_ready) ? m->s.fut : nullptr; }
+
+extern "C" void dspmap_voxel_center(const dspmap_t* m, int index, float* px, float* py, float* pz) {  // :1556-1572
+    const MapDims& d = m->d;
+    const int zc = d.ny * d.nx;
+    const int zi = index / zc, rest = index - zi * zc, yi = rest / d.nx, xi = rest - yi * d.nx;
+    const float cx = -d.half_x + d.res * 0.5f, cy = -d.half_y + d.res * 0.5f, cz = -d.half_z + d.res * 0.5f;
+    *px = (float)xi * d.res + cx; *py = (float)yi * d.res + cy; *pz = (float)zi * d.res + cz;
+}
+extern "C" int dspmap_point_voxel_index(const dspmap_t* m, float px, float py, float pz, int* index) {  // :1574-1584
+    const MapDims& d = m->d;
+    if (px >= d.half_x || px <= -d.half_x || py >= d.half_y || py <= -d.half_y || pz >= d.half_z || pz <= -d.half_z) return 0;
+    const int x = (int)((px + d.half_x) / d.res), y = (int)((py + d.half_y) / d.res), z = (int)((pz + d.half_z) / d.res);
+    *index = z * d.ny * d.nx + y * d.nx + x;
+    if (*index < 0 || *index >= d.v_glob) return 0;
+    return 1;
+}
+
+extern "C" int dspmap_voxel_num(const dspmap_t* m) { return m ? m->d.v_glob : 0; }
+extern "C" int dspmap_local_voxel_num(const dspmap_t* m) { return m ? m->d.v_loc : 0; }
+extern "C" int dspmap_slots_per_voxel(const dspmap_t* m) { return m ? m->d.slots : 0; }
+extern "C" int dspmap_pyramid_num(const dspmap_t* m) { return m ? m->d.np : 0; }
+extern "C" int dspmap_pyramid_capacity(const dspmap_t* m) { return m ? m->d.capp : 0; }
+
+extern "C" int dspmap_get_counters(dspmap_t* m, dspmap_counters* out) {
+    READY(m);
+    if (!out) return DSPMAP_E_ARG;
+    LaunchCtx c = ctx_of(m);
+    launch_reduce_counters(c);
+    FrameScalars fs;
+    HIPCHK(m, hipMemcpyAsync(&fs, m->s.fs, sizeof(fs), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    memset(out, 0, sizeof(*out));
+    out->n_points_in = m->last_n_points;
+    out->n_valid = fs.n_valid; out->n_obs = fs.n_obs; out->n_live_in = fs.n_live_in; out->n_moved = fs.n_moved;
+    out->n_out_of_map = fs.n_out_of_map; out->n_voxel_full = fs.n_voxel_full; out->n_pyramid_full = fs.n_pyramid_full;
+    out->n_fov = fs.n_fov; out->n_born = fs.n_born; out->n_born_dropped = fs.n_born_dropped;
+    out->n_live_out = fs.n_live_out; out->n_exported_up = fs.n_exp_up; out->n_exported_down = fs.n_exp_down;
+    out->newborn_weight = fs.newborn_w;
+    if (m->ev_valid) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, m->ev0, m->ev1) == hipSuccess) out->update_ms = ms;
+    }
+    return DSPMAP_OK;
+}
+
+// ------------------------------------------------------------ state access
+static int ensure_vz(dspmap* m) {
+    if (!m->s.vz0) {
+        const size_t S = (size_t)m->d.v_loc * m->d.slots;
+        HIPCHK(m, dalloc(&m->s.vz0, S));
+        HIPCHK(m, hipMemset(m->s.vz0, 0, sizeof(float) * S));
+    }
+    m->vz_frames = 2;  // seeded (flag 15) particles are first predicted in the second frame
+    return DSPMAP_OK;
+}
+
+extern "C" int dspmap_clear_state(dspmap_t* m) {
+    READY(m);
+    const MapDims& d = m->d;
+    const size_t W = (size_t)d.v_loc * d.mw;
+    HIPCHK(m, hipMemsetAsync(m->s.mask, 0, sizeof(u64) * W, m->stream));
+    HIPCHK(m, hipMemsetAsync(m->s.nbmask, 0, sizeof(u64) * W, m->stream));
+    HIPCHK(m, hipMemsetAsync(m->k.mvmask, 0, sizeof(u64) * W, m->stream));
+    HIPCHK(m, hipMemsetAsync(m->s.res4, 0, sizeof(float4) * (size_t)d.v_loc, m->stream));
+    HIPCHK(m, hipMemsetAsync(m->s.fut, 0, sizeof(float) * (size_t)d.v_loc * (d.T ? d.T : 1), m->stream));
+    HIPCHK(m, hipMemsetAsync(m->s.pyr_cnt, 0, sizeof(int) * d.np, m->stream));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    m->have_last = false;
+    return DSPMAP_OK;
+}
+
+extern "C" int dspmap_import_state(dspmap_t* m, int n, const int* voxel, const int* slot, const float* rec8) {
+    READY(m);
+    if (n < 0 || (n > 0 && (!voxel || !rec8))) return DSPMAP_E_ARG;
+    if (n == 0) return DSPMAP_OK;
+    bool any_vz = false;
+    for (int i = 0; i < n && !any_vz; i++) any_vz = rec8[8 * (size_t)i + 3] != 0.f;
+    if (any_vz) { int rc = ensure_vz(m); if (rc != DSPMAP_OK) return rc; }
+    int *dv = nullptr, *ds = nullptr, *dfail = nullptr;
+    float* dr = nullptr;
+    HIPCHK(m, dalloc(&dv, (size_t)n));
+    HIPCHK(m, dalloc(&dr, (size_t)n * 8));
+    HIPCHK(m, dalloc(&dfail, (size_t)1));
+    HIPCHK(m, hipMemcpy(dv, voxel, sizeof(int) * n, hipMemcpyHostToDevice));
+    HIPCHK(m, hipMemcpy(dr, rec8, sizeof(float) * 8 * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHK(m, hipMemset(dfail, 0, sizeof(int)));
+    if (slot) { HIPCHK(m, dalloc(&ds, (size_t)n)); HIPCHK(m, hipMemcpy(ds, slot, sizeof(int) * n, hipMemcpyHostToDevice)); }
+    LaunchCtx c = ctx_of(m);
+    launch_import(c, n, dv, ds, dr, dfail);
+    int nfail = 0;
+    HIPCHK(m, hipMemcpyAsync(&nfail, dfail, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    (void)hipFree(dv); (void)hipFree(dr); (void)hipFree(dfail); if (ds) (void)hipFree(ds);
+    if (nfail) return fail(m, DSPMAP_E_STATE, "%d of %d records could not be placed (outside slab, bad slot, or voxel full)", nfail, n);
+    return DSPMAP_OK;
+}
+
+extern "C" int dspmap_export_state(dspmap_t* m, int cap, int* voxel, int* slot, float* rec8, int* n_out) {
+    READY(m);
+    if (cap < 0) return DSPMAP_E_ARG;
+    int *dv = nullptr, *ds = nullptr, *dc = nullptr;
+    float* dr = nullptr;
+    const size_t c1 = cap ? cap : 1;
+    HIPCHK(m, dalloc(&dv, c1)); HIPCHK(m, dalloc(&ds, c1)); HIPCHK(m, dalloc(&dr, c1 * 8)); HIPCHK(m, dalloc(&dc, (size_t)1));
+    HIPCHK(m, hipMemsetAsync(dc, 0, sizeof(int), m->stream));
+    LaunchCtx c = ctx_of(m);
+    if (m->vz_frames <= 0) c.s.vz0 = nullptr;
+    launch_export(c, dv, ds, dr, dc, cap);
+    int n = 0;
+    HIPCHK(m, hipMemcpyAsync(&n, dc, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    const int ncopy = n < cap ? n : cap;
+    if (ncopy > 0) {
+        if (voxel) HIPCHK(m, hipMemcpy(voxel, dv, sizeof(int) * ncopy, hipMemcpyDeviceToHost));
+        if (slot) HIPCHK(m, hipMemcpy(slot, ds, sizeof(int) * ncopy, hipMemcpyDeviceToHost));
+        if (rec8) HIPCHK(m, hipMemcpy(rec8, dr, sizeof(float) * 8 * (size_t)ncopy, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(dv); (void)hipFree(ds); (void)hipFree(dr); (void)hipFree(dc);
+    if (n_out) *n_out = n;
+    return DSPMAP_OK;
+}
+
+extern "C" int dspmap_add_random_particles(dspmap_t* m, int n, float weight) {
+    READY(m);
+    if (n < 0) return DSPMAP_E_ARG;
+    int rc = ensure_vz(m);
+    if (rc != DSPMAP_OK) return rc;
+    LaunchCtx c = ctx_of(m);
+    launch_add_random(c, n, weight);
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}
+
+extern "C" int dspmap_seed_uniform(dspmap_t* m, int per_voxel, float weight, unsigned seed) {
+    READY(m);
+    if (per_voxel < 0 || per_voxel > m->d.slots) return fail(m, DSPMAP_E_ARG, "per_voxel must be in [0, %d]", m->d.slots);
+    LaunchCtx c = ctx_of(m);
+    launch_seed_uniform(c, per_voxel, weight, seed);
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}
+
+// ------------------------------------------------------------------ stages
+extern "C" int dspmap_stage_bin_points(dspmap_t* m, int n, int stride, const float* pts, float qw, float qx, float qy, float qz) {
+    READY(m);
+    if (n < 0 || (n > 0 && (!pts || stride < 3))) return DSPMAP_E_ARG;
+    m->quat[0] = qw; m->quat[1] = qx; m->quat[2] = qy; m->quat[3] = qz;
+    int rc = stage_points(m, n, stride, pts);
+    if (rc != DSPMAP_OK) return rc;
+    LaunchCtx c = ctx_of(m);
+    launch_frame_setup(c, m->quat, m->cur_pos, true);
+    launch_obs_bin(c, n, m->pts_dev, m->quat, !m->h_birth_valid);
+    m->last_n_points = n;
+    if (!m->h_birth_valid) { m->last_n_birth = n; m->last_birth_static = true; }
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}
+extern "C" int dspmap_set_current_position(dspmap_t* m, float x, float y, float z) {
+    if (!m) return DSPMAP_E_ARG;
+    m->cur_pos[0] = x; m->cur_pos[1] = y; m->cur_pos[2] = z;
+    return DSPMAP_OK;
+}
+extern "C" int dspmap_stage_predict(dspmap_t* m, float dx, float dy, float dz, float dt) {
+    READY(m);
+    LaunchCtx c = ctx_of(m);
+    if (m->vz_frames <= 0) c.s.vz0 = nullptr;
+    launch_frame_setup(c, m->quat, m->cur_pos, false);
+    launch_predict(c, dx, dy, dz, dt);
+    if (m->vz_frames > 0) --m->vz_frames;
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}
+extern "C" int dspmap_stage_update(dspmap_t* m) {
+    READY(m);
+    LaunchCtx c = ctx_of(m);
+    launch_ck_partial(c);
+    launch_ck_finalize(c);
+    launch_weight_update(c);
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}
+extern "C" int dspmap_stage_birth(dspmap_t* m) {
+    READY(m);
+    freeze_birth_statics(m);
+    int nb = m->last_n_birth;
+    if (m->h_birth_valid) {
+        nb = (int)m->h_birth.size();
+        int rc = upload_birth(m, m->h_birth.data(), nb);
+        if (rc != DSPMAP_OK) return rc;
+        m->last_birth_static = false;
+        m->last_n_birth = nb;
+    }
+    LaunchCtx c = ctx_of(m);
+    if (m->vz_frames <= 0) c.s.vz0 = nullptr;
+    launch_birth(c, nb, false);
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}
+extern "C" int dspmap_stage_resample(dspmap_t* m) {
+    READY(m);
+    LaunchCtx c = ctx_of(m);
+    if (m->vz_frames <= 0) c.s.vz0 = nullptr;
+    launch_resample(c);
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}
+
+extern "C" int dspmap_get_observations(dspmap_t* m, float* obs_out, int* count_out, float* maxlen_out, float* expected_out) {
+    READY(m);
+    const MapDims& d = m->d;
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    std::vector<float4> o((size_t)d.np * DSP_OBS_CAP);
+    std::vector<float> ck((size_t)d.np * DSP_OBS_CAP);
+    std::vector<int> cnt(d.np);
+    HIPCHK(m, hipMemcpy(o.data(), m->s.obs, sizeof(float4) * o.size(), hipMemcpyDeviceToHost));
+    HIPCHK(m, hipMemcpy(ck.data(), m->s.obs_ck, sizeof(float) * ck.size(), hipMemcpyDeviceToHost));
+    HIPCHK(m, hipMemcpy(cnt.data(), m->s.obs_cnt, sizeof(int) * d.np, hipMemcpyDeviceToHost));
+    if (count_out) memcpy(count_out, cnt.data(), sizeof(int) * d.np);
+    if (maxlen_out) HIPCHK(m, hipMemcpy(maxlen_out, m->s.obs_maxlen, sizeof(float) * d.np, hipMemcpyDeviceToHost));
+    if (obs_out) {
+        memset(obs_out, 0, sizeof(float) * 5 * o.size());
+        for (int b = 0; b < d.np; b++)
+            for (int j = 0; j < cnt[b]; j++) {
+                const size_t i = (size_t)b * DSP_OBS_CAP + j;
+                obs_out[5 * i] = o[i].x; obs_out[5 * i + 1] = o[i].y; obs_out[5 * i + 2] = o[i].z;
+                obs_out[5 * i + 3] = ck[i]; obs_out[5 * i + 4] = o[i].w;
+            }
+    }
+    if (expected_out) {
+        FrameScalars fs;
+        HIPCHK(m, hipMemcpy(&fs, m->s.fs, sizeof(fs), hipMemcpyDeviceToHost));
+        *expected_out = fs.has_expected_override ? fs.expected_newborn
+                                                 : m->fp.nb_weight * (float)fs.n_valid * (float)m->fp.nb_num;
+    }
+    return DSPMAP_OK;
+}
+extern "C" int dspmap_set_expected_newborn(dspmap_t* m, float v) {
+    READY(m);
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    FrameScalars fs;
+    HIPCHK(m, hipMemcpy(&fs, m->s.fs, sizeof(fs), hipMemcpyDeviceToHost));
+    fs.expected_newborn = v; fs.has_expected_override = 1;
+    HIPCHK(m, hipMemcpy(m->s.fs, &fs, sizeof(fs), hipMemcpyHostToDevice));
+    return DSPMAP_OK;
+}
+
+// ------------------------------------------------- multi-GPU split-phase (see dspmap_mgpu.hip)

@@ -1,0 +1,183 @@
+// dspmap_device.h -- device-side primitives (gfx950, wave64).
+// Geometry / index math restates include/dsp_dynamic.h:1062-1125,1303-1367 of
+// the reference with the SAME operation order (this TU is compiled with
+// -ffp-contract=off so that a*b+c is two roundings, like the strict oracle).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dspmap_types.h"
+
+#define WAVE 64
+
+__device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+// inclusive prefix sum over the 64 lanes (wavefront scan, Hillis-Steele)
+__device__ __forceinline__ float wave_incl_scan(float v) {
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        float t = __shfl_up(v, o, WAVE);
+        if (l >= o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_incl_scan_i(int v) {
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        int t = __shfl_up(v, o, WAVE);
+        if (l >= o) v += t;
+    }
+    return v;
+}
+
+// Wave-aggregated "append": every active lane gets a distinct position in the
+// list counted by cnt[key]; one global atomic per distinct key per wave.
+// Must be called from wave-uniform control flow (inactive lanes pass active=false).
+__device__ __forceinline__ int wave_agg_inc(int* cnt, int key, bool active) {
+    int pos = -1;
+    u64 todo = __ballot(active);
+    const int l = lane_id();
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(key, leader, WAVE);
+        const bool mine = active && key == k;
+        const u64 grp = __ballot(mine);
+        int base = 0;
+        if (l == leader) base = atomicAdd(&cnt[k], (int)__popcll(grp));
+        base = __shfl(base, leader, WAVE);
+        if (mine) pos = base + (int)__popcll(grp & ((1ull << l) - 1ull));
+        todo &= ~grp;
+    }
+    return pos;
+}
+// single-counter variant
+__device__ __forceinline__ int wave_agg_inc1(int* cnt, bool active) {
+    const u64 grp = __ballot(active);
+    if (!grp) return -1;
+    const int l = lane_id();
+    const int leader = __ffsll((long long)grp) - 1;
+    int base = 0;
+    if (l == leader) base = atomicAdd(cnt, (int)__popcll(grp));
+    base = __shfl(base, leader, WAVE);
+    return active ? base + (int)__popcll(grp & ((1ull << l) - 1ull)) : -1;
+}
+__device__ __forceinline__ void wave_count_add(int* cnt, bool active) {
+    const u64 grp = __ballot(active);
+    if (grp && lane_id() == __ffsll((long long)grp) - 1) atomicAdd(cnt, (int)__popcll(grp));
+}
+
+// ---- quaternion rotation: rotateVectorByQuaternion dsp_dynamic.h:1303-1322
+// (att * (0,v) * att.inverse(); Hamilton product in Eigen's generic operand order)
+__device__ __forceinline__ void quat_mul(const float a[4], const float b[4], float r[4]) {
+    r[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    r[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    r[2] = a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3];
+    r[3] = a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1];
+}
+__device__ __forceinline__ void rotate_by_quat(float vx, float vy, float vz, const float q[4], float out[3]) {
+    float vq[4] = {0.f, vx, vy, vz};
+    float n2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + q[0] * q[0];
+    float inv[4] = {__fdiv_rn(q[0], n2), __fdiv_rn(-q[1], n2), __fdiv_rn(-q[2], n2), __fdiv_rn(-q[3], n2)};
+    float t[4], r[4];
+    quat_mul(q, vq, t);
+    quat_mul(t, inv, r);
+    out[0] = r[1]; out[1] = r[2]; out[2] = r[3];
+}
+
+// ---- vectorMultiply :1324-1326
+__device__ __forceinline__ float dot3(float x, float y, float z, const float* n) {
+    return x * n[0] + y * n[1] + z * n[2];
+}
+
+// ---- ifInPyramidsArea :1329-1339 + findPointPyramid{Horizontal,Vertical}Index :1341-1367.
+// The reference scans the 28 / 16 boundary planes linearly for the first sign
+// change; the dot products are monotone along the plane index for any point
+// inside the FOV wedge, so a binary search with the SAME predicate (same
+// rotated normals, same dot expression) returns the same cell with 9 instead
+// of 44 dot products.  Returns h*np_v+v, or -1 outside the FOV.
+__device__ __forceinline__ int pyramid_of(const MapDims& d, const float* ph, const float* pv, float x, float y, float z) {
+    if (!(dot3(x, y, z, ph) >= 0.f && dot3(x, y, z, ph + 3 * d.np_h) <= 0.f &&
+          dot3(x, y, z, pv) <= 0.f && dot3(x, y, z, pv + 3 * d.np_v) >= 0.f))
+        return -1;
+    int lo = 0, hi = d.np_h - 1;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (dot3(x, y, z, ph + 3 * (mid + 1)) <= 0.f) hi = mid; else lo = mid + 1;
+    }
+    const int h = lo;
+    lo = 0; hi = d.np_v - 1;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (dot3(x, y, z, pv + 3 * (mid + 1)) >= 0.f) hi = mid; else lo = mid + 1;
+    }
+    return h * d.np_v + lo;
+}
+
+// ---- getParticleVoxelsIndex :1076-1088 + ifParticleIsOut :1118-1125.
+// True fp32 division by the resolution (Appendix A-10: a reciprocal multiply
+// would move particles that sit on voxel faces).  Returns the GLOBAL index.
+__device__ __forceinline__ bool voxel_of(const MapDims& d, float px, float py, float pz, int& gidx) {
+    if (px >= d.half_x || px <= -d.half_x || py >= d.half_y || py <= -d.half_y ||
+        pz >= d.half_z || pz <= -d.half_z)
+        return false;
+    const int x = (int)__fdiv_rn(px + d.half_x, d.res);
+    const int y = (int)__fdiv_rn(py + d.half_y, d.res);
+    const int z = (int)__fdiv_rn(pz + d.half_z, d.res);
+    gidx = z * d.ny * d.nx + y * d.nx + x;
+    return gidx >= 0 && gidx < d.v_glob;
+}
+
+// ---- queryNormalPDF :1294-1301 reproduced arithmetically.  The reference's
+// LUT (calculateNormalPDFBuffer :1288-1292) holds c*exp(-t^2/2) at
+// t = (i-10000)*0.001 with c = 1/sqrt(pi); the index truncates
+// z*1000+10000 after clamping z to +-9.9.  We compute the same quantised t per
+// axis and ONE exp for the product of the three axis factors:
+//   g(x)g(y)g(z) = c^3 * exp(-(tx^2+ty^2+tz^2)/2).
+// Deviation from the reference (documented, tolerance-level): (x-mu)*(1/sigma)
+// instead of (x-mu)/sigma.
+__device__ __forceinline__ float axis_t(float a, float mu, float inv_sigma) {
+    float z = (a - mu) * inv_sigma;
+    z = fminf(fmaxf(z, -9.9f), 9.9f);
+    const int i = (int)(z * 1000.f + 10000.f);
+    return (float)(i - 10000) * 0.001f;
+}
+__device__ __forceinline__ float pair_gk(float px, float py, float pz, float ox, float oy, float oz,
+                                         float inv_sigma, float c3) {
+    const float tx = axis_t(px, ox, inv_sigma);
+    const float ty = axis_t(py, oy, inv_sigma);
+    const float tz = axis_t(pz, oz, inv_sigma);
+    const float s = tx * tx + ty * ty + tz * tz;
+    return c3 * __expf(-0.5f * s);
+}
+
+// claim the lowest free slot of a voxel: first-free-slot rule of addAParticle /
+// moveParticle (:1184-1185,1214-1215) as one atomic OR per attempt.
+// Returns the slot or -1 if the voxel is full.
+__device__ __forceinline__ int claim_slot(u64* mask, int lv, const MapDims& d) {
+    for (int wi = 0; wi < d.mw; ++wi) {
+        u64* wp = mask + (size_t)lv * d.mw + wi;
+        const int nbits = min(64, d.slots - wi * 64);
+        const u64 valid = nbits == 64 ? ~0ull : ((1ull << nbits) - 1ull);
+        u64 cur = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (true) {
+            const u64 free_bits = ~cur & valid;
+            if (!free_bits) break;
+            const u64 bit = free_bits & (~free_bits + 1ull);
+            const u64 prev = atomicOr(wp, bit);
+            if (!(prev & bit)) return wi * 64 + (__ffsll((long long)bit) - 1);
+            cur = prev | bit;
+        }
+    }
+    return -1;
+}

@@ -1,0 +1,51 @@
+// dspmap_kernels.h -- launchers of the gfx950 kernels (host-callable).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dspmap_types.h"
+
+// scratch owned by the runtime
+struct KernelScratch {
+    u64* mvmask;        // [v_loc*mw] particles that must change voxel (set by k_predict, consumed by k_claim)
+    u64* expmask;       // [v_loc*mw] particles that left the slab (multi-GPU), or nullptr
+    int* part_predict;  // [nblk_sweep*4]
+    int* part_claim;    // [nblk_sweep*2]
+    int* part_resample; // [nblk_resample*4]
+    int nblk_sweep, nblk_resample;
+    int tpb_sweep, vpw_sweep;
+};
+
+struct LaunchCtx {
+    MapDims d;
+    FilterParams fp;
+    DevState s;
+    KernelScratch k;
+    hipStream_t stream;
+    int pt_cap, birth_cap;
+};
+int sweep_geometry(int slots, int* vpw_out);  // threads per block for the lane-per-slot sweeps
+
+// frame setup: rotate boundary planes (:226-232), reset per-frame counters/bins (:235-238)
+void launch_frame_setup(const LaunchCtx& c, const float quat[4], const float cur_pos[3], bool reset_obs);
+// observation binning (:244-290)
+void launch_obs_bin(const LaunchCtx& c, int n_pts, const float* pts_dev, const float quat[4], bool make_static_birth);
+// mapPrediction (:627-701) incl. re-binning of movers (moveParticle :1206-1274)
+void launch_predict(const LaunchCtx& c, float odx, float ody, float odz, float dt);
+void launch_reduce_counters(const LaunchCtx& c);  // folds the per-block partial counters into FrameScalars
+// mapUpdate (:704-793)
+void launch_ck_partial(const LaunchCtx& c);
+void launch_ck_finalize(const LaunchCtx& c);
+void launch_weight_update(const LaunchCtx& c);
+// mapAddNewBornParticlesByObservation (:796-921)
+void launch_birth(const LaunchCtx& c, int n_birth, bool skip_split_reduce);
+void launch_birth_split(const LaunchCtx& c, int n_birth);
+void launch_birth_plan_insert(const LaunchCtx& c, int n_birth);
+// mapOccupancyCalculationAndResample (:924-1057)
+void launch_resample(const LaunchCtx& c);
+// readout (:385-438)
+void launch_occupied_compact(const LaunchCtx& c, float thr);
+void launch_clear_future(const LaunchCtx& c);
+// state helpers
+void launch_seed_uniform(const LaunchCtx& c, int per_voxel, float weight, unsigned seed);
+void launch_import(const LaunchCtx& c, int n, const int* voxel_dev, const int* slot_dev, const float* rec8_dev, int* n_failed_dev);
+void launch_export(const LaunchCtx& c, int* voxel_out, int* slot_out, float* rec8_out, int* count_dev, int cap);
+void launch_add_random(const LaunchCtx& c, int n, float weight);

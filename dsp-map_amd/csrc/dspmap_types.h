@@ -1,0 +1,133 @@
+// dspmap_types.h -- structures shared by the host runtime and the gfx950 kernels.
+//
+// Data layout in HBM:
+//   * voxel structure: dense slots like the reference's
+//     voxels_with_particle[V][SLOTS][9] (dsp_dynamic.h:116) but SoA: one fp32
+//     array per field indexed by local_voxel*SLOTS + slot, plus one 64-bit
+//     occupancy word per voxel per 64 slots (bit = slot is live) and a second
+//     word marking particles born this frame (the reference's flag 15,
+//     dsp_dynamic.h:1186).  vz and update_time are not stored: vz is
+//     identically 0 after the first prediction under LIMIT_MOVEMENT_IN_XY_PLANE
+//     (:661-663) and update_time is never read.
+//   * pyramid structure: instead of back-pointer lists (pyramids_in_fov, :124)
+//     a per-pyramid staging area holding a copy {x,y,z,w} + slot id of each
+//     particle inside that angular bin, rebuilt by the prediction kernel.
+//   * result grid: float4 {mass, mean vx, vy, vz} per voxel + [V][T] future
+//     accumulators (voxels_objects_number, :118-120).
+#pragma once
+#include <stdint.h>
+
+#define DSP_MAX_PRED 16
+#define DSP_OBS_CAP 100            // observation_max_points_num_one_pyramid :69
+#define DSP_MAX_PLANES_H 129       // np_h + 1 boundary planes
+#define DSP_MAX_PLANES_V 97
+
+typedef unsigned long long u64;
+
+struct MapDims {
+    int nx, ny, nz;        // global grid
+    int z_lo, z_hi;        // owned slab [z_lo, z_hi)
+    int v_loc;             // local voxel count = nx*ny*(z_hi-z_lo)
+    int v_base;            // global index of local voxel 0 = z_lo*nx*ny
+    int v_glob;            // nx*ny*nz
+    int slots;             // SAFE_PARTICLE_NUM_VOXEL = 2*M  :65
+    int mw;                // mask words per voxel = ceil(slots/64)
+    int M;                 // MAX_PARTICLE_NUM_VOXEL :43
+    int np_h, np_v, np;    // pyramids :58-60
+    int capp;              // SAFE_PARTICLE_NUM_PYRAMID :66
+    int T;                 // PREDICTION_TIMES :46
+    float res;
+    float half_x, half_y, half_z; // :528-530
+    float pred_t[DSP_MAX_PRED];
+};
+
+struct FilterParams {
+    float sigma_ob;        // :156
+    float inv_sigma_ob;    // 1/sigma_ob (host fp32 division)
+    float kappa;           // :157
+    float p_det;           // :158
+    float nb_weight;       // new_born_particle_weight :162
+    int nb_num;            // new_born_particle_number_each_point :163
+    int min_static_nb;     // (int)(n*0.15f), frozen at first birth call :808
+    int model_nb;          // (int)(n*0.8f) :811
+    float pdf_c;           // 1/sqrtf(2*pi/2): centre of the reference's LUT :1284
+    float pdf_c3;          // pdf_c^3
+    float occl_margin;     // obstacle_thickness_for_occlusion :70
+    int tab_n;             // Gaussian table length :72
+    int rtab_n;            // rand table length
+};
+
+// Device-side per-frame scalars and counters (one instance in HBM).
+struct FrameScalars {
+    int n_valid;        // valid_points :286
+    int n_obs;
+    int n_live_in;
+    int n_moved;
+    int n_out_of_map;
+    int n_voxel_full;
+    int n_pyramid_full;
+    int n_fov;
+    int n_born;
+    int n_born_dropped;
+    int n_live_out;
+    int n_exp_up, n_exp_down;
+    int mover_count;    // local movers appended by the prediction kernel
+    int occupied_count; // readout
+    int pad0;
+    float expected_newborn;  // expected_new_born_objects :292
+    float newborn_w;         // updated_weight_new_born :805
+    float cur_pos[3];        // current_position :131
+    int p_cur, v_cur, r_cur; // table cursors :483-484 (+ rand stream)
+    int has_expected_override;
+};
+
+struct DevState {
+    u64* mask;     // [v_loc*mw] live bits
+    u64* nbmask;   // [v_loc*mw] born-this-frame bits
+    float* px; float* py; float* pz;
+    float* vx; float* vy; float* w;
+    float* vz0;    // optional, only right after an import with vz != 0 (consumed by the next prediction)
+    float4* res4;  // [v_loc] {mass, mean vx, mean vy, mean vz}
+    float* fut;    // [v_loc][T]
+    // observations
+    float4* obs;       // [np*100] {x,y,z,len}
+    float* obs_ck;     // [np*100]
+    int* obs_cnt;      // [np]
+    float* obs_maxlen; // [np]
+    float* planes_h;   // [(np_h+1)*3] rotated
+    float* planes_v;   // [(np_v+1)*3]
+    float* planes_h0;  // un-rotated :563-578
+    float* planes_v0;
+    // input points
+    float4* pt_rot;    // [pt_cap] rotated xyz + len
+    int* pt_pyr;       // [pt_cap] pyramid id or -1
+    // birth
+    struct BirthSrc* birth; // [birth_cap]
+    struct BirthPlan* plan; // [birth_cap]
+    int* nstatic;           // [birth_cap] (multi-GPU all-reduce(max) buffer)
+    // FOV staging
+    float4* fov_rec;   // [np*capp] {x,y,z,w}
+    int* fov_slot;     // [np*capp] local slot index (lv*slots+s)
+    int* pyr_cnt;      // [np]
+    // movers
+    float* mv_rec;     // [mv_cap*8]
+    float* exp_up;     // [exp_cap*8]
+    float* exp_down;
+    // readout scratch
+    int* blk_cnt;      // [ceil(v_loc/256)+1]
+    float* occ_xyz;    // [v_loc*3] (allocated on first use)
+    // tables
+    float* p_tab; float* v_tab; int* r_tab;
+    FrameScalars* fs;
+};
+
+struct BirthSrc {   // == dspmap_vpoint
+    float x, y, z, nx, ny, nz, intensity;
+};
+struct BirthPlan {
+    float cx, cy, cz;   // source point in the sensor-centred frame :818-820
+    int gvox;           // global voxel of the source point, -1 = outside map / invalid
+    int n_static;       // :862-866
+    unsigned inside;    // bit k: child k landed inside the map :875
+    int pbase, vbase, rbase; // table cursors of this point's first draw
+};

@@ -1,0 +1,229 @@
+/*
+ * dspmap.h -- C ABI of libdspmap_hip.so: the MI355X-native particle-based
+ * dynamic occupancy mapper (hand-written HIP kernels for gfx950).
+ *
+ * This is the drop-in boundary for the per-frame loop of g-ch/DSP-map's
+ * include/dsp_dynamic.h (class DSPMap).  Every entry point names the reference
+ * interface it replaces (file:line relative to the reference tree).  Plain
+ * pointers and sizes only; no C++/torch types cross this boundary.  The C++
+ * class surface (`class DSPMap`, include/dsp_dynamic.h in THIS repo) and the
+ * Python/ctypes binding (dsp-map_amd/capi.py) are thin forwards to it; the
+ * binding a maintainer of the reference would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - All functions return DSPMAP_OK (1) on success unless stated otherwise;
+ *    0 = "frame rejected, state unchanged" for update (as the reference's
+ *    `return 0`, dsp_dynamic.h:193-208); negative = error, text via
+ *    dspmap_last_error().  Nothing throws.  There is NO CPU fallback: if no
+ *    HIP device is usable every compute entry point fails with DSPMAP_E_DEVICE.
+ *  - `host` pointers are caller-owned host memory, never retained past return.
+ *    `dev` pointers are device memory on the handle's device.
+ *  - One frame in flight per handle; a handle is not re-entrant (the reference
+ *    is not either: function statics + file-scope state, dsp_dynamic.h:116-140,187-190).
+ *  - Voxel indexing, slot capacity, pyramid (angular bin) layout and all
+ *    constants follow the reference (dsp_dynamic.h:38-70).
+ */
+#ifndef DSPMAP_H
+#define DSPMAP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSPMAP_OK 1
+#define DSPMAP_REJECTED 0
+#define DSPMAP_E_ARG (-1)
+#define DSPMAP_E_DEVICE (-2)
+#define DSPMAP_E_STATE (-3)
+
+#define DSPMAP_MAX_PRED_TIMES 16
+
+typedef struct dspmap dspmap_t;
+
+/* Run-time replacement of the reference's compile-time macros
+ * (dsp_dynamic.h:38-50) plus what a multi-GPU shard needs. */
+typedef struct dspmap_config {
+    int nx, ny, nz;             /* MAP_LENGTH/WIDTH/HEIGHT_VOXEL_NUM  :38-40 */
+    float voxel_resolution;     /* VOXEL_RESOLUTION                   :41 */
+    int angle_resolution;       /* ANGLE_RESOLUTION, degrees          :42 */
+    int max_particle_num_voxel; /* MAX_PARTICLE_NUM_VOXEL             :43 */
+    int half_fov_h, half_fov_v; /* :49-50, degrees */
+    int prediction_times;       /* PREDICTION_TIMES                   :46 */
+    float prediction_future_time[DSPMAP_MAX_PRED_TIMES]; /* :47 */
+    /* Z-slab owned by this handle: voxel layers [z_lo, z_hi) of the global
+     * grid (voxel index is z-major, :1081).  z_lo == z_hi == 0 means all. */
+    int z_lo, z_hi;
+    int device;                 /* HIP device ordinal, -1 = current device */
+    int gaussian_table_size;    /* GAUSSIAN_RANDOMS_NUM :72 (10,000,000); 0 = default */
+    unsigned seed;              /* table/rand seed; 0 = time(NULL) like :586,1151 */
+} dspmap_config;
+
+/* Birth-source point = one entry of the reference's input_cloud_with_velocity
+ * (pcl::PointXYZINormal, dsp_dynamic.h:134,1510-1539): world-frame xyz,
+ * normal = estimated velocity (-10000 when the cluster is unmatched, :104-106),
+ * intensity = cluster tag (0 = static / ground). */
+typedef struct dspmap_vpoint {
+    float x, y, z;
+    float nx, ny, nz;
+    float intensity;
+} dspmap_vpoint;
+
+/* Per-frame device counters (the reference computes similar counters and
+ * never prints them, dsp_dynamic.h:629-632,926-927). */
+typedef struct dspmap_counters {
+    int n_points_in;       /* points handed to update() */
+    int n_valid;           /* valid_points :286 (in FOV, incl. overflowed) */
+    int n_obs;             /* stored observations (<= 99 per pyramid, :279-284) */
+    int n_live_in;         /* live particles entering prediction */
+    int n_moved;           /* particles that changed voxel */
+    int n_out_of_map;      /* removed: left the map :688 */
+    int n_voxel_full;      /* removed: destination voxel full (-1, :1227) */
+    int n_pyramid_full;    /* removed: pyramid list full (-2, :1256) */
+    int n_fov;             /* particles registered in pyramids after prediction */
+    int n_born;            /* newborn particles inserted :911 */
+    int n_born_dropped;    /* newborn dropped: voxel full :1198 */
+    int n_live_out;        /* live particles after resampling */
+    int n_exported_up, n_exported_down; /* multi-GPU: left the slab through z_hi / z_lo */
+    float newborn_weight;  /* updated_weight_new_born :805 */
+    float update_ms;       /* device time of the last update (HIP events) */
+} dspmap_counters;
+
+enum dspmap_param {
+    DSPMAP_P_POSITION_STDDEV = 1,   /* setPredictionVariance arg 1   :355 */
+    DSPMAP_P_VELOCITY_STDDEV = 2,   /* setPredictionVariance arg 2   :355 */
+    DSPMAP_P_OBSERVATION_STDDEV = 3,/* setObservationStdDev          :362 */
+    DSPMAP_P_NEWBORN_WEIGHT = 4,    /* setNewBornParticleWeight      :366 */
+    DSPMAP_P_NEWBORN_NUMBER = 5,    /* setNewBornParticleNumberofEachPoint :370 */
+    DSPMAP_P_VOXEL_FILTER_RES = 6,  /* setOriginalVoxelFilterResolution :380 */
+    DSPMAP_P_KAPPA = 7,             /* kappa :157 */
+    DSPMAP_P_DETECTION = 8,         /* P_detection :158 */
+    DSPMAP_P_VELOCITY_ESTIMATOR = 9,/* 1 = run the host velocity estimator inside dspmap_update (:297),
+                                       0 = births use the caller's cloud / all-static tags */
+    DSPMAP_P_REGENERATE_TABLES = 10 /* 1 = setPredictionVariance regenerates the Gaussian tables (:359) */
+};
+
+/* ---- lifecycle: DSPMap::DSPMap / ~DSPMap  dsp_dynamic.h:145-179 ---- */
+void dspmap_default_config(dspmap_config* cfg);          /* the reference's shipped macro values */
+dspmap_t* dspmap_create(const dspmap_config* cfg);        /* no HIP call: safe during static init (src/map_sim_example.cpp:39) */
+void dspmap_destroy(dspmap_t* m);
+int dspmap_init_device(dspmap_t* m);                      /* allocate device state now (otherwise lazily on first use) */
+const char* dspmap_last_error(const dspmap_t* m);
+int dspmap_sync(dspmap_t* m);                             /* wait for all queued work of this handle */
+int dspmap_set_stream(dspmap_t* m, void* hip_stream);     /* run on a caller-owned hipStream_t (e.g. torch's) */
+
+/* ---- setters: dsp_dynamic.h:355-382 ---- */
+int dspmap_set_param(dspmap_t* m, int key, double value);
+double dspmap_get_param(const dspmap_t* m, int key);
+
+/* ---- randomness.  The reference pre-draws two N(0,sigma) tables
+ * (dsp_dynamic.h:138-139,1150-1160) and uses libc rand() for uniform
+ * velocities (:1551-1553).  Tables can be injected so that runs can be
+ * compared with another implementation fed the same tables. ---- */
+int dspmap_set_gaussian_tables(dspmap_t* m, const float* p_tab_host, const float* v_tab_host, int n);
+int dspmap_set_rand_table(dspmap_t* m, const int* rand_ints_host, int n); /* values in [0, RAND_MAX] */
+int dspmap_set_cursors(dspmap_t* m, int p_cursor, int v_cursor, int r_cursor);
+int dspmap_get_cursors(dspmap_t* m, int* p_cursor, int* v_cursor, int* r_cursor);
+
+/* ---- the frame: DSPMap::update  dsp_dynamic.h:181-353 ----
+ * Same arguments and the same 1 / 0 contract (0 = invalid quaternion or
+ * |dp| > 10 m or dt outside [0,10] s; state and the "last pose" untouched). */
+int dspmap_update(dspmap_t* m, int point_cloud_num, int size_of_one_point, const float* point_cloud_host,
+                  float sensor_px, float sensor_py, float sensor_pz, double time_stamp_second,
+                  float qw, float qx, float qy, float qz);
+
+/* Same frame with inputs already resident in HBM: `points_dev` = n x 3 floats
+ * (sensor frame, packed xyz); `birth_dev`/n_birth = the birth-source cloud
+ * (what the velocity estimator would output) or NULL/0 = every in-FOV point is
+ * a static source (zero velocity tag).  Asynchronous: returns after enqueue. */
+int dspmap_update_device(dspmap_t* m, int n_points, const float* points_dev, int n_birth,
+                         const dspmap_vpoint* birth_dev, const float sensor_pos[3],
+                         double time_stamp_second, const float quat_wxyz[4]);
+
+/* Supply the birth-source cloud used by the next dspmap_update /
+ * dspmap_stage_birth when the velocity estimator is off (what the reference's
+ * velocityEstimationThread leaves in input_cloud_with_velocity, :134). */
+int dspmap_set_birth_cloud(dspmap_t* m, const dspmap_vpoint* pts_host, int n);
+/* getKMClusterResult :441-445 : the birth-source cloud of the last frame */
+int dspmap_get_birth_cloud(dspmap_t* m, dspmap_vpoint* out_host, int cap, int* n_out);
+
+/* ---- readout: dsp_dynamic.h:385-438 ---- */
+/* getOccupancyMap :385-402 : voxel centres with occupancy mass > thr, ascending voxel
+ * index; ALSO zeroes the future accumulators like the reference (:397-400). */
+int dspmap_get_occupancy(dspmap_t* m, float threshold, float* xyz_out_host, int cap, int* n_out);
+/* getOccupancyMapWithFutureStatus :405-426 : as above + copies V x T future masses, then zeroes them */
+int dspmap_get_occupancy_with_future(dspmap_t* m, float threshold, float* xyz_out_host, int cap, int* n_out,
+                                     float* future_status_host /* [V_local][T] */);
+/* north-star name getFutureStatus(): the V x T copy + zeroing only */
+int dspmap_get_future(dspmap_t* m, float* future_status_host);
+/* clearOccupancyMapPrediction :431-438 */
+int dspmap_clear_future(dspmap_t* m);
+/* voxels_objects_number[v][0..3] (:118-120): occupancy mass + mean velocity, V_local x 4 floats */
+int dspmap_get_results(dspmap_t* m, float* out_host);
+/* device-resident views for callers that keep the map on the GPU (no copy) */
+const float* dspmap_results_device(dspmap_t* m); /* [V_local][4] */
+const float* dspmap_future_device(dspmap_t* m);  /* [V_local][T] */
+
+/* getVoxelPositionFromIndexPublic :1556-1572 / getPointVoxelsIndexPublic :1574-1584 (host math) */
+void dspmap_voxel_center(const dspmap_t* m, int index, float* px, float* py, float* pz);
+int dspmap_point_voxel_index(const dspmap_t* m, float px, float py, float pz, int* index);
+
+/* ---- sizes ---- */
+int dspmap_voxel_num(const dspmap_t* m);        /* global VOXEL_NUM :62 */
+int dspmap_local_voxel_num(const dspmap_t* m);  /* voxels in this handle's slab */
+int dspmap_slots_per_voxel(const dspmap_t* m);  /* SAFE_PARTICLE_NUM_VOXEL :65 */
+int dspmap_pyramid_num(const dspmap_t* m);      /* observation_pyramid_num :60 */
+int dspmap_pyramid_capacity(const dspmap_t* m); /* SAFE_PARTICLE_NUM_PYRAMID :66 */
+int dspmap_get_counters(dspmap_t* m, dspmap_counters* out);
+
+/* ---- state access (the reference's equivalent is direct access to its
+ * file-scope arrays, dsp_dynamic.h:116).  A record is 8 floats
+ * {flag, vx, vy, vz, px, py, pz, weight} (:114-115 minus the dead update_time).
+ * `voxel` is the GLOBAL voxel index; slot < 0 = first free slot (:1184-1185). ---- */
+int dspmap_clear_state(dspmap_t* m);
+int dspmap_import_state(dspmap_t* m, int n, const int* voxel_host, const int* slot_host, const float* rec8_host);
+int dspmap_export_state(dspmap_t* m, int cap, int* voxel_out_host, int* slot_out_host, float* rec8_out_host, int* n_out);
+/* addRandomParticles :594-624 (constructor pre-fill); uses the rand table */
+int dspmap_add_random_particles(dspmap_t* m, int n, float weight);
+/* benchmark fill: every voxel gets `per_voxel` zero-velocity particles,
+ * uniform in-voxel positions, given weight; generated on device from `seed`. */
+int dspmap_seed_uniform(dspmap_t* m, int per_voxel, float weight, unsigned seed);
+
+/* ---- single stages on the current state (test hooks; the reference's
+ * stages are private members made reachable the same way by its own author
+ * for mapAddNewBornParticlesByObservation, :795-796) ---- */
+int dspmap_stage_bin_points(dspmap_t* m, int n, int stride, const float* pts_host,
+                            float qw, float qx, float qy, float qz);                  /* :220-293 */
+int dspmap_set_current_position(dspmap_t* m, float x, float y, float z);             /* :213-215 */
+int dspmap_stage_predict(dspmap_t* m, float odom_dx, float odom_dy, float odom_dz, float dt); /* mapPrediction :627 */
+int dspmap_stage_update(dspmap_t* m);                                                /* mapUpdate :704 */
+int dspmap_stage_birth(dspmap_t* m);                                                 /* mapAddNewBornParticlesByObservation :796 */
+int dspmap_stage_resample(dspmap_t* m);                                              /* mapOccupancyCalculationAndResample :924 */
+/* observation bins after binning / update: xyz+Ck+len per stored obs (:497-501,514-515) */
+int dspmap_get_observations(dspmap_t* m, float* obs_out_host /* [NP][100][5] */, int* count_out_host /* [NP] */,
+                            float* max_len_out_host /* [NP] */, float* expected_newborn_out);
+int dspmap_set_expected_newborn(dspmap_t* m, float v);
+
+/* ---- multi-GPU split-phase frame (Z-slab sharding; no counterpart in the
+ * single-process reference).  The caller (one process per GPU) runs
+ *   begin -> exchange movers -> import_movers -> ck_partial -> all-reduce(sum) Ck
+ *   -> finish
+ * with the collectives done by the caller (RCCL via torch.distributed).
+ * Buffers are device pointers owned by the caller. ---- */
+int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_dev, int n_birth,
+                      const dspmap_vpoint* birth_dev, const float sensor_pos[3],
+                      double time_stamp_second, const float quat_wxyz[4]);
+/* movers that left the slab: records of 8 floats {gvoxel(as int bits), vx, vy, px, py, pz, w, 0};
+ * dir = +1 (through z_hi) or -1 (through z_lo).  Returns the device buffer + count (host sync). */
+int dspmap_mgpu_get_exports(dspmap_t* m, int dir, const float** rec_dev, int* n_out);
+int dspmap_mgpu_import_movers(dspmap_t* m, int n, const float* rec_dev);
+int dspmap_mgpu_ck_partial(dspmap_t* m, float** ck_dev, int* n_floats); /* [NP*100] partial sums, to be all-reduced in place */
+int dspmap_mgpu_nstatic_partial(dspmap_t* m, int** nstatic_dev, int* n_ints); /* per birth point, all-reduce(max) in place */
+int dspmap_mgpu_finish(dspmap_t* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSPMAP_H */

@@ -984,6 +984,22 @@ void dspo_velocity_estimation(dsp_oracle* o) {
     free(ng); free(st);
 }
 
+/* Test convenience (no counterpart in the reference): tag every in-FOV point as
+ * a static birth source, in view order -- i.e. the velocity estimator's output
+ * format (:1529-1540) without its ground/cluster re-ordering.  This is what
+ * libdspmap_hip does when no birth cloud is supplied. */
+void dspo_static_birth_cloud(dsp_oracle* o) {
+    birth_reserve(o, o->cloud_view_n);
+    o->birth_n = 0;
+    for (int i = 0; i < o->cloud_view_n; i++) {
+        dspo_vpoint* q = &o->birth[o->birth_n++];
+        q->x = o->cloud_view[3 * i] + o->current_position[0];
+        q->y = o->cloud_view[3 * i + 1] + o->current_position[1];
+        q->z = o->cloud_view[3 * i + 2] + o->current_position[2];
+        q->nx = q->ny = q->nz = 0.f; q->intensity = 0.f;
+    }
+}
+
 /* ------------------------------------------------------------- whole frame */
 /* DSPMap::update :181-353 (CSV dump :326-350 omitted: write-only debug aid) */
 int dspo_update(dsp_oracle* o, int n_pts, int stride, const float* pts, float sx, float sy, float sz,
@@ -1004,7 +1020,8 @@ int dspo_update(dsp_oracle* o, int n_pts, int stride, const float* pts, float sx
     dspo_bin_points(o, n_pts, stride, pts, qw, qx, qy, qz);
     /* the reference forks velocityEstimationThread here (:297) and joins at :311;
      * it shares no state with prediction/update, so running it first is equivalent */
-    if (o->use_vel_est) dspo_velocity_estimation(o);
+    if (o->use_vel_est == 1) dspo_velocity_estimation(o);
+    else if (o->use_vel_est == 2) dspo_static_birth_cloud(o);
     dspo_map_prediction(o, -dx, -dy, -dz, dt); /* :300 */
     if (n_pts >= 0) dspo_map_update(o);        /* :303-307 */
     if (n_pts >= 0) dspo_add_newborn(o);       /* :314-316 */

@@ -93,7 +93,8 @@ void dspo_get_cursors(const dsp_oracle* o, int* p_cursor, int* v_cursor, int* r_
 int dspo_update(dsp_oracle* o, int n_pts, int stride, const float* pts,
                 float sx, float sy, float sz, double stamp,
                 float qw, float qx, float qy, float qz);
-void dspo_use_velocity_estimator(dsp_oracle* o, int on);
+void dspo_use_velocity_estimator(dsp_oracle* o, int mode); /* 0 caller's cloud, 1 restated estimator, 2 all-static tags in view order */
+void dspo_static_birth_cloud(dsp_oracle* o);
 void dspo_set_birth_cloud(dsp_oracle* o, const dspo_vpoint* pts, int n);
 int dspo_get_birth_cloud(const dsp_oracle* o, dspo_vpoint* out, int cap);
 

@@ -66,6 +66,7 @@ def _load(fast=False):
         "dspo_get_cursors": (None, [P, ip, ip, ip]),
         "dspo_update": (i, [P, i, i, P, f, f, f, C.c_double, f, f, f, f]),
         "dspo_use_velocity_estimator": (None, [P, i]),
+        "dspo_static_birth_cloud": (None, [P]),
         "dspo_set_birth_cloud": (None, [P, P, i]),
         "dspo_get_birth_cloud": (i, [P, P, i]),
         "dspo_bin_points": (i, [P, i, i, P, f, f, f, f]),

@@ -1,0 +1,92 @@
+"""CPU tests of the drop-in boundary: the shared library loads, exports every symbol
+include/dspmap.h declares, host-only entry points work, and compute entry points FAIL LOUDLY
+without a GPU (there is no CPU fallback in the product)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dspmap.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dspmap_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported_and_bound(dsp):
+    names = declared_symbols()
+    assert len(names) >= 45
+    lib = dsp.load_library()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", dsp.capi.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (dspmap_[a-z_0-9]+)", out))
+    missing = [n for n in names if n not in exported]
+    assert not missing, missing
+    assert sorted(dsp.capi.SIGNATURES) == names  # the ctypes binding covers exactly the header
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
+def test_library_has_gfx950_code_object(dsp):
+    blob = open(dsp.capi.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for k in (b"k_predict", b"k_claim", b"k_ck_partial", b"k_weight", b"k_birth_insert", b"k_resample"):
+        assert k in blob, k
+
+
+def test_host_only_entry_points(dsp, orc):
+    m = dsp.DSPMap(dsp.make_config(ppv=24))
+    o = orc.Oracle(orc.make_config(ppv=24))
+    assert (m.V, m.slots, m.NP, m.capp) == (o.V, o.slots, o.NP, o.capp)
+    idx = C.c_int()
+    x, y, z = C.c_float(), C.c_float(), C.c_float()
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        p = rng.uniform(-5.2, 5.2, 3).astype(np.float32)
+        ok, i = m.getPointVoxelsIndexPublic(float(p[0]), float(p[1]), float(p[2]))
+        ok_o = o.L.dspo_voxel_index(o.h, float(p[0]), float(p[1]), float(p[2]), C.byref(idx))
+        assert ok == ok_o and (not ok or i == idx.value)
+    for v in (0, 1, 66, 4356, 174239):
+        o.L.dspo_voxel_center(o.h, v, C.byref(x), C.byref(y), C.byref(z))
+        assert m.getVoxelPositionFromIndexPublic(v) == (x.value, y.value, z.value)
+    assert m.L.dspmap_get_param(m.h, dsp.capi.P_OBSERVATION_STDDEV) == pytest.approx(0.1)
+    assert m.L.dspmap_set_param(m.h, 999, 1.0) < 0
+    assert b"unknown parameter" in m.L.dspmap_last_error(m.h)
+    m.close(); o.close()
+
+
+def test_create_rejects_bad_config(dsp):
+    L = dsp.load_library()
+    bad = dsp.make_config(nx=0)
+    assert not L.dspmap_create(C.byref(bad))
+    bad = dsp.make_config(ppv=65)
+    assert not L.dspmap_create(C.byref(bad))
+    bad = dsp.make_config(z_lo=30, z_hi=50)
+    assert not L.dspmap_create(C.byref(bad))
+
+
+def test_compute_fails_loudly_without_gpu(dsp):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    m = dsp.DSPMap()
+    pts = np.zeros((4, 3), np.float32)
+    with pytest.raises(dsp.capi.DSPMapError, match="no HIP device"):
+        m.update(pts, (0, 0, 0), 0.0, (1, 0, 0, 0))
+    with pytest.raises(dsp.capi.DSPMapError):
+        m.getOccupancyMap(0.2)
+    m.close()
+
+
+def test_product_never_imports_oracle():
+    """the product package must not reference oracle/ (a CPU fallback would void parity claims)"""
+    pkg = os.path.join(ROOT, "dsp-map_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                t = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_py" not in t and "dsp_oracle" not in t and "dspo_" not in t, f
