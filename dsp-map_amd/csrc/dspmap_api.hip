@@ -169,7 +169,7 @@ static void free_dev(dspmap* m) {
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.nstatic, s.fov_rec, s.fov_slot, s.pyr_cnt, s.mv_rec, s.exp_up, s.exp_down,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mvmask, m->k.expmask,
-                    m->k.part_predict, m->k.part_claim, m->k.part_resample, m->pts_dev};
+                    m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->pts_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->pts_pin) (void)hipHostFree(m->pts_pin);
     if (m->birth_pin) (void)hipHostFree(m->birth_pin);
@@ -291,6 +291,8 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&k.part_predict, (size_t)k.nblk_sweep * 4));
     HIPCHK(m, dalloc(&k.part_claim, (size_t)k.nblk_sweep * 2));
     HIPCHK(m, dalloc(&k.part_resample, (size_t)k.nblk_resample * 4));
+    HIPCHK(m, dalloc(&k.vb_cnt, (size_t)d.v_loc));
+    HIPCHK(m, dalloc(&k.vb_idx, (size_t)d.v_loc * 128));
     HIPCHK(m, dalloc(&s.blk_cnt, (size_t)k.nblk_resample + 1));
     HIPCHK(m, hipMemset(s.mask, 0, sizeof(u64) * W)); HIPCHK(m, hipMemset(s.nbmask, 0, sizeof(u64) * W));
     HIPCHK(m, hipMemset(k.mvmask, 0, sizeof(u64) * W));

@@ -144,19 +144,24 @@ __device__ __forceinline__ bool voxel_of(const MapDims& d, float px, float py, f
 // z*1000+10000 after clamping z to +-9.9.  We compute the same quantised t per
 // axis and ONE exp for the product of the three axis factors:
 //   g(x)g(y)g(z) = c^3 * exp(-(tx^2+ty^2+tz^2)/2).
-// Deviation from the reference (documented, tolerance-level): (x-mu)*(1/sigma)
-// instead of (x-mu)/sigma.
-__device__ __forceinline__ float axis_t(float a, float mu, float inv_sigma) {
-    float z = (a - mu) * inv_sigma;
+// The division (x-mu)/sigma by the frame-constant sigma is done as a reciprocal
+// multiply plus one FMA residual correction (q = d*y; r = fma(-q,sigma,d);
+// q' = fma(r,y,q)), which returns the correctly rounded quotient (Markstein),
+// i.e. the same quantisation bin as the reference, for 3 VALU ops instead of ~10.
+__device__ __forceinline__ float axis_t(float a, float mu, float sigma, float inv_sigma) {
+    const float dlt = a - mu;
+    const float q0 = dlt * inv_sigma;
+    const float rr = __fmaf_rn(-q0, sigma, dlt);
+    float z = __fmaf_rn(rr, inv_sigma, q0);
     z = fminf(fmaxf(z, -9.9f), 9.9f);
     const int i = (int)(z * 1000.f + 10000.f);
     return (float)(i - 10000) * 0.001f;
 }
 __device__ __forceinline__ float pair_gk(float px, float py, float pz, float ox, float oy, float oz,
-                                         float inv_sigma, float c3) {
-    const float tx = axis_t(px, ox, inv_sigma);
-    const float ty = axis_t(py, oy, inv_sigma);
-    const float tz = axis_t(pz, oz, inv_sigma);
+                                         float sigma, float inv_sigma, float c3) {
+    const float tx = axis_t(px, ox, sigma, inv_sigma);
+    const float ty = axis_t(py, oy, sigma, inv_sigma);
+    const float tz = axis_t(pz, oz, sigma, inv_sigma);
     const float s = tx * tx + ty * ty + tz * tz;
     return c3 * __expf(-0.5f * s);
 }

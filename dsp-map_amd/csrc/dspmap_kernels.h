@@ -10,6 +10,8 @@ struct KernelScratch {
     int* part_predict;  // [nblk_sweep*4]
     int* part_claim;    // [nblk_sweep*2]
     int* part_resample; // [nblk_resample*4]
+    int* vb_cnt;        // [v_loc] children per destination voxel this frame (birth ordering)
+    int* vb_idx;        // [v_loc*128] their birth indices
     int nblk_sweep, nblk_resample;
     int tpb_sweep, vpw_sweep;
 };

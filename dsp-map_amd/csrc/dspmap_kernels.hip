@@ -77,7 +77,7 @@ __global__ void k_obs_points(MapDims d, DevState s, int n_pts, const float* __re
         float r[3];
         rotate_by_quat(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], q, r);
         const int pyr = pyramid_of(d, s_ph, s_pv, r[0], r[1], r[2]);
-        const float len = __fsqrt_rn(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        const float len = sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
         s.pt_rot[i] = make_float4(r[0], r[1], r[2], len);
         s.pt_pyr[i] = pyr;
         valid = pyr >= 0;
@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, Fi
         float acc = 0.f;
         for (int i = 0; i < npart; ++i) {
             const float4 p = s_p[i];
-            acc += p.w * pair_gk(p.x, p.y, p.z, z.x, z.y, z.z, fp.inv_sigma_ob, fp.pdf_c3);
+            acc += p.w * pair_gk(p.x, p.y, p.z, z.x, z.y, z.z, fp.sigma_ob, fp.inv_sigma_ob, fp.pdf_c3);
         }
         unsafeAtomicAdd(&s.obs_ck[oi], acc);
     }
@@ -503,12 +503,12 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
     const size_t ri = (size_t)b * d.capp + i;
     const float4 p = s.fov_rec[ri];
     const float maxlen = s.obs_maxlen[b];
-    const float dist = __fsqrt_rn(p.x * p.x + p.y * p.y + p.z * p.z);
+    const float dist = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
     if (maxlen > 0.f && dist > maxlen + fp.occl_margin) return;  // occluded :761-765
     float sum = 0.f;
     for (int o = 0; o < O; ++o) {
         const float4 z = s_o[o];
-        sum += pair_gk(p.x, p.y, p.z, z.x, z.y, z.z, fp.inv_sigma_ob, fp.pdf_c3) * z.w;
+        sum += pair_gk(p.x, p.y, p.z, z.x, z.y, z.z, fp.sigma_ob, fp.inv_sigma_ob, fp.pdf_c3) * z.w;
     }
     s.w[s.fov_slot[ri]] = p.w * ((1.f - fp.p_det) + sum);  // :786
 }
@@ -655,13 +655,49 @@ __device__ __forceinline__ float rand_float(const DevState& s, const FilterParam
     return lo + __fdiv_rn((float)r, __fdiv_rn((float)2147483647, (hi - lo)));
 }
 
+// Children are inserted in the reference's sequential order WITHOUT a sort:
+// k_birth_bucket records, per destination voxel, the birth index (point*n_nb+child)
+// of every child landing there; k_birth_insert ranks each child among its voxel's
+// children by birth index and takes the rank-th free slot of the PRE-birth
+// occupancy word -- exactly the slot addAParticle's first-free scan (:1183-1201)
+// would hand out when children arrive one after another; children whose rank
+// exceeds the free slots are dropped, as in the reference (:1198-1200).
+// New particles only set their bit in nbmask (live = mask | nbmask), so the
+// pre-birth word stays stable while the kernel runs.
+#define BIRTH_BUCKET_CAP 128
+
+__device__ __forceinline__ bool child_position(const MapDims& d, const DevState& s, const FilterParams& fp,
+                                               const BirthPlan& pl, int k, float& x, float& y, float& z, int& lv) {
+    const int c = (int)(((long long)pl.pbase + 3 * k) % fp.tab_n);
+    x = pl.cx + s.p_tab[c];                      // :871-873
+    y = pl.cy + s.p_tab[(c + 1) % fp.tab_n];
+    z = pl.cz + s.p_tab[(c + 2) % fp.tab_n];
+    int gv = 0;
+    voxel_of(d, x, y, z, gv);
+    lv = gv - d.v_base;
+    return lv >= 0 && lv < d.v_loc;  // children landing in another slab are inserted by their owner
+}
+
+__global__ void k_birth_bucket(MapDims d, DevState s, FilterParams fp, int n_birth, int* __restrict__ vb_cnt,
+                               int* __restrict__ vb_idx) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nb = fp.nb_num;
+    const int i = t / nb, k = t - i * nb;
+    if (i >= n_birth) return;
+    const BirthPlan pl = s.plan[i];
+    if (pl.gvox < 0 || !((pl.inside >> k) & 1u)) return;
+    float x, y, z;
+    int lv;
+    if (!child_position(d, s, fp, pl, k, x, y, z, lv)) return;
+    const int pos = atomicAdd(&vb_cnt[lv], 1);
+    if (pos < BIRTH_BUCKET_CAP) vb_idx[(size_t)lv * BIRTH_BUCKET_CAP + pos] = t;
+}
+
 // k_birth_insert: one thread per (source point, child).  Position = source +
 // N(0,sigma_p) (:871-873); velocity by branch (:877-903); vz = 0 (:905-907);
-// weight = the global newborn weight (:909); inserted into the first free slot
-// with the newborn flag (addAParticle :1183-1201), silently dropped when the
-// voxel is full (:1198-1200).  Children landing in another slab are skipped
-// (their owner inserts them).
-__global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, int n_birth) {
+// weight = the global newborn weight (:909); newborn flag (= nbmask bit).
+__global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, int n_birth, const int* __restrict__ vb_cnt,
+                               const int* __restrict__ vb_idx) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int nb = fp.nb_num;
     const int i = t / nb, k = t - i * nb;
@@ -670,14 +706,9 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, int n_bir
         const BirthPlan pl = s.plan[i];
         if (pl.gvox >= 0 && ((pl.inside >> k) & 1u)) {
             const BirthSrc src = s.birth[i];
-            const int c = (int)(((long long)pl.pbase + 3 * k) % fp.tab_n);
-            const float x = pl.cx + s.p_tab[c];
-            const float y = pl.cy + s.p_tab[(c + 1) % fp.tab_n];
-            const float z = pl.cz + s.p_tab[(c + 2) % fp.tab_n];
-            int gv = 0;
-            voxel_of(d, x, y, z, gv);
-            const int lv = gv - d.v_base;
-            if (lv >= 0 && lv < d.v_loc) {
+            float x, y, z;
+            int lv;
+            if (child_position(d, s, fp, pl, k, x, y, z, lv)) {
                 float vx = 0.f, vy = 0.f;
                 if (k >= pl.n_static && src.intensity > 0.01f) {
                     const int model_end = src.nx > -100.f ? fp.model_nb : pl.n_static;
@@ -696,7 +727,31 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, int n_bir
                         vy = rand_float(s, fp, cr + 1, -1.5f, 1.5f);          // :896
                     }
                 }
-                const int sl = claim_slot(s.mask, lv, d);
+                // rank among this voxel's children, by birth index
+                const int total = vb_cnt[lv];
+                const int n = min(total, BIRTH_BUCKET_CAP);
+                int rank = 0;
+                bool recorded = false;
+                const int* bl = vb_idx + (size_t)lv * BIRTH_BUCKET_CAP;
+                for (int j = 0; j < n; ++j) {
+                    const int o = bl[j];
+                    rank += (o < t) ? 1 : 0;
+                    recorded |= (o == t);
+                }
+                int sl = -1;
+                if (recorded) {
+                    // rank-th free slot of the pre-birth occupancy
+                    int r = rank;
+                    for (int e = 0; e < d.mw && sl < 0; ++e) {
+                        const int nbits = min(64, d.slots - e * 64);
+                        const u64 valid = nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
+                        u64 fr = ~s.mask[(size_t)lv * d.mw + e] & valid;
+                        const int nf = (int)__popcll(fr);
+                        if (r >= nf) { r -= nf; continue; }
+                        for (int q = 0; q < r; ++q) fr &= fr - 1ull;
+                        sl = e * 64 + (__ffsll((long long)fr) - 1);
+                    }
+                }
                 if (sl >= 0) {
                     const size_t idx = (size_t)lv * d.slots + sl;
                     s.px[idx] = x; s.py[idx] = y; s.pz[idx] = z;
@@ -782,15 +837,18 @@ __device__ __forceinline__ void resample_voxel(const MapDims& d, const DevState&
     for (int e = 0; e < EPL; ++e) newmask[e] = alive_m[e];
     if (n < 5) return;  // :986
     const int n_after = n > d.M ? d.M : n;               // :992-997
-    const float w_after = __fdiv_rn(occ, (float)n_after);  // :1000
     // inclusive prefix sum of the surviving weights in slot order (acc_ori_weight :1011)
     float A[EPL];
+    // (fp32 prefix scan; the reference accumulates sequentially, so the two differ in the last
+    // bits -- this only matters when a running sum sits exactly on a threshold, e.g. a voxel that
+    // holds nothing but equal-weight newborns with n > M; see DESIGN.md "threshold ties")
     float carry = 0.f;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         A[e] = wave_incl_scan(w[e]) + carry;
         carry = __shfl(A[e], 63, WAVE);
     }
+    const float w_after = __fdiv_rn(occ, (float)n_after);  // :1000
     // K(a) = number of thresholds tau_m < a, tau_0 = 0.5 w', tau_{m+1} = tau_m + w' (fp32, :1006,1015,1043)
     int K[EPL];
 #pragma unroll
@@ -893,8 +951,8 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
     for (int e = 0; e < EPL; ++e) {
         mym[e] = 0; mynb[e] = 0;
         if (my_lv < d.v_loc) {
-            mym[e] = s.mask[(size_t)my_lv * EPL + e];
             mynb[e] = s.nbmask[(size_t)my_lv * EPL + e];
+            mym[e] = s.mask[(size_t)my_lv * EPL + e] | mynb[e];  // newborns live only in nbmask until now
         }
         nonempty |= mym[e] != 0;
     }
@@ -1061,7 +1119,7 @@ __global__ void k_export(MapDims d, DevState s, int* __restrict__ voxel, int* __
     int lv = 0, sl = 0;
     if (t < total) {
         lv = (int)(t / d.slots); sl = (int)(t - (size_t)lv * d.slots);
-        live = (s.mask[(size_t)lv * d.mw + (sl >> 6)] >> (sl & 63)) & 1ull;
+        live = ((s.mask[(size_t)lv * d.mw + (sl >> 6)] | s.nbmask[(size_t)lv * d.mw + (sl >> 6)]) >> (sl & 63)) & 1ull;
     }
     const int pos = wave_agg_inc1(count, live);
     if (live && pos < cap) {
@@ -1164,7 +1222,9 @@ void launch_birth_plan_insert(const LaunchCtx& c, int n_birth) {
     if (n_birth <= 0) return;
     hipLaunchKernelGGL(k_birth_plan, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp, n_birth);
     const long long total = (long long)n_birth * c.fp.nb_num;
-    hipLaunchKernelGGL(k_birth_insert, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, c.d, c.s, c.fp, n_birth);
+    (void)hipMemsetAsync(c.k.vb_cnt, 0, sizeof(int) * (size_t)c.d.v_loc, c.stream);
+    hipLaunchKernelGGL(k_birth_bucket, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, c.d, c.s, c.fp, n_birth, c.k.vb_cnt, c.k.vb_idx);
+    hipLaunchKernelGGL(k_birth_insert, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, c.d, c.s, c.fp, n_birth, c.k.vb_cnt, c.k.vb_idx);
 }
 void launch_birth(const LaunchCtx& c, int n_birth, bool) {
     launch_birth_split(c, n_birth);
