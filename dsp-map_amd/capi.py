@@ -87,6 +87,8 @@ SIGNATURES = {
     "dspmap_pyramid_num": (_i, [_P]),
     "dspmap_pyramid_capacity": (_i, [_P]),
     "dspmap_get_counters": (_i, [_P, C.POINTER(Counters)]),
+    "dspmap_set_profiling": (_i, [_P, _i]),
+    "dspmap_get_stage_ms": (_i, [_P, _fp, _ip]),
     "dspmap_clear_state": (_i, [_P]),
     "dspmap_import_state": (_i, [_P, _i, _P, _P, _P]),
     "dspmap_export_state": (_i, [_P, _i, _P, _P, _P, _ip]),
@@ -309,6 +311,18 @@ class DSPMap:
         c = Counters()
         self._chk(self.L.dspmap_get_counters(self.h, C.byref(c)))
         return c.as_dict()
+
+    STAGES = ("setup+bin", "predict", "claim", "ck_partial", "ck_finalize", "weight", "birth", "resample")
+
+    def set_profiling(self, on=True):
+        self._chk(self.L.dspmap_set_profiling(self.h, 1 if on else 0))
+
+    def stage_ms(self):
+        """(per-stage summed device ms, frames) accumulated since set_profiling(True)"""
+        out = (C.c_float * 8)()
+        n = C.c_int()
+        self._chk(self.L.dspmap_get_stage_ms(self.h, out, C.byref(n)))
+        return dict(zip(self.STAGES, list(out))), n.value
 
     # -- state
     def clear_state(self):

@@ -64,7 +64,27 @@ struct dspmap {
     int vz_frames = 0;
     int last_n_points = 0;
     VelocityEstimator vel;
+    // per-stage profiling
+    bool prof = false;
+    hipEvent_t pev[DSPMAP_N_STAGES + 1] = {};
+    double stage_ms[DSPMAP_N_STAGES] = {};
+    int prof_frames = 0;
+    bool prof_pending = false;
 };
+
+static void prof_mark(dspmap* m, int i) {
+    if (m->prof) (void)hipEventRecord(m->pev[i], m->stream);
+}
+static void prof_collect(dspmap* m) {
+    if (!m->prof || !m->prof_pending) return;
+    (void)hipEventSynchronize(m->pev[DSPMAP_N_STAGES]);
+    for (int i = 0; i < DSPMAP_N_STAGES; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, m->pev[i], m->pev[i + 1]) == hipSuccess) m->stage_ms[i] += ms;
+    }
+    m->prof_frames++;
+    m->prof_pending = false;
+}
 
 static int fail(dspmap* m, int code, const char* fmt, ...) {
     char buf[512];
@@ -497,13 +517,23 @@ static int gate_and_delta(dspmap* m, const float pos[3], double stamp, const flo
 
 // enqueue the stages after binning; birth source already selected in c.s.birth
 static void enqueue_filter(dspmap* m, LaunchCtx& c, const float dp[3], float dt, int n_birth) {
-    launch_predict(c, -dp[0], -dp[1], -dp[2], dt);  // particles move opposite to the sensor (:300)
+    prof_mark(m, 1);
+    launch_predict_only(c, -dp[0], -dp[1], -dp[2], dt);  // particles move opposite to the sensor (:300)
+    prof_mark(m, 2);
+    launch_claim(c);
+    prof_mark(m, 3);
     launch_ck_partial(c);
+    prof_mark(m, 4);
     launch_ck_finalize(c);
+    prof_mark(m, 5);
     launch_weight_update(c);
+    prof_mark(m, 6);
     launch_birth(c, n_birth, false);
+    prof_mark(m, 7);
     launch_resample(c);
-    if (m->vz_frames > 0 && --m->vz_frames == 0) { /* vz0 stays allocated but is no longer consulted */ }
+    prof_mark(m, 8);
+    if (m->prof) m->prof_pending = true;
+    if (m->vz_frames > 0) --m->vz_frames;
 }
 
 extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* points_dev, int n_birth,
@@ -521,7 +551,9 @@ extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* poin
     const bool static_birth = birth_dev == nullptr;
     if (!static_birth) c.s.birth = (BirthSrc*)birth_dev;
     const int nb = static_birth ? n_points : n_birth;
+    prof_collect(m);
     HIPCHK(m, hipEventRecord(m->ev0, m->stream));
+    prof_mark(m, 0);
     launch_frame_setup(c, m->quat, m->cur_pos, true);
     launch_obs_bin(c, n_points, points_dev, m->quat, static_birth);
     enqueue_filter(m, c, dp, dt, nb);
@@ -944,6 +976,26 @@ extern "C" int dspmap_set_expected_newborn(dspmap_t* m, float v) {
     HIPCHK(m, hipMemcpy(&fs, m->s.fs, sizeof(fs), hipMemcpyDeviceToHost));
     fs.expected_newborn = v; fs.has_expected_override = 1;
     HIPCHK(m, hipMemcpy(m->s.fs, &fs, sizeof(fs), hipMemcpyHostToDevice));
+    return DSPMAP_OK;
+}
+
+extern "C" int dspmap_set_profiling(dspmap_t* m, int on) {
+    READY(m);
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (on && !m->pev[0])
+        for (int i = 0; i <= DSPMAP_N_STAGES; i++) HIPCHK(m, hipEventCreate(&m->pev[i]));
+    m->prof = on != 0;
+    m->prof_pending = false;
+    m->prof_frames = 0;
+    for (int i = 0; i < DSPMAP_N_STAGES; i++) m->stage_ms[i] = 0.0;
+    return DSPMAP_OK;
+}
+extern "C" int dspmap_get_stage_ms(dspmap_t* m, float out[DSPMAP_N_STAGES], int* n_frames) {
+    READY(m);
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    prof_collect(m);
+    for (int i = 0; i < DSPMAP_N_STAGES; i++) out[i] = (float)m->stage_ms[i];
+    if (n_frames) *n_frames = m->prof_frames;
     return DSPMAP_OK;
 }
 

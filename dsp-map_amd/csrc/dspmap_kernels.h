@@ -32,6 +32,8 @@ void launch_frame_setup(const LaunchCtx& c, const float quat[4], const float cur
 void launch_obs_bin(const LaunchCtx& c, int n_pts, const float* pts_dev, const float quat[4], bool make_static_birth);
 // mapPrediction (:627-701) incl. re-binning of movers (moveParticle :1206-1274)
 void launch_predict(const LaunchCtx& c, float odx, float ody, float odz, float dt);
+void launch_predict_only(const LaunchCtx& c, float odx, float ody, float odz, float dt);
+void launch_claim(const LaunchCtx& c);
 void launch_reduce_counters(const LaunchCtx& c);  // folds the per-block partial counters into FrameScalars
 // mapUpdate (:704-793)
 void launch_ck_partial(const LaunchCtx& c);

@@ -1192,12 +1192,19 @@ void launch_obs_bin(const LaunchCtx& c, int n_pts, const float* pts_dev, const f
     hipLaunchKernelGGL(k_obs_gather, dim3(c.d.np), dim3(WAVE), 0, c.stream, c.d, c.s, n_pts);
 }
 
-void launch_predict(const LaunchCtx& c, float odx, float ody, float odz, float dt) {
+void launch_predict_only(const LaunchCtx& c, float odx, float ody, float odz, float dt) {
     const KernelScratch* k = &c.k;
-    const int vpw = k->vpw_sweep, tpb = k->tpb_sweep, nblk = k->nblk_sweep;
-    hipLaunchKernelGGL(k_predict, dim3(nblk), dim3(tpb), 0, c.stream, c.d, c.s, c.fp, odx, ody, odz, dt, vpw,
-                       c.s.vz0 ? 1 : 0, k->part_predict, k->mvmask, k->expmask);
-    hipLaunchKernelGGL(k_claim, dim3(nblk), dim3(tpb), 0, c.stream, c.d, c.s, vpw, k->mvmask, k->part_claim);
+    hipLaunchKernelGGL(k_predict, dim3(k->nblk_sweep), dim3(k->tpb_sweep), 0, c.stream, c.d, c.s, c.fp, odx, ody, odz, dt,
+                       k->vpw_sweep, c.s.vz0 ? 1 : 0, k->part_predict, k->mvmask, k->expmask);
+}
+void launch_claim(const LaunchCtx& c) {
+    const KernelScratch* k = &c.k;
+    hipLaunchKernelGGL(k_claim, dim3(k->nblk_sweep), dim3(k->tpb_sweep), 0, c.stream, c.d, c.s, k->vpw_sweep, k->mvmask,
+                       k->part_claim);
+}
+void launch_predict(const LaunchCtx& c, float odx, float ody, float odz, float dt) {
+    launch_predict_only(c, odx, ody, odz, dt);
+    launch_claim(c);
 }
 
 void launch_ck_partial(const LaunchCtx& c) {

@@ -178,6 +178,14 @@ int dspmap_pyramid_num(const dspmap_t* m);      /* observation_pyramid_num :60 *
 int dspmap_pyramid_capacity(const dspmap_t* m); /* SAFE_PARTICLE_NUM_PYRAMID :66 */
 int dspmap_get_counters(dspmap_t* m, dspmap_counters* out);
 
+/* per-stage device timing (HIP events on the handle's stream around each kernel group).
+ * Off by default; when on, every update records events and the elapsed times accumulate.
+ * Stages: 0 setup+binning, 1 predict, 2 claim(movers), 3 Ck partial, 4 Ck finalize,
+ *         5 weight update, 6 birth, 7 occupancy+resample. */
+#define DSPMAP_N_STAGES 8
+int dspmap_set_profiling(dspmap_t* m, int on);
+int dspmap_get_stage_ms(dspmap_t* m, float ms_sum_out[DSPMAP_N_STAGES], int* n_frames_out); /* sums since enabling; syncs */
+
 /* ---- state access (the reference's equivalent is direct access to its
  * file-scope arrays, dsp_dynamic.h:116).  A record is 8 floats
  * {flag, vx, vy, vz, px, py, pz, weight} (:114-115 minus the dead update_time).
