@@ -189,7 +189,7 @@ static void free_dev(dspmap* m) {
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.nstatic, s.fov_rec, s.fov_slot, s.pyr_cnt, s.mv_rec, s.exp_up, s.exp_down,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mvmask, m->k.expmask,
-                    m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->pts_dev};
+                    m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.work_count, m->k.child, m->pts_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->pts_pin) (void)hipHostFree(m->pts_pin);
     if (m->birth_pin) (void)hipHostFree(m->birth_pin);
@@ -260,7 +260,7 @@ static int ensure_point_cap(dspmap* m, int n) {
     HIPCHK(m, hipStreamSynchronize(m->stream));
     DevState& s = m->s;
     const int cap = n + n / 2 + 1024;
-    void* olds[] = {s.pt_rot, s.pt_pyr, s.birth, s.plan, s.nstatic, m->pts_dev};
+    void* olds[] = {s.pt_rot, s.pt_pyr, s.birth, s.plan, s.nstatic, m->pts_dev, m->k.child};
     for (void* p : olds) if (p) (void)hipFree(p);
     HIPCHK(m, dalloc(&s.pt_rot, (size_t)cap));
     HIPCHK(m, dalloc(&s.pt_pyr, (size_t)cap));
@@ -268,6 +268,7 @@ static int ensure_point_cap(dspmap* m, int n) {
     HIPCHK(m, dalloc(&s.plan, (size_t)cap));
     HIPCHK(m, dalloc(&s.nstatic, (size_t)cap));
     HIPCHK(m, dalloc(&m->pts_dev, (size_t)cap * 3));
+    HIPCHK(m, dalloc(&m->k.child, (size_t)cap * 32));
     m->pt_cap = cap; m->birth_cap = cap;
     return DSPMAP_OK;
 }
@@ -304,16 +305,18 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     KernelScratch& k = m->k;
     k.tpb_sweep = sweep_geometry(d.slots, &k.vpw_sweep);
     k.nblk_sweep = (d.v_loc + k.vpw_sweep - 1) / k.vpw_sweep;
-    k.nblk_resample = (d.v_loc + 255) / 256;
+    k.nblk_resample = (d.v_loc + 255) / 256 < 2048 ? (d.v_loc + 255) / 256 : 2048;  // persistent waves (4 per block)
     HIPCHK(m, dalloc(&k.mvmask, W));
     const bool slab = !(d.z_lo == 0 && d.z_hi == d.nz);
     if (slab) HIPCHK(m, dalloc(&k.expmask, W));
     HIPCHK(m, dalloc(&k.part_predict, (size_t)k.nblk_sweep * 4));
     HIPCHK(m, dalloc(&k.part_claim, (size_t)k.nblk_sweep * 2));
     HIPCHK(m, dalloc(&k.part_resample, (size_t)k.nblk_resample * 4));
+    HIPCHK(m, dalloc(&k.work_list, (size_t)d.v_loc));
+    HIPCHK(m, dalloc(&k.work_count, (size_t)1));
     HIPCHK(m, dalloc(&k.vb_cnt, (size_t)d.v_loc));
     HIPCHK(m, dalloc(&k.vb_idx, (size_t)d.v_loc * 128));
-    HIPCHK(m, dalloc(&s.blk_cnt, (size_t)k.nblk_resample + 1));
+    HIPCHK(m, dalloc(&s.blk_cnt, (size_t)(d.v_loc + 255) / 256 + 1));
     HIPCHK(m, hipMemset(s.mask, 0, sizeof(u64) * W)); HIPCHK(m, hipMemset(s.nbmask, 0, sizeof(u64) * W));
     HIPCHK(m, hipMemset(k.mvmask, 0, sizeof(u64) * W));
     if (k.expmask) HIPCHK(m, hipMemset(k.expmask, 0, sizeof(u64) * W));

@@ -11,35 +11,41 @@
 __device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+// ---- wavefront scan / reduction on the DPP network (no LDS traffic).
+// gfx9 pattern: 4 row_shr steps scan each row of 16 lanes, row_bcast:15 / :31
+// carry the row totals across (same sequence LLVM's atomic optimizer emits).
+// Requires all 64 lanes active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_f(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
-__device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_add_i(int v) {
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
 }
-// inclusive prefix sum over the 64 lanes (wavefront scan, Hillis-Steele)
+// inclusive prefix sum over the 64 lanes
 __device__ __forceinline__ float wave_incl_scan(float v) {
-    const int l = lane_id();
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        float t = __shfl_up(v, o, WAVE);
-        if (l >= o) v += t;
-    }
+    v = dpp_add_f<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add_f<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add_f<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add_f<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_add_f<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+    v = dpp_add_f<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
     return v;
 }
 __device__ __forceinline__ int wave_incl_scan_i(int v) {
-    const int l = lane_id();
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        int t = __shfl_up(v, o, WAVE);
-        if (l >= o) v += t;
-    }
+    v = dpp_add_i<0x111, 0xf>(v);
+    v = dpp_add_i<0x112, 0xf>(v);
+    v = dpp_add_i<0x114, 0xf>(v);
+    v = dpp_add_i<0x118, 0xf>(v);
+    v = dpp_add_i<0x142, 0xa>(v);
+    v = dpp_add_i<0x143, 0xc>(v);
     return v;
 }
+__device__ __forceinline__ float wave_sum(float v) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_incl_scan(v)), 63));
+}
+__device__ __forceinline__ int wave_sum_i(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_i(v), 63); }
 
 // Wave-aggregated "append": every active lane gets a distinct position in the
 // list counted by cnt[key]; one global atomic per distinct key per wave.

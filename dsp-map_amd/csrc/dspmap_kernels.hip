@@ -359,7 +359,7 @@ __global__ void k_claim(MapDims d, DevState s, int vpw, u64* __restrict__ mvmask
 // same XCD (blockIdx % 8) so its obs tile and Ck lines stay in one L2.
 // --------------------------------------------------------------------------
 #define CK_TPB 128
-#define CK_PCH 512
+#define CK_PCH 128
 
 __device__ __forceinline__ void decode_pyr_block(int bid, int nchunk, int np, int& b, int& chunk) {
     const int xcd = bid & 7;
@@ -564,10 +564,9 @@ __global__ void k_birth_split(MapDims d, DevState s, FilterParams fp, int n_birt
     if (l == 0) { s.plan[i] = pl; s.nstatic[i] = n_static; }
 }
 
-// k_birth_plan: ONE workgroup.  Reproduces the sequential consumption order of
-// the three random streams (:871-873 position table, :884-886 velocity table,
-// :895-897 rand()) with two block-wide prefix sums: draws of source point i
-// start at cursor + (draws of all earlier points).
+// The sequential consumption order of the three random streams (:871-873 position table,
+// :884-886 velocity table, :895-897 rand()) is reproduced with block-wide prefix sums over the
+// source points: draws of point i start at cursor + (draws of all earlier points).
 __device__ __forceinline__ int block_excl_scan_1024(int v, int* s_tmp, int* total) {
     // s_tmp: 17 ints.  blockDim.x == 1024
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
@@ -586,47 +585,92 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int* s_tmp, int* tota
     return r;
 }
 
-__global__ void __launch_bounds__(1024) k_birth_plan(MapDims d, DevState s, FilterParams fp, int n_birth) {
+// k_birth_rank (one workgroup): rank of every valid source point among the valid ones ->
+// first position-table cursor of the point (3 draws per child, always consumed, :871-873).
+__global__ void __launch_bounds__(1024) k_birth_rank(MapDims d, DevState s, FilterParams fp, int n_birth) {
     __shared__ int s_tmp[17];
-    __shared__ int s_run[3];
+    __shared__ int s_run;
     const int tid = threadIdx.x;
-    if (tid < 3) s_run[tid] = 0;
+    if (tid == 0) s_run = 0;
     __syncthreads();
-    const int p_cur = s.fs->p_cur, v_cur = s.fs->v_cur, r_cur = s.fs->r_cur;
+    const int p_cur = s.fs->p_cur;
     const int nb = fp.nb_num;
     for (int base = 0; base < n_birth; base += 1024) {
         const int i = base + tid;
-        BirthPlan pl;
-        BirthSrc src;
-        bool ok = false;
-        if (i < n_birth) {
-            pl = s.plan[i];
-            src = s.birth[i];
-            pl.n_static = s.nstatic[i];
-            ok = pl.gvox >= 0;
-        }
+        const bool ok = i < n_birth && s.plan[i].gvox >= 0;
         int tot;
         const int r = block_excl_scan_1024(ok ? 1 : 0, s_tmp, &tot);
-        const int prun = s_run[0];
-        int cv = 0, cr = 0;
-        if (ok) {
-            // position draws: 3 per child, always consumed (:871-873)
-            pl.pbase = (int)(((long long)p_cur + 3ll * nb * (long long)(prun + r)) % fp.tab_n);
-            unsigned inside = 0;
-            for (int k = 0; k < nb; ++k) {
-                const int c = (int)(((long long)pl.pbase + 3 * k) % fp.tab_n);
-                const float x = pl.cx + s.p_tab[c];
-                const float y = pl.cy + s.p_tab[(c + 1) % fp.tab_n];
-                const float z = pl.cz + s.p_tab[(c + 2) % fp.tab_n];
-                int gv;
-                if (voxel_of(d, x, y, z, gv)) inside |= 1u << k;  // :875
-            }
-            pl.inside = inside;
-            if (src.intensity > 0.01f) {
-                const int model_end = src.nx > -100.f ? fp.model_nb : pl.n_static;  // :881
-                for (int k = pl.n_static; k < nb; ++k) {
-                    if (!((inside >> k) & 1u)) continue;
-                    if (k < model_end) cv += 3; else cr += 3;
+        if (ok) s.plan[i].pbase = (int)(((long long)p_cur + 3ll * nb * (long long)(s_run + r)) % fp.tab_n);
+        __syncthreads();
+        if (tid == 0) s_run += tot;
+        __syncthreads();
+    }
+    if (tid == 0) s.fs->p_cur = (int)(((long long)p_cur + 3ll * nb * s_run) % fp.tab_n);
+}
+
+// Children are inserted in the reference's sequential order WITHOUT a sort:
+// k_birth_children computes every child's position (:871-873) and destination voxel, marks it
+// "inside the map" (:875) and records its birth index (point*n_nb+child) in the per-voxel bucket;
+// k_birth_insert ranks each child among its voxel's children by birth index and takes the
+// rank-th free slot of the PRE-birth occupancy word -- exactly the slot addAParticle's
+// first-free scan (:1183-1201) would hand out when children arrive one after another; children
+// whose rank exceeds the free slots are dropped, as in the reference (:1198-1200).
+// New particles only set their bit in nbmask (live = mask | nbmask), so the pre-birth word
+// stays stable while the kernel runs.
+#define BIRTH_BUCKET_CAP 128
+
+__global__ void k_birth_children(MapDims d, DevState s, FilterParams fp, int n_birth, float4* __restrict__ child,
+                                 int* __restrict__ vb_cnt, int* __restrict__ vb_idx) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nb = fp.nb_num;
+    const int i = t / nb, k = t - i * nb;
+    if (i >= n_birth) return;
+    const BirthPlan pl = s.plan[i];
+    if (pl.gvox < 0) return;
+    const int c = (int)(((long long)pl.pbase + 3 * k) % fp.tab_n);
+    const float x = pl.cx + s.p_tab[c];                      // :871-873
+    const float y = pl.cy + s.p_tab[(c + 1) % fp.tab_n];
+    const float z = pl.cz + s.p_tab[(c + 2) % fp.tab_n];
+    int gv = 0;
+    int lv = -1;
+    if (voxel_of(d, x, y, z, gv)) {                          // :875
+        atomicOr(&s.plan[i].inside, 1u << k);
+        lv = gv - d.v_base;
+        if (lv >= 0 && lv < d.v_loc) {                       // children landing in another slab are inserted by their owner
+            const int pos = atomicAdd(&vb_cnt[lv], 1);
+            if (pos < BIRTH_BUCKET_CAP) vb_idx[(size_t)lv * BIRTH_BUCKET_CAP + pos] = t;
+        } else {
+            lv = -1;
+        }
+    }
+    child[t] = make_float4(x, y, z, __int_as_float(lv));
+}
+
+// k_birth_cursors (one workgroup): velocity-table and rand() cursors per source point (:884-886,:895-897)
+__global__ void __launch_bounds__(1024) k_birth_cursors(MapDims d, DevState s, FilterParams fp, int n_birth) {
+    __shared__ int s_tmp[17];
+    __shared__ int s_run[2];
+    const int tid = threadIdx.x;
+    if (tid < 2) s_run[tid] = 0;
+    __syncthreads();
+    const int v_cur = s.fs->v_cur, r_cur = s.fs->r_cur;
+    const int nb = fp.nb_num;
+    for (int base = 0; base < n_birth; base += 1024) {
+        const int i = base + tid;
+        int cv = 0, cr = 0, n_static = 0;
+        bool ok = false;
+        if (i < n_birth) {
+            const BirthPlan pl = s.plan[i];
+            ok = pl.gvox >= 0;
+            if (ok) {
+                n_static = s.nstatic[i];
+                const BirthSrc src = s.birth[i];
+                if (src.intensity > 0.01f) {
+                    const int model_end = src.nx > -100.f ? fp.model_nb : n_static;  // :881
+                    for (int k = n_static; k < nb; ++k) {
+                        if (!((pl.inside >> k) & 1u)) continue;
+                        if (k < model_end) cv += 3; else cr += 3;
+                    }
                 }
             }
         }
@@ -634,18 +678,17 @@ __global__ void __launch_bounds__(1024) k_birth_plan(MapDims d, DevState s, Filt
         const int ev = block_excl_scan_1024(cv, s_tmp, &totv);
         const int er = block_excl_scan_1024(cr, s_tmp, &totr);
         if (ok) {
-            pl.vbase = (int)(((long long)v_cur + s_run[1] + ev) % fp.tab_n);
-            pl.rbase = (int)(((long long)r_cur + s_run[2] + er) % max(fp.rtab_n, 1));
+            s.plan[i].n_static = n_static;
+            s.plan[i].vbase = (int)(((long long)v_cur + s_run[0] + ev) % fp.tab_n);
+            s.plan[i].rbase = (int)(((long long)r_cur + s_run[1] + er) % max(fp.rtab_n, 1));
         }
-        if (i < n_birth) s.plan[i] = pl;
         __syncthreads();
-        if (tid == 0) { s_run[0] += tot; s_run[1] += totv; s_run[2] += totr; }
+        if (tid == 0) { s_run[0] += totv; s_run[1] += totr; }
         __syncthreads();
     }
     if (tid == 0) {
-        s.fs->p_cur = (int)(((long long)p_cur + 3ll * nb * s_run[0]) % fp.tab_n);
-        s.fs->v_cur = (int)(((long long)v_cur + s_run[1]) % fp.tab_n);
-        s.fs->r_cur = (int)(((long long)r_cur + s_run[2]) % max(fp.rtab_n, 1));
+        s.fs->v_cur = (int)(((long long)v_cur + s_run[0]) % fp.tab_n);
+        s.fs->r_cur = (int)(((long long)r_cur + s_run[1]) % max(fp.rtab_n, 1));
     }
 }
 
@@ -655,49 +698,10 @@ __device__ __forceinline__ float rand_float(const DevState& s, const FilterParam
     return lo + __fdiv_rn((float)r, __fdiv_rn((float)2147483647, (hi - lo)));
 }
 
-// Children are inserted in the reference's sequential order WITHOUT a sort:
-// k_birth_bucket records, per destination voxel, the birth index (point*n_nb+child)
-// of every child landing there; k_birth_insert ranks each child among its voxel's
-// children by birth index and takes the rank-th free slot of the PRE-birth
-// occupancy word -- exactly the slot addAParticle's first-free scan (:1183-1201)
-// would hand out when children arrive one after another; children whose rank
-// exceeds the free slots are dropped, as in the reference (:1198-1200).
-// New particles only set their bit in nbmask (live = mask | nbmask), so the
-// pre-birth word stays stable while the kernel runs.
-#define BIRTH_BUCKET_CAP 128
-
-__device__ __forceinline__ bool child_position(const MapDims& d, const DevState& s, const FilterParams& fp,
-                                               const BirthPlan& pl, int k, float& x, float& y, float& z, int& lv) {
-    const int c = (int)(((long long)pl.pbase + 3 * k) % fp.tab_n);
-    x = pl.cx + s.p_tab[c];                      // :871-873
-    y = pl.cy + s.p_tab[(c + 1) % fp.tab_n];
-    z = pl.cz + s.p_tab[(c + 2) % fp.tab_n];
-    int gv = 0;
-    voxel_of(d, x, y, z, gv);
-    lv = gv - d.v_base;
-    return lv >= 0 && lv < d.v_loc;  // children landing in another slab are inserted by their owner
-}
-
-__global__ void k_birth_bucket(MapDims d, DevState s, FilterParams fp, int n_birth, int* __restrict__ vb_cnt,
-                               int* __restrict__ vb_idx) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nb = fp.nb_num;
-    const int i = t / nb, k = t - i * nb;
-    if (i >= n_birth) return;
-    const BirthPlan pl = s.plan[i];
-    if (pl.gvox < 0 || !((pl.inside >> k) & 1u)) return;
-    float x, y, z;
-    int lv;
-    if (!child_position(d, s, fp, pl, k, x, y, z, lv)) return;
-    const int pos = atomicAdd(&vb_cnt[lv], 1);
-    if (pos < BIRTH_BUCKET_CAP) vb_idx[(size_t)lv * BIRTH_BUCKET_CAP + pos] = t;
-}
-
-// k_birth_insert: one thread per (source point, child).  Position = source +
-// N(0,sigma_p) (:871-873); velocity by branch (:877-903); vz = 0 (:905-907);
-// weight = the global newborn weight (:909); newborn flag (= nbmask bit).
-__global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, int n_birth, const int* __restrict__ vb_cnt,
-                               const int* __restrict__ vb_idx) {
+// k_birth_insert: one thread per (source point, child): velocity by branch (:877-903); vz = 0
+// (:905-907); weight = the global newborn weight (:909); newborn flag (= nbmask bit).
+__global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, int n_birth, const float4* __restrict__ child,
+                               const int* __restrict__ vb_cnt, const int* __restrict__ vb_idx) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int nb = fp.nb_num;
     const int i = t / nb, k = t - i * nb;
@@ -705,10 +709,10 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, int n_bir
     if (i < n_birth) {
         const BirthPlan pl = s.plan[i];
         if (pl.gvox >= 0 && ((pl.inside >> k) & 1u)) {
-            const BirthSrc src = s.birth[i];
-            float x, y, z;
-            int lv;
-            if (child_position(d, s, fp, pl, k, x, y, z, lv)) {
+            const float4 ch = child[t];
+            const int lv = __float_as_int(ch.w);
+            if (lv >= 0) {
+                const BirthSrc src = s.birth[i];
                 float vx = 0.f, vy = 0.f;
                 if (k >= pl.n_static && src.intensity > 0.01f) {
                     const int model_end = src.nx > -100.f ? fp.model_nb : pl.n_static;
@@ -728,8 +732,7 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, int n_bir
                     }
                 }
                 // rank among this voxel's children, by birth index
-                const int total = vb_cnt[lv];
-                const int n = min(total, BIRTH_BUCKET_CAP);
+                const int n = min(vb_cnt[lv], BIRTH_BUCKET_CAP);
                 int rank = 0;
                 bool recorded = false;
                 const int* bl = vb_idx + (size_t)lv * BIRTH_BUCKET_CAP;
@@ -739,8 +742,7 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, int n_bir
                     recorded |= (o == t);
                 }
                 int sl = -1;
-                if (recorded) {
-                    // rank-th free slot of the pre-birth occupancy
+                if (recorded) {  // rank-th free slot of the pre-birth occupancy
                     int r = rank;
                     for (int e = 0; e < d.mw && sl < 0; ++e) {
                         const int nbits = min(64, d.slots - e * 64);
@@ -754,7 +756,7 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, int n_bir
                 }
                 if (sl >= 0) {
                     const size_t idx = (size_t)lv * d.slots + sl;
-                    s.px[idx] = x; s.py[idx] = y; s.pz[idx] = z;
+                    s.px[idx] = ch.x; s.py[idx] = ch.y; s.pz[idx] = ch.z;
                     s.vx[idx] = vx; s.vy[idx] = vy;
                     s.w[idx] = s.fs->newborn_w;
                     atomicOr(&s.nbmask[(size_t)lv * d.mw + (sl >> 6)], 1ull << (sl & 63));  // flag 15
@@ -770,21 +772,71 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, int n_bir
 }
 
 // --------------------------------------------------------------------------
-// k_resample: mapOccupancyCalculationAndResample :924-1057.
-// Each wave owns 64 consecutive voxels: lanes first look at one voxel each
-// (occupancy word), empty voxels are finished right there; the non-empty ones
-// are then processed one at a time by the whole wave with LANES = SLOTS:
-//   cull w < 1e-3 (:941), mass = wavefront reduction (:970-974), mean velocity
-//   (:944-948,976-984), constant-velocity future rollout scattered with float
-//   atomics (:950-964), systematic resampling driven by a wavefront prefix
-//   scan of the weights (:1005-1053) incl. lowest-free-slot copies and the
-//   "no free slot -> fold the weight back" rule (:1037-1041).
+// mapOccupancyCalculationAndResample :924-1057, two kernels:
+//  k_resample_scan : one lane per voxel looks at the occupancy words; empty voxels get their
+//                    (zero) result written right there, non-empty ones are appended to a work
+//                    list (one atomic per 1024-voxel block) -> perfect load balance whatever the
+//                    spatial clustering of the particles.
+//  k_resample_work : persistent waves stride over the work list; ONE WAVE PER VOXEL, LANES =
+//                    SLOTS.  All six field loads of a voxel are issued unconditionally up front
+//                    and the next voxel's loads are in flight while the current one is processed.
+//     cull w < 1e-3 (:941), mass = wavefront reduction (:970-974), mean velocity
+//     (:944-948,976-984), constant-velocity future rollout scattered with float atomics
+//     (:950-964; a voxel whose particles are all static adds its mass to itself for every
+//     horizon without any index math), systematic resampling driven by a wavefront (DPP) prefix
+//     scan of the weights (:1005-1053) incl. lowest-free-slot copies and the "no free slot ->
+//     fold the weight back" rule (:1037-1041).
 // --------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_resample_scan(MapDims d, DevState s, int* __restrict__ work_list,
+                                                        int* __restrict__ work_count) {
+    __shared__ int s_w[16];
+    __shared__ int s_base;
+    const int lv = blockIdx.x * 1024 + threadIdx.x;
+    bool nonempty = false;
+    if (lv < d.v_loc) {
+        for (int e = 0; e < d.mw; ++e)
+            nonempty |= (s.mask[(size_t)lv * d.mw + e] | s.nbmask[(size_t)lv * d.mw + e]) != 0ull;
+        if (!nonempty) s.res4[lv] = make_float4(0.f, 0.f, 0.f, 0.f);  // :974-984 for an empty voxel
+    }
+    const u64 b = __ballot(nonempty);
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 0) s_w[w] = (int)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int k = 0; k < 16; ++k) { const int t = s_w[k]; s_w[k] = tot; tot += t; }
+        s_base = tot ? atomicAdd(work_count, tot) : 0;
+    }
+    __syncthreads();
+    if (nonempty) work_list[s_base + s_w[w] + (int)__popcll(b & lanemask_lt())] = lv;
+}
+
 template <int EPL>
-__device__ __forceinline__ void resample_voxel(const MapDims& d, const DevState& s, int lv,
-                                               const u64 (&m)[EPL], const u64 (&nb)[EPL],
-                                               float4& res, u64 (&newmask)[EPL]) {
+struct VoxRegs {
+    u64 m[EPL], nb[EPL];
+    float w[EPL], vx[EPL], vy[EPL], px[EPL], py[EPL], pz[EPL];
+    int lv;
+};
+
+template <int EPL>
+__device__ __forceinline__ void load_voxel(const MapDims& d, const DevState& s, int lv, VoxRegs<EPL>& r) {
     const int l = lane_id();
+    r.lv = lv;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        r.nb[e] = s.nbmask[(size_t)lv * EPL + e];
+        r.m[e] = s.mask[(size_t)lv * EPL + e] | r.nb[e];  // newborns live only in nbmask until now
+        const int sl = e * 64 + l;
+        const size_t idx = (size_t)lv * d.slots + (sl < d.slots ? sl : 0);
+        r.w[e] = s.w[idx]; r.vx[e] = s.vx[idx]; r.vy[e] = s.vy[idx];
+        r.px[e] = s.px[idx]; r.py[e] = s.py[idx]; r.pz[e] = s.pz[idx];
+    }
+}
+
+template <int EPL>
+__device__ __forceinline__ int resample_voxel(const MapDims& d, const DevState& s, const VoxRegs<EPL>& r) {
+    const int l = lane_id();
+    const int lv = r.lv;
     float w[EPL];
     bool alive[EPL];
     u64 alive_m[EPL], old_m[EPL];
@@ -792,203 +844,209 @@ __device__ __forceinline__ void resample_voxel(const MapDims& d, const DevState&
     float occ = 0.f;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
-        const bool live = (m[e] >> l) & 1ull;
-        const size_t idx = (size_t)lv * d.slots + e * 64 + l;
-        w[e] = live ? s.w[idx] : 0.f;
+        const bool live = (r.m[e] >> l) & 1ull;
+        w[e] = live ? r.w[e] : 0.f;
         alive[e] = live && !(w[e] < 1e-3f);  // :941
         alive_m[e] = __ballot(alive[e]);
-        old_m[e] = alive_m[e] & ~nb[e];      // flag < 10 :944
+        old_m[e] = alive_m[e] & ~r.nb[e];    // flag < 10 :944
         n += (int)__popcll(alive_m[e]);
         n_old += (int)__popcll(old_m[e]);
         if (!alive[e]) w[e] = 0.f;
         occ += w[e];
     }
     occ = wave_sum(occ);  // :970,974
-    // mean velocity of non-newborn survivors + future rollout
-    float vxs = 0.f, vys = 0.f;
+    float4 res = make_float4(occ, 0.f, 0.f, 0.f);
     if (n_old > 0) {
+        float vxs = 0.f, vys = 0.f, wold = 0.f;
+        u64 moving = 0ull;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             const bool old = (old_m[e] >> l) & 1ull;
-            const size_t idx = (size_t)lv * d.slots + e * 64 + l;
-            float vx = 0.f, vy = 0.f, px = 0.f, py = 0.f, pz = 0.f;
-            if (old) { vx = s.vx[idx]; vy = s.vy[idx]; px = s.px[idx]; py = s.py[idx]; pz = s.pz[idx]; }
+            const float vx = old ? r.vx[e] : 0.f, vy = old ? r.vy[e] : 0.f;
             vxs += vx; vys += vy;
-            for (int t = 0; t < d.T; ++t) {  // :952-963
-                const float pt = d.pred_t[t];
-                const float fx = px + vx * pt;
-                const float fy = py + vy * pt;
-                const float fz = pz + 0.f * pt;
-                int gv = -1;
-                const bool in = old && voxel_of(d, fx, fy, fz, gv);
-                const int dl = gv - d.v_base;
-                const bool own = in && dl == lv;
-                const float sown = wave_sum(own ? w[e] : 0.f);
-                if (l == 0 && sown != 0.f) unsafeAtomicAdd(&s.fut[(size_t)lv * d.T + t], sown);
-                if (in && !own && dl >= 0 && dl < d.v_loc) unsafeAtomicAdd(&s.fut[(size_t)dl * d.T + t], w[e]);
-            }
+            wold += old ? w[e] : 0.f;
+            moving |= __ballot(old && (vx != 0.f || vy != 0.f));
         }
         vxs = wave_sum(vxs); vys = wave_sum(vys);
-        res = make_float4(occ, __fdiv_rn(vxs, (float)n_old), __fdiv_rn(vys, (float)n_old), 0.f);
-    } else {
-        res = make_float4(occ, 0.f, 0.f, 0.f);
-    }
+        res.y = __fdiv_rn(vxs, (float)n_old);
+        res.z = __fdiv_rn(vys, (float)n_old);
+        // future rollout :950-964
+        if (!moving) {
+            // every survivor is static: p + 0*t stays in this voxel for every horizon
+            const float sown = wave_sum(wold);
+            if (l < d.T && sown != 0.f) unsafeAtomicAdd(&s.fut[(size_t)lv * d.T + l], sown);
+        } else {
+            const int gz = (lv + d.v_base) / (d.ny * d.nx);  // z layer is unchanged (vz == 0)
+            for (int t = 0; t < d.T; ++t) {
+                const float pt = d.pred_t[t];
+                float sown = 0.f;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) newmask[e] = alive_m[e];
-    if (n < 5) return;  // :986
-    const int n_after = n > d.M ? d.M : n;               // :992-997
-    // inclusive prefix sum of the surviving weights in slot order (acc_ori_weight :1011)
-    float A[EPL];
-    // (fp32 prefix scan; the reference accumulates sequentially, so the two differ in the last
-    // bits -- this only matters when a running sum sits exactly on a threshold, e.g. a voxel that
-    // holds nothing but equal-weight newborns with n > M; see DESIGN.md "threshold ties")
-    float carry = 0.f;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-        A[e] = wave_incl_scan(w[e]) + carry;
-        carry = __shfl(A[e], 63, WAVE);
-    }
-    const float w_after = __fdiv_rn(occ, (float)n_after);  // :1000
-    // K(a) = number of thresholds tau_m < a, tau_0 = 0.5 w', tau_{m+1} = tau_m + w' (fp32, :1006,1015,1043)
-    int K[EPL];
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) K[e] = 0;
-    {
-        float tau = w_after * 0.5f;
-        for (int q = 0; q <= n_after; ++q) {
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) K[e] += (A[e] > tau) ? 1 : 0;
-            tau += w_after;
-        }
-    }
-    int want[EPL], extra[EPL];
-    u64 kept_m[EPL], removed_m[EPL], copy_m[EPL];
-    int prev_last = 0;
-    bool any_copy = false;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-        int kp = __shfl_up(K[e], 1, WAVE);
-        if (l == 0) kp = prev_last;
-        prev_last = __shfl(K[e], 63, WAVE);
-        want[e] = alive[e] ? K[e] - kp : 0;
-        extra[e] = want[e] > 1 ? want[e] - 1 : 0;
-        kept_m[e] = __ballot(alive[e] && want[e] >= 1);
-        removed_m[e] = alive_m[e] & ~kept_m[e];  // :1046-1049
-        copy_m[e] = __ballot(extra[e] > 0);
-        any_copy |= copy_m[e] != 0;
-    }
-    int fold[EPL];
-    int src_of[EPL];
-    u64 taken[EPL];
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) { fold[e] = 0; src_of[e] = -1; taken[e] = 0; }
-    if (any_copy) {
-        // sequential part of the reference loop, wave-uniform: copies go to the LOWEST free slot at the
-        // time the sweep reaches the heavy particle (:1019-1035); free = empty after the cull, or
-        // freed by a removal earlier in the sweep, and not yet taken by a copy.
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            u64 cm = copy_m[e];
-            while (cm) {
-                const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)cm) - 1);
-                cm &= cm - 1;
-                const int dj = __builtin_amdgcn_readlane(extra[e], j);
-                int nfold = 0;
-                for (int c = 0; c < dj; ++c) {
-                    int fe = -1, fq = -1;
-#pragma unroll
-                    for (int e2 = 0; e2 < EPL; ++e2) {
-                        if (fe >= 0) continue;
-                        const int nbits = min(64, d.slots - e2 * 64);
-                        const u64 valid = nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
-                        u64 below;  // slots of word e2 already passed by the sweep
-                        if (e2 < e) below = ~0ull; else if (e2 == e) below = (1ull << j) - 1ull; else below = 0ull;
-                        const u64 occupied = (alive_m[e2] & ~(removed_m[e2] & below)) | taken[e2];
-                        const u64 fr = ~occupied & valid;
-                        if (fr) { fe = e2; fq = __ffsll((long long)fr) - 1; }
-                    }
-                    if (fe < 0) { nfold = dj - c; break; }  // full: fold the rest back (:1037-1041)
-#pragma unroll
-                    for (int e2 = 0; e2 < EPL; ++e2)
-                        if (e2 == fe) {
-                            taken[e2] |= 1ull << fq;
-                            src_of[e2] = (l == fq) ? (e * 64 + j) : src_of[e2];
-                        }
+                for (int e = 0; e < EPL; ++e) {
+                    const bool old = (old_m[e] >> l) & 1ull;
+                    const float fx = r.px[e] + r.vx[e] * pt;
+                    const float fy = r.py[e] + r.vy[e] * pt;
+                    const bool in = old && !(fx >= d.half_x || fx <= -d.half_x || fy >= d.half_y || fy <= -d.half_y);
+                    const int xi = (int)__fdiv_rn(fx + d.half_x, d.res);
+                    const int yi = (int)__fdiv_rn(fy + d.half_y, d.res);
+                    const int dl = gz * d.ny * d.nx + yi * d.nx + xi - d.v_base;
+                    const bool own = in && dl == lv;
+                    sown += own ? w[e] : 0.f;
+                    if (in && !own && dl >= 0 && dl < d.v_loc) unsafeAtomicAdd(&s.fut[(size_t)dl * d.T + t], w[e]);
                 }
-                if (nfold) fold[e] = (l == j) ? nfold : fold[e];
+                sown = wave_sum(sown);
+                if (l == 0 && sown != 0.f) unsafeAtomicAdd(&s.fut[(size_t)lv * d.T + t], sown);
             }
         }
     }
-    // write back: kept particles get w' (+ folded copies, :1014,1039); copies replicate their source
+    if (l == 0) s.res4[lv] = res;  // voxels_objects_number[v][0..3] :974-984
+    u64 newmask[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) newmask[e] = alive_m[e];
+    if (n >= 5) {  // :986
+        const int n_after = n > d.M ? d.M : n;               // :992-997
+        const float w_after = __fdiv_rn(occ, (float)n_after);  // :1000
+        // inclusive prefix sum of the surviving weights in slot order (acc_ori_weight :1011).
+        // (fp32 prefix scan; the reference accumulates sequentially, so the two differ in the last
+        // bits -- this only matters when a running sum sits exactly on a threshold, e.g. a voxel that
+        // holds nothing but equal-weight newborns with n > M; see DESIGN.md "threshold ties")
+        float A[EPL];
+        float carry = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            A[e] = wave_incl_scan(w[e]) + carry;
+            carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A[e]), 63));
+        }
+        // K(a) = number of thresholds tau_m < a, tau_0 = 0.5 w', tau_{m+1} = tau_m + w' (fp32, :1006,1015,1043)
+        int K[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) K[e] = 0;
+        {
+            float tau = w_after * 0.5f;
+            for (int q = 0; q <= n_after; ++q) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) K[e] += (A[e] > tau) ? 1 : 0;
+                tau += w_after;
+            }
+        }
+        int extra[EPL];
+        u64 kept_m[EPL], removed_m[EPL], copy_m[EPL];
+        int prev_last = 0;
+        bool any_copy = false;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            int kp = __builtin_amdgcn_update_dpp(0, K[e], 0x138, 0xf, 0xf, false);  // wave_shr:1
+            if (l == 0) kp = prev_last;
+            prev_last = __builtin_amdgcn_readlane(K[e], 63);
+            const int want = alive[e] ? K[e] - kp : 0;
+            extra[e] = want > 1 ? want - 1 : 0;
+            kept_m[e] = __ballot(alive[e] && want >= 1);
+            removed_m[e] = alive_m[e] & ~kept_m[e];  // :1046-1049
+            copy_m[e] = __ballot(extra[e] > 0);
+            any_copy |= copy_m[e] != 0;
+        }
+        int fold[EPL], src_of[EPL];
+        u64 taken[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { fold[e] = 0; src_of[e] = -1; taken[e] = 0; }
+        if (any_copy) {
+            // sequential part of the reference loop, wave-uniform: copies go to the LOWEST free slot at
+            // the time the sweep reaches the heavy particle (:1019-1035); free = empty after the cull,
+            // or freed by a removal earlier in the sweep, and not yet taken by a copy.
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                u64 cm = copy_m[e];
+                while (cm) {
+                    const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)cm) - 1);
+                    cm &= cm - 1;
+                    const int dj = __builtin_amdgcn_readlane(extra[e], j);
+                    int nfold = 0;
+                    for (int c = 0; c < dj; ++c) {
+                        int fe = -1, fq = -1;
+#pragma unroll
+                        for (int e2 = 0; e2 < EPL; ++e2) {
+                            if (fe >= 0) continue;
+                            const int nbits = min(64, d.slots - e2 * 64);
+                            const u64 valid = nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
+                            u64 below;  // slots of word e2 already passed by the sweep
+                            if (e2 < e) below = ~0ull; else if (e2 == e) below = (1ull << j) - 1ull; else below = 0ull;
+                            const u64 occupied = (alive_m[e2] & ~(removed_m[e2] & below)) | taken[e2];
+                            const u64 fr = ~occupied & valid;
+                            if (fr) { fe = e2; fq = __ffsll((long long)fr) - 1; }
+                        }
+                        if (fe < 0) { nfold = dj - c; break; }  // full: fold the rest back (:1037-1041)
+#pragma unroll
+                        for (int e2 = 0; e2 < EPL; ++e2)
+                            if (e2 == fe) {
+                                taken[e2] |= 1ull << fq;
+                                src_of[e2] = (l == fq) ? (e * 64 + j) : src_of[e2];
+                            }
+                    }
+                    if (nfold) fold[e] = (l == j) ? nfold : fold[e];
+                }
+            }
+        }
+        // write back: kept particles get w' (+ folded copies, :1014,1039); copies replicate their source
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const size_t idx = (size_t)lv * d.slots + e * 64 + l;
+            if ((kept_m[e] >> l) & 1ull) {
+                float wn = w_after;
+                for (int f = 0; f < fold[e]; ++f) wn += w_after;
+                s.w[idx] = wn;
+            }
+            if (any_copy) {
+                // fetch the source record from its lane (the whole voxel is in registers)
+                const int so = src_of[e] < 0 ? 0 : src_of[e];
+                float cpx = 0, cpy = 0, cpz = 0, cvx = 0, cvy = 0;
+#pragma unroll
+                for (int e2 = 0; e2 < EPL; ++e2) {
+                    const int sl = so - e2 * 64;
+                    const bool pick = sl >= 0 && sl < 64;
+                    const int srcl = pick ? sl : 0;
+                    const float tx = __shfl(r.px[e2], srcl, WAVE), ty = __shfl(r.py[e2], srcl, WAVE), tz = __shfl(r.pz[e2], srcl, WAVE);
+                    const float tvx = __shfl(r.vx[e2], srcl, WAVE), tvy = __shfl(r.vy[e2], srcl, WAVE);
+                    if (pick) { cpx = tx; cpy = ty; cpz = tz; cvx = tvx; cvy = tvy; }
+                }
+                if ((taken[e] >> l) & 1ull) {
+                    s.px[idx] = cpx; s.py[idx] = cpy; s.pz[idx] = cpz; s.vx[idx] = cvx; s.vy[idx] = cvy;
+                    if (s.vz0) s.vz0[idx] = s.vz0[(size_t)lv * d.slots + so];
+                    s.w[idx] = w_after;
+                }
+            }
+            newmask[e] = kept_m[e] | taken[e];
+        }
+    }
+    int live_out = 0;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
-        const size_t idx = (size_t)lv * d.slots + e * 64 + l;
-        if ((kept_m[e] >> l) & 1ull) {
-            float wn = w_after;
-            for (int f = 0; f < fold[e]; ++f) wn += w_after;
-            s.w[idx] = wn;
+        live_out += (int)__popcll(newmask[e]);
+        if (l == 0) {
+            s.mask[(size_t)lv * EPL + e] = newmask[e];
+            if (r.nb[e]) s.nbmask[(size_t)lv * EPL + e] = 0ull;  // newborn flag -> 1 (:968)
         }
-        if ((taken[e] >> l) & 1ull) {
-            const size_t sidx = (size_t)lv * d.slots + src_of[e];
-            s.px[idx] = s.px[sidx]; s.py[idx] = s.py[sidx]; s.pz[idx] = s.pz[sidx];
-            s.vx[idx] = s.vx[sidx]; s.vy[idx] = s.vy[sidx];
-            if (s.vz0) s.vz0[idx] = s.vz0[sidx];
-            s.w[idx] = w_after;
-        }
-        newmask[e] = kept_m[e] | taken[e];
     }
+    return live_out;
 }
 
 template <int EPL>
-__global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __restrict__ part_live) {
-    const int l = lane_id();
-    const int wave = threadIdx.x >> 6;
-    const int lv_base = (blockIdx.x * 4 + wave) * WAVE;
-    const int my_lv = lv_base + l;
-    u64 mym[EPL], mynb[EPL];
-    bool nonempty = false;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-        mym[e] = 0; mynb[e] = 0;
-        if (my_lv < d.v_loc) {
-            mynb[e] = s.nbmask[(size_t)my_lv * EPL + e];
-            mym[e] = s.mask[(size_t)my_lv * EPL + e] | mynb[e];  // newborns live only in nbmask until now
-        }
-        nonempty |= mym[e] != 0;
-    }
-    float4 myres = make_float4(0.f, 0.f, 0.f, 0.f);
-    u64 todo = __ballot(nonempty);
+__global__ void __launch_bounds__(256) k_resample_work(MapDims d, DevState s, const int* __restrict__ work_list,
+                                                       const int* __restrict__ work_count, int* __restrict__ part_live) {
+    const int wpb = blockDim.x >> 6;
+    const int wave = blockIdx.x * wpb + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * wpb;
+    const int count = *work_count;
     int live_out = 0;
-    while (todo) {
-        const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-        todo &= todo - 1;
-        u64 m[EPL], nb[EPL], nm[EPL];
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            m[e] = __shfl(mym[e], j, WAVE);
-            nb[e] = __shfl(mynb[e], j, WAVE);
-        }
-        float4 r;
-        resample_voxel<EPL>(d, s, lv_base + j, m, nb, r, nm);
-        if (l == j) {
-            myres = r;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) mym[e] = nm[e];
-        }
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) live_out += (int)__popcll(nm[e]);
+    int i = wave;
+    VoxRegs<EPL> cur, nxt;
+    if (i < count) load_voxel<EPL>(d, s, __builtin_amdgcn_readfirstlane(work_list[i]), cur);
+    while (i < count) {
+        const int inext = i + nwaves;
+        if (inext < count) load_voxel<EPL>(d, s, __builtin_amdgcn_readfirstlane(work_list[inext]), nxt);
+        live_out += resample_voxel<EPL>(d, s, cur);
+        cur = nxt;
+        i = inext;
     }
-    if (my_lv < d.v_loc) {
-        s.res4[my_lv] = myres;  // voxels_objects_number[v][0..3] :974-984 (zero for empty voxels)
-        if (nonempty) {
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                s.mask[(size_t)my_lv * EPL + e] = mym[e];
-                if (mynb[e]) s.nbmask[(size_t)my_lv * EPL + e] = 0ull;  // newborn flag -> 1 (:968)
-            }
-        }
-    }
-    if (l == 0) part_live[blockIdx.x * 4 + wave] = live_out;
+    if (lane_id() == 0) part_live[wave] = live_out;
 }
 
 // --------------------------------------------------------------------------
@@ -1227,11 +1285,13 @@ void launch_birth_split(const LaunchCtx& c, int n_birth) {
 }
 void launch_birth_plan_insert(const LaunchCtx& c, int n_birth) {
     if (n_birth <= 0) return;
-    hipLaunchKernelGGL(k_birth_plan, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp, n_birth);
     const long long total = (long long)n_birth * c.fp.nb_num;
+    const unsigned gb = (unsigned)((total + 255) / 256);
     (void)hipMemsetAsync(c.k.vb_cnt, 0, sizeof(int) * (size_t)c.d.v_loc, c.stream);
-    hipLaunchKernelGGL(k_birth_bucket, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, c.d, c.s, c.fp, n_birth, c.k.vb_cnt, c.k.vb_idx);
-    hipLaunchKernelGGL(k_birth_insert, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, c.d, c.s, c.fp, n_birth, c.k.vb_cnt, c.k.vb_idx);
+    hipLaunchKernelGGL(k_birth_rank, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp, n_birth);
+    hipLaunchKernelGGL(k_birth_children, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, n_birth, c.k.child, c.k.vb_cnt, c.k.vb_idx);
+    hipLaunchKernelGGL(k_birth_cursors, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp, n_birth);
+    hipLaunchKernelGGL(k_birth_insert, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, n_birth, c.k.child, c.k.vb_cnt, c.k.vb_idx);
 }
 void launch_birth(const LaunchCtx& c, int n_birth, bool) {
     launch_birth_split(c, n_birth);
@@ -1240,9 +1300,11 @@ void launch_birth(const LaunchCtx& c, int n_birth, bool) {
 
 void launch_resample(const LaunchCtx& c) {
     const KernelScratch* k = &c.k;
-    const int nblk = k->nblk_resample;
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_resample<1>, dim3(nblk), dim3(256), 0, c.stream, c.d, c.s, k->part_resample);
-    else hipLaunchKernelGGL(k_resample<2>, dim3(nblk), dim3(256), 0, c.stream, c.d, c.s, k->part_resample);
+    (void)hipMemsetAsync(k->work_count, 0, sizeof(int), c.stream);
+    hipLaunchKernelGGL(k_resample_scan, dim3((c.d.v_loc + 1023) / 1024), dim3(1024), 0, c.stream, c.d, c.s, k->work_list, k->work_count);
+    const int nblk = k->nblk_resample;  // persistent: nblk*4 waves stride over the work list
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_resample_work<1>, dim3(nblk), dim3(256), 0, c.stream, c.d, c.s, k->work_list, k->work_count, k->part_resample);
+    else hipLaunchKernelGGL(k_resample_work<2>, dim3(nblk), dim3(256), 0, c.stream, c.d, c.s, k->work_list, k->work_count, k->part_resample);
 }
 
 void launch_occupied_compact(const LaunchCtx& c, float thr) {

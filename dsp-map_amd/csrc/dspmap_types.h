@@ -128,6 +128,6 @@ struct BirthPlan {
     float cx, cy, cz;   // source point in the sensor-centred frame :818-820
     int gvox;           // global voxel of the source point, -1 = outside map / invalid
     int n_static;       // :862-866
-    unsigned inside;    // bit k: child k landed inside the map :875
+    unsigned inside;    // bit k: child k landed inside the map :875 (set with atomicOr)
     int pbase, vbase, rbase; // table cursors of this point's first draw
 };
