@@ -185,7 +185,7 @@ extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
 static void free_dev(dspmap* m) {
     if (!m->device_ready) return;
     DevState& s = m->s;
-    void* ptrs[] = {s.mask, s.nbmask, s.px, s.py, s.pz, s.vx, s.vy, s.w, s.vz0, s.res4, s.fut, s.obs, s.obs_ck,
+    void* ptrs[] = {s.fut_stat, s.mask, s.nbmask, s.px, s.py, s.pz, s.vx, s.vy, s.w, s.vz0, s.res4, s.fut, s.obs, s.obs_ck,
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.nstatic, s.fov_rec, s.fov_slot, s.pyr_cnt, s.mv_rec, s.exp_up, s.exp_down,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mvmask, m->k.expmask,
@@ -286,12 +286,17 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, hipEventCreate(&m->ev1));
     const MapDims& d = m->d;
     DevState& s = m->s;
-    const size_t S = (size_t)d.v_loc * d.slots, W = (size_t)d.v_loc * d.mw;
+    const size_t ntiles = ((size_t)d.v_loc + 63) / 64;
+    const size_t S = ntiles * 64 * d.slots, W = (size_t)d.v_loc * d.mw;
     HIPCHK(m, dalloc(&s.mask, W)); HIPCHK(m, dalloc(&s.nbmask, W));
     HIPCHK(m, dalloc(&s.px, S)); HIPCHK(m, dalloc(&s.py, S)); HIPCHK(m, dalloc(&s.pz, S));
     HIPCHK(m, dalloc(&s.vx, S)); HIPCHK(m, dalloc(&s.vy, S)); HIPCHK(m, dalloc(&s.w, S));
     HIPCHK(m, dalloc(&s.res4, (size_t)d.v_loc));
     HIPCHK(m, dalloc(&s.fut, (size_t)d.v_loc * (d.T ? d.T : 1)));
+    HIPCHK(m, dalloc(&s.fut_stat, (size_t)d.v_loc));
+    HIPCHK(m, hipMemset(s.fut_stat, 0, sizeof(float) * (size_t)d.v_loc));
+    HIPCHK(m, hipMemset(s.px, 0, sizeof(float) * S)); HIPCHK(m, hipMemset(s.py, 0, sizeof(float) * S)); HIPCHK(m, hipMemset(s.pz, 0, sizeof(float) * S));
+    HIPCHK(m, hipMemset(s.vx, 0, sizeof(float) * S)); HIPCHK(m, hipMemset(s.vy, 0, sizeof(float) * S)); HIPCHK(m, hipMemset(s.w, 0, sizeof(float) * S));
     HIPCHK(m, dalloc(&s.obs, (size_t)d.np * DSP_OBS_CAP));
     HIPCHK(m, dalloc(&s.obs_ck, (size_t)d.np * DSP_OBS_CAP));
     HIPCHK(m, dalloc(&s.obs_cnt, (size_t)d.np));
@@ -303,15 +308,15 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&s.pyr_cnt, (size_t)d.np));
     HIPCHK(m, dalloc(&s.fs, (size_t)1));
     KernelScratch& k = m->k;
-    k.tpb_sweep = sweep_geometry(d.slots, &k.vpw_sweep);
-    k.nblk_sweep = (d.v_loc + k.vpw_sweep - 1) / k.vpw_sweep;
+    k.ntiles = (int)ntiles;
+    k.nblk_sweep = (int)((ntiles + 3) / 4);  // k_resample: 4 tiles (waves) per 256-thread block
     k.nblk_resample = (d.v_loc + 255) / 256 < 2048 ? (d.v_loc + 255) / 256 : 2048;  // persistent waves (4 per block)
     HIPCHK(m, dalloc(&k.mvmask, W));
     const bool slab = !(d.z_lo == 0 && d.z_hi == d.nz);
     if (slab) HIPCHK(m, dalloc(&k.expmask, W));
-    HIPCHK(m, dalloc(&k.part_predict, (size_t)k.nblk_sweep * 4));
-    HIPCHK(m, dalloc(&k.part_claim, (size_t)k.nblk_sweep * 2));
-    HIPCHK(m, dalloc(&k.part_resample, (size_t)k.nblk_resample * 4));
+    HIPCHK(m, dalloc(&k.part_predict, (size_t)k.ntiles * 4));
+    HIPCHK(m, dalloc(&k.part_claim, (size_t)k.ntiles * 2));
+    HIPCHK(m, dalloc(&k.part_resample, (size_t)k.nblk_sweep * 4));
     HIPCHK(m, dalloc(&k.work_list, (size_t)d.v_loc));
     HIPCHK(m, dalloc(&k.work_count, (size_t)1));
     HIPCHK(m, dalloc(&k.vb_cnt, (size_t)d.v_loc));
@@ -326,9 +331,9 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, hipMemset(s.obs_cnt, 0, sizeof(int) * d.np));
     HIPCHK(m, hipMemset(s.obs_ck, 0, sizeof(float) * d.np * DSP_OBS_CAP));
     HIPCHK(m, hipMemset(s.pyr_cnt, 0, sizeof(int) * d.np));
-    HIPCHK(m, hipMemset(k.part_predict, 0, sizeof(int) * (size_t)k.nblk_sweep * 4));
-    HIPCHK(m, hipMemset(k.part_claim, 0, sizeof(int) * (size_t)k.nblk_sweep * 2));
-    HIPCHK(m, hipMemset(k.part_resample, 0, sizeof(int) * (size_t)k.nblk_resample * 4));
+    HIPCHK(m, hipMemset(k.part_predict, 0, sizeof(int) * (size_t)k.ntiles * 4));
+    HIPCHK(m, hipMemset(k.part_claim, 0, sizeof(int) * (size_t)k.ntiles * 2));
+    HIPCHK(m, hipMemset(k.part_resample, 0, sizeof(int) * (size_t)k.nblk_sweep * 4));
     {   // boundary-plane normals, sensor frame (:563-578; float sin/cos like the C++ overloads)
         std::vector<float> h((size_t)(d.np_h + 1) * 3), v((size_t)(d.np_v + 1) * 3);
         const float pi_f = 3.14159265358979323846f;
@@ -708,6 +713,7 @@ static int readout(dspmap* m, float thr, float* xyz, int cap, int* n_out, float*
         const int ncopy = n < cap ? n : cap;
         if (xyz && ncopy > 0) HIPCHK(m, hipMemcpyAsync(xyz, m->s.occ_xyz, sizeof(float) * 3 * (size_t)ncopy, hipMemcpyDeviceToHost, m->stream));
     }
+    if (fut_out && d.T > 0) launch_future_combine(c);
     if (fut_out && d.T > 0)
         HIPCHK(m, hipMemcpyAsync(fut_out, m->s.fut, sizeof(float) * (size_t)d.v_loc * d.T, hipMemcpyDeviceToHost, m->stream));
     launch_clear_future(c);  // :397-400, :420-424
@@ -735,7 +741,12 @@ extern "C" int dspmap_get_results(dspmap_t* m, float* out) {
     return DSPMAP_OK;
 }
 extern "C" const float* dspmap_results_device(dspmap_t* m) { return (m && m->device_ready) ? (const float*)m->s.res4 : nullptr; }
-extern "C" const float* dspmap_future_device(dspmap_t* m) { return (m && m->device_ready) ? m->s.fut : nullptr; }
+extern "C" const float* dspmap_future_device(dspmap_t* m) {
+    if (!m || !m->device_ready) return nullptr;
+    LaunchCtx c = ctx_of(m);
+    launch_future_combine(c);  // static-particle mass is kept per voxel and folded in on demand
+    return m->s.fut;
+}
 
 extern "C" void dspmap_voxel_center(const dspmap_t* m, int index, float* px, float* py, float* pz) {  // :1556-1572
     const MapDims& d = m->d;
@@ -784,7 +795,7 @@ extern "C" int dspmap_get_counters(dspmap_t* m, dspmap_counters* out) {
 // ------------------------------------------------------------ state access
 static int ensure_vz(dspmap* m) {
     if (!m->s.vz0) {
-        const size_t S = (size_t)m->d.v_loc * m->d.slots;
+        const size_t S = (((size_t)m->d.v_loc + 63) / 64) * 64 * m->d.slots;
         HIPCHK(m, dalloc(&m->s.vz0, S));
         HIPCHK(m, hipMemset(m->s.vz0, 0, sizeof(float) * S));
     }
@@ -801,6 +812,7 @@ extern "C" int dspmap_clear_state(dspmap_t* m) {
     HIPCHK(m, hipMemsetAsync(m->k.mvmask, 0, sizeof(u64) * W, m->stream));
     HIPCHK(m, hipMemsetAsync(m->s.res4, 0, sizeof(float4) * (size_t)d.v_loc, m->stream));
     HIPCHK(m, hipMemsetAsync(m->s.fut, 0, sizeof(float) * (size_t)d.v_loc * (d.T ? d.T : 1), m->stream));
+    HIPCHK(m, hipMemsetAsync(m->s.fut_stat, 0, sizeof(float) * (size_t)d.v_loc, m->stream));
     HIPCHK(m, hipMemsetAsync(m->s.pyr_cnt, 0, sizeof(int) * d.np, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     m->have_last = false;

@@ -172,6 +172,11 @@ __device__ __forceinline__ float pair_gk(float px, float py, float pz, float ox,
     return c3 * __expf(-0.5f * s);
 }
 
+// particle storage index: tiles of 64 voxels, slot-major inside a tile (see dspmap_sweep.hip)
+__device__ __forceinline__ size_t pidx(const MapDims& d, int lv, int slot) {
+    return ((size_t)(lv >> 6) * d.slots + slot) * 64 + (lv & 63);
+}
+
 // claim the lowest free slot of a voxel: first-free-slot rule of addAParticle /
 // moveParticle (:1184-1185,1214-1215) as one atomic OR per attempt.
 // Returns the slot or -1 if the voxel is full.

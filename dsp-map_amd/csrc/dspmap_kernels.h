@@ -7,16 +7,16 @@
 struct KernelScratch {
     u64* mvmask;        // [v_loc*mw] particles that must change voxel (set by k_predict, consumed by k_claim)
     u64* expmask;       // [v_loc*mw] particles that left the slab (multi-GPU), or nullptr
-    int* part_predict;  // [nblk_sweep*4]
-    int* part_claim;    // [nblk_sweep*2]
+    int* part_predict;  // [ntiles*4]
+    int* part_claim;    // [ntiles*2]
     int* part_resample; // [nblk_resample*4]
     int* vb_cnt;        // [v_loc] children per destination voxel this frame (birth ordering)
     int* vb_idx;        // [v_loc*128] their birth indices
     float4* child;      // [birth_cap*32] child position + destination voxel of this frame's births
     int* work_list;     // [v_loc] non-empty voxels of this frame (resample work list)
     int* work_count;    // [1]
+    int ntiles;         // tiles of 64 voxels; k_predict / k_claim run one workgroup per tile
     int nblk_sweep, nblk_resample;
-    int tpb_sweep, vpw_sweep;
 };
 
 struct LaunchCtx {
@@ -27,7 +27,6 @@ struct LaunchCtx {
     hipStream_t stream;
     int pt_cap, birth_cap;
 };
-int sweep_geometry(int slots, int* vpw_out);  // threads per block for the lane-per-slot sweeps
 
 // frame setup: rotate boundary planes (:226-232), reset per-frame counters/bins (:235-238)
 void launch_frame_setup(const LaunchCtx& c, const float quat[4], const float cur_pos[3], bool reset_obs);
@@ -51,6 +50,7 @@ void launch_resample(const LaunchCtx& c);
 // readout (:385-438)
 void launch_occupied_compact(const LaunchCtx& c, float thr);
 void launch_clear_future(const LaunchCtx& c);
+void launch_future_combine(const LaunchCtx& c);  // fold the static-particle future mass into the [V][T] grid
 // state helpers
 void launch_seed_uniform(const LaunchCtx& c, int per_voxel, float weight, unsigned seed);
 void launch_import(const LaunchCtx& c, int n, const int* voxel_dev, const int* slot_dev, const float* rec8_dev, int* n_failed_dev);

@@ -1,0 +1,729 @@
+// dspmap_sweep.hip -- the three HBM-streaming sweeps over the particle store
+// (prediction, mover re-binning, occupancy/rollout/resampling) + state helpers.
+//
+// Layout: voxels are grouped in TILES of 64; inside a tile the
+// particle fields are stored slot-major, index = ((lv>>6)*SLOTS + slot)*64 + (lv&63).
+// ONE LANE OWNS ONE VOXEL, one wave owns one tile, and the wave walks the slot
+// rows that are live anywhere in the tile:
+//   * every row access is one fully coalesced 256-byte wave transaction;
+//   * slots fill from the bottom (first-free-slot rule), so rows above the
+//     tile's occupancy are never touched: HBM traffic follows the LIVE particle
+//     count, not the 2x capacity the reference's dense sweeps pay for
+//     (include/dsp_dynamic.h:645-647,929-938);
+//   * all per-voxel reductions (mass, mean velocity, resampling thresholds) are
+//     sequential per lane in slot order -- the reference's own operation order
+//     (:938-1053), so sums, thresholds and copy placement match it bit for bit,
+//     and at saturation every lane is busy (a wave-per-voxel mapping keeps 24 of
+//     64 lanes busy at 24 particles/voxel).
+#include <hip/hip_runtime.h>
+#include "dspmap_device.h"
+#include "dspmap_kernels.h"
+
+// OR of a 64-bit value over the wave (DPP network, both halves)
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ u64 wave_or_u64(u64 v) {
+    return ((u64)wave_or_u32((unsigned)(v >> 32)) << 32) | (u64)wave_or_u32((unsigned)v);
+}
+__device__ __forceinline__ u64 valid_bits(const MapDims& d, int e) {
+    const int nbits = min(64, d.slots - e * 64);
+    return nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
+}
+
+// rows of a tile are processed in batches of RB: all loads of a batch are issued before any is
+// consumed, so a wave pays one memory round trip per batch instead of one per row
+#define RB 4
+
+// Deferred wave-aggregated append of up to RB items per lane into per-pyramid lists
+// (pyramids_in_fov registration, :1245-1254): one global atomic per DISTINCT pyramid of the
+// batch, all atomics in flight together, return values collected afterwards.
+// key[r] < 0 = no item.  pos[r] receives the list position.
+__device__ __forceinline__ void batch_append(int* cnt, const int (&key)[RB], int (&pos)[RB]) {
+    const int l = lane_id();
+    u64 todo[RB];
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) { todo[r] = __ballot(key[r] >= 0); any |= todo[r] != 0ull; pos[r] = -1; }
+    while (any) {
+        int nkeys = 0, mykey = -1, mybase = 0;
+        while (any && nkeys < 64) {
+            int k = -1;
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                if (k < 0 && todo[r]) k = __builtin_amdgcn_readlane(key[r], __ffsll((long long)todo[r]) - 1);
+            int c = 0;
+            any = false;
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const u64 g = __ballot(key[r] == k);
+                c += (int)__popcll(g);
+                todo[r] &= ~g;
+                any |= todo[r] != 0ull;
+            }
+            if (l == nkeys) { mykey = k; mybase = atomicAdd(&cnt[k], c); }
+            ++nkeys;
+        }
+        for (int j = 0; j < nkeys; ++j) {
+            const int k = __builtin_amdgcn_readlane(mykey, j);
+            int run = __builtin_amdgcn_readlane(mybase, j);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const u64 g = __ballot(key[r] == k);
+                if (key[r] == k) pos[r] = run + (int)__popcll(g & lanemask_lt());
+                run += (int)__popcll(g);
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------
+// k_predict: mapPrediction :645-694.
+//   constant-velocity advance + ego-motion shift (:665-667), vz := 0 (:661-663),
+//   out-of-map removal (:688); particles that stay in their voxel are registered
+//   in their pyramid (:1233-1259); particles whose voxel changed are only MARKED
+//   (mvmask) -- k_claim moves them, so every particle is advanced exactly once
+//   (the role of flag 7, :649,1219).
+// part[blockIdx*4 + {0,1,2,3}] = {live in, left the map, pyramid full, moved}
+// --------------------------------------------------------------------------
+// every 4th live row of the tile, starting at `wave` (the 4 waves of a workgroup share one tile)
+__device__ __forceinline__ u64 rows_of_wave(u64 tor, int wave) {
+    u64 mine = 0ull;
+    int k = 0;
+    while (tor) {
+        const u64 low = tor & (~tor + 1ull);
+        if ((k & 3) == wave) mine |= low;
+        tor ^= low;
+        ++k;
+    }
+    return mine;
+}
+
+template <int MW>
+__global__ void __launch_bounds__(256) k_predict(MapDims d, DevState s, FilterParams fp, float odx, float ody, float odz,
+                                                 float dt, int has_vz, int* __restrict__ part,
+                                                 u64* __restrict__ mvmask, u64* __restrict__ expmask) {
+    __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
+    __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
+    __shared__ u64 s_keep[MW * 64], s_mv[MW * 64], s_ex[MW * 64];
+    __shared__ int s_cnt[4];
+    __shared__ int s_any;
+    const int tid = threadIdx.x;
+    const int l = lane_id();
+    const int wave = tid >> 6;
+    const int lv = blockIdx.x * 64 + l;   // all four waves of the block look at the same tile
+    const bool inr = lv < d.v_loc;
+    const int lvs = inr ? lv : 0;
+    u64 mword[MW], live[MW];
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < MW; ++e) {
+        mword[e] = 0ull; u64 nbword = 0ull;
+        if (inr) { mword[e] = s.mask[(size_t)lv * MW + e]; nbword = s.nbmask[(size_t)lv * MW + e]; }
+        live[e] = mword[e] & ~nbword;  // particles born/seeded this frame (flag 15) are not predicted (:649)
+        any |= live[e] != 0ull;
+        if (wave == 0) { s_keep[e * 64 + l] = live[e]; s_mv[e * 64 + l] = 0ull; s_ex[e * 64 + l] = 0ull; }
+    }
+    if (tid == 0) s_any = 0;
+    if (tid < 4) s_cnt[tid] = 0;
+    __syncthreads();
+    if (wave == 0 && __ballot(any) && l == 0) s_any = 1;
+    __syncthreads();
+    if (!s_any) {  // empty tile
+        if (tid < 4) part[blockIdx.x * 4 + tid] = 0;
+        return;
+    }
+    for (int i = tid; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
+    for (int i = tid; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
+    __syncthreads();
+    int c_live = 0, c_out = 0, c_pf = 0, c_mv = 0;
+#pragma unroll
+    for (int e = 0; e < MW; ++e) {
+        u64 keep_clr = 0ull, mv = 0ull, ex = 0ull;
+        u64 tor = rows_of_wave(wave_or_u64(live[e]), wave);
+        while (tor) {
+            int row[RB];
+            float vx[RB], vy[RB], px[RB], py[RB], pz[RB], w[RB];
+            bool act[RB];
+            size_t idx[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {  // issue every load of the batch
+                row[r] = tor ? __ffsll((long long)tor) - 1 : -1;
+                if (tor) tor &= tor - 1ull;
+                act[r] = row[r] >= 0 && ((live[e] >> (row[r] & 63)) & 1ull);
+                idx[r] = pidx(d, lvs, e * 64 + (row[r] < 0 ? 0 : row[r]));
+                vx[r] = vy[r] = px[r] = py[r] = pz[r] = w[r] = 0.f;
+                if (act[r]) {
+                    vx[r] = s.vx[idx[r]]; vy[r] = s.vy[idx[r]];
+                    px[r] = s.px[idx[r]]; py[r] = s.py[idx[r]]; pz[r] = s.pz[idx[r]];
+                    w[r] = s.w[idx[r]];
+                }
+            }
+            int pyr[RB], pos[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                pyr[r] = -1;
+                if (act[r]) {
+                    const u64 bit = 1ull << row[r];
+                    if (has_vz) {
+                        // velocity process noise only when |vx*vy*vz| >= 1e-6 (:653-659): reachable only for
+                        // constructor-seeded particles on their first step
+                        const float vz = s.vz0[idx[r]];
+                        if (!(fabs((double)(vx[r] * vy[r] * vz)) < 1e-6)) {
+                            const int c = (int)(((long long)s.fs->v_cur + 3ll * (long long)((size_t)(lv + d.v_base) * d.slots + e * 64 + row[r])) % fp.tab_n);
+                            vx[r] += s.v_tab[c];
+                            vy[r] += s.v_tab[(c + 1) % fp.tab_n];
+                            s.vx[idx[r]] = vx[r]; s.vy[idx[r]] = vy[r];
+                        }
+                        s.vz0[idx[r]] = 0.f;
+                    }
+                    px[r] += dt * vx[r] + odx;   // :665
+                    py[r] += dt * vy[r] + ody;   // :666
+                    pz[r] += dt * 0.f + odz;     // :667 with vz forced to 0 (:662)
+                    int gv;
+                    ++c_live;
+                    if (!voxel_of(d, px[r], py[r], pz[r], gv)) {
+                        keep_clr |= bit;         // left the map :688
+                        ++c_out;
+                    } else {
+                        s.px[idx[r]] = px[r]; s.py[idx[r]] = py[r]; s.pz[idx[r]] = pz[r];
+                        const int nlv = gv - d.v_base;
+                        if (nlv == lv) pyr[r] = pyramid_of(d, s_ph, s_pv, px[r], py[r], pz[r]);
+                        else if (nlv < 0 || nlv >= d.v_loc) ex |= bit;   // left the slab (multi-GPU)
+                        else { mv |= bit; ++c_mv; }
+                    }
+                }
+            }
+            // pyramid registration of particles that stay in their voxel
+            batch_append(s.pyr_cnt, pyr, pos);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                if (pyr[r] >= 0) {
+                    if (pos[r] < d.capp) {
+                        const size_t o = (size_t)pyr[r] * d.capp + pos[r];
+                        s.fov_rec[o] = make_float4(px[r], py[r], pz[r], w[r]);
+                        s.fov_slot[o] = (int)idx[r];
+                    } else {
+                        keep_clr |= 1ull << row[r];  // pyramid list full: the particle vanishes (-2, :1256-1259)
+                        ++c_pf;
+                    }
+                }
+            }
+        }
+        if (keep_clr) atomicAnd(&s_keep[e * 64 + l], ~keep_clr);
+        if (mv) atomicOr(&s_mv[e * 64 + l], mv);
+        if (ex) atomicOr(&s_ex[e * 64 + l], ex);
+    }
+    // per-block statistics (reduced lazily by the host; no global atomics here)
+    c_live = wave_sum_i(c_live); c_out = wave_sum_i(c_out); c_pf = wave_sum_i(c_pf); c_mv = wave_sum_i(c_mv);
+    if (l == 0) {
+        if (c_live) atomicAdd(&s_cnt[0], c_live);
+        if (c_out) atomicAdd(&s_cnt[1], c_out);
+        if (c_pf) atomicAdd(&s_cnt[2], c_pf);
+        if (c_mv) atomicAdd(&s_cnt[3], c_mv);
+    }
+    __syncthreads();
+    if (wave == 0 && inr) {
+#pragma unroll
+        for (int e = 0; e < MW; ++e) {
+            // movers / exports keep their live bit until k_claim / the export pass has copied them out
+            const u64 nm = s_keep[e * 64 + l] | (mword[e] & ~live[e]);
+            if (nm != mword[e]) s.mask[(size_t)lv * MW + e] = nm;
+            if (s_mv[e * 64 + l]) mvmask[(size_t)lv * MW + e] = s_mv[e * 64 + l];
+            if (expmask && s_ex[e * 64 + l]) expmask[(size_t)lv * MW + e] = s_ex[e * 64 + l];
+        }
+    }
+    if (tid < 4) part[blockIdx.x * 4 + tid] = s_cnt[tid];
+}
+
+// --------------------------------------------------------------------------
+// k_claim: the voxel-changing half of moveParticle (:1209-1230) for the
+// particles k_predict marked.  A mover claims the lowest free slot of its
+// destination voxel with one atomic OR (first-free-slot rule :1214-1215), copies
+// its record, registers in its pyramid (:1233-1259); the source slots of a voxel
+// are released together once all its movers have been read.  Destination full ->
+// the particle vanishes (-1, :1227-1229).
+// part2[blockIdx*2 + {0,1}] = {voxel full, pyramid full}
+// --------------------------------------------------------------------------
+template <int MW>
+__global__ void __launch_bounds__(256) k_claim(MapDims d, DevState s, u64* __restrict__ mvmask, int* __restrict__ part2) {
+    __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
+    __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
+    __shared__ int s_cnt[2];
+    __shared__ int s_any;
+    const int tid = threadIdx.x;
+    const int l = lane_id();
+    const int wave = tid >> 6;
+    const int lv = blockIdx.x * 64 + l;   // the four waves of the block share one tile
+    const bool inr = lv < d.v_loc;
+    const int lvs = inr ? lv : 0;
+    u64 mvw[MW];
+    bool any = false;
+    if (tid == 0) s_any = 0;
+    if (tid < 2) s_cnt[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < MW; ++e) {
+        mvw[e] = inr ? mvmask[(size_t)lv * MW + e] : 0ull;
+        any |= mvw[e] != 0ull;
+    }
+    if (wave == 0 && __ballot(any) && l == 0) s_any = 1;
+    __syncthreads();
+    if (!s_any) {
+        if (tid < 2) part2[blockIdx.x * 2 + tid] = 0;
+        return;
+    }
+    for (int i = tid; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
+    for (int i = tid; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
+    __syncthreads();
+    int c_vf = 0, c_pf = 0;
+#pragma unroll
+    for (int e = 0; e < MW; ++e) {
+        u64 tor = rows_of_wave(wave_or_u64(mvw[e]), wave);
+        u64 mine = 0ull;  // source slots handled (and to be released) by this wave
+        while (tor) {
+            int row[RB];
+            float vx[RB], vy[RB], px[RB], py[RB], pz[RB], w[RB];
+            bool act[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                row[r] = tor ? __ffsll((long long)tor) - 1 : -1;
+                if (tor) tor &= tor - 1ull;
+                act[r] = row[r] >= 0 && ((mvw[e] >> (row[r] & 63)) & 1ull);
+                vx[r] = vy[r] = px[r] = py[r] = pz[r] = w[r] = 0.f;
+                if (act[r]) {
+                    const size_t idx = pidx(d, lvs, e * 64 + row[r]);
+                    vx[r] = s.vx[idx]; vy[r] = s.vy[idx];
+                    px[r] = s.px[idx]; py[r] = s.py[idx]; pz[r] = s.pz[idx];
+                    w[r] = s.w[idx];
+                    mine |= 1ull << row[r];
+                }
+            }
+            int pyr[RB], pos[RB], nlv[RB], nsl[RB];
+            size_t nidx[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                pyr[r] = -1; nlv[r] = -1; nsl[r] = -1; nidx[r] = 0;
+                if (act[r]) {
+                    int gv = 0;
+                    voxel_of(d, px[r], py[r], pz[r], gv);  // in-map and in-slab by construction (k_predict)
+                    nlv[r] = gv - d.v_base;
+                    nsl[r] = claim_slot(s.mask, nlv[r], d);
+                    if (nsl[r] >= 0) {
+                        nidx[r] = pidx(d, nlv[r], nsl[r]);
+                        s.px[nidx[r]] = px[r]; s.py[nidx[r]] = py[r]; s.pz[nidx[r]] = pz[r];
+                        s.vx[nidx[r]] = vx[r]; s.vy[nidx[r]] = vy[r]; s.w[nidx[r]] = w[r];
+                        pyr[r] = pyramid_of(d, s_ph, s_pv, px[r], py[r], pz[r]);
+                    } else {
+                        ++c_vf;
+                    }
+                }
+            }
+            batch_append(s.pyr_cnt, pyr, pos);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                if (pyr[r] >= 0) {
+                    if (pos[r] < d.capp) {
+                        const size_t o = (size_t)pyr[r] * d.capp + pos[r];
+                        s.fov_rec[o] = make_float4(px[r], py[r], pz[r], w[r]);
+                        s.fov_slot[o] = (int)nidx[r];
+                    } else {
+                        ++c_pf;  // :1256-1259
+                        atomicAnd(&s.mask[(size_t)nlv[r] * MW + (nsl[r] >> 6)], ~(1ull << (nsl[r] & 63)));
+                    }
+                }
+            }
+        }
+        if (mine) {
+            // every record of these movers is in registers / on its way to the new slot: release the
+            // source slots.  The wait makes sure the loads above have returned before another mover
+            // can see a slot free and overwrite it.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            atomicAnd(&s.mask[(size_t)lv * MW + e], ~mine);
+            atomicAnd(&mvmask[(size_t)lv * MW + e], ~mine);
+        }
+    }
+    c_vf = wave_sum_i(c_vf); c_pf = wave_sum_i(c_pf);
+    if (l == 0) {
+        if (c_vf) atomicAdd(&s_cnt[0], c_vf);
+        if (c_pf) atomicAdd(&s_cnt[1], c_pf);
+    }
+    __syncthreads();
+    if (tid < 2) part2[blockIdx.x * 2 + tid] = s_cnt[tid];
+}
+
+// --------------------------------------------------------------------------
+// k_resample: mapOccupancyCalculationAndResample :924-1057, one lane per voxel.
+// pass 1 (rows in slot order): cull w < 1e-3 (:941), mass (:970-974), mean velocity of
+//   the non-newborn survivors (:944-948,976-984), constant-velocity future rollout
+//   (:950-964; static particles stay in their voxel for every horizon and are kept in a
+//   per-voxel accumulator folded in at readout, moving ones scatter with float atomics).
+// pass 2 (voxels with >= 5 survivors): systematic resampling exactly as the reference's
+//   loop (:1005-1053): running sum vs. accumulated thresholds in fp32, copies into the
+//   lowest free slot, "no free slot -> fold the weight back" (:1037-1041).
+// part_live[global wave] = live particles left in the wave's tile
+// --------------------------------------------------------------------------
+#define RBK 8  // rows per batch in k_resample (few registers per row: deeper batches, fewer round trips)
+
+template <int MW>
+__global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __restrict__ part_live) {
+    const int l = lane_id();
+    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lv = wave_g * 64 + l;
+    const bool inr = lv < d.v_loc;
+    const int lvs = inr ? lv : 0;
+    u64 m[MW], nb[MW];
+    bool nonempty = false;
+#pragma unroll
+    for (int e = 0; e < MW; ++e) {
+        m[e] = 0ull; nb[e] = 0ull;
+        if (inr) {
+            nb[e] = s.nbmask[(size_t)lv * MW + e];
+            m[e] = s.mask[(size_t)lv * MW + e] | nb[e];  // newborns live only in nbmask until now
+        }
+        nonempty |= m[e] != 0ull;
+    }
+    if (!__ballot(nonempty)) {  // whole tile empty
+        if (inr) s.res4[lv] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l == 0) part_live[wave_g] = 0;
+        return;
+    }
+    const int T = d.T;
+    const int gz = inr ? (lv + d.v_base) / (d.ny * d.nx) : 0;  // z layer never changes in the rollout (vz == 0)
+    int n = 0, n_old = 0;
+    float wsum = 0.f, vxs = 0.f, vys = 0.f, stat_w = 0.f;
+#pragma unroll
+    for (int e = 0; e < MW; ++e) {
+        u64 tor = wave_or_u64(m[e]);
+        while (tor) {
+            int row[RBK];
+            float w[RBK], vx[RBK], vy[RBK];
+            bool act[RBK];
+#pragma unroll
+            for (int r = 0; r < RBK; ++r) {
+                row[r] = tor ? __ffsll((long long)tor) - 1 : -1;
+                if (tor) tor &= tor - 1ull;
+                act[r] = row[r] >= 0 && ((m[e] >> (row[r] & 63)) & 1ull);
+                w[r] = vx[r] = vy[r] = 0.f;
+                if (act[r]) {
+                    const size_t idx = pidx(d, lvs, e * 64 + row[r]);
+                    w[r] = s.w[idx];
+                    if (!((nb[e] >> row[r]) & 1ull)) { vx[r] = s.vx[idx]; vy[r] = s.vy[idx]; }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RBK; ++r) {
+                if (!act[r]) continue;
+                const u64 bit = 1ull << row[r];
+                if (w[r] < 1e-3f) {               // :941
+                    m[e] &= ~bit;
+                } else {
+                    if (!(nb[e] & bit)) {         // flag < 10 :944
+                        ++n_old;
+                        vxs += vx[r]; vys += vy[r];
+                        if (vx[r] == 0.f && vy[r] == 0.f) {
+                            stat_w += w[r];       // p + 0*t stays in this voxel for every horizon
+                        } else {
+                            const size_t idx = pidx(d, lvs, e * 64 + row[r]);
+                            const float px = s.px[idx], py = s.py[idx];
+                            for (int t = 0; t < T; ++t) {  // :952-963
+                                const float pt = d.pred_t[t];
+                                const float fx = px + vx[r] * pt;
+                                const float fy = py + vy[r] * pt;
+                                if (!(fx >= d.half_x || fx <= -d.half_x || fy >= d.half_y || fy <= -d.half_y)) {
+                                    const int xi = (int)__fdiv_rn(fx + d.half_x, d.res);
+                                    const int yi = (int)__fdiv_rn(fy + d.half_y, d.res);
+                                    const int dl = gz * d.ny * d.nx + yi * d.nx + xi - d.v_base;
+                                    if (dl >= 0 && dl < d.v_loc) unsafeAtomicAdd(&s.fut[(size_t)dl * T + t], w[r]);
+                                }
+                            }
+                        }
+                    }
+                    ++n;
+                    wsum += w[r];                 // :970
+                }
+            }
+        }
+    }
+    if (inr) {
+        float4 res = make_float4(wsum, 0.f, 0.f, 0.f);  // voxels_objects_number[v][0..3] :974-984
+        if (n_old > 0) { res.y = __fdiv_rn(vxs, (float)n_old); res.z = __fdiv_rn(vys, (float)n_old); }
+        s.res4[lv] = res;
+        if (stat_w != 0.f) s.fut_stat[lv] += stat_w;  // only this lane ever writes fut_stat[lv]
+    }
+    // ---- systematic resampling :986-1053
+    const bool resample = n >= 5;
+    if (__ballot(resample)) {
+        const int n_after = n > d.M ? d.M : n;                  // :992-997
+        const float w_after = __fdiv_rn(wsum, (float)n_after);  // :1000
+        float acc_ori = 0.f, acc_new = w_after * 0.5f;          // :1005-1006
+        u64 a0[MW];
+#pragma unroll
+        for (int e = 0; e < MW; ++e) a0[e] = resample ? m[e] : 0ull;  // survivors before any copy (copies are not revisited)
+#pragma unroll
+        for (int e = 0; e < MW; ++e) {
+            u64 tor = wave_or_u64(a0[e]);
+            while (tor) {
+                int row[RBK];
+                float w[RBK];
+#pragma unroll
+                for (int r = 0; r < RBK; ++r) {
+                    row[r] = tor ? __ffsll((long long)tor) - 1 : -1;
+                    if (tor) tor &= tor - 1ull;
+                    w[r] = 0.f;
+                    if (row[r] >= 0 && ((a0[e] >> row[r]) & 1ull)) w[r] = s.w[pidx(d, lvs, e * 64 + row[r])];
+                }
+#pragma unroll
+                for (int r = 0; r < RBK; ++r) {
+                    if (row[r] < 0 || !((a0[e] >> row[r]) & 1ull)) continue;
+                    const u64 bit = 1ull << row[r];
+                    const size_t idx = pidx(d, lvs, e * 64 + row[r]);
+                    acc_ori += w[r];                           // :1011
+                    if (acc_ori > acc_new) {
+                        float wn = w_after;                    // keep, new weight :1014
+                        acc_new += w_after;
+                        bool full = false;
+                        while (acc_ori > acc_new) {            // copy heavy particles :1021
+                            int fslot = -1;
+                            if (!full) {
+#pragma unroll
+                                for (int e2 = 0; e2 < MW; ++e2) {
+                                    const u64 fr = ~m[e2] & valid_bits(d, e2);
+                                    if (fslot < 0 && fr) { fslot = e2 * 64 + (__ffsll((long long)fr) - 1); m[e2] |= fr & (~fr + 1ull); }
+                                }
+                            }
+                            if (fslot >= 0) {
+                                const size_t didx = pidx(d, lvs, fslot);
+                                s.px[didx] = s.px[idx]; s.py[didx] = s.py[idx]; s.pz[didx] = s.pz[idx];
+                                s.vx[didx] = s.vx[idx]; s.vy[didx] = s.vy[idx];
+                                if (s.vz0) s.vz0[didx] = s.vz0[idx];
+                                s.w[didx] = w_after;
+                            } else {
+                                wn += w_after;                 // no free slot: fold the weight back :1037-1041
+                                full = true;
+                            }
+                            acc_new += w_after;
+                        }
+                        s.w[idx] = wn;
+                    } else {
+                        m[e] &= ~bit;                          // remove :1046-1049
+                    }
+                }
+            }
+        }
+    }
+    int live_out = 0;
+    if (inr) {
+#pragma unroll
+        for (int e = 0; e < MW; ++e) {
+            live_out += (int)__popcll(m[e]);
+            s.mask[(size_t)lv * MW + e] = m[e];
+            if (nb[e]) s.nbmask[(size_t)lv * MW + e] = 0ull;  // newborn flag -> 1 (:968)
+        }
+    }
+    live_out = wave_sum_i(live_out);
+    if (l == 0) part_live[wave_g] = live_out;
+}
+
+// --------------------------------------------------------------------------
+// state helpers
+// --------------------------------------------------------------------------
+__device__ __forceinline__ unsigned hash_u32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+// benchmark fill (SURVEY 8d "saturated"): per_voxel zero-velocity particles per voxel,
+// uniform in-voxel positions (kept 2% away from the faces), slots 0..per_voxel-1.
+__global__ void k_seed_uniform(MapDims d, DevState s, int per_voxel, float weight, unsigned seed) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)d.v_loc * d.slots;
+    if (t >= total) return;
+    const int lv = (int)(t / d.slots), sl = (int)(t - (size_t)lv * d.slots);
+    if (sl == 0) {
+        for (int e = 0; e < d.mw; ++e) {
+            const int nbits = max(0, min(64, per_voxel - e * 64));
+            s.mask[(size_t)lv * d.mw + e] = nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
+            s.nbmask[(size_t)lv * d.mw + e] = 0ull;
+        }
+    }
+    if (sl >= per_voxel) return;
+    const int index = lv + d.v_base;
+    const int zc = d.ny * d.nx;
+    const int zi = index / zc, rest = index - zi * zc, yi = rest / d.nx, xi = rest - yi * d.nx;
+    const unsigned h0 = hash_u32(seed ^ hash_u32((unsigned)index * 73u + (unsigned)sl));
+    const unsigned h1 = hash_u32(h0 + 0x9e3779b9U), h2 = hash_u32(h1 + 0x9e3779b9U);
+    const float u0 = 0.02f + 0.96f * (float)(h0 >> 8) * (1.f / 16777216.f);
+    const float u1 = 0.02f + 0.96f * (float)(h1 >> 8) * (1.f / 16777216.f);
+    const float u2 = 0.02f + 0.96f * (float)(h2 >> 8) * (1.f / 16777216.f);
+    const size_t idx = pidx(d, lv, sl);
+    s.px[idx] = ((float)xi + u0) * d.res - d.half_x;
+    s.py[idx] = ((float)yi + u1) * d.res - d.half_y;
+    s.pz[idx] = ((float)zi + u2) * d.res - d.half_z;
+    s.vx[idx] = 0.f; s.vy[idx] = 0.f; s.w[idx] = weight;
+}
+
+// import sparse records {flag,vx,vy,vz,px,py,pz,w} at (global voxel, slot); slot < 0 = first free
+__global__ void k_import(MapDims d, DevState s, int n, const int* __restrict__ voxel, const int* __restrict__ slot,
+                         const float* __restrict__ rec, int* __restrict__ n_failed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int lv = voxel[i] - d.v_base;
+    bool ok = lv >= 0 && lv < d.v_loc;
+    int sl = -1;
+    if (ok) {
+        sl = slot ? slot[i] : -1;
+        if (sl >= d.slots) ok = false;
+        else if (sl < 0) { sl = claim_slot(s.mask, lv, d); ok = sl >= 0; }
+        else {
+            const u64 bit = 1ull << (sl & 63);
+            const u64 prev = atomicOr(&s.mask[(size_t)lv * d.mw + (sl >> 6)], bit);
+            ok = !(prev & bit);
+        }
+    }
+    if (!ok) { atomicAdd(n_failed, 1); return; }
+    const float* r = rec + 8 * (size_t)i;
+    const size_t idx = pidx(d, lv, sl);
+    s.vx[idx] = r[1]; s.vy[idx] = r[2];
+    if (s.vz0) s.vz0[idx] = r[3];
+    s.px[idx] = r[4]; s.py[idx] = r[5]; s.pz[idx] = r[6]; s.w[idx] = r[7];
+    if (r[0] > 10.f) atomicOr(&s.nbmask[(size_t)lv * d.mw + (sl >> 6)], 1ull << (sl & 63));
+}
+
+__global__ void k_export(MapDims d, DevState s, int* __restrict__ voxel, int* __restrict__ slot,
+                         float* __restrict__ rec, int* __restrict__ count, int cap) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)d.v_loc * d.slots;
+    bool live = false;
+    int lv = 0, sl = 0;
+    if (t < total) {
+        lv = (int)(t / d.slots); sl = (int)(t - (size_t)lv * d.slots);
+        live = ((s.mask[(size_t)lv * d.mw + (sl >> 6)] | s.nbmask[(size_t)lv * d.mw + (sl >> 6)]) >> (sl & 63)) & 1ull;
+    }
+    const int pos = wave_agg_inc1(count, live);
+    if (live && pos < cap) {
+        const bool nbf = (s.nbmask[(size_t)lv * d.mw + (sl >> 6)] >> (sl & 63)) & 1ull;
+        const size_t idx = pidx(d, lv, sl);
+        voxel[pos] = lv + d.v_base;
+        slot[pos] = sl;
+        float* r = rec + 8 * (size_t)pos;
+        r[0] = nbf ? 15.f : 1.f;
+        r[1] = s.vx[idx]; r[2] = s.vy[idx]; r[3] = s.vz0 ? s.vz0[idx] : 0.f;
+        r[4] = s.px[idx]; r[5] = s.py[idx]; r[6] = s.pz[idx]; r[7] = s.w[idx];
+    }
+}
+
+// generateRandomFloat :1551-1553 fed from the rand() table
+__device__ __forceinline__ float rand_float_t(const DevState& s, const FilterParams& fp, int c, float lo, float hi) {
+    const int r = s.r_tab[c % max(fp.rtab_n, 1)];
+    return lo + __fdiv_rn((float)r, __fdiv_rn((float)2147483647, (hi - lo)));
+}
+// addRandomParticles :594-624 from the rand() table: 6 draws per particle, newborn flag (addAParticle)
+__global__ void k_add_random(MapDims d, DevState s, FilterParams fp, int n, float weight) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = s.fs->r_cur + 6 * i;
+    const float px = rand_float_t(s, fp, c, -d.half_x, d.half_x);
+    const float py = rand_float_t(s, fp, c + 1, -d.half_y, d.half_y);
+    const float pz = rand_float_t(s, fp, c + 2, -d.half_z, d.half_z);
+    const float vx = rand_float_t(s, fp, c + 3, -1.f, 1.f);
+    const float vy = rand_float_t(s, fp, c + 4, -1.f, 1.f);
+    const float vz = rand_float_t(s, fp, c + 5, -1.f, 1.f);
+    int gv;
+    if (!voxel_of(d, px, py, pz, gv)) return;
+    const int lv = gv - d.v_base;
+    if (lv < 0 || lv >= d.v_loc) return;
+    const int sl = claim_slot(s.mask, lv, d);
+    if (sl < 0) return;
+    const size_t idx = pidx(d, lv, sl);
+    s.px[idx] = px; s.py[idx] = py; s.pz[idx] = pz; s.vx[idx] = vx; s.vy[idx] = vy; s.w[idx] = weight;
+    if (s.vz0) s.vz0[idx] = vz;
+    atomicOr(&s.nbmask[(size_t)lv * d.mw + (sl >> 6)], 1ull << (sl & 63));
+}
+__global__ void k_advance_rcur(DevState s, FilterParams fp, int by) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) s.fs->r_cur = (int)(((long long)s.fs->r_cur + by) % max(fp.rtab_n, 1));
+}
+
+// fold per-block partial counters (written without global atomics by the sweeps) into FrameScalars
+__global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScratch k, MapDims d) {
+    __shared__ int s_red[1024];
+    const int tid = threadIdx.x;
+    int acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < k.ntiles; i += 1024) {
+        acc[0] += k.part_predict[i * 4]; acc[1] += k.part_predict[i * 4 + 1];
+        acc[2] += k.part_predict[i * 4 + 2]; acc[3] += k.part_predict[i * 4 + 3];
+        acc[4] += k.part_claim[i * 2]; acc[5] += k.part_claim[i * 2 + 1];
+    }
+    for (int i = tid; i < k.nblk_sweep * 4; i += 1024) acc[6] += k.part_resample[i];
+    int out[7];
+    for (int c = 0; c < 7; ++c) {
+        s_red[tid] = acc[c];
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) {
+            if (tid < o) s_red[tid] += s_red[tid + o];
+            __syncthreads();
+        }
+        out[c] = s_red[0];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        s.fs->n_live_in = out[0]; s.fs->n_out_of_map = out[1];
+        s.fs->n_pyramid_full = out[2] + out[5]; s.fs->n_moved = out[3];
+        s.fs->n_voxel_full = out[4]; s.fs->n_live_out = out[6];
+        int nf = 0;
+        for (int b = 0; b < d.np; ++b) nf += min(s.pyr_cnt[b], d.capp);
+        s.fs->n_fov = nf;
+    }
+}
+
+// ==========================================================================
+// launchers
+// ==========================================================================
+void launch_predict_only(const LaunchCtx& c, float odx, float ody, float odz, float dt) {
+    const KernelScratch* k = &c.k;
+    if (c.d.mw == 1)
+        hipLaunchKernelGGL(k_predict<1>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, c.fp, odx, ody, odz, dt,
+                           c.s.vz0 ? 1 : 0, k->part_predict, k->mvmask, k->expmask);
+    else
+        hipLaunchKernelGGL(k_predict<2>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, c.fp, odx, ody, odz, dt,
+                           c.s.vz0 ? 1 : 0, k->part_predict, k->mvmask, k->expmask);
+}
+void launch_claim(const LaunchCtx& c) {
+    const KernelScratch* k = &c.k;
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_claim<1>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->mvmask, k->part_claim);
+    else hipLaunchKernelGGL(k_claim<2>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->mvmask, k->part_claim);
+}
+void launch_predict(const LaunchCtx& c, float odx, float ody, float odz, float dt) {
+    launch_predict_only(c, odx, ody, odz, dt);
+    launch_claim(c);
+}
+void launch_resample(const LaunchCtx& c) {
+    const KernelScratch* k = &c.k;
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_resample<1>, dim3(k->nblk_sweep), dim3(256), 0, c.stream, c.d, c.s, k->part_resample);
+    else hipLaunchKernelGGL(k_resample<2>, dim3(k->nblk_sweep), dim3(256), 0, c.stream, c.d, c.s, k->part_resample);
+}
+void launch_seed_uniform(const LaunchCtx& c, int per_voxel, float weight, unsigned seed) {
+    const size_t total = (size_t)c.d.v_loc * c.d.slots;
+    hipLaunchKernelGGL(k_seed_uniform, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, c.d, c.s, per_voxel, weight, seed);
+}
+void launch_import(const LaunchCtx& c, int n, const int* voxel_dev, const int* slot_dev, const float* rec8_dev, int* n_failed_dev) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_import, dim3((n + 255) / 256), dim3(256), 0, c.stream, c.d, c.s, n, voxel_dev, slot_dev, rec8_dev, n_failed_dev);
+}
+void launch_export(const LaunchCtx& c, int* voxel_out, int* slot_out, float* rec8_out, int* count_dev, int cap) {
+    const size_t total = (size_t)c.d.v_loc * c.d.slots;
+    hipLaunchKernelGGL(k_export, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, c.d, c.s, voxel_out, slot_out, rec8_out, count_dev, cap);
+}
+void launch_add_random(const LaunchCtx& c, int n, float weight) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_add_random, dim3((n + 255) / 256), dim3(256), 0, c.stream, c.d, c.s, c.fp, n, weight);
+    hipLaunchKernelGGL(k_advance_rcur, dim3(1), dim3(64), 0, c.stream, c.s, c.fp, 6 * n);
+}
+void launch_reduce_counters(const LaunchCtx& c) {
+    hipLaunchKernelGGL(k_reduce_counters, dim3(1), dim3(1024), 0, c.stream, c.s, c.k, c.d);
+}

@@ -3,7 +3,8 @@
 // Data layout in HBM:
 //   * voxel structure: dense slots like the reference's
 //     voxels_with_particle[V][SLOTS][9] (dsp_dynamic.h:116) but SoA: one fp32
-//     array per field indexed by local_voxel*SLOTS + slot, plus one 64-bit
+//     array per field, voxels grouped in tiles of 64 and stored slot-major inside
+//     a tile: index = ((lv>>6)*SLOTS + slot)*64 + (lv&63); plus one 64-bit
 //     occupancy word per voxel per 64 slots (bit = slot is live) and a second
 //     word marking particles born this frame (the reference's flag 15,
 //     dsp_dynamic.h:1186).  vz and update_time are not stored: vz is
@@ -88,7 +89,8 @@ struct DevState {
     float* vx; float* vy; float* w;
     float* vz0;    // optional, only right after an import with vz != 0 (consumed by the next prediction)
     float4* res4;  // [v_loc] {mass, mean vx, mean vy, mean vz}
-    float* fut;    // [v_loc][T]
+    float* fut;    // [v_loc][T]  future mass scattered by moving particles
+    float* fut_stat; // [v_loc]   future mass of static particles (identical for every horizon; folded in at readout)
     // observations
     float4* obs;       // [np*100] {x,y,z,len}
     float* obs_ck;     // [np*100]
