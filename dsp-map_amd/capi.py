@@ -102,11 +102,13 @@ SIGNATURES = {
     "dspmap_stage_resample": (_i, [_P]),
     "dspmap_get_observations": (_i, [_P, _P, _P, _P, _fp]),
     "dspmap_set_expected_newborn": (_i, [_P, _f]),
+    "dspmap_get_pyramid_counts": (_i, [_P, _P]),
+    "dspmap_mgpu_bind": (_i, [_P, _P, _P, _i]),
     "dspmap_mgpu_begin": (_i, [_P, _i, _P, _i, _P, _P, _d, _P]),
-    "dspmap_mgpu_get_exports": (_i, [_P, _i, C.POINTER(_P), _ip]),
-    "dspmap_mgpu_import_movers": (_i, [_P, _i, _P]),
-    "dspmap_mgpu_ck_partial": (_i, [_P, C.POINTER(_P), _ip]),
-    "dspmap_mgpu_nstatic_partial": (_i, [_P, C.POINTER(_P), _ip]),
+    "dspmap_mgpu_export": (_i, [_P, _i, _P, _i, _ip]),
+    "dspmap_mgpu_import": (_i, [_P, _i, _P]),
+    "dspmap_mgpu_ck_partial": (_i, [_P]),
+    "dspmap_mgpu_weights_and_split": (_i, [_P]),
     "dspmap_mgpu_finish": (_i, [_P]),
 }
 
@@ -369,6 +371,11 @@ class DSPMap:
 
     def occupancy_resample(self):
         self._chk(self.L.dspmap_stage_resample(self.h))
+
+    def pyramid_counts(self):
+        out = np.zeros(self.NP, np.int32)
+        self._chk(self.L.dspmap_get_pyramid_counts(self.h, _ptr(out)))
+        return out
 
     def observations(self):
         obs = np.zeros((self.NP, 100, 5), np.float32)

@@ -16,66 +16,12 @@
 #include <string>
 #include <vector>
 
-#include "../../include/dspmap.h"
-#include "dspmap_kernels.h"
-#include "velocity_estimator.h"
+#include "dspmap_internal.h"
 
-struct dspmap {
-    dspmap_config cfg;
-    MapDims d;
-    FilterParams fp;
-    DevState s;
-    KernelScratch k;
-    bool device_ready = false;
-    bool own_stream = false;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_valid = false;
-    int device = -1;
-    std::string err;
-    // parameters
-    float p_stddev = 0.2f, v_stddev = 0.1f;  // :154-155
-    float voxel_filter_res = 0.15f;          // :132
-    bool use_vel_est = false;
-    bool regen_tables = false;
-    bool nb_frozen = false;                  // function statics of the birth stage (:808-811)
-    // tables (host copies kept until upload)
-    std::vector<float> h_ptab, h_vtab;
-    std::vector<int> h_rtab;
-    bool tables_injected = false, rtab_injected = false;
-    int pend_cursor[3] = {0, 0, 0};
-    // function statics of update() (:187-190)
-    bool have_last = false;
-    float last_p[3] = {0, 0, 0};
-    double last_stamp = 0.0;
-    float cur_pos[3] = {0, 0, 0};
-    float quat[4] = {1, 0, 0, 0};
-    float dt_last = 0.f;
-    // capacities
-    int pt_cap = 0, birth_cap = 0;
-    float* pts_dev = nullptr;        // staging for host-fed clouds
-    float* pts_pin = nullptr; int pts_pin_cap = 0;
-    BirthSrc* birth_pin = nullptr; int birth_pin_cap = 0;
-    // birth cloud supplied by the caller (estimator off) / produced by the estimator
-    std::vector<dspmap_vpoint> h_birth;
-    bool h_birth_valid = false;
-    int last_n_birth = 0;            // entries of s.birth used by the last frame
-    bool last_birth_static = false;
-    int vz_frames = 0;
-    int last_n_points = 0;
-    VelocityEstimator vel;
-    // per-stage profiling
-    bool prof = false;
-    hipEvent_t pev[DSPMAP_N_STAGES + 1] = {};
-    double stage_ms[DSPMAP_N_STAGES] = {};
-    int prof_frames = 0;
-    bool prof_pending = false;
-};
-
-static void prof_mark(dspmap* m, int i) {
+void dspmap_prof_mark(dspmap* m, int i) {
     if (m->prof) (void)hipEventRecord(m->pev[i], m->stream);
 }
-static void prof_collect(dspmap* m) {
+void dspmap_prof_collect(dspmap* m) {
     if (!m->prof || !m->prof_pending) return;
     (void)hipEventSynchronize(m->pev[DSPMAP_N_STAGES]);
     for (int i = 0; i < DSPMAP_N_STAGES; i++) {
@@ -86,7 +32,7 @@ static void prof_collect(dspmap* m) {
     m->prof_pending = false;
 }
 
-static int fail(dspmap* m, int code, const char* fmt, ...) {
+int dspmap_fail(dspmap* m, int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -95,14 +41,9 @@ static int fail(dspmap* m, int code, const char* fmt, ...) {
     if (m) m->err = buf;
     return code;
 }
-#define HIPCHK(m, call)                                                                            \
-    do {                                                                                           \
-        hipError_t e_ = (call);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return fail((m), DSPMAP_E_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
 
-static LaunchCtx ctx_of(dspmap* m) {
+
+LaunchCtx dspmap_ctx_of(dspmap* m) {
     LaunchCtx c;
     c.d = m->d; c.fp = m->fp; c.s = m->s; c.k = m->k; c.stream = m->stream;
     c.pt_cap = m->pt_cap; c.birth_cap = m->birth_cap;
@@ -185,6 +126,8 @@ extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
 static void free_dev(dspmap* m) {
     if (!m->device_ready) return;
     DevState& s = m->s;
+    if (m->mgpu_bound) { s.obs_ck = nullptr; s.nstatic = nullptr; }  // caller-owned
+    if (m->mgpu_count) (void)hipFree(m->mgpu_count);
     void* ptrs[] = {s.fut_stat, s.mask, s.nbmask, s.px, s.py, s.pz, s.vx, s.vy, s.w, s.vz0, s.res4, s.fut, s.obs, s.obs_ck,
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.nstatic, s.fov_rec, s.fov_slot, s.pyr_cnt, s.mv_rec, s.exp_up, s.exp_down,
@@ -255,11 +198,12 @@ static int upload_rtab(dspmap* m) {
     return DSPMAP_OK;
 }
 
-static int ensure_point_cap(dspmap* m, int n) {
+int dspmap_ensure_point_cap(dspmap* m, int n) {
     if (n <= m->pt_cap) return DSPMAP_OK;
     HIPCHK(m, hipStreamSynchronize(m->stream));
     DevState& s = m->s;
     const int cap = n + n / 2 + 1024;
+    if (m->mgpu_bound) return dspmap_fail(m, DSPMAP_E_ARG, "%d points exceed the capacity bound with dspmap_mgpu_bind", n);
     void* olds[] = {s.pt_rot, s.pt_pyr, s.birth, s.plan, s.nstatic, m->pts_dev, m->k.child};
     for (void* p : olds) if (p) (void)hipFree(p);
     HIPCHK(m, dalloc(&s.pt_rot, (size_t)cap));
@@ -278,7 +222,7 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     if (m->device_ready) return DSPMAP_OK;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(m, DSPMAP_E_DEVICE, "no HIP device available (libdspmap_hip has no CPU fallback)");
+        return dspmap_fail(m, DSPMAP_E_DEVICE, "no HIP device available (libdspmap_hip has no CPU fallback)");
     if (m->device >= 0) HIPCHK(m, hipSetDevice(m->device));
     else HIPCHK(m, hipGetDevice(&m->device));
     if (!m->stream) { HIPCHK(m, hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
@@ -361,22 +305,13 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
         fs.p_cur = m->pend_cursor[0]; fs.v_cur = m->pend_cursor[1]; fs.r_cur = m->pend_cursor[2];
         HIPCHK(m, hipMemcpy(s.fs, &fs, sizeof(fs), hipMemcpyHostToDevice));
     }
-    rc = ensure_point_cap(m, 8192);
+    rc = dspmap_ensure_point_cap(m, 8192);
     if (rc != DSPMAP_OK) return rc;
     HIPCHK(m, hipDeviceSynchronize());
     return DSPMAP_OK;
 }
 
-#define READY(m)                                       \
-    do {                                               \
-        if (!(m)) return DSPMAP_E_ARG;                 \
-        if (!(m)->device_ready) {                      \
-            int rc_ = dspmap_init_device(m);           \
-            if (rc_ != DSPMAP_OK) return rc_;          \
-        } else if ((m)->device >= 0) {                 \
-            (void)hipSetDevice((m)->device);           \
-        }                                              \
-    } while (0)
+
 
 extern "C" int dspmap_sync(dspmap_t* m) {
     if (!m) return DSPMAP_E_ARG;
@@ -403,7 +338,7 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
         case DSPMAP_P_OBSERVATION_STDDEV: m->fp.sigma_ob = (float)v; refresh_fp(m); break;
         case DSPMAP_P_NEWBORN_WEIGHT: m->fp.nb_weight = (float)v; break;
         case DSPMAP_P_NEWBORN_NUMBER:
-            if (v < 1 || v > 32) return fail(m, DSPMAP_E_ARG, "newborn number must be in [1,32]");
+            if (v < 1 || v > 32) return dspmap_fail(m, DSPMAP_E_ARG, "newborn number must be in [1,32]");
             m->fp.nb_num = (int)v; break;
         case DSPMAP_P_VOXEL_FILTER_RES: m->voxel_filter_res = (float)v; break;
         case DSPMAP_P_KAPPA: m->fp.kappa = (float)v; break;
@@ -416,7 +351,7 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
                 if (m->device_ready) { HIPCHK(m, hipStreamSynchronize(m->stream)); return upload_tables(m); }
             }
             break;
-        default: return fail(m, DSPMAP_E_ARG, "unknown parameter key %d", key);
+        default: return dspmap_fail(m, DSPMAP_E_ARG, "unknown parameter key %d", key);
     }
     return DSPMAP_OK;
 }
@@ -492,7 +427,7 @@ extern "C" int dspmap_get_cursors(dspmap_t* m, int* pc, int* vc, int* rc) {
 }
 
 // --------------------------------------------------------------- the frame
-static void freeze_birth_statics(dspmap* m) {
+void dspmap_freeze_birth_statics(dspmap* m) {
     if (m->nb_frozen) return;  // function statics initialised at first call (:808-811)
     m->fp.min_static_nb = (int)((float)m->fp.nb_num * 0.15f);
     m->fp.model_nb = (int)((float)m->fp.nb_num * 0.8f);
@@ -500,7 +435,7 @@ static void freeze_birth_statics(dspmap* m) {
 }
 
 // C0 gate + deltas, update() :187-218.  returns 1 (accepted) / 0 (rejected)
-static int gate_and_delta(dspmap* m, const float pos[3], double stamp, const float q[4], float dp[3], float* dt) {
+int dspmap_gate_and_delta(dspmap* m, const float pos[3], double stamp, const float q[4], float dp[3], float* dt) {
     if (!m->have_last) {
         m->last_p[0] = pos[0]; m->last_p[1] = pos[1]; m->last_p[2] = pos[2];
         m->last_stamp = stamp;
@@ -525,21 +460,21 @@ static int gate_and_delta(dspmap* m, const float pos[3], double stamp, const flo
 
 // enqueue the stages after binning; birth source already selected in c.s.birth
 static void enqueue_filter(dspmap* m, LaunchCtx& c, const float dp[3], float dt, int n_birth) {
-    prof_mark(m, 1);
+    dspmap_prof_mark(m, 1);
     launch_predict_only(c, -dp[0], -dp[1], -dp[2], dt);  // particles move opposite to the sensor (:300)
-    prof_mark(m, 2);
+    dspmap_prof_mark(m, 2);
     launch_claim(c);
-    prof_mark(m, 3);
+    dspmap_prof_mark(m, 3);
     launch_ck_partial(c);
-    prof_mark(m, 4);
+    dspmap_prof_mark(m, 4);
     launch_ck_finalize(c);
-    prof_mark(m, 5);
+    dspmap_prof_mark(m, 5);
     launch_weight_update(c);
-    prof_mark(m, 6);
+    dspmap_prof_mark(m, 6);
     launch_birth(c, n_birth, false);
-    prof_mark(m, 7);
+    dspmap_prof_mark(m, 7);
     launch_resample(c);
-    prof_mark(m, 8);
+    dspmap_prof_mark(m, 8);
     if (m->prof) m->prof_pending = true;
     if (m->vz_frames > 0) --m->vz_frames;
 }
@@ -548,20 +483,20 @@ extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* poin
                                     const dspmap_vpoint* birth_dev, const float pos[3], double stamp,
                                     const float q[4]) {
     READY(m);
-    if (n_points < 0 || (n_points > 0 && !points_dev) || !pos || !q) return fail(m, DSPMAP_E_ARG, "bad arguments");
+    if (n_points < 0 || (n_points > 0 && !points_dev) || !pos || !q) return dspmap_fail(m, DSPMAP_E_ARG, "bad arguments");
     float dp[3], dt;
-    if (!gate_and_delta(m, pos, stamp, q, dp, &dt)) return DSPMAP_REJECTED;
-    int rc = ensure_point_cap(m, n_points > n_birth ? n_points : n_birth);
+    if (!dspmap_gate_and_delta(m, pos, stamp, q, dp, &dt)) return DSPMAP_REJECTED;
+    int rc = dspmap_ensure_point_cap(m, n_points > n_birth ? n_points : n_birth);
     if (rc != DSPMAP_OK) return rc;
-    freeze_birth_statics(m);
-    LaunchCtx c = ctx_of(m);
+    dspmap_freeze_birth_statics(m);
+    LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
     const bool static_birth = birth_dev == nullptr;
     if (!static_birth) c.s.birth = (BirthSrc*)birth_dev;
     const int nb = static_birth ? n_points : n_birth;
-    prof_collect(m);
+    dspmap_prof_collect(m);
     HIPCHK(m, hipEventRecord(m->ev0, m->stream));
-    prof_mark(m, 0);
+    dspmap_prof_mark(m, 0);
     launch_frame_setup(c, m->quat, m->cur_pos, true);
     launch_obs_bin(c, n_points, points_dev, m->quat, static_birth);
     enqueue_filter(m, c, dp, dt, nb);
@@ -575,7 +510,7 @@ extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* poin
 }
 
 static int stage_points(dspmap* m, int n, int stride, const float* pts) {
-    int rc = ensure_point_cap(m, n);
+    int rc = dspmap_ensure_point_cap(m, n);
     if (rc != DSPMAP_OK) return rc;
     if (n > m->pts_pin_cap) {
         if (m->pts_pin) (void)hipHostFree(m->pts_pin);
@@ -592,7 +527,7 @@ static int stage_points(dspmap* m, int n, int stride, const float* pts) {
 }
 
 static int upload_birth(dspmap* m, const dspmap_vpoint* pts, int n) {
-    int rc = ensure_point_cap(m, n);
+    int rc = dspmap_ensure_point_cap(m, n);
     if (rc != DSPMAP_OK) return rc;
     if (n > m->birth_pin_cap) {
         if (m->birth_pin) (void)hipHostFree(m->birth_pin);
@@ -627,16 +562,16 @@ static void rotate_host(const float v[3], const float q[4], float out[3]) {
 extern "C" int dspmap_update(dspmap_t* m, int n, int stride, const float* pts, float sx, float sy, float sz,
                              double stamp, float qw, float qx, float qy, float qz) {
     READY(m);
-    if (n > 0 && (!pts || stride < 3)) return fail(m, DSPMAP_E_ARG, "bad point cloud arguments");
+    if (n > 0 && (!pts || stride < 3)) return dspmap_fail(m, DSPMAP_E_ARG, "bad point cloud arguments");
     const float pos[3] = {sx, sy, sz};
     const float q[4] = {qw, qx, qy, qz};
     float dp[3], dt;
-    if (!gate_and_delta(m, pos, stamp, q, dp, &dt)) return DSPMAP_REJECTED;
+    if (!dspmap_gate_and_delta(m, pos, stamp, q, dp, &dt)) return DSPMAP_REJECTED;
     const int np = n > 0 ? n : 0;
     int rc = stage_points(m, np, stride, pts);
     if (rc != DSPMAP_OK) return rc;
-    freeze_birth_statics(m);
-    LaunchCtx c = ctx_of(m);
+    dspmap_freeze_birth_statics(m);
+    LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
     const bool have_cloud = m->use_vel_est || m->h_birth_valid;
     HIPCHK(m, hipEventRecord(m->ev0, m->stream));
@@ -702,7 +637,7 @@ extern "C" int dspmap_get_birth_cloud(dspmap_t* m, dspmap_vpoint* out, int cap, 
 // ----------------------------------------------------------------- readout
 static int readout(dspmap* m, float thr, float* xyz, int cap, int* n_out, float* fut_out, bool want_occ) {
     READY(m);
-    LaunchCtx c = ctx_of(m);
+    LaunchCtx c = dspmap_ctx_of(m);
     const MapDims& d = m->d;
     int n = 0;
     if (want_occ) {
@@ -730,7 +665,7 @@ extern "C" int dspmap_get_occupancy_with_future(dspmap_t* m, float thr, float* x
 extern "C" int dspmap_get_future(dspmap_t* m, float* fut) { return readout(m, 0.f, nullptr, 0, nullptr, fut, false); }
 extern "C" int dspmap_clear_future(dspmap_t* m) {
     READY(m);
-    LaunchCtx c = ctx_of(m);
+    LaunchCtx c = dspmap_ctx_of(m);
     launch_clear_future(c);
     return DSPMAP_OK;
 }
@@ -743,7 +678,7 @@ extern "C" int dspmap_get_results(dspmap_t* m, float* out) {
 extern "C" const float* dspmap_results_device(dspmap_t* m) { return (m && m->device_ready) ? (const float*)m->s.res4 : nullptr; }
 extern "C" const float* dspmap_future_device(dspmap_t* m) {
     if (!m || !m->device_ready) return nullptr;
-    LaunchCtx c = ctx_of(m);
+    LaunchCtx c = dspmap_ctx_of(m);
     launch_future_combine(c);  // static-particle mass is kept per voxel and folded in on demand
     return m->s.fut;
 }
@@ -773,7 +708,7 @@ extern "C" int dspmap_pyramid_capacity(const dspmap_t* m) { return m ? m->d.capp
 extern "C" int dspmap_get_counters(dspmap_t* m, dspmap_counters* out) {
     READY(m);
     if (!out) return DSPMAP_E_ARG;
-    LaunchCtx c = ctx_of(m);
+    LaunchCtx c = dspmap_ctx_of(m);
     launch_reduce_counters(c);
     FrameScalars fs;
     HIPCHK(m, hipMemcpyAsync(&fs, m->s.fs, sizeof(fs), hipMemcpyDeviceToHost, m->stream));
@@ -835,13 +770,13 @@ extern "C" int dspmap_import_state(dspmap_t* m, int n, const int* voxel, const i
     HIPCHK(m, hipMemcpy(dr, rec8, sizeof(float) * 8 * (size_t)n, hipMemcpyHostToDevice));
     HIPCHK(m, hipMemset(dfail, 0, sizeof(int)));
     if (slot) { HIPCHK(m, dalloc(&ds, (size_t)n)); HIPCHK(m, hipMemcpy(ds, slot, sizeof(int) * n, hipMemcpyHostToDevice)); }
-    LaunchCtx c = ctx_of(m);
+    LaunchCtx c = dspmap_ctx_of(m);
     launch_import(c, n, dv, ds, dr, dfail);
     int nfail = 0;
     HIPCHK(m, hipMemcpyAsync(&nfail, dfail, sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     (void)hipFree(dv); (void)hipFree(dr); (void)hipFree(dfail); if (ds) (void)hipFree(ds);
-    if (nfail) return fail(m, DSPMAP_E_STATE, "%d of %d records could not be placed (outside slab, bad slot, or voxel full)", nfail, n);
+    if (nfail) return dspmap_fail(m, DSPMAP_E_STATE, "%d of %d records could not be placed (outside slab, bad slot, or voxel full)", nfail, n);
     return DSPMAP_OK;
 }
 
@@ -853,7 +788,7 @@ extern "C" int dspmap_export_state(dspmap_t* m, int cap, int* voxel, int* slot, 
     const size_t c1 = cap ? cap : 1;
     HIPCHK(m, dalloc(&dv, c1)); HIPCHK(m, dalloc(&ds, c1)); HIPCHK(m, dalloc(&dr, c1 * 8)); HIPCHK(m, dalloc(&dc, (size_t)1));
     HIPCHK(m, hipMemsetAsync(dc, 0, sizeof(int), m->stream));
-    LaunchCtx c = ctx_of(m);
+    LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
     launch_export(c, dv, ds, dr, dc, cap);
     int n = 0;
@@ -875,7 +810,7 @@ extern "C" int dspmap_add_random_particles(dspmap_t* m, int n, float weight) {
     if (n < 0) return DSPMAP_E_ARG;
     int rc = ensure_vz(m);
     if (rc != DSPMAP_OK) return rc;
-    LaunchCtx c = ctx_of(m);
+    LaunchCtx c = dspmap_ctx_of(m);
     launch_add_random(c, n, weight);
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
@@ -883,8 +818,8 @@ extern "C" int dspmap_add_random_particles(dspmap_t* m, int n, float weight) {
 
 extern "C" int dspmap_seed_uniform(dspmap_t* m, int per_voxel, float weight, unsigned seed) {
     READY(m);
-    if (per_voxel < 0 || per_voxel > m->d.slots) return fail(m, DSPMAP_E_ARG, "per_voxel must be in [0, %d]", m->d.slots);
-    LaunchCtx c = ctx_of(m);
+    if (per_voxel < 0 || per_voxel > m->d.slots) return dspmap_fail(m, DSPMAP_E_ARG, "per_voxel must be in [0, %d]", m->d.slots);
+    LaunchCtx c = dspmap_ctx_of(m);
     launch_seed_uniform(c, per_voxel, weight, seed);
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
@@ -897,7 +832,7 @@ extern "C" int dspmap_stage_bin_points(dspmap_t* m, int n, int stride, const flo
     m->quat[0] = qw; m->quat[1] = qx; m->quat[2] = qy; m->quat[3] = qz;
     int rc = stage_points(m, n, stride, pts);
     if (rc != DSPMAP_OK) return rc;
-    LaunchCtx c = ctx_of(m);
+    LaunchCtx c = dspmap_ctx_of(m);
     launch_frame_setup(c, m->quat, m->cur_pos, true);
     launch_obs_bin(c, n, m->pts_dev, m->quat, !m->h_birth_valid);
     m->last_n_points = n;
@@ -912,7 +847,7 @@ extern "C" int dspmap_set_current_position(dspmap_t* m, float x, float y, float 
 }
 extern "C" int dspmap_stage_predict(dspmap_t* m, float dx, float dy, float dz, float dt) {
     READY(m);
-    LaunchCtx c = ctx_of(m);
+    LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
     launch_frame_setup(c, m->quat, m->cur_pos, false);
     launch_predict(c, dx, dy, dz, dt);
@@ -922,7 +857,7 @@ extern "C" int dspmap_stage_predict(dspmap_t* m, float dx, float dy, float dz, f
 }
 extern "C" int dspmap_stage_update(dspmap_t* m) {
     READY(m);
-    LaunchCtx c = ctx_of(m);
+    LaunchCtx c = dspmap_ctx_of(m);
     launch_ck_partial(c);
     launch_ck_finalize(c);
     launch_weight_update(c);
@@ -931,7 +866,7 @@ extern "C" int dspmap_stage_update(dspmap_t* m) {
 }
 extern "C" int dspmap_stage_birth(dspmap_t* m) {
     READY(m);
-    freeze_birth_statics(m);
+    dspmap_freeze_birth_statics(m);
     int nb = m->last_n_birth;
     if (m->h_birth_valid) {
         nb = (int)m->h_birth.size();
@@ -940,7 +875,7 @@ extern "C" int dspmap_stage_birth(dspmap_t* m) {
         m->last_birth_static = false;
         m->last_n_birth = nb;
     }
-    LaunchCtx c = ctx_of(m);
+    LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
     launch_birth(c, nb, false);
     HIPCHK(m, hipGetLastError());
@@ -948,7 +883,7 @@ extern "C" int dspmap_stage_birth(dspmap_t* m) {
 }
 extern "C" int dspmap_stage_resample(dspmap_t* m) {
     READY(m);
-    LaunchCtx c = ctx_of(m);
+    LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
     launch_resample(c);
     HIPCHK(m, hipGetLastError());
@@ -994,6 +929,14 @@ extern "C" int dspmap_set_expected_newborn(dspmap_t* m, float v) {
     return DSPMAP_OK;
 }
 
+extern "C" int dspmap_get_pyramid_counts(dspmap_t* m, int* out) {
+    READY(m);
+    if (!out) return DSPMAP_E_ARG;
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    HIPCHK(m, hipMemcpy(out, m->s.pyr_cnt, sizeof(int) * m->d.np, hipMemcpyDeviceToHost));
+    for (int i = 0; i < m->d.np; i++) if (out[i] > m->d.capp) out[i] = m->d.capp;
+    return DSPMAP_OK;
+}
 extern "C" int dspmap_set_profiling(dspmap_t* m, int on) {
     READY(m);
     HIPCHK(m, hipStreamSynchronize(m->stream));
@@ -1008,7 +951,7 @@ extern "C" int dspmap_set_profiling(dspmap_t* m, int on) {
 extern "C" int dspmap_get_stage_ms(dspmap_t* m, float out[DSPMAP_N_STAGES], int* n_frames) {
     READY(m);
     HIPCHK(m, hipStreamSynchronize(m->stream));
-    prof_collect(m);
+    dspmap_prof_collect(m);
     for (int i = 0; i < DSPMAP_N_STAGES; i++) out[i] = (float)m->stage_ms[i];
     if (n_frames) *n_frames = m->prof_frames;
     return DSPMAP_OK;

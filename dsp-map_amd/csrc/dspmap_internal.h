@@ -1,0 +1,93 @@
+// dspmap_internal.h -- the handle behind dspmap_t and helpers shared by dspmap_api.hip / dspmap_mgpu.hip
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/dspmap.h"
+#include "dspmap_kernels.h"
+#include "velocity_estimator.h"
+
+struct dspmap {
+    dspmap_config cfg;
+    MapDims d;
+    FilterParams fp;
+    DevState s;
+    KernelScratch k;
+    bool device_ready = false;
+    bool own_stream = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    int device = -1;
+    std::string err;
+    // parameters
+    float p_stddev = 0.2f, v_stddev = 0.1f;  // :154-155
+    float voxel_filter_res = 0.15f;          // :132
+    bool use_vel_est = false;
+    bool regen_tables = false;
+    bool nb_frozen = false;                  // function statics of the birth stage (:808-811)
+    // tables (host copies kept until upload)
+    std::vector<float> h_ptab, h_vtab;
+    std::vector<int> h_rtab;
+    bool tables_injected = false, rtab_injected = false;
+    int pend_cursor[3] = {0, 0, 0};
+    // function statics of update() (:187-190)
+    bool have_last = false;
+    float last_p[3] = {0, 0, 0};
+    double last_stamp = 0.0;
+    float cur_pos[3] = {0, 0, 0};
+    float quat[4] = {1, 0, 0, 0};
+    float dt_last = 0.f;
+    // capacities
+    int pt_cap = 0, birth_cap = 0;
+    float* pts_dev = nullptr;        // staging for host-fed clouds
+    float* pts_pin = nullptr; int pts_pin_cap = 0;
+    BirthSrc* birth_pin = nullptr; int birth_pin_cap = 0;
+    // birth cloud supplied by the caller (estimator off) / produced by the estimator
+    std::vector<dspmap_vpoint> h_birth;
+    bool h_birth_valid = false;
+    int last_n_birth = 0;            // entries of s.birth used by the last frame
+    bool last_birth_static = false;
+    int vz_frames = 0;
+    int last_n_points = 0;
+    VelocityEstimator vel;
+    // multi-GPU split-phase state
+    bool mgpu_bound = false;
+    int mgpu_nstatic_cap = 0;
+    int* mgpu_count = nullptr;
+    BirthSrc* mgpu_birth = nullptr;
+    // per-stage profiling
+    bool prof = false;
+    hipEvent_t pev[DSPMAP_N_STAGES + 1] = {};
+    double stage_ms[DSPMAP_N_STAGES] = {};
+    int prof_frames = 0;
+    bool prof_pending = false;
+};
+
+int dspmap_fail(dspmap* m, int code, const char* fmt, ...);
+void dspmap_prof_mark(dspmap* m, int i);
+void dspmap_prof_collect(dspmap* m);
+LaunchCtx dspmap_ctx_of(dspmap* m);
+int dspmap_gate_and_delta(dspmap* m, const float pos[3], double stamp, const float q[4], float dp[3], float* dt);
+void dspmap_freeze_birth_statics(dspmap* m);
+int dspmap_ensure_point_cap(dspmap* m, int n);
+
+#define HIPCHK(m, call)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return dspmap_fail((m), DSPMAP_E_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define READY(m)                                       \
+    do {                                               \
+        if (!(m)) return DSPMAP_E_ARG;                 \
+        if (!(m)->device_ready) {                      \
+            int rc_ = dspmap_init_device(m);           \
+            if (rc_ != DSPMAP_OK) return rc_;          \
+        } else if ((m)->device >= 0) {                 \
+            (void)hipSetDevice((m)->device);           \
+        }                                              \
+    } while (0)

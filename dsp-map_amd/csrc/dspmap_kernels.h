@@ -36,7 +36,10 @@ void launch_obs_bin(const LaunchCtx& c, int n_pts, const float* pts_dev, const f
 void launch_predict(const LaunchCtx& c, float odx, float ody, float odz, float dt);
 void launch_predict_only(const LaunchCtx& c, float odx, float ody, float odz, float dt);
 void launch_claim(const LaunchCtx& c);
-void launch_reduce_counters(const LaunchCtx& c);  // folds the per-block partial counters into FrameScalars
+void launch_reduce_counters(const LaunchCtx& c);
+// multi-GPU: compact particles that left the slab / insert particles received from a neighbour
+void launch_export_slab(const LaunchCtx& c, int dir, float* rec_out, int cap, int* count_dev);
+void launch_import_movers(const LaunchCtx& c, int n, const float* rec);  // folds the per-block partial counters into FrameScalars
 // mapUpdate (:704-793)
 void launch_ck_partial(const LaunchCtx& c);
 void launch_ck_finalize(const LaunchCtx& c);

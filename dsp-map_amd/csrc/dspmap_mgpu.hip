@@ -1,19 +1,112 @@
-// dspmap_mgpu.hip -- split-phase frame for Z-slab sharding across GPUs (one
-// process per GPU; collectives are issued by the caller through
-// torch.distributed / RCCL).  Round-1 status: the slab-aware kernels exist
-// (every kernel takes z_lo/z_hi through MapDims and k_predict marks particles
-// that leave the slab), the exchange entry points below are not wired yet and
-// report an error instead of silently doing nothing.
-#include <hip/hip_runtime.h>
-#include "../../include/dspmap.h"
+// dspmap_mgpu.hip -- split-phase frame for Z-slab sharding across GPUs (include/dspmap.h,
+// "multi-GPU split-phase frame").  One process per GPU; the collectives between the phases are
+// issued by the caller through torch.distributed / RCCL on buffers it owns and binds here.
+#include "dspmap_internal.h"
 
-static int not_yet(const char* name) {
-    fprintf(stderr, "libdspmap_hip: %s is not implemented yet\n", name);
-    return DSPMAP_E_STATE;
+extern "C" int dspmap_mgpu_bind(dspmap_t* m, float* ck_dev, int* nstatic_dev, int nstatic_cap) {
+    READY(m);
+    if (!ck_dev || !nstatic_dev || nstatic_cap <= 0) return dspmap_fail(m, DSPMAP_E_ARG, "bad buffers");
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    int rc = dspmap_ensure_point_cap(m, nstatic_cap);  // so that no later frame re-allocates the point buffers
+    if (rc != DSPMAP_OK) return rc;
+    if (!m->mgpu_bound) {
+        (void)hipFree(m->s.obs_ck);
+        (void)hipFree(m->s.nstatic);
+    }
+    m->s.obs_ck = ck_dev;
+    m->s.nstatic = nstatic_dev;
+    m->mgpu_bound = true;
+    m->mgpu_nstatic_cap = nstatic_cap;
+    HIPCHK(m, hipMemsetAsync(ck_dev, 0, sizeof(float) * (size_t)m->d.np * DSP_OBS_CAP, m->stream));
+    if (!m->k.expmask) {
+        const size_t W = (size_t)m->d.v_loc * m->d.mw;
+        HIPCHK(m, hipMalloc((void**)&m->k.expmask, sizeof(u64) * W));
+        HIPCHK(m, hipMemsetAsync(m->k.expmask, 0, sizeof(u64) * W, m->stream));
+    }
+    if (!m->mgpu_count) HIPCHK(m, hipMalloc((void**)&m->mgpu_count, sizeof(int)));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    return DSPMAP_OK;
 }
-extern "C" int dspmap_mgpu_begin(dspmap_t*, int, const float*, int, const dspmap_vpoint*, const float*, double, const float*) { return not_yet("dspmap_mgpu_begin"); }
-extern "C" int dspmap_mgpu_get_exports(dspmap_t*, int, const float**, int*) { return not_yet("dspmap_mgpu_get_exports"); }
-extern "C" int dspmap_mgpu_import_movers(dspmap_t*, int, const float*) { return not_yet("dspmap_mgpu_import_movers"); }
-extern "C" int dspmap_mgpu_ck_partial(dspmap_t*, float**, int*) { return not_yet("dspmap_mgpu_ck_partial"); }
-extern "C" int dspmap_mgpu_nstatic_partial(dspmap_t*, int**, int*) { return not_yet("dspmap_mgpu_nstatic_partial"); }
-extern "C" int dspmap_mgpu_finish(dspmap_t*) { return not_yet("dspmap_mgpu_finish"); }
+
+extern "C" int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_dev, int n_birth,
+                                 const dspmap_vpoint* birth_dev, const float pos[3], double stamp, const float q[4]) {
+    READY(m);
+    if (!m->mgpu_bound) return dspmap_fail(m, DSPMAP_E_STATE, "call dspmap_mgpu_bind first");
+    if (n_points < 0 || (n_points > 0 && !points_dev) || !pos || !q) return dspmap_fail(m, DSPMAP_E_ARG, "bad arguments");
+    const int nb = birth_dev ? n_birth : n_points;
+    if (nb > m->mgpu_nstatic_cap || n_points > m->pt_cap) return dspmap_fail(m, DSPMAP_E_ARG, "more points than the bound capacity");
+    float dp[3], dt;
+    if (!dspmap_gate_and_delta(m, pos, stamp, q, dp, &dt)) return DSPMAP_REJECTED;
+    dspmap_freeze_birth_statics(m);
+    LaunchCtx c = dspmap_ctx_of(m);
+    if (m->vz_frames <= 0) c.s.vz0 = nullptr;
+    const bool static_birth = birth_dev == nullptr;
+    m->mgpu_birth = static_birth ? nullptr : (BirthSrc*)birth_dev;
+    if (!static_birth) c.s.birth = m->mgpu_birth;
+    dspmap_prof_collect(m);
+    HIPCHK(m, hipEventRecord(m->ev0, m->stream));
+    launch_frame_setup(c, m->quat, m->cur_pos, true);
+    launch_obs_bin(c, n_points, points_dev, m->quat, static_birth);
+    launch_predict(c, -dp[0], -dp[1], -dp[2], dt);
+    if (m->vz_frames > 0) --m->vz_frames;
+    m->last_n_points = n_points;
+    m->last_n_birth = nb;
+    m->last_birth_static = static_birth;
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}
+
+extern "C" int dspmap_mgpu_export(dspmap_t* m, int dir, float* rec_dev_out, int cap, int* n_out) {
+    READY(m);
+    if (!m->mgpu_bound || !rec_dev_out || cap < 0 || !n_out) return dspmap_fail(m, DSPMAP_E_ARG, "bad arguments");
+    LaunchCtx c = dspmap_ctx_of(m);
+    HIPCHK(m, hipMemsetAsync(m->mgpu_count, 0, sizeof(int), m->stream));
+    launch_export_slab(c, dir, rec_dev_out, cap, m->mgpu_count);
+    int n = 0;
+    HIPCHK(m, hipMemcpyAsync(&n, m->mgpu_count, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (n > cap) return dspmap_fail(m, DSPMAP_E_STATE, "export buffer too small: %d > %d", n, cap);
+    *n_out = n;
+    return DSPMAP_OK;
+}
+
+extern "C" int dspmap_mgpu_import(dspmap_t* m, int n, const float* rec_dev) {
+    READY(m);
+    if (n < 0 || (n > 0 && !rec_dev)) return DSPMAP_E_ARG;
+    LaunchCtx c = dspmap_ctx_of(m);
+    launch_import_movers(c, n, rec_dev);
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}
+
+extern "C" int dspmap_mgpu_ck_partial(dspmap_t* m) {
+    READY(m);
+    LaunchCtx c = dspmap_ctx_of(m);
+    launch_ck_partial(c);
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}
+
+extern "C" int dspmap_mgpu_weights_and_split(dspmap_t* m) {
+    READY(m);
+    LaunchCtx c = dspmap_ctx_of(m);
+    if (m->mgpu_birth) c.s.birth = m->mgpu_birth;
+    launch_ck_finalize(c);
+    launch_weight_update(c);
+    launch_birth_split(c, m->last_n_birth);
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}
+
+extern "C" int dspmap_mgpu_finish(dspmap_t* m) {
+    READY(m);
+    LaunchCtx c = dspmap_ctx_of(m);
+    if (m->vz_frames <= 0) c.s.vz0 = nullptr;
+    if (m->mgpu_birth) c.s.birth = m->mgpu_birth;
+    launch_birth_plan_insert(c, m->last_n_birth);
+    launch_resample(c);
+    HIPCHK(m, hipEventRecord(m->ev1, m->stream));
+    m->ev_valid = true;
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}

@@ -649,6 +649,93 @@ __global__ void k_advance_rcur(DevState s, FilterParams fp, int by) {
     if (threadIdx.x == 0 && blockIdx.x == 0) s.fs->r_cur = (int)(((long long)s.fs->r_cur + by) % max(fp.rtab_n, 1));
 }
 
+// --------------------------------------------------------------------------
+// multi-GPU: particles whose new voxel lies in another Z-slab (marked in expmask by k_predict).
+// k_export_slab compacts those leaving in direction `dir` into the caller's send buffer and frees
+// their slots; k_import_movers is k_claim for records received from a neighbour.
+// --------------------------------------------------------------------------
+template <int MW>
+__global__ void __launch_bounds__(256) k_export_slab(MapDims d, DevState s, u64* __restrict__ expmask, int dir,
+                                                      float* __restrict__ rec_out, int cap, int* __restrict__ count) {
+    const int l = lane_id();
+    const int lv = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + l;
+    const bool inr = lv < d.v_loc;
+#pragma unroll
+    for (int e = 0; e < MW; ++e) {
+        const u64 ex = inr ? expmask[(size_t)lv * MW + e] : 0ull;
+        u64 tor = wave_or_u64(ex);
+        u64 done = 0ull;
+        while (tor) {
+            const int sb = __ffsll((long long)tor) - 1;
+            tor &= tor - 1ull;
+            bool mine = false;
+            float px = 0, py = 0, pz = 0, vx = 0, vy = 0, w = 0;
+            int gv = 0;
+            if (ex & (1ull << sb)) {
+                const size_t idx = pidx(d, lv, e * 64 + sb);
+                px = s.px[idx]; py = s.py[idx]; pz = s.pz[idx];
+                vx = s.vx[idx]; vy = s.vy[idx]; w = s.w[idx];
+                voxel_of(d, px, py, pz, gv);
+                const int nlv = gv - d.v_base;
+                mine = dir > 0 ? nlv >= d.v_loc : nlv < 0;
+            }
+            const int pos = wave_agg_inc1(count, mine);
+            if (mine) {
+                if (pos < cap) {
+                    float* r = rec_out + 8 * (size_t)pos;
+                    r[0] = __int_as_float(gv); r[1] = vx; r[2] = vy; r[3] = px; r[4] = py; r[5] = pz; r[6] = w; r[7] = 0.f;
+                }
+                done |= 1ull << sb;
+            }
+        }
+        if (done) {
+            atomicAnd(&s.mask[(size_t)lv * MW + e], ~done);
+            expmask[(size_t)lv * MW + e] = ex & ~done;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_import_movers(MapDims d, DevState s, int n, const float* __restrict__ rec,
+                                                       int* __restrict__ dropped) {
+    __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
+    __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
+    for (int i = threadIdx.x; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
+    for (int i = threadIdx.x; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int pyr = -1;
+    size_t nidx = 0;
+    int nlv = -1, nsl = -1;
+    float px = 0, py = 0, pz = 0, w = 0;
+    bool lost = false;
+    if (i < n) {
+        const float* r = rec + 8 * (size_t)i;
+        nlv = __float_as_int(r[0]) - d.v_base;
+        px = r[3]; py = r[4]; pz = r[5]; w = r[6];
+        if (nlv >= 0 && nlv < d.v_loc) {
+            nsl = claim_slot(s.mask, nlv, d);
+            if (nsl >= 0) {
+                nidx = pidx(d, nlv, nsl);
+                s.px[nidx] = px; s.py[nidx] = py; s.pz[nidx] = pz;
+                s.vx[nidx] = r[1]; s.vy[nidx] = r[2]; s.w[nidx] = w;
+                pyr = pyramid_of(d, s_ph, s_pv, px, py, pz);
+            } else lost = true;   // destination voxel full (-1, :1227-1229)
+        } else lost = true;       // not a neighbouring slab's voxel (jump larger than a slab)
+    }
+    const int pos = wave_agg_inc(s.pyr_cnt, pyr, pyr >= 0);
+    if (pyr >= 0) {
+        if (pos < d.capp) {
+            const size_t o = (size_t)pyr * d.capp + pos;
+            s.fov_rec[o] = make_float4(px, py, pz, w);
+            s.fov_slot[o] = (int)nidx;
+        } else {
+            lost = true;
+            atomicAnd(&s.mask[(size_t)nlv * d.mw + (nsl >> 6)], ~(1ull << (nsl & 63)));
+        }
+    }
+    wave_count_add(dropped, lost);
+}
+
 // fold per-block partial counters (written without global atomics by the sweeps) into FrameScalars
 __global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScratch k, MapDims d) {
     __shared__ int s_red[1024];
@@ -723,6 +810,15 @@ void launch_add_random(const LaunchCtx& c, int n, float weight) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_add_random, dim3((n + 255) / 256), dim3(256), 0, c.stream, c.d, c.s, c.fp, n, weight);
     hipLaunchKernelGGL(k_advance_rcur, dim3(1), dim3(64), 0, c.stream, c.s, c.fp, 6 * n);
+}
+void launch_export_slab(const LaunchCtx& c, int dir, float* rec_out, int cap, int* count_dev) {
+    const KernelScratch* k = &c.k;
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_export_slab<1>, dim3(k->nblk_sweep), dim3(256), 0, c.stream, c.d, c.s, k->expmask, dir, rec_out, cap, count_dev);
+    else hipLaunchKernelGGL(k_export_slab<2>, dim3(k->nblk_sweep), dim3(256), 0, c.stream, c.d, c.s, k->expmask, dir, rec_out, cap, count_dev);
+}
+void launch_import_movers(const LaunchCtx& c, int n, const float* rec) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_import_movers, dim3((n + 255) / 256), dim3(256), 0, c.stream, c.d, c.s, n, rec, &c.s.fs->n_voxel_full);
 }
 void launch_reduce_counters(const LaunchCtx& c) {
     hipLaunchKernelGGL(k_reduce_counters, dim3(1), dim3(1024), 0, c.stream, c.s, c.k, c.d);

@@ -1,0 +1,205 @@
+"""Z-slab sharding of the map across the GPUs of one node.
+
+One process per GPU.  Rank g owns the voxel layers [z_lo, z_hi) -- a contiguous
+index range because the voxel index is z-major (reference include/dsp_dynamic.h:1081).
+Every rank is fed the same cloud + pose.  Per frame (see include/dspmap.h,
+"multi-GPU split-phase frame"):
+
+    begin                      binning, prediction, local re-binning
+    exchange                   particles that crossed a slab face -> neighbour rank (send/recv)
+    ck_partial + all-reduce    per-observation sums Ck (pyramids cut across slabs)     [SUM, <= 177 kB]
+    weights_and_split + a-r    n_static of each birth source, known to the owner only  [MAX, <= 20 kB]
+    finish                     births (each rank keeps the children landing in its slab), resampling
+
+With vz == 0 (LIMIT_MOVEMENT_IN_XY_PLANE, :661-663) only the sensor's own vertical motion moves
+particles across layers, so the exchange is a thin boundary layer to the two neighbours; both
+all-reduces are latency-bound, not link-bound.
+
+The driver is written against two small interfaces so that the same orchestration runs on
+RCCL (torch.distributed "nccl"), on gloo (CPU tests) and inside one process (several slabs on
+one GPU, for tests):  a *slab backend* (HipSlab below; tests provide an oracle-based one) and a
+*communicator* (TorchDistComm / LocalComm).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+
+def slab_ranges(nz, world):
+    """contiguous z-layer ranges, as even as possible"""
+    base, rem = divmod(nz, world)
+    out, z = [], 0
+    for r in range(world):
+        h = base + (1 if r < rem else 0)
+        out.append((z, z + h))
+        z += h
+    return out
+
+
+# --------------------------------------------------------------------------- communicators
+class TorchDistComm:
+    """torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in CPU tests)"""
+
+    def __init__(self, device):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = device
+
+    def exchange(self, up, down):
+        """send `up` to rank+1 and `down` to rank-1; returns (from_below, from_above). Tensors (n, 8) f32."""
+        dist = self.dist
+        r, w = self.rank, self.world
+        counts = torch.tensor([up.shape[0], down.shape[0]], dtype=torch.int64, device=self.device)
+        allc = [torch.zeros_like(counts) for _ in range(w)]
+        dist.all_gather(allc, counts)
+        n_from_below = int(allc[r - 1][0]) if r > 0 else 0       # what rank-1 sends up
+        n_from_above = int(allc[r + 1][1]) if r < w - 1 else 0   # what rank+1 sends down
+        from_below = torch.empty((n_from_below, 8), dtype=torch.float32, device=self.device)
+        from_above = torch.empty((n_from_above, 8), dtype=torch.float32, device=self.device)
+        ops = []
+        if r < w - 1 and up.shape[0] > 0:
+            ops.append(dist.P2POp(dist.isend, up.contiguous(), r + 1))
+        if r > 0 and down.shape[0] > 0:
+            ops.append(dist.P2POp(dist.isend, down.contiguous(), r - 1))
+        if n_from_below > 0:
+            ops.append(dist.P2POp(dist.irecv, from_below, r - 1))
+        if n_from_above > 0:
+            ops.append(dist.P2POp(dist.irecv, from_above, r + 1))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return from_below, from_above
+
+    def allreduce_sum(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+
+    def allreduce_max(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+
+
+class LocalComm:
+    """all slabs live in this process: ShardedDSPMap then drives every slab itself"""
+    rank, world = 0, 1
+
+
+# --------------------------------------------------------------------------- HIP slab backend
+class HipSlab:
+    """one Z-slab on one GPU through the C ABI (dspmap_mgpu_*)"""
+
+    def __init__(self, dsp, cfg_kwargs, z_lo, z_hi, device_index=0, point_cap=8192, example_params=True):
+        self.D = dsp
+        self.dev = torch.device("cuda", device_index)
+        cfg = dsp.make_config(z_lo=z_lo, z_hi=z_hi, device=device_index, **cfg_kwargs)
+        self.map = dsp.DSPMap(cfg, example_params=example_params)
+        m = self.map
+        self.z_lo, self.z_hi = z_lo, z_hi
+        self.ck = torch.zeros(m.NP * 100, dtype=torch.float32, device=self.dev)
+        self.nstatic = torch.zeros(point_cap, dtype=torch.int32, device=self.dev)
+        self.point_cap = point_cap
+        layer = cfg.nx * cfg.ny * m.slots
+        self.exp_cap = max(4096, 2 * layer)
+        self.exp_buf = {+1: torch.empty((self.exp_cap, 8), dtype=torch.float32, device=self.dev),
+                        -1: torch.empty((self.exp_cap, 8), dtype=torch.float32, device=self.dev)}
+        m._chk(m.L.dspmap_mgpu_bind(m.h, self.ck.data_ptr(), self.nstatic.data_ptr(), point_cap))
+        self.n_birth = 0
+
+    def begin(self, pts, pos, stamp, quat, birth=None):
+        m = self.map
+        pos_a = (C.c_float * 3)(*pos)
+        q_a = (C.c_float * 4)(*quat)
+        n = int(pts.shape[0])
+        self.n_birth = n if birth is None else int(birth.shape[0])
+        bptr = None if birth is None else birth.data_ptr()
+        return m._chk(m.L.dspmap_mgpu_begin(m.h, n, pts.data_ptr(), self.n_birth, bptr, C.cast(pos_a, C.c_void_p),
+                                            float(stamp), C.cast(q_a, C.c_void_p)))
+
+    def export(self, direction):
+        m = self.map
+        n = C.c_int()
+        buf = self.exp_buf[direction]
+        m._chk(m.L.dspmap_mgpu_export(m.h, direction, buf.data_ptr(), self.exp_cap, C.byref(n)))
+        return buf[:n.value]
+
+    def import_(self, rec):
+        if rec.shape[0]:
+            rec = rec.contiguous()
+            self.map._chk(self.map.L.dspmap_mgpu_import(self.map.h, int(rec.shape[0]), rec.data_ptr()))
+            self.map.sync()  # `rec` may be a temporary
+
+    def ck_partial(self):
+        self.map._chk(self.map.L.dspmap_mgpu_ck_partial(self.map.h))
+        self.map.sync()
+        return self.ck
+
+    def weights_and_split(self):
+        self.map._chk(self.map.L.dspmap_mgpu_weights_and_split(self.map.h))
+        self.map.sync()
+        return self.nstatic[:self.n_birth]
+
+    def finish(self):
+        self.map._chk(self.map.L.dspmap_mgpu_finish(self.map.h))
+
+    def results(self):
+        return self.map.results()
+
+    def sync(self):
+        self.map.sync()
+
+
+# --------------------------------------------------------------------------- driver
+class ShardedDSPMap:
+    """update() over the slabs this process owns (one per rank with TorchDistComm; all with LocalComm)"""
+
+    def __init__(self, slabs, comm):
+        self.slabs = list(slabs)
+        self.comm = comm
+        self.local = isinstance(comm, LocalComm)
+        if not self.local:
+            assert len(self.slabs) == 1
+
+    def update(self, pts, pos, stamp, quat, birth=None):
+        rcs = [s.begin(pts, pos, stamp, quat, birth) for s in self.slabs]
+        if any(rc == 0 for rc in rcs):
+            return 0
+        # (1) particles that crossed a slab face
+        ups = [s.export(+1) for s in self.slabs]
+        downs = [s.export(-1) for s in self.slabs]
+        if self.local:
+            for i, s in enumerate(self.slabs):
+                if i > 0:
+                    s.import_(ups[i - 1])
+                if i < len(self.slabs) - 1:
+                    s.import_(downs[i + 1])
+        else:
+            below, above = self.comm.exchange(ups[0], downs[0])
+            self.slabs[0].import_(below)
+            self.slabs[0].import_(above)
+        # (2) per-observation sums
+        cks = [s.ck_partial() for s in self.slabs]
+        if self.local:
+            tot = cks[0].clone()
+            for c in cks[1:]:
+                tot += c
+            for c in cks:
+                c.copy_(tot)
+        else:
+            self.comm.allreduce_sum(cks[0])
+        # (3) n_static of the birth sources
+        ns = [s.weights_and_split() for s in self.slabs]
+        if self.local:
+            mx = ns[0].clone()
+            for t in ns[1:]:
+                mx = torch.maximum(mx, t)
+            for t in ns:
+                t.copy_(mx)
+        else:
+            self.comm.allreduce_max(ns[0])
+        for s in self.slabs:
+            s.finish()
+        return 1
+
+    def sync(self):
+        for s in self.slabs:
+            s.sync()

@@ -213,22 +213,31 @@ int dspmap_stage_resample(dspmap_t* m);                                         
 int dspmap_get_observations(dspmap_t* m, float* obs_out_host /* [NP][100][5] */, int* count_out_host /* [NP] */,
                             float* max_len_out_host /* [NP] */, float* expected_newborn_out);
 int dspmap_set_expected_newborn(dspmap_t* m, float v);
+/* particles registered per pyramid by the last prediction (size of each pyramids_in_fov list, :124) */
+int dspmap_get_pyramid_counts(dspmap_t* m, int* count_out_host /* [NP] */);
 
-/* ---- multi-GPU split-phase frame (Z-slab sharding; no counterpart in the
- * single-process reference).  The caller (one process per GPU) runs
- *   begin -> exchange movers -> import_movers -> ck_partial -> all-reduce(sum) Ck
- *   -> finish
- * with the collectives done by the caller (RCCL via torch.distributed).
- * Buffers are device pointers owned by the caller. ---- */
+/* ---- multi-GPU split-phase frame (Z-slab sharding; the single-process reference has no
+ * counterpart).  One process per GPU owns the voxel layers [z_lo, z_hi) (dspmap_config).  Every
+ * rank is fed the same cloud and pose; per frame the caller runs
+ *     begin -> export(+1), export(-1) -> [send to rank+1 / rank-1] -> import
+ *           -> ck_partial -> [all-reduce SUM over the bound Ck buffer]
+ *           -> weights_and_split -> [all-reduce MAX over the bound n_static buffer]
+ *           -> finish
+ * and issues the collectives itself (RCCL through torch.distributed).  What crosses slabs:
+ *  (1) particles whose new voxel lies in another slab after prediction (vz == 0, so only the
+ *      ego-motion's z component moves particles across layers, dsp_dynamic.h:661-667);
+ *  (2) the per-observation sums Ck, because pyramids cut across slabs (:709-735);
+ *  (3) n_static of each birth source, known only to the rank owning the source's voxel (:827-866).
+ * Records are 8 floats {global voxel index (int bits), vx, vy, px, py, pz, w, 0}. */
+int dspmap_mgpu_bind(dspmap_t* m, float* ck_dev /* [NP*100] */, int* nstatic_dev, int nstatic_cap);
 int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_dev, int n_birth,
                       const dspmap_vpoint* birth_dev, const float sensor_pos[3],
-                      double time_stamp_second, const float quat_wxyz[4]);
-/* movers that left the slab: records of 8 floats {gvoxel(as int bits), vx, vy, px, py, pz, w, 0};
- * dir = +1 (through z_hi) or -1 (through z_lo).  Returns the device buffer + count (host sync). */
-int dspmap_mgpu_get_exports(dspmap_t* m, int dir, const float** rec_dev, int* n_out);
-int dspmap_mgpu_import_movers(dspmap_t* m, int n, const float* rec_dev);
-int dspmap_mgpu_ck_partial(dspmap_t* m, float** ck_dev, int* n_floats); /* [NP*100] partial sums, to be all-reduced in place */
-int dspmap_mgpu_nstatic_partial(dspmap_t* m, int** nstatic_dev, int* n_ints); /* per birth point, all-reduce(max) in place */
+                      double time_stamp_second, const float quat_wxyz[4]);   /* 1 / 0 like dspmap_update */
+int dspmap_mgpu_export(dspmap_t* m, int dir /* +1 through z_hi, -1 through z_lo */, float* rec_dev_out,
+                       int cap, int* n_out);                                 /* synchronises */
+int dspmap_mgpu_import(dspmap_t* m, int n, const float* rec_dev);
+int dspmap_mgpu_ck_partial(dspmap_t* m);
+int dspmap_mgpu_weights_and_split(dspmap_t* m);
 int dspmap_mgpu_finish(dspmap_t* m);
 
 #ifdef __cplusplus

@@ -79,6 +79,7 @@ struct dsp_oracle {
     float* cloud_view; int cloud_view_n, cloud_view_cap;      /* cloud_in_current_view_rotated :130 */
     dspo_vpoint* birth; int birth_n, birth_cap;               /* input_cloud_with_velocity :134 */
     int use_vel_est;
+    const int* nstatic_override;
     cluster_feature* last_clusters; int last_clusters_n;      /* clusters_feature_vector_dynamic_last :1401 */
 };
 
@@ -541,8 +542,8 @@ void dspo_map_prediction(dsp_oracle* o, float odx, float ody, float odz, float d
 }
 
 /* ------------------------------------------------------------------ update */
-/* mapUpdate :704-793 */
-void dspo_map_update(dsp_oracle* o) {
+/* mapUpdate :704-793, pass 1 (:709-735) without the final += (lambda + kappa) of :737 */
+static void map_update_pass1(dsp_oracle* o, int add_const) {
     for (int i = 0; i < o->np; ++i) { /* pass 1, :709-739 */
         for (int j = 0; j < o->obs_count[i]; ++j) {
             float* ob = OBS(o, i, j);
@@ -560,9 +561,12 @@ void dspo_map_update(dsp_oracle* o) {
                     }
                 }
             }
-            ob[3] += (o->expected_new_born_objects + o->kappa); /* :737 */
+            if (add_const) ob[3] += (o->expected_new_born_objects + o->kappa); /* :737 */
         }
     }
+}
+/* mapUpdate pass 2 (:743-790) */
+static void map_update_pass2(dsp_oracle* o) {
     for (int i = 0; i < o->np; i++) { /* pass 2, :743-790 */
         for (int s = 0; s < o->capp; s++) {
             const int* e = PYR(o, i, s);
@@ -589,6 +593,75 @@ void dspo_map_update(dsp_oracle* o) {
         }
     }
 }
+/* mapUpdate :704-793 */
+void dspo_map_update(dsp_oracle* o) {
+    map_update_pass1(o, 1);
+    map_update_pass2(o);
+}
+/* The two halves of mapUpdate, callable separately (test infrastructure for the Z-slab sharding
+ * test: the per-observation sums of the slabs are added between them).  ck: pass 1 without the
+ * constant of :737; weights: adds that constant, then pass 2. */
+void dspo_map_update_ck(dsp_oracle* o) { map_update_pass1(o, 0); }
+void dspo_map_update_weights(dsp_oracle* o) {
+    for (int i = 0; i < o->np; ++i)
+        for (int j = 0; j < o->obs_count[i]; ++j) OBS(o, i, j)[3] += (o->expected_new_born_objects + o->kappa);
+    map_update_pass2(o);
+}
+
+/* Dempster-Shafer static/dynamic split of one birth source (:822-866).  Returns 0 if the source
+ * lies outside the map (:827,847). */
+static int birth_nstatic(dsp_oracle* o, float cx, float cy, float cz, int* out) {
+    int pv;
+    float ws = 0.f, wd = 0.f, wsd = 0.f;
+    if (dspo_voxel_index(o, cx, cy, cz, &pv)) { /* :827 */
+        for (int kk = 0; kk < o->slots; ++kk) {
+            const float* r = PART(o, pv, kk);
+            if (r[0] > 0.9f && r[0] < 14.f) { /* :830 */
+                float v_abs = fabsf(r[1]) + fabsf(r[2]) + fabsf(r[3]);
+                if (v_abs < 0.1f) ws += r[7];
+                else if (v_abs < 0.5f) wsd += r[7];
+                else wd += r[7];
+            }
+        }
+    } else {
+        return 0;
+    }
+    /* Dempster-Shafer :850-866 */
+    float total = ws + wd + wsd;
+    float m_s = ws / total, m_d = wd / total, m_sd = wsd / total;
+    float p_s = (m_s + m_s + m_sd) * 0.5f;
+    float p_d = (m_d + m_d + m_sd) * 0.5f;
+    float p_s_n = p_s / (p_s + p_d);
+    float fstat = (float)o->model_generated_nb * p_s_n;
+    /* (int) of NaN when the voxel is empty: cvttss2si gives INT_MIN on x86,
+     * so max(min_static, .) picks min_static. */
+    int n_static = (fstat != fstat) ? INT_MIN : (int)fstat;
+    if (n_static < o->min_static_nb) n_static = o->min_static_nb; /* :866 */
+    *out = n_static;
+    return 1;
+}
+
+static void birth_statics_init(dsp_oracle* o) {
+    if (!o->nb_statics_init) { /* function statics frozen at first call :808-811 */
+        const int n_nb = o->new_born_particle_number_each_point;
+        o->min_static_nb = (int)((float)n_nb * 0.15f);
+        o->model_generated_nb = (int)((float)n_nb * 0.8f);
+        o->nb_statics_init = 1;
+    }
+}
+/* test infrastructure for the Z-slab sharding test: n_static of every birth source as this
+ * instance sees it (0 for sources outside the map), and an override used by dspo_add_newborn */
+void dspo_compute_nstatic(dsp_oracle* o, int* out) {
+    birth_statics_init(o);
+    for (int q = 0; q < o->birth_n; q++) {
+        const dspo_vpoint* pt = &o->birth[q];
+        int ns = 0;
+        if (!birth_nstatic(o, pt->x - o->current_position[0], pt->y - o->current_position[1],
+                           pt->z - o->current_position[2], &ns)) ns = 0;
+        out[q] = ns;
+    }
+}
+void dspo_set_nstatic_override(dsp_oracle* o, const int* arr) { o->nstatic_override = arr; }
 
 /* ------------------------------------------------------------------- birth */
 /* mapAddNewBornParticlesByObservation :796-921 */
@@ -598,42 +671,15 @@ void dspo_add_newborn(dsp_oracle* o) {
         for (int j = 0; j < o->obs_count[i]; j++) norm += 1.f / OBS(o, i, j)[3];
     float w_new = o->new_born_particle_weight * norm;
     const int n_nb = o->new_born_particle_number_each_point;
-    if (!o->nb_statics_init) { /* function statics frozen at first call :808-811 */
-        o->min_static_nb = (int)((float)n_nb * 0.15f);
-        o->model_generated_nb = (int)((float)n_nb * 0.8f);
-        o->nb_statics_init = 1;
-    }
+    birth_statics_init(o);
     for (int q = 0; q < o->birth_n; q++) { /* :815 */
         const dspo_vpoint* pt = &o->birth[q];
         float cx = pt->x - o->current_position[0]; /* :818-820 */
         float cy = pt->y - o->current_position[1];
         float cz = pt->z - o->current_position[2];
-        int pv;
-        float ws = 0.f, wd = 0.f, wsd = 0.f;
-        if (dspo_voxel_index(o, cx, cy, cz, &pv)) { /* :827 */
-            for (int kk = 0; kk < o->slots; ++kk) {
-                const float* r = PART(o, pv, kk);
-                if (r[0] > 0.9f && r[0] < 14.f) { /* :830 */
-                    float v_abs = fabsf(r[1]) + fabsf(r[2]) + fabsf(r[3]);
-                    if (v_abs < 0.1f) ws += r[7];
-                    else if (v_abs < 0.5f) wsd += r[7];
-                    else wd += r[7];
-                }
-            }
-        } else {
-            continue; /* :847 */
-        }
-        /* Dempster-Shafer :850-866 */
-        float total = ws + wd + wsd;
-        float m_s = ws / total, m_d = wd / total, m_sd = wsd / total;
-        float p_s = (m_s + m_s + m_sd) * 0.5f;
-        float p_d = (m_d + m_d + m_sd) * 0.5f;
-        float p_s_n = p_s / (p_s + p_d);
-        float fstat = (float)o->model_generated_nb * p_s_n;
-        /* (int) of NaN when the voxel is empty: cvttss2si gives INT_MIN on x86,
-         * so max(min_static, .) picks min_static. */
-        int n_static = (fstat != fstat) ? INT_MIN : (int)fstat;
-        if (n_static < o->min_static_nb) n_static = o->min_static_nb; /* :866 */
+        int n_static;
+        if (!birth_nstatic(o, cx, cy, cz, &n_static)) continue; /* :847 */
+        if (o->nstatic_override) n_static = o->nstatic_override[q];
         for (int p = 0; p < n_nb; p++) { /* :868 */
             float px = cx + draw_p(o);
             float py = cy + draw_p(o);

@@ -107,6 +107,11 @@ void dspo_set_current_position(dsp_oracle* o, float x, float y, float z); /* cur
 void dspo_map_prediction(dsp_oracle* o, float dx, float dy, float dz, float dt); /* :627-701 */
 void dspo_map_update(dsp_oracle* o);                                            /* :704-793 */
 void dspo_add_newborn(dsp_oracle* o);                                           /* :796-921 */
+/* halves of mapUpdate + n_static hooks: test infrastructure for the Z-slab sharding test */
+void dspo_map_update_ck(dsp_oracle* o);      /* pass 1 (:709-735) without the constant of :737 */
+void dspo_map_update_weights(dsp_oracle* o); /* += lambda+kappa (:737), then pass 2 (:743-790) */
+void dspo_compute_nstatic(dsp_oracle* o, int* out);
+void dspo_set_nstatic_override(dsp_oracle* o, const int* arr);
 void dspo_occupancy_resample(dsp_oracle* o);                                    /* :924-1057 */
 void dspo_velocity_estimation(dsp_oracle* o);                                   /* :1377-1544 */
 

@@ -73,6 +73,10 @@ def _load(fast=False):
         "dspo_set_current_position": (None, [P, f, f, f]),
         "dspo_map_prediction": (None, [P, f, f, f, f]),
         "dspo_map_update": (None, [P]),
+        "dspo_map_update_ck": (None, [P]),
+        "dspo_map_update_weights": (None, [P]),
+        "dspo_compute_nstatic": (None, [P, P]),
+        "dspo_set_nstatic_override": (None, [P, P]),
         "dspo_add_newborn": (None, [P]),
         "dspo_occupancy_resample": (None, [P]),
         "dspo_velocity_estimation": (None, [P]),

@@ -90,3 +90,23 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 t = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_py" not in t and "dsp_oracle" not in t and "dspo_" not in t, f
+
+
+def test_dropin_header_compiles_without_ros(dsp):
+    """include/dsp_dynamic.h (ours) offers the reference's DSPMap surface; the ROS-free twin of
+    src/map_sim_example.cpp must compile and link against libdspmap_hip.so"""
+    exe = os.path.join(ROOT, "examples", "map_example")
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "map_example.cpp"),
+                           "-L" + os.path.join(ROOT, "dsp-map_amd", "lib"), "-ldspmap_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "dsp-map_amd", "lib"), "-o", exe])
+    hdr = open(os.path.join(ROOT, "include", "dsp_dynamic.h")).read()
+    for member in ("int update(int point_cloud_num, int size_of_one_point, float* point_cloud_ptr",
+                   "void setPredictionVariance(float p_stddev, float v_stddev)", "void setObservationStdDev(",
+                   "void setNewBornParticleWeight(", "void setNewBornParticleNumberofEachPoint(",
+                   "void setParticleRecordFlag(", "static void setOriginalVoxelFilterResolution(",
+                   "void getOccupancyMap(int& obstacles_num", "void getOccupancyMapWithFutureStatus(int& obstacles_num",
+                   "void clearOccupancyMapPrediction()", "void getKMClusterResult(",
+                   "void mapAddNewBornParticlesByObservation()", "static float generateRandomFloat(",
+                   "void getVoxelPositionFromIndexPublic(", "int getPointVoxelsIndexPublic(", "void getFutureStatus("):
+        assert member in hdr, member

@@ -1,0 +1,105 @@
+"""GPU tests of the Z-slab path through the C ABI (dspmap_mgpu_*): several slabs on ONE GPU in one
+process (LocalComm) against the unsharded HIP map and the oracle, and the drop-in C++ example."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _stream(n_frames, seed=5):
+    rng = np.random.default_rng(seed)
+    ys, zs = np.meshgrid(np.linspace(-2.0, 2.0, 41), np.linspace(-1.0, 1.0, 21))
+    base = np.stack([np.full(ys.size, 2.2) + 0.2 * np.sin(2 * ys.ravel()), ys.ravel(), zs.ravel()], 1).astype(np.float32)
+    out = []
+    for f in range(n_frames):
+        t = f / 30.0
+        pts = base + rng.normal(0, 0.005, base.shape).astype(np.float32)
+        out.append((pts, (0.4 * t, 0.0, 0.1 * np.sin(5 * t)), t, (1.0, 0.0, 0.0, 0.0)))
+    return out
+
+
+@pytest.mark.parametrize("world,ppv", [(2, 12), (4, 36)])
+def test_slabs_on_one_gpu_match_unsharded(dsp, orc, world, ppv):
+    sharded = __import__("dsp-map_amd.sharded", fromlist=["ShardedDSPMap"])
+    cfg = dict(nx=40, ny=40, nz=24, res=0.15, ppv=ppv)
+    tables = common.tables(3)
+    slabs = []
+    for (z_lo, z_hi) in sharded.slab_ranges(cfg["nz"], world):
+        s = sharded.HipSlab(dsp, cfg, z_lo, z_hi, 0)
+        s.map.set_tables(*tables)
+        slabs.append(s)
+    sm = sharded.ShardedDSPMap(slabs, sharded.LocalComm())
+    full = dsp.DSPMap(dsp.make_config(**cfg))
+    full.set_tables(*tables)
+    o = orc.Oracle(orc.make_config(**cfg))
+    o.set_tables(*tables)
+    o.L.dspo_use_velocity_estimator(o.h, 2)
+    crossed = 0
+    for pts, pos, t, q in _stream(8):
+        d = torch.from_numpy(pts).cuda()
+        assert sm.update(d, pos, t, q) == 1
+        assert full.update(pts, pos, t, q) == 1
+        assert o.update(pts, pos, t, q) == 1
+        sm.sync()
+        crossed += sum(s.map.counters()["n_exported_up"] for s in slabs)
+    got = np.concatenate([s.results() for s in slabs], 0)
+    want = full.results()
+    ref = o.results[:, :4]
+    for other, name in ((want, "unsharded HIP"), (ref, "oracle")):
+        m_o, m_g = other[:, 0].astype(np.float64).sum(), got[:, 0].astype(np.float64).sum()
+        assert abs(m_g - m_o) < 5e-3 * m_o, name
+        close = np.abs(got[:, 0] - other[:, 0]) <= 1e-3 * np.maximum(1.0, np.abs(other[:, 0]))
+        assert close.mean() > 0.97, (name, close.mean())
+    live = sum(s.map.counters()["n_live_out"] for s in slabs)
+    assert abs(live - full.counters()["n_live_out"]) <= 0.02 * live
+    # every slab only holds particles of its own layers
+    for s in slabs:
+        v, _, _ = s.map.export_state()
+        if len(v):
+            lay = v // (cfg["nx"] * cfg["ny"])
+            assert lay.min() >= s.z_lo and lay.max() < s.z_hi
+    o.close(); full.close()
+
+
+def test_first_frame_slabs_equal_unsharded_exactly(dsp):
+    """frame 0 has no exchange and identical Ck -> every slab must hold exactly the unsharded result"""
+    sharded = __import__("dsp-map_amd.sharded", fromlist=["ShardedDSPMap"])
+    cfg = dict(nx=40, ny=40, nz=24, res=0.15, ppv=12)
+    tables = common.tables(4)
+    slabs = []
+    for (z_lo, z_hi) in sharded.slab_ranges(cfg["nz"], 3):
+        s = sharded.HipSlab(dsp, cfg, z_lo, z_hi, 0)
+        s.map.set_tables(*tables)
+        slabs.append(s)
+    sm = sharded.ShardedDSPMap(slabs, sharded.LocalComm())
+    full = dsp.DSPMap(dsp.make_config(**cfg))
+    full.set_tables(*tables)
+    pts, pos, t, q = _stream(1)[0]
+    assert sm.update(torch.from_numpy(pts).cuda(), pos, t, q) == 1
+    assert full.update(pts, pos, t, q) == 1
+    got = np.concatenate([s.results() for s in slabs], 0)
+    want = full.results()
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-7)
+    a = np.concatenate([np.column_stack(s.map.export_state()[0:2]) for s in slabs])
+    b = np.column_stack(full.export_state()[0:2])
+    assert np.array_equal(a[np.lexsort((a[:, 1], a[:, 0]))], b)  # same particles in the same slots
+    full.close()
+
+
+def test_dropin_example_runs(dsp):
+    exe = os.path.join(ROOT, "examples", "map_example")
+    subprocess.check_call(["g++", "-std=c++14", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "map_example.cpp"),
+                           "-L" + os.path.join(ROOT, "dsp-map_amd", "lib"), "-ldspmap_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "dsp-map_amd", "lib"), "-o", exe])
+    out = subprocess.check_output([exe, "12"]).decode()
+    assert "Map is ready to update!" in out and "occupied" in out
+    occ = int(out.split("occupied")[1].split()[0])
+    assert occ > 50
