@@ -70,13 +70,22 @@ class TorchDistComm:
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+            if self.device.type == "cuda":
+                torch.cuda.current_stream(self.device).synchronize()
         return from_below, from_above
+
+    def _done(self):
+        # the library runs on its own stream: make sure the collective has landed before it reads
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
 
     def allreduce_sum(self, t):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        self._done()
 
     def allreduce_max(self, t):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        self._done()
 
 
 class LocalComm:
