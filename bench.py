@@ -137,9 +137,11 @@ def main():
         barrier()
         t0 = time.perf_counter()
         run_frames(m, frames[prefill + warmup:prefill + warmup + steps])
+        t_issue = time.perf_counter() - t0   # host time to enqueue the frames (launch-bound if ~= dt)
         m.sync()
         barrier()
         dt = time.perf_counter() - t0
+        measure.host_issue_ms = t_issue / steps * 1e3
         cnt = m.counters()
         stage = None
         if profile:
@@ -226,6 +228,7 @@ def main():
                                                                 "2 small all-reduces per frame" % world,
                    "n_points": int(frames[-1][0].shape[0])},
         "roofline": roof,
+        "host_enqueue_ms_per_step": round(getattr(measure, "host_issue_ms", 0.0), 5),
         "frame": {"b_alg_bytes": int(balg), "b_alg_GBps": round(balg / (ms * 1e-3) / 1e9, 3),
                   "frac_of_8TBps": round(balg / (ms * 1e-3) / 1e9 / peak, 6),
                   "stage_ms": {k: round(v, 5) for k, v in stage.items()} if stage else None,

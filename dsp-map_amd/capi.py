@@ -18,7 +18,7 @@ MAX_PRED = 16
 OK, REJECTED = 1, 0
 
 P_POSITION_STDDEV, P_VELOCITY_STDDEV, P_OBSERVATION_STDDEV, P_NEWBORN_WEIGHT, P_NEWBORN_NUMBER, \
-    P_VOXEL_FILTER_RES, P_KAPPA, P_DETECTION, P_VELOCITY_ESTIMATOR, P_REGENERATE_TABLES = range(1, 11)
+    P_VOXEL_FILTER_RES, P_KAPPA, P_DETECTION, P_VELOCITY_ESTIMATOR, P_REGENERATE_TABLES, P_USE_GRAPH = range(1, 12)
 
 
 class Config(C.Structure):
@@ -314,7 +314,7 @@ class DSPMap:
         self._chk(self.L.dspmap_get_counters(self.h, C.byref(c)))
         return c.as_dict()
 
-    STAGES = ("setup+bin", "predict", "claim", "ck_partial", "ck_finalize", "weight", "birth", "resample")
+    STAGES = ("setup+bin", "predict", "claim", "ck_partial", "weight", "ck_finalize", "birth", "resample")
 
     def set_profiling(self, on=True):
         self._chk(self.L.dspmap_set_profiling(self.h, 1 if on else 0))

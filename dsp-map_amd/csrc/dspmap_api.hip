@@ -128,12 +128,14 @@ static void free_dev(dspmap* m) {
     DevState& s = m->s;
     if (m->mgpu_bound) { s.obs_ck = nullptr; s.nstatic = nullptr; }  // caller-owned
     if (m->mgpu_count) (void)hipFree(m->mgpu_count);
-    void* ptrs[] = {s.fut_stat, s.mask, s.nbmask, s.px, s.py, s.pz, s.vx, s.vy, s.w, s.vz0, s.res4, s.fut, s.obs, s.obs_ck,
+    void* ptrs[] = {s.fpar, s.obs_ckf, s.part_inv, s.fut_stat, s.mask, s.nbmask, s.px, s.py, s.pz, s.vx, s.vy, s.w, s.vz0, s.res4, s.fut, s.obs, s.obs_ck,
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.nstatic, s.fov_rec, s.fov_slot, s.pyr_cnt, s.mv_rec, s.exp_up, s.exp_down,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mvmask, m->k.expmask,
                     m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.work_count, m->k.child, m->pts_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    if (m->graph) (void)hipGraphDestroy(m->graph);
     if (m->pts_pin) (void)hipHostFree(m->pts_pin);
     if (m->birth_pin) (void)hipHostFree(m->birth_pin);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
@@ -178,6 +180,7 @@ static void gen_rand_table(dspmap* m, unsigned seed) {
 
 static int upload_tables(dspmap* m) {
     DevState& s = m->s;
+    m->graph_epoch++;
     if (s.p_tab) { (void)hipFree(s.p_tab); s.p_tab = nullptr; }
     if (s.v_tab) { (void)hipFree(s.v_tab); s.v_tab = nullptr; }
     const size_t n = m->h_ptab.size();
@@ -190,6 +193,7 @@ static int upload_tables(dspmap* m) {
 }
 static int upload_rtab(dspmap* m) {
     DevState& s = m->s;
+    m->graph_epoch++;
     if (s.r_tab) { (void)hipFree(s.r_tab); s.r_tab = nullptr; }
     const size_t n = m->h_rtab.size();
     HIPCHK(m, dalloc(&s.r_tab, n));
@@ -200,6 +204,7 @@ static int upload_rtab(dspmap* m) {
 
 int dspmap_ensure_point_cap(dspmap* m, int n) {
     if (n <= m->pt_cap) return DSPMAP_OK;
+    m->graph_epoch++;
     HIPCHK(m, hipStreamSynchronize(m->stream));
     DevState& s = m->s;
     const int cap = n + n / 2 + 1024;
@@ -243,6 +248,10 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, hipMemset(s.vx, 0, sizeof(float) * S)); HIPCHK(m, hipMemset(s.vy, 0, sizeof(float) * S)); HIPCHK(m, hipMemset(s.w, 0, sizeof(float) * S));
     HIPCHK(m, dalloc(&s.obs, (size_t)d.np * DSP_OBS_CAP));
     HIPCHK(m, dalloc(&s.obs_ck, (size_t)d.np * DSP_OBS_CAP));
+    HIPCHK(m, dalloc(&s.obs_ckf, (size_t)d.np * DSP_OBS_CAP));
+    HIPCHK(m, dalloc(&s.part_inv, (size_t)d.np));
+    HIPCHK(m, hipMemset(s.obs_ckf, 0, sizeof(float) * d.np * DSP_OBS_CAP));
+    HIPCHK(m, hipMemset(s.part_inv, 0, sizeof(float) * d.np));
     HIPCHK(m, dalloc(&s.obs_cnt, (size_t)d.np));
     HIPCHK(m, dalloc(&s.obs_maxlen, (size_t)d.np));
     HIPCHK(m, dalloc(&s.planes_h, (size_t)(d.np_h + 1) * 3)); HIPCHK(m, dalloc(&s.planes_v, (size_t)(d.np_v + 1) * 3));
@@ -251,6 +260,8 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&s.fov_slot, (size_t)d.np * d.capp));
     HIPCHK(m, dalloc(&s.pyr_cnt, (size_t)d.np));
     HIPCHK(m, dalloc(&s.fs, (size_t)1));
+    HIPCHK(m, dalloc(&s.fpar, (size_t)1));
+    HIPCHK(m, hipMemset(s.fpar, 0, sizeof(FrameParams)));
     KernelScratch& k = m->k;
     k.ntiles = (int)ntiles;
     k.nblk_sweep = (int)((ntiles + 3) / 4);  // k_resample: 4 tiles (waves) per 256-thread block
@@ -326,12 +337,14 @@ extern "C" int dspmap_set_stream(dspmap_t* m, void* hip_stream) {
     if (m->device_ready) HIPCHK(m, hipStreamSynchronize(m->stream));
     if (m->own_stream && m->stream) { (void)hipStreamDestroy(m->stream); m->own_stream = false; }
     m->stream = (hipStream_t)hip_stream;
+    m->graph_epoch++;
     return DSPMAP_OK;
 }
 
 // ------------------------------------------------------------------ setters
 extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
     if (!m) return DSPMAP_E_ARG;
+    m->graph_epoch++;
     switch (key) {
         case DSPMAP_P_POSITION_STDDEV: m->p_stddev = (float)v; break;
         case DSPMAP_P_VELOCITY_STDDEV: m->v_stddev = (float)v; break;
@@ -344,6 +357,7 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
         case DSPMAP_P_KAPPA: m->fp.kappa = (float)v; break;
         case DSPMAP_P_DETECTION: m->fp.p_det = (float)v; break;
         case DSPMAP_P_VELOCITY_ESTIMATOR: m->use_vel_est = v != 0; break;
+        case DSPMAP_P_USE_GRAPH: m->use_graph = v != 0; break;
         case DSPMAP_P_REGENERATE_TABLES:
             // setPredictionVariance regenerates both tables with a fresh seed (:355-360)
             if (v != 0 && !m->tables_injected) {
@@ -428,10 +442,22 @@ extern "C" int dspmap_get_cursors(dspmap_t* m, int* pc, int* vc, int* rc) {
 
 // --------------------------------------------------------------- the frame
 void dspmap_freeze_birth_statics(dspmap* m) {
-    if (m->nb_frozen) return;  // function statics initialised at first call (:808-811)
+    if (m->nb_frozen) return;
+    m->graph_epoch++;  // function statics initialised at first call (:808-811)
     m->fp.min_static_nb = (int)((float)m->fp.nb_num * 0.15f);
     m->fp.model_nb = (int)((float)m->fp.nb_num * 0.8f);
     m->nb_frozen = true;
+}
+
+int dspmap_push_frame_params(dspmap* m) {
+    // pageable source: the runtime stages the bytes before returning, so m->hp can be reused at once
+    HIPCHK(m, hipMemcpyAsync(m->s.fpar, &m->hp, sizeof(FrameParams), hipMemcpyHostToDevice, m->stream));
+    return DSPMAP_OK;
+}
+static void fill_pose(dspmap* m, const float dp[3], float dt) {
+    for (int i = 0; i < 4; i++) m->hp.quat[i] = m->quat[i];
+    for (int i = 0; i < 3; i++) { m->hp.cur_pos[i] = m->cur_pos[i]; m->hp.od[i] = -dp[i]; }  // particles move opposite to the sensor (:300)
+    m->hp.dt = dt;
 }
 
 // C0 gate + deltas, update() :187-218.  returns 1 (accepted) / 0 (rejected)
@@ -458,25 +484,27 @@ int dspmap_gate_and_delta(dspmap* m, const float pos[3], double stamp, const flo
     return 1;
 }
 
-// enqueue the stages after binning; birth source already selected in c.s.birth
-static void enqueue_filter(dspmap* m, LaunchCtx& c, const float dp[3], float dt, int n_birth) {
+// enqueue one whole device-resident frame (setup .. resample); every per-frame value is read from s.fpar
+static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid) {
+    dspmap_prof_mark(m, 0);
+    launch_frame_setup(c, true);
+    launch_obs_bin(c, pts_grid);
     dspmap_prof_mark(m, 1);
-    launch_predict_only(c, -dp[0], -dp[1], -dp[2], dt);  // particles move opposite to the sensor (:300)
+    launch_predict_only(c);
     dspmap_prof_mark(m, 2);
     launch_claim(c);
     dspmap_prof_mark(m, 3);
     launch_ck_partial(c);
     dspmap_prof_mark(m, 4);
-    launch_ck_finalize(c);
-    dspmap_prof_mark(m, 5);
     launch_weight_update(c);
+    dspmap_prof_mark(m, 5);
+    launch_ck_finalize(c);
     dspmap_prof_mark(m, 6);
-    launch_birth(c, n_birth, false);
+    launch_birth(c, birth_grid, false);
     dspmap_prof_mark(m, 7);
     launch_resample(c);
     dspmap_prof_mark(m, 8);
     if (m->prof) m->prof_pending = true;
-    if (m->vz_frames > 0) --m->vz_frames;
 }
 
 extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* points_dev, int n_birth,
@@ -490,16 +518,35 @@ extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* poin
     if (rc != DSPMAP_OK) return rc;
     dspmap_freeze_birth_statics(m);
     LaunchCtx c = dspmap_ctx_of(m);
-    if (m->vz_frames <= 0) c.s.vz0 = nullptr;
+    const bool has_vz = m->vz_frames > 0;
+    if (!has_vz) c.s.vz0 = nullptr;
     const bool static_birth = birth_dev == nullptr;
-    if (!static_birth) c.s.birth = (BirthSrc*)birth_dev;
     const int nb = static_birth ? n_points : n_birth;
+    fill_pose(m, dp, dt);
+    m->hp.n_pts = n_points; m->hp.n_birth = nb; m->hp.static_birth = static_birth ? 1 : 0;
+    m->hp.pts = points_dev;
+    m->hp.birth = static_birth ? m->s.birth : (BirthSrc*)birth_dev;
+    rc = dspmap_push_frame_params(m);
+    if (rc != DSPMAP_OK) return rc;
     dspmap_prof_collect(m);
     HIPCHK(m, hipEventRecord(m->ev0, m->stream));
-    dspmap_prof_mark(m, 0);
-    launch_frame_setup(c, m->quat, m->cur_pos, true);
-    launch_obs_bin(c, n_points, points_dev, m->quat, static_birth);
-    enqueue_filter(m, c, dp, dt, nb);
+    if (m->use_graph && !m->prof) {
+        // the kernel arguments of a frame are constant (per-frame values live in s.fpar): capture once, replay
+        const unsigned long long key = ((unsigned long long)m->graph_epoch << 8) | (has_vz ? 1u : 0u);
+        if (!m->graph_exec || m->graph_key != key) {
+            if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+            if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+            HIPCHK(m, hipStreamBeginCapture(m->stream, hipStreamCaptureModeRelaxed));
+            enqueue_frame(m, c, m->pt_cap, m->birth_cap);  // grids sized for the capacity; kernels bound-check against fpar
+            HIPCHK(m, hipStreamEndCapture(m->stream, &m->graph));
+            HIPCHK(m, hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
+            m->graph_key = key;
+        }
+        HIPCHK(m, hipGraphLaunch(m->graph_exec, m->stream));
+    } else {
+        enqueue_frame(m, c, n_points, nb);
+    }
+    if (m->vz_frames > 0) --m->vz_frames;
     HIPCHK(m, hipEventRecord(m->ev1, m->stream));
     m->ev_valid = true;
     m->last_n_points = n_points;
@@ -513,7 +560,9 @@ static int stage_points(dspmap* m, int n, int stride, const float* pts) {
     int rc = dspmap_ensure_point_cap(m, n);
     if (rc != DSPMAP_OK) return rc;
     if (n > m->pts_pin_cap) {
-        if (m->pts_pin) (void)hipHostFree(m->pts_pin);
+        if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    if (m->graph) (void)hipGraphDestroy(m->graph);
+    if (m->pts_pin) (void)hipHostFree(m->pts_pin);
         m->pts_pin_cap = n + n / 2 + 1024;
         HIPCHK(m, hipHostMalloc((void**)&m->pts_pin, sizeof(float) * 3 * (size_t)m->pts_pin_cap));
     }
@@ -574,13 +623,18 @@ extern "C" int dspmap_update(dspmap_t* m, int n, int stride, const float* pts, f
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
     const bool have_cloud = m->use_vel_est || m->h_birth_valid;
+    fill_pose(m, dp, dt);
+    m->hp.n_pts = np; m->hp.n_birth = np; m->hp.static_birth = have_cloud ? 0 : 1;
+    m->hp.pts = m->pts_dev; m->hp.birth = m->s.birth;
+    rc = dspmap_push_frame_params(m);
+    if (rc != DSPMAP_OK) return rc;
     HIPCHK(m, hipEventRecord(m->ev0, m->stream));
-    launch_frame_setup(c, m->quat, m->cur_pos, true);
-    launch_obs_bin(c, np, m->pts_dev, m->quat, !have_cloud);
-    launch_predict(c, -dp[0], -dp[1], -dp[2], dt);
+    launch_frame_setup(c, true);
+    launch_obs_bin(c, np);
+    launch_predict(c);
     launch_ck_partial(c);
-    launch_ck_finalize(c);
     launch_weight_update(c);
+    launch_ck_finalize(c);
     int nb = np;
     if (m->use_vel_est) {
         // the reference forks velocityEstimationThread before prediction and joins before the birth
@@ -597,6 +651,9 @@ extern "C" int dspmap_update(dspmap_t* m, int n, int stride, const float* pts, f
         if (rc != DSPMAP_OK) return rc;
         c.s = m->s;  // pointers may have been re-allocated
         if (m->vz_frames <= 0) c.s.vz0 = nullptr;
+        m->hp.n_birth = nb; m->hp.birth = m->s.birth;
+        rc = dspmap_push_frame_params(m);
+        if (rc != DSPMAP_OK) return rc;
     }
     if (n >= 0) launch_birth(c, nb, false);  // :314-316
     launch_resample(c);
@@ -729,6 +786,7 @@ extern "C" int dspmap_get_counters(dspmap_t* m, dspmap_counters* out) {
 
 // ------------------------------------------------------------ state access
 static int ensure_vz(dspmap* m) {
+    m->graph_epoch++;
     if (!m->s.vz0) {
         const size_t S = (((size_t)m->d.v_loc + 63) / 64) * 64 * m->d.slots;
         HIPCHK(m, dalloc(&m->s.vz0, S));
@@ -833,8 +891,14 @@ extern "C" int dspmap_stage_bin_points(dspmap_t* m, int n, int stride, const flo
     int rc = stage_points(m, n, stride, pts);
     if (rc != DSPMAP_OK) return rc;
     LaunchCtx c = dspmap_ctx_of(m);
-    launch_frame_setup(c, m->quat, m->cur_pos, true);
-    launch_obs_bin(c, n, m->pts_dev, m->quat, !m->h_birth_valid);
+    for (int i = 0; i < 4; i++) m->hp.quat[i] = m->quat[i];
+    for (int i = 0; i < 3; i++) m->hp.cur_pos[i] = m->cur_pos[i];
+    m->hp.n_pts = n; m->hp.n_birth = n; m->hp.static_birth = m->h_birth_valid ? 0 : 1;
+    m->hp.pts = m->pts_dev; m->hp.birth = m->s.birth;
+    rc = dspmap_push_frame_params(m);
+    if (rc != DSPMAP_OK) return rc;
+    launch_frame_setup(c, true);
+    launch_obs_bin(c, n);
     m->last_n_points = n;
     if (!m->h_birth_valid) { m->last_n_birth = n; m->last_birth_static = true; }
     HIPCHK(m, hipGetLastError());
@@ -849,8 +913,13 @@ extern "C" int dspmap_stage_predict(dspmap_t* m, float dx, float dy, float dz, f
     READY(m);
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
-    launch_frame_setup(c, m->quat, m->cur_pos, false);
-    launch_predict(c, dx, dy, dz, dt);
+    for (int i = 0; i < 4; i++) m->hp.quat[i] = m->quat[i];
+    for (int i = 0; i < 3; i++) m->hp.cur_pos[i] = m->cur_pos[i];
+    m->hp.od[0] = dx; m->hp.od[1] = dy; m->hp.od[2] = dz; m->hp.dt = dt;
+    if (!m->hp.birth) m->hp.birth = m->s.birth;
+    { int rc = dspmap_push_frame_params(m); if (rc != DSPMAP_OK) return rc; }
+    launch_frame_setup(c, false);
+    launch_predict(c);
     if (m->vz_frames > 0) --m->vz_frames;
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
@@ -859,8 +928,8 @@ extern "C" int dspmap_stage_update(dspmap_t* m) {
     READY(m);
     LaunchCtx c = dspmap_ctx_of(m);
     launch_ck_partial(c);
-    launch_ck_finalize(c);
     launch_weight_update(c);
+    launch_ck_finalize(c);
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
 }
@@ -877,6 +946,9 @@ extern "C" int dspmap_stage_birth(dspmap_t* m) {
     }
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
+    for (int i = 0; i < 3; i++) m->hp.cur_pos[i] = m->cur_pos[i];
+    m->hp.n_birth = nb; m->hp.birth = m->s.birth;
+    { int rc = dspmap_push_frame_params(m); if (rc != DSPMAP_OK) return rc; }
     launch_birth(c, nb, false);
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
@@ -898,7 +970,7 @@ extern "C" int dspmap_get_observations(dspmap_t* m, float* obs_out, int* count_o
     std::vector<float> ck((size_t)d.np * DSP_OBS_CAP);
     std::vector<int> cnt(d.np);
     HIPCHK(m, hipMemcpy(o.data(), m->s.obs, sizeof(float4) * o.size(), hipMemcpyDeviceToHost));
-    HIPCHK(m, hipMemcpy(ck.data(), m->s.obs_ck, sizeof(float) * ck.size(), hipMemcpyDeviceToHost));
+    HIPCHK(m, hipMemcpy(ck.data(), m->s.obs_ckf, sizeof(float) * ck.size(), hipMemcpyDeviceToHost));
     HIPCHK(m, hipMemcpy(cnt.data(), m->s.obs_cnt, sizeof(int) * d.np, hipMemcpyDeviceToHost));
     if (count_out) memcpy(count_out, cnt.data(), sizeof(int) * d.np);
     if (maxlen_out) HIPCHK(m, hipMemcpy(maxlen_out, m->s.obs_maxlen, sizeof(float) * d.np, hipMemcpyDeviceToHost));

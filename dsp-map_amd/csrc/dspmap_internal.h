@@ -53,6 +53,14 @@ struct dspmap {
     int vz_frames = 0;
     int last_n_points = 0;
     VelocityEstimator vel;
+    // per-frame parameter block (host copy; pushed to s.fpar with one H2D copy per frame)
+    FrameParams hp = {};
+    // HIP graph of the device-resident frame (dspmap_update_device)
+    bool use_graph = true;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    unsigned long long graph_key = ~0ull;
+    unsigned graph_epoch = 0;   // bumped whenever a baked-in kernel argument (pointer / parameter) changes
     // multi-GPU split-phase state
     bool mgpu_bound = false;
     int mgpu_nstatic_cap = 0;
@@ -73,6 +81,7 @@ LaunchCtx dspmap_ctx_of(dspmap* m);
 int dspmap_gate_and_delta(dspmap* m, const float pos[3], double stamp, const float q[4], float dp[3], float* dt);
 void dspmap_freeze_birth_statics(dspmap* m);
 int dspmap_ensure_point_cap(dspmap* m, int n);
+int dspmap_push_frame_params(dspmap* m);   // m->hp -> device
 
 #define HIPCHK(m, call)                                                                            \
     do {                                                                                           \

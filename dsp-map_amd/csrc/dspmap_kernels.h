@@ -29,12 +29,12 @@ struct LaunchCtx {
 };
 
 // frame setup: rotate boundary planes (:226-232), reset per-frame counters/bins (:235-238)
-void launch_frame_setup(const LaunchCtx& c, const float quat[4], const float cur_pos[3], bool reset_obs);
+void launch_frame_setup(const LaunchCtx& c, bool reset_obs);
 // observation binning (:244-290)
-void launch_obs_bin(const LaunchCtx& c, int n_pts, const float* pts_dev, const float quat[4], bool make_static_birth);
+void launch_obs_bin(const LaunchCtx& c, int n_pts_grid);
 // mapPrediction (:627-701) incl. re-binning of movers (moveParticle :1206-1274)
-void launch_predict(const LaunchCtx& c, float odx, float ody, float odz, float dt);
-void launch_predict_only(const LaunchCtx& c, float odx, float ody, float odz, float dt);
+void launch_predict(const LaunchCtx& c);
+void launch_predict_only(const LaunchCtx& c);
 void launch_claim(const LaunchCtx& c);
 void launch_reduce_counters(const LaunchCtx& c);
 // multi-GPU: compact particles that left the slab / insert particles received from a neighbour

@@ -24,8 +24,9 @@
 //  RESET_OBS   : zero per-pyramid observation counters, max range = -1 (:235-238), Ck = 0
 //  RESET_PRED  : zero the per-pyramid particle counters (pyramids are rebuilt by prediction, :638-642)
 // --------------------------------------------------------------------------
-__global__ void k_reset(MapDims d, DevState s, int flags, float qw, float qx, float qy, float qz,
-                        float cx, float cy, float cz) {
+__global__ void k_reset(MapDims d, DevState s, int flags) {
+    const float qw = s.fpar->quat[0], qx = s.fpar->quat[1], qy = s.fpar->quat[2], qz = s.fpar->quat[3];
+    const float cx = s.fpar->cur_pos[0], cy = s.fpar->cur_pos[1], cz = s.fpar->cur_pos[2];
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     const int gn = gridDim.x * blockDim.x;
     if (flags & RESET_PLANES) {
@@ -63,8 +64,11 @@ __global__ void k_reset(MapDims d, DevState s, int flags, float qw, float qx, fl
 // k_obs_points: one thread per input point: rotate into the world-aligned
 // sensor-centred frame (:247), FOV test (:250), pyramid cell (:260-263), range (:266).
 // --------------------------------------------------------------------------
-__global__ void k_obs_points(MapDims d, DevState s, int n_pts, const float* __restrict__ pts,
-                             float qw, float qx, float qy, float qz, int make_static_birth) {
+__global__ void k_obs_points(MapDims d, DevState s) {
+    const int n_pts = s.fpar->n_pts;
+    const float* __restrict__ pts = s.fpar->pts;
+    const float qw = s.fpar->quat[0], qx = s.fpar->quat[1], qy = s.fpar->quat[2], qz = s.fpar->quat[3];
+    const int make_static_birth = s.fpar->static_birth;
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
     for (int i = threadIdx.x; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
@@ -88,7 +92,7 @@ __global__ void k_obs_points(MapDims d, DevState s, int n_pts, const float* __re
             b.x = r[0] + s.fs->cur_pos[0]; b.y = r[1] + s.fs->cur_pos[1]; b.z = r[2] + s.fs->cur_pos[2];
             b.nx = b.ny = b.nz = 0.f;
             b.intensity = valid ? 0.f : -2.f;  // -2 = not a source (point outside the FOV)
-            s.birth[i] = b;
+            s.fpar->birth[i] = b;
         }
     }
     wave_count_add(&s.fs->n_valid, valid);  // valid_points :286
@@ -97,22 +101,32 @@ __global__ void k_obs_points(MapDims d, DevState s, int n_pts, const float* __re
 // k_obs_gather: one wave per pyramid.  Appends matching points in INPUT order
 // (stable, ballot + prefix popcount) to the pyramid's bin, keeps the first 99
 // (count saturates, :279-284), tracks the max range over ALL matches (:275-277).
-__global__ void k_obs_gather(MapDims d, DevState s, int n_pts) {
+__global__ void k_obs_gather(MapDims d, DevState s) {
+    const int n_pts = s.fpar->n_pts;
     const int b = blockIdx.x;
     const int l = lane_id();
     int count = 0;
     float maxlen = -1.f;
-    for (int base = 0; base < n_pts; base += WAVE) {
-        const int i = base + l;
-        const bool match = i < n_pts && s.pt_pyr[i] == b;
-        const u64 m = __ballot(match);
-        if (match) {
-            const int pos = count + (int)__popcll(m & lanemask_lt());
-            const float4 p = s.pt_rot[i];
-            if (pos < DSP_OBS_CAP - 1) s.obs[b * DSP_OBS_CAP + pos] = p;
-            maxlen = fmaxf(maxlen, p.w);
+    for (int base = 0; base < n_pts; base += 4 * WAVE) {
+        int pid[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // four independent loads in flight
+            const int i = base + k * WAVE + l;
+            pid[k] = i < n_pts ? s.pt_pyr[i] : -1;
         }
-        count += (int)__popcll(m);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + k * WAVE + l;
+            const bool match = pid[k] == b;
+            const u64 m = __ballot(match);
+            if (match) {
+                const int pos = count + (int)__popcll(m & lanemask_lt());
+                const float4 p = s.pt_rot[i];
+                if (pos < DSP_OBS_CAP - 1) s.obs[b * DSP_OBS_CAP + pos] = p;
+                maxlen = fmaxf(maxlen, p.w);
+            }
+            count += (int)__popcll(m);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) maxlen = fmaxf(maxlen, __shfl_xor(maxlen, o, WAVE));
@@ -204,32 +218,27 @@ __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, Fi
     }
 }
 
-// k_ck_finalize: Ck += expected_new_born_objects + kappa (:737) and the birth
-// normaliser  w_nb * sum_k 1/Ck  (:799-805).  One workgroup, deterministic tree reduction.
-__global__ void __launch_bounds__(1024) k_ck_finalize(MapDims d, DevState s, FilterParams fp) {
-    __shared__ float s_red[1024];
+// Ck += expected_new_born_objects + kappa (:737) is applied on the fly by k_weight (each workgroup
+// adds the frame constant when it stages its observation tile); the chunk-0 workgroup of every
+// pyramid also writes the final Ck of its own bin and the bin's sum of 1/Ck.  k_ck_sum then
+// reduces the 448 partial sums deterministically into the birth normaliser w_nb * sum_k 1/Ck (:799-805).
+__device__ __forceinline__ float frame_lambda(const DevState& s, const FilterParams& fp) {
+    if (s.fs->has_expected_override) return s.fs->expected_newborn;
+    return fp.nb_weight * (float)s.fs->n_valid * (float)fp.nb_num;  // :292
+}
+__global__ void __launch_bounds__(512) k_ck_sum(MapDims d, DevState s, FilterParams fp) {
+    __shared__ float s_red[512];
     const int tid = threadIdx.x;
-    float lambda;
-    if (s.fs->has_expected_override) lambda = s.fs->expected_newborn;
-    else lambda = fp.nb_weight * (float)s.fs->n_valid * (float)fp.nb_num;  // :292
-    const float add = lambda + fp.kappa;
     float acc = 0.f;
-    for (int i = tid; i < d.np * DSP_OBS_CAP; i += 1024) {
-        const int b = i / DSP_OBS_CAP, j = i - b * DSP_OBS_CAP;
-        if (j < s.obs_cnt[b]) {
-            const float ck = s.obs_ck[i] + add;
-            s.obs_ck[i] = ck;
-            acc += __fdiv_rn(1.f, ck);
-        }
-    }
+    for (int i = tid; i < d.np; i += 512) acc += s.part_inv[i];
     s_red[tid] = acc;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
+    for (int o = 256; o > 0; o >>= 1) {
         if (tid < o) s_red[tid] += s_red[tid + o];
         __syncthreads();
     }
     if (tid == 0) {
-        s.fs->expected_newborn = lambda;
+        s.fs->expected_newborn = frame_lambda(s, fp);
         s.fs->newborn_w = fp.nb_weight * s_red[0];  // :805
     }
 }
@@ -247,13 +256,30 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
     __shared__ float4 s_o[9 * DSP_OBS_CAP];
     __shared__ int s_bin[9];
     __shared__ int s_off[10];
+    __shared__ float s_inv[WU_TPB / 64];
     int b, chunk;
     decode_pyr_block(blockIdx.x, nchunk, d.np, b, chunk);
     if (b >= d.np) return;
     const int P = min(s.pyr_cnt[b], d.capp);
     const int start = chunk * WU_TPB;
-    if (start >= P) return;
+    if (start >= P && chunk != 0) return;
     const int tid = threadIdx.x;
+    const float add = frame_lambda(s, fp) + fp.kappa;  // :737
+    if (chunk == 0) {
+        // final Ck of this pyramid's own observations + their sum of 1/Ck (:799-804)
+        const int nob = s.obs_cnt[b];
+        float inv = 0.f;
+        if (tid < nob) {
+            const float ck = s.obs_ck[b * DSP_OBS_CAP + tid] + add;
+            s.obs_ckf[b * DSP_OBS_CAP + tid] = ck;
+            inv = __fdiv_rn(1.f, ck);
+        }
+        inv = wave_sum(inv);
+        if ((tid & 63) == 0) s_inv[tid >> 6] = inv;
+        __syncthreads();
+        if (tid == 0) s.part_inv[b] = (s_inv[0] + s_inv[1]) + (s_inv[2] + s_inv[3]);
+        if (start >= P) return;
+    }
     if (tid == 0) {
         int bins[9];
         const int n = neighbor_bins(d, b, bins);
@@ -272,7 +298,7 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
         for (int q = 1; q < 9; ++q) k += (o >= s_off[q]) ? 1 : 0;
         const int oi = s_bin[k] * DSP_OBS_CAP + (o - s_off[k]);
         float4 z = s.obs[oi];
-        z.w = __fdiv_rn(fp.p_det, s.obs_ck[oi]);
+        z.w = __fdiv_rn(fp.p_det, s.obs_ck[oi] + add);
         s_o[o] = z;
     }
     __syncthreads();
@@ -296,12 +322,13 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
 // k_birth_split: one wave per source point.  Dempster-Shafer static/dynamic
 // split from the mass already in the point's voxel (:827-866), lanes = slots.
 // --------------------------------------------------------------------------
-__global__ void k_birth_split(MapDims d, DevState s, FilterParams fp, int n_birth) {
+__global__ void k_birth_split(MapDims d, DevState s, FilterParams fp) {
+    const int n_birth = s.fpar->n_birth;
     const int wpb = blockDim.x / WAVE;
     const int i = blockIdx.x * wpb + threadIdx.x / WAVE;
     if (i >= n_birth) return;
     const int l = lane_id();
-    const BirthSrc src = s.birth[i];
+    const BirthSrc src = s.fpar->birth[i];
     BirthPlan pl;
     pl.cx = src.x - s.fs->cur_pos[0];  // :818-820
     pl.cy = src.y - s.fs->cur_pos[1];
@@ -365,7 +392,8 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int* s_tmp, int* tota
 
 // k_birth_rank (one workgroup): rank of every valid source point among the valid ones ->
 // first position-table cursor of the point (3 draws per child, always consumed, :871-873).
-__global__ void __launch_bounds__(1024) k_birth_rank(MapDims d, DevState s, FilterParams fp, int n_birth) {
+__global__ void __launch_bounds__(1024) k_birth_rank(MapDims d, DevState s, FilterParams fp) {
+    const int n_birth = s.fpar->n_birth;
     __shared__ int s_tmp[17];
     __shared__ int s_run;
     const int tid = threadIdx.x;
@@ -397,8 +425,9 @@ __global__ void __launch_bounds__(1024) k_birth_rank(MapDims d, DevState s, Filt
 // stays stable while the kernel runs.
 #define BIRTH_BUCKET_CAP 128
 
-__global__ void k_birth_children(MapDims d, DevState s, FilterParams fp, int n_birth, float4* __restrict__ child,
+__global__ void k_birth_children(MapDims d, DevState s, FilterParams fp, float4* __restrict__ child,
                                  int* __restrict__ vb_cnt, int* __restrict__ vb_idx) {
+    const int n_birth = s.fpar->n_birth;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int nb = fp.nb_num;
     const int i = t / nb, k = t - i * nb;
@@ -425,7 +454,8 @@ __global__ void k_birth_children(MapDims d, DevState s, FilterParams fp, int n_b
 }
 
 // k_birth_cursors (one workgroup): velocity-table and rand() cursors per source point (:884-886,:895-897)
-__global__ void __launch_bounds__(1024) k_birth_cursors(MapDims d, DevState s, FilterParams fp, int n_birth) {
+__global__ void __launch_bounds__(1024) k_birth_cursors(MapDims d, DevState s, FilterParams fp) {
+    const int n_birth = s.fpar->n_birth;
     __shared__ int s_tmp[17];
     __shared__ int s_run[2];
     const int tid = threadIdx.x;
@@ -442,7 +472,7 @@ __global__ void __launch_bounds__(1024) k_birth_cursors(MapDims d, DevState s, F
             ok = pl.gvox >= 0;
             if (ok) {
                 n_static = s.nstatic[i];
-                const BirthSrc src = s.birth[i];
+                const BirthSrc src = s.fpar->birth[i];
                 if (src.intensity > 0.01f) {
                     const int model_end = src.nx > -100.f ? fp.model_nb : n_static;  // :881
                     for (int k = n_static; k < nb; ++k) {
@@ -478,8 +508,9 @@ __device__ __forceinline__ float rand_float(const DevState& s, const FilterParam
 
 // k_birth_insert: one thread per (source point, child): velocity by branch (:877-903); vz = 0
 // (:905-907); weight = the global newborn weight (:909); newborn flag (= nbmask bit).
-__global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, int n_birth, const float4* __restrict__ child,
+__global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, const float4* __restrict__ child,
                                const int* __restrict__ vb_cnt, const int* __restrict__ vb_idx) {
+    const int n_birth = s.fpar->n_birth;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int nb = fp.nb_num;
     const int i = t / nb, k = t - i * nb;
@@ -490,7 +521,7 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, int n_bir
             const float4 ch = child[t];
             const int lv = __float_as_int(ch.w);
             if (lv >= 0) {
-                const BirthSrc src = s.birth[i];
+                const BirthSrc src = s.fpar->birth[i];
                 float vx = 0.f, vy = 0.f;
                 if (k >= pl.n_static && src.intensity > 0.01f) {
                     const int model_end = src.nx > -100.f ? fp.model_nb : pl.n_static;
@@ -513,11 +544,17 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, int n_bir
                 const int n = min(vb_cnt[lv], BIRTH_BUCKET_CAP);
                 int rank = 0;
                 bool recorded = false;
-                const int* bl = vb_idx + (size_t)lv * BIRTH_BUCKET_CAP;
-                for (int j = 0; j < n; ++j) {
-                    const int o = bl[j];
-                    rank += (o < t) ? 1 : 0;
-                    recorded |= (o == t);
+                const int4* bl4 = reinterpret_cast<const int4*>(vb_idx + (size_t)lv * BIRTH_BUCKET_CAP);
+                for (int j = 0; j < n; j += 8) {  // 2 x 16-byte loads per step, entries beyond n ignored
+                    const int4 a = bl4[j >> 2];
+                    const int4 b = (j + 4 < n) ? bl4[(j >> 2) + 1] : make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);
+                    const int o[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const bool valid = j + q < n;
+                        rank += (valid && o[q] < t) ? 1 : 0;
+                        recorded |= valid && (o[q] == t);
+                    }
                 }
                 int sl = -1;
                 if (recorded) {  // rank-th free slot of the pre-birth occupancy
@@ -611,29 +648,25 @@ __global__ void __launch_bounds__(256) k_occ_emit(MapDims d, DevState s, float t
 // ==========================================================================
 
 
-void launch_frame_setup(const LaunchCtx& c, const float quat[4], const float cur_pos[3], bool reset_obs) {
+void launch_frame_setup(const LaunchCtx& c, bool reset_obs) {
     const int flags = RESET_PLANES | RESET_PRED | (reset_obs ? RESET_OBS : 0);
     const int n = c.d.np * DSP_OBS_CAP;
     const int grid = reset_obs ? (n + 1023) / 1024 : 1;
-    hipLaunchKernelGGL(k_reset, dim3(grid), dim3(1024), 0, c.stream, c.d, c.s, flags, quat[0], quat[1], quat[2], quat[3],
-                       cur_pos[0], cur_pos[1], cur_pos[2]);
+    hipLaunchKernelGGL(k_reset, dim3(grid), dim3(1024), 0, c.stream, c.d, c.s, flags);
 }
 
-void launch_obs_bin(const LaunchCtx& c, int n_pts, const float* pts_dev, const float quat[4], bool make_static_birth) {
-    if (n_pts > 0)
-        hipLaunchKernelGGL(k_obs_points, dim3((n_pts + 255) / 256), dim3(256), 0, c.stream, c.d, c.s, n_pts, pts_dev,
-                           quat[0], quat[1], quat[2], quat[3], make_static_birth ? 1 : 0);
-    hipLaunchKernelGGL(k_obs_gather, dim3(c.d.np), dim3(WAVE), 0, c.stream, c.d, c.s, n_pts);
+void launch_obs_bin(const LaunchCtx& c, int n_pts_grid) {
+    if (n_pts_grid > 0) hipLaunchKernelGGL(k_obs_points, dim3((n_pts_grid + 255) / 256), dim3(256), 0, c.stream, c.d, c.s);
+    hipLaunchKernelGGL(k_obs_gather, dim3(c.d.np), dim3(WAVE), 0, c.stream, c.d, c.s);
 }
-
 
 void launch_ck_partial(const LaunchCtx& c) {
     const int nchunk = (c.d.capp + CK_PCH - 1) / CK_PCH;
     const int np8 = (c.d.np + 7) / 8 * 8;
     hipLaunchKernelGGL(k_ck_partial, dim3(np8 * nchunk), dim3(CK_TPB), 0, c.stream, c.d, c.s, c.fp, nchunk);
 }
-void launch_ck_finalize(const LaunchCtx& c) {
-    hipLaunchKernelGGL(k_ck_finalize, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
+void launch_ck_finalize(const LaunchCtx& c) {  // after launch_weight_update: reduces the per-pyramid 1/Ck sums
+    hipLaunchKernelGGL(k_ck_sum, dim3(1), dim3(512), 0, c.stream, c.d, c.s, c.fp);
 }
 void launch_weight_update(const LaunchCtx& c) {
     const int nchunk = (c.d.capp + WU_TPB - 1) / WU_TPB;
@@ -641,25 +674,25 @@ void launch_weight_update(const LaunchCtx& c) {
     hipLaunchKernelGGL(k_weight, dim3(np8 * nchunk), dim3(WU_TPB), 0, c.stream, c.d, c.s, c.fp, nchunk);
 }
 
-void launch_birth_split(const LaunchCtx& c, int n_birth) {
-    if (n_birth <= 0) return;
-    hipLaunchKernelGGL(k_birth_split, dim3((n_birth + 3) / 4), dim3(256), 0, c.stream, c.d, c.s, c.fp, n_birth);
+// n_birth_grid sizes the launches (>= the frame's n_birth, which the kernels read from FrameParams)
+void launch_birth_split(const LaunchCtx& c, int n_birth_grid) {
+    if (n_birth_grid <= 0) return;
+    hipLaunchKernelGGL(k_birth_split, dim3((n_birth_grid + 3) / 4), dim3(256), 0, c.stream, c.d, c.s, c.fp);
 }
-void launch_birth_plan_insert(const LaunchCtx& c, int n_birth) {
-    if (n_birth <= 0) return;
-    const long long total = (long long)n_birth * c.fp.nb_num;
+void launch_birth_plan_insert(const LaunchCtx& c, int n_birth_grid) {
+    if (n_birth_grid <= 0) return;
+    const long long total = (long long)n_birth_grid * c.fp.nb_num;
     const unsigned gb = (unsigned)((total + 255) / 256);
     (void)hipMemsetAsync(c.k.vb_cnt, 0, sizeof(int) * (size_t)c.d.v_loc, c.stream);
-    hipLaunchKernelGGL(k_birth_rank, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp, n_birth);
-    hipLaunchKernelGGL(k_birth_children, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, n_birth, c.k.child, c.k.vb_cnt, c.k.vb_idx);
-    hipLaunchKernelGGL(k_birth_cursors, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp, n_birth);
-    hipLaunchKernelGGL(k_birth_insert, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, n_birth, c.k.child, c.k.vb_cnt, c.k.vb_idx);
+    hipLaunchKernelGGL(k_birth_rank, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
+    hipLaunchKernelGGL(k_birth_children, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx);
+    hipLaunchKernelGGL(k_birth_cursors, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
+    hipLaunchKernelGGL(k_birth_insert, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx);
 }
-void launch_birth(const LaunchCtx& c, int n_birth, bool) {
-    launch_birth_split(c, n_birth);
-    launch_birth_plan_insert(c, n_birth);
+void launch_birth(const LaunchCtx& c, int n_birth_grid, bool) {
+    launch_birth_split(c, n_birth_grid);
+    launch_birth_plan_insert(c, n_birth_grid);
 }
-
 
 void launch_occupied_compact(const LaunchCtx& c, float thr) {
     const int nblk = (c.d.v_loc + 255) / 256;

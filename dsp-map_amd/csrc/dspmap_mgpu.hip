@@ -42,12 +42,19 @@ extern "C" int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
     const bool static_birth = birth_dev == nullptr;
     m->mgpu_birth = static_birth ? nullptr : (BirthSrc*)birth_dev;
-    if (!static_birth) c.s.birth = m->mgpu_birth;
+    for (int i = 0; i < 4; i++) m->hp.quat[i] = m->quat[i];
+    for (int i = 0; i < 3; i++) { m->hp.cur_pos[i] = m->cur_pos[i]; m->hp.od[i] = -dp[i]; }
+    m->hp.dt = dt;
+    m->hp.n_pts = n_points; m->hp.n_birth = nb; m->hp.static_birth = static_birth ? 1 : 0;
+    m->hp.pts = points_dev;
+    m->hp.birth = static_birth ? m->s.birth : m->mgpu_birth;
+    int rcp = dspmap_push_frame_params(m);
+    if (rcp != DSPMAP_OK) return rcp;
     dspmap_prof_collect(m);
     HIPCHK(m, hipEventRecord(m->ev0, m->stream));
-    launch_frame_setup(c, m->quat, m->cur_pos, true);
-    launch_obs_bin(c, n_points, points_dev, m->quat, static_birth);
-    launch_predict(c, -dp[0], -dp[1], -dp[2], dt);
+    launch_frame_setup(c, true);
+    launch_obs_bin(c, n_points);
+    launch_predict(c);
     if (m->vz_frames > 0) --m->vz_frames;
     m->last_n_points = n_points;
     m->last_n_birth = nb;
@@ -90,9 +97,8 @@ extern "C" int dspmap_mgpu_ck_partial(dspmap_t* m) {
 extern "C" int dspmap_mgpu_weights_and_split(dspmap_t* m) {
     READY(m);
     LaunchCtx c = dspmap_ctx_of(m);
-    if (m->mgpu_birth) c.s.birth = m->mgpu_birth;
-    launch_ck_finalize(c);
     launch_weight_update(c);
+    launch_ck_finalize(c);
     launch_birth_split(c, m->last_n_birth);
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
@@ -102,7 +108,6 @@ extern "C" int dspmap_mgpu_finish(dspmap_t* m) {
     READY(m);
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
-    if (m->mgpu_birth) c.s.birth = m->mgpu_birth;
     launch_birth_plan_insert(c, m->last_n_birth);
     launch_resample(c);
     HIPCHK(m, hipEventRecord(m->ev1, m->stream));

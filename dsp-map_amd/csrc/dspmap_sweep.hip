@@ -106,14 +106,14 @@ __device__ __forceinline__ u64 rows_of_wave(u64 tor, int wave) {
 }
 
 template <int MW>
-__global__ void __launch_bounds__(256) k_predict(MapDims d, DevState s, FilterParams fp, float odx, float ody, float odz,
-                                                 float dt, int has_vz, int* __restrict__ part,
+__global__ void __launch_bounds__(256) k_predict(MapDims d, DevState s, FilterParams fp, int has_vz, int* __restrict__ part,
                                                  u64* __restrict__ mvmask, u64* __restrict__ expmask) {
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
     __shared__ u64 s_keep[MW * 64], s_mv[MW * 64], s_ex[MW * 64];
     __shared__ int s_cnt[4];
     __shared__ int s_any;
+    const float odx = s.fpar->od[0], ody = s.fpar->od[1], odz = s.fpar->od[2], dt = s.fpar->dt;
     const int tid = threadIdx.x;
     const int l = lane_id();
     const int wave = tid >> 6;
@@ -771,13 +771,13 @@ __global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScra
 // ==========================================================================
 // launchers
 // ==========================================================================
-void launch_predict_only(const LaunchCtx& c, float odx, float ody, float odz, float dt) {
+void launch_predict_only(const LaunchCtx& c) {
     const KernelScratch* k = &c.k;
     if (c.d.mw == 1)
-        hipLaunchKernelGGL(k_predict<1>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, c.fp, odx, ody, odz, dt,
+        hipLaunchKernelGGL(k_predict<1>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, c.fp,
                            c.s.vz0 ? 1 : 0, k->part_predict, k->mvmask, k->expmask);
     else
-        hipLaunchKernelGGL(k_predict<2>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, c.fp, odx, ody, odz, dt,
+        hipLaunchKernelGGL(k_predict<2>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, c.fp,
                            c.s.vz0 ? 1 : 0, k->part_predict, k->mvmask, k->expmask);
 }
 void launch_claim(const LaunchCtx& c) {
@@ -785,8 +785,8 @@ void launch_claim(const LaunchCtx& c) {
     if (c.d.mw == 1) hipLaunchKernelGGL(k_claim<1>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->mvmask, k->part_claim);
     else hipLaunchKernelGGL(k_claim<2>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->mvmask, k->part_claim);
 }
-void launch_predict(const LaunchCtx& c, float odx, float ody, float odz, float dt) {
-    launch_predict_only(c, odx, ody, odz, dt);
+void launch_predict(const LaunchCtx& c) {
+    launch_predict_only(c);
     launch_claim(c);
 }
 void launch_resample(const LaunchCtx& c) {

@@ -82,6 +82,21 @@ struct FrameScalars {
     int has_expected_override;
 };
 
+// Per-frame inputs, written by ONE small H2D copy per frame and read by the kernels from HBM, so that
+// the kernel arguments of a frame never change and the whole frame can be replayed as a HIP graph.
+struct FrameParams {
+    float quat[4];      // sensor attitude w,x,y,z
+    float cur_pos[3];   // current_position :131
+    float od[3];        // -delta position (particles move opposite to the sensor, :300)
+    float dt;
+    int n_pts;          // points in `pts`
+    int n_birth;        // entries in `birth`
+    int static_birth;   // 1: k_obs_points writes the birth cloud (every in-FOV point a static source)
+    int pad;
+    const float* pts;   // n_pts x 3, sensor frame
+    struct BirthSrc* birth;
+};
+
 struct DevState {
     u64* mask;     // [v_loc*mw] live bits
     u64* nbmask;   // [v_loc*mw] born-this-frame bits
@@ -93,7 +108,9 @@ struct DevState {
     float* fut_stat; // [v_loc]   future mass of static particles (identical for every horizon; folded in at readout)
     // observations
     float4* obs;       // [np*100] {x,y,z,len}
-    float* obs_ck;     // [np*100]
+    float* obs_ck;     // [np*100] sum over particles of P_d*w*g (pass 1), without the frame constant
+    float* obs_ckf;    // [np*100] final Ck = obs_ck + lambda + kappa (:737)
+    float* part_inv;   // [np] per-pyramid sum of 1/Ck
     int* obs_cnt;      // [np]
     float* obs_maxlen; // [np]
     float* planes_h;   // [(np_h+1)*3] rotated
@@ -121,6 +138,7 @@ struct DevState {
     // tables
     float* p_tab; float* v_tab; int* r_tab;
     FrameScalars* fs;
+    FrameParams* fpar;
 };
 
 struct BirthSrc {   // == dspmap_vpoint

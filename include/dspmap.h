@@ -102,7 +102,8 @@ enum dspmap_param {
     DSPMAP_P_DETECTION = 8,         /* P_detection :158 */
     DSPMAP_P_VELOCITY_ESTIMATOR = 9,/* 1 = run the host velocity estimator inside dspmap_update (:297),
                                        0 = births use the caller's cloud / all-static tags */
-    DSPMAP_P_REGENERATE_TABLES = 10 /* 1 = setPredictionVariance regenerates the Gaussian tables (:359) */
+    DSPMAP_P_REGENERATE_TABLES = 10,/* 1 = setPredictionVariance regenerates the Gaussian tables (:359) */
+    DSPMAP_P_USE_GRAPH = 11         /* 1 (default) = dspmap_update_device replays the frame as a captured HIP graph */
 };
 
 /* ---- lifecycle: DSPMap::DSPMap / ~DSPMap  dsp_dynamic.h:145-179 ---- */
@@ -180,8 +181,8 @@ int dspmap_get_counters(dspmap_t* m, dspmap_counters* out);
 
 /* per-stage device timing (HIP events on the handle's stream around each kernel group).
  * Off by default; when on, every update records events and the elapsed times accumulate.
- * Stages: 0 setup+binning, 1 predict, 2 claim(movers), 3 Ck partial, 4 Ck finalize,
- *         5 weight update, 6 birth, 7 occupancy+resample. */
+ * Stages: 0 setup+binning, 1 predict, 2 claim(movers), 3 Ck partial, 4 weight update,
+ *         5 Ck sum (birth normaliser), 6 birth, 7 occupancy+resample. */
 #define DSPMAP_N_STAGES 8
 int dspmap_set_profiling(dspmap_t* m, int on);
 int dspmap_get_stage_ms(dspmap_t* m, float ms_sum_out[DSPMAP_N_STAGES], int* n_frames_out); /* sums since enabling; syncs */

@@ -492,3 +492,53 @@ def test_slab_sized_72_slots(dsp, orc):
     vg, sg, rg = gpu_state(m)
     assert np.bincount(vg, minlength=m.V).max() <= 36
     o.close(); m.close()
+
+
+def test_device_resident_frame_and_graph_replay(dsp, orc):
+    """dspmap_update_device (inputs in HBM, frame replayed as a captured HIP graph) == the host-fed
+    dspmap_update == the oracle on frame 0, and graph replay on/off agree over a short run"""
+    import torch
+    cfgkw = dict(nx=40, ny=40, nz=20, ppv=12)
+    maps = []
+    for use_graph in (1, 0):
+        m = dsp.DSPMap(dsp.make_config(**cfgkw))
+        m.set_tables(*common.tables(2))
+        m.set_param(dsp.capi.P_USE_GRAPH, use_graph)
+        maps.append(m)
+    host = dsp.DSPMap(dsp.make_config(**cfgkw))
+    host.set_tables(*common.tables(2))
+    o = orc.Oracle(orc.make_config(**cfgkw))
+    o.set_tables(*common.tables(2))
+    o.L.dspo_use_velocity_estimator(o.h, 2)
+    base = common.wall_cloud(8, n_side=40, dist=2.2, half_w=1.8, half_h=0.9)
+    for f in range(6):
+        t = f / 30.0
+        pts = base.copy(); pts[:, 0] -= np.float32(0.3 * t)
+        pos, q = (0.3 * t, 0.0, 0.02 * f), (1.0, 0.0, 0.0, 0.0)
+        d = torch.from_numpy(pts).cuda()
+        for m in maps:
+            assert m.update_device(d.data_ptr(), len(pts), pos, t, q) == 1
+        assert host.update(pts, pos, t, q) == 1
+        assert o.update(pts, pos, t, q) == 1
+        for m in maps:
+            m.sync()
+        if f == 0:
+            ref = o.results[:, 0]
+            for m in maps + [host]:
+                assert np.allclose(m.results()[:, 0], ref, rtol=RTOL, atol=1e-6)
+                assert m.counters()["n_born"] == maps[0].counters()["n_born"]
+        for m in maps + [host]:
+            m.clearOccupancyMapPrediction()
+        o.L.dspo_clear_future(o.h)
+    a, b, c = maps[0].results()[:, 0].astype(np.float64), maps[1].results()[:, 0].astype(np.float64), host.results()[:, 0].astype(np.float64)
+    assert abs(a.sum() - b.sum()) < 5e-3 * b.sum() and abs(c.sum() - b.sum()) < 5e-3 * b.sum()
+    assert abs(maps[0].counters()["n_live_out"] - maps[1].counters()["n_live_out"]) < 0.02 * maps[1].counters()["n_live_out"]
+    # a parameter change must invalidate the captured graph (kernel arguments are baked in)
+    maps[0].setObservationStdDev(0.2)
+    d = torch.from_numpy(base).cuda()
+    assert maps[0].update_device(d.data_ptr(), len(base), (0.06, 0, 0.1), 0.2, (1, 0, 0, 0)) == 1
+    maps[0].sync()
+    assert maps[0].counters()["n_live_out"] > 0
+    o.close()
+    for m in maps + [host]:
+        m.close()
