@@ -132,7 +132,7 @@ static void free_dev(dspmap* m) {
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.nstatic, s.fov_rec, s.fov_slot, s.pyr_cnt, s.mv_rec, s.exp_up, s.exp_down,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mvmask, m->k.expmask,
-                    m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.work_count, m->k.child, m->pts_dev};
+                    m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.work_count, m->k.child, m->k.part_birth, m->pts_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
     if (m->graph) (void)hipGraphDestroy(m->graph);
@@ -209,7 +209,7 @@ int dspmap_ensure_point_cap(dspmap* m, int n) {
     DevState& s = m->s;
     const int cap = n + n / 2 + 1024;
     if (m->mgpu_bound) return dspmap_fail(m, DSPMAP_E_ARG, "%d points exceed the capacity bound with dspmap_mgpu_bind", n);
-    void* olds[] = {s.pt_rot, s.pt_pyr, s.birth, s.plan, s.nstatic, m->pts_dev, m->k.child};
+    void* olds[] = {s.pt_rot, s.pt_pyr, s.birth, s.plan, s.nstatic, m->pts_dev, m->k.child, m->k.part_birth};
     for (void* p : olds) if (p) (void)hipFree(p);
     HIPCHK(m, dalloc(&s.pt_rot, (size_t)cap));
     HIPCHK(m, dalloc(&s.pt_pyr, (size_t)cap));
@@ -218,6 +218,8 @@ int dspmap_ensure_point_cap(dspmap* m, int n) {
     HIPCHK(m, dalloc(&s.nstatic, (size_t)cap));
     HIPCHK(m, dalloc(&m->pts_dev, (size_t)cap * 3));
     HIPCHK(m, dalloc(&m->k.child, (size_t)cap * 32));
+    HIPCHK(m, dalloc(&m->k.part_birth, ((size_t)cap * 32 + 255) / 256 * 2));
+    HIPCHK(m, hipMemset(m->k.part_birth, 0, sizeof(int) * (((size_t)cap * 32 + 255) / 256 * 2)));
     m->pt_cap = cap; m->birth_cap = cap;
     return DSPMAP_OK;
 }
@@ -775,7 +777,7 @@ extern "C" int dspmap_get_counters(dspmap_t* m, dspmap_counters* out) {
     out->n_valid = fs.n_valid; out->n_obs = fs.n_obs; out->n_live_in = fs.n_live_in; out->n_moved = fs.n_moved;
     out->n_out_of_map = fs.n_out_of_map; out->n_voxel_full = fs.n_voxel_full; out->n_pyramid_full = fs.n_pyramid_full;
     out->n_fov = fs.n_fov; out->n_born = fs.n_born; out->n_born_dropped = fs.n_born_dropped;
-    out->n_live_out = fs.n_live_out; out->n_exported_up = fs.n_exp_up; out->n_exported_down = fs.n_exp_down;
+    out->n_live_out = fs.n_live_out; out->n_exported_up = m->last_exp[1]; out->n_exported_down = m->last_exp[0];
     out->newborn_weight = fs.newborn_w;
     if (m->ev_valid) {
         float ms = 0.f;

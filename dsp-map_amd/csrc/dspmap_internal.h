@@ -66,6 +66,7 @@ struct dspmap {
     int mgpu_nstatic_cap = 0;
     int* mgpu_count = nullptr;
     BirthSrc* mgpu_birth = nullptr;
+    int last_exp[2] = {0, 0};   // particles exported down / up in the last frame
     // per-stage profiling
     bool prof = false;
     hipEvent_t pev[DSPMAP_N_STAGES + 1] = {};

@@ -53,7 +53,7 @@ __global__ void k_reset(MapDims d, DevState s, int flags) {
     if (flags & RESET_PRED) {
         for (int i = gt; i < d.np; i += gn) s.pyr_cnt[i] = 0;
         if (gt == 0) {
-            s.fs->n_born = 0; s.fs->n_born_dropped = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0;
+            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0;
             s.fs->mover_count = 0;
         }
     }
@@ -150,7 +150,7 @@ __global__ void k_obs_gather(MapDims d, DevState s) {
 // blockIdx -> (b, chunk) is XCD-aware: all chunks of one pyramid land on the
 // same XCD (blockIdx % 8) so its obs tile and Ck lines stay in one L2.
 // --------------------------------------------------------------------------
-#define CK_TPB 128
+#define CK_TPB 256
 #define CK_PCH 128
 
 __device__ __forceinline__ void decode_pyr_block(int bid, int nchunk, int np, int& b, int& chunk) {
@@ -172,6 +172,36 @@ __device__ __forceinline__ int neighbor_bins(const MapDims& d, int b, int* bins)
     return n;
 }
 
+// neighbourhood table of a pyramid in LDS: s_bin[9] bins, s_off[10] exclusive offsets of their
+// observation counts.  The 9 counts are loaded by 9 lanes at once (one memory round trip).
+__device__ __forceinline__ void neighbor_setup(const MapDims& d, const DevState& s, int b, int* s_bin, int* s_off) {
+    const int tid = threadIdx.x;
+    if (tid < 9) {
+        const int h0 = b / d.np_v, v0 = b % d.np_v;
+        const int h = h0 + tid / 3 - 1, v = v0 + tid % 3 - 1;
+        const bool ok = h >= 0 && h < d.np_h && v >= 0 && v < d.np_v;
+        const int bin = ok ? h * d.np_v + v : -1;
+        const int cnt = ok ? s.obs_cnt[bin] : 0;
+        // compact valid neighbours in h-major order (findPyramidNeighborIndexInFOV :1128-1147)
+        const u64 okm = __ballot(ok) & 0x1ffull;
+        const int slot = (int)__popcll(okm & ((1ull << tid) - 1ull));
+        s_bin[tid] = -1;
+        __builtin_amdgcn_s_waitcnt(0);
+        if (ok) { s_bin[slot] = bin; s_off[slot] = cnt; }
+    }
+}
+__device__ __forceinline__ void neighbor_prefix(int* s_bin, int* s_off) {
+    if (threadIdx.x == 0) {
+        int off = 0;
+        for (int k = 0; k < 9; ++k) {
+            const int c = s_bin[k] >= 0 ? s_off[k] : 0;
+            s_off[k] = off;
+            off += c;
+        }
+        s_off[9] = off;
+    }
+}
+
 __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, FilterParams fp, int nchunk) {
     __shared__ float4 s_p[CK_PCH];
     __shared__ int s_bin[9];
@@ -184,16 +214,9 @@ __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, Fi
     if (start >= P) return;
     const int npart = min(CK_PCH, P - start);
     const int tid = threadIdx.x;
-    if (tid == 0) {
-        int bins[9];
-        const int n = neighbor_bins(d, b, bins);
-        int off = 0;
-        for (int k = 0; k < 9; ++k) {
-            s_off[k] = off;
-            if (k < n) { s_bin[k] = bins[k]; off += s.obs_cnt[bins[k]]; } else s_bin[k] = -1;
-        }
-        s_off[9] = off;
-    }
+    neighbor_setup(d, s, b, s_bin, s_off);
+    __syncthreads();
+    neighbor_prefix(s_bin, s_off);
     __syncthreads();
     const int O = s_off[9];
     if (O == 0) return;
@@ -280,16 +303,9 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
         if (tid == 0) s.part_inv[b] = (s_inv[0] + s_inv[1]) + (s_inv[2] + s_inv[3]);
         if (start >= P) return;
     }
-    if (tid == 0) {
-        int bins[9];
-        const int n = neighbor_bins(d, b, bins);
-        int off = 0;
-        for (int k = 0; k < 9; ++k) {
-            s_off[k] = off;
-            if (k < n) { s_bin[k] = bins[k]; off += s.obs_cnt[bins[k]]; } else s_bin[k] = -1;
-        }
-        s_off[9] = off;
-    }
+    neighbor_setup(d, s, b, s_bin, s_off);
+    __syncthreads();
+    neighbor_prefix(s_bin, s_off);
     __syncthreads();
     const int O = s_off[9];
     for (int o = tid; o < O; o += WU_TPB) {
@@ -509,7 +525,7 @@ __device__ __forceinline__ float rand_float(const DevState& s, const FilterParam
 // k_birth_insert: one thread per (source point, child): velocity by branch (:877-903); vz = 0
 // (:905-907); weight = the global newborn weight (:909); newborn flag (= nbmask bit).
 __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, const float4* __restrict__ child,
-                               const int* __restrict__ vb_cnt, const int* __restrict__ vb_idx) {
+                               const int* __restrict__ vb_cnt, const int* __restrict__ vb_idx, int* __restrict__ part_birth) {
     const int n_birth = s.fpar->n_birth;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int nb = fp.nb_num;
@@ -582,8 +598,17 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, const flo
             }
         }
     }
-    wave_count_add(&s.fs->n_born, born);
-    wave_count_add(&s.fs->n_born_dropped, dropped);
+    // per-block partial counts (a same-address global atomic per wave would serialise, ~12 ns each)
+    __shared__ int s_bc[2];
+    if (threadIdx.x < 2) s_bc[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 bb = __ballot(born), bd = __ballot(dropped);
+    if (lane_id() == 0) {
+        if (bb) atomicAdd(&s_bc[0], (int)__popcll(bb));
+        if (bd) atomicAdd(&s_bc[1], (int)__popcll(bd));
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) part_birth[blockIdx.x * 2 + threadIdx.x] = s_bc[threadIdx.x];
 }
 
 // --------------------------------------------------------------------------
@@ -687,7 +712,7 @@ void launch_birth_plan_insert(const LaunchCtx& c, int n_birth_grid) {
     hipLaunchKernelGGL(k_birth_rank, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
     hipLaunchKernelGGL(k_birth_children, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx);
     hipLaunchKernelGGL(k_birth_cursors, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
-    hipLaunchKernelGGL(k_birth_insert, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx);
+    hipLaunchKernelGGL(k_birth_insert, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx, c.k.part_birth);
 }
 void launch_birth(const LaunchCtx& c, int n_birth_grid, bool) {
     launch_birth_split(c, n_birth_grid);

@@ -74,6 +74,7 @@ extern "C" int dspmap_mgpu_export(dspmap_t* m, int dir, float* rec_dev_out, int 
     HIPCHK(m, hipStreamSynchronize(m->stream));
     if (n > cap) return dspmap_fail(m, DSPMAP_E_STATE, "export buffer too small: %d > %d", n, cap);
     *n_out = n;
+    m->last_exp[dir > 0 ? 1 : 0] = n;
     return DSPMAP_OK;
 }
 

@@ -371,8 +371,11 @@ __global__ void __launch_bounds__(256) k_claim(MapDims d, DevState s, u64* __res
 // --------------------------------------------------------------------------
 #define RBK 8  // rows per batch in k_resample (few registers per row: deeper batches, fewer round trips)
 
+#define CPMAX 64  // copies a voxel can make in one resampling (<= M <= 64)
+
 template <int MW>
 __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __restrict__ part_live) {
+    __shared__ unsigned short s_cp[256 * CPMAX];
     const int l = lane_id();
     const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lv = wave_g * 64 + l;
@@ -458,10 +461,13 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
         if (stat_w != 0.f) s.fut_stat[lv] += stat_w;  // only this lane ever writes fut_stat[lv]
     }
     // ---- systematic resampling :986-1053
+    int ncp = 0;
+    float w_copy = 0.f;
     const bool resample = n >= 5;
     if (__ballot(resample)) {
         const int n_after = n > d.M ? d.M : n;                  // :992-997
         const float w_after = __fdiv_rn(wsum, (float)n_after);  // :1000
+        w_copy = w_after;
         float acc_ori = 0.f, acc_new = w_after * 0.5f;          // :1005-1006
         u64 a0[MW];
 #pragma unroll
@@ -499,11 +505,10 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
                                 }
                             }
                             if (fslot >= 0) {
-                                const size_t didx = pidx(d, lvs, fslot);
-                                s.px[didx] = s.px[idx]; s.py[didx] = s.py[idx]; s.pz[didx] = s.pz[idx];
-                                s.vx[didx] = s.vx[idx]; s.vy[didx] = s.vy[idx];
-                                if (s.vz0) s.vz0[didx] = s.vz0[idx];
-                                s.w[didx] = w_after;
+                                // the copy itself (5 loads + 6 stores) is deferred: only (source, destination)
+                                // is noted here so that no global load sits in this sequential loop
+                                if (ncp < CPMAX) s_cp[threadIdx.x * CPMAX + ncp] = (unsigned short)(((e * 64 + row[r]) << 8) | fslot);
+                                ++ncp;
                             } else {
                                 wn += w_after;                 // no free slot: fold the weight back :1037-1041
                                 full = true;
@@ -515,6 +520,32 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
                         m[e] &= ~bit;                          // remove :1046-1049
                     }
                 }
+            }
+        }
+    }
+    // deferred copies :1026-1031, four at a time so that their loads overlap
+    if (ncp > CPMAX) ncp = CPMAX;  // cannot happen: a voxel makes at most M <= 64 copies
+    for (int k0 = 0; __ballot(k0 < ncp); k0 += 4) {
+        float cx[4], cy[4], cz[4], cvx[4], cvy[4], cvz[4];
+        size_t didx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            didx[j] = 0;
+            if (k0 + j < ncp) {
+                const unsigned pr = s_cp[threadIdx.x * CPMAX + k0 + j];
+                const size_t sidx = pidx(d, lvs, (int)(pr >> 8));
+                didx[j] = pidx(d, lvs, (int)(pr & 0xff));
+                cx[j] = s.px[sidx]; cy[j] = s.py[sidx]; cz[j] = s.pz[sidx]; cvx[j] = s.vx[sidx]; cvy[j] = s.vy[sidx];
+                cvz[j] = s.vz0 ? s.vz0[sidx] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (k0 + j < ncp) {
+                s.px[didx[j]] = cx[j]; s.py[didx[j]] = cy[j]; s.pz[didx[j]] = cz[j];
+                s.vx[didx[j]] = cvx[j]; s.vy[didx[j]] = cvy[j];
+                if (s.vz0) s.vz0[didx[j]] = cvz[j];
+                s.w[didx[j]] = w_copy;
             }
         }
     }
@@ -737,7 +768,7 @@ __global__ void __launch_bounds__(256) k_import_movers(MapDims d, DevState s, in
 }
 
 // fold per-block partial counters (written without global atomics by the sweeps) into FrameScalars
-__global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScratch k, MapDims d) {
+__global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScratch k, MapDims d, int fp_nb_num) {
     __shared__ int s_red[1024];
     const int tid = threadIdx.x;
     int acc[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -747,6 +778,9 @@ __global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScra
         acc[4] += k.part_claim[i * 2]; acc[5] += k.part_claim[i * 2 + 1];
     }
     for (int i = tid; i < k.nblk_sweep * 4; i += 1024) acc[6] += k.part_resample[i];
+    int accb[2] = {0, 0};
+    const int nbb = (int)(((long long)s.fpar->n_birth * fp_nb_num + 255) / 256);  // blocks of the last k_birth_insert that covered real children
+    for (int i = tid; i < nbb; i += 1024) { accb[0] += k.part_birth[i * 2]; accb[1] += k.part_birth[i * 2 + 1]; }
     int out[7];
     for (int c = 0; c < 7; ++c) {
         s_red[tid] = acc[c];
@@ -761,10 +795,20 @@ __global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScra
     if (tid == 0) {
         s.fs->n_live_in = out[0]; s.fs->n_out_of_map = out[1];
         s.fs->n_pyramid_full = out[2] + out[5]; s.fs->n_moved = out[3];
-        s.fs->n_voxel_full = out[4]; s.fs->n_live_out = out[6];
+        s.fs->n_voxel_full = out[4] + s.fs->n_voxel_full_import; s.fs->n_live_out = out[6];
         int nf = 0;
         for (int b = 0; b < d.np; ++b) nf += min(s.pyr_cnt[b], d.capp);
         s.fs->n_fov = nf;
+    }
+    for (int c = 0; c < 2; ++c) {
+        s_red[tid] = accb[c];
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) {
+            if (tid < o) s_red[tid] += s_red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) { if (c == 0) s.fs->n_born = s_red[0]; else s.fs->n_born_dropped = s_red[0]; }
+        __syncthreads();
     }
 }
 
@@ -818,8 +862,8 @@ void launch_export_slab(const LaunchCtx& c, int dir, float* rec_out, int cap, in
 }
 void launch_import_movers(const LaunchCtx& c, int n, const float* rec) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_import_movers, dim3((n + 255) / 256), dim3(256), 0, c.stream, c.d, c.s, n, rec, &c.s.fs->n_voxel_full);
+    hipLaunchKernelGGL(k_import_movers, dim3((n + 255) / 256), dim3(256), 0, c.stream, c.d, c.s, n, rec, &c.s.fs->n_voxel_full_import);
 }
 void launch_reduce_counters(const LaunchCtx& c) {
-    hipLaunchKernelGGL(k_reduce_counters, dim3(1), dim3(1024), 0, c.stream, c.s, c.k, c.d);
+    hipLaunchKernelGGL(k_reduce_counters, dim3(1), dim3(1024), 0, c.stream, c.s, c.k, c.d, c.fp.nb_num);
 }

@@ -74,7 +74,7 @@ struct FrameScalars {
     int n_exp_up, n_exp_down;
     int mover_count;    // local movers appended by the prediction kernel
     int occupied_count; // readout
-    int pad0;
+    int n_voxel_full_import; // multi-GPU: movers received from a neighbour that found their voxel full
     float expected_newborn;  // expected_new_born_objects :292
     float newborn_w;         // updated_weight_new_born :805
     float cur_pos[3];        // current_position :131
