@@ -202,13 +202,21 @@ def main():
     balg = b_alg(cnt, V, T)
     ms = dt / args.steps * 1e3
     peak = 8000.0
+    traffic_db = {}
+    try:  # HBM bytes per launch from the committed PMC passes of the same command (profiles/r01_c_pmc_traffic.md)
+        traffic_db = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")))["workloads"]
+    except Exception:
+        pass
     if stage is not None:
         dom = max((k for k in stage if k not in ("setup+bin", "ck_finalize", "birth")), key=lambda k: stage[k])
         dom_bytes = kernel_alg_bytes(dom, cnt, V, T)
         dom_ms = stage[dom]
         roof = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(dom_bytes / (dom_ms * 1e-3) / 1e9, 3),
                 "peak": peak, "unit": "GB/s", "frac": round(dom_bytes / (dom_ms * 1e-3) / 1e9 / peak, 6),
-                "traffic": None, "kernel_ms": round(dom_ms, 6), "algorithmic_bytes": int(dom_bytes)}
+                "traffic": traffic_db.get(wl_name, {}).get("k_" + dom, {}).get("hbm_bytes"),
+                "traffic_source": "profiles/pmc_traffic_r01.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this workload, "
+                                  "corrected: 2*FETCH+WRITE)" if wl_name in traffic_db else None,
+                "kernel_ms": round(dom_ms, 6), "algorithmic_bytes": int(dom_bytes)}
     else:  # sharded run: whole-frame algorithmic bytes over all ranks against N x 8 TB/s
         roof = {"bound": "hbm", "kernel": "whole frame (all ranks)", "achieved": round(balg / (ms * 1e-3) / 1e9, 3),
                 "peak": peak * world, "unit": "GB/s", "frac": round(balg / (ms * 1e-3) / 1e9 / (peak * world), 6),

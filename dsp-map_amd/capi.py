@@ -89,6 +89,7 @@ SIGNATURES = {
     "dspmap_get_counters": (_i, [_P, C.POINTER(Counters)]),
     "dspmap_set_profiling": (_i, [_P, _i]),
     "dspmap_get_stage_ms": (_i, [_P, _fp, _ip]),
+    "dspmap_debug_stream": (_i, [_P, _i, C.POINTER(C.c_longlong)]),
     "dspmap_clear_state": (_i, [_P]),
     "dspmap_import_state": (_i, [_P, _i, _P, _P, _P]),
     "dspmap_export_state": (_i, [_P, _i, _P, _P, _P, _ip]),

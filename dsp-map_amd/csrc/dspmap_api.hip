@@ -1003,6 +1003,15 @@ extern "C" int dspmap_set_expected_newborn(dspmap_t* m, float v) {
     return DSPMAP_OK;
 }
 
+extern "C" int dspmap_debug_stream(dspmap_t* m, int mode, long long* bytes_out) {
+    READY(m);
+    const size_t S = (((size_t)m->d.v_loc + 63) / 64) * 64 * m->d.slots;
+    LaunchCtx c = dspmap_ctx_of(m);
+    launch_calib(c, mode, S);
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (bytes_out) *bytes_out = (long long)(mode == 0 ? S * 24 : S * 4);
+    return DSPMAP_OK;
+}
 extern "C" int dspmap_get_pyramid_counts(dspmap_t* m, int* out) {
     READY(m);
     if (!out) return DSPMAP_E_ARG;

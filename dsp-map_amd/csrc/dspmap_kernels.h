@@ -38,6 +38,7 @@ void launch_predict(const LaunchCtx& c);
 void launch_predict_only(const LaunchCtx& c);
 void launch_claim(const LaunchCtx& c);
 void launch_reduce_counters(const LaunchCtx& c);
+void launch_calib(const LaunchCtx& c, int mode, size_t n);
 // multi-GPU: compact particles that left the slab / insert particles received from a neighbour
 void launch_export_slab(const LaunchCtx& c, int dir, float* rec_out, int cap, int* count_dev);
 void launch_import_movers(const LaunchCtx& c, int n, const float* rec);  // folds the per-block partial counters into FrameScalars

@@ -767,6 +767,21 @@ __global__ void __launch_bounds__(256) k_import_movers(MapDims d, DevState s, in
     wave_count_add(dropped, lost);
 }
 
+// PMC calibration: stream the field arrays with the sweeps' 4-byte-per-lane pattern
+__global__ void __launch_bounds__(256) k_calib_read(DevState s, size_t n, float* __restrict__ sink) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        acc += s.px[i] + s.py[i] + s.pz[i] + s.vx[i] + s.vy[i] + s.w[i];
+    if (acc == 1.2345e-30f) *sink = acc;
+}
+__global__ void __launch_bounds__(256) k_calib_write(DevState s, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s.px[i] = s.px[i] + 0.f;
+}
+void launch_calib(const LaunchCtx& c, int mode, size_t n) {
+    if (mode == 0) hipLaunchKernelGGL(k_calib_read, dim3(8192), dim3(256), 0, c.stream, c.s, n, (float*)c.s.fs);
+    else hipLaunchKernelGGL(k_calib_write, dim3(8192), dim3(256), 0, c.stream, c.s, n);
+}
+
 // fold per-block partial counters (written without global atomics by the sweeps) into FrameScalars
 __global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScratch k, MapDims d, int fp_nb_num) {
     __shared__ int s_red[1024];

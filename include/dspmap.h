@@ -187,6 +187,11 @@ int dspmap_get_counters(dspmap_t* m, dspmap_counters* out);
 int dspmap_set_profiling(dspmap_t* m, int on);
 int dspmap_get_stage_ms(dspmap_t* m, float ms_sum_out[DSPMAP_N_STAGES], int* n_frames_out); /* sums since enabling; syncs */
 
+/* profiling aid: streams the six particle field arrays once with the sweeps' access pattern
+ * (4 B per lane, 256 B per wave) -- mode 0 reads them (known byte count = 6*4*capacity), mode 1
+ * rewrites px in place -- to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE for this pattern. */
+int dspmap_debug_stream(dspmap_t* m, int mode, long long* bytes_out);
+
 /* ---- state access (the reference's equivalent is direct access to its
  * file-scope arrays, dsp_dynamic.h:116).  A record is 8 floats
  * {flag, vx, vy, vz, px, py, pz, weight} (:114-115 minus the dead update_time).
