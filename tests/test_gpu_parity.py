@@ -542,3 +542,49 @@ def test_device_resident_frame_and_graph_replay(dsp, orc):
     o.close()
     for m in maps + [host]:
         m.close()
+
+
+def test_velocity_estimator_matches_oracle_restatement(dsp, orc):
+    """a17 (adjacent): host velocity estimator inside dspmap_update (ground split, Euclidean clustering,
+    Hungarian matching) against the oracle's restatement of velocityEstimationThread (:1377-1544) on a
+    scene with ground, a big static wall and a small box moving at 1.2 m/s."""
+    cfgkw = dict(nx=66, ny=66, nz=40, ppv=9)
+    o, m = make_pair(dsp, orc, **cfgkw)
+    m.useVelocityEstimator(True)
+    o.L.dspo_use_velocity_estimator(o.h, 1)
+
+    def cloud(t):
+        pts = []
+        ys, zs = np.meshgrid(np.arange(-2.0, 2.0, 0.1), np.arange(-0.9, 1.0, 0.1))
+        pts.append(np.stack([np.full(ys.size, 3.5), ys.ravel(), zs.ravel()], 1))       # wall (> 200 points: static)
+        gx, gy = np.meshgrid(np.arange(1.0, 3.0, 0.1), np.arange(-1.0, 1.0, 0.1))
+        pts.append(np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, -1.2)], 1))      # ground (z_world <= 0.1)
+        by, bz = np.meshgrid(np.arange(0, 0.4, 0.1), np.arange(-0.9, 0.3, 0.1))
+        pts.append(np.stack([np.full(by.size, 2.0), -1.0 + 1.2 * t + by.ravel(), bz.ravel()], 1))  # moving box
+        return np.concatenate(pts).astype(np.float32)
+
+    pos = (0.0, 0.0, 1.25)
+    for f in range(3):
+        t = f / 10.0
+        pts = cloud(t)
+        assert m.update(pts, pos, t, (1, 0, 0, 0)) == 1
+        assert o.update(pts, pos, t, (1, 0, 0, 0)) == 1
+        g = m.get_birth_cloud()
+        w = o.get_birth_cloud()
+        assert len(g) == len(w) > 500
+        key = lambda a: np.lexsort((np.round(a["z"], 4), np.round(a["y"], 4), np.round(a["x"], 4)))
+        g, w = g[key(g)], w[key(w)]
+        assert np.allclose(g["x"], w["x"]) and np.allclose(g["y"], w["y"]) and np.allclose(g["z"], w["z"])
+        dyn_g, dyn_w = g["intensity"] > 0.01, w["intensity"] > 0.01
+        assert np.array_equal(dyn_g, dyn_w)           # same points tagged as possibly-dynamic cluster
+        assert 20 < dyn_g.sum() < 80                  # the box, not the wall / ground
+        assert np.allclose(g["nx"], w["nx"], atol=1e-3) and np.allclose(g["ny"], w["ny"], atol=1e-3)
+        if f == 0:
+            assert (g["nx"][dyn_g] < -100).all()      # first frame: unmatched cluster sentinel (-10000, :104-106)
+        else:
+            assert np.allclose(g["ny"][dyn_g], 1.2, atol=0.05) and np.allclose(g["nx"][dyn_g], 0.0, atol=0.05)
+        o.get_occupancy_with_future(0.2); m.getOccupancyMapWithFutureStatus(0.2)
+    # births used the estimated velocities: particles with vy ~ 1.2 exist around the box
+    vg, sg, rg = gpu_state(m)
+    assert ((np.abs(rg[:, 2] - 1.2) < 0.5) & (rg[:, 7] > 0)).sum() > 20
+    o.close(); m.close()
