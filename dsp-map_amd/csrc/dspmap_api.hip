@@ -138,6 +138,9 @@ static void free_dev(dspmap* m) {
     if (m->graph) (void)hipGraphDestroy(m->graph);
     if (m->pts_pin) (void)hipHostFree(m->pts_pin);
     if (m->birth_pin) (void)hipHostFree(m->birth_pin);
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    if (m->stream2) (void)hipStreamDestroy(m->stream2);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
     if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
@@ -233,6 +236,9 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     if (m->device >= 0) HIPCHK(m, hipSetDevice(m->device));
     else HIPCHK(m, hipGetDevice(&m->device));
     if (!m->stream) { HIPCHK(m, hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
+    HIPCHK(m, hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
+    HIPCHK(m, hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    HIPCHK(m, hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     HIPCHK(m, hipEventCreate(&m->ev0));
     HIPCHK(m, hipEventCreate(&m->ev1));
     const MapDims& d = m->d;
@@ -486,15 +492,28 @@ int dspmap_gate_and_delta(dspmap* m, const float pos[3], double stamp, const flo
     return 1;
 }
 
-// enqueue one whole device-resident frame (setup .. resample); every per-frame value is read from s.fpar
-static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid) {
+// enqueue one whole device-resident frame (setup .. resample); every per-frame value is read from s.fpar.
+// When `fork` is set (graph capture) the observation binning runs on a second stream concurrently with
+// prediction + re-binning: the two only share the rotated planes written by k_reset and meet again at
+// the Ck kernel.
+static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid, bool fork) {
     dspmap_prof_mark(m, 0);
     launch_frame_setup(c, true);
-    launch_obs_bin(c, pts_grid);
+    if (fork) {
+        (void)hipEventRecord(m->ev_fork, m->stream);
+        (void)hipStreamWaitEvent(m->stream2, m->ev_fork, 0);
+        LaunchCtx c2 = c;
+        c2.stream = m->stream2;
+        launch_obs_bin(c2, pts_grid);
+        (void)hipEventRecord(m->ev_join, m->stream2);
+    } else {
+        launch_obs_bin(c, pts_grid);
+    }
     dspmap_prof_mark(m, 1);
     launch_predict_only(c);
     dspmap_prof_mark(m, 2);
     launch_claim(c);
+    if (fork) (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
     dspmap_prof_mark(m, 3);
     launch_ck_partial(c);
     dspmap_prof_mark(m, 4);
@@ -539,14 +558,14 @@ extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* poin
             if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
             if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
             HIPCHK(m, hipStreamBeginCapture(m->stream, hipStreamCaptureModeRelaxed));
-            enqueue_frame(m, c, m->pt_cap, m->birth_cap);  // grids sized for the capacity; kernels bound-check against fpar
+            enqueue_frame(m, c, m->pt_cap, m->birth_cap, false);  // (fork=true measured slower: HIP replays multi-branch graphs with a much higher launch cost) grids sized for the capacity; kernels bound-check against fpar
             HIPCHK(m, hipStreamEndCapture(m->stream, &m->graph));
             HIPCHK(m, hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
             m->graph_key = key;
         }
         HIPCHK(m, hipGraphLaunch(m->graph_exec, m->stream));
     } else {
-        enqueue_frame(m, c, n_points, nb);
+        enqueue_frame(m, c, n_points, nb, false);
     }
     if (m->vz_frames > 0) --m->vz_frames;
     HIPCHK(m, hipEventRecord(m->ev1, m->stream));

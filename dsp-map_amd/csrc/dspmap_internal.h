@@ -57,6 +57,8 @@ struct dspmap {
     FrameParams hp = {};
     // HIP graph of the device-resident frame (dspmap_update_device)
     bool use_graph = true;
+    hipStream_t stream2 = nullptr;   // fork/join branch inside the captured frame
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     unsigned long long graph_key = ~0ull;
