@@ -131,7 +131,7 @@ static void free_dev(dspmap* m) {
     void* ptrs[] = {s.fpar, s.obs_ckf, s.part_inv, s.fut_stat, s.mask, s.nbmask, s.px, s.py, s.pz, s.vx, s.vy, s.w, s.vz0, s.res4, s.fut, s.obs, s.obs_ck,
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.nstatic, s.fov_rec, s.fov_slot, s.pyr_cnt, s.mv_rec, s.exp_up, s.exp_down,
-                    s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mvmask, m->k.expmask,
+                    s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.mv_cnt, m->k.expmask,
                     m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.work_count, m->k.child, m->k.part_birth, m->pts_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
@@ -274,7 +274,9 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     k.ntiles = (int)ntiles;
     k.nblk_sweep = (int)((ntiles + 3) / 4);  // k_resample: 4 tiles (waves) per 256-thread block
     k.nblk_resample = (d.v_loc + 255) / 256 < 2048 ? (d.v_loc + 255) / 256 : 2048;  // persistent waves (4 per block)
-    HIPCHK(m, dalloc(&k.mvmask, W));
+    HIPCHK(m, dalloc(&k.mv_rec, ntiles * 64 * d.slots * 2));
+    HIPCHK(m, dalloc(&k.mv_cnt, ntiles));
+    HIPCHK(m, hipMemset(k.mv_cnt, 0, sizeof(int) * ntiles));
     const bool slab = !(d.z_lo == 0 && d.z_hi == d.nz);
     if (slab) HIPCHK(m, dalloc(&k.expmask, W));
     HIPCHK(m, dalloc(&k.part_predict, (size_t)k.ntiles * 4));
@@ -286,7 +288,6 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&k.vb_idx, (size_t)d.v_loc * 128));
     HIPCHK(m, dalloc(&s.blk_cnt, (size_t)(d.v_loc + 255) / 256 + 1));
     HIPCHK(m, hipMemset(s.mask, 0, sizeof(u64) * W)); HIPCHK(m, hipMemset(s.nbmask, 0, sizeof(u64) * W));
-    HIPCHK(m, hipMemset(k.mvmask, 0, sizeof(u64) * W));
     if (k.expmask) HIPCHK(m, hipMemset(k.expmask, 0, sizeof(u64) * W));
     HIPCHK(m, hipMemset(s.res4, 0, sizeof(float4) * (size_t)d.v_loc));
     HIPCHK(m, hipMemset(s.fut, 0, sizeof(float) * (size_t)d.v_loc * (d.T ? d.T : 1)));
@@ -823,7 +824,6 @@ extern "C" int dspmap_clear_state(dspmap_t* m) {
     const size_t W = (size_t)d.v_loc * d.mw;
     HIPCHK(m, hipMemsetAsync(m->s.mask, 0, sizeof(u64) * W, m->stream));
     HIPCHK(m, hipMemsetAsync(m->s.nbmask, 0, sizeof(u64) * W, m->stream));
-    HIPCHK(m, hipMemsetAsync(m->k.mvmask, 0, sizeof(u64) * W, m->stream));
     HIPCHK(m, hipMemsetAsync(m->s.res4, 0, sizeof(float4) * (size_t)d.v_loc, m->stream));
     HIPCHK(m, hipMemsetAsync(m->s.fut, 0, sizeof(float) * (size_t)d.v_loc * (d.T ? d.T : 1), m->stream));
     HIPCHK(m, hipMemsetAsync(m->s.fut_stat, 0, sizeof(float) * (size_t)d.v_loc, m->stream));

@@ -5,7 +5,8 @@
 
 // scratch owned by the runtime
 struct KernelScratch {
-    u64* mvmask;        // [v_loc*mw] particles that must change voxel (set by k_predict, consumed by k_claim)
+    float4* mv_rec;     // [ntiles][64*slots][2] staged records of particles that change voxel (k_predict -> k_claim)
+    int* mv_cnt;        // [ntiles] records staged per tile
     u64* expmask;       // [v_loc*mw] particles that left the slab (multi-GPU), or nullptr
     int* part_predict;  // [ntiles*4]
     int* part_claim;    // [ntiles*2]

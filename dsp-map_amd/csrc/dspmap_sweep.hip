@@ -88,7 +88,7 @@ __device__ __forceinline__ void batch_append(int* cnt, const int (&key)[RB], int
 //   constant-velocity advance + ego-motion shift (:665-667), vz := 0 (:661-663),
 //   out-of-map removal (:688); particles that stay in their voxel are registered
 //   in their pyramid (:1233-1259); particles whose voxel changed are only MARKED
-//   (mvmask) -- k_claim moves them, so every particle is advanced exactly once
+//   staged in the tile's mover list -- k_claim re-bins them, so every particle is advanced exactly once
 //   (the role of flag 7, :649,1219).
 // part[blockIdx*4 + {0,1,2,3}] = {live in, left the map, pyramid full, moved}
 // --------------------------------------------------------------------------
@@ -107,10 +107,11 @@ __device__ __forceinline__ u64 rows_of_wave(u64 tor, int wave) {
 
 template <int MW>
 __global__ void __launch_bounds__(256) k_predict(MapDims d, DevState s, FilterParams fp, int has_vz, int* __restrict__ part,
-                                                 u64* __restrict__ mvmask, u64* __restrict__ expmask) {
+                                                 float4* __restrict__ mv_rec, int* __restrict__ mv_cnt, u64* __restrict__ expmask) {
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
-    __shared__ u64 s_keep[MW * 64], s_mv[MW * 64], s_ex[MW * 64];
+    __shared__ u64 s_keep[MW * 64], s_ex[MW * 64];
+    __shared__ int s_nmv;
     __shared__ int s_cnt[4];
     __shared__ int s_any;
     const float odx = s.fpar->od[0], ody = s.fpar->od[1], odz = s.fpar->od[2], dt = s.fpar->dt;
@@ -128,24 +129,26 @@ __global__ void __launch_bounds__(256) k_predict(MapDims d, DevState s, FilterPa
         if (inr) { mword[e] = s.mask[(size_t)lv * MW + e]; nbword = s.nbmask[(size_t)lv * MW + e]; }
         live[e] = mword[e] & ~nbword;  // particles born/seeded this frame (flag 15) are not predicted (:649)
         any |= live[e] != 0ull;
-        if (wave == 0) { s_keep[e * 64 + l] = live[e]; s_mv[e * 64 + l] = 0ull; s_ex[e * 64 + l] = 0ull; }
+        if (wave == 0) { s_keep[e * 64 + l] = live[e]; s_ex[e * 64 + l] = 0ull; }
     }
-    if (tid == 0) s_any = 0;
+    if (tid == 0) { s_any = 0; s_nmv = 0; }
     if (tid < 4) s_cnt[tid] = 0;
     __syncthreads();
     if (wave == 0 && __ballot(any) && l == 0) s_any = 1;
     __syncthreads();
     if (!s_any) {  // empty tile
         if (tid < 4) part[blockIdx.x * 4 + tid] = 0;
+        if (tid == 0) mv_cnt[blockIdx.x] = 0;
         return;
     }
+    const size_t mv_base = (size_t)blockIdx.x * 64 * d.slots;  // this tile's staging area (2 float4 per record)
     for (int i = tid; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
     for (int i = tid; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
     __syncthreads();
     int c_live = 0, c_out = 0, c_pf = 0, c_mv = 0;
 #pragma unroll
     for (int e = 0; e < MW; ++e) {
-        u64 keep_clr = 0ull, mv = 0ull, ex = 0ull;
+        u64 keep_clr = 0ull, ex = 0ull;
         u64 tor = rows_of_wave(wave_or_u64(live[e]), wave);
         while (tor) {
             int row[RB];
@@ -196,7 +199,15 @@ __global__ void __launch_bounds__(256) k_predict(MapDims d, DevState s, FilterPa
                         const int nlv = gv - d.v_base;
                         if (nlv == lv) pyr[r] = pyramid_of(d, s_ph, s_pv, px[r], py[r], pz[r]);
                         else if (nlv < 0 || nlv >= d.v_loc) ex |= bit;   // left the slab (multi-GPU)
-                        else { mv |= bit; ++c_mv; }
+                        else {
+                            // voxel changed: hand the record to k_claim through the tile's staging list and
+                            // free the slot now (the record is safe in the list)
+                            const int k = atomicAdd(&s_nmv, 1);
+                            mv_rec[(mv_base + k) * 2] = make_float4(__int_as_float(gv), vx[r], vy[r], px[r]);
+                            mv_rec[(mv_base + k) * 2 + 1] = make_float4(py[r], pz[r], w[r], 0.f);
+                            keep_clr |= bit;
+                            ++c_mv;
+                        }
                     }
                 }
             }
@@ -217,7 +228,6 @@ __global__ void __launch_bounds__(256) k_predict(MapDims d, DevState s, FilterPa
             }
         }
         if (keep_clr) atomicAnd(&s_keep[e * 64 + l], ~keep_clr);
-        if (mv) atomicOr(&s_mv[e * 64 + l], mv);
         if (ex) atomicOr(&s_ex[e * 64 + l], ex);
     }
     // per-block statistics (reduced lazily by the host; no global atomics here)
@@ -232,125 +242,75 @@ __global__ void __launch_bounds__(256) k_predict(MapDims d, DevState s, FilterPa
     if (wave == 0 && inr) {
 #pragma unroll
         for (int e = 0; e < MW; ++e) {
-            // movers / exports keep their live bit until k_claim / the export pass has copied them out
+            // exports keep their live bit until the export pass has copied them out
             const u64 nm = s_keep[e * 64 + l] | (mword[e] & ~live[e]);
             if (nm != mword[e]) s.mask[(size_t)lv * MW + e] = nm;
-            if (s_mv[e * 64 + l]) mvmask[(size_t)lv * MW + e] = s_mv[e * 64 + l];
             if (expmask && s_ex[e * 64 + l]) expmask[(size_t)lv * MW + e] = s_ex[e * 64 + l];
         }
     }
+    if (tid == 0) mv_cnt[blockIdx.x] = s_nmv;
     if (tid < 4) part[blockIdx.x * 4 + tid] = s_cnt[tid];
 }
 
 // --------------------------------------------------------------------------
-// k_claim: the voxel-changing half of moveParticle (:1209-1230) for the
-// particles k_predict marked.  A mover claims the lowest free slot of its
-// destination voxel with one atomic OR (first-free-slot rule :1214-1215), copies
-// its record, registers in its pyramid (:1233-1259); the source slots of a voxel
-// are released together once all its movers have been read.  Destination full ->
-// the particle vanishes (-1, :1227-1229).
+// k_claim: the voxel-changing half of moveParticle (:1209-1230).  One workgroup per source tile
+// walks the tile's staged mover records with DENSE lanes (coalesced 32-byte records): a mover claims
+// the lowest free slot of its destination voxel with one atomic OR (first-free-slot rule
+// :1214-1215), writes its record there and registers in its pyramid (:1233-1259).  Destination
+// full -> the particle vanishes (-1, :1227-1229).
 // part2[blockIdx*2 + {0,1}] = {voxel full, pyramid full}
 // --------------------------------------------------------------------------
 template <int MW>
-__global__ void __launch_bounds__(256) k_claim(MapDims d, DevState s, u64* __restrict__ mvmask, int* __restrict__ part2) {
+__global__ void __launch_bounds__(256) k_claim(MapDims d, DevState s, const float4* __restrict__ mv_rec,
+                                               const int* __restrict__ mv_cnt, int* __restrict__ part2) {
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
     __shared__ int s_cnt[2];
-    __shared__ int s_any;
     const int tid = threadIdx.x;
-    const int l = lane_id();
-    const int wave = tid >> 6;
-    const int lv = blockIdx.x * 64 + l;   // the four waves of the block share one tile
-    const bool inr = lv < d.v_loc;
-    const int lvs = inr ? lv : 0;
-    u64 mvw[MW];
-    bool any = false;
-    if (tid == 0) s_any = 0;
-    if (tid < 2) s_cnt[tid] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < MW; ++e) {
-        mvw[e] = inr ? mvmask[(size_t)lv * MW + e] : 0ull;
-        any |= mvw[e] != 0ull;
-    }
-    if (wave == 0 && __ballot(any) && l == 0) s_any = 1;
-    __syncthreads();
-    if (!s_any) {
+    const int n = mv_cnt[blockIdx.x];
+    if (n == 0) {
         if (tid < 2) part2[blockIdx.x * 2 + tid] = 0;
         return;
     }
     for (int i = tid; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
     for (int i = tid; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
+    if (tid < 2) s_cnt[tid] = 0;
     __syncthreads();
+    const size_t mv_base = (size_t)blockIdx.x * 64 * d.slots;
     int c_vf = 0, c_pf = 0;
-#pragma unroll
-    for (int e = 0; e < MW; ++e) {
-        u64 tor = rows_of_wave(wave_or_u64(mvw[e]), wave);
-        u64 mine = 0ull;  // source slots handled (and to be released) by this wave
-        while (tor) {
-            int row[RB];
-            float vx[RB], vy[RB], px[RB], py[RB], pz[RB], w[RB];
-            bool act[RB];
-#pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                row[r] = tor ? __ffsll((long long)tor) - 1 : -1;
-                if (tor) tor &= tor - 1ull;
-                act[r] = row[r] >= 0 && ((mvw[e] >> (row[r] & 63)) & 1ull);
-                vx[r] = vy[r] = px[r] = py[r] = pz[r] = w[r] = 0.f;
-                if (act[r]) {
-                    const size_t idx = pidx(d, lvs, e * 64 + row[r]);
-                    vx[r] = s.vx[idx]; vy[r] = s.vy[idx];
-                    px[r] = s.px[idx]; py[r] = s.py[idx]; pz[r] = s.pz[idx];
-                    w[r] = s.w[idx];
-                    mine |= 1ull << row[r];
-                }
-            }
-            int pyr[RB], pos[RB], nlv[RB], nsl[RB];
-            size_t nidx[RB];
-#pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                pyr[r] = -1; nlv[r] = -1; nsl[r] = -1; nidx[r] = 0;
-                if (act[r]) {
-                    int gv = 0;
-                    voxel_of(d, px[r], py[r], pz[r], gv);  // in-map and in-slab by construction (k_predict)
-                    nlv[r] = gv - d.v_base;
-                    nsl[r] = claim_slot(s.mask, nlv[r], d);
-                    if (nsl[r] >= 0) {
-                        nidx[r] = pidx(d, nlv[r], nsl[r]);
-                        s.px[nidx[r]] = px[r]; s.py[nidx[r]] = py[r]; s.pz[nidx[r]] = pz[r];
-                        s.vx[nidx[r]] = vx[r]; s.vy[nidx[r]] = vy[r]; s.w[nidx[r]] = w[r];
-                        pyr[r] = pyramid_of(d, s_ph, s_pv, px[r], py[r], pz[r]);
-                    } else {
-                        ++c_vf;
-                    }
-                }
-            }
-            batch_append(s.pyr_cnt, pyr, pos);
-#pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                if (pyr[r] >= 0) {
-                    if (pos[r] < d.capp) {
-                        const size_t o = (size_t)pyr[r] * d.capp + pos[r];
-                        s.fov_rec[o] = make_float4(px[r], py[r], pz[r], w[r]);
-                        s.fov_slot[o] = (int)nidx[r];
-                    } else {
-                        ++c_pf;  // :1256-1259
-                        atomicAnd(&s.mask[(size_t)nlv[r] * MW + (nsl[r] >> 6)], ~(1ull << (nsl[r] & 63)));
-                    }
-                }
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        int pyr = -1, nlv = -1, nsl = -1;
+        size_t nidx = 0;
+        float px = 0, py = 0, pz = 0, w = 0;
+        if (i < n) {
+            const float4 a = mv_rec[(mv_base + i) * 2], b = mv_rec[(mv_base + i) * 2 + 1];
+            px = a.w; py = b.x; pz = b.y; w = b.z;
+            nlv = __float_as_int(a.x) - d.v_base;
+            nsl = claim_slot(s.mask, nlv, d);
+            if (nsl >= 0) {
+                nidx = pidx(d, nlv, nsl);
+                s.px[nidx] = px; s.py[nidx] = py; s.pz[nidx] = pz;
+                s.vx[nidx] = a.y; s.vy[nidx] = a.z; s.w[nidx] = w;
+                pyr = pyramid_of(d, s_ph, s_pv, px, py, pz);
+            } else {
+                ++c_vf;
             }
         }
-        if (mine) {
-            // every record of these movers is in registers / on its way to the new slot: release the
-            // source slots.  The wait makes sure the loads above have returned before another mover
-            // can see a slot free and overwrite it.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            atomicAnd(&s.mask[(size_t)lv * MW + e], ~mine);
-            atomicAnd(&mvmask[(size_t)lv * MW + e], ~mine);
+        const int pos = wave_agg_inc(s.pyr_cnt, pyr, pyr >= 0);
+        if (pyr >= 0) {
+            if (pos < d.capp) {
+                const size_t o = (size_t)pyr * d.capp + pos;
+                s.fov_rec[o] = make_float4(px, py, pz, w);
+                s.fov_slot[o] = (int)nidx;
+            } else {
+                ++c_pf;  // :1256-1259
+                atomicAnd(&s.mask[(size_t)nlv * MW + (nsl >> 6)], ~(1ull << (nsl & 63)));
+            }
         }
     }
     c_vf = wave_sum_i(c_vf); c_pf = wave_sum_i(c_pf);
-    if (l == 0) {
+    if (lane_id() == 0) {
         if (c_vf) atomicAdd(&s_cnt[0], c_vf);
         if (c_pf) atomicAdd(&s_cnt[1], c_pf);
     }
@@ -358,17 +318,6 @@ __global__ void __launch_bounds__(256) k_claim(MapDims d, DevState s, u64* __res
     if (tid < 2) part2[blockIdx.x * 2 + tid] = s_cnt[tid];
 }
 
-// --------------------------------------------------------------------------
-// k_resample: mapOccupancyCalculationAndResample :924-1057, one lane per voxel.
-// pass 1 (rows in slot order): cull w < 1e-3 (:941), mass (:970-974), mean velocity of
-//   the non-newborn survivors (:944-948,976-984), constant-velocity future rollout
-//   (:950-964; static particles stay in their voxel for every horizon and are kept in a
-//   per-voxel accumulator folded in at readout, moving ones scatter with float atomics).
-// pass 2 (voxels with >= 5 survivors): systematic resampling exactly as the reference's
-//   loop (:1005-1053): running sum vs. accumulated thresholds in fp32, copies into the
-//   lowest free slot, "no free slot -> fold the weight back" (:1037-1041).
-// part_live[global wave] = live particles left in the wave's tile
-// --------------------------------------------------------------------------
 #define RBK 8  // rows per batch in k_resample (few registers per row: deeper batches, fewer round trips)
 
 #define CPMAX 64  // copies a voxel can make in one resampling (<= M <= 64)
@@ -834,15 +783,15 @@ void launch_predict_only(const LaunchCtx& c) {
     const KernelScratch* k = &c.k;
     if (c.d.mw == 1)
         hipLaunchKernelGGL(k_predict<1>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, c.fp,
-                           c.s.vz0 ? 1 : 0, k->part_predict, k->mvmask, k->expmask);
+                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->mv_cnt, k->expmask);
     else
         hipLaunchKernelGGL(k_predict<2>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, c.fp,
-                           c.s.vz0 ? 1 : 0, k->part_predict, k->mvmask, k->expmask);
+                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->mv_cnt, k->expmask);
 }
 void launch_claim(const LaunchCtx& c) {
     const KernelScratch* k = &c.k;
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_claim<1>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->mvmask, k->part_claim);
-    else hipLaunchKernelGGL(k_claim<2>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->mvmask, k->part_claim);
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_claim<1>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->mv_rec, k->mv_cnt, k->part_claim);
+    else hipLaunchKernelGGL(k_claim<2>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->mv_rec, k->mv_cnt, k->part_claim);
 }
 void launch_predict(const LaunchCtx& c) {
     launch_predict_only(c);
