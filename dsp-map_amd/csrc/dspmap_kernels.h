@@ -13,6 +13,9 @@ struct KernelScratch {
     int* part_resample; // [nblk_resample*4]
     int* vb_cnt;        // [v_loc] children per destination voxel this frame (birth ordering)
     int* vb_idx;        // [v_loc*128] their birth indices
+    int* ck_items;      // [np * ceil(capp/128)] work items of k_ck_partial (pyramid<<12 | chunk)
+    int* wu_items;      // [np * (ceil(capp/256)+1)] work items of k_weight
+    int* n_items;       // [2]
     int* part_birth;    // [ceil(birth_cap*32/256)*2] per-block {born, dropped} of k_birth_insert
     float4* child;      // [birth_cap*32] child position + destination voxel of this frame's births
     int* work_list;     // [v_loc] non-empty voxels of this frame (resample work list)

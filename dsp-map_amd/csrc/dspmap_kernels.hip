@@ -152,14 +152,45 @@ __global__ void k_obs_gather(MapDims d, DevState s) {
 // --------------------------------------------------------------------------
 #define CK_TPB 256
 #define CK_PCH 128
+#define WU_TPB 256
 
-__device__ __forceinline__ void decode_pyr_block(int bid, int nchunk, int np, int& b, int& chunk) {
-    const int xcd = bid & 7;
-    const int j = bid >> 3;
-    b = (j / nchunk) * 8 + xcd;
-    chunk = j % nchunk;
-    (void)np;
+// Work items of the two pair kernels: (pyramid, chunk of its particle list).  The list lengths are only
+// known on the device, so a one-workgroup kernel expands them into a compact item list each frame and the
+// pair kernels run a fixed grid that strides over it -- no empty workgroups, and the items of a heavy
+// pyramid spread over all XCDs.  item = (pyramid << 12) | chunk.
+__global__ void __launch_bounds__(512) k_pyr_items(MapDims d, DevState s, int* __restrict__ ck_items, int* __restrict__ wu_items,
+                                                   int* __restrict__ n_items) {
+    __shared__ int s_ck[513], s_wu[513];
+    __shared__ int s_base[2];
+    const int tid = threadIdx.x;
+    if (tid < 2) s_base[tid] = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < d.np; b0 += 512) {
+        const int b = b0 + tid;
+        int nck = 0, nwu = 0;
+        if (b < d.np) {
+            const int P = min(s.pyr_cnt[b], d.capp);
+            nck = (P + CK_PCH - 1) / CK_PCH;
+            nwu = max(1, (P + WU_TPB - 1) / WU_TPB);  // chunk 0 always exists: it owns the bin's 1/Ck sum
+        }
+        s_ck[tid] = nck; s_wu[tid] = nwu;
+        __syncthreads();
+        if (tid == 0) {
+            int a = s_base[0], w = s_base[1];
+            for (int k = 0; k < 512; ++k) { const int x = s_ck[k], y = s_wu[k]; s_ck[k] = a; s_wu[k] = w; a += x; w += y; }
+            s_ck[512] = a; s_wu[512] = w;
+        }
+        __syncthreads();
+        if (b < d.np) {
+            for (int c = 0; c < nck; ++c) ck_items[s_ck[tid] + c] = (b << 12) | c;
+            for (int c = 0; c < nwu; ++c) wu_items[s_wu[tid] + c] = (b << 12) | c;
+        }
+        __syncthreads();
+        if (tid == 0) { s_base[0] = s_ck[512]; s_base[1] = s_wu[512]; n_items[0] = s_ck[512]; n_items[1] = s_wu[512]; }
+        __syncthreads();
+    }
 }
+
 __device__ __forceinline__ int neighbor_bins(const MapDims& d, int b, int* bins) {
     // findPyramidNeighborIndexInFOV :1128-1147 (h-major order, clipped at the FOV edge)
     const int h0 = b / d.np_v, v0 = b % d.np_v;
@@ -202,42 +233,45 @@ __device__ __forceinline__ void neighbor_prefix(int* s_bin, int* s_off) {
     }
 }
 
-__global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, FilterParams fp, int nchunk) {
+__global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, FilterParams fp, const int* __restrict__ items,
+                                                       const int* __restrict__ n_items) {
     __shared__ float4 s_p[CK_PCH];
     __shared__ int s_bin[9];
     __shared__ int s_off[10];
-    int b, chunk;
-    decode_pyr_block(blockIdx.x, nchunk, d.np, b, chunk);
-    if (b >= d.np) return;
-    const int P = min(s.pyr_cnt[b], d.capp);
-    const int start = chunk * CK_PCH;
-    if (start >= P) return;
-    const int npart = min(CK_PCH, P - start);
     const int tid = threadIdx.x;
-    neighbor_setup(d, s, b, s_bin, s_off);
-    __syncthreads();
-    neighbor_prefix(s_bin, s_off);
-    __syncthreads();
-    const int O = s_off[9];
-    if (O == 0) return;
-    for (int i = tid; i < npart; i += CK_TPB) {
-        float4 r = s.fov_rec[(size_t)b * d.capp + start + i];
-        r.w = fp.p_det * r.w;  // P_detection * weight (pre-update weights), :732
-        s_p[i] = r;
-    }
-    __syncthreads();
-    for (int o = tid; o < O; o += CK_TPB) {
-        int k = 0;
-#pragma unroll
-        for (int q = 1; q < 9; ++q) k += (o >= s_off[q]) ? 1 : 0;
-        const int oi = s_bin[k] * DSP_OBS_CAP + (o - s_off[k]);
-        const float4 z = s.obs[oi];
-        float acc = 0.f;
-        for (int i = 0; i < npart; ++i) {
-            const float4 p = s_p[i];
-            acc += p.w * pair_gk(p.x, p.y, p.z, z.x, z.y, z.z, fp.sigma_ob, fp.inv_sigma_ob, fp.pdf_c3);
+    const int total = n_items[0];
+    for (int it = blockIdx.x; it < total; it += gridDim.x) {
+        const int item = items[it];
+        const int b = item >> 12, chunk = item & 0xfff;
+        const int P = min(s.pyr_cnt[b], d.capp);
+        const int start = chunk * CK_PCH;
+        const int npart = min(CK_PCH, P - start);
+        __syncthreads();  // LDS reuse across items
+        neighbor_setup(d, s, b, s_bin, s_off);
+        __syncthreads();
+        neighbor_prefix(s_bin, s_off);
+        __syncthreads();
+        const int O = s_off[9];
+        if (O == 0) continue;
+        for (int i = tid; i < npart; i += CK_TPB) {
+            float4 r = s.fov_rec[(size_t)b * d.capp + start + i];
+            r.w = fp.p_det * r.w;  // P_detection * weight (pre-update weights), :732
+            s_p[i] = r;
         }
-        unsafeAtomicAdd(&s.obs_ck[oi], acc);
+        __syncthreads();
+        for (int o = tid; o < O; o += CK_TPB) {
+            int k = 0;
+#pragma unroll
+            for (int q = 1; q < 9; ++q) k += (o >= s_off[q]) ? 1 : 0;
+            const int oi = s_bin[k] * DSP_OBS_CAP + (o - s_off[k]);
+            const float4 z = s.obs[oi];
+            float acc = 0.f;
+            for (int i = 0; i < npart; ++i) {
+                const float4 p = s_p[i];
+                acc += p.w * pair_gk(p.x, p.y, p.z, z.x, z.y, z.z, fp.sigma_ob, fp.inv_sigma_ob, fp.pdf_c3);
+            }
+            unsafeAtomicAdd(&s.obs_ck[oi], acc);
+        }
     }
 }
 
@@ -273,64 +307,65 @@ __global__ void __launch_bounds__(512) k_ck_sum(MapDims d, DevState s, FilterPar
 // Lanes are particles; the neighbourhood's observations {x,y,z,P_d/Ck} are
 // staged in LDS and broadcast.  The new weight is scattered back to the slot.
 // --------------------------------------------------------------------------
-#define WU_TPB 256
-
-__global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, FilterParams fp, int nchunk) {
+__global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, FilterParams fp, const int* __restrict__ items,
+                                                   const int* __restrict__ n_items) {
     __shared__ float4 s_o[9 * DSP_OBS_CAP];
     __shared__ int s_bin[9];
     __shared__ int s_off[10];
     __shared__ float s_inv[WU_TPB / 64];
-    int b, chunk;
-    decode_pyr_block(blockIdx.x, nchunk, d.np, b, chunk);
-    if (b >= d.np) return;
-    const int P = min(s.pyr_cnt[b], d.capp);
-    const int start = chunk * WU_TPB;
-    if (start >= P && chunk != 0) return;
     const int tid = threadIdx.x;
+    const int total = n_items[1];
     const float add = frame_lambda(s, fp) + fp.kappa;  // :737
-    if (chunk == 0) {
-        // final Ck of this pyramid's own observations + their sum of 1/Ck (:799-804)
-        const int nob = s.obs_cnt[b];
-        float inv = 0.f;
-        if (tid < nob) {
-            const float ck = s.obs_ck[b * DSP_OBS_CAP + tid] + add;
-            s.obs_ckf[b * DSP_OBS_CAP + tid] = ck;
-            inv = __fdiv_rn(1.f, ck);
+    for (int it = blockIdx.x; it < total; it += gridDim.x) {
+        const int item = items[it];
+        const int b = item >> 12, chunk = item & 0xfff;
+        const int P = min(s.pyr_cnt[b], d.capp);
+        const int start = chunk * WU_TPB;
+        __syncthreads();  // LDS reuse across items
+        if (chunk == 0) {
+            // final Ck of this pyramid's own observations + their sum of 1/Ck (:799-804)
+            const int nob = s.obs_cnt[b];
+            float inv = 0.f;
+            if (tid < nob) {
+                const float ck = s.obs_ck[b * DSP_OBS_CAP + tid] + add;
+                s.obs_ckf[b * DSP_OBS_CAP + tid] = ck;
+                inv = __fdiv_rn(1.f, ck);
+            }
+            inv = wave_sum(inv);
+            if ((tid & 63) == 0) s_inv[tid >> 6] = inv;
+            __syncthreads();
+            if (tid == 0) s.part_inv[b] = (s_inv[0] + s_inv[1]) + (s_inv[2] + s_inv[3]);
+            if (start >= P) continue;
         }
-        inv = wave_sum(inv);
-        if ((tid & 63) == 0) s_inv[tid >> 6] = inv;
+        neighbor_setup(d, s, b, s_bin, s_off);
         __syncthreads();
-        if (tid == 0) s.part_inv[b] = (s_inv[0] + s_inv[1]) + (s_inv[2] + s_inv[3]);
-        if (start >= P) return;
-    }
-    neighbor_setup(d, s, b, s_bin, s_off);
-    __syncthreads();
-    neighbor_prefix(s_bin, s_off);
-    __syncthreads();
-    const int O = s_off[9];
-    for (int o = tid; o < O; o += WU_TPB) {
-        int k = 0;
+        neighbor_prefix(s_bin, s_off);
+        __syncthreads();
+        const int O = s_off[9];
+        for (int o = tid; o < O; o += WU_TPB) {
+            int k = 0;
 #pragma unroll
-        for (int q = 1; q < 9; ++q) k += (o >= s_off[q]) ? 1 : 0;
-        const int oi = s_bin[k] * DSP_OBS_CAP + (o - s_off[k]);
-        float4 z = s.obs[oi];
-        z.w = __fdiv_rn(fp.p_det, s.obs_ck[oi] + add);
-        s_o[o] = z;
+            for (int q = 1; q < 9; ++q) k += (o >= s_off[q]) ? 1 : 0;
+            const int oi = s_bin[k] * DSP_OBS_CAP + (o - s_off[k]);
+            float4 z = s.obs[oi];
+            z.w = __fdiv_rn(fp.p_det, s.obs_ck[oi] + add);
+            s_o[o] = z;
+        }
+        __syncthreads();
+        const int i = start + tid;
+        if (i >= P) continue;
+        const size_t ri = (size_t)b * d.capp + i;
+        const float4 p = s.fov_rec[ri];
+        const float maxlen = s.obs_maxlen[b];
+        const float dist = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
+        if (maxlen > 0.f && dist > maxlen + fp.occl_margin) continue;  // occluded :761-765
+        float sum = 0.f;
+        for (int o = 0; o < O; ++o) {
+            const float4 z = s_o[o];
+            sum += pair_gk(p.x, p.y, p.z, z.x, z.y, z.z, fp.sigma_ob, fp.inv_sigma_ob, fp.pdf_c3) * z.w;
+        }
+        s.w[s.fov_slot[ri]] = p.w * ((1.f - fp.p_det) + sum);  // :786
     }
-    __syncthreads();
-    const int i = start + tid;
-    if (i >= P) return;
-    const size_t ri = (size_t)b * d.capp + i;
-    const float4 p = s.fov_rec[ri];
-    const float maxlen = s.obs_maxlen[b];
-    const float dist = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
-    if (maxlen > 0.f && dist > maxlen + fp.occl_margin) return;  // occluded :761-765
-    float sum = 0.f;
-    for (int o = 0; o < O; ++o) {
-        const float4 z = s_o[o];
-        sum += pair_gk(p.x, p.y, p.z, z.x, z.y, z.z, fp.sigma_ob, fp.inv_sigma_ob, fp.pdf_c3) * z.w;
-    }
-    s.w[s.fov_slot[ri]] = p.w * ((1.f - fp.p_det) + sum);  // :786
 }
 
 // --------------------------------------------------------------------------
@@ -686,17 +721,14 @@ void launch_obs_bin(const LaunchCtx& c, int n_pts_grid) {
 }
 
 void launch_ck_partial(const LaunchCtx& c) {
-    const int nchunk = (c.d.capp + CK_PCH - 1) / CK_PCH;
-    const int np8 = (c.d.np + 7) / 8 * 8;
-    hipLaunchKernelGGL(k_ck_partial, dim3(np8 * nchunk), dim3(CK_TPB), 0, c.stream, c.d, c.s, c.fp, nchunk);
+    hipLaunchKernelGGL(k_pyr_items, dim3(1), dim3(512), 0, c.stream, c.d, c.s, c.k.ck_items, c.k.wu_items, c.k.n_items);
+    hipLaunchKernelGGL(k_ck_partial, dim3(4096), dim3(CK_TPB), 0, c.stream, c.d, c.s, c.fp, c.k.ck_items, c.k.n_items);
 }
 void launch_ck_finalize(const LaunchCtx& c) {  // after launch_weight_update: reduces the per-pyramid 1/Ck sums
     hipLaunchKernelGGL(k_ck_sum, dim3(1), dim3(512), 0, c.stream, c.d, c.s, c.fp);
 }
-void launch_weight_update(const LaunchCtx& c) {
-    const int nchunk = (c.d.capp + WU_TPB - 1) / WU_TPB;
-    const int np8 = (c.d.np + 7) / 8 * 8;
-    hipLaunchKernelGGL(k_weight, dim3(np8 * nchunk), dim3(WU_TPB), 0, c.stream, c.d, c.s, c.fp, nchunk);
+void launch_weight_update(const LaunchCtx& c) {  // after launch_ck_partial (which also builds the item lists)
+    hipLaunchKernelGGL(k_weight, dim3(4096), dim3(WU_TPB), 0, c.stream, c.d, c.s, c.fp, c.k.wu_items, c.k.n_items);
 }
 
 // n_birth_grid sizes the launches (>= the frame's n_birth, which the kernels read from FrameParams)
