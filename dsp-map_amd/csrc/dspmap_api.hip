@@ -276,8 +276,8 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     k.nblk_resample = (d.v_loc + 255) / 256 < 2048 ? (d.v_loc + 255) / 256 : 2048;  // persistent waves (4 per block)
     HIPCHK(m, dalloc(&k.mv_rec, ntiles * 64 * d.slots * 2));
     HIPCHK(m, dalloc(&k.mv_cnt, ntiles));
-    HIPCHK(m, dalloc(&k.ck_items, (size_t)d.np * ((d.capp + 127) / 128 + 1)));
-    HIPCHK(m, dalloc(&k.wu_items, (size_t)d.np * ((d.capp + 255) / 256 + 1)));
+    HIPCHK(m, dalloc(&k.ck_items, (size_t)d.np * ((d.capp + 63) / 64 + 1)));
+    HIPCHK(m, dalloc(&k.wu_items, (size_t)d.np * ((d.capp + 31) / 32 + 1)));
     HIPCHK(m, dalloc(&k.n_items, (size_t)2));
     HIPCHK(m, hipMemset(k.mv_cnt, 0, sizeof(int) * ntiles));
     const bool slab = !(d.z_lo == 0 && d.z_hi == d.nz);

@@ -151,13 +151,15 @@ __global__ void k_obs_gather(MapDims d, DevState s) {
 // same XCD (blockIdx % 8) so its obs tile and Ck lines stay in one L2.
 // --------------------------------------------------------------------------
 #define CK_TPB 256
-#define CK_PCH 128
+#define CK_PCH 64
 #define WU_TPB 256
 
 // Work items of the two pair kernels: (pyramid, chunk of its particle list).  The list lengths are only
 // known on the device, so a one-workgroup kernel expands them into a compact item list each frame and the
 // pair kernels run a fixed grid that strides over it -- no empty workgroups, and the items of a heavy
 // pyramid spread over all XCDs.  item = (pyramid << 12) | chunk.
+__device__ __forceinline__ int wu_split(int O) { return O <= 64 ? 1 : (O <= 128 ? 2 : (O <= 256 ? 4 : 8)); }
+
 __global__ void __launch_bounds__(512) k_pyr_items(MapDims d, DevState s, int* __restrict__ ck_items, int* __restrict__ wu_items,
                                                    int* __restrict__ n_items) {
     __shared__ int s_ck[513], s_wu[513];
@@ -170,8 +172,17 @@ __global__ void __launch_bounds__(512) k_pyr_items(MapDims d, DevState s, int* _
         int nck = 0, nwu = 0;
         if (b < d.np) {
             const int P = min(s.pyr_cnt[b], d.capp);
-            nck = (P + CK_PCH - 1) / CK_PCH;
-            nwu = max(1, (P + WU_TPB - 1) / WU_TPB);  // chunk 0 always exists: it owns the bin's 1/Ck sum
+            // observations in the 3x3 neighbourhood: decides how many lanes share one particle in k_weight
+            const int h0 = b / d.np_v, v0 = b % d.np_v;
+            int O = 0;
+            for (int i = -1; i <= 1; ++i)
+                for (int j = -1; j <= 1; ++j) {
+                    const int h = h0 + i, v = v0 + j;
+                    if (h >= 0 && h < d.np_h && v >= 0 && v < d.np_v) O += s.obs_cnt[h * d.np_v + v];
+                }
+            const int pw = WU_TPB / wu_split(O);      // particles per k_weight item
+            nck = O > 0 ? (P + CK_PCH - 1) / CK_PCH : 0;
+            nwu = max(1, (P + pw - 1) / pw);          // chunk 0 always exists: it owns the bin's 1/Ck sum
         }
         s_ck[tid] = nck; s_wu[tid] = nwu;
         __syncthreads();
@@ -259,14 +270,19 @@ __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, Fi
             s_p[i] = r;
         }
         __syncthreads();
-        for (int o = tid; o < O; o += CK_TPB) {
+        // lanes = (observation, particle group): with few observations the 256 lanes split the particle
+        // chunk G ways so that every lane is busy and the loop is short; partial sums meet in the atomic
+        const int opad = O <= 64 ? 64 : (O <= 128 ? 128 : 256);
+        const int G = CK_TPB / opad;
+        const int g = tid / opad;
+        for (int o = tid % opad; o < O; o += opad) {
             int k = 0;
 #pragma unroll
             for (int q = 1; q < 9; ++q) k += (o >= s_off[q]) ? 1 : 0;
             const int oi = s_bin[k] * DSP_OBS_CAP + (o - s_off[k]);
             const float4 z = s.obs[oi];
             float acc = 0.f;
-            for (int i = 0; i < npart; ++i) {
+            for (int i = g; i < npart; i += G) {
                 const float4 p = s_p[i];
                 acc += p.w * pair_gk(p.x, p.y, p.z, z.x, z.y, z.z, fp.sigma_ob, fp.inv_sigma_ob, fp.pdf_c3);
             }
@@ -320,7 +336,6 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
         const int item = items[it];
         const int b = item >> 12, chunk = item & 0xfff;
         const int P = min(s.pyr_cnt[b], d.capp);
-        const int start = chunk * WU_TPB;
         __syncthreads();  // LDS reuse across items
         if (chunk == 0) {
             // final Ck of this pyramid's own observations + their sum of 1/Ck (:799-804)
@@ -335,7 +350,7 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
             if ((tid & 63) == 0) s_inv[tid >> 6] = inv;
             __syncthreads();
             if (tid == 0) s.part_inv[b] = (s_inv[0] + s_inv[1]) + (s_inv[2] + s_inv[3]);
-            if (start >= P) continue;
+            if (P == 0) continue;
         }
         neighbor_setup(d, s, b, s_bin, s_off);
         __syncthreads();
@@ -352,19 +367,33 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
             s_o[o] = z;
         }
         __syncthreads();
-        const int i = start + tid;
-        if (i >= P) continue;
-        const size_t ri = (size_t)b * d.capp + i;
-        const float4 p = s.fov_rec[ri];
-        const float maxlen = s.obs_maxlen[b];
-        const float dist = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
-        if (maxlen > 0.f && dist > maxlen + fp.occl_margin) continue;  // occluded :761-765
-        float sum = 0.f;
-        for (int o = 0; o < O; ++o) {
-            const float4 z = s_o[o];
-            sum += pair_gk(p.x, p.y, p.z, z.x, z.y, z.z, fp.sigma_ob, fp.inv_sigma_ob, fp.pdf_c3) * z.w;
+        // SPL adjacent lanes share one particle and split the observation loop (short critical path when
+        // the neighbourhood holds hundreds of observations); their partial sums are combined with shuffles
+        const int spl = wu_split(O);
+        const int pw = WU_TPB / spl;
+        const int i = chunk * pw + tid / spl;
+        const int sub = tid % spl;
+        const bool valid = i < P;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        size_t ri = 0;
+        bool occluded = false;
+        if (valid) {
+            ri = (size_t)b * d.capp + i;
+            p = s.fov_rec[ri];
+            const float maxlen = s.obs_maxlen[b];
+            const float dist = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
+            occluded = maxlen > 0.f && dist > maxlen + fp.occl_margin;  // :761-765
         }
-        s.w[s.fov_slot[ri]] = p.w * ((1.f - fp.p_det) + sum);  // :786
+        float sum = 0.f;
+        if (valid && !occluded)
+            for (int o = sub; o < O; o += spl) {
+                const float4 z = s_o[o];
+                sum += pair_gk(p.x, p.y, p.z, z.x, z.y, z.z, fp.sigma_ob, fp.inv_sigma_ob, fp.pdf_c3) * z.w;
+            }
+        if (spl >= 2) sum += __shfl_xor(sum, 1, WAVE);
+        if (spl >= 4) sum += __shfl_xor(sum, 2, WAVE);
+        if (spl >= 8) sum += __shfl_xor(sum, 4, WAVE);
+        if (valid && !occluded && sub == 0) s.w[s.fov_slot[ri]] = p.w * ((1.f - fp.p_det) + sum);  // :786
     }
 }
 
