@@ -765,11 +765,17 @@ void launch_birth_split(const LaunchCtx& c, int n_birth_grid) {
     if (n_birth_grid <= 0) return;
     hipLaunchKernelGGL(k_birth_split, dim3((n_birth_grid + 3) / 4), dim3(256), 0, c.stream, c.d, c.s, c.fp);
 }
+// Zeroing kernel instead of hipMemsetAsync: a memset node inside the captured frame graph
+// faulted on ROCm 7.2 whenever other streams were busy between replays; kernel nodes do not.
+__global__ void k_zero_i32(int* __restrict__ p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
 void launch_birth_plan_insert(const LaunchCtx& c, int n_birth_grid) {
     if (n_birth_grid <= 0) return;
     const long long total = (long long)n_birth_grid * c.fp.nb_num;
     const unsigned gb = (unsigned)((total + 255) / 256);
-    (void)hipMemsetAsync(c.k.vb_cnt, 0, sizeof(int) * (size_t)c.d.v_loc, c.stream);
+    hipLaunchKernelGGL(k_zero_i32, dim3((c.d.v_loc + 255) / 256), dim3(256), 0, c.stream, c.k.vb_cnt, c.d.v_loc);
     hipLaunchKernelGGL(k_birth_rank, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
     hipLaunchKernelGGL(k_birth_children, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx);
     hipLaunchKernelGGL(k_birth_cursors, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
