@@ -131,7 +131,7 @@ static void free_dev(dspmap* m) {
     void* ptrs[] = {s.fpar, s.obs_ckf, s.part_inv, s.fut_stat, s.mask, s.nbmask, s.px, s.py, s.pz, s.vx, s.vy, s.w, s.vz0, s.res4, s.fut, s.obs, s.obs_ck,
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.nstatic, s.fov_rec, s.fov_slot, s.pyr_cnt, s.mv_rec, s.exp_up, s.exp_down,
-                    s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.mv_cnt, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.expmask,
+                    s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.in_rec, m->k.in_cnt, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.expmask,
                     m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.work_count, m->k.child, m->k.part_birth, m->pts_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
@@ -275,11 +275,12 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     k.nblk_sweep = (int)((ntiles + 3) / 4);  // k_resample: 4 tiles (waves) per 256-thread block
     k.nblk_resample = (d.v_loc + 255) / 256 < 2048 ? (d.v_loc + 255) / 256 : 2048;  // persistent waves (4 per block)
     HIPCHK(m, dalloc(&k.mv_rec, ntiles * 64 * d.slots * 2));
-    HIPCHK(m, dalloc(&k.mv_cnt, ntiles));
+    HIPCHK(m, dalloc(&k.in_rec, ntiles * 64 * d.slots * 2));
+    HIPCHK(m, dalloc(&k.in_cnt, ntiles));
     HIPCHK(m, dalloc(&k.ck_items, (size_t)d.np * ((d.capp + 63) / 64 + 1)));
     HIPCHK(m, dalloc(&k.wu_items, (size_t)d.np * ((d.capp + 31) / 32 + 1)));
     HIPCHK(m, dalloc(&k.n_items, (size_t)2));
-    HIPCHK(m, hipMemset(k.mv_cnt, 0, sizeof(int) * ntiles));
+    HIPCHK(m, hipMemset(k.in_cnt, 0, sizeof(int) * ntiles));
     const bool slab = !(d.z_lo == 0 && d.z_hi == d.nz);
     if (slab) HIPCHK(m, dalloc(&k.expmask, W));
     HIPCHK(m, dalloc(&k.part_predict, (size_t)k.ntiles * 4));

@@ -5,8 +5,9 @@
 
 // scratch owned by the runtime
 struct KernelScratch {
-    float4* mv_rec;     // [ntiles][64*slots][2] staged records of particles that change voxel (k_predict -> k_claim)
-    int* mv_cnt;        // [ntiles] records staged per tile
+    float4* mv_rec;     // [ntiles][64*slots][2] per-source-tile staging of k_predict (movers up, in-FOV stayers down)
+    float4* in_rec;     // [ntiles][64*slots][2] per-destination-tile inbox of movers (k_predict tail -> k_place)
+    int* in_cnt;        // [ntiles] inbox fill; zeroed again by k_place
     u64* expmask;       // [v_loc*mw] particles that left the slab (multi-GPU), or nullptr
     int* part_predict;  // [ntiles*4]
     int* part_claim;    // [ntiles*2]
@@ -20,7 +21,7 @@ struct KernelScratch {
     float4* child;      // [birth_cap*32] child position + destination voxel of this frame's births
     int* work_list;     // [v_loc] non-empty voxels of this frame (resample work list)
     int* work_count;    // [1]
-    int ntiles;         // tiles of 64 voxels; k_predict / k_claim run one workgroup per tile
+    int ntiles;         // tiles of 64 voxels; k_predict / k_place run one workgroup per tile
     int nblk_sweep, nblk_resample;
 };
 

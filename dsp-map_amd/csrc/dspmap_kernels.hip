@@ -3,7 +3,7 @@
 //
 // Reference behaviour being reproduced: include/dsp_dynamic.h of g-ch/DSP-map
 //   update() preamble      :220-293   -> k_reset, k_obs_points, k_obs_gather
-//   mapPrediction          :627-701   -> k_predict, k_claim (moveParticle :1206-1274)
+//   mapPrediction          :627-701   -> k_predict, k_place (moveParticle :1206-1274)
 //   mapUpdate              :704-793   -> k_ck_partial, k_ck_finalize, k_weight
 //   mapAddNewBorn...       :796-921   -> k_birth_split, k_birth_plan, k_birth_insert
 //   mapOccupancy...Resample:924-1057  -> k_resample

@@ -39,29 +39,32 @@ __device__ __forceinline__ u64 valid_bits(const MapDims& d, int e) {
 
 // rows of a tile are processed in batches of RB: all loads of a batch are issued before any is
 // consumed, so a wave pays one memory round trip per batch instead of one per row
-#define RB 4
+#define RB 2
+#define TB 2      // records per thread and step in the tails of k_predict / k_place
+#define LSTG 224  // records of each kind a workgroup of k_predict notes in LDS before spilling to HBM
 
-// Deferred wave-aggregated append of up to RB items per lane into per-pyramid lists
-// (pyramids_in_fov registration, :1245-1254): one global atomic per DISTINCT pyramid of the
-// batch, all atomics in flight together, return values collected afterwards.
-// key[r] < 0 = no item.  pos[r] receives the list position.
-__device__ __forceinline__ void batch_append(int* cnt, const int (&key)[RB], int (&pos)[RB]) {
+// Deferred wave-aggregated append of up to N items per lane into counted lists
+// (pyramids_in_fov registration :1245-1254, mover routing): one global atomic per DISTINCT key of
+// the batch, all atomics in flight together, return values collected afterwards.
+// key[r] < 0 = no item.  pos[r] receives the list position.  Wave-uniform control flow only.
+template <int N>
+__device__ __forceinline__ void batch_append(int* cnt, const int (&key)[N], int (&pos)[N]) {
     const int l = lane_id();
-    u64 todo[RB];
+    u64 todo[N];
     bool any = false;
 #pragma unroll
-    for (int r = 0; r < RB; ++r) { todo[r] = __ballot(key[r] >= 0); any |= todo[r] != 0ull; pos[r] = -1; }
+    for (int r = 0; r < N; ++r) { todo[r] = __ballot(key[r] >= 0); any |= todo[r] != 0ull; pos[r] = -1; }
     while (any) {
         int nkeys = 0, mykey = -1, mybase = 0;
         while (any && nkeys < 64) {
             int k = -1;
 #pragma unroll
-            for (int r = 0; r < RB; ++r)
+            for (int r = 0; r < N; ++r)
                 if (k < 0 && todo[r]) k = __builtin_amdgcn_readlane(key[r], __ffsll((long long)todo[r]) - 1);
             int c = 0;
             any = false;
 #pragma unroll
-            for (int r = 0; r < RB; ++r) {
+            for (int r = 0; r < N; ++r) {
                 const u64 g = __ballot(key[r] == k);
                 c += (int)__popcll(g);
                 todo[r] &= ~g;
@@ -74,7 +77,7 @@ __device__ __forceinline__ void batch_append(int* cnt, const int (&key)[RB], int
             const int k = __builtin_amdgcn_readlane(mykey, j);
             int run = __builtin_amdgcn_readlane(mybase, j);
 #pragma unroll
-            for (int r = 0; r < RB; ++r) {
+            for (int r = 0; r < N; ++r) {
                 const u64 g = __ballot(key[r] == k);
                 if (key[r] == k) pos[r] = run + (int)__popcll(g & lanemask_lt());
                 run += (int)__popcll(g);
@@ -83,37 +86,57 @@ __device__ __forceinline__ void batch_append(int* cnt, const int (&key)[RB], int
     }
 }
 
-// --------------------------------------------------------------------------
-// k_predict: mapPrediction :645-694.
-//   constant-velocity advance + ego-motion shift (:665-667), vz := 0 (:661-663),
-//   out-of-map removal (:688); particles that stay in their voxel are registered
-//   in their pyramid (:1233-1259); particles whose voxel changed are only MARKED
-//   staged in the tile's mover list -- k_claim re-bins them, so every particle is advanced exactly once
-//   (the role of flag 7, :649,1219).
-// part[blockIdx*4 + {0,1,2,3}] = {live in, left the map, pyramid full, moved}
-// --------------------------------------------------------------------------
-// every 4th live row of the tile, starting at `wave` (the 4 waves of a workgroup share one tile)
+// wave-aggregated reservation of one entry per flagged lane in an LDS counter (returns -1 when not flagged)
+__device__ __forceinline__ int lds_agg_inc(int* cnt, bool flag) {
+    const u64 g = __ballot(flag);
+    if (!g) return -1;
+    const int leader = __ffsll((long long)g) - 1;
+    int base = 0;
+    if (lane_id() == leader) base = atomicAdd(cnt, (int)__popcll(g));
+    base = __builtin_amdgcn_readlane(base, leader);
+    return flag ? base + (int)__popcll(g & lanemask_lt()) : -1;
+}
+
+// every NW-th live row of the tile, starting at `wave` (the NW waves of a workgroup share one tile)
+template <int NW>
 __device__ __forceinline__ u64 rows_of_wave(u64 tor, int wave) {
     u64 mine = 0ull;
     int k = 0;
     while (tor) {
         const u64 low = tor & (~tor + 1ull);
-        if ((k & 3) == wave) mine |= low;
+        if ((k & (NW - 1)) == wave) mine |= low;
         tor ^= low;
         ++k;
     }
     return mine;
 }
 
-template <int MW>
-__global__ void __launch_bounds__(256) k_predict(MapDims d, DevState s, FilterParams fp, int has_vz, int* __restrict__ part,
-                                                 float4* __restrict__ mv_rec, int* __restrict__ mv_cnt, u64* __restrict__ expmask) {
+// --------------------------------------------------------------------------
+// k_predict: mapPrediction :645-694.
+//   constant-velocity advance + ego-motion shift (:665-667), vz := 0 (:661-663),
+//   out-of-map removal (:688).  The streaming loop issues no global atomics: a particle that must
+//   be registered in a pyramid (:1233-1259) or that changed voxel (moveParticle :1206) is noted in
+//   the tile's staging area (movers from the bottom, in-FOV stayers from the top; both together
+//   never exceed the tile's capacity).  The workgroup's tail then
+//     * registers the stayers in their pyramids (one aggregated atomic per distinct pyramid), and
+//     * routes the movers to the inbox of their DESTINATION tile (one atomic per distinct tile);
+//   k_place, which owns a destination tile exclusively, gives them slots.  Every particle is
+//   advanced exactly once (the role of flag 7, :649,1219).
+// part[blockIdx*4 + {0,1,2,3}] = {live in, left the map, pyramid full, moved}
+// --------------------------------------------------------------------------
+template <int MW, int NW>
+__global__ void __launch_bounds__(NW * 64) k_predict(MapDims d, DevState s, FilterParams fp, int has_vz, int* __restrict__ part,
+                                                 float4* __restrict__ mv_rec, float4* __restrict__ in_rec, int* __restrict__ in_cnt,
+                                                 u64* __restrict__ expmask) {
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
     __shared__ u64 s_keep[MW * 64], s_ex[MW * 64];
-    __shared__ int s_nmv;
+    __shared__ int s_nmv, s_nst;
     __shared__ int s_cnt[4];
     __shared__ int s_any;
+    // the first LSTG movers / stayers of the tile are noted in LDS (free: registers, not LDS, bound the
+    // occupancy of this kernel), the rest in the tile's staging area in HBM
+    __shared__ float4 s_mv[LSTG * 2], s_st[LSTG * 2];
     const float odx = s.fpar->od[0], ody = s.fpar->od[1], odz = s.fpar->od[2], dt = s.fpar->dt;
     const int tid = threadIdx.x;
     const int l = lane_id();
@@ -131,17 +154,17 @@ __global__ void __launch_bounds__(256) k_predict(MapDims d, DevState s, FilterPa
         any |= live[e] != 0ull;
         if (wave == 0) { s_keep[e * 64 + l] = live[e]; s_ex[e * 64 + l] = 0ull; }
     }
-    if (tid == 0) { s_any = 0; s_nmv = 0; }
+    if (tid == 0) { s_any = 0; s_nmv = 0; s_nst = 0; }
     if (tid < 4) s_cnt[tid] = 0;
     __syncthreads();
     if (wave == 0 && __ballot(any) && l == 0) s_any = 1;
     __syncthreads();
     if (!s_any) {  // empty tile
         if (tid < 4) part[blockIdx.x * 4 + tid] = 0;
-        if (tid == 0) mv_cnt[blockIdx.x] = 0;
         return;
     }
-    const size_t mv_base = (size_t)blockIdx.x * 64 * d.slots;  // this tile's staging area (2 float4 per record)
+    const int cap = 64 * d.slots;                       // records per staging area / inbox
+    const size_t mv_base = (size_t)blockIdx.x * cap;    // this tile's staging area (2 float4 per record)
     for (int i = tid; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
     for (int i = tid; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
     __syncthreads();
@@ -149,18 +172,18 @@ __global__ void __launch_bounds__(256) k_predict(MapDims d, DevState s, FilterPa
 #pragma unroll
     for (int e = 0; e < MW; ++e) {
         u64 keep_clr = 0ull, ex = 0ull;
-        u64 tor = rows_of_wave(wave_or_u64(live[e]), wave);
+        u64 tor = rows_of_wave<NW>(wave_or_u64(live[e]), wave);
         while (tor) {
             int row[RB];
             float vx[RB], vy[RB], px[RB], py[RB], pz[RB], w[RB];
             bool act[RB];
-            size_t idx[RB];
+            unsigned idx[RB];   // slot index fits 31 bits (fov_slot is an int; checked at create)
 #pragma unroll
             for (int r = 0; r < RB; ++r) {  // issue every load of the batch
                 row[r] = tor ? __ffsll((long long)tor) - 1 : -1;
                 if (tor) tor &= tor - 1ull;
                 act[r] = row[r] >= 0 && ((live[e] >> (row[r] & 63)) & 1ull);
-                idx[r] = pidx(d, lvs, e * 64 + (row[r] < 0 ? 0 : row[r]));
+                idx[r] = (unsigned)pidx(d, lvs, e * 64 + (row[r] < 0 ? 0 : row[r]));
                 vx[r] = vy[r] = px[r] = py[r] = pz[r] = w[r] = 0.f;
                 if (act[r]) {
                     vx[r] = s.vx[idx[r]]; vy[r] = s.vy[idx[r]];
@@ -168,10 +191,10 @@ __global__ void __launch_bounds__(256) k_predict(MapDims d, DevState s, FilterPa
                     w[r] = s.w[idx[r]];
                 }
             }
-            int pyr[RB], pos[RB];
+            int pyr[RB], mgv[RB];
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                pyr[r] = -1;
+                pyr[r] = -1; mgv[r] = -1;
                 if (act[r]) {
                     const u64 bit = 1ull << row[r];
                     if (has_vz) {
@@ -200,35 +223,94 @@ __global__ void __launch_bounds__(256) k_predict(MapDims d, DevState s, FilterPa
                         if (nlv == lv) pyr[r] = pyramid_of(d, s_ph, s_pv, px[r], py[r], pz[r]);
                         else if (nlv < 0 || nlv >= d.v_loc) ex |= bit;   // left the slab (multi-GPU)
                         else {
-                            // voxel changed: hand the record to k_claim through the tile's staging list and
-                            // free the slot now (the record is safe in the list)
-                            const int k = atomicAdd(&s_nmv, 1);
-                            mv_rec[(mv_base + k) * 2] = make_float4(__int_as_float(gv), vx[r], vy[r], px[r]);
-                            mv_rec[(mv_base + k) * 2 + 1] = make_float4(py[r], pz[r], w[r], 0.f);
+                            mgv[r] = gv;         // voxel changed: the slot is freed now, the record travels
                             keep_clr |= bit;
                             ++c_mv;
                         }
                     }
                 }
             }
-            // pyramid registration of particles that stay in their voxel
-            batch_append(s.pyr_cnt, pyr, pos);
+            // note stayers that need a pyramid entry (top of the staging area, downwards) and movers (bottom, upwards)
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                if (pyr[r] >= 0) {
-                    if (pos[r] < d.capp) {
-                        const size_t o = (size_t)pyr[r] * d.capp + pos[r];
-                        s.fov_rec[o] = make_float4(px[r], py[r], pz[r], w[r]);
-                        s.fov_slot[o] = (int)idx[r];
-                    } else {
-                        keep_clr |= 1ull << row[r];  // pyramid list full: the particle vanishes (-2, :1256-1259)
-                        ++c_pf;
-                    }
+                const int ks = lds_agg_inc(&s_nst, pyr[r] >= 0);
+                if (ks >= 0) {
+                    const float4 a = make_float4(__int_as_float(pyr[r]), __int_as_float(((e * 64 + row[r]) << 6) | l), px[r], py[r]);
+                    const float4 b = make_float4(pz[r], w[r], 0.f, 0.f);
+                    if (ks < LSTG) { s_st[ks * 2] = a; s_st[ks * 2 + 1] = b; }
+                    else { const size_t o = (mv_base + cap - 1 - ks) * 2; mv_rec[o] = a; mv_rec[o + 1] = b; }
+                }
+                const int km = lds_agg_inc(&s_nmv, mgv[r] >= 0);
+                if (km >= 0) {
+                    const float4 a = make_float4(__int_as_float(mgv[r]), vx[r], vy[r], px[r]);
+                    const float4 b = make_float4(py[r], pz[r], w[r], 0.f);
+                    if (km < LSTG) { s_mv[km * 2] = a; s_mv[km * 2 + 1] = b; }
+                    else { const size_t o = (mv_base + km) * 2; mv_rec[o] = a; mv_rec[o + 1] = b; }
                 }
             }
         }
         if (keep_clr) atomicAnd(&s_keep[e * 64 + l], ~keep_clr);
         if (ex) atomicOr(&s_ex[e * 64 + l], ex);
+    }
+    // workgroup-scope ordering is enough for the read-back below: the waves of a workgroup share the
+    // CU's write-through L1 (an agent-scope fence would write back the XCD's whole L2)
+    __syncthreads();
+    // ---- tail 1: pyramid registration of the stayers (:1245-1259); TB records per thread so that all
+    // the atomics of up to TB * blockDim records are in flight together
+    const int nst = s_nst, nmv = s_nmv;
+    auto st_rec = [&](int i, float4& a, float4& b) {
+        if (i < LSTG) { a = s_st[i * 2]; b = s_st[i * 2 + 1]; }
+        else { const size_t o = (mv_base + cap - 1 - i) * 2; a = mv_rec[o]; b = mv_rec[o + 1]; }
+    };
+    auto mv_get = [&](int i, float4& a, float4& b) {
+        if (i < LSTG) { a = s_mv[i * 2]; b = s_mv[i * 2 + 1]; }
+        else { a = mv_rec[(mv_base + i) * 2]; b = mv_rec[(mv_base + i) * 2 + 1]; }
+    };
+    for (int i0 = 0; i0 < nst; i0 += NW * 64 * TB) {
+        int key[TB], pos[TB];
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int i = i0 + j * NW * 64 + tid;
+            key[j] = -1;
+            if (i < nst) key[j] = __float_as_int(i < LSTG ? s_st[i * 2].x : mv_rec[(mv_base + cap - 1 - i) * 2].x);
+        }
+        batch_append<TB>(s.pyr_cnt, key, pos);
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            if (key[j] < 0) continue;
+            float4 a, b;
+            st_rec(i0 + j * NW * 64 + tid, a, b);
+            const int sl = __float_as_int(a.y);   // (slot << 6) | lane
+            if (pos[j] < d.capp) {
+                const size_t o = (size_t)key[j] * d.capp + pos[j];
+                s.fov_rec[o] = make_float4(a.z, a.w, b.x, b.y);
+                s.fov_slot[o] = (int)(((size_t)blockIdx.x * d.slots + (sl >> 6)) * 64 + (sl & 63));
+            } else {
+                // pyramid list full: the particle vanishes (-2, :1256-1259)
+                atomicAnd(&s_keep[((sl >> 12) & 1) * 64 + (sl & 63)], ~(1ull << ((sl >> 6) & 63)));
+                ++c_pf;
+            }
+        }
+    }
+    // ---- tail 2: route the movers to the inbox of their destination tile
+    for (int i0 = 0; i0 < nmv; i0 += NW * 64 * TB) {
+        int key[TB], pos[TB];
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int i = i0 + j * NW * 64 + tid;
+            key[j] = -1;
+            if (i < nmv) key[j] = (__float_as_int(i < LSTG ? s_mv[i * 2].x : mv_rec[(mv_base + i) * 2].x) - d.v_base) >> 6;
+        }
+        batch_append<TB>(in_cnt, key, pos);
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            // beyond the inbox: more arrivals than the tile has slots; k_place counts them as dropped
+            if (key[j] < 0 || pos[j] >= cap) continue;
+            float4 a, b;
+            mv_get(i0 + j * NW * 64 + tid, a, b);
+            const size_t o = ((size_t)key[j] * cap + pos[j]) * 2;
+            in_rec[o] = a; in_rec[o + 1] = b;
+        }
     }
     // per-block statistics (reduced lazily by the host; no global atomics here)
     c_live = wave_sum_i(c_live); c_out = wave_sum_i(c_out); c_pf = wave_sum_i(c_pf); c_mv = wave_sum_i(c_mv);
@@ -248,65 +330,93 @@ __global__ void __launch_bounds__(256) k_predict(MapDims d, DevState s, FilterPa
             if (expmask && s_ex[e * 64 + l]) expmask[(size_t)lv * MW + e] = s_ex[e * 64 + l];
         }
     }
-    if (tid == 0) mv_cnt[blockIdx.x] = s_nmv;
     if (tid < 4) part[blockIdx.x * 4 + tid] = s_cnt[tid];
 }
 
 // --------------------------------------------------------------------------
-// k_claim: the voxel-changing half of moveParticle (:1209-1230).  One workgroup per source tile
-// walks the tile's staged mover records with DENSE lanes (coalesced 32-byte records): a mover claims
-// the lowest free slot of its destination voxel with one atomic OR (first-free-slot rule
-// :1214-1215), writes its record there and registers in its pyramid (:1233-1259).  Destination
-// full -> the particle vanishes (-1, :1227-1229).
+// k_place: the voxel-changing half of moveParticle (:1209-1230).  One workgroup OWNS one destination
+// tile: it reads the tile's inbox (dense lanes, coalesced 32-byte records), ranks the arrivals per
+// destination voxel in LDS and gives arrival r of a voxel the r-th lowest free slot -- the
+// first-free-slot rule (:1214-1215) without a single global atomic on the occupancy words.
+// Destination full -> the particle vanishes (-1, :1227-1229).  Pyramid registration :1233-1259.
 // part2[blockIdx*2 + {0,1}] = {voxel full, pyramid full}
 // --------------------------------------------------------------------------
 template <int MW>
-__global__ void __launch_bounds__(256) k_claim(MapDims d, DevState s, const float4* __restrict__ mv_rec,
-                                               const int* __restrict__ mv_cnt, int* __restrict__ part2) {
+__global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const float4* __restrict__ in_rec,
+                                               int* __restrict__ in_cnt, int* __restrict__ part2) {
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
+    __shared__ u64 s_mask[MW * 64], s_new[MW * 64];
+    __shared__ int s_rank[64];
     __shared__ int s_cnt[2];
     const int tid = threadIdx.x;
-    const int n = mv_cnt[blockIdx.x];
-    if (n == 0) {
+    const int n_all = in_cnt[blockIdx.x];
+    if (n_all == 0) {
         if (tid < 2) part2[blockIdx.x * 2 + tid] = 0;
         return;
     }
+    const int cap = 64 * d.slots;
+    const int n = min(n_all, cap);
     for (int i = tid; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
     for (int i = tid; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
+    if (tid < 64) {
+        const int lv = blockIdx.x * 64 + tid;
+        s_rank[tid] = 0;
+#pragma unroll
+        for (int e = 0; e < MW; ++e) {
+            s_mask[e * 64 + tid] = lv < d.v_loc ? s.mask[(size_t)lv * MW + e] : ~0ull;
+            s_new[e * 64 + tid] = 0ull;
+        }
+    }
     if (tid < 2) s_cnt[tid] = 0;
     __syncthreads();
-    const size_t mv_base = (size_t)blockIdx.x * 64 * d.slots;
-    int c_vf = 0, c_pf = 0;
+    const size_t base = (size_t)blockIdx.x * cap;
+    int c_vf = tid == 0 ? n_all - n : 0, c_pf = 0;
     for (int i0 = 0; i0 < n; i0 += 256) {
         const int i = i0 + tid;
-        int pyr = -1, nlv = -1, nsl = -1;
+        int key[1] = {-1}, pos[1];
+        int ln = 0, nsl = -1;
         size_t nidx = 0;
         float px = 0, py = 0, pz = 0, w = 0;
         if (i < n) {
-            const float4 a = mv_rec[(mv_base + i) * 2], b = mv_rec[(mv_base + i) * 2 + 1];
+            const float4 a = in_rec[(base + i) * 2], b = in_rec[(base + i) * 2 + 1];
             px = a.w; py = b.x; pz = b.y; w = b.z;
-            nlv = __float_as_int(a.x) - d.v_base;
-            nsl = claim_slot(s.mask, nlv, d);
+            ln = (__float_as_int(a.x) - d.v_base) & 63;
+            int r = atomicAdd(&s_rank[ln], 1);
+#pragma unroll
+            for (int e = 0; e < MW; ++e) {
+                u64 fr = ~s_mask[e * 64 + ln] & valid_bits(d, e);
+                const int c = (int)__popcll(fr);
+                if (nsl < 0) {
+                    if (r < c) {
+                        for (; r > 0; --r) fr &= fr - 1ull;
+                        nsl = e * 64 + (__ffsll((long long)fr) - 1);
+                    } else r -= c;
+                }
+            }
             if (nsl >= 0) {
-                nidx = pidx(d, nlv, nsl);
+                nidx = pidx(d, blockIdx.x * 64 + ln, nsl);
                 s.px[nidx] = px; s.py[nidx] = py; s.pz[nidx] = pz;
                 s.vx[nidx] = a.y; s.vy[nidx] = a.z; s.w[nidx] = w;
-                pyr = pyramid_of(d, s_ph, s_pv, px, py, pz);
+                key[0] = pyramid_of(d, s_ph, s_pv, px, py, pz);
             } else {
                 ++c_vf;
             }
         }
-        const int pos = wave_agg_inc(s.pyr_cnt, pyr, pyr >= 0);
-        if (pyr >= 0) {
-            if (pos < d.capp) {
-                const size_t o = (size_t)pyr * d.capp + pos;
-                s.fov_rec[o] = make_float4(px, py, pz, w);
-                s.fov_slot[o] = (int)nidx;
-            } else {
-                ++c_pf;  // :1256-1259
-                atomicAnd(&s.mask[(size_t)nlv * MW + (nsl >> 6)], ~(1ull << (nsl & 63)));
+        batch_append<1>(s.pyr_cnt, key, pos);
+        if (nsl >= 0) {
+            bool keep = true;
+            if (key[0] >= 0) {
+                if (pos[0] < d.capp) {
+                    const size_t o = (size_t)key[0] * d.capp + pos[0];
+                    s.fov_rec[o] = make_float4(px, py, pz, w);
+                    s.fov_slot[o] = (int)nidx;
+                } else {
+                    ++c_pf;  // :1256-1259
+                    keep = false;
+                }
             }
+            if (keep) atomicOr(&s_new[(nsl >> 6) * 64 + ln], 1ull << (nsl & 63));
         }
     }
     c_vf = wave_sum_i(c_vf); c_pf = wave_sum_i(c_pf);
@@ -315,18 +425,43 @@ __global__ void __launch_bounds__(256) k_claim(MapDims d, DevState s, const floa
         if (c_pf) atomicAdd(&s_cnt[1], c_pf);
     }
     __syncthreads();
+    if (tid < 64) {
+        const int lv = blockIdx.x * 64 + tid;
+#pragma unroll
+        for (int e = 0; e < MW; ++e)
+            if (s_new[e * 64 + tid]) s.mask[(size_t)lv * MW + e] = s_mask[e * 64 + tid] | s_new[e * 64 + tid];
+    }
+    if (tid == 0) in_cnt[blockIdx.x] = 0;   // ready for the next frame
     if (tid < 2) part2[blockIdx.x * 2 + tid] = s_cnt[tid];
 }
 
-#define RBK 8  // rows per batch in k_resample (few registers per row: deeper batches, fewer round trips)
+#define RBK 16  // rows per batch of the loads in k_resample
+#define RS_DMA 0
+#define CPB 8   // deferred copies per step
 
-#define CPMAX 64  // copies a voxel can make in one resampling (<= M <= 64)
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
+// --------------------------------------------------------------------------
+// k_resample: mapOccupancyCalculationAndResample :924-1057.  One wave per tile, one lane per voxel.
+//   * the WEIGHT rows of the tile go straight from HBM into the wave's LDS panel with
+//     global_load_lds (no staging registers, every row in flight at once): both sequential passes
+//     (cull/mass :938-984, systematic resampling :986-1053) then read weights from LDS, so the
+//     second pass costs no memory round trip and the weights cross HBM once;
+//   * velocities stream through registers in batches of RBK rows; positions are read only for moving
+//     particles (the rollout :950-964) and for copies;
+//   * all per-voxel sums run sequentially per lane in slot order = the reference's operation order.
+// dynamic LDS per wave: [slots][64] fp32 weights + [64][M] u16 (source slot, destination slot) of deferred copies
+// --------------------------------------------------------------------------
 template <int MW>
 __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __restrict__ part_live) {
-    __shared__ unsigned short s_cp[256 * CPMAX];
+    extern __shared__ float s_dyn[];
     const int l = lane_id();
-    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave = threadIdx.x >> 6;
+    const int cpmax = d.M;   // a voxel makes at most M copies
+    float* s_w = s_dyn + (size_t)wave * (d.slots * 64 + (64 * cpmax + 1) / 2);
+    unsigned short* s_cp = (unsigned short*)(s_w + d.slots * 64);
+    const int wave_g = blockIdx.x * (blockDim.x >> 6) + wave;
     const int lv = wave_g * 64 + l;
     const bool inr = lv < d.v_loc;
     const int lvs = inr ? lv : 0;
@@ -343,9 +478,23 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
     }
     if (!__ballot(nonempty)) {  // whole tile empty
         if (inr) s.res4[lv] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (l == 0) part_live[wave_g] = 0;
+        if (l == 0 && wave_g * 64 < d.v_loc + 63) part_live[wave_g] = 0;
         return;
     }
+    // every live weight row of the tile -> LDS, all loads in flight together
+#if RS_DMA
+#pragma unroll
+    for (int e = 0; e < MW; ++e) {
+        u64 tor = wave_or_u64(m[e]);
+        while (tor) {
+            const int row = __ffsll((long long)tor) - 1;
+            tor &= tor - 1ull;
+            if ((m[e] >> row) & 1ull)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(s.w + pidx(d, lvs, e * 64 + row)),
+                                                 (lds_ptr_t)(s_w + (e * 64 + row) * 64), 4, 0, 0);
+        }
+    }
+#endif
     const int T = d.T;
     const int gz = inr ? (lv + d.v_base) / (d.ny * d.nx) : 0;  // z layer never changes in the rollout (vz == 0)
     int n = 0, n_old = 0;
@@ -355,32 +504,47 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
         u64 tor = wave_or_u64(m[e]);
         while (tor) {
             int row[RBK];
-            float w[RBK], vx[RBK], vy[RBK];
+            float vx[RBK], vy[RBK];
+#if !RS_DMA
+            float wr[RBK];
+#endif
             bool act[RBK];
 #pragma unroll
             for (int r = 0; r < RBK; ++r) {
                 row[r] = tor ? __ffsll((long long)tor) - 1 : -1;
                 if (tor) tor &= tor - 1ull;
                 act[r] = row[r] >= 0 && ((m[e] >> (row[r] & 63)) & 1ull);
-                w[r] = vx[r] = vy[r] = 0.f;
-                if (act[r]) {
+                vx[r] = vy[r] = 0.f;
+#if !RS_DMA
+                wr[r] = 0.f;
+                if (act[r]) wr[r] = s.w[pidx(d, lvs, e * 64 + row[r])];
+#endif
+                if (act[r] && !((nb[e] >> row[r]) & 1ull)) {
                     const size_t idx = pidx(d, lvs, e * 64 + row[r]);
-                    w[r] = s.w[idx];
-                    if (!((nb[e] >> row[r]) & 1ull)) { vx[r] = s.vx[idx]; vy[r] = s.vy[idx]; }
+                    vx[r] = s.vx[idx]; vy[r] = s.vy[idx];
                 }
             }
+#if RS_DMA
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weight panel (first batch) + this batch's velocities
+#endif
 #pragma unroll
             for (int r = 0; r < RBK; ++r) {
                 if (!act[r]) continue;
                 const u64 bit = 1ull << row[r];
-                if (w[r] < 1e-3f) {               // :941
+#if RS_DMA
+                const float w = s_w[(e * 64 + row[r]) * 64 + l];
+#else
+                const float w = wr[r];
+                s_w[(e * 64 + row[r]) * 64 + l] = w;   // the resampling pass below reads the weights from LDS
+#endif
+                if (w < 1e-3f) {                  // :941
                     m[e] &= ~bit;
                 } else {
                     if (!(nb[e] & bit)) {         // flag < 10 :944
                         ++n_old;
                         vxs += vx[r]; vys += vy[r];
                         if (vx[r] == 0.f && vy[r] == 0.f) {
-                            stat_w += w[r];       // p + 0*t stays in this voxel for every horizon
+                            stat_w += w;          // p + 0*t stays in this voxel for every horizon
                         } else {
                             const size_t idx = pidx(d, lvs, e * 64 + row[r]);
                             const float px = s.px[idx], py = s.py[idx];
@@ -392,13 +556,13 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
                                     const int xi = (int)__fdiv_rn(fx + d.half_x, d.res);
                                     const int yi = (int)__fdiv_rn(fy + d.half_y, d.res);
                                     const int dl = gz * d.ny * d.nx + yi * d.nx + xi - d.v_base;
-                                    if (dl >= 0 && dl < d.v_loc) unsafeAtomicAdd(&s.fut[(size_t)dl * T + t], w[r]);
+                                    if (dl >= 0 && dl < d.v_loc) unsafeAtomicAdd(&s.fut[(size_t)dl * T + t], w);
                                 }
                             }
                         }
                     }
                     ++n;
-                    wsum += w[r];                 // :970
+                    wsum += w;                    // :970
                 }
             }
         }
@@ -409,87 +573,72 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
         s.res4[lv] = res;
         if (stat_w != 0.f) s.fut_stat[lv] += stat_w;  // only this lane ever writes fut_stat[lv]
     }
-    // ---- systematic resampling :986-1053
+    // ---- systematic resampling :986-1053 (weights from the LDS panel)
     int ncp = 0;
     float w_copy = 0.f;
     const bool resample = n >= 5;
-    if (__ballot(resample)) {
+    if (resample) {
         const int n_after = n > d.M ? d.M : n;                  // :992-997
         const float w_after = __fdiv_rn(wsum, (float)n_after);  // :1000
         w_copy = w_after;
         float acc_ori = 0.f, acc_new = w_after * 0.5f;          // :1005-1006
-        u64 a0[MW];
-#pragma unroll
-        for (int e = 0; e < MW; ++e) a0[e] = resample ? m[e] : 0ull;  // survivors before any copy (copies are not revisited)
 #pragma unroll
         for (int e = 0; e < MW; ++e) {
-            u64 tor = wave_or_u64(a0[e]);
-            while (tor) {
-                int row[RBK];
-                float w[RBK];
+            u64 todo = m[e];                                    // survivors before any copy (copies are not revisited)
+            while (todo) {
+                const int row = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const u64 bit = 1ull << row;
+                acc_ori += s_w[(e * 64 + row) * 64 + l];        // :1011
+                if (acc_ori > acc_new) {
+                    float wn = w_after;                         // keep, new weight :1014
+                    acc_new += w_after;
+                    bool full = false;
+                    while (acc_ori > acc_new) {                 // copy heavy particles :1021
+                        int fslot = -1;
+                        if (!full) {
 #pragma unroll
-                for (int r = 0; r < RBK; ++r) {
-                    row[r] = tor ? __ffsll((long long)tor) - 1 : -1;
-                    if (tor) tor &= tor - 1ull;
-                    w[r] = 0.f;
-                    if (row[r] >= 0 && ((a0[e] >> row[r]) & 1ull)) w[r] = s.w[pidx(d, lvs, e * 64 + row[r])];
-                }
-#pragma unroll
-                for (int r = 0; r < RBK; ++r) {
-                    if (row[r] < 0 || !((a0[e] >> row[r]) & 1ull)) continue;
-                    const u64 bit = 1ull << row[r];
-                    const size_t idx = pidx(d, lvs, e * 64 + row[r]);
-                    acc_ori += w[r];                           // :1011
-                    if (acc_ori > acc_new) {
-                        float wn = w_after;                    // keep, new weight :1014
-                        acc_new += w_after;
-                        bool full = false;
-                        while (acc_ori > acc_new) {            // copy heavy particles :1021
-                            int fslot = -1;
-                            if (!full) {
-#pragma unroll
-                                for (int e2 = 0; e2 < MW; ++e2) {
-                                    const u64 fr = ~m[e2] & valid_bits(d, e2);
-                                    if (fslot < 0 && fr) { fslot = e2 * 64 + (__ffsll((long long)fr) - 1); m[e2] |= fr & (~fr + 1ull); }
-                                }
+                            for (int e2 = 0; e2 < MW; ++e2) {
+                                const u64 fr = ~m[e2] & valid_bits(d, e2);
+                                if (fslot < 0 && fr) { fslot = e2 * 64 + (__ffsll((long long)fr) - 1); m[e2] |= fr & (~fr + 1ull); }
                             }
-                            if (fslot >= 0) {
-                                // the copy itself (5 loads + 6 stores) is deferred: only (source, destination)
-                                // is noted here so that no global load sits in this sequential loop
-                                if (ncp < CPMAX) s_cp[threadIdx.x * CPMAX + ncp] = (unsigned short)(((e * 64 + row[r]) << 8) | fslot);
-                                ++ncp;
-                            } else {
-                                wn += w_after;                 // no free slot: fold the weight back :1037-1041
-                                full = true;
-                            }
-                            acc_new += w_after;
                         }
-                        s.w[idx] = wn;
-                    } else {
-                        m[e] &= ~bit;                          // remove :1046-1049
+                        if (fslot >= 0) {
+                            // the copy itself (5 loads + 6 stores) is deferred: only (source, destination)
+                            // is noted here so that no global access sits in this sequential loop
+                            if (ncp < cpmax) s_cp[l * cpmax + ncp] = (unsigned short)(((e * 64 + row) << 8) | fslot);
+                            ++ncp;
+                        } else {
+                            wn += w_after;                      // no free slot: fold the weight back :1037-1041
+                            full = true;
+                        }
+                        acc_new += w_after;
                     }
+                    s.w[pidx(d, lvs, e * 64 + row)] = wn;
+                } else {
+                    m[e] &= ~bit;                               // remove :1046-1049
                 }
             }
         }
     }
-    // deferred copies :1026-1031, four at a time so that their loads overlap
-    if (ncp > CPMAX) ncp = CPMAX;  // cannot happen: a voxel makes at most M <= 64 copies
-    for (int k0 = 0; __ballot(k0 < ncp); k0 += 4) {
-        float cx[4], cy[4], cz[4], cvx[4], cvy[4], cvz[4];
-        size_t didx[4];
+    // deferred copies :1026-1031, CPB at a time so that their loads overlap
+    if (ncp > cpmax) ncp = cpmax;  // cannot happen: a voxel makes at most M copies
+    for (int k0 = 0; __ballot(k0 < ncp); k0 += CPB) {
+        float cx[CPB], cy[CPB], cz[CPB], cvx[CPB], cvy[CPB], cvz[CPB];
+        unsigned didx[CPB];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < CPB; ++j) {
             didx[j] = 0;
             if (k0 + j < ncp) {
-                const unsigned pr = s_cp[threadIdx.x * CPMAX + k0 + j];
+                const unsigned pr = s_cp[l * cpmax + k0 + j];
                 const size_t sidx = pidx(d, lvs, (int)(pr >> 8));
-                didx[j] = pidx(d, lvs, (int)(pr & 0xff));
+                didx[j] = (unsigned)pidx(d, lvs, (int)(pr & 0xff));
                 cx[j] = s.px[sidx]; cy[j] = s.py[sidx]; cz[j] = s.pz[sidx]; cvx[j] = s.vx[sidx]; cvy[j] = s.vy[sidx];
                 cvz[j] = s.vz0 ? s.vz0[sidx] : 0.f;
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < CPB; ++j) {
             if (k0 + j < ncp) {
                 s.px[didx[j]] = cx[j]; s.py[didx[j]] = cy[j]; s.pz[didx[j]] = cz[j];
                 s.vx[didx[j]] = cvx[j]; s.vy[didx[j]] = cvy[j];
@@ -632,7 +781,7 @@ __global__ void k_advance_rcur(DevState s, FilterParams fp, int by) {
 // --------------------------------------------------------------------------
 // multi-GPU: particles whose new voxel lies in another Z-slab (marked in expmask by k_predict).
 // k_export_slab compacts those leaving in direction `dir` into the caller's send buffer and frees
-// their slots; k_import_movers is k_claim for records received from a neighbour.
+// their slots; k_import_movers places records received from a neighbour.
 // --------------------------------------------------------------------------
 template <int MW>
 __global__ void __launch_bounds__(256) k_export_slab(MapDims d, DevState s, u64* __restrict__ expmask, int dir,
@@ -782,16 +931,16 @@ __global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScra
 void launch_predict_only(const LaunchCtx& c) {
     const KernelScratch* k = &c.k;
     if (c.d.mw == 1)
-        hipLaunchKernelGGL(k_predict<1>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, c.fp,
-                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->mv_cnt, k->expmask);
+        hipLaunchKernelGGL((k_predict<1, 4>), dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, c.fp,
+                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask);
     else
-        hipLaunchKernelGGL(k_predict<2>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, c.fp,
-                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->mv_cnt, k->expmask);
+        hipLaunchKernelGGL((k_predict<2, 4>), dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, c.fp,
+                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask);
 }
 void launch_claim(const LaunchCtx& c) {
     const KernelScratch* k = &c.k;
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_claim<1>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->mv_rec, k->mv_cnt, k->part_claim);
-    else hipLaunchKernelGGL(k_claim<2>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->mv_rec, k->mv_cnt, k->part_claim);
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim);
+    else hipLaunchKernelGGL(k_place<2>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim);
 }
 void launch_predict(const LaunchCtx& c) {
     launch_predict_only(c);
@@ -799,8 +948,11 @@ void launch_predict(const LaunchCtx& c) {
 }
 void launch_resample(const LaunchCtx& c) {
     const KernelScratch* k = &c.k;
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_resample<1>, dim3(k->nblk_sweep), dim3(256), 0, c.stream, c.d, c.s, k->part_resample);
-    else hipLaunchKernelGGL(k_resample<2>, dim3(k->nblk_sweep), dim3(256), 0, c.stream, c.d, c.s, k->part_resample);
+    const int nw = 1;   // waves (= tiles) per workgroup; the LDS panel bounds the occupancy, small groups pack best
+    const size_t lds = (size_t)nw * (c.d.slots * 64 + (64 * c.d.M + 1) / 2) * sizeof(float);
+    const unsigned grid = (unsigned)((k->ntiles + nw - 1) / nw);
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_resample<1>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample);
+    else hipLaunchKernelGGL(k_resample<2>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample);
 }
 void launch_seed_uniform(const LaunchCtx& c, int per_voxel, float weight, unsigned seed) {
     const size_t total = (size_t)c.d.v_loc * c.d.slots;

@@ -34,7 +34,7 @@ def test_header_symbols_all_exported_and_bound(dsp):
 def test_library_has_gfx950_code_object(dsp):
     blob = open(dsp.capi.LIB_PATH, "rb").read()
     assert b"gfx950" in blob
-    for k in (b"k_predict", b"k_claim", b"k_ck_partial", b"k_weight", b"k_birth_insert", b"k_resample"):
+    for k in (b"k_predict", b"k_place", b"k_ck_partial", b"k_weight", b"k_birth_insert", b"k_resample"):
         assert k in blob, k
 
 
