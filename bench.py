@@ -101,10 +101,12 @@ def main():
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
+    globals_barrier = barrier
 
     def make_map(w):
+        kw = {"pred_times": w["pred_times"]} if "pred_times" in w else {}
         cfg = D.make_config(nx=w["nx"], ny=w["ny"], nz=w["nz"], res=w["res"], ppv=w["ppv"], device=local_rank,
-                            seed=1234)
+                            seed=1234, **kw)
         m = D.DSPMap(cfg)
         m.L.dspmap_init_device(m.h)
         return m
@@ -126,12 +128,14 @@ def main():
             assert rc == 1, rc
             m.clearOccupancyMapPrediction()  # the reference requires this once per frame (:429-438)
 
-    def measure(w, steps, warmup, prefill, profile=True):
+    def measure(w, steps, warmup, prefill, profile=True, solo=False):
+        """solo: this rank measures alone (no collective barrier): the single-GPU origin of an N > 1 run"""
+        barrier = (lambda: torch.cuda.synchronize()) if solo else globals_barrier
         m = make_map(w)
         n_total = prefill + warmup + steps + (steps if profile else 0)
         frames = gen_frames(w, n_total, seed=1234 + rank)
         if w["sat"]:
-            m.seed_uniform(w["ppv"], 0.01, 99)  # M zero-velocity particles in every voxel
+            m.seed_uniform(w["ppv"], 0.01, 99, w.get("vmax", 0.0))  # SURVEY 8(d): M zero-velocity particles in every voxel
         run_frames(m, frames[:prefill])
         run_frames(m, frames[prefill:prefill + warmup])
         barrier()
@@ -269,6 +273,49 @@ def main():
         except Exception as e:  # the extra line must never break the contract line
             result["saturated_132x132x60"] = {"error": repr(e)}
 
+    # ------------------------------------------------------------------ config D: the future-status rollout, T = 10
+    if rank == 0 and not sharded_run and not args.no_extra and wl_name == "B":
+        try:
+            out = {}
+            for tag, vmax in (("static_fill", 0.0), ("moving_fill", 1.0)):
+                wd = dict(WORKLOADS["C_sat"], pred_times=tuple(0.2 * (k + 1) for k in range(10)), vmax=vmax)
+                md, frd, dtd, cd, sd = measure(wd, 20, 3, 2)
+                n_old = cd["n_live_in"]  # particles that enter the rollout (newborns of the frame are excluded, :944)
+                bd = 28 * n_old + 8 * md.T * md.V_local   # B_alg(D)
+                out[tag] = {"k_resample_ms": round(sd["resample"], 5), "n_old": int(n_old), "T": md.T,
+                            "b_alg_D_bytes": int(bd), "GBps": round(bd / (sd["resample"] * 1e-3) / 1e9, 2),
+                            "frac_of_8TBps": round(bd / (sd["resample"] * 1e-3) / 1e9 / peak, 5),
+                            "update_ms": round(dtd / 20 * 1e3, 4)}
+                md.close()
+                del frd
+            result["rollout_D_132x132x60_T10"] = {
+                "workload": "D: C's grid, PREDICTION_TIMES = 10, horizons 0.2*(k+1) s; the rollout is fused into "
+                            "k_resample (cull + mass + mean velocity + rollout + resampling), timed with HIP events; "
+                            "static_fill = SURVEY's saturated zero-velocity state (one fut_stat add per voxel), "
+                            "moving_fill = same fill with velocities uniform in +-1 m/s (10 float atomics per particle)",
+                **out}
+        except Exception as e:
+            result["rollout_D_132x132x60_T10"] = {"error": repr(e)}
+
+    # ------------------------------------------------------------------ strong-scaling origin: config E on ONE GPU, unsharded
+    if rank == 0 and not args.no_extra and (wl_name == "B" or sharded_run) and os.environ.get("DSPMAP_BENCH_ORIGIN", "1") == "1":
+        try:
+            if sharded_run:
+                m.close()
+            we = WORKLOADS["E_sat"]
+            me, fre, dte, ce, ste = measure(we, 12, 2, 3, profile=False, solo=True)
+            be = b_alg(ce, me.V_local, me.T)
+            mse = dte / 12 * 1e3
+            result["single_gpu_264x264x80"] = {
+                "workload": "E_sat unsharded on one GPU (the N = 1 point of the Z-slab strong-scaling series that "
+                            "bench.py --gpus N > 1 reports)",
+                "frames_per_s": round(12 / dte, 2), "ms_per_step": round(mse, 4), "b_alg_bytes": int(be),
+                "frac_of_8TBps": round(be / (mse * 1e-3) / 1e9 / peak, 5)}
+            me.close()
+            del fre
+        except Exception as e:
+            result["single_gpu_264x264x80"] = {"error": repr(e)}
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)
     if rank == 0 and not sharded_run and not args.no_cpu:
         try:
@@ -305,7 +352,12 @@ def main():
             result["cpu_baseline"] = {"error": repr(e)}
 
     if rank == 0:
-        print(json.dumps(result))
+        try:  # RCCL's banner and other C stdio output must not trail the JSON line
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

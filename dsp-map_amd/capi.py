@@ -94,6 +94,7 @@ SIGNATURES = {
     "dspmap_import_state": (_i, [_P, _i, _P, _P, _P]),
     "dspmap_export_state": (_i, [_P, _i, _P, _P, _P, _ip]),
     "dspmap_add_random_particles": (_i, [_P, _i, _f]),
+    "dspmap_seed_uniform_moving": (_i, [_P, _i, _f, C.c_uint, _f]),
     "dspmap_seed_uniform": (_i, [_P, _i, _f, C.c_uint]),
     "dspmap_stage_bin_points": (_i, [_P, _i, _i, _P, _f, _f, _f, _f]),
     "dspmap_set_current_position": (_i, [_P, _f, _f, _f]),
@@ -350,8 +351,8 @@ class DSPMap:
         order = np.lexsort((slot, voxel))
         return voxel[order], slot[order], rec[order]
 
-    def seed_uniform(self, per_voxel, weight=0.01, seed=99):
-        self._chk(self.L.dspmap_seed_uniform(self.h, per_voxel, weight, seed))
+    def seed_uniform(self, per_voxel, weight=0.01, seed=99, vmax=0.0):
+        self._chk(self.L.dspmap_seed_uniform_moving(self.h, per_voxel, weight, seed, vmax))
 
     # -- stages
     def bin_points(self, pts, quat=(1, 0, 0, 0)):

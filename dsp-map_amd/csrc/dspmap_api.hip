@@ -899,13 +899,17 @@ extern "C" int dspmap_add_random_particles(dspmap_t* m, int n, float weight) {
     return DSPMAP_OK;
 }
 
-extern "C" int dspmap_seed_uniform(dspmap_t* m, int per_voxel, float weight, unsigned seed) {
+extern "C" int dspmap_seed_uniform_moving(dspmap_t* m, int per_voxel, float weight, unsigned seed, float vmax) {
     READY(m);
     if (per_voxel < 0 || per_voxel > m->d.slots) return dspmap_fail(m, DSPMAP_E_ARG, "per_voxel must be in [0, %d]", m->d.slots);
+    if (!(vmax >= 0.f)) return dspmap_fail(m, DSPMAP_E_ARG, "vmax must be >= 0");
     LaunchCtx c = dspmap_ctx_of(m);
-    launch_seed_uniform(c, per_voxel, weight, seed);
+    launch_seed_uniform(c, per_voxel, weight, seed, vmax);
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
+}
+extern "C" int dspmap_seed_uniform(dspmap_t* m, int per_voxel, float weight, unsigned seed) {
+    return dspmap_seed_uniform_moving(m, per_voxel, weight, seed, 0.f);
 }
 
 // ------------------------------------------------------------------ stages

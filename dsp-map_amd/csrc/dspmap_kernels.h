@@ -62,7 +62,7 @@ void launch_occupied_compact(const LaunchCtx& c, float thr);
 void launch_clear_future(const LaunchCtx& c);
 void launch_future_combine(const LaunchCtx& c);  // fold the static-particle future mass into the [V][T] grid
 // state helpers
-void launch_seed_uniform(const LaunchCtx& c, int per_voxel, float weight, unsigned seed);
+void launch_seed_uniform(const LaunchCtx& c, int per_voxel, float weight, unsigned seed, float vmax);
 void launch_import(const LaunchCtx& c, int n, const int* voxel_dev, const int* slot_dev, const float* rec8_dev, int* n_failed_dev);
 void launch_export(const LaunchCtx& c, int* voxel_out, int* slot_out, float* rec8_out, int* count_dev, int cap);
 void launch_add_random(const LaunchCtx& c, int n, float weight);

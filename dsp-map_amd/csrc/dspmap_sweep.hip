@@ -669,7 +669,7 @@ __device__ __forceinline__ unsigned hash_u32(unsigned x) {
 }
 // benchmark fill (SURVEY 8d "saturated"): per_voxel zero-velocity particles per voxel,
 // uniform in-voxel positions (kept 2% away from the faces), slots 0..per_voxel-1.
-__global__ void k_seed_uniform(MapDims d, DevState s, int per_voxel, float weight, unsigned seed) {
+__global__ void k_seed_uniform(MapDims d, DevState s, int per_voxel, float weight, unsigned seed, float vmax) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)d.v_loc * d.slots;
     if (t >= total) return;
@@ -694,7 +694,13 @@ __global__ void k_seed_uniform(MapDims d, DevState s, int per_voxel, float weigh
     s.px[idx] = ((float)xi + u0) * d.res - d.half_x;
     s.py[idx] = ((float)yi + u1) * d.res - d.half_y;
     s.pz[idx] = ((float)zi + u2) * d.res - d.half_z;
-    s.vx[idx] = 0.f; s.vy[idx] = 0.f; s.w[idx] = weight;
+    float vx = 0.f, vy = 0.f;
+    if (vmax > 0.f) {  // benchmark variant with moving particles: velocities uniform in +-vmax
+        const unsigned h3 = hash_u32(h2 + 0x9e3779b9U), h4 = hash_u32(h3 + 0x9e3779b9U);
+        vx = vmax * (2.f * (float)(h3 >> 8) * (1.f / 16777216.f) - 1.f);
+        vy = vmax * (2.f * (float)(h4 >> 8) * (1.f / 16777216.f) - 1.f);
+    }
+    s.vx[idx] = vx; s.vy[idx] = vy; s.w[idx] = weight;
 }
 
 // import sparse records {flag,vx,vy,vz,px,py,pz,w} at (global voxel, slot); slot < 0 = first free
@@ -954,9 +960,9 @@ void launch_resample(const LaunchCtx& c) {
     if (c.d.mw == 1) hipLaunchKernelGGL(k_resample<1>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample);
     else hipLaunchKernelGGL(k_resample<2>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample);
 }
-void launch_seed_uniform(const LaunchCtx& c, int per_voxel, float weight, unsigned seed) {
+void launch_seed_uniform(const LaunchCtx& c, int per_voxel, float weight, unsigned seed, float vmax) {
     const size_t total = (size_t)c.d.v_loc * c.d.slots;
-    hipLaunchKernelGGL(k_seed_uniform, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, c.d, c.s, per_voxel, weight, seed);
+    hipLaunchKernelGGL(k_seed_uniform, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, c.d, c.s, per_voxel, weight, seed, vmax);
 }
 void launch_import(const LaunchCtx& c, int n, const int* voxel_dev, const int* slot_dev, const float* rec8_dev, int* n_failed_dev) {
     if (n <= 0) return;

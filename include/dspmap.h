@@ -204,6 +204,8 @@ int dspmap_add_random_particles(dspmap_t* m, int n, float weight);
 /* benchmark fill: every voxel gets `per_voxel` zero-velocity particles,
  * uniform in-voxel positions, given weight; generated on device from `seed`. */
 int dspmap_seed_uniform(dspmap_t* m, int per_voxel, float weight, unsigned seed);
+/* same fill with velocities uniform in [-vmax, vmax] (benchmark of the future-status rollout) */
+int dspmap_seed_uniform_moving(dspmap_t* m, int per_voxel, float weight, unsigned seed, float vmax);
 
 /* ---- single stages on the current state (test hooks; the reference's
  * stages are private members made reachable the same way by its own author

@@ -1,0 +1,18 @@
+import sys, os
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+import dsp_map_amd as D
+scene_mod = __import__("dsp-map_amd.scene", fromlist=["CorridorScene"])
+w=dict(nx=66,ny=66,nz=40,res=0.15,ppv=24)
+m=D.DSPMap(D.make_config(**w, seed=1234)); m.L.dspmap_init_device(m.h)
+sc=scene_mod.CorridorScene(w["nx"]*w["res"], w["ny"]*w["res"], w["nz"]*w["res"], device="cuda")
+fr=[sc.frame(f/30) for f in range(300)]
+torch.cuda.synchronize()
+for f in range(300):
+    pts,pos,q=fr[f]; m.update_device(pts.data_ptr(), pts.shape[0], pos, f/30, q); m.clearOccupancyMapPrediction()
+m.sync()
+r=np.asarray(m.results()).reshape(-1,4)
+nt=r.shape[0]//64
+t=r[:nt*64,3].reshape(nt,64)
+ne=t[:,0]>0
+print("wall ticks(10ns) mean", t[ne,0].mean(), "shader cycles mean", t[ne,1].mean(), "=> MHz", (t[ne,1]/t[ne,0]).mean()*100)

@@ -544,6 +544,51 @@ def test_device_resident_frame_and_graph_replay(dsp, orc):
         m.close()
 
 
+def test_rollout_ten_horizons_moving_particles(dsp, orc):
+    """BASELINE config [3] / SURVEY 8(d) D: PREDICTION_TIMES = 10, horizons 0.2*(k+1) s, 80 % of the
+    particles moving: future mass per (voxel, horizon) against the oracle (:950-964), mass conservation inside the
+    map, and getOccupancyMapWithFutureStatus == getFutureStatus + clear (:405-438)"""
+    pred = tuple(0.2 * (k + 1) for k in range(10))
+    cfgkw = dict(nx=36, ny=28, nz=12, ppv=12, pred_times=pred)
+    o, m = make_pair(dsp, orc, **cfgkw)
+    assert m.T == 10
+    half = common.half_extent(o.cfg)
+    px, py, pz, vx, vy, w = common.random_particles(11, 30000, (half[0] * 0.9, half[1] * 0.9, half[2] * 0.9),
+                                                    vmax=1.5, static_frac=0.2, wlo=0.002, whi=0.05)
+    flag = np.ones_like(w)
+    common.inject_both(o, m, px, py, pz, vx, vy, w, flag)
+    o.occupancy_resample(); m.occupancy_resample()
+    res_o = o.results
+    fut_g = m.getFutureStatus()          # reads and clears
+    assert fut_g.shape == (m.V, 10)
+    assert np.allclose(fut_g, res_o[:, 4:14], rtol=1e-4, atol=1e-6)
+    # every horizon holds the mass of the particles still inside the map at that horizon: non-increasing in time
+    tot = fut_g.astype(np.float64).sum(axis=0)
+    assert np.all(np.diff(tot) <= 1e-6 * tot[0]) and tot[-1] > 0.2 * tot[0]
+    assert np.count_nonzero(m.getFutureStatus()) == 0      # the getter cleared the accumulators (:420-424)
+    o.close(); m.close()
+
+
+def test_graph_replay_with_foreign_kernels_between_frames(dsp):
+    """regression: a memset node inside the captured frame graph faulted as soon as another stream ran
+    kernels between two replays (large map, ~6 frames).  The frame graph now holds kernel nodes only."""
+    import importlib
+    import torch
+    scene = importlib.import_module("dsp-map_amd.scene")
+    w = dict(nx=132, ny=132, nz=60, res=0.15, ppv=24)
+    m = dsp.DSPMap(dsp.make_config(**w, seed=5))
+    m.set_param(dsp.capi.P_USE_GRAPH, 1)
+    sc = scene.CorridorScene(w["nx"] * w["res"], w["ny"] * w["res"], w["nz"] * w["res"], device="cuda")
+    for f in range(14):
+        pts, pos, q = sc.frame(f / 30.0)        # torch kernels (sort / unique / index_add) on torch's stream
+        assert m.update_device(pts.data_ptr(), pts.shape[0], pos, f / 30.0, q) == 1
+        m.clearOccupancyMapPrediction()
+    m.sync()
+    c = m.counters()
+    assert c["n_live_out"] > 10000 and c["n_voxel_full"] == 0
+    m.close()
+
+
 def test_velocity_estimator_matches_oracle_restatement(dsp, orc):
     """a17 (adjacent): host velocity estimator inside dspmap_update (ground split, Euclidean clustering,
     Hungarian matching) against the oracle's restatement of velocityEstimationThread (:1377-1544) on a
