@@ -302,6 +302,7 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, hipMemset(k.part_predict, 0, sizeof(int) * (size_t)k.ntiles * 4));
     HIPCHK(m, hipMemset(k.part_claim, 0, sizeof(int) * (size_t)k.ntiles * 2));
     HIPCHK(m, hipMemset(k.part_resample, 0, sizeof(int) * (size_t)k.nblk_sweep * 4));
+    HIPCHK(m, hipMemset(k.vb_cnt, 0, sizeof(int) * (size_t)d.v_loc));   // invariant: empty outside a birth stage
     {   // boundary-plane normals, sensor frame (:563-578; float sin/cos like the C++ overloads)
         std::vector<float> h((size_t)(d.np_h + 1) * 3), v((size_t)(d.np_v + 1) * 3);
         const float pi_f = 3.14159265358979323846f;
@@ -524,9 +525,9 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     dspmap_prof_mark(m, 4);
     launch_weight_update(c);
     dspmap_prof_mark(m, 5);
-    launch_ck_finalize(c);
+    if (birth_grid <= 0) launch_ck_finalize(c);   // otherwise k_birth_rank reduces the 1/Ck sums (one launch less)
     dspmap_prof_mark(m, 6);
-    launch_birth(c, birth_grid, false);
+    launch_birth(c, birth_grid, true);
     dspmap_prof_mark(m, 7);
     launch_resample(c);
     dspmap_prof_mark(m, 8);
@@ -660,7 +661,6 @@ extern "C" int dspmap_update(dspmap_t* m, int n, int stride, const float* pts, f
     launch_predict(c);
     launch_ck_partial(c);
     launch_weight_update(c);
-    launch_ck_finalize(c);
     int nb = np;
     if (m->use_vel_est) {
         // the reference forks velocityEstimationThread before prediction and joins before the birth
@@ -681,7 +681,8 @@ extern "C" int dspmap_update(dspmap_t* m, int n, int stride, const float* pts, f
         rc = dspmap_push_frame_params(m);
         if (rc != DSPMAP_OK) return rc;
     }
-    if (n >= 0) launch_birth(c, nb, false);  // :314-316
+    if (n >= 0 && nb > 0) launch_birth(c, nb, true);  // :314-316
+    else launch_ck_finalize(c);
     launch_resample(c);
     if (m->vz_frames > 0) --m->vz_frames;
     HIPCHK(m, hipEventRecord(m->ev1, m->stream));

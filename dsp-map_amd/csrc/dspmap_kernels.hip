@@ -158,15 +158,66 @@ __global__ void k_obs_gather(MapDims d, DevState s) {
 // known on the device, so a one-workgroup kernel expands them into a compact item list each frame and the
 // pair kernels run a fixed grid that strides over it -- no empty workgroups, and the items of a heavy
 // pyramid spread over all XCDs.  item = (pyramid << 12) | chunk.
+// exclusive prefix sum over the workgroup
+__device__ __forceinline__ int block_excl_scan_1024(int v, int* s_tmp, int* total) {
+    // s_tmp: 17 ints.  Any blockDim.x that is a multiple of 64, up to 1024; all threads must call.
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, nw = blockDim.x >> 6;
+    const int inc = wave_incl_scan_i(v);
+    if (l == 63) s_tmp[w] = inc;
+    __syncthreads();
+    if (w == 0) {  // scan of the wave totals by the first wave (no serial loop)
+        const int t = l < nw ? s_tmp[l] : 0;
+        const int ti = wave_incl_scan_i(t);
+        if (l < nw) s_tmp[l] = ti - t;
+        if (l == 63) s_tmp[16] = ti;
+    }
+    __syncthreads();
+    const int r = inc - v + s_tmp[w];
+    *total = s_tmp[16];
+    __syncthreads();
+    return r;
+}
+
+// BK independent exclusive prefix sums over the workgroup at once (two barriers in total).
+// Element order: v[0] of all threads, then v[1] of all threads, ... -- i.e. the order of the
+// coalesced index i = j * blockDim + tid.  Returns the grand total; v[j] becomes the exclusive prefix.
+// s_tmp: BK * 16 + 1 ints.
+template <int NB>
+__device__ __forceinline__ int block_excl_scan_multi(int (&v)[NB], int* s_tmp) {
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, nw = blockDim.x >> 6;
+    int inc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        inc[j] = wave_incl_scan_i(v[j]);
+        if (l == 63) s_tmp[j * 16 + w] = inc[j];
+    }
+    __syncthreads();
+    if (w == 0) {
+        int run = 0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int t = l < nw ? s_tmp[j * 16 + l] : 0;
+            const int ti = wave_incl_scan_i(t);
+            if (l < nw) s_tmp[j * 16 + l] = run + ti - t;
+            run += __builtin_amdgcn_readlane(ti, 63);
+        }
+        if (l == 0) s_tmp[NB * 16] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NB; ++j) v[j] = inc[j] - v[j] + s_tmp[j * 16 + w];
+    const int total = s_tmp[NB * 16];
+    __syncthreads();
+    return total;
+}
+
 __device__ __forceinline__ int wu_split(int O) { return O <= 64 ? 1 : (O <= 128 ? 2 : (O <= 256 ? 4 : 8)); }
 
 __global__ void __launch_bounds__(512) k_pyr_items(MapDims d, DevState s, int* __restrict__ ck_items, int* __restrict__ wu_items,
                                                    int* __restrict__ n_items) {
-    __shared__ int s_ck[513], s_wu[513];
-    __shared__ int s_base[2];
+    __shared__ int s_tmp[17];
     const int tid = threadIdx.x;
-    if (tid < 2) s_base[tid] = 0;
-    __syncthreads();
+    int base_ck = 0, base_wu = 0;
     for (int b0 = 0; b0 < d.np; b0 += 512) {
         const int b = b0 + tid;
         int nck = 0, nwu = 0;
@@ -184,22 +235,14 @@ __global__ void __launch_bounds__(512) k_pyr_items(MapDims d, DevState s, int* _
             nck = O > 0 ? (P + CK_PCH - 1) / CK_PCH : 0;
             nwu = max(1, (P + pw - 1) / pw);          // chunk 0 always exists: it owns the bin's 1/Ck sum
         }
-        s_ck[tid] = nck; s_wu[tid] = nwu;
-        __syncthreads();
-        if (tid == 0) {
-            int a = s_base[0], w = s_base[1];
-            for (int k = 0; k < 512; ++k) { const int x = s_ck[k], y = s_wu[k]; s_ck[k] = a; s_wu[k] = w; a += x; w += y; }
-            s_ck[512] = a; s_wu[512] = w;
-        }
-        __syncthreads();
-        if (b < d.np) {
-            for (int c = 0; c < nck; ++c) ck_items[s_ck[tid] + c] = (b << 12) | c;
-            for (int c = 0; c < nwu; ++c) wu_items[s_wu[tid] + c] = (b << 12) | c;
-        }
-        __syncthreads();
-        if (tid == 0) { s_base[0] = s_ck[512]; s_base[1] = s_wu[512]; n_items[0] = s_ck[512]; n_items[1] = s_wu[512]; }
-        __syncthreads();
+        int tot_ck, tot_wu;
+        const int o_ck = base_ck + block_excl_scan_1024(nck, s_tmp, &tot_ck);
+        const int o_wu = base_wu + block_excl_scan_1024(nwu, s_tmp, &tot_wu);
+        for (int c = 0; c < nck; ++c) ck_items[o_ck + c] = (b << 12) | c;
+        for (int c = 0; c < nwu; ++c) wu_items[o_wu + c] = (b << 12) | c;
+        base_ck += tot_ck; base_wu += tot_wu;
     }
+    if (tid == 0) { n_items[0] = base_ck; n_items[1] = base_wu; }
 }
 
 __device__ __forceinline__ int neighbor_bins(const MapDims& d, int b, int* bins) {
@@ -299,21 +342,10 @@ __device__ __forceinline__ float frame_lambda(const DevState& s, const FilterPar
     if (s.fs->has_expected_override) return s.fs->expected_newborn;
     return fp.nb_weight * (float)s.fs->n_valid * (float)fp.nb_num;  // :292
 }
+__device__ __forceinline__ void ck_sum_block(const MapDims& d, const DevState& s, const FilterParams& fp, float* s_red);
 __global__ void __launch_bounds__(512) k_ck_sum(MapDims d, DevState s, FilterParams fp) {
     __shared__ float s_red[512];
-    const int tid = threadIdx.x;
-    float acc = 0.f;
-    for (int i = tid; i < d.np; i += 512) acc += s.part_inv[i];
-    s_red[tid] = acc;
-    __syncthreads();
-    for (int o = 256; o > 0; o >>= 1) {
-        if (tid < o) s_red[tid] += s_red[tid + o];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        s.fs->expected_newborn = frame_lambda(s, fp);
-        s.fs->newborn_w = fp.nb_weight * s_red[0];  // :805
-    }
+    ck_sum_block(d, s, fp, s_red);
 }
 
 // --------------------------------------------------------------------------
@@ -452,46 +484,54 @@ __global__ void k_birth_split(MapDims d, DevState s, FilterParams fp) {
 // The sequential consumption order of the three random streams (:871-873 position table,
 // :884-886 velocity table, :895-897 rand()) is reproduced with block-wide prefix sums over the
 // source points: draws of point i start at cursor + (draws of all earlier points).
-__device__ __forceinline__ int block_excl_scan_1024(int v, int* s_tmp, int* total) {
-    // s_tmp: 17 ints.  blockDim.x == 1024
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const int inc = wave_incl_scan_i(v);
-    if (l == 63) s_tmp[w] = inc;
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int k = 0; k < 16; ++k) { const int t = s_tmp[k]; s_tmp[k] = run; run += t; }
-        s_tmp[16] = run;
-    }
-    __syncthreads();
-    const int r = inc - v + s_tmp[w];
-    *total = s_tmp[16];
-    __syncthreads();
-    return r;
-}
-
 // k_birth_rank (one workgroup): rank of every valid source point among the valid ones ->
 // first position-table cursor of the point (3 draws per child, always consumed, :871-873).
-__global__ void __launch_bounds__(1024) k_birth_rank(MapDims d, DevState s, FilterParams fp) {
-    const int n_birth = s.fpar->n_birth;
-    __shared__ int s_tmp[17];
-    __shared__ int s_run;
+// Every thread owns BK consecutive points, so all loads are in flight together and one scan suffices.
+// with_ck_sum: also reduce the per-pyramid 1/Ck sums into the birth normaliser (k_ck_sum's job),
+// which saves a launch per frame.
+#define BK 8
+__device__ __forceinline__ void ck_sum_block(const MapDims& d, const DevState& s, const FilterParams& fp, float* s_red) {
     const int tid = threadIdx.x;
-    if (tid == 0) s_run = 0;
+    float acc = 0.f;
+    if (tid < 512) {
+        for (int i = tid; i < d.np; i += 512) acc += s.part_inv[i];
+        s_red[tid] = acc;
+    }
     __syncthreads();
-    const int p_cur = s.fs->p_cur;
-    const int nb = fp.nb_num;
-    for (int base = 0; base < n_birth; base += 1024) {
-        const int i = base + tid;
-        const bool ok = i < n_birth && s.plan[i].gvox >= 0;
-        int tot;
-        const int r = block_excl_scan_1024(ok ? 1 : 0, s_tmp, &tot);
-        if (ok) s.plan[i].pbase = (int)(((long long)p_cur + 3ll * nb * (long long)(s_run + r)) % fp.tab_n);
-        __syncthreads();
-        if (tid == 0) s_run += tot;
+    for (int o = 256; o > 0; o >>= 1) {
+        if (tid < o) s_red[tid] += s_red[tid + o];
         __syncthreads();
     }
-    if (tid == 0) s.fs->p_cur = (int)(((long long)p_cur + 3ll * nb * s_run) % fp.tab_n);
+    if (tid == 0) {
+        s.fs->expected_newborn = frame_lambda(s, fp);
+        s.fs->newborn_w = fp.nb_weight * s_red[0];  // :805
+    }
+}
+__global__ void __launch_bounds__(1024) k_birth_rank(MapDims d, DevState s, FilterParams fp, int with_ck_sum) {
+    const int n_birth = s.fpar->n_birth;
+    __shared__ int s_tmp[BK * 16 + 1];
+    __shared__ float s_red[512];
+    const int tid = threadIdx.x;
+    if (with_ck_sum) ck_sum_block(d, s, fp, s_red);
+    const int p_cur = s.fs->p_cur;
+    const int nb = fp.nb_num;
+    int run = 0;
+    for (int base = 0; base < n_birth; base += 1024 * BK) {
+        int v[BK];
+        bool ok[BK];
+#pragma unroll
+        for (int j = 0; j < BK; ++j) {   // coalesced index, all loads in flight together
+            const int i = base + j * 1024 + tid;
+            ok[j] = i < n_birth && s.plan[i].gvox >= 0;
+            v[j] = ok[j] ? 1 : 0;
+        }
+        const int tot = block_excl_scan_multi<BK>(v, s_tmp);
+#pragma unroll
+        for (int j = 0; j < BK; ++j)
+            if (ok[j]) s.plan[base + j * 1024 + tid].pbase = (int)(((long long)p_cur + 3ll * nb * (long long)(run + v[j])) % fp.tab_n);
+        run += tot;
+    }
+    if (tid == 0) s.fs->p_cur = (int)(((long long)p_cur + 3ll * nb * run) % fp.tab_n);
 }
 
 // Children are inserted in the reference's sequential order WITHOUT a sort:
@@ -536,47 +576,54 @@ __global__ void k_birth_children(MapDims d, DevState s, FilterParams fp, float4*
 // k_birth_cursors (one workgroup): velocity-table and rand() cursors per source point (:884-886,:895-897)
 __global__ void __launch_bounds__(1024) k_birth_cursors(MapDims d, DevState s, FilterParams fp) {
     const int n_birth = s.fpar->n_birth;
-    __shared__ int s_tmp[17];
-    __shared__ int s_run[2];
+    __shared__ int s_tmp[BK * 16 + 1];
     const int tid = threadIdx.x;
-    if (tid < 2) s_run[tid] = 0;
-    __syncthreads();
     const int v_cur = s.fs->v_cur, r_cur = s.fs->r_cur;
     const int nb = fp.nb_num;
-    for (int base = 0; base < n_birth; base += 1024) {
-        const int i = base + tid;
-        int cv = 0, cr = 0, n_static = 0;
-        bool ok = false;
-        if (i < n_birth) {
-            const BirthPlan pl = s.plan[i];
-            ok = pl.gvox >= 0;
-            if (ok) {
-                n_static = s.nstatic[i];
-                const BirthSrc src = s.fpar->birth[i];
-                if (src.intensity > 0.01f) {
-                    const int model_end = src.nx > -100.f ? fp.model_nb : n_static;  // :881
-                    for (int k = n_static; k < nb; ++k) {
-                        if (!((pl.inside >> k) & 1u)) continue;
-                        if (k < model_end) cv += 3; else cr += 3;
-                    }
+    const BirthSrc* __restrict__ birth = s.fpar->birth;
+    int run_v = 0, run_r = 0;
+    for (int base = 0; base < n_birth; base += 1024 * BK) {
+        int gvox[BK], nst[BK];
+        unsigned inside[BK];
+        float inten[BK], snx[BK];
+#pragma unroll
+        for (int j = 0; j < BK; ++j) {   // coalesced index, every load independent: one memory round trip
+            const int i = base + j * 1024 + tid;
+            gvox[j] = -1; nst[j] = 0; inside[j] = 0u; inten[j] = 0.f; snx[j] = 0.f;
+            if (i < n_birth) {
+                gvox[j] = s.plan[i].gvox; inside[j] = s.plan[i].inside;
+                nst[j] = s.nstatic[i];
+                inten[j] = birth[i].intensity; snx[j] = birth[i].nx;
+            }
+        }
+        int cv[BK], cr[BK];
+#pragma unroll
+        for (int j = 0; j < BK; ++j) {
+            cv[j] = 0; cr[j] = 0;
+            if (gvox[j] >= 0 && inten[j] > 0.01f) {
+                const int model_end = snx[j] > -100.f ? fp.model_nb : nst[j];  // :881
+                for (int k = nst[j]; k < nb; ++k) {
+                    if (!((inside[j] >> k) & 1u)) continue;
+                    if (k < model_end) cv[j] += 3; else cr[j] += 3;
                 }
             }
         }
-        int totv, totr;
-        const int ev = block_excl_scan_1024(cv, s_tmp, &totv);
-        const int er = block_excl_scan_1024(cr, s_tmp, &totr);
-        if (ok) {
-            s.plan[i].n_static = n_static;
-            s.plan[i].vbase = (int)(((long long)v_cur + s_run[0] + ev) % fp.tab_n);
-            s.plan[i].rbase = (int)(((long long)r_cur + s_run[1] + er) % max(fp.rtab_n, 1));
+        const int totv = block_excl_scan_multi<BK>(cv, s_tmp);
+        const int totr = block_excl_scan_multi<BK>(cr, s_tmp);
+#pragma unroll
+        for (int j = 0; j < BK; ++j) {
+            if (gvox[j] >= 0) {
+                BirthPlan* pl = &s.plan[base + j * 1024 + tid];
+                pl->n_static = nst[j];
+                pl->vbase = (int)(((long long)v_cur + run_v + cv[j]) % fp.tab_n);
+                pl->rbase = (int)(((long long)r_cur + run_r + cr[j]) % max(fp.rtab_n, 1));
+            }
         }
-        __syncthreads();
-        if (tid == 0) { s_run[0] += totv; s_run[1] += totr; }
-        __syncthreads();
+        run_v += totv; run_r += totr;
     }
     if (tid == 0) {
-        s.fs->v_cur = (int)(((long long)v_cur + s_run[0]) % fp.tab_n);
-        s.fs->r_cur = (int)(((long long)r_cur + s_run[1]) % max(fp.rtab_n, 1));
+        s.fs->v_cur = (int)(((long long)v_cur + run_v) % fp.tab_n);
+        s.fs->r_cur = (int)(((long long)r_cur + run_r) % max(fp.rtab_n, 1));
     }
 }
 
@@ -771,19 +818,21 @@ __global__ void k_zero_i32(int* __restrict__ p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0;
 }
-void launch_birth_plan_insert(const LaunchCtx& c, int n_birth_grid) {
+void launch_birth_plan_insert(const LaunchCtx& c, int n_birth_grid, bool in_frame) {
     if (n_birth_grid <= 0) return;
     const long long total = (long long)n_birth_grid * c.fp.nb_num;
     const unsigned gb = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(k_zero_i32, dim3((c.d.v_loc + 255) / 256), dim3(256), 0, c.stream, c.k.vb_cnt, c.d.v_loc);
-    hipLaunchKernelGGL(k_birth_rank, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
+    // invariant: the per-voxel buckets (vb_cnt) are all zero whenever no birth stage is in progress.
+    // in_frame: k_resample, which follows, zeroes them again, and k_birth_rank also does k_ck_sum's job.
+    hipLaunchKernelGGL(k_birth_rank, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp, in_frame ? 1 : 0);
     hipLaunchKernelGGL(k_birth_children, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx);
     hipLaunchKernelGGL(k_birth_cursors, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
     hipLaunchKernelGGL(k_birth_insert, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx, c.k.part_birth);
+    if (!in_frame) hipLaunchKernelGGL(k_zero_i32, dim3((c.d.v_loc + 255) / 256), dim3(256), 0, c.stream, c.k.vb_cnt, c.d.v_loc);
 }
-void launch_birth(const LaunchCtx& c, int n_birth_grid, bool) {
+void launch_birth(const LaunchCtx& c, int n_birth_grid, bool in_frame) {
     launch_birth_split(c, n_birth_grid);
-    launch_birth_plan_insert(c, n_birth_grid);
+    launch_birth_plan_insert(c, n_birth_grid, in_frame);
 }
 
 void launch_occupied_compact(const LaunchCtx& c, float thr) {

@@ -454,7 +454,7 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 // dynamic LDS per wave: [slots][64] fp32 weights + [64][M] u16 (source slot, destination slot) of deferred copies
 // --------------------------------------------------------------------------
 template <int MW>
-__global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __restrict__ part_live) {
+__global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __restrict__ part_live, int* __restrict__ vb_cnt) {
     extern __shared__ float s_dyn[];
     const int l = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -476,6 +476,7 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
         }
         nonempty |= m[e] != 0ull;
     }
+    if (inr) vb_cnt[lv] = 0;    // birth buckets of this frame are consumed: leave them empty for the next one
     if (!__ballot(nonempty)) {  // whole tile empty
         if (inr) s.res4[lv] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (l == 0 && wave_g * 64 < d.v_loc + 63) part_live[wave_g] = 0;
@@ -957,8 +958,8 @@ void launch_resample(const LaunchCtx& c) {
     const int nw = 1;   // waves (= tiles) per workgroup; the LDS panel bounds the occupancy, small groups pack best
     const size_t lds = (size_t)nw * (c.d.slots * 64 + (64 * c.d.M + 1) / 2) * sizeof(float);
     const unsigned grid = (unsigned)((k->ntiles + nw - 1) / nw);
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_resample<1>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample);
-    else hipLaunchKernelGGL(k_resample<2>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample);
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_resample<1>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt);
+    else hipLaunchKernelGGL(k_resample<2>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt);
 }
 void launch_seed_uniform(const LaunchCtx& c, int per_voxel, float weight, unsigned seed, float vmax) {
     const size_t total = (size_t)c.d.v_loc * c.d.slots;
