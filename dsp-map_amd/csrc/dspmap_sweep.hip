@@ -349,6 +349,10 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
     __shared__ u64 s_mask[MW * 64], s_new[MW * 64];
     __shared__ int s_rank[64];
     __shared__ int s_cnt[2];
+    // the records of a step are written out sorted by slot row, so that the lanes of one store instruction
+    // fall into few 128-byte lines (a scattered 4-byte store costs one transaction per lane)
+    __shared__ int s_hist[128], s_tot;
+    __shared__ float s_srt[7 * 256];
     const int tid = threadIdx.x;
     const int n_all = in_cnt[blockIdx.x];
     if (n_all == 0) {
@@ -377,10 +381,12 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
         int key[1] = {-1}, pos[1];
         int ln = 0, nsl = -1;
         size_t nidx = 0;
-        float px = 0, py = 0, pz = 0, w = 0;
+        float px = 0, py = 0, pz = 0, w = 0, mvx = 0, mvy = 0;
+        if (tid < 128) s_hist[tid] = 0;
+        __syncthreads();
         if (i < n) {
             const float4 a = in_rec[(base + i) * 2], b = in_rec[(base + i) * 2 + 1];
-            px = a.w; py = b.x; pz = b.y; w = b.z;
+            px = a.w; py = b.x; pz = b.y; w = b.z; mvx = a.y; mvy = a.z;
             ln = (__float_as_int(a.x) - d.v_base) & 63;
             int r = atomicAdd(&s_rank[ln], 1);
 #pragma unroll
@@ -396,12 +402,34 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
             }
             if (nsl >= 0) {
                 nidx = pidx(d, blockIdx.x * 64 + ln, nsl);
-                s.px[nidx] = px; s.py[nidx] = py; s.pz[nidx] = pz;
-                s.vx[nidx] = a.y; s.vy[nidx] = a.z; s.w[nidx] = w;
                 key[0] = pyramid_of(d, s_ph, s_pv, px, py, pz);
             } else {
                 ++c_vf;
             }
+        }
+        // counting sort of the step's placed records by slot row, then row-ordered stores
+        int rk = -1;
+        if (nsl >= 0) rk = atomicAdd(&s_hist[nsl], 1);
+        __syncthreads();
+        if (tid < 64) {
+            const int a0 = s_hist[2 * tid], a1 = s_hist[2 * tid + 1];
+            const int inc = wave_incl_scan_i(a0 + a1);
+            s_hist[2 * tid] = inc - a0 - a1; s_hist[2 * tid + 1] = inc - a1;
+            if (tid == 63) s_tot = inc;
+        }
+        __syncthreads();
+        if (nsl >= 0) {
+            const int q = s_hist[nsl] + rk;
+            s_srt[q] = __int_as_float(nsl * 64 + ln);
+            s_srt[256 + q] = px; s_srt[512 + q] = py; s_srt[768 + q] = pz;
+            s_srt[1024 + q] = mvx; s_srt[1280 + q] = mvy; s_srt[1536 + q] = w;
+        }
+        __syncthreads();
+        if (tid < s_tot) {
+            const int cell = __float_as_int(s_srt[tid]);
+            const size_t o = ((size_t)blockIdx.x * d.slots + (cell >> 6)) * 64 + (cell & 63);
+            s.px[o] = s_srt[256 + tid]; s.py[o] = s_srt[512 + tid]; s.pz[o] = s_srt[768 + tid];
+            s.vx[o] = s_srt[1024 + tid]; s.vy[o] = s_srt[1280 + tid]; s.w[o] = s_srt[1536 + tid];
         }
         batch_append<1>(s.pyr_cnt, key, pos);
         if (nsl >= 0) {
