@@ -128,7 +128,7 @@ static void free_dev(dspmap* m) {
     DevState& s = m->s;
     if (m->mgpu_bound) { s.obs_ck = nullptr; s.nstatic = nullptr; }  // caller-owned
     if (m->mgpu_count) (void)hipFree(m->mgpu_count);
-    void* ptrs[] = {s.fpar, s.obs_ckf, s.part_inv, s.fut_stat, s.mask, s.nbmask, s.px, s.py, s.pz, s.vx, s.vy, s.w, s.vz0, s.res4, s.fut, s.obs, s.obs_ck,
+    void* ptrs[] = {s.fpar, s.obs_ckf, s.part_inv, s.fut_stat, s.mask, s.nbmask, s.pos, s.vel, s.w, s.vz0, s.res4, s.fut, s.obs, s.obs_ck,
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.nstatic, s.fov_rec, s.fov_slot, s.pyr_cnt, s.mv_rec, s.exp_up, s.exp_down,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.in_rec, m->k.in_cnt, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.expmask,
@@ -246,14 +246,13 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     const size_t ntiles = ((size_t)d.v_loc + 63) / 64;
     const size_t S = ntiles * 64 * d.slots, W = (size_t)d.v_loc * d.mw;
     HIPCHK(m, dalloc(&s.mask, W)); HIPCHK(m, dalloc(&s.nbmask, W));
-    HIPCHK(m, dalloc(&s.px, S)); HIPCHK(m, dalloc(&s.py, S)); HIPCHK(m, dalloc(&s.pz, S));
-    HIPCHK(m, dalloc(&s.vx, S)); HIPCHK(m, dalloc(&s.vy, S)); HIPCHK(m, dalloc(&s.w, S));
+    HIPCHK(m, dalloc(&s.pos, 3 * S)); HIPCHK(m, dalloc(&s.vel, 2 * S)); HIPCHK(m, dalloc(&s.w, S));
     HIPCHK(m, dalloc(&s.res4, (size_t)d.v_loc));
     HIPCHK(m, dalloc(&s.fut, (size_t)d.v_loc * (d.T ? d.T : 1)));
     HIPCHK(m, dalloc(&s.fut_stat, (size_t)d.v_loc));
     HIPCHK(m, hipMemset(s.fut_stat, 0, sizeof(float) * (size_t)d.v_loc));
-    HIPCHK(m, hipMemset(s.px, 0, sizeof(float) * S)); HIPCHK(m, hipMemset(s.py, 0, sizeof(float) * S)); HIPCHK(m, hipMemset(s.pz, 0, sizeof(float) * S));
-    HIPCHK(m, hipMemset(s.vx, 0, sizeof(float) * S)); HIPCHK(m, hipMemset(s.vy, 0, sizeof(float) * S)); HIPCHK(m, hipMemset(s.w, 0, sizeof(float) * S));
+    HIPCHK(m, hipMemset(s.pos, 0, sizeof(float) * 3 * S)); HIPCHK(m, hipMemset(s.vel, 0, sizeof(float) * 2 * S));
+    HIPCHK(m, hipMemset(s.w, 0, sizeof(float) * S));
     HIPCHK(m, dalloc(&s.obs, (size_t)d.np * DSP_OBS_CAP));
     HIPCHK(m, dalloc(&s.obs_ck, (size_t)d.np * DSP_OBS_CAP));
     HIPCHK(m, dalloc(&s.obs_ckf, (size_t)d.np * DSP_OBS_CAP));

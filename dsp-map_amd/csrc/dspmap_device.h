@@ -177,6 +177,20 @@ __device__ __forceinline__ size_t pidx(const MapDims& d, int lv, int slot) {
     return ((size_t)(lv >> 6) * d.slots + slot) * 64 + (lv & 63);
 }
 
+// particle field records (see DevState): 12-byte positions, 8-byte velocities; one vector access each
+struct P3 { float x, y, z; };
+struct V2 { float x, y; };
+__device__ __forceinline__ P3 ld_pos(const DevState& s, size_t idx) { return reinterpret_cast<const P3*>(s.pos)[idx]; }
+__device__ __forceinline__ V2 ld_vel(const DevState& s, size_t idx) { return reinterpret_cast<const V2*>(s.vel)[idx]; }
+__device__ __forceinline__ void st_pos(const DevState& s, size_t idx, float x, float y, float z) {
+    P3 v; v.x = x; v.y = y; v.z = z;
+    reinterpret_cast<P3*>(s.pos)[idx] = v;
+}
+__device__ __forceinline__ void st_vel(const DevState& s, size_t idx, float x, float y) {
+    V2 v; v.x = x; v.y = y;
+    reinterpret_cast<V2*>(s.vel)[idx] = v;
+}
+
 // claim the lowest free slot of a voxel: first-free-slot rule of addAParticle /
 // moveParticle (:1184-1185,1214-1215) as one atomic OR per attempt.
 // Returns the slot or -1 if the voxel is full.

@@ -459,7 +459,8 @@ __global__ void k_birth_split(MapDims d, DevState s, FilterParams fp) {
                 const u64 m = s.mask[(size_t)lv * d.mw + e] & ~s.nbmask[(size_t)lv * d.mw + e];  // 0.9<flag<14 :830
                 if (sl < d.slots && ((m >> l) & 1ull)) {
                     const size_t idx = pidx(d, lv, sl);
-                    const float vabs = fabsf(s.vx[idx]) + fabsf(s.vy[idx]) + 0.f;  // vz == 0
+                    const V2 pv = ld_vel(s, idx);
+                    const float vabs = fabsf(pv.x) + fabsf(pv.y) + 0.f;  // vz == 0
                     const float w = s.w[idx];
                     if (vabs < 0.1f) ws += w; else if (vabs < 0.5f) wsd += w; else wd += w;
                 }
@@ -698,8 +699,8 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, const flo
                 }
                 if (sl >= 0) {
                     const size_t idx = pidx(d, lv, sl);
-                    s.px[idx] = ch.x; s.py[idx] = ch.y; s.pz[idx] = ch.z;
-                    s.vx[idx] = vx; s.vy[idx] = vy;
+                    st_pos(s, idx, ch.x, ch.y, ch.z);
+                    st_vel(s, idx, vx, vy);
                     s.w[idx] = s.fs->newborn_w;
                     atomicOr(&s.nbmask[(size_t)lv * d.mw + (sl >> 6)], 1ull << (sl & 63));  // flag 15
                     born = true;

@@ -175,7 +175,9 @@ __global__ void __launch_bounds__(NW * 64) k_predict(MapDims d, DevState s, Filt
         u64 tor = rows_of_wave<NW>(wave_or_u64(live[e]), wave);
         while (tor) {
             int row[RB];
-            float vx[RB], vy[RB], px[RB], py[RB], pz[RB], w[RB];
+            P3 pp[RB];
+            V2 vv[RB];
+            float w[RB];
             bool act[RB];
             unsigned idx[RB];   // slot index fits 31 bits (fov_slot is an int; checked at create)
 #pragma unroll
@@ -184,13 +186,15 @@ __global__ void __launch_bounds__(NW * 64) k_predict(MapDims d, DevState s, Filt
                 if (tor) tor &= tor - 1ull;
                 act[r] = row[r] >= 0 && ((live[e] >> (row[r] & 63)) & 1ull);
                 idx[r] = (unsigned)pidx(d, lvs, e * 64 + (row[r] < 0 ? 0 : row[r]));
-                vx[r] = vy[r] = px[r] = py[r] = pz[r] = w[r] = 0.f;
-                if (act[r]) {
-                    vx[r] = s.vx[idx[r]]; vy[r] = s.vy[idx[r]];
-                    px[r] = s.px[idx[r]]; py[r] = s.py[idx[r]]; pz[r] = s.pz[idx[r]];
-                    w[r] = s.w[idx[r]];
-                }
+                // unconditional loads (idx is always a valid cell of this lane's voxel; dead cells share the row's
+                // cache lines): a predicated vector load makes the compiler wait for it before issuing the next row
+                vv[r] = ld_vel(s, idx[r]);
+                pp[r] = ld_pos(s, idx[r]);
+                w[r] = s.w[idx[r]];
             }
+            float vx[RB], vy[RB], px[RB], py[RB], pz[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) { vx[r] = vv[r].x; vy[r] = vv[r].y; px[r] = pp[r].x; py[r] = pp[r].y; pz[r] = pp[r].z; }
             int pyr[RB], mgv[RB];
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
@@ -205,7 +209,7 @@ __global__ void __launch_bounds__(NW * 64) k_predict(MapDims d, DevState s, Filt
                             const int c = (int)(((long long)s.fs->v_cur + 3ll * (long long)((size_t)(lv + d.v_base) * d.slots + e * 64 + row[r])) % fp.tab_n);
                             vx[r] += s.v_tab[c];
                             vy[r] += s.v_tab[(c + 1) % fp.tab_n];
-                            s.vx[idx[r]] = vx[r]; s.vy[idx[r]] = vy[r];
+                            st_vel(s, idx[r], vx[r], vy[r]);
                         }
                         s.vz0[idx[r]] = 0.f;
                     }
@@ -218,7 +222,7 @@ __global__ void __launch_bounds__(NW * 64) k_predict(MapDims d, DevState s, Filt
                         keep_clr |= bit;         // left the map :688
                         ++c_out;
                     } else {
-                        s.px[idx[r]] = px[r]; s.py[idx[r]] = py[r]; s.pz[idx[r]] = pz[r];
+                        st_pos(s, idx[r], px[r], py[r], pz[r]);
                         const int nlv = gv - d.v_base;
                         if (nlv == lv) pyr[r] = pyramid_of(d, s_ph, s_pv, px[r], py[r], pz[r]);
                         else if (nlv < 0 || nlv >= d.v_loc) ex |= bit;   // left the slab (multi-GPU)
@@ -428,8 +432,9 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
         if (tid < s_tot) {
             const int cell = __float_as_int(s_srt[tid]);
             const size_t o = ((size_t)blockIdx.x * d.slots + (cell >> 6)) * 64 + (cell & 63);
-            s.px[o] = s_srt[256 + tid]; s.py[o] = s_srt[512 + tid]; s.pz[o] = s_srt[768 + tid];
-            s.vx[o] = s_srt[1024 + tid]; s.vy[o] = s_srt[1280 + tid]; s.w[o] = s_srt[1536 + tid];
+            st_pos(s, o, s_srt[256 + tid], s_srt[512 + tid], s_srt[768 + tid]);
+            st_vel(s, o, s_srt[1024 + tid], s_srt[1280 + tid]);
+            s.w[o] = s_srt[1536 + tid];
         }
         batch_append<1>(s.pyr_cnt, key, pos);
         if (nsl >= 0) {
@@ -533,7 +538,7 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
         u64 tor = wave_or_u64(m[e]);
         while (tor) {
             int row[RBK];
-            float vx[RBK], vy[RBK];
+            V2 vv[RBK];
 #if !RS_DMA
             float wr[RBK];
 #endif
@@ -543,15 +548,18 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
                 row[r] = tor ? __ffsll((long long)tor) - 1 : -1;
                 if (tor) tor &= tor - 1ull;
                 act[r] = row[r] >= 0 && ((m[e] >> (row[r] & 63)) & 1ull);
-                vx[r] = vy[r] = 0.f;
+                // unconditional loads, see k_predict
+                const size_t idx = pidx(d, lvs, e * 64 + (row[r] < 0 ? 0 : row[r]));
 #if !RS_DMA
-                wr[r] = 0.f;
-                if (act[r]) wr[r] = s.w[pidx(d, lvs, e * 64 + row[r])];
+                wr[r] = s.w[idx];
 #endif
-                if (act[r] && !((nb[e] >> row[r]) & 1ull)) {
-                    const size_t idx = pidx(d, lvs, e * 64 + row[r]);
-                    vx[r] = s.vx[idx]; vy[r] = s.vy[idx];
-                }
+                vv[r] = ld_vel(s, idx);
+            }
+            float vx[RBK], vy[RBK];
+#pragma unroll
+            for (int r = 0; r < RBK; ++r) {
+                const bool old = act[r] && !((nb[e] >> row[r]) & 1ull);
+                vx[r] = old ? vv[r].x : 0.f; vy[r] = old ? vv[r].y : 0.f;
             }
 #if RS_DMA
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weight panel (first batch) + this batch's velocities
@@ -576,7 +584,8 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
                             stat_w += w;          // p + 0*t stays in this voxel for every horizon
                         } else {
                             const size_t idx = pidx(d, lvs, e * 64 + row[r]);
-                            const float px = s.px[idx], py = s.py[idx];
+                            const P3 p3 = ld_pos(s, idx);
+                            const float px = p3.x, py = p3.y;
                             for (int t = 0; t < T; ++t) {  // :952-963
                                 const float pt = d.pred_t[t];
                                 const float fx = px + vx[r] * pt;
@@ -653,7 +662,9 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
     // deferred copies :1026-1031, CPB at a time so that their loads overlap
     if (ncp > cpmax) ncp = cpmax;  // cannot happen: a voxel makes at most M copies
     for (int k0 = 0; __ballot(k0 < ncp); k0 += CPB) {
-        float cx[CPB], cy[CPB], cz[CPB], cvx[CPB], cvy[CPB], cvz[CPB];
+        P3 cp[CPB];
+        V2 cv[CPB];
+        float cvz[CPB];
         unsigned didx[CPB];
 #pragma unroll
         for (int j = 0; j < CPB; ++j) {
@@ -662,15 +673,16 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
                 const unsigned pr = s_cp[l * cpmax + k0 + j];
                 const size_t sidx = pidx(d, lvs, (int)(pr >> 8));
                 didx[j] = (unsigned)pidx(d, lvs, (int)(pr & 0xff));
-                cx[j] = s.px[sidx]; cy[j] = s.py[sidx]; cz[j] = s.pz[sidx]; cvx[j] = s.vx[sidx]; cvy[j] = s.vy[sidx];
+                cp[j] = ld_pos(s, sidx);
+                cv[j] = ld_vel(s, sidx);
                 cvz[j] = s.vz0 ? s.vz0[sidx] : 0.f;
             }
         }
 #pragma unroll
         for (int j = 0; j < CPB; ++j) {
             if (k0 + j < ncp) {
-                s.px[didx[j]] = cx[j]; s.py[didx[j]] = cy[j]; s.pz[didx[j]] = cz[j];
-                s.vx[didx[j]] = cvx[j]; s.vy[didx[j]] = cvy[j];
+                st_pos(s, didx[j], cp[j].x, cp[j].y, cp[j].z);
+                st_vel(s, didx[j], cv[j].x, cv[j].y);
                 if (s.vz0) s.vz0[didx[j]] = cvz[j];
                 s.w[didx[j]] = w_copy;
             }
@@ -720,16 +732,14 @@ __global__ void k_seed_uniform(MapDims d, DevState s, int per_voxel, float weigh
     const float u1 = 0.02f + 0.96f * (float)(h1 >> 8) * (1.f / 16777216.f);
     const float u2 = 0.02f + 0.96f * (float)(h2 >> 8) * (1.f / 16777216.f);
     const size_t idx = pidx(d, lv, sl);
-    s.px[idx] = ((float)xi + u0) * d.res - d.half_x;
-    s.py[idx] = ((float)yi + u1) * d.res - d.half_y;
-    s.pz[idx] = ((float)zi + u2) * d.res - d.half_z;
+    st_pos(s, idx, ((float)xi + u0) * d.res - d.half_x, ((float)yi + u1) * d.res - d.half_y, ((float)zi + u2) * d.res - d.half_z);
     float vx = 0.f, vy = 0.f;
     if (vmax > 0.f) {  // benchmark variant with moving particles: velocities uniform in +-vmax
         const unsigned h3 = hash_u32(h2 + 0x9e3779b9U), h4 = hash_u32(h3 + 0x9e3779b9U);
         vx = vmax * (2.f * (float)(h3 >> 8) * (1.f / 16777216.f) - 1.f);
         vy = vmax * (2.f * (float)(h4 >> 8) * (1.f / 16777216.f) - 1.f);
     }
-    s.vx[idx] = vx; s.vy[idx] = vy; s.w[idx] = weight;
+    st_vel(s, idx, vx, vy); s.w[idx] = weight;
 }
 
 // import sparse records {flag,vx,vy,vz,px,py,pz,w} at (global voxel, slot); slot < 0 = first free
@@ -753,9 +763,9 @@ __global__ void k_import(MapDims d, DevState s, int n, const int* __restrict__ v
     if (!ok) { atomicAdd(n_failed, 1); return; }
     const float* r = rec + 8 * (size_t)i;
     const size_t idx = pidx(d, lv, sl);
-    s.vx[idx] = r[1]; s.vy[idx] = r[2];
+    st_vel(s, idx, r[1], r[2]);
     if (s.vz0) s.vz0[idx] = r[3];
-    s.px[idx] = r[4]; s.py[idx] = r[5]; s.pz[idx] = r[6]; s.w[idx] = r[7];
+    st_pos(s, idx, r[4], r[5], r[6]); s.w[idx] = r[7];
     if (r[0] > 10.f) atomicOr(&s.nbmask[(size_t)lv * d.mw + (sl >> 6)], 1ull << (sl & 63));
 }
 
@@ -777,8 +787,10 @@ __global__ void k_export(MapDims d, DevState s, int* __restrict__ voxel, int* __
         slot[pos] = sl;
         float* r = rec + 8 * (size_t)pos;
         r[0] = nbf ? 15.f : 1.f;
-        r[1] = s.vx[idx]; r[2] = s.vy[idx]; r[3] = s.vz0 ? s.vz0[idx] : 0.f;
-        r[4] = s.px[idx]; r[5] = s.py[idx]; r[6] = s.pz[idx]; r[7] = s.w[idx];
+        const V2 v2 = ld_vel(s, idx);
+        const P3 p3 = ld_pos(s, idx);
+        r[1] = v2.x; r[2] = v2.y; r[3] = s.vz0 ? s.vz0[idx] : 0.f;
+        r[4] = p3.x; r[5] = p3.y; r[6] = p3.z; r[7] = s.w[idx];
     }
 }
 
@@ -805,7 +817,7 @@ __global__ void k_add_random(MapDims d, DevState s, FilterParams fp, int n, floa
     const int sl = claim_slot(s.mask, lv, d);
     if (sl < 0) return;
     const size_t idx = pidx(d, lv, sl);
-    s.px[idx] = px; s.py[idx] = py; s.pz[idx] = pz; s.vx[idx] = vx; s.vy[idx] = vy; s.w[idx] = weight;
+    st_pos(s, idx, px, py, pz); st_vel(s, idx, vx, vy); s.w[idx] = weight;
     if (s.vz0) s.vz0[idx] = vz;
     atomicOr(&s.nbmask[(size_t)lv * d.mw + (sl >> 6)], 1ull << (sl & 63));
 }
@@ -837,8 +849,10 @@ __global__ void __launch_bounds__(256) k_export_slab(MapDims d, DevState s, u64*
             int gv = 0;
             if (ex & (1ull << sb)) {
                 const size_t idx = pidx(d, lv, e * 64 + sb);
-                px = s.px[idx]; py = s.py[idx]; pz = s.pz[idx];
-                vx = s.vx[idx]; vy = s.vy[idx]; w = s.w[idx];
+                const P3 p3 = ld_pos(s, idx);
+                const V2 v2 = ld_vel(s, idx);
+                px = p3.x; py = p3.y; pz = p3.z;
+                vx = v2.x; vy = v2.y; w = s.w[idx];
                 voxel_of(d, px, py, pz, gv);
                 const int nlv = gv - d.v_base;
                 mine = dir > 0 ? nlv >= d.v_loc : nlv < 0;
@@ -880,8 +894,8 @@ __global__ void __launch_bounds__(256) k_import_movers(MapDims d, DevState s, in
             nsl = claim_slot(s.mask, nlv, d);
             if (nsl >= 0) {
                 nidx = pidx(d, nlv, nsl);
-                s.px[nidx] = px; s.py[nidx] = py; s.pz[nidx] = pz;
-                s.vx[nidx] = r[1]; s.vy[nidx] = r[2]; s.w[nidx] = w;
+                st_pos(s, nidx, px, py, pz);
+                st_vel(s, nidx, r[1], r[2]); s.w[nidx] = w;
                 pyr = pyramid_of(d, s_ph, s_pv, px, py, pz);
             } else lost = true;   // destination voxel full (-1, :1227-1229)
         } else lost = true;       // not a neighbouring slab's voxel (jump larger than a slab)
@@ -904,11 +918,11 @@ __global__ void __launch_bounds__(256) k_import_movers(MapDims d, DevState s, in
 __global__ void __launch_bounds__(256) k_calib_read(DevState s, size_t n, float* __restrict__ sink) {
     float acc = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        acc += s.px[i] + s.py[i] + s.pz[i] + s.vx[i] + s.vy[i] + s.w[i];
+    { const P3 p3 = ld_pos(s, i); const V2 v2 = ld_vel(s, i); acc += p3.x + p3.y + p3.z + v2.x + v2.y + s.w[i]; }
     if (acc == 1.2345e-30f) *sink = acc;
 }
 __global__ void __launch_bounds__(256) k_calib_write(DevState s, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s.px[i] = s.px[i] + 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s.w[i] = s.w[i] + 0.f;
 }
 void launch_calib(const LaunchCtx& c, int mode, size_t n) {
     if (mode == 0) hipLaunchKernelGGL(k_calib_read, dim3(8192), dim3(256), 0, c.stream, c.s, n, (float*)c.s.fs);

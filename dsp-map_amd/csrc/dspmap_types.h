@@ -100,8 +100,11 @@ struct FrameParams {
 struct DevState {
     u64* mask;     // [v_loc*mw] live bits
     u64* nbmask;   // [v_loc*mw] born-this-frame bits
-    float* px; float* py; float* pz;
-    float* vx; float* vy; float* w;
+    // particle fields, cell index = pidx(lv, slot); grouped by what is always written together, because a
+    // scattered store costs one memory transaction per lane whatever its width (<= 16 B):
+    float* pos;   // [S][3] {px, py, pz}   rewritten by every prediction
+    float* vel;   // [S][2] {vx, vy}       written at birth / move / copy only
+    float* w;     // [S]                   rewritten by the weight update and the resampler
     float* vz0;    // optional, only right after an import with vz != 0 (consumed by the next prediction)
     float4* res4;  // [v_loc] {mass, mean vx, mean vy, mean vz}
     float* fut;    // [v_loc][T]  future mass scattered by moving particles
