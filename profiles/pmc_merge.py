@@ -1,0 +1,79 @@
+"""Merge the outputs of profiles/collect.sh (gpurun_out/<tag>_*) into the tracked summaries:
+   profiles/pmc_traffic_r01.json  (read by bench.py for roofline.traffic)
+   profiles/<tag>_pmc_traffic.md, profiles/<tag>_kernel_stats.md, profiles/<tag>_<W>_kernel_stats.csv"""
+import io
+import json
+import os
+import shutil
+import sys
+from contextlib import redirect_stdout
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import summarize  # noqa: E402
+
+CMD = {
+    "B": "python bench.py --steps 300 --warmup 30 --no-cpu --no-extra",
+    "C_sat": "python bench.py --workload C_sat --steps 40 --warmup 5 --prefill 3 --no-cpu --no-extra",
+    "E_sat": "python bench.py --workload E_sat --steps 12 --warmup 2 --prefill 3 --no-cpu --no-extra",
+}
+PMC_CMD = {
+    "B": "python bench.py --steps 100 --warmup 10 --no-cpu --no-extra",
+    "C_sat": "python bench.py --workload C_sat --steps 20 --warmup 3 --prefill 3 --no-cpu --no-extra",
+}
+
+
+def base(name):
+    return name.split("<")[0]
+
+
+def main(tag):
+    g = os.path.join(ROOT, "gpurun_out")
+    cal_f = json.load(open(os.path.join(g, tag + "_cal_FETCH_SIZE.json")))
+    cal_w = json.load(open(os.path.join(g, tag + "_cal_WRITE_SIZE.json")))
+    cal_bytes = dict(l.split()[1::2] for l in open(os.path.join(g, tag + "_cal_bytes.txt")) if l.startswith("mode"))
+    rd_bytes, wr_bytes = int(cal_bytes["0"]), int(cal_bytes["1"])
+    f_ratio = cal_f["k_calib_read"]["FETCH_SIZE"]["avg"] * 1024 / rd_bytes
+    w_ratio = cal_w["k_calib_write"]["WRITE_SIZE"]["avg"] * 1024 / wr_bytes
+    note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate counter-only passes, KB per dispatch, averaged over the "
+            "dispatches of the run). Calibration on the same box with streams of known size (dspmap_debug_stream: the "
+            "sweeps' access pattern): FETCH_SIZE*1024 = %.3f x bytes read (%d B read), WRITE_SIZE*1024 = %.3f x bytes "
+            "written (%d B). hbm_bytes = FETCH_SIZE*1024/%.3f + WRITE_SIZE*1024/%.3f." %
+            (f_ratio, rd_bytes, w_ratio, wr_bytes, f_ratio, w_ratio))
+    out = {"note": note, "commands": {w: "rocprofv3 --pmc <C> --kernel-trace --output-format csv -- " + c for w, c in PMC_CMD.items()},
+           "workloads": {}}
+    md = ["# %s -- HBM traffic per kernel launch (PMC)\n" % tag, note, ""]
+    for w in ("B", "C_sat"):
+        jf = json.load(open(os.path.join(g, "%s_pmc_%s_FETCH_SIZE.json" % (tag, w))))
+        jw = json.load(open(os.path.join(g, "%s_pmc_%s_WRITE_SIZE.json" % (tag, w))))
+        rows = {}
+        for k in jf:
+            f = jf[k]["FETCH_SIZE"]["avg"]
+            wv = jw.get(k, {}).get("WRITE_SIZE", {}).get("avg", 0.0)
+            rows[base(k)] = {"fetch_kb": round(f, 1), "write_kb": round(wv, 1),
+                             "hbm_bytes": int(f * 1024 / f_ratio + wv * 1024 / w_ratio)}
+        out["workloads"][w] = dict(sorted(rows.items(), key=lambda kv: -kv[1]["hbm_bytes"]))
+        md += ["\n## workload %s\n" % w, "`rocprofv3 --pmc <C> --kernel-trace --output-format csv -- %s`\n" % PMC_CMD[w],
+               "| kernel | FETCH_SIZE KB | WRITE_SIZE KB | corrected HBM bytes / launch |", "|---|---|---|---|"]
+        for k, v in out["workloads"][w].items():
+            md.append("| %s | %.1f | %.1f | %s |" % (k, v["fetch_kb"], v["write_kb"], format(v["hbm_bytes"], ",")))
+    json.dump(out, open(os.path.join(HERE, "pmc_traffic_r01.json"), "w"), indent=1)
+    open(os.path.join(HERE, tag + "_pmc_traffic.md"), "w").write("\n".join(md) + "\n")
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        for w in ("B", "C_sat", "E_sat"):
+            src = os.path.join(g, "%s_%s_kernel_stats.csv" % (tag, w))
+            shutil.copy(src, os.path.join(HERE, "%s_%s_kernel_stats.csv" % (tag, w)))
+            summarize.main(src, "%s -- workload %s: rocprofv3 --kernel-trace --stats -- %s" % (tag, w, CMD[w]))
+            try:
+                j = json.loads(open(os.path.join(g, "%s_%s_bench.json" % (tag, w))).read())
+                print("bench line of this run (under the profiler): %.1f frames/s, %.4f ms/step; stage_ms (HIP events) %s\n"
+                      % (j["value"], j["ms_per_step"], json.dumps(j["frame"]["stage_ms"])))
+            except Exception as e:  # noqa: BLE001
+                print("(bench line not captured: %r)\n" % (e,))
+    open(os.path.join(HERE, tag + "_kernel_stats.md"), "w").write(buf.getvalue())
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01_e")
