@@ -462,7 +462,16 @@ void dspmap_freeze_birth_statics(dspmap* m) {
     m->nb_frozen = true;
 }
 
+void dspmap_flush_future_clear(dspmap* m) {
+    if (!m->fut_clear_pending) return;
+    LaunchCtx c = dspmap_ctx_of(m);
+    launch_clear_future(c);
+    m->fut_clear_pending = false;
+}
 int dspmap_push_frame_params(dspmap* m) {
+    // a pending clear of the future accumulators rides on the frame: its k_predict does it (no extra launch)
+    m->hp.clear_fut = m->fut_clear_pending ? 1 : 0;
+    m->fut_clear_pending = false;
     // pageable source: the runtime stages the bytes before returning, so m->hp can be reused at once
     HIPCHK(m, hipMemcpyAsync(m->s.fpar, &m->hp, sizeof(FrameParams), hipMemcpyHostToDevice, m->stream));
     return DSPMAP_OK;
@@ -731,10 +740,12 @@ static int readout(dspmap* m, float thr, float* xyz, int cap, int* n_out, float*
         const int ncopy = n < cap ? n : cap;
         if (xyz && ncopy > 0) HIPCHK(m, hipMemcpyAsync(xyz, m->s.occ_xyz, sizeof(float) * 3 * (size_t)ncopy, hipMemcpyDeviceToHost, m->stream));
     }
-    if (fut_out && d.T > 0) launch_future_combine(c);
-    if (fut_out && d.T > 0)
+    if (fut_out && d.T > 0) {
+        dspmap_flush_future_clear(m);
+        launch_future_combine(c);
         HIPCHK(m, hipMemcpyAsync(fut_out, m->s.fut, sizeof(float) * (size_t)d.v_loc * d.T, hipMemcpyDeviceToHost, m->stream));
-    launch_clear_future(c);  // :397-400, :420-424
+    }
+    m->fut_clear_pending = true;  // :397-400, :420-424
     HIPCHK(m, hipStreamSynchronize(m->stream));
     if (n_out) *n_out = n;
     return DSPMAP_OK;
@@ -748,8 +759,7 @@ extern "C" int dspmap_get_occupancy_with_future(dspmap_t* m, float thr, float* x
 extern "C" int dspmap_get_future(dspmap_t* m, float* fut) { return readout(m, 0.f, nullptr, 0, nullptr, fut, false); }
 extern "C" int dspmap_clear_future(dspmap_t* m) {
     READY(m);
-    LaunchCtx c = dspmap_ctx_of(m);
-    launch_clear_future(c);
+    m->fut_clear_pending = true;   // :431-438, carried out by the next frame's k_predict or before the next read
     return DSPMAP_OK;
 }
 extern "C" int dspmap_get_results(dspmap_t* m, float* out) {
@@ -761,6 +771,7 @@ extern "C" int dspmap_get_results(dspmap_t* m, float* out) {
 extern "C" const float* dspmap_results_device(dspmap_t* m) { return (m && m->device_ready) ? (const float*)m->s.res4 : nullptr; }
 extern "C" const float* dspmap_future_device(dspmap_t* m) {
     if (!m || !m->device_ready) return nullptr;
+    dspmap_flush_future_clear(m);
     LaunchCtx c = dspmap_ctx_of(m);
     launch_future_combine(c);  // static-particle mass is kept per voxel and folded in on demand
     return m->s.fut;
@@ -831,6 +842,7 @@ extern "C" int dspmap_clear_state(dspmap_t* m) {
     HIPCHK(m, hipMemsetAsync(m->s.res4, 0, sizeof(float4) * (size_t)d.v_loc, m->stream));
     HIPCHK(m, hipMemsetAsync(m->s.fut, 0, sizeof(float) * (size_t)d.v_loc * (d.T ? d.T : 1), m->stream));
     HIPCHK(m, hipMemsetAsync(m->s.fut_stat, 0, sizeof(float) * (size_t)d.v_loc, m->stream));
+    m->fut_clear_pending = false;
     HIPCHK(m, hipMemsetAsync(m->s.pyr_cnt, 0, sizeof(int) * d.np, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     m->have_last = false;
@@ -984,6 +996,7 @@ extern "C" int dspmap_stage_birth(dspmap_t* m) {
 }
 extern "C" int dspmap_stage_resample(dspmap_t* m) {
     READY(m);
+    dspmap_flush_future_clear(m);   // a pending clear must not wipe what this stage accumulates
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
     launch_resample(c);

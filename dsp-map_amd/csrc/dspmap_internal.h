@@ -57,6 +57,7 @@ struct dspmap {
     FrameParams hp = {};
     // HIP graph of the device-resident frame (dspmap_update_device)
     bool use_graph = true;
+    bool fut_clear_pending = false;   // clearOccupancyMapPrediction is lazy: done by the next frame's k_predict, or by the next reader
     hipStream_t stream2 = nullptr;   // fork/join branch inside the captured frame
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipGraph_t graph = nullptr;
@@ -84,7 +85,8 @@ LaunchCtx dspmap_ctx_of(dspmap* m);
 int dspmap_gate_and_delta(dspmap* m, const float pos[3], double stamp, const float q[4], float dp[3], float* dt);
 void dspmap_freeze_birth_statics(dspmap* m);
 int dspmap_ensure_point_cap(dspmap* m, int n);
-int dspmap_push_frame_params(dspmap* m);   // m->hp -> device
+int dspmap_push_frame_params(dspmap* m);
+void dspmap_flush_future_clear(dspmap* m);   // m->hp -> device
 
 #define HIPCHK(m, call)                                                                            \
     do {                                                                                           \

@@ -142,6 +142,13 @@ __global__ void __launch_bounds__(NW * 64) k_predict(MapDims d, DevState s, Filt
     const int l = lane_id();
     const int wave = tid >> 6;
     const int lv = blockIdx.x * 64 + l;   // all four waves of the block look at the same tile
+    if (s.fpar->clear_fut) {
+        // clearOccupancyMapPrediction (:431-438) was requested since the last frame: this tile's share of the
+        // future accumulators is zeroed here instead of by two extra memset launches per frame
+        const int v0 = blockIdx.x * 64, nv = min(64, d.v_loc - v0);
+        for (int i = tid; i < nv * d.T; i += NW * 64) s.fut[(size_t)v0 * d.T + i] = 0.f;
+        if (tid < nv) s.fut_stat[v0 + tid] = 0.f;
+    }
     const bool inr = lv < d.v_loc;
     const int lvs = inr ? lv : 0;
     u64 mword[MW], live[MW];

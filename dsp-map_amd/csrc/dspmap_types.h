@@ -92,7 +92,7 @@ struct FrameParams {
     int n_pts;          // points in `pts`
     int n_birth;        // entries in `birth`
     int static_birth;   // 1: k_obs_points writes the birth cloud (every in-FOV point a static source)
-    int pad;
+    int clear_fut;      // 1: k_predict zeroes the future accumulators first (a clearOccupancyMapPrediction is pending)
     const float* pts;   // n_pts x 3, sensor frame
     struct BirthSrc* birth;
 };

@@ -569,6 +569,36 @@ def test_rollout_ten_horizons_moving_particles(dsp, orc):
     o.close(); m.close()
 
 
+def test_lazy_future_clear_semantics(dsp, orc):
+    """clearOccupancyMapPrediction (:431-438) is carried out lazily (by the next frame's k_predict or before
+    the next read): accumulate-until-cleared must look exactly like the reference's eager clear"""
+    cfgkw = dict(nx=30, ny=30, nz=16, ppv=10)
+    o, m = make_pair(dsp, orc, **cfgkw)
+    o.L.dspo_use_velocity_estimator(o.h, 2)
+    base = common.wall_cloud(5, n_side=30, dist=1.6, half_w=1.2, half_h=0.7)
+    q = (1.0, 0.0, 0.0, 0.0)
+    # frames 0,1 without clearing: accumulators hold the sum of both frames (+= :961)
+    for f in range(2):
+        assert m.update(base, (0.01 * f, 0, 0), f / 30.0, q) == 1
+        assert o.update(base, (0.01 * f, 0, 0), f / 30.0, q) == 1
+    acc2 = o.results[:, 4:].astype(np.float64).sum()
+    m.clearOccupancyMapPrediction(); o.L.dspo_clear_future(o.h)
+    # cleared, nothing new accumulated: a read sees zeros (the lazy clear is flushed by the reader)
+    assert np.count_nonzero(m.getFutureStatus()) == 0
+    # clear pending -> next frame accumulates from zero
+    m.clearOccupancyMapPrediction()
+    assert m.update(base, (0.02, 0, 0), 2 / 30.0, q) == 1
+    assert o.update(base, (0.02, 0, 0), 2 / 30.0, q) == 1
+    one = o.results[:, 4:].astype(np.float64).sum()
+    got = m.getFutureStatus().astype(np.float64).sum()
+    assert one > 0 and abs(got - one) < 2e-3 * one and got < 0.8 * (acc2 + one)   # not added on top of the old sum
+    # the getter cleared again (:420-424); a stage call after it must not be wiped by the pending clear
+    m.occupancy_resample(); o.occupancy_resample()
+    again = m.getFutureStatus().astype(np.float64).sum()
+    assert abs(again - o.results[:, 4:].astype(np.float64).sum()) < 2e-3 * one and again > 0
+    o.close(); m.close()
+
+
 def test_graph_replay_with_foreign_kernels_between_frames(dsp):
     """regression: a memset node inside the captured frame graph faulted as soon as another stream ran
     kernels between two replays (large map, ~6 frames).  The frame graph now holds kernel nodes only."""
