@@ -593,6 +593,7 @@ def test_lazy_future_clear_semantics(dsp, orc):
     got = m.getFutureStatus().astype(np.float64).sum()
     assert one > 0 and abs(got - one) < 2e-3 * one and got < 0.8 * (acc2 + one)   # not added on top of the old sum
     # the getter cleared again (:420-424); a stage call after it must not be wiped by the pending clear
+    o.L.dspo_clear_future(o.h)
     m.occupancy_resample(); o.occupancy_resample()
     again = m.getFutureStatus().astype(np.float64).sum()
     assert abs(again - o.results[:, 4:].astype(np.float64).sum()) < 2e-3 * one and again > 0
