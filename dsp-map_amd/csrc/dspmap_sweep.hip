@@ -41,6 +41,7 @@ __device__ __forceinline__ u64 valid_bits(const MapDims& d, int e) {
 // consumed, so a wave pays one memory round trip per batch instead of one per row
 #define RB 2
 #define TB 2      // records per thread and step in the tails of k_predict / k_place
+#define HIST_NP 1024   // pyramids up to which k_predict ranks its stayers with an LDS histogram
 #define LSTG 224  // records of each kind a workgroup of k_predict notes in LDS before spilling to HBM
 
 // Deferred wave-aggregated append of up to N items per lane into counted lists
@@ -137,6 +138,7 @@ __global__ void __launch_bounds__(NW * 64) k_predict(MapDims d, DevState s, Filt
     // the first LSTG movers / stayers of the tile are noted in LDS (free: registers, not LDS, bound the
     // occupancy of this kernel), the rest in the tile's staging area in HBM
     __shared__ float4 s_mv[LSTG * 2], s_st[LSTG * 2];
+    __shared__ int s_hist[HIST_NP];   // stayers per pyramid of this tile, then the base of the tile's run in each list
     const float odx = s.fpar->od[0], ody = s.fpar->od[1], odz = s.fpar->od[2], dt = s.fpar->dt;
     const int tid = threadIdx.x;
     const int l = lane_id();
@@ -163,6 +165,7 @@ __global__ void __launch_bounds__(NW * 64) k_predict(MapDims d, DevState s, Filt
     }
     if (tid == 0) { s_any = 0; s_nmv = 0; s_nst = 0; }
     if (tid < 4) s_cnt[tid] = 0;
+    if (d.np <= HIST_NP) for (int b = tid; b < d.np; b += NW * 64) s_hist[b] = 0;
     __syncthreads();
     if (wave == 0 && __ballot(any) && l == 0) s_any = 1;
     __syncthreads();
@@ -277,6 +280,37 @@ __global__ void __launch_bounds__(NW * 64) k_predict(MapDims d, DevState s, Filt
         if (i < LSTG) { a = s_mv[i * 2]; b = s_mv[i * 2 + 1]; }
         else { a = mv_rec[(mv_base + i) * 2]; b = mv_rec[(mv_base + i) * 2 + 1]; }
     };
+    if (d.np <= HIST_NP) {
+        // rank every stayer inside its pyramid's run with an LDS atomic, reserve the runs with ONE global atomic per
+        // non-empty pyramid (all in flight together), then place the records: one memory round trip per tile
+        for (int i = tid; i < nst; i += NW * 64) {
+            const int pyr = __float_as_int(i < LSTG ? s_st[i * 2].x : mv_rec[(mv_base + cap - 1 - i) * 2].x);
+            const float r = __int_as_float(atomicAdd(&s_hist[pyr], 1));
+            if (i < LSTG) s_st[i * 2 + 1].z = r;
+            else reinterpret_cast<float*>(&mv_rec[(mv_base + cap - 1 - i) * 2 + 1])[2] = r;
+        }
+        __syncthreads();
+        for (int b = tid; b < d.np; b += NW * 64) {
+            const int c = s_hist[b];
+            if (c) s_hist[b] = atomicAdd(&s.pyr_cnt[b], c);
+        }
+        __syncthreads();
+        for (int i = tid; i < nst; i += NW * 64) {
+            float4 a, b;
+            st_rec(i, a, b);
+            const int pyr = __float_as_int(a.x), sl = __float_as_int(a.y);   // sl = (slot << 6) | lane
+            const int pos = s_hist[pyr] + __float_as_int(b.z);
+            if (pos < d.capp) {
+                const size_t o = (size_t)pyr * d.capp + pos;
+                s.fov_rec[o] = make_float4(a.z, a.w, b.x, b.y);
+                s.fov_slot[o] = (int)(((size_t)blockIdx.x * d.slots + (sl >> 6)) * 64 + (sl & 63));
+            } else {
+                // pyramid list full: the particle vanishes (-2, :1256-1259)
+                atomicAnd(&s_keep[((sl >> 12) & 1) * 64 + (sl & 63)], ~(1ull << ((sl >> 6) & 63)));
+                ++c_pf;
+            }
+        }
+    } else
     for (int i0 = 0; i0 < nst; i0 += NW * 64 * TB) {
         int key[TB], pos[TB];
 #pragma unroll
