@@ -41,6 +41,7 @@ __device__ __forceinline__ u64 valid_bits(const MapDims& d, int e) {
 // consumed, so a wave pays one memory round trip per batch instead of one per row
 #define RB 2
 #define TB 2      // records per thread and step in the tails of k_predict / k_place
+#define DENSE_MAX 4096  // live cells up to which k_predict may take the dense-lane path
 #define HIST_NP 1024   // pyramids up to which k_predict ranks its stayers with an LDS histogram
 #define LSTG 224  // records of each kind a workgroup of k_predict notes in LDS before spilling to HBM
 
@@ -125,6 +126,22 @@ __device__ __forceinline__ u64 rows_of_wave(u64 tor, int wave) {
 //   advanced exactly once (the role of flag 7, :649,1219).
 // part[blockIdx*4 + {0,1,2,3}] = {live in, left the map, pyramid full, moved}
 // --------------------------------------------------------------------------
+// one particle of mapPrediction: advance (:665-667, vz forced to 0 :662), classify.
+// returns 0 = left the map (:688), 1 = stays in its voxel (pyr = its pyramid or -1), 2 = changed voxel (gv = the
+// new global voxel), 3 = left this rank's slab (multi-GPU)
+__device__ __forceinline__ int advance_one(const MapDims& d, const float* s_ph, const float* s_pv, float dt, float odx, float ody,
+                                           float odz, float vx, float vy, float& px, float& py, float& pz, int lvp, int& pyr, int& gv) {
+    px += dt * vx + odx;   // :665
+    py += dt * vy + ody;   // :666
+    pz += dt * 0.f + odz;  // :667
+    pyr = -1;
+    if (!voxel_of(d, px, py, pz, gv)) return 0;
+    const int nlv = gv - d.v_base;
+    if (nlv == lvp) { pyr = pyramid_of(d, s_ph, s_pv, px, py, pz); return 1; }
+    if (nlv < 0 || nlv >= d.v_loc) return 3;
+    return 2;
+}
+
 template <int MW, int NW>
 __global__ void __launch_bounds__(NW * 64) k_predict(MapDims d, DevState s, FilterParams fp, int has_vz, int* __restrict__ part,
                                                  float4* __restrict__ mv_rec, float4* __restrict__ in_rec, int* __restrict__ in_cnt,
@@ -139,6 +156,8 @@ __global__ void __launch_bounds__(NW * 64) k_predict(MapDims d, DevState s, Filt
     // occupancy of this kernel), the rest in the tile's staging area in HBM
     __shared__ float4 s_mv[LSTG * 2], s_st[LSTG * 2];
     __shared__ int s_hist[HIST_NP];   // stayers per pyramid of this tile, then the base of the tile's run in each list
+    __shared__ unsigned short s_cells[DENSE_MAX];   // sparse tiles: compact list of live cells ((slot << 6) | lane)
+    __shared__ int s_ncell;
     const float odx = s.fpar->od[0], ody = s.fpar->od[1], odz = s.fpar->od[2], dt = s.fpar->dt;
     const int tid = threadIdx.x;
     const int l = lane_id();
@@ -163,22 +182,83 @@ __global__ void __launch_bounds__(NW * 64) k_predict(MapDims d, DevState s, Filt
         any |= live[e] != 0ull;
         if (wave == 0) { s_keep[e * 64 + l] = live[e]; s_ex[e * 64 + l] = 0ull; }
     }
-    if (tid == 0) { s_any = 0; s_nmv = 0; s_nst = 0; }
+    if (tid == 0) { s_any = 0; s_nmv = 0; s_nst = 0; s_ncell = 0; }
     if (tid < 4) s_cnt[tid] = 0;
     if (d.np <= HIST_NP) for (int b = tid; b < d.np; b += NW * 64) s_hist[b] = 0;
     __syncthreads();
-    if (wave == 0 && __ballot(any) && l == 0) s_any = 1;
+    if (wave == 0 && __ballot(any)) {
+        // sparse tile (few live cells per live row): the heavy per-particle work runs on DENSE lanes over a compact
+        // cell list instead of row by row with mostly idle lanes -- what a realistic map (particles near surfaces
+        // only) consists of; saturated tiles keep the coalesced row sweep
+        int cl = 0, nrows = 0;
+#pragma unroll
+        for (int e = 0; e < MW; ++e) { cl += (int)__popcll(live[e]); nrows += (int)__popcll(wave_or_u64(live[e])); }
+        const int nlive = wave_sum_i(cl);
+        if (l == 0) s_any = (!has_vz && nlive <= DENSE_MAX && nlive * 5 < nrows * 64 * 3) ? 2 : 1;
+    }
     __syncthreads();
     if (!s_any) {  // empty tile
         if (tid < 4) part[blockIdx.x * 4 + tid] = 0;
         return;
     }
+    const bool dense = s_any == 2;
     const int cap = 64 * d.slots;                       // records per staging area / inbox
     const size_t mv_base = (size_t)blockIdx.x * cap;    // this tile's staging area (2 float4 per record)
     for (int i = tid; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
     for (int i = tid; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
     __syncthreads();
     int c_live = 0, c_out = 0, c_pf = 0, c_mv = 0;
+    if (dense) {
+        // cell list: every wave compacts its share of the live rows
+#pragma unroll
+        for (int e = 0; e < MW; ++e) {
+            u64 tor = rows_of_wave<NW>(wave_or_u64(live[e]), wave);
+            while (tor) {
+                const int row = __ffsll((long long)tor) - 1;
+                tor &= tor - 1ull;
+                const bool on = (live[e] >> row) & 1ull;
+                const int k = lds_agg_inc(&s_ncell, on);
+                if (on) s_cells[k] = (unsigned short)(((e * 64 + row) << 6) | l);
+            }
+        }
+        __syncthreads();
+        const int ncell = s_ncell;
+        for (int c0 = 0; c0 < ncell; c0 += NW * 64) {
+            const int c = c0 + tid;
+            const bool act = c < ncell;
+            const int cell = act ? (int)s_cells[c] : 0;
+            const int slot = cell >> 6, ln = cell & 63;
+            const unsigned idx = (unsigned)pidx(d, blockIdx.x * 64 + (act ? ln : l), act ? slot : 0);
+            const V2 v2 = ld_vel(s, idx);
+            const P3 p3 = ld_pos(s, idx);
+            const float w = s.w[idx];
+            float px = p3.x, py = p3.y, pz = p3.z;
+            int pyr = -1, gv = -1, kind = -1;
+            if (act) {
+                kind = advance_one(d, s_ph, s_pv, dt, odx, ody, odz, v2.x, v2.y, px, py, pz, blockIdx.x * 64 + ln, pyr, gv);
+                ++c_live;
+                const u64 bit = 1ull << (slot & 63);
+                if (kind != 0) st_pos(s, idx, px, py, pz);
+                if (kind == 0) { ++c_out; atomicAnd(&s_keep[(slot >> 6) * 64 + ln], ~bit); }
+                else if (kind == 2) { ++c_mv; atomicAnd(&s_keep[(slot >> 6) * 64 + ln], ~bit); }
+                else if (kind == 3) atomicOr(&s_ex[(slot >> 6) * 64 + ln], bit);
+            }
+            const int ks = lds_agg_inc(&s_nst, kind == 1 && pyr >= 0);
+            if (ks >= 0) {
+                const float4 a = make_float4(__int_as_float(pyr), __int_as_float(cell), px, py);
+                const float4 b = make_float4(pz, w, 0.f, 0.f);
+                if (ks < LSTG) { s_st[ks * 2] = a; s_st[ks * 2 + 1] = b; }
+                else { const size_t o = (mv_base + cap - 1 - ks) * 2; mv_rec[o] = a; mv_rec[o + 1] = b; }
+            }
+            const int km = lds_agg_inc(&s_nmv, kind == 2);
+            if (km >= 0) {
+                const float4 a = make_float4(__int_as_float(gv), v2.x, v2.y, px);
+                const float4 b = make_float4(py, pz, w, 0.f);
+                if (km < LSTG) { s_mv[km * 2] = a; s_mv[km * 2 + 1] = b; }
+                else { const size_t o = (mv_base + km) * 2; mv_rec[o] = a; mv_rec[o + 1] = b; }
+            }
+        }
+    } else
 #pragma unroll
     for (int e = 0; e < MW; ++e) {
         u64 keep_clr = 0ull, ex = 0ull;
@@ -223,25 +303,13 @@ __global__ void __launch_bounds__(NW * 64) k_predict(MapDims d, DevState s, Filt
                         }
                         s.vz0[idx[r]] = 0.f;
                     }
-                    px[r] += dt * vx[r] + odx;   // :665
-                    py[r] += dt * vy[r] + ody;   // :666
-                    pz[r] += dt * 0.f + odz;     // :667 with vz forced to 0 (:662)
                     int gv;
                     ++c_live;
-                    if (!voxel_of(d, px[r], py[r], pz[r], gv)) {
-                        keep_clr |= bit;         // left the map :688
-                        ++c_out;
-                    } else {
-                        st_pos(s, idx[r], px[r], py[r], pz[r]);
-                        const int nlv = gv - d.v_base;
-                        if (nlv == lv) pyr[r] = pyramid_of(d, s_ph, s_pv, px[r], py[r], pz[r]);
-                        else if (nlv < 0 || nlv >= d.v_loc) ex |= bit;   // left the slab (multi-GPU)
-                        else {
-                            mgv[r] = gv;         // voxel changed: the slot is freed now, the record travels
-                            keep_clr |= bit;
-                            ++c_mv;
-                        }
-                    }
+                    const int kind = advance_one(d, s_ph, s_pv, dt, odx, ody, odz, vx[r], vy[r], px[r], py[r], pz[r], lv, pyr[r], gv);
+                    if (kind != 0) st_pos(s, idx[r], px[r], py[r], pz[r]);
+                    if (kind == 0) { keep_clr |= bit; ++c_out; }            // left the map :688
+                    else if (kind == 3) ex |= bit;                          // left the slab (multi-GPU)
+                    else if (kind == 2) { mgv[r] = gv; keep_clr |= bit; ++c_mv; }   // voxel changed: the slot is freed now, the record travels
                 }
             }
             // note stayers that need a pyramid entry (top of the staging area, downwards) and movers (bottom, upwards)
