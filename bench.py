@@ -297,6 +297,31 @@ def main():
         except Exception as e:
             result["rollout_D_132x132x60_T10"] = {"error": repr(e)}
 
+    # ------------------------------------------------------------------ next row: the caller's pre-processing on the device
+    if rank == 0 and not sharded_run and not args.no_extra and wl_name == "B":
+        try:
+            mp = make_map(wl)
+            sc = scene_mod.CorridorScene(wl["nx"] * wl["res"], wl["ny"] * wl["res"], wl["nz"] * wl["res"], seed=1234, device=dev)
+            raws = [sc.raw(f / 30.0)[0] for f in range(8)]
+            outb = torch.zeros((5000, 3), dtype=torch.float32, device=dev)
+            for r in raws[:2]:
+                mp.preprocess_cloud(r.data_ptr(), r.shape[0], outb.data_ptr(), 5000, leaf=0.1, swap_axes=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps, kept = 0, 0
+            for _ in range(10):
+                for r in raws:
+                    kept, _ = mp.preprocess_cloud(r.data_ptr(), r.shape[0], outb.data_ptr(), 5000, leaf=0.1, swap_axes=False)
+                    reps += 1
+            dtp = (time.perf_counter() - t0) / reps
+            result["preprocess_640x480"] = {
+                "what": "dspmap_preprocess_cloud: 0.1 m voxel-grid centroid filter + crop + cap on the device "
+                        "(src/map_sim_example.cpp:309-336), synchronous call incl. two small D2H reads",
+                "points_in": int(raws[0].shape[0]), "points_out": int(kept), "ms_per_cloud": round(dtp * 1e3, 4)}
+            mp.close()
+        except Exception as e:
+            result["preprocess_640x480"] = {"error": repr(e)}
+
     # ------------------------------------------------------------------ strong-scaling origin: config E on ONE GPU, unsharded
     if rank == 0 and not args.no_extra and (wl_name == "B" or sharded_run) and os.environ.get("DSPMAP_BENCH_ORIGIN", "1") == "1":
         try:

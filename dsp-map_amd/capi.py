@@ -93,6 +93,7 @@ SIGNATURES = {
     "dspmap_clear_state": (_i, [_P]),
     "dspmap_import_state": (_i, [_P, _i, _P, _P, _P]),
     "dspmap_export_state": (_i, [_P, _i, _P, _P, _P, _ip]),
+    "dspmap_preprocess_cloud": (_i, [_P, _i, _P, _i, _f, _i, _i, _P, _ip, _ip]),
     "dspmap_add_random_particles": (_i, [_P, _i, _f]),
     "dspmap_seed_uniform_moving": (_i, [_P, _i, _f, C.c_uint, _f]),
     "dspmap_seed_uniform": (_i, [_P, _i, _f, C.c_uint]),
@@ -350,6 +351,14 @@ class DSPMap:
             self._chk(self.L.dspmap_export_state(self.h, cap, _ptr(voxel), _ptr(slot), _ptr(rec), C.byref(n)))
         order = np.lexsort((slot, voxel))
         return voxel[order], slot[order], rec[order]
+
+    def preprocess_cloud(self, points_ptr, n, out_ptr, max_points, leaf=0.1, swap_axes=True, stride=3):
+        """voxel-grid filter + axis swap + crop + cap on the device (src/map_sim_example.cpp:309-336);
+        returns (points written to out_ptr, occupied leaves touching the map box)"""
+        n_out, n_leaves = C.c_int(), C.c_int()
+        self._chk(self.L.dspmap_preprocess_cloud(self.h, n, points_ptr, stride, leaf, 1 if swap_axes else 0, max_points,
+                                                 out_ptr, C.byref(n_out), C.byref(n_leaves)))
+        return n_out.value, n_leaves.value
 
     def seed_uniform(self, per_voxel, weight=0.01, seed=99, vmax=0.0):
         self._chk(self.L.dspmap_seed_uniform_moving(self.h, per_voxel, weight, seed, vmax))

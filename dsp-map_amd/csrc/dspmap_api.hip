@@ -134,6 +134,9 @@ static void free_dev(dspmap* m) {
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.in_rec, m->k.in_cnt, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.expmask,
                     m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.work_count, m->k.child, m->k.part_birth, m->pts_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (m->pp_box) (void)hipFree(m->pp_box);
+    if (m->pp_acc) (void)hipFree(m->pp_acc);
+    if (m->pp_blk) (void)hipFree(m->pp_blk);
     if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
     if (m->graph) (void)hipGraphDestroy(m->graph);
     if (m->pts_pin) (void)hipHostFree(m->pts_pin);

@@ -70,6 +70,11 @@ struct dspmap {
     int* mgpu_count = nullptr;
     BirthSrc* mgpu_birth = nullptr;
     int last_exp[2] = {0, 0};   // particles exported down / up in the last frame
+    // cloud pre-processing scratch (dspmap_preprocess.hip)
+    void* pp_box = nullptr;
+    void* pp_acc = nullptr;
+    int* pp_blk = nullptr;
+    size_t pp_cells_cap = 0;
     // per-stage profiling
     bool prof = false;
     hipEvent_t pev[DSPMAP_N_STAGES + 1] = {};

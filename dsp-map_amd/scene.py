@@ -114,12 +114,17 @@ class CorridorScene:
                 upd(tt, ok & (zz > 0) & (zz < self.ped_h))
         return best, pos, quat
 
-    def frame(self, t):
-        """-> (points (n,3) float32 on self.dev in the SENSOR frame, pos, quat)"""
+    def raw(self, t):
+        """-> (back-projected cloud (n,3) float32 in the SENSOR frame, before any filtering; pos, quat)"""
         depth, pos, quat = self._depth(t)
         ok = torch.isfinite(depth)
         noise = 1.0 + 0.01 * torch.randn(depth.shape, device=self.dev, generator=self.gen)
         p = self.dir_body[ok] * (depth[ok] * noise[ok]).unsqueeze(1)
+        return p.contiguous().float(), pos, quat
+
+    def frame(self, t):
+        """-> (points (n,3) float32 on self.dev in the SENSOR frame, pos, quat)"""
+        p, pos, quat = self.raw(t)
         # voxel-grid centroid filter (pcl::VoxelGrid, src/map_sim_example.cpp:313-317)
         cellf = torch.floor(p / self.voxel_filter).to(torch.int64)
         cellf = cellf - cellf.min(0).values

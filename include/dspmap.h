@@ -199,6 +199,18 @@ int dspmap_debug_stream(dspmap_t* m, int mode, long long* bytes_out);
 int dspmap_clear_state(dspmap_t* m);
 int dspmap_import_state(dspmap_t* m, int n, const int* voxel_host, const int* slot_host, const float* rec8_host);
 int dspmap_export_state(dspmap_t* m, int cap, int* voxel_out_host, int* slot_out_host, float* rec8_out_host, int* n_out);
+/* ---- caller-side pre-processing on the device (next to the hot path; reference src/map_sim_example.cpp:309-336)
+ * points_dev: n points, xyz first, stride_floats floats apart, device memory, in the frame the sensor driver
+ * delivers (swap_axes = 1: camera optical frame, mapped x = z, y = -x, z = -y like :321-323; 0: already x forward).
+ * Voxel-grid centroid filter with leaf size `leaf` (pcl::VoxelGrid, :313-317), crop to the open map box (:325),
+ * at most max_points points in the filter's output order (:332) -> out_dev (max_points x 3 floats, device memory,
+ * ready for dspmap_update_device).  *n_out = points written, *n_leaves_out (optional) = occupied leaves that touch
+ * the map box.  Non-finite points are ignored (PCL does the same for non-dense clouds).  Only leaves touching the
+ * map box are accumulated (the others cannot survive the crop), so the cost does not depend on far returns;
+ * refuses leaf sizes that put more than 2^27 leaves into the map box. */
+int dspmap_preprocess_cloud(dspmap_t* m, int n, const float* points_dev, int stride_floats, float leaf, int swap_axes,
+                            int max_points, float* out_dev, int* n_out, int* n_leaves_out);
+
 /* addRandomParticles :594-624 (constructor pre-fill); uses the rand table */
 int dspmap_add_random_particles(dspmap_t* m, int n, float weight);
 /* benchmark fill: every voxel gets `per_voxel` zero-velocity particles,

@@ -11,6 +11,7 @@
 #define _GNU_SOURCE
 #include "dsp_oracle.h"
 
+#include <float.h>
 #include <limits.h>
 #include <math.h>
 #include <stdio.h>
@@ -1073,4 +1074,85 @@ int dspo_update(dsp_oracle* o, int n_pts, int stride, const float* pts, float sx
     if (n_pts >= 0) dspo_add_newborn(o);       /* :314-316 */
     dspo_occupancy_resample(o);                /* :322 */
     return 1;
+}
+
+/* ==========================================================================
+ * Caller-side pre-processing, src/map_sim_example.cpp:309-336.
+ *
+ * pcl::VoxelGrid is third-party code that is not under /root/reference (PCL, version unpinned by the
+ * reference: readme.md:21-24).  Its published algorithm (pcl/filters/impl/voxel_grid.hpp; the arithmetic
+ * below is the same in PCL 1.8 ... 1.12) is restated: bounding box of the finite points -> leaf lattice ->
+ * (leaf index, point) pairs -> sort by leaf index -> one centroid per leaf in ascending leaf order.
+ * std::sort leaves the order of equal keys unspecified; this restatement breaks ties by point index.
+ * PARITY UNPINNED for this function: PCL is absent from the image and the reference has no fixture for it.
+ * ========================================================================== */
+typedef struct { int idx; int pt; } dspo_leaf_pair;
+static int dspo_leaf_cmp(const void* a, const void* b) {
+    const dspo_leaf_pair* x = (const dspo_leaf_pair*)a;
+    const dspo_leaf_pair* y = (const dspo_leaf_pair*)b;
+    if (x->idx != y->idx) return x->idx < y->idx ? -1 : 1;
+    return x->pt < y->pt ? -1 : (x->pt > y->pt ? 1 : 0);
+}
+
+int dspo_preprocess_cloud(int n, const float* pts, int stride, float leaf, int swap_axes, float hx, float hy, float hz,
+                          int max_points, float* out, int* n_leaves) {
+    if (n_leaves) *n_leaves = 0;
+    if (n <= 0) return 0;
+    /* getMinMax3D over the finite points */
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    int nfin = 0;
+    for (int i = 0; i < n; i++) {
+        const float* p = pts + (size_t)i * stride;
+        if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+        for (int a = 0; a < 3; a++) { if (p[a] < mn[a]) mn[a] = p[a]; if (p[a] > mx[a]) mx[a] = p[a]; }
+        nfin++;
+    }
+    if (!nfin) return 0;
+    const float inv = 1.0f / leaf;                     /* inverse_leaf_size_ */
+    int min_b[3], div_b[3];
+    for (int a = 0; a < 3; a++) {
+        min_b[a] = (int)floorf(mn[a] * inv);
+        div_b[a] = (int)floorf(mx[a] * inv) - min_b[a] + 1;
+    }
+    const int mul[3] = {1, div_b[0], div_b[0] * div_b[1]};   /* divb_mul_ */
+    dspo_leaf_pair* iv = (dspo_leaf_pair*)malloc(sizeof(dspo_leaf_pair) * (size_t)nfin);
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        const float* p = pts + (size_t)i * stride;
+        if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+        const int ijk0 = (int)(floorf(p[0] * inv) - (float)min_b[0]);
+        const int ijk1 = (int)(floorf(p[1] * inv) - (float)min_b[1]);
+        const int ijk2 = (int)(floorf(p[2] * inv) - (float)min_b[2]);
+        iv[m].idx = ijk0 * mul[0] + ijk1 * mul[1] + ijk2 * mul[2];
+        iv[m].pt = i;
+        m++;
+    }
+    qsort(iv, (size_t)m, sizeof(dspo_leaf_pair), dspo_leaf_cmp);
+    int written = 0, leaves = 0;
+    int first = 0;
+    while (first < m) {
+        int last = first + 1;
+        while (last < m && iv[last].idx == iv[first].idx) last++;
+        float c[3] = {0.f, 0.f, 0.f};                   /* centroid += point; centroid /= count */
+        for (int k = first; k < last; k++) {
+            const float* p = pts + (size_t)iv[k].pt * stride;
+            c[0] += p[0]; c[1] += p[1]; c[2] += p[2];
+        }
+        const float cnt = (float)(last - first);
+        c[0] /= cnt; c[1] /= cnt; c[2] /= cnt;
+        leaves++;
+        /* cloudCallback :319-336: axis swap, open-interval crop (inRange :190-197), stop when the buffer is full */
+        if (written < max_points) {
+            float x, y, z;
+            if (swap_axes) { x = c[2]; y = -c[0]; z = -c[1]; } else { x = c[0]; y = c[1]; z = c[2]; }
+            if (x > -hx && x < hx && y > -hy && y < hy && z > -hz && z < hz) {
+                out[3 * written] = x; out[3 * written + 1] = y; out[3 * written + 2] = z;
+                written++;
+            }
+        }
+        first = last;
+    }
+    free(iv);
+    if (n_leaves) *n_leaves = leaves;
+    return written;
 }

@@ -145,6 +145,11 @@ void dspo_set_expected_newborn(dsp_oracle* o, float v);
 float dspo_update_time(const dsp_oracle* o);
 int dspo_count_live(const dsp_oracle* o);
 
+/* ---- caller-side pre-processing (src/map_sim_example.cpp:309-336; pcl::VoxelGrid restated, parity unpinned) ----
+ * returns the number of points written to out (<= max_points); *n_leaves = occupied leaves before the crop */
+int dspo_preprocess_cloud(int n, const float* pts, int stride, float leaf, int swap_axes, float hx, float hy, float hz,
+                          int max_points, float* out, int* n_leaves);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,6 +99,7 @@ def _load(fast=False):
         "dspo_expected_newborn": (f, [P]), "dspo_set_expected_newborn": (None, [P, f]),
         "dspo_update_time": (f, [P]), "dspo_count_live": (i, [P]),
         "dspo_fill_gaussian_tables": (None, [P, P, i, f, f, C.c_uint]),
+        "dspo_preprocess_cloud": (i, [i, P, i, f, i, f, f, f, i, P, ip]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -114,6 +115,17 @@ def lib(fast=False):
     if fast not in _LIBS:
         _LIBS[fast] = _load(fast)
     return _LIBS[fast]
+
+
+def preprocess_cloud(pts, leaf, half, max_points=5000, swap_axes=True):
+    """cloudCallback's pre-processing (src/map_sim_example.cpp:309-336): -> (points (n,3), occupied leaves)"""
+    pts = np.ascontiguousarray(pts, np.float32)
+    out = np.zeros((max_points, 3), np.float32)
+    nl = C.c_int()
+    n = lib().dspo_preprocess_cloud(pts.shape[0], pts.ctypes.data_as(C.c_void_p), pts.shape[1], float(leaf), 1 if swap_axes else 0,
+                                    float(half[0]), float(half[1]), float(half[2]), max_points,
+                                    out.ctypes.data_as(C.c_void_p), C.byref(nl))
+    return out[:n].copy(), nl.value
 
 
 def make_config(nx=66, ny=66, nz=40, res=0.15, ppv=9, angle=3, half_fov_h=42, half_fov_v=24,

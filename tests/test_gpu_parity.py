@@ -600,6 +600,44 @@ def test_lazy_future_clear_semantics(dsp, orc):
     o.close(); m.close()
 
 
+def test_preprocess_cloud_against_oracle(dsp, orc):
+    """dspmap_preprocess_cloud (voxel-grid centroid filter, axis swap, crop, cap on the device) against the
+    oracle's restatement of src/map_sim_example.cpp:309-336: same leaves, same order, same count;
+    centroids within fp32 summation-order noise (1e-5 m)"""
+    import torch
+    m = dsp.DSPMap(dsp.make_config(nx=66, ny=66, nz=40, ppv=9))
+    half = common.half_extent(m.cfg)
+    rng = np.random.default_rng(21)
+    # a 640x480 "depth image" worth of camera-frame points: a wavy wall + clutter + non-finite pixels
+    u, v = np.meshgrid(np.linspace(-1, 1, 640, dtype=np.float32), np.linspace(-0.6, 0.6, 480, dtype=np.float32))
+    depth = (3.0 + 0.5 * np.sin(3 * u) + 0.2 * rng.standard_normal(u.shape)).astype(np.float32)
+    pts = np.stack([u * depth, v * depth, depth], -1).reshape(-1, 3).astype(np.float32)
+    pts[::53] = np.inf
+    pts[::101, 2] += 4000.0                    # far returns: outside the map box after the swap, huge bounding box
+    for cap in (5000, 100000):
+        ref, leaves_o = orc.preprocess_cloud(pts, 0.1, half, max_points=cap, swap_axes=True)
+        d_in = torch.from_numpy(pts).cuda()
+        d_out = torch.zeros((cap, 3), dtype=torch.float32, device="cuda")
+        n, leaves = m.preprocess_cloud(d_in.data_ptr(), pts.shape[0], d_out.data_ptr(), cap, leaf=0.1, swap_axes=True)
+        got = d_out[:n].cpu().numpy()
+        assert n == len(ref) and 0 < leaves <= leaves_o   # `leaves` counts only leaves touching the map box
+        assert np.allclose(got, ref, atol=1e-5)
+    # strided input, no axis swap, tiny cap, empty cloud
+    p5 = np.zeros((1000, 5), np.float32); p5[:, :3] = (rng.random((1000, 3), dtype=np.float32) - 0.5) * 3
+    ref, _ = orc.preprocess_cloud(p5, 0.25, half, max_points=7, swap_axes=False)
+    d_in = torch.from_numpy(p5).cuda(); d_out = torch.zeros((7, 3), device="cuda")
+    n, _ = m.preprocess_cloud(d_in.data_ptr(), 1000, d_out.data_ptr(), 7, leaf=0.25, swap_axes=False, stride=5)
+    assert n == 7 and np.allclose(d_out.cpu().numpy(), ref, atol=1e-5)
+    assert m.preprocess_cloud(None, 0, d_out.data_ptr(), 7) == (0, 0)
+    # the filtered cloud feeds update_device directly
+    d_in = torch.from_numpy(pts).cuda(); d_out = torch.zeros((5000, 3), device="cuda")
+    n, _ = m.preprocess_cloud(d_in.data_ptr(), pts.shape[0], d_out.data_ptr(), 5000)
+    assert m.update_device(d_out.data_ptr(), n, (0, 0, 0), 0.0, (1, 0, 0, 0)) == 1
+    m.sync()
+    assert m.counters()["n_obs"] > 100
+    m.close()
+
+
 def test_graph_replay_with_foreign_kernels_between_frames(dsp):
     """regression: a memset node inside the captured frame graph faulted as soon as another stream ran
     kernels between two replays (large map, ~6 frames).  The frame graph now holds kernel nodes only."""

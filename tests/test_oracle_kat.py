@@ -232,3 +232,37 @@ def test_golden_regression_vectors(orc):
     want = json.load(open(path))
     for k in want:
         assert np.allclose(got[k], want[k], rtol=2e-5, atol=1e-6), k
+
+
+def test_preprocess_voxel_grid_properties(orc):
+    """cloudCallback pre-processing (src/map_sim_example.cpp:309-336), pcl::VoxelGrid restated: every output is the
+    mean of the input points of one leaf, leaves come in ascending lattice order, crop is an open interval, the cap
+    keeps the first points of that order"""
+    rng = np.random.default_rng(3)
+    pts = (rng.random((20000, 3), dtype=np.float32) - 0.5) * np.array([8.0, 5.0, 9.0], np.float32)
+    pts[::97] = np.nan                                   # non-finite points are skipped
+    leaf, half = 0.1, (4.95, 4.95, 3.0)
+    out, leaves = orc.preprocess_cloud(pts, leaf, half, max_points=100000, swap_axes=True)
+    fin = pts[np.isfinite(pts).all(1)]
+    inv = np.float32(1.0) / np.float32(leaf)
+    ijk = np.floor(fin * inv).astype(np.int64)
+    ijk -= ijk.min(0)
+    dims = ijk.max(0) + 1
+    key = ijk[:, 0] + ijk[:, 1] * dims[0] + ijk[:, 2] * dims[0] * dims[1]
+    uniq, inv_idx = np.unique(key, return_inverse=True)
+    assert leaves == len(uniq)
+    cen = np.zeros((len(uniq), 3), np.float64)
+    np.add.at(cen, inv_idx, fin.astype(np.float64))
+    cen /= np.bincount(inv_idx)[:, None]
+    sw = np.stack([cen[:, 2], -cen[:, 0], -cen[:, 1]], 1)            # x = z, y = -x, z = -y (:321-323)
+    keep = (np.abs(sw) < np.array(half)).all(1)
+    assert len(out) == int(keep.sum())
+    assert np.allclose(out, sw[keep], atol=2e-6)                      # same leaves in the same (ascending) order
+    capped, _ = orc.preprocess_cloud(pts, leaf, half, max_points=500, swap_axes=True)
+    assert len(capped) == 500 and np.array_equal(capped, out[:500])   # :332 stops at the cap
+    empty, nl = orc.preprocess_cloud(np.zeros((0, 3), np.float32), leaf, half)
+    assert len(empty) == 0 and nl == 0
+    # a point exactly on the box face is outside (inRange uses > and <, :190-197)
+    face = np.array([[0.0, 0.0, 4.95]], np.float32)                   # z_cam -> x = 4.95 = x_max
+    o2, _ = orc.preprocess_cloud(face, leaf, half, swap_axes=True)
+    assert len(o2) == 0
