@@ -128,6 +128,14 @@ def load_library(path=None):
         raise FileNotFoundError(
             "%s not found: build it with `python dsp-map_amd/build_ext.py` (hipcc, gfx950). "
             "There is no CPU fallback." % p)
+    # Load order matters in a process that also uses PyTorch-ROCm: torch ships its own copy of the HIP / HSA
+    # runtime, and the copy that is initialised first owns the device; a second one then reports "no device".
+    # Import torch (when it is installed) BEFORE this library so that both share torch's runtime, whatever
+    # order the caller imports things in.  A process without torch is unaffected.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # noqa: BLE001
+        pass
     lib = C.CDLL(p)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

@@ -234,8 +234,10 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     if (!m) return DSPMAP_E_ARG;
     if (m->device_ready) return DSPMAP_OK;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return dspmap_fail(m, DSPMAP_E_DEVICE, "no HIP device available (libdspmap_hip has no CPU fallback)");
+    const hipError_t e_cnt = hipGetDeviceCount(&ndev);
+    if (e_cnt != hipSuccess || ndev <= 0)
+        return dspmap_fail(m, DSPMAP_E_DEVICE, "no HIP device available (hipGetDeviceCount: %s, %d devices; libdspmap_hip has no CPU fallback)",
+                           hipGetErrorString(e_cnt), ndev);
     if (m->device >= 0) HIPCHK(m, hipSetDevice(m->device));
     else HIPCHK(m, hipGetDevice(&m->device));
     if (!m->stream) { HIPCHK(m, hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
