@@ -154,22 +154,27 @@ __device__ __forceinline__ bool voxel_of(const MapDims& d, float px, float py, f
 // multiply plus one FMA residual correction (q = d*y; r = fma(-q,sigma,d);
 // q' = fma(r,y,q)), which returns the correctly rounded quotient (Markstein),
 // i.e. the same quantisation bin as the reference, for 3 VALU ops instead of ~10.
-__device__ __forceinline__ float axis_t(float a, float mu, float sigma, float inv_sigma) {
+// axis_u returns the LUT index relative to the table centre as a float, u = i - 10000 with
+// i = (int)(z*1000 + 10000) (:1296-1299).  z*1000 + 10000 is positive after the clamp, so the truncation is a
+// floor (one v_floor instead of two conversions) and the clamp is one v_med3.  The axis factor is
+// c * exp(-t^2/2) with t = u * 0.001; pair_gk sums the three u^2 (integers up to 9.8e7, fp32-exact to 6e-8
+// relative) and folds 0.001^2 / 2 and log2(e) into the single exp2: ~30 VALU operations per pair.
+__device__ __forceinline__ float axis_u(float a, float mu, float sigma, float inv_sigma) {
     const float dlt = a - mu;
     const float q0 = dlt * inv_sigma;
     const float rr = __fmaf_rn(-q0, sigma, dlt);
     float z = __fmaf_rn(rr, inv_sigma, q0);
-    z = fminf(fmaxf(z, -9.9f), 9.9f);
-    const int i = (int)(z * 1000.f + 10000.f);
-    return (float)(i - 10000) * 0.001f;
+    z = __builtin_amdgcn_fmed3f(z, -9.9f, 9.9f);
+    return floorf(z * 1000.f + 10000.f) - 10000.f;   // same two roundings as the reference's (int)(z*1000+10000)
 }
 __device__ __forceinline__ float pair_gk(float px, float py, float pz, float ox, float oy, float oz,
                                          float sigma, float inv_sigma, float c3) {
-    const float tx = axis_t(px, ox, sigma, inv_sigma);
-    const float ty = axis_t(py, oy, sigma, inv_sigma);
-    const float tz = axis_t(pz, oz, sigma, inv_sigma);
-    const float s = tx * tx + ty * ty + tz * tz;
-    return c3 * __expf(-0.5f * s);
+    const float ux = axis_u(px, ox, sigma, inv_sigma);
+    const float uy = axis_u(py, oy, sigma, inv_sigma);
+    const float uz = axis_u(pz, oz, sigma, inv_sigma);
+    const float s = ux * ux + uy * uy + uz * uz;
+    // exp(-0.5 * 1e-6 * s) = exp2(s * (-0.5e-6 * log2(e)))
+    return c3 * __builtin_amdgcn_exp2f(s * -7.213475204444817e-07f);
 }
 
 // particle storage index: tiles of 64 voxels, slot-major inside a tile (see dspmap_sweep.hip)
