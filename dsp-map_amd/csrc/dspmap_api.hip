@@ -515,7 +515,7 @@ int dspmap_gate_and_delta(dspmap* m, const float pos[3], double stamp, const flo
 // When `fork` is set (graph capture) the observation binning runs on a second stream concurrently with
 // prediction + re-binning: the two only share the rotated planes written by k_reset and meet again at
 // the Ck kernel.
-static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid, bool fork) {
+static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid, bool fork, bool all_static) {
     dspmap_prof_mark(m, 0);
     launch_frame_setup(c, true);
     if (fork) {
@@ -540,7 +540,7 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     dspmap_prof_mark(m, 5);
     if (birth_grid <= 0) launch_ck_finalize(c);   // otherwise k_birth_rank reduces the 1/Ck sums (one launch less)
     dspmap_prof_mark(m, 6);
-    launch_birth(c, birth_grid, true);
+    launch_birth(c, birth_grid, true, all_static);
     dspmap_prof_mark(m, 7);
     launch_resample(c);
     dspmap_prof_mark(m, 8);
@@ -572,19 +572,19 @@ extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* poin
     HIPCHK(m, hipEventRecord(m->ev0, m->stream));
     if (m->use_graph && !m->prof) {
         // the kernel arguments of a frame are constant (per-frame values live in s.fpar): capture once, replay
-        const unsigned long long key = ((unsigned long long)m->graph_epoch << 8) | (has_vz ? 1u : 0u);
+        const unsigned long long key = ((unsigned long long)m->graph_epoch << 8) | (has_vz ? 1u : 0u) | (static_birth ? 2u : 0u);
         if (!m->graph_exec || m->graph_key != key) {
             if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
             if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
             HIPCHK(m, hipStreamBeginCapture(m->stream, hipStreamCaptureModeRelaxed));
-            enqueue_frame(m, c, m->pt_cap, m->birth_cap, false);  // (fork=true measured slower: HIP replays multi-branch graphs with a much higher launch cost) grids sized for the capacity; kernels bound-check against fpar
+            enqueue_frame(m, c, m->pt_cap, m->birth_cap, false, static_birth);  // (fork=true measured slower: HIP replays multi-branch graphs with a much higher launch cost) grids sized for the capacity; kernels bound-check against fpar
             HIPCHK(m, hipStreamEndCapture(m->stream, &m->graph));
             HIPCHK(m, hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
             m->graph_key = key;
         }
         HIPCHK(m, hipGraphLaunch(m->graph_exec, m->stream));
     } else {
-        enqueue_frame(m, c, n_points, nb, false);
+        enqueue_frame(m, c, n_points, nb, false, static_birth);
     }
     if (m->vz_frames > 0) --m->vz_frames;
     HIPCHK(m, hipEventRecord(m->ev1, m->stream));
@@ -694,7 +694,7 @@ extern "C" int dspmap_update(dspmap_t* m, int n, int stride, const float* pts, f
         rc = dspmap_push_frame_params(m);
         if (rc != DSPMAP_OK) return rc;
     }
-    if (n >= 0 && nb > 0) launch_birth(c, nb, true);  // :314-316
+    if (n >= 0 && nb > 0) launch_birth(c, nb, true, !have_cloud);  // :314-316
     else launch_ck_finalize(c);
     launch_resample(c);
     if (m->vz_frames > 0) --m->vz_frames;
@@ -995,7 +995,7 @@ extern "C" int dspmap_stage_birth(dspmap_t* m) {
     for (int i = 0; i < 3; i++) m->hp.cur_pos[i] = m->cur_pos[i];
     m->hp.n_birth = nb; m->hp.birth = m->s.birth;
     { int rc = dspmap_push_frame_params(m); if (rc != DSPMAP_OK) return rc; }
-    launch_birth(c, nb, false);
+    launch_birth(c, nb, false, false);
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
 }

@@ -52,9 +52,9 @@ void launch_ck_partial(const LaunchCtx& c);
 void launch_ck_finalize(const LaunchCtx& c);
 void launch_weight_update(const LaunchCtx& c);
 // mapAddNewBornParticlesByObservation (:796-921)
-void launch_birth(const LaunchCtx& c, int n_birth, bool in_frame);  // in_frame: between k_weight and k_resample of a whole frame
+void launch_birth(const LaunchCtx& c, int n_birth, bool in_frame, bool all_static);  // in_frame: between k_weight and k_resample of a whole frame
 void launch_birth_split(const LaunchCtx& c, int n_birth);
-void launch_birth_plan_insert(const LaunchCtx& c, int n_birth, bool in_frame);
+void launch_birth_plan_insert(const LaunchCtx& c, int n_birth, bool in_frame, bool all_static);
 // mapOccupancyCalculationAndResample (:924-1057)
 void launch_resample(const LaunchCtx& c);
 // readout (:385-438)

@@ -819,7 +819,7 @@ __global__ void k_zero_i32(int* __restrict__ p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0;
 }
-void launch_birth_plan_insert(const LaunchCtx& c, int n_birth_grid, bool in_frame) {
+void launch_birth_plan_insert(const LaunchCtx& c, int n_birth_grid, bool in_frame, bool all_static) {
     if (n_birth_grid <= 0) return;
     const long long total = (long long)n_birth_grid * c.fp.nb_num;
     const unsigned gb = (unsigned)((total + 255) / 256);
@@ -827,13 +827,15 @@ void launch_birth_plan_insert(const LaunchCtx& c, int n_birth_grid, bool in_fram
     // in_frame: k_resample, which follows, zeroes them again, and k_birth_rank also does k_ck_sum's job.
     hipLaunchKernelGGL(k_birth_rank, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp, in_frame ? 1 : 0);
     hipLaunchKernelGGL(k_birth_children, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx);
-    hipLaunchKernelGGL(k_birth_cursors, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
+    // all_static (every birth source has intensity 0, the synthesized cloud): no child draws from the velocity or
+    // rand() streams (:877-903), so the cursor kernel has nothing to compute and k_birth_insert never reads its output
+    if (!all_static) hipLaunchKernelGGL(k_birth_cursors, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
     hipLaunchKernelGGL(k_birth_insert, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx, c.k.part_birth);
     if (!in_frame) hipLaunchKernelGGL(k_zero_i32, dim3((c.d.v_loc + 255) / 256), dim3(256), 0, c.stream, c.k.vb_cnt, c.d.v_loc);
 }
-void launch_birth(const LaunchCtx& c, int n_birth_grid, bool in_frame) {
+void launch_birth(const LaunchCtx& c, int n_birth_grid, bool in_frame, bool all_static) {
     launch_birth_split(c, n_birth_grid);
-    launch_birth_plan_insert(c, n_birth_grid, in_frame);
+    launch_birth_plan_insert(c, n_birth_grid, in_frame, all_static);
 }
 
 void launch_occupied_compact(const LaunchCtx& c, float thr) {

@@ -109,7 +109,7 @@ extern "C" int dspmap_mgpu_finish(dspmap_t* m) {
     READY(m);
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
-    launch_birth_plan_insert(c, m->last_n_birth, false);
+    launch_birth_plan_insert(c, m->last_n_birth, false, m->last_birth_static);
     launch_resample(c);
     HIPCHK(m, hipEventRecord(m->ev1, m->stream));
     m->ev_valid = true;
