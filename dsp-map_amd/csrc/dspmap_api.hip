@@ -517,16 +517,16 @@ int dspmap_gate_and_delta(dspmap* m, const float pos[3], double stamp, const flo
 // the Ck kernel.
 static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid, bool fork, bool all_static) {
     dspmap_prof_mark(m, 0);
-    launch_frame_setup(c, true);
-    if (fork) {
+    if (!fork) {
+        launch_setup_and_bin(c, pts_grid);
+    } else {
+        launch_frame_setup(c, true);
         (void)hipEventRecord(m->ev_fork, m->stream);
         (void)hipStreamWaitEvent(m->stream2, m->ev_fork, 0);
         LaunchCtx c2 = c;
         c2.stream = m->stream2;
         launch_obs_bin(c2, pts_grid);
         (void)hipEventRecord(m->ev_join, m->stream2);
-    } else {
-        launch_obs_bin(c, pts_grid);
     }
     dspmap_prof_mark(m, 1);
     launch_predict_only(c);
@@ -669,8 +669,7 @@ extern "C" int dspmap_update(dspmap_t* m, int n, int stride, const float* pts, f
     rc = dspmap_push_frame_params(m);
     if (rc != DSPMAP_OK) return rc;
     HIPCHK(m, hipEventRecord(m->ev0, m->stream));
-    launch_frame_setup(c, true);
-    launch_obs_bin(c, np);
+    launch_setup_and_bin(c, np);
     launch_predict(c);
     launch_ck_partial(c);
     launch_weight_update(c);

@@ -38,6 +38,7 @@ struct LaunchCtx {
 void launch_frame_setup(const LaunchCtx& c, bool reset_obs);
 // observation binning (:244-290)
 void launch_obs_bin(const LaunchCtx& c, int n_pts_grid);
+void launch_setup_and_bin(const LaunchCtx& c, int n_pts_grid);
 // mapPrediction (:627-701) incl. re-binning of movers (moveParticle :1206-1274)
 void launch_predict(const LaunchCtx& c);
 void launch_predict_only(const LaunchCtx& c);

@@ -64,38 +64,64 @@ __global__ void k_reset(MapDims d, DevState s, int flags) {
 // k_obs_points: one thread per input point: rotate into the world-aligned
 // sensor-centred frame (:247), FOV test (:250), pyramid cell (:260-263), range (:266).
 // --------------------------------------------------------------------------
-__global__ void k_obs_points(MapDims d, DevState s) {
+template <bool FUSED>
+__global__ void __launch_bounds__(256) k_obs_points(MapDims d, DevState s) {
     const int n_pts = s.fpar->n_pts;
     const float* __restrict__ pts = s.fpar->pts;
     const float qw = s.fpar->quat[0], qx = s.fpar->quat[1], qy = s.fpar->quat[2], qz = s.fpar->quat[3];
+    const float cpx = s.fpar->cur_pos[0], cpy = s.fpar->cur_pos[1], cpz = s.fpar->cur_pos[2];
     const int make_static_birth = s.fpar->static_birth;
+    const float q[4] = {qw, qx, qy, qz};
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
-    for (int i = threadIdx.x; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
-    for (int i = threadIdx.x; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
+    if (FUSED) {
+        // whole-frame variant: k_reset's work rides on this kernel (one launch less per frame).  Every workgroup
+        // rotates the boundary planes for itself (:226-232); workgroup 0 also publishes them for the later kernels.
+        const int nh = d.np_h + 1, nv = d.np_v + 1;
+        for (int i = threadIdx.x; i < nh + nv; i += blockDim.x) {
+            float o[3];
+            if (i < nh) {
+                rotate_by_quat(s.planes_h0[3 * i], s.planes_h0[3 * i + 1], s.planes_h0[3 * i + 2], q, o);
+                s_ph[3 * i] = o[0]; s_ph[3 * i + 1] = o[1]; s_ph[3 * i + 2] = o[2];
+                if (blockIdx.x == 0) { s.planes_h[3 * i] = o[0]; s.planes_h[3 * i + 1] = o[1]; s.planes_h[3 * i + 2] = o[2]; }
+            } else {
+                const int j = i - nh;
+                rotate_by_quat(s.planes_v0[3 * j], s.planes_v0[3 * j + 1], s.planes_v0[3 * j + 2], q, o);
+                s_pv[3 * j] = o[0]; s_pv[3 * j + 1] = o[1]; s_pv[3 * j + 2] = o[2];
+                if (blockIdx.x == 0) { s.planes_v[3 * j] = o[0]; s.planes_v[3 * j + 1] = o[1]; s.planes_v[3 * j + 2] = o[2]; }
+            }
+        }
+        const int gt = blockIdx.x * blockDim.x + threadIdx.x, gn = gridDim.x * blockDim.x;
+        for (int i = gt; i < d.np * DSP_OBS_CAP; i += gn) s.obs_ck[i] = 0.f;       // Ck = 0 (:235-238)
+        for (int i = gt; i < d.np; i += gn) s.pyr_cnt[i] = 0;                       // pyramids are rebuilt by prediction (:638-642)
+        if (gt == 0) {
+            s.fs->cur_pos[0] = cpx; s.fs->cur_pos[1] = cpy; s.fs->cur_pos[2] = cpz;
+            s.fs->n_valid = 0; s.fs->n_obs = 0; s.fs->has_expected_override = 0;   // k_obs_gather accumulates the first two
+            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->mover_count = 0;
+        }
+    } else {
+        for (int i = threadIdx.x; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
+        for (int i = threadIdx.x; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
+    }
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool valid = false;
     if (i < n_pts) {
-        const float q[4] = {qw, qx, qy, qz};
         float r[3];
         rotate_by_quat(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], q, r);
         const int pyr = pyramid_of(d, s_ph, s_pv, r[0], r[1], r[2]);
         const float len = sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
         s.pt_rot[i] = make_float4(r[0], r[1], r[2], len);
         s.pt_pyr[i] = pyr;
-        valid = pyr >= 0;
         if (make_static_birth) {
             // what velocityEstimationThread emits for a static point (:1389-1391,1529-1540):
             // world position = rotated + current_position, zero velocity tag, intensity 0
             BirthSrc b;
-            b.x = r[0] + s.fs->cur_pos[0]; b.y = r[1] + s.fs->cur_pos[1]; b.z = r[2] + s.fs->cur_pos[2];
+            b.x = r[0] + cpx; b.y = r[1] + cpy; b.z = r[2] + cpz;
             b.nx = b.ny = b.nz = 0.f;
-            b.intensity = valid ? 0.f : -2.f;  // -2 = not a source (point outside the FOV)
+            b.intensity = pyr >= 0 ? 0.f : -2.f;  // -2 = not a source (point outside the FOV)
             s.fpar->birth[i] = b;
         }
     }
-    wave_count_add(&s.fs->n_valid, valid);  // valid_points :286
 }
 
 // k_obs_gather: one wave per pyramid.  Appends matching points in INPUT order
@@ -135,6 +161,7 @@ __global__ void k_obs_gather(MapDims d, DevState s) {
         s.obs_cnt[b] = c;
         s.obs_maxlen[b] = maxlen;
         if (c) atomicAdd(&s.fs->n_obs, c);
+        if (count) atomicAdd(&s.fs->n_valid, count);   // valid_points :286 counts the overflowed points too
     }
 }
 
@@ -792,8 +819,13 @@ void launch_frame_setup(const LaunchCtx& c, bool reset_obs) {
     hipLaunchKernelGGL(k_reset, dim3(grid), dim3(1024), 0, c.stream, c.d, c.s, flags);
 }
 
+void launch_setup_and_bin(const LaunchCtx& c, int n_pts_grid) {   // whole frame: launch_frame_setup(c, true) + launch_obs_bin
+    const int grid = n_pts_grid > 0 ? (n_pts_grid + 255) / 256 : 1;
+    hipLaunchKernelGGL(k_obs_points<true>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s);
+    hipLaunchKernelGGL(k_obs_gather, dim3(c.d.np), dim3(WAVE), 0, c.stream, c.d, c.s);
+}
 void launch_obs_bin(const LaunchCtx& c, int n_pts_grid) {
-    if (n_pts_grid > 0) hipLaunchKernelGGL(k_obs_points, dim3((n_pts_grid + 255) / 256), dim3(256), 0, c.stream, c.d, c.s);
+    if (n_pts_grid > 0) hipLaunchKernelGGL(k_obs_points<false>, dim3((n_pts_grid + 255) / 256), dim3(256), 0, c.stream, c.d, c.s);
     hipLaunchKernelGGL(k_obs_gather, dim3(c.d.np), dim3(WAVE), 0, c.stream, c.d, c.s);
 }
 

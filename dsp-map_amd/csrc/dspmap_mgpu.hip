@@ -52,8 +52,7 @@ extern "C" int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_
     if (rcp != DSPMAP_OK) return rcp;
     dspmap_prof_collect(m);
     HIPCHK(m, hipEventRecord(m->ev0, m->stream));
-    launch_frame_setup(c, true);
-    launch_obs_bin(c, n_points);
+    launch_setup_and_bin(c, n_points);
     launch_predict(c);
     if (m->vz_frames > 0) --m->vz_frames;
     m->last_n_points = n_points;
