@@ -638,6 +638,34 @@ def test_preprocess_cloud_against_oracle(dsp, orc):
     m.close()
 
 
+def test_caller_owned_stream(dsp):
+    """dspmap_set_stream: the frame runs on a caller-owned stream (e.g. a torch stream), stream-ordered with the
+    caller's own work on it; results equal the library-stream run"""
+    import torch
+    cfgkw = dict(nx=40, ny=40, nz=20, ppv=12)
+    base = common.wall_cloud(8, n_side=40, dist=2.2, half_w=1.8, half_h=0.9)
+    outs = []
+    for own in (False, True):
+        m = dsp.DSPMap(dsp.make_config(**cfgkw))
+        m.set_tables(*common.tables(4))
+        st = torch.cuda.Stream()
+        if own:
+            m._chk(m.L.dspmap_set_stream(m.h, st.cuda_stream))
+        with torch.cuda.stream(st):
+            for f in range(4):
+                pts = base.copy(); pts[:, 0] -= np.float32(0.01 * f)
+                d = torch.from_numpy(pts).cuda(non_blocking=True)   # H2D enqueued on `st`, consumed by the frame on `st`
+                if not own:
+                    st.synchronize()
+                assert m.update_device(d.data_ptr(), len(pts), (0.01 * f, 0.0, 0.0), f / 30.0, (1, 0, 0, 0)) == 1
+                m.clearOccupancyMapPrediction()
+        m.sync()
+        outs.append((m.results()[:, 0].astype(np.float64), m.counters()["n_live_out"]))
+        m.close()
+    (a, na), (b, nb) = outs
+    assert abs(a.sum() - b.sum()) < 5e-3 * a.sum() and abs(na - nb) < 0.02 * na and na > 1000
+
+
 def test_graph_replay_with_foreign_kernels_between_frames(dsp):
     """regression: a memset node inside the captured frame graph faulted as soon as another stream ran
     kernels between two replays (large map, ~6 frames).  The frame graph now holds kernel nodes only."""
