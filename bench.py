@@ -33,6 +33,8 @@ WORKLOADS = {
     "C_sat": dict(nx=132, ny=132, nz=60, res=0.15, ppv=24, sat=True),
     "E": dict(nx=264, ny=264, nz=80, res=0.10, ppv=36, sat=False),
     "E_sat": dict(nx=264, ny=264, nz=80, res=0.10, ppv=36, sat=True),
+    # one rank's share of E_sat on 8 GPUs (10 of the 80 layers) as a stand-alone map: driver-overhead studies
+    "E8_sat": dict(nx=264, ny=264, nz=10, res=0.10, ppv=36, sat=True),
 }
 REC = 32  # bytes of one live particle record in SURVEY 8(d)'s accounting
 

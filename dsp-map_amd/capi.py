@@ -109,6 +109,8 @@ SIGNATURES = {
     "dspmap_mgpu_bind": (_i, [_P, _P, _P, _i]),
     "dspmap_mgpu_begin": (_i, [_P, _i, _P, _i, _P, _P, _d, _P]),
     "dspmap_mgpu_export": (_i, [_P, _i, _P, _i, _ip]),
+    "dspmap_mgpu_export_both": (_i, [_P, _P, _P, _i, _P]),
+    "dspmap_mgpu_set_export_counts": (_i, [_P, _i, _i]),
     "dspmap_mgpu_import": (_i, [_P, _i, _P]),
     "dspmap_mgpu_ck_partial": (_i, [_P]),
     "dspmap_mgpu_weights_and_split": (_i, [_P]),

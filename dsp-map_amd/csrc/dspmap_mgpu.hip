@@ -77,6 +77,26 @@ extern "C" int dspmap_mgpu_export(dspmap_t* m, int dir, float* rec_dev_out, int 
     return DSPMAP_OK;
 }
 
+// Asynchronous variant for stream-ordered drivers: both directions in one call, counts stay on the device
+// (counts_dev[0] = up, [1] = down) so that the caller can all-gather them without a host round trip first.
+extern "C" int dspmap_mgpu_export_both(dspmap_t* m, float* up_dev_out, float* down_dev_out, int cap, int* counts_dev) {
+    READY(m);
+    if (!m->mgpu_bound || !up_dev_out || !down_dev_out || cap < 0 || !counts_dev) return dspmap_fail(m, DSPMAP_E_ARG, "bad arguments");
+    LaunchCtx c = dspmap_ctx_of(m);
+    HIPCHK(m, hipMemsetAsync(counts_dev, 0, 2 * sizeof(int), m->stream));
+    launch_export_slab(c, +1, up_dev_out, cap, counts_dev);
+    launch_export_slab(c, -1, down_dev_out, cap, counts_dev + 1);
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}
+// bookkeeping for dspmap_get_counters once the caller has read the counts of dspmap_mgpu_export_both
+extern "C" int dspmap_mgpu_set_export_counts(dspmap_t* m, int n_up, int n_down) {
+    if (!m) return DSPMAP_E_ARG;
+    m->last_exp[1] = n_up;
+    m->last_exp[0] = n_down;
+    return DSPMAP_OK;
+}
+
 extern "C" int dspmap_mgpu_import(dspmap_t* m, int n, const float* rec_dev) {
     READY(m);
     if (n < 0 || (n > 0 && !rec_dev)) return DSPMAP_E_ARG;

@@ -47,22 +47,27 @@ class TorchDistComm:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = device
 
-    def exchange(self, up, down):
-        """send `up` to rank+1 and `down` to rank-1; returns (from_below, from_above). Tensors (n, 8) f32."""
+    ordered = False   # True: the slab runs on the torch stream the collectives are issued from (no host syncs needed)
+
+    def exchange(self, up, down, counts):
+        """send the first counts[0] rows of `up` to rank+1 and the first counts[1] rows of `down` to rank-1.
+        `counts` is an int32[2] tensor on the communicator's device (it may still be in flight on the stream).
+        Returns (from_below, from_above, (n_up, n_down)).  ONE host synchronisation: reading the gathered counts."""
         dist = self.dist
         r, w = self.rank, self.world
-        counts = torch.tensor([up.shape[0], down.shape[0]], dtype=torch.int64, device=self.device)
         allc = [torch.zeros_like(counts) for _ in range(w)]
         dist.all_gather(allc, counts)
-        n_from_below = int(allc[r - 1][0]) if r > 0 else 0       # what rank-1 sends up
-        n_from_above = int(allc[r + 1][1]) if r < w - 1 else 0   # what rank+1 sends down
+        host = torch.stack(allc).cpu().tolist()
+        n_up, n_down = int(host[r][0]), int(host[r][1])
+        n_from_below = int(host[r - 1][0]) if r > 0 else 0       # what rank-1 sends up
+        n_from_above = int(host[r + 1][1]) if r < w - 1 else 0   # what rank+1 sends down
         from_below = torch.empty((n_from_below, 8), dtype=torch.float32, device=self.device)
         from_above = torch.empty((n_from_above, 8), dtype=torch.float32, device=self.device)
         ops = []
-        if r < w - 1 and up.shape[0] > 0:
-            ops.append(dist.P2POp(dist.isend, up.contiguous(), r + 1))
-        if r > 0 and down.shape[0] > 0:
-            ops.append(dist.P2POp(dist.isend, down.contiguous(), r - 1))
+        if r < w - 1 and n_up > 0:
+            ops.append(dist.P2POp(dist.isend, up[:n_up].contiguous(), r + 1))
+        if r > 0 and n_down > 0:
+            ops.append(dist.P2POp(dist.isend, down[:n_down].contiguous(), r - 1))
         if n_from_below > 0:
             ops.append(dist.P2POp(dist.irecv, from_below, r - 1))
         if n_from_above > 0:
@@ -70,13 +75,13 @@ class TorchDistComm:
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
-            if self.device.type == "cuda":
-                torch.cuda.current_stream(self.device).synchronize()
-        return from_below, from_above
+            self._done()
+        return from_below, from_above, (n_up, n_down)
 
     def _done(self):
-        # the library runs on its own stream: make sure the collective has landed before it reads
-        if self.device.type == "cuda":
+        # slab on its own stream: make sure the collective has landed before the library reads its result.
+        # ordered mode: the library runs on the stream the collective was issued from -- stream order suffices.
+        if self.device.type == "cuda" and not self.ordered:
             torch.cuda.current_stream(self.device).synchronize()
 
     def allreduce_sum(self, t):
@@ -113,6 +118,29 @@ class HipSlab:
                         -1: torch.empty((self.exp_cap, 8), dtype=torch.float32, device=self.dev)}
         m._chk(m.L.dspmap_mgpu_bind(m.h, self.ck.data_ptr(), self.nstatic.data_ptr(), point_cap))
         self.n_birth = 0
+        self.counts = torch.zeros(2, dtype=torch.int32, device=self.dev)
+        self.ordered = False
+
+    def adopt_stream(self, stream):
+        """run the library on `stream` (a torch.cuda.Stream): everything the driver enqueues on that stream -- kernels
+        of this slab, torch ops, RCCL collectives -- is then ordered by the stream and needs no host synchronisation"""
+        self.map.sync()
+        self.map._chk(self.map.L.dspmap_set_stream(self.map.h, stream.cuda_stream))
+        self.ordered = True
+
+    def export_both(self):
+        """both exports without a host round trip: (up buffer, down buffer, device int32[2] counts)"""
+        m = self.map
+        m._chk(m.L.dspmap_mgpu_export_both(m.h, self.exp_buf[+1].data_ptr(), self.exp_buf[-1].data_ptr(), self.exp_cap,
+                                           self.counts.data_ptr()))
+        if not self.ordered:
+            m.sync()
+        return self.exp_buf[+1], self.exp_buf[-1], self.counts
+
+    def note_exports(self, n_up, n_down):
+        if n_up > self.exp_cap or n_down > self.exp_cap:
+            raise RuntimeError("slab export buffer too small: %d / %d > %d" % (n_up, n_down, self.exp_cap))
+        self.map._chk(self.map.L.dspmap_mgpu_set_export_counts(self.map.h, n_up, n_down))
 
     def begin(self, pts, pos, stamp, quat, birth=None):
         m = self.map
@@ -135,16 +163,19 @@ class HipSlab:
         if rec.shape[0]:
             rec = rec.contiguous()
             self.map._chk(self.map.L.dspmap_mgpu_import(self.map.h, int(rec.shape[0]), rec.data_ptr()))
-            self.map.sync()  # `rec` may be a temporary
+            if not self.ordered:
+                self.map.sync()  # `rec` may be a temporary (ordered mode: same stream as its allocation)
 
     def ck_partial(self):
         self.map._chk(self.map.L.dspmap_mgpu_ck_partial(self.map.h))
-        self.map.sync()
+        if not self.ordered:
+            self.map.sync()
         return self.ck
 
     def weights_and_split(self):
         self.map._chk(self.map.L.dspmap_mgpu_weights_and_split(self.map.h))
-        self.map.sync()
+        if not self.ordered:
+            self.map.sync()
         return self.nstatic[:self.n_birth]
 
     def finish(self):
@@ -165,26 +196,51 @@ class ShardedDSPMap:
         self.slabs = list(slabs)
         self.comm = comm
         self.local = isinstance(comm, LocalComm)
+        self.stream = None
         if not self.local:
             assert len(self.slabs) == 1
+            dev = getattr(comm, "device", None)
+            if dev is not None and dev.type == "cuda" and hasattr(self.slabs[0], "adopt_stream"):
+                # one stream for the slab's kernels, the torch ops and the collectives: no host syncs between phases
+                self.stream = torch.cuda.Stream(dev)
+                self.slabs[0].adopt_stream(self.stream)
+                comm.ordered = True
 
     def update(self, pts, pos, stamp, quat, birth=None):
+        if self.stream is None:
+            return self._update(pts, pos, stamp, quat, birth)
+        self.stream.wait_stream(torch.cuda.current_stream(self.stream.device))   # inputs produced on the caller's stream
+        with torch.cuda.stream(self.stream):
+            return self._update(pts, pos, stamp, quat, birth)
+
+    @staticmethod
+    def _export_both(slab):
+        if hasattr(slab, "export_both"):
+            return slab.export_both()
+        up, down = slab.export(+1), slab.export(-1)
+        return up, down, torch.tensor([up.shape[0], down.shape[0]], dtype=torch.int32, device=up.device)
+
+    def _update(self, pts, pos, stamp, quat, birth=None):
         rcs = [s.begin(pts, pos, stamp, quat, birth) for s in self.slabs]
         if any(rc == 0 for rc in rcs):
             return 0
         # (1) particles that crossed a slab face
-        ups = [s.export(+1) for s in self.slabs]
-        downs = [s.export(-1) for s in self.slabs]
         if self.local:
+            ups = [s.export(+1) for s in self.slabs]
+            downs = [s.export(-1) for s in self.slabs]
             for i, s in enumerate(self.slabs):
                 if i > 0:
                     s.import_(ups[i - 1])
                 if i < len(self.slabs) - 1:
                     s.import_(downs[i + 1])
         else:
-            below, above = self.comm.exchange(ups[0], downs[0])
-            self.slabs[0].import_(below)
-            self.slabs[0].import_(above)
+            slab = self.slabs[0]
+            up, down, counts = self._export_both(slab)
+            below, above, (n_up, n_down) = self.comm.exchange(up, down, counts)
+            if hasattr(slab, "note_exports"):
+                slab.note_exports(n_up, n_down)
+            slab.import_(below)
+            slab.import_(above)
         # (2) per-observation sums
         cks = [s.ck_partial() for s in self.slabs]
         if self.local:

@@ -255,6 +255,12 @@ int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_dev, int n_
                       double time_stamp_second, const float quat_wxyz[4]);   /* 1 / 0 like dspmap_update */
 int dspmap_mgpu_export(dspmap_t* m, int dir /* +1 through z_hi, -1 through z_lo */, float* rec_dev_out,
                        int cap, int* n_out);                                 /* synchronises */
+/* stream-ordered variant of the two exports: no host synchronisation; counts_dev[0] = records written to
+ * up_dev_out, counts_dev[1] = to down_dev_out (device memory).  A count above `cap` means the buffer was too small
+ * (the surplus particles are lost): the caller must check after reading the counts, then report them with
+ * dspmap_mgpu_set_export_counts (statistics only). */
+int dspmap_mgpu_export_both(dspmap_t* m, float* up_dev_out, float* down_dev_out, int cap, int* counts_dev);
+int dspmap_mgpu_set_export_counts(dspmap_t* m, int n_up, int n_down);
 int dspmap_mgpu_import(dspmap_t* m, int n, const float* rec_dev);
 int dspmap_mgpu_ck_partial(dspmap_t* m);
 int dspmap_mgpu_weights_and_split(dspmap_t* m);

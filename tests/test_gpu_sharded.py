@@ -93,6 +93,44 @@ def test_first_frame_slabs_equal_unsharded_exactly(dsp):
     full.close()
 
 
+def test_rccl_driver_single_rank_stream_ordered(dsp):
+    """the torch.distributed (RCCL) driver in its stream-ordered mode -- slab kernels, torch ops and collectives on
+    ONE torch stream, a single host synchronisation per frame -- with world_size 1 (all this box has): the one
+    full-height slab must reproduce the unsharded map frame by frame (same kernels, same order of operations)"""
+    import torch.distributed as dist
+    sharded = __import__("dsp-map_amd.sharded", fromlist=["ShardedDSPMap"])
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        cfg = dict(nx=40, ny=40, nz=24, res=0.15, ppv=12)
+        tables = common.tables(6)
+        slab = sharded.HipSlab(dsp, cfg, 0, cfg["nz"], 0)
+        slab.map.set_tables(*tables)
+        sm = sharded.ShardedDSPMap([slab], sharded.TorchDistComm(torch.device("cuda", 0)))
+        assert sm.stream is not None and slab.ordered
+        full = dsp.DSPMap(dsp.make_config(**cfg))
+        full.set_tables(*tables)
+        for pts, pos, t, q in _stream(6):
+            d = torch.from_numpy(pts).cuda()
+            assert sm.update(d, pos, t, q) == 1
+            assert full.update(pts, pos, t, q) == 1
+            slab.map.clearOccupancyMapPrediction(); full.clearOccupancyMapPrediction()
+        sm.sync()
+        got, want = slab.results(), full.results()
+        m_g, m_w = got[:, 0].astype(np.float64).sum(), want[:, 0].astype(np.float64).sum()
+        assert abs(m_g - m_w) < 5e-3 * m_w
+        assert (np.abs(got[:, 0] - want[:, 0]) <= 1e-3 * np.maximum(1.0, np.abs(want[:, 0]))).mean() > 0.97
+        assert abs(slab.map.counters()["n_live_out"] - full.counters()["n_live_out"]) <= 0.02 * full.counters()["n_live_out"]
+        full.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_dropin_example_runs(dsp):
     exe = os.path.join(ROOT, "examples", "map_example")
     subprocess.check_call(["g++", "-std=c++14", "-I" + os.path.join(ROOT, "include"),
