@@ -93,6 +93,8 @@ SIGNATURES = {
     "dspmap_clear_state": (_i, [_P]),
     "dspmap_import_state": (_i, [_P, _i, _P, _P, _P]),
     "dspmap_export_state": (_i, [_P, _i, _P, _P, _P, _ip]),
+    "dspmap_save_checkpoint": (_i, [_P, C.c_char_p]),
+    "dspmap_load_checkpoint": (_i, [_P, C.c_char_p]),
     "dspmap_preprocess_cloud": (_i, [_P, _i, _P, _i, _f, _i, _i, _P, _ip, _ip]),
     "dspmap_add_random_particles": (_i, [_P, _i, _f]),
     "dspmap_seed_uniform_moving": (_i, [_P, _i, _f, C.c_uint, _f]),
@@ -361,6 +363,12 @@ class DSPMap:
             self._chk(self.L.dspmap_export_state(self.h, cap, _ptr(voxel), _ptr(slot), _ptr(rec), C.byref(n)))
         order = np.lexsort((slot, voxel))
         return voxel[order], slot[order], rec[order]
+
+    def save_checkpoint(self, path):
+        self._chk(self.L.dspmap_save_checkpoint(self.h, str(path).encode()))
+
+    def load_checkpoint(self, path):
+        self._chk(self.L.dspmap_load_checkpoint(self.h, str(path).encode()))
 
     def preprocess_cloud(self, points_ptr, n, out_ptr, max_points, leaf=0.1, swap_axes=True, stride=3):
         """voxel-grid filter + axis swap + crop + cap on the device (src/map_sim_example.cpp:309-336);

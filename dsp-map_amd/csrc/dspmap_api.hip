@@ -1085,3 +1085,113 @@ extern "C" int dspmap_get_stage_ms(dspmap_t* m, float out[DSPMAP_N_STAGES], int*
 }
 
 // ------------------------------------------------- multi-GPU split-phase (see dspmap_mgpu.hip)
+
+// ------------------------------------------------------------------ binary checkpoint
+// The reference has no resume capability (its only dump is the one-shot particle CSV, :326-350).  A checkpoint
+// holds what the next update() depends on: every live particle with its slot, the function statics of update()
+// (:187-190) and of the birth stage (:808-811), the table cursors, the result grid and the future accumulators.
+// Not saved: the Gaussian / rand() tables (regenerated from the configuration's seed, or re-injected by the
+// caller) and the host velocity estimator's previous clusters (the first frame after a restore matches nothing,
+// exactly like the first frame of a run).
+namespace {
+struct CkHeader {
+    char magic[8];
+    int version;
+    dspmap_config cfg;
+    FilterParams fp;
+    int nb_frozen, have_last, vz_frames, pad;
+    float last_p[3], cur_pos[3], quat[4], dt_last, p_stddev, v_stddev, voxel_filter_res;
+    double last_stamp;
+    int cursors[3];
+    int n_particles;
+    long long v_loc;
+};
+}  // namespace
+
+extern "C" int dspmap_save_checkpoint(dspmap_t* m, const char* path) {
+    READY(m);
+    if (!path) return DSPMAP_E_ARG;
+    dspmap_flush_future_clear(m);
+    int n = 0;
+    int rc = dspmap_export_state(m, 0, nullptr, nullptr, nullptr, &n);
+    if (rc != DSPMAP_OK) return rc;
+    std::vector<int> voxel((size_t)n + 1), slot((size_t)n + 1);
+    std::vector<float> rec((size_t)n * 8 + 8);
+    rc = dspmap_export_state(m, n, voxel.data(), slot.data(), rec.data(), &n);
+    if (rc != DSPMAP_OK) return rc;
+    const size_t V = (size_t)m->d.v_loc, T = (size_t)m->d.T;
+    std::vector<float> res(V * 4), fut(V * (T ? T : 1));
+    LaunchCtx c = dspmap_ctx_of(m);
+    launch_future_combine(c);   // fold the static-particle mass into the per-horizon accumulators
+    HIPCHK(m, hipMemcpyAsync(res.data(), m->s.res4, sizeof(float4) * V, hipMemcpyDeviceToHost, m->stream));
+    if (T) HIPCHK(m, hipMemcpyAsync(fut.data(), m->s.fut, sizeof(float) * V * T, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    CkHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "DSPMAPCK", 8);
+    h.version = 1;
+    h.cfg = m->cfg; h.fp = m->fp;
+    h.nb_frozen = m->nb_frozen; h.have_last = m->have_last; h.vz_frames = m->vz_frames;
+    for (int i = 0; i < 3; i++) { h.last_p[i] = m->last_p[i]; h.cur_pos[i] = m->cur_pos[i]; }
+    for (int i = 0; i < 4; i++) h.quat[i] = m->quat[i];
+    h.dt_last = m->dt_last; h.p_stddev = m->p_stddev; h.v_stddev = m->v_stddev; h.voxel_filter_res = m->voxel_filter_res;
+    h.last_stamp = m->last_stamp;
+    rc = dspmap_get_cursors(m, &h.cursors[0], &h.cursors[1], &h.cursors[2]);
+    if (rc != DSPMAP_OK) return rc;
+    h.n_particles = n; h.v_loc = (long long)V;
+    FILE* f = fopen(path, "wb");
+    if (!f) return dspmap_fail(m, DSPMAP_E_ARG, "cannot open %s for writing", path);
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+    ok = ok && (n == 0 || (fwrite(voxel.data(), sizeof(int), n, f) == (size_t)n && fwrite(slot.data(), sizeof(int), n, f) == (size_t)n &&
+                           fwrite(rec.data(), sizeof(float) * 8, n, f) == (size_t)n));
+    ok = ok && fwrite(res.data(), sizeof(float) * 4, V, f) == V;
+    ok = ok && (T == 0 || fwrite(fut.data(), sizeof(float) * T, V, f) == V);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) return dspmap_fail(m, DSPMAP_E_STATE, "short write to %s", path);
+    return DSPMAP_OK;
+}
+
+extern "C" int dspmap_load_checkpoint(dspmap_t* m, const char* path) {
+    READY(m);
+    if (!path) return DSPMAP_E_ARG;
+    FILE* f = fopen(path, "rb");
+    if (!f) return dspmap_fail(m, DSPMAP_E_ARG, "cannot open %s", path);
+    CkHeader h;
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "DSPMAPCK", 8) != 0 || h.version != 1) {
+        fclose(f);
+        return dspmap_fail(m, DSPMAP_E_ARG, "%s is not a version-1 dspmap checkpoint", path);
+    }
+    const dspmap_config &a = h.cfg, &b = m->cfg;
+    bool same = a.nx == b.nx && a.ny == b.ny && a.nz == b.nz && a.voxel_resolution == b.voxel_resolution &&
+                a.angle_resolution == b.angle_resolution && a.max_particle_num_voxel == b.max_particle_num_voxel &&
+                a.half_fov_h == b.half_fov_h && a.half_fov_v == b.half_fov_v && a.prediction_times == b.prediction_times &&
+                a.z_lo == b.z_lo && a.z_hi == b.z_hi && h.v_loc == (long long)m->d.v_loc;
+    for (int k = 0; same && k < a.prediction_times; k++) same = a.prediction_future_time[k] == b.prediction_future_time[k];
+    if (!same) { fclose(f); return dspmap_fail(m, DSPMAP_E_ARG, "checkpoint was written by a map with a different configuration"); }
+    const int n = h.n_particles;
+    const size_t V = (size_t)m->d.v_loc, T = (size_t)m->d.T;
+    std::vector<int> voxel((size_t)n + 1), slot((size_t)n + 1);
+    std::vector<float> rec((size_t)n * 8 + 8), res(V * 4), fut(V * (T ? T : 1));
+    bool ok = n == 0 || (fread(voxel.data(), sizeof(int), n, f) == (size_t)n && fread(slot.data(), sizeof(int), n, f) == (size_t)n &&
+                         fread(rec.data(), sizeof(float) * 8, n, f) == (size_t)n);
+    ok = ok && fread(res.data(), sizeof(float) * 4, V, f) == V;
+    ok = ok && (T == 0 || fread(fut.data(), sizeof(float) * T, V, f) == V);
+    fclose(f);
+    if (!ok) return dspmap_fail(m, DSPMAP_E_ARG, "%s is truncated", path);
+    int rc = dspmap_clear_state(m);
+    if (rc != DSPMAP_OK) return rc;
+    rc = dspmap_import_state(m, n, voxel.data(), slot.data(), rec.data());
+    if (rc != DSPMAP_OK) return rc;
+    HIPCHK(m, hipMemcpyAsync(m->s.res4, res.data(), sizeof(float4) * V, hipMemcpyHostToDevice, m->stream));
+    if (T) HIPCHK(m, hipMemcpyAsync(m->s.fut, fut.data(), sizeof(float) * V * T, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    m->fp = h.fp;
+    m->nb_frozen = h.nb_frozen != 0; m->have_last = h.have_last != 0; m->vz_frames = h.vz_frames;
+    for (int i = 0; i < 3; i++) { m->last_p[i] = h.last_p[i]; m->cur_pos[i] = h.cur_pos[i]; }
+    for (int i = 0; i < 4; i++) m->quat[i] = h.quat[i];
+    m->dt_last = h.dt_last; m->p_stddev = h.p_stddev; m->v_stddev = h.v_stddev; m->voxel_filter_res = h.voxel_filter_res;
+    m->last_stamp = h.last_stamp;
+    m->fut_clear_pending = false;
+    m->graph_epoch++;
+    return dspmap_set_cursors(m, h.cursors[0], h.cursors[1], h.cursors[2]);
+}

@@ -199,6 +199,13 @@ int dspmap_debug_stream(dspmap_t* m, int mode, long long* bytes_out);
 int dspmap_clear_state(dspmap_t* m);
 int dspmap_import_state(dspmap_t* m, int n, const int* voxel_host, const int* slot_host, const float* rec8_host);
 int dspmap_export_state(dspmap_t* m, int cap, int* voxel_out_host, int* slot_out_host, float* rec8_out_host, int* n_out);
+/* ---- binary checkpoint / restore (the reference has none).  Saves every live particle with its
+ * slot, the function statics of update() and of the birth stage, the table cursors, the result grid and the future
+ * accumulators; the random tables come from the configuration's seed (or are re-injected by the caller).  Loading
+ * requires a handle created with the same configuration.  The host velocity estimator's previous clusters are not
+ * saved: the first frame after a restore matches no cluster, like the first frame of a run. */
+int dspmap_save_checkpoint(dspmap_t* m, const char* path);
+int dspmap_load_checkpoint(dspmap_t* m, const char* path);
 /* ---- caller-side pre-processing on the device (next to the hot path; reference src/map_sim_example.cpp:309-336)
  * points_dev: n points, xyz first, stride_floats floats apart, device memory, in the frame the sensor driver
  * delivers (swap_axes = 1: camera optical frame, mapped x = z, y = -x, z = -y like :321-323; 0: already x forward).

@@ -666,6 +666,47 @@ def test_caller_owned_stream(dsp):
     assert abs(a.sum() - b.sum()) < 5e-3 * a.sum() and abs(na - nb) < 0.02 * na and na > 1000
 
 
+def test_checkpoint_restore(dsp, tmp_path):
+    """dspmap_save_checkpoint / dspmap_load_checkpoint: particles (same slots), result grid, future accumulators,
+    table cursors and update()'s statics survive; the restored map continues like the original"""
+    cfgkw = dict(nx=40, ny=40, nz=20, ppv=12)
+    base = common.wall_cloud(9, n_side=40, dist=2.2, half_w=1.8, half_h=0.9)
+    q = (1.0, 0.0, 0.0, 0.0)
+    a = dsp.DSPMap(dsp.make_config(**cfgkw)); a.set_tables(*common.tables(7))
+    for f in range(5):
+        assert a.update(base, (0.02 * f, 0.0, 0.0), f / 30.0, q) == 1
+    path = tmp_path / "map.ck"
+    a.save_checkpoint(path)
+    b = dsp.DSPMap(dsp.make_config(**cfgkw)); b.set_tables(*common.tables(7))
+    b.load_checkpoint(path)
+
+    def state(m):
+        v, sl, r = m.export_state()
+        o = np.lexsort((sl, v))
+        return v[o], sl[o], r[o]
+    for x, y in zip(state(a), state(b)):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a.results(), b.results())
+    pc, vc, rc = [C.c_int() for _ in range(3)], [C.c_int() for _ in range(3)], None
+    a.L.dspmap_get_cursors(a.h, C.byref(pc[0]), C.byref(pc[1]), C.byref(pc[2]))
+    b.L.dspmap_get_cursors(b.h, C.byref(vc[0]), C.byref(vc[1]), C.byref(vc[2]))
+    assert [x.value for x in pc] == [x.value for x in vc]
+    fa, fb = a.getFutureStatus(), b.getFutureStatus()      # accumulated over 5 uncleared frames
+    assert fa.sum() > 0 and np.allclose(fa, fb, rtol=1e-6, atol=1e-7)
+    # both continue: same gating statics (a stamp in the past is rejected by both), same evolution
+    assert a.update(base, (0.1, 0, 0), 0.05, q) == 0 and b.update(base, (0.1, 0, 0), 0.05, q) == 0
+    for f in range(5, 8):
+        assert a.update(base, (0.02 * f, 0.0, 0.0), f / 30.0, q) == 1
+        assert b.update(base, (0.02 * f, 0.0, 0.0), f / 30.0, q) == 1
+    ma, mb = a.results()[:, 0].astype(np.float64).sum(), b.results()[:, 0].astype(np.float64).sum()
+    assert abs(ma - mb) < 5e-3 * ma
+    # a map with another configuration refuses the file
+    c = dsp.DSPMap(dsp.make_config(nx=40, ny=40, nz=20, ppv=9))
+    with pytest.raises(dsp.capi.DSPMapError):
+        c.load_checkpoint(path)
+    a.close(); b.close(); c.close()
+
+
 def test_graph_replay_with_foreign_kernels_between_frames(dsp):
     """regression: a memset node inside the captured frame graph faulted as soon as another stream ran
     kernels between two replays (large map, ~6 frames).  The frame graph now holds kernel nodes only."""
