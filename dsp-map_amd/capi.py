@@ -18,7 +18,7 @@ MAX_PRED = 16
 OK, REJECTED = 1, 0
 
 P_POSITION_STDDEV, P_VELOCITY_STDDEV, P_OBSERVATION_STDDEV, P_NEWBORN_WEIGHT, P_NEWBORN_NUMBER, \
-    P_VOXEL_FILTER_RES, P_KAPPA, P_DETECTION, P_VELOCITY_ESTIMATOR, P_REGENERATE_TABLES, P_USE_GRAPH = range(1, 12)
+    P_VOXEL_FILTER_RES, P_KAPPA, P_DETECTION, P_VELOCITY_ESTIMATOR, P_REGENERATE_TABLES, P_USE_GRAPH, P_OCCLUSION_MARGIN = range(1, 13)
 
 
 class Config(C.Structure):
@@ -34,6 +34,7 @@ class Config(C.Structure):
         ("device", C.c_int),
         ("gaussian_table_size", C.c_int),
         ("seed", C.c_uint),
+        ("pyramid_neighbor_n", C.c_int), ("safe_particle_factor", C.c_int), ("static_model", C.c_int),
     ]
 
 
@@ -152,8 +153,9 @@ def load_library(path=None):
 
 def make_config(nx=66, ny=66, nz=40, res=0.15, ppv=9, angle=3, half_fov_h=42, half_fov_v=24,
                 pred_times=(0.05, 0.2, 0.5, 1.0, 1.5, 2.0), z_lo=0, z_hi=0, device=-1,
-                table_size=0, seed=0):
+                table_size=0, seed=0, neighbor_n=0, safe_factor=0, static_model=0):
     c = Config()
+    c.pyramid_neighbor_n, c.safe_particle_factor, c.static_model = neighbor_n, safe_factor, static_model
     c.nx, c.ny, c.nz = nx, ny, nz
     c.voxel_resolution = res
     c.angle_resolution = angle

@@ -74,7 +74,10 @@ static void derive_dims(dspmap* m) {
     d.v_base = d.z_lo * c.nx * c.ny;
     d.v_glob = c.nx * c.ny * c.nz;                                     // :62
     d.M = c.max_particle_num_voxel;
-    d.slots = 2 * d.M;                                                 // :65
+    d.slots = (c.safe_particle_factor > 0 ? c.safe_particle_factor : 2) * d.M;   // :65 (x2); dsp_static.h:63 uses x5
+    d.nn = c.pyramid_neighbor_n > 0 ? c.pyramid_neighbor_n : 1;
+    d.nbins = (2 * d.nn + 1) * (2 * d.nn + 1);
+    d.static_model = c.static_model ? 1 : 0;
     d.mw = (d.slots + 63) / 64;
     const int A = c.angle_resolution;
     d.np_h = c.half_fov_h * 2 / A;                                     // :58
@@ -105,6 +108,8 @@ extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
     if (cfg->angle_resolution <= 0 || cfg->max_particle_num_voxel <= 0 || cfg->max_particle_num_voxel > 64) return nullptr;
     if (cfg->prediction_times < 0 || cfg->prediction_times > DSPMAP_MAX_PRED_TIMES) return nullptr;
     if (cfg->z_lo < 0 || cfg->z_hi > cfg->nz || cfg->z_lo > cfg->z_hi) return nullptr;
+    if (cfg->pyramid_neighbor_n < 0 || cfg->pyramid_neighbor_n > 2 || cfg->safe_particle_factor < 0) return nullptr;
+    if ((cfg->safe_particle_factor > 0 ? cfg->safe_particle_factor : 2) * cfg->max_particle_num_voxel > 128) return nullptr;  // two occupancy words
     dspmap* m = new dspmap();
     m->cfg = *cfg;
     derive_dims(m);
@@ -376,6 +381,7 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
         case DSPMAP_P_DETECTION: m->fp.p_det = (float)v; break;
         case DSPMAP_P_VELOCITY_ESTIMATOR: m->use_vel_est = v != 0; break;
         case DSPMAP_P_USE_GRAPH: m->use_graph = v != 0; break;
+        case DSPMAP_P_OCCLUSION_MARGIN: m->fp.occl_margin = (float)v; break;
         case DSPMAP_P_REGENERATE_TABLES:
             // setPredictionVariance regenerates both tables with a fresh seed (:355-360)
             if (v != 0 && !m->tables_injected) {
@@ -399,6 +405,7 @@ extern "C" double dspmap_get_param(const dspmap_t* m, int key) {
         case DSPMAP_P_KAPPA: return m->fp.kappa;
         case DSPMAP_P_DETECTION: return m->fp.p_det;
         case DSPMAP_P_VELOCITY_ESTIMATOR: return m->use_vel_est ? 1 : 0;
+        case DSPMAP_P_OCCLUSION_MARGIN: return m->fp.occl_margin;
         default: return 0;
     }
 }
@@ -662,7 +669,8 @@ extern "C" int dspmap_update(dspmap_t* m, int n, int stride, const float* pts, f
     dspmap_freeze_birth_statics(m);
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
-    const bool have_cloud = m->use_vel_est || m->h_birth_valid;
+    // dsp_static.h has no velocity estimation: every in-FOV point is a zero-velocity birth source
+    const bool have_cloud = !m->cfg.static_model && (m->use_vel_est || m->h_birth_valid);
     fill_pose(m, dp, dt);
     m->hp.n_pts = np; m->hp.n_birth = np; m->hp.static_birth = have_cloud ? 0 : 1;
     m->hp.pts = m->pts_dev; m->hp.birth = m->s.birth;
@@ -674,7 +682,7 @@ extern "C" int dspmap_update(dspmap_t* m, int n, int stride, const float* pts, f
     launch_ck_partial(c);
     launch_weight_update(c);
     int nb = np;
-    if (m->use_vel_est) {
+    if (m->use_vel_est && !m->cfg.static_model) {
         // the reference forks velocityEstimationThread before prediction and joins before the birth
         // stage (:297,311); here the host estimator overlaps with the kernels queued above
         std::vector<float> view;

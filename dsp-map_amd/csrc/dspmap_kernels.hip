@@ -253,8 +253,8 @@ __global__ void __launch_bounds__(512) k_pyr_items(MapDims d, DevState s, int* _
             // observations in the 3x3 neighbourhood: decides how many lanes share one particle in k_weight
             const int h0 = b / d.np_v, v0 = b % d.np_v;
             int O = 0;
-            for (int i = -1; i <= 1; ++i)
-                for (int j = -1; j <= 1; ++j) {
+            for (int i = -d.nn; i <= d.nn; ++i)
+                for (int j = -d.nn; j <= d.nn; ++j) {
                     const int h = h0 + i, v = v0 + j;
                     if (h >= 0 && h < d.np_h && v >= 0 && v < d.np_v) O += s.obs_cnt[h * d.np_v + v];
                 }
@@ -276,49 +276,51 @@ __device__ __forceinline__ int neighbor_bins(const MapDims& d, int b, int* bins)
     // findPyramidNeighborIndexInFOV :1128-1147 (h-major order, clipped at the FOV edge)
     const int h0 = b / d.np_v, v0 = b % d.np_v;
     int n = 0;
-    for (int i = -1; i <= 1; ++i)
-        for (int j = -1; j <= 1; ++j) {
+    for (int i = -d.nn; i <= d.nn; ++i)
+        for (int j = -d.nn; j <= d.nn; ++j) {
             const int h = h0 + i, v = v0 + j;
             if (h >= 0 && h < d.np_h && v >= 0 && v < d.np_v) bins[n++] = h * d.np_v + v;
         }
     return n;
 }
 
-// neighbourhood table of a pyramid in LDS: s_bin[9] bins, s_off[10] exclusive offsets of their
-// observation counts.  The 9 counts are loaded by 9 lanes at once (one memory round trip).
+// neighbourhood table of a pyramid in LDS: s_bin[nbins] bins, s_off[nbins+1] exclusive offsets of their
+// observation counts (nbins = (2*nn+1)^2 <= 25).  The counts are loaded by nbins lanes at once (one round trip).
 __device__ __forceinline__ void neighbor_setup(const MapDims& d, const DevState& s, int b, int* s_bin, int* s_off) {
     const int tid = threadIdx.x;
-    if (tid < 9) {
+    if (tid < 64) {   // first wave (ballot below)
+        const int side = 2 * d.nn + 1;
         const int h0 = b / d.np_v, v0 = b % d.np_v;
-        const int h = h0 + tid / 3 - 1, v = v0 + tid % 3 - 1;
-        const bool ok = h >= 0 && h < d.np_h && v >= 0 && v < d.np_v;
+        const bool lane = tid < d.nbins;
+        const int h = h0 + tid / side - d.nn, v = v0 + tid % side - d.nn;
+        const bool ok = lane && h >= 0 && h < d.np_h && v >= 0 && v < d.np_v;
         const int bin = ok ? h * d.np_v + v : -1;
         const int cnt = ok ? s.obs_cnt[bin] : 0;
         // compact valid neighbours in h-major order (findPyramidNeighborIndexInFOV :1128-1147)
-        const u64 okm = __ballot(ok) & 0x1ffull;
+        const u64 okm = __ballot(ok);
         const int slot = (int)__popcll(okm & ((1ull << tid) - 1ull));
-        s_bin[tid] = -1;
+        if (lane) s_bin[tid] = -1;
         __builtin_amdgcn_s_waitcnt(0);
         if (ok) { s_bin[slot] = bin; s_off[slot] = cnt; }
     }
 }
-__device__ __forceinline__ void neighbor_prefix(int* s_bin, int* s_off) {
+__device__ __forceinline__ void neighbor_prefix(const MapDims& d, int* s_bin, int* s_off) {
     if (threadIdx.x == 0) {
         int off = 0;
-        for (int k = 0; k < 9; ++k) {
+        for (int k = 0; k < d.nbins; ++k) {
             const int c = s_bin[k] >= 0 ? s_off[k] : 0;
             s_off[k] = off;
             off += c;
         }
-        s_off[9] = off;
+        s_off[d.nbins] = off;
     }
 }
 
 __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, FilterParams fp, const int* __restrict__ items,
                                                        const int* __restrict__ n_items) {
     __shared__ float4 s_p[CK_PCH];
-    __shared__ int s_bin[9];
-    __shared__ int s_off[10];
+    __shared__ int s_bin[DSP_MAX_NBINS];
+    __shared__ int s_off[DSP_MAX_NBINS + 1];
     const int tid = threadIdx.x;
     const int total = n_items[0];
     for (int it = blockIdx.x; it < total; it += gridDim.x) {
@@ -330,9 +332,9 @@ __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, Fi
         __syncthreads();  // LDS reuse across items
         neighbor_setup(d, s, b, s_bin, s_off);
         __syncthreads();
-        neighbor_prefix(s_bin, s_off);
+        neighbor_prefix(d, s_bin, s_off);
         __syncthreads();
-        const int O = s_off[9];
+        const int O = s_off[d.nbins];
         if (O == 0) continue;
         for (int i = tid; i < npart; i += CK_TPB) {
             float4 r = s.fov_rec[(size_t)b * d.capp + start + i];
@@ -347,8 +349,7 @@ __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, Fi
         const int g = tid / opad;
         for (int o = tid % opad; o < O; o += opad) {
             int k = 0;
-#pragma unroll
-            for (int q = 1; q < 9; ++q) k += (o >= s_off[q]) ? 1 : 0;
+            for (int q = 1; q < d.nbins; ++q) k += (o >= s_off[q]) ? 1 : 0;
             const int oi = s_bin[k] * DSP_OBS_CAP + (o - s_off[k]);
             const float4 z = s.obs[oi];
             float acc = 0.f;
@@ -384,9 +385,9 @@ __global__ void __launch_bounds__(512) k_ck_sum(MapDims d, DevState s, FilterPar
 // --------------------------------------------------------------------------
 __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, FilterParams fp, const int* __restrict__ items,
                                                    const int* __restrict__ n_items) {
-    __shared__ float4 s_o[9 * DSP_OBS_CAP];
-    __shared__ int s_bin[9];
-    __shared__ int s_off[10];
+    extern __shared__ float4 s_o[];   // [nbins * DSP_OBS_CAP]: the neighbourhood's observations {x, y, z, P_d/Ck}
+    __shared__ int s_bin[DSP_MAX_NBINS];
+    __shared__ int s_off[DSP_MAX_NBINS + 1];
     __shared__ float s_inv[WU_TPB / 64];
     const int tid = threadIdx.x;
     const int total = n_items[1];
@@ -413,13 +414,12 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
         }
         neighbor_setup(d, s, b, s_bin, s_off);
         __syncthreads();
-        neighbor_prefix(s_bin, s_off);
+        neighbor_prefix(d, s_bin, s_off);
         __syncthreads();
-        const int O = s_off[9];
+        const int O = s_off[d.nbins];
         for (int o = tid; o < O; o += WU_TPB) {
             int k = 0;
-#pragma unroll
-            for (int q = 1; q < 9; ++q) k += (o >= s_off[q]) ? 1 : 0;
+            for (int q = 1; q < d.nbins; ++q) k += (o >= s_off[q]) ? 1 : 0;
             const int oi = s_bin[k] * DSP_OBS_CAP + (o - s_off[k]);
             float4 z = s.obs[oi];
             z.w = __fdiv_rn(fp.p_det, s.obs_ck[oi] + add);
@@ -837,7 +837,8 @@ void launch_ck_finalize(const LaunchCtx& c) {  // after launch_weight_update: re
     hipLaunchKernelGGL(k_ck_sum, dim3(1), dim3(512), 0, c.stream, c.d, c.s, c.fp);
 }
 void launch_weight_update(const LaunchCtx& c) {  // after launch_ck_partial (which also builds the item lists)
-    hipLaunchKernelGGL(k_weight, dim3(4096), dim3(WU_TPB), 0, c.stream, c.d, c.s, c.fp, c.k.wu_items, c.k.n_items);
+    hipLaunchKernelGGL(k_weight, dim3(4096), dim3(WU_TPB), sizeof(float4) * (size_t)c.d.nbins * DSP_OBS_CAP, c.stream, c.d, c.s, c.fp,
+                       c.k.wu_items, c.k.n_items);
 }
 
 // n_birth_grid sizes the launches (>= the frame's n_birth, which the kernels read from FrameParams)

@@ -229,11 +229,15 @@ __global__ void __launch_bounds__(NW * 64) k_predict(MapDims d, DevState s, Filt
             const int cell = act ? (int)s_cells[c] : 0;
             const int slot = cell >> 6, ln = cell & 63;
             const unsigned idx = (unsigned)pidx(d, blockIdx.x * 64 + (act ? ln : l), act ? slot : 0);
-            const V2 v2 = ld_vel(s, idx);
+            V2 v2 = ld_vel(s, idx);
             const P3 p3 = ld_pos(s, idx);
             const float w = s.w[idx];
             float px = p3.x, py = p3.y, pz = p3.z;
             int pyr = -1, gv = -1, kind = -1;
+            if (d.static_model) {   // dsp_static.h:640-646
+                if (act && (v2.x != 0.f || v2.y != 0.f)) st_vel(s, idx, 0.f, 0.f);
+                v2.x = 0.f; v2.y = 0.f;
+            }
             if (act) {
                 kind = advance_one(d, s_ph, s_pv, dt, odx, ody, odz, v2.x, v2.y, px, py, pz, blockIdx.x * 64 + ln, pyr, gv);
                 ++c_live;
@@ -285,6 +289,13 @@ __global__ void __launch_bounds__(NW * 64) k_predict(MapDims d, DevState s, Filt
             float vx[RB], vy[RB], px[RB], py[RB], pz[RB];
 #pragma unroll
             for (int r = 0; r < RB; ++r) { vx[r] = vv[r].x; vy[r] = vv[r].y; px[r] = pp[r].x; py[r] = pp[r].y; pz[r] = pp[r].z; }
+            if (d.static_model) {   // dsp_static.h:640-646: velocities forced to zero, positions follow the ego-motion only
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    if (act[r] && (vx[r] != 0.f || vy[r] != 0.f)) st_vel(s, idx[r], 0.f, 0.f);
+                    vx[r] = 0.f; vy[r] = 0.f;
+                }
+            }
             int pyr[RB], mgv[RB];
 #pragma unroll
             for (int r = 0; r < RB; ++r) {

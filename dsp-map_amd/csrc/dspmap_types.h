@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #define DSP_MAX_PRED 16
+#define DSP_MAX_NBINS 25           // neighbourhood bins supported by the pair kernels (radius <= 2)
 #define DSP_OBS_CAP 100            // observation_max_points_num_one_pyramid :69
 #define DSP_MAX_PLANES_H 129       // np_h + 1 boundary planes
 #define DSP_MAX_PLANES_V 97
@@ -37,6 +38,9 @@ struct MapDims {
     int np_h, np_v, np;    // pyramids :58-60
     int capp;              // SAFE_PARTICLE_NUM_PYRAMID :66
     int T;                 // PREDICTION_TIMES :46
+    int nn;                // pyramid neighbourhood radius: 1 = 3x3 (:1135-1136), 2 = 5x5 (dsp_dynamic_multiple_neighbors.h)
+    int nbins;             // (2*nn+1)^2
+    int static_model;      // dsp_static.h's motion model: velocities forced to 0 in prediction
     float res;
     float half_x, half_y, half_z; // :528-530
     float pred_t[DSP_MAX_PRED];

@@ -113,8 +113,24 @@ public:
         cfg.half_fov_h = half_fov_h; cfg.half_fov_v = half_fov_v;
         cfg.prediction_times = PREDICTION_TIMES;
         for (int i = 0; i < PREDICTION_TIMES; i++) cfg.prediction_future_time[i] = prediction_future_time[i];
+        // the reference's two other headers are parameter sets of the same kernels:
+        //   dsp_dynamic_multiple_neighbors.h: -DANGLE_RESOLUTION=1 -DPYRAMID_NEIGHBOR_N=2 (+ its map macros, :38-51)
+        //   dsp_static.h: -DDSPMAP_STATIC_MODEL=1 -DDSPMAP_SAFE_PARTICLE_FACTOR=5 -DPREDICTION_TIMES=1 (:46-47,63,640-646)
+        // both test occlusion with VOXEL_RESOLUTION instead of 0.3 m (:761 there): -DDSPMAP_OCCLUSION_MARGIN=VOXEL_RESOLUTION
+#ifdef PYRAMID_NEIGHBOR_N
+        cfg.pyramid_neighbor_n = PYRAMID_NEIGHBOR_N;
+#endif
+#ifdef DSPMAP_SAFE_PARTICLE_FACTOR
+        cfg.safe_particle_factor = DSPMAP_SAFE_PARTICLE_FACTOR;
+#endif
+#ifdef DSPMAP_STATIC_MODEL
+        cfg.static_model = DSPMAP_STATIC_MODEL;
+#endif
         h_ = dspmap_create(&cfg);
         if (h_) dspmap_set_param(h_, DSPMAP_P_VELOCITY_ESTIMATOR, 1);  // update() runs the velocity estimator like :297
+#ifdef DSPMAP_OCCLUSION_MARGIN
+        if (h_) dspmap_set_param(h_, DSPMAP_P_OCCLUSION_MARGIN, (double)(DSPMAP_OCCLUSION_MARGIN));
+#endif
         cout << "Map is ready to update!" << endl;  // :174
     }
     ~DSPMap() {  // :177-179

@@ -59,6 +59,10 @@ typedef struct dspmap_config {
     int device;                 /* HIP device ordinal, -1 = current device */
     int gaussian_table_size;    /* GAUSSIAN_RANDOMS_NUM :72 (10,000,000); 0 = default */
     unsigned seed;              /* table/rand seed; 0 = time(NULL) like :586,1151 */
+    /* the reference's two other headers as run-time parameters of the same kernels; 0 = dsp_dynamic.h's value */
+    int pyramid_neighbor_n;     /* PYRAMID_NEIGHBOR_N (dsp_dynamic_multiple_neighbors.h:43: 2 -> 5x5 neighbourhood); default 1 */
+    int safe_particle_factor;   /* SAFE_PARTICLE_NUM_VOXEL / MAX_PARTICLE_NUM_VOXEL: default 2 (:65); dsp_static.h:63 uses 5 */
+    int static_model;           /* 1 = dsp_static.h: velocities forced to zero in prediction, every birth source static */
 } dspmap_config;
 
 /* Birth-source point = one entry of the reference's input_cloud_with_velocity
@@ -103,7 +107,8 @@ enum dspmap_param {
     DSPMAP_P_VELOCITY_ESTIMATOR = 9,/* 1 = run the host velocity estimator inside dspmap_update (:297),
                                        0 = births use the caller's cloud / all-static tags */
     DSPMAP_P_REGENERATE_TABLES = 10,/* 1 = setPredictionVariance regenerates the Gaussian tables (:359) */
-    DSPMAP_P_USE_GRAPH = 11         /* 1 (default) = dspmap_update_device replays the frame as a captured HIP graph */
+    DSPMAP_P_USE_GRAPH = 11,        /* 1 (default) = dspmap_update_device replays the frame as a captured HIP graph */
+    DSPMAP_P_OCCLUSION_MARGIN = 12  /* obstacle_thickness_for_occlusion :70 (0.3 m); the reference's two other headers use VOXEL_RESOLUTION */
 };
 
 /* ---- lifecycle: DSPMap::DSPMap / ~DSPMap  dsp_dynamic.h:145-179 ---- */

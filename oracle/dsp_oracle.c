@@ -50,7 +50,9 @@ struct dsp_oracle {
     float* particles;  /* [V][slots][9] */
     float* results;    /* [V][rdim]     */
     int* pyr_lists;    /* [np][capp][3] */
-    int* neighbors;    /* [np][10]      */
+    int* neighbors;    /* [np][nbs]     */
+    int nn, nbs;       /* neighbourhood radius, table stride */
+    float occl_margin;
     float* obs;        /* [np][100][5]  */
     int* obs_count;    /* [np] */
     float* obs_maxlen; /* [np] */
@@ -214,8 +216,9 @@ void dspo_voxel_center(const dsp_oracle* o, int index, float* px, float* py, flo
 static void find_neighbors(const dsp_oracle* o, int index_ori, int* num, int* out) {
     int h0 = index_ori / o->np_v, v0 = index_ori % o->np_v;
     *num = 0;
-    for (int i = -1; i <= 1; ++i)
-        for (int j = -1; j <= 1; ++j) {
+    const int N = o->nn;   /* 1 in dsp_dynamic.h; PYRAMID_NEIGHBOR_N in dsp_dynamic_multiple_neighbors.h:1135-1136 */
+    for (int i = -N; i <= N; ++i)
+        for (int j = -N; j <= N; ++j) {
             int h = h0 + i, v = v0 + j;
             if (h >= 0 && h < o->np_h && v >= 0 && v < o->np_v) {
                 out[*num] = h * o->np_v + v;
@@ -262,7 +265,10 @@ dsp_oracle* dspo_create(const dspo_config* cfg) {
     o->V = cfg->nx * cfg->ny * cfg->nz; /* :62 */
     int pyramid_num = 360 * 180 / A / A;                                         /* :63 */
     int safe_particle_num = (int)((double)o->V * cfg->max_particle_num_voxel + 1e5); /* :64 */
-    o->slots = cfg->max_particle_num_voxel * 2;                                  /* :65 */
+    o->nn = cfg->pyramid_neighbor_n > 0 ? cfg->pyramid_neighbor_n : 1;          /* 3x3; dsp_dynamic_multiple_neighbors.h:43 uses 2 */
+    o->nbs = (2 * o->nn + 1) * (2 * o->nn + 1) + 1;                              /* neighbour table stride, :126-127 */
+    o->occl_margin = 0.3f;                                                       /* obstacle_thickness_for_occlusion :70 */
+    o->slots = cfg->max_particle_num_voxel * (cfg->safe_particle_factor > 0 ? cfg->safe_particle_factor : 2); /* :65; x5 in dsp_static.h:63 */
     o->capp = safe_particle_num / pyramid_num * 2;                               /* :66 */
     o->rdim = 4 + cfg->prediction_times;                                         /* :119 */
     o->res = cfg->voxel_resolution;
@@ -280,7 +286,7 @@ dsp_oracle* dspo_create(const dspo_config* cfg) {
     o->particles = (float*)calloc((size_t)o->V * o->slots * PSTRIDE, sizeof(float));
     o->results = (float*)calloc((size_t)o->V * o->rdim, sizeof(float));
     o->pyr_lists = (int*)calloc((size_t)o->np * o->capp * 3, sizeof(int));
-    o->neighbors = (int*)calloc((size_t)o->np * 10, sizeof(int));
+    o->neighbors = (int*)calloc((size_t)o->np * o->nbs, sizeof(int));
     o->obs = (float*)calloc((size_t)o->np * DSPO_OBS_MAX_PER_PYRAMID * 5, sizeof(float));
     o->obs_count = (int*)calloc((size_t)o->np, sizeof(int));
     o->obs_maxlen = (float*)calloc((size_t)o->np, sizeof(float));
@@ -311,7 +317,7 @@ dsp_oracle* dspo_create(const dspo_config* cfg) {
     memcpy(o->bp_v, o->bp_ori_v, sizeof(float) * (o->np_v + 1) * 3);
     o->quat[0] = 1.f;
     for (int i = 0; i < o->np; i++) /* :581-583 */
-        find_neighbors(o, i, &o->neighbors[i * 10], &o->neighbors[i * 10 + 1]);
+        find_neighbors(o, i, &o->neighbors[i * o->nbs], &o->neighbors[i * o->nbs + 1]);
     for (int i = 0; i < DSPO_PDF_LUT_SIZE; ++i) /* calculateNormalPDFBuffer :1288-1292 */
         o->pdf[i] = standard_normal_pdf((float)(i - 10000) * 0.001f);
     o->use_vel_est = 1;
@@ -359,6 +365,7 @@ int* dspo_obs_count(dsp_oracle* o) { return o->obs_count; }
 float* dspo_obs_max_length(dsp_oracle* o) { return o->obs_maxlen; }
 float dspo_expected_newborn(const dsp_oracle* o) { return o->expected_new_born_objects; }
 void dspo_set_expected_newborn(dsp_oracle* o, float v) { o->expected_new_born_objects = v; }
+void dspo_set_occlusion_margin(dsp_oracle* o, float v) { o->occl_margin = v; }
 float dspo_update_time(const dsp_oracle* o) { return o->update_time; }
 void dspo_use_velocity_estimator(dsp_oracle* o, int on) { o->use_vel_est = on; }
 void dspo_set_current_position(dsp_oracle* o, float x, float y, float z) {
@@ -521,7 +528,9 @@ void dspo_map_prediction(dsp_oracle* o, float odx, float ody, float odz, float d
             float* r = PART(o, v, p);
             if (r[0] > 0.1f && r[0] < 6.f) { /* :649 */
                 r[0] = 1.f;
-                if (fabs(r[1] * r[2] * r[3]) < 1e-6) { /* :653 */
+                if (o->cfg.static_model) {
+                    r[1] = 0.f; r[2] = 0.f; r[3] = 0.f; /* dsp_static.h:640-642: the static motion model */
+                } else if (fabs(r[1] * r[2] * r[3]) < 1e-6) { /* :653 */
                 } else {
                     r[1] += draw_v(o);
                     r[2] += draw_v(o);
@@ -548,7 +557,7 @@ static void map_update_pass1(dsp_oracle* o, int add_const) {
     for (int i = 0; i < o->np; ++i) { /* pass 1, :709-739 */
         for (int j = 0; j < o->obs_count[i]; ++j) {
             float* ob = OBS(o, i, j);
-            const int* nb = o->neighbors + i * 10;
+            const int* nb = o->neighbors + i * o->nbs;
             for (int n = 0; n < nb[0]; ++n) {
                 int b = nb[n + 1];
                 for (int s = 0; s < o->capp; ++s) {
@@ -572,11 +581,11 @@ static void map_update_pass2(dsp_oracle* o) {
         for (int s = 0; s < o->capp; s++) {
             const int* e = PYR(o, i, s);
             if (e[0] & 1) {
-                const int* nb = o->neighbors + i * 10;
+                const int* nb = o->neighbors + i * o->nbs;
                 float* r = PART(o, e[1], e[2]);
                 float px = r[4], py = r[5], pz = r[6];
                 float dist = sqrtf(px * px + py * py + pz * pz);
-                if (o->obs_maxlen[i] > 0.f && dist > o->obs_maxlen[i] + 0.3f) continue; /* :761, obstacle_thickness :70 */
+                if (o->obs_maxlen[i] > 0.f && dist > o->obs_maxlen[i] + o->occl_margin) continue; /* :761, obstacle_thickness :70 */
                 float sum = 0.f;
                 for (int n = 0; n < nb[0]; ++n) {
                     int b = nb[n + 1];
@@ -1067,7 +1076,9 @@ int dspo_update(dsp_oracle* o, int n_pts, int stride, const float* pts, float sx
     dspo_bin_points(o, n_pts, stride, pts, qw, qx, qy, qz);
     /* the reference forks velocityEstimationThread here (:297) and joins at :311;
      * it shares no state with prediction/update, so running it first is equivalent */
-    if (o->use_vel_est == 1) dspo_velocity_estimation(o);
+    /* dsp_static.h has no velocity estimation: every in-FOV point is a zero-velocity birth source (:797-825) */
+    if (o->cfg.static_model) dspo_static_birth_cloud(o);
+    else if (o->use_vel_est == 1) dspo_velocity_estimation(o);
     else if (o->use_vel_est == 2) dspo_static_birth_cloud(o);
     dspo_map_prediction(o, -dx, -dy, -dz, dt); /* :300 */
     if (n_pts >= 0) dspo_map_update(o);        /* :303-307 */

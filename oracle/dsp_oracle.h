@@ -39,6 +39,10 @@ typedef struct dspo_config {
     int half_fov_h, half_fov_v;  /* :49-50 (deg) */
     int prediction_times;        /* PREDICTION_TIMES                   :46 */
     float prediction_future_time[DSPO_MAX_PRED_TIMES]; /* :47 */
+    /* variants of the reference as run-time parameters; 0 = the dsp_dynamic.h value */
+    int pyramid_neighbor_n;      /* PYRAMID_NEIGHBOR_N of dsp_dynamic_multiple_neighbors.h:43 (there 2); default 1 = 3x3 */
+    int safe_particle_factor;    /* SAFE_PARTICLE_NUM_VOXEL / MAX_PARTICLE_NUM_VOXEL: 2 (:65), 5 in dsp_static.h:63 */
+    int static_model;            /* 1 = dsp_static.h's motion model: velocities forced to 0 in prediction and birth */
 } dspo_config;
 
 /* source point handed to the birth stage = reference's input_cloud_with_velocity
@@ -142,6 +146,7 @@ int* dspo_obs_count(dsp_oracle* o);         /* [NP]           observation_num_ea
 float* dspo_obs_max_length(dsp_oracle* o);  /* [NP]           point_cloud_max_length :515 */
 float dspo_expected_newborn(const dsp_oracle* o); /* expected_new_born_objects :292 */
 void dspo_set_expected_newborn(dsp_oracle* o, float v);
+void dspo_set_occlusion_margin(dsp_oracle* o, float v); /* obstacle_thickness_for_occlusion :70 (0.3); the variants use voxel_resolution */
 float dspo_update_time(const dsp_oracle* o);
 int dspo_count_live(const dsp_oracle* o);
 

@@ -24,6 +24,7 @@ class Config(C.Structure):
         ("half_fov_h", C.c_int), ("half_fov_v", C.c_int),
         ("prediction_times", C.c_int),
         ("prediction_future_time", C.c_float * MAX_PRED),
+        ("pyramid_neighbor_n", C.c_int), ("safe_particle_factor", C.c_int), ("static_model", C.c_int),
     ]
 
 
@@ -97,6 +98,7 @@ def _load(fast=False):
         "dspo_particles": (fp, [P]), "dspo_results": (fp, [P]), "dspo_pyramid_lists": (ip, [P]),
         "dspo_obs": (fp, [P]), "dspo_obs_count": (ip, [P]), "dspo_obs_max_length": (fp, [P]),
         "dspo_expected_newborn": (f, [P]), "dspo_set_expected_newborn": (None, [P, f]),
+        "dspo_set_occlusion_margin": (None, [P, f]),
         "dspo_update_time": (f, [P]), "dspo_count_live": (i, [P]),
         "dspo_fill_gaussian_tables": (None, [P, P, i, f, f, C.c_uint]),
         "dspo_preprocess_cloud": (i, [i, P, i, f, i, f, f, f, i, P, ip]),
@@ -129,8 +131,9 @@ def preprocess_cloud(pts, leaf, half, max_points=5000, swap_axes=True):
 
 
 def make_config(nx=66, ny=66, nz=40, res=0.15, ppv=9, angle=3, half_fov_h=42, half_fov_v=24,
-                pred_times=(0.05, 0.2, 0.5, 1.0, 1.5, 2.0)):
+                pred_times=(0.05, 0.2, 0.5, 1.0, 1.5, 2.0), neighbor_n=0, safe_factor=0, static_model=0):
     c = Config()
+    c.pyramid_neighbor_n, c.safe_particle_factor, c.static_model = neighbor_n, safe_factor, static_model
     c.nx, c.ny, c.nz = nx, ny, nz
     c.voxel_resolution = res
     c.angle_resolution = angle

@@ -201,6 +201,76 @@ def test_weight_update_against_oracle(dsp, orc, qi):
     o.close(); m.close()
 
 
+def test_variant_multiple_neighbors_weight_update(dsp, orc):
+    """the reference's dsp_dynamic_multiple_neighbors.h as run-time parameters: 1 degree
+    pyramids, 5x5 neighbourhood (PYRAMID_NEIGHBOR_N = 2, :43,1135-1136), occlusion margin = voxel resolution
+    (:761): Ck and weights against the oracle with the same parameters"""
+    cfg = dict(nx=50, ny=50, nz=30, res=0.2, ppv=30, angle=1, half_fov_v=27, neighbor_n=2)   # that header's :38-51
+    o, m, pts, q, n = _setup_update_scene(dsp, orc, 41, 0, n_particles=40000, **cfg)
+    assert m.NP == 84 * 54
+    o.L.dspo_set_occlusion_margin(o.h, 0.2); m.set_param(dsp.capi.P_OCCLUSION_MARGIN, 0.2)
+    o.bin_points(pts, q); m.bin_points(pts, q)
+    o.predict(-0.01, 0.0, 0.002, 1 / 30.0); m.predict(-0.01, 0.0, 0.002, 1 / 30.0)
+    assert m.counters()["n_voxel_full"] == 0 and m.counters()["n_pyramid_full"] == 0
+    o.map_update(); m.map_update()
+    obs, cnt, ml, lam = m.observations()
+    assert np.array_equal(cnt, o.obs_count)
+    ck_o = np.concatenate([o.obs[b, :cnt[b], 3] for b in np.nonzero(cnt)[0]])
+    ck_g = np.concatenate([obs[b, :cnt[b], 3] for b in np.nonzero(cnt)[0]])
+    rel = np.abs(ck_g - ck_o) / ck_o
+    assert rel.max() < RTOL and np.median(rel) < 1e-6
+    vo, so, ro = o.export_sparse()
+    vg, sg, rg = gpu_state(m)
+    a_v, a_r = common.sorted_records(vo, ro, cols=(4, 5, 6, 1, 2))
+    b_v, b_r = common.sorted_records(vg, rg, cols=(4, 5, 6, 1, 2))
+    assert np.array_equal(a_v, b_v)
+    relw = np.abs(a_r[:, 7] - b_r[:, 7]) / np.maximum(np.abs(a_r[:, 7]), 1e-12)
+    assert relw.max() < RTOL, relw.max()
+    # the wider neighbourhood really is in effect: with the 3x3 default the weights differ
+    o3, m3, _, _, _ = _setup_update_scene(dsp, orc, 41, 0, n_particles=40000, **dict(cfg, neighbor_n=0))
+    m3.set_param(dsp.capi.P_OCCLUSION_MARGIN, 0.2)
+    m3.bin_points(pts, q); m3.predict(-0.01, 0.0, 0.002, 1 / 30.0); m3.map_update()
+    v3, s3, r3 = gpu_state(m3)
+    _, c_r = common.sorted_records(v3, r3, cols=(4, 5, 6, 1, 2))
+    assert (np.abs(c_r[:, 7] - b_r[:, 7]) > 1e-3 * np.abs(b_r[:, 7])).mean() > 0.05
+    o.close(); m.close(); o3.close(); m3.close()
+
+
+def test_variant_static_model(dsp, orc):
+    """the reference's dsp_static.h as run-time parameters: 5 x MAX_PARTICLE_NUM_VOXEL slots (:63), one prediction
+    horizon (:46-47), velocities forced to zero in the prediction (:640-646), every birth source static (:797-825),
+    occlusion margin = voxel resolution: prediction from an injected state with velocities, then a short run"""
+    cfg = dict(nx=30, ny=30, nz=16, res=0.2, ppv=10, half_fov_v=27, pred_times=(0.05,), safe_factor=5, static_model=1)
+    o, m = make_pair(dsp, orc, **cfg)
+    assert m.slots == 50 and m.T == 1
+    for x in (o, ):
+        x.L.dspo_set_occlusion_margin(x.h, 0.2)
+    m.set_param(dsp.capi.P_OCCLUSION_MARGIN, 0.2)
+    half = common.half_extent(o.cfg)
+    px, py, pz, vx, vy, w = common.random_particles(5, 20000, (half[0] * 0.9, half[1] * 0.9, half[2] * 0.9), vmax=1.0, static_frac=0.3)
+    common.inject_both(o, m, px, py, pz, vx, vy, w)
+    o.predict(-0.02, 0.01, 0.0, 1 / 30.0); m.predict(-0.02, 0.01, 0.0, 1 / 30.0)
+    vo, so, ro = o.export_sparse()
+    vg, sg, rg = gpu_state(m)
+    a_v, a_r = common.sorted_records(vo, ro, cols=(4, 5, 6))
+    b_v, b_r = common.sorted_records(vg, rg, cols=(4, 5, 6))
+    assert np.array_equal(a_v, b_v) and np.array_equal(a_r[:, 4:7], b_r[:, 4:7])     # moved by the ego-motion only
+    assert not rg[:, 1:4].any() and not ro[:, 1:4].any()                              # velocities are gone
+    o.close(); m.close()
+    # a short run: same occupancy as the oracle with the same parameters (no estimator in this model)
+    o, m = make_pair(dsp, orc, **cfg)
+    o.L.dspo_set_occlusion_margin(o.h, 0.2); m.set_param(dsp.capi.P_OCCLUSION_MARGIN, 0.2)
+    m.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, 1)       # ignored by the static model
+    base = common.wall_cloud(3, n_side=40, dist=2.0, half_w=1.6, half_h=0.8)
+    for f in range(4):
+        assert o.update(base, (0.01 * f, 0, 0), f / 30.0, (1, 0, 0, 0)) == 1
+        assert m.update(base, (0.01 * f, 0, 0), f / 30.0, (1, 0, 0, 0)) == 1
+    mo, mg = o.results[:, 0].astype(np.float64).sum(), m.results()[:, 0].astype(np.float64).sum()
+    assert mo > 10 and abs(mg - mo) < 5e-3 * mo
+    assert np.count_nonzero(m.results()[:, 1:3]) == 0                                 # mean velocities are zero
+    o.close(); m.close()
+
+
 def test_unobserved_and_occluded_particles(dsp, orc):
     """Appendix A-6: occluded particles keep their weight; particles in pyramids without any
     observation get w *= (1-Pd) + neighbour terms"""
