@@ -28,7 +28,7 @@ for W in B C_sat; do
 done
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/cal_$C
-  (cd $R && rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/cal_$C -- python scratch/calib.py > /tmp/cal_$C.log 2>&1)
+  (cd $R && rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/cal_$C -- python tools/calib.py > /tmp/cal_$C.log 2>&1)
   python $R/profiles/pmc_reduce.py $(find /tmp/cal_$C -name "*counter_collection.csv" | head -1) $R/gpurun_out/${TAG}_cal_$C.json > /dev/null
   grep bytes /tmp/cal_$C.log > $R/gpurun_out/${TAG}_cal_bytes.txt
 done
