@@ -88,15 +88,26 @@ struct PointCloud {
 #endif
 #ifndef PREDICTION_TIMES
 #define PREDICTION_TIMES 6
-static const float prediction_future_time[PREDICTION_TIMES] = {0.05f, 0.2f, 0.5f, 1.f, 1.5f, 2.f};
+#define DSPMAP_PREDICTION_TIME_LIST 0.05f, 0.2f, 0.5f, 1.f, 1.5f, 2.f
+#elif PREDICTION_TIMES == 1 && !defined(DSPMAP_PREDICTION_TIME_LIST)
+#define DSPMAP_PREDICTION_TIME_LIST 0.05f   /* dsp_static.h:46-47 */
 #endif
+#ifdef DSPMAP_PREDICTION_TIME_LIST
+static const float prediction_future_time[PREDICTION_TIMES] = {DSPMAP_PREDICTION_TIME_LIST};
+#endif  /* otherwise the including file defines prediction_future_time[PREDICTION_TIMES] before this header */
 #if !LIMIT_MOVEMENT_IN_XY_PLANE
 #error "libdspmap_hip implements the reference's default LIMIT_MOVEMENT_IN_XY_PLANE 1 (vz == 0)"
 #endif
 
 static const int VOXEL_NUM = MAP_LENGTH_VOXEL_NUM * MAP_WIDTH_VOXEL_NUM * MAP_HEIGHT_VOXEL_NUM;  // :62
-static const int half_fov_h = 42;  // :49
-static const int half_fov_v = 24;  // :50
+#ifndef DSPMAP_HALF_FOV_H
+#define DSPMAP_HALF_FOV_H 42
+#endif
+#ifndef DSPMAP_HALF_FOV_V
+#define DSPMAP_HALF_FOV_V 24   /* 27 in the reference's two other headers */
+#endif
+static const int half_fov_h = DSPMAP_HALF_FOV_H;  // :49
+static const int half_fov_v = DSPMAP_HALF_FOV_V;  // :50
 
 class DSPMap {
 public:

@@ -100,6 +100,15 @@ def test_dropin_header_compiles_without_ros(dsp):
                            os.path.join(ROOT, "examples", "map_example.cpp"),
                            "-L" + os.path.join(ROOT, "dsp-map_amd", "lib"), "-ldspmap_hip",
                            "-Wl,-rpath," + os.path.join(ROOT, "dsp-map_amd", "lib"), "-o", exe])
+    # the reference's two other headers as macro sets in front of the same header
+    for macros in (["-DMAP_LENGTH_VOXEL_NUM=50", "-DMAP_WIDTH_VOXEL_NUM=50", "-DMAP_HEIGHT_VOXEL_NUM=30", "-DVOXEL_RESOLUTION=0.2",
+                    "-DANGLE_RESOLUTION=1", "-DPYRAMID_NEIGHBOR_N=2", "-DMAX_PARTICLE_NUM_VOXEL=30", "-DDSPMAP_HALF_FOV_V=27",
+                    "-DDSPMAP_OCCLUSION_MARGIN=VOXEL_RESOLUTION"],
+                   ["-DMAP_LENGTH_VOXEL_NUM=50", "-DMAP_WIDTH_VOXEL_NUM=50", "-DMAP_HEIGHT_VOXEL_NUM=30", "-DVOXEL_RESOLUTION=0.2",
+                    "-DMAX_PARTICLE_NUM_VOXEL=10", "-DDSPMAP_STATIC_MODEL=1", "-DDSPMAP_SAFE_PARTICLE_FACTOR=5",
+                    "-DPREDICTION_TIMES=1", "-DDSPMAP_HALF_FOV_V=27", "-DDSPMAP_OCCLUSION_MARGIN=VOXEL_RESOLUTION"]):
+        subprocess.check_call(["g++", "-std=c++14", "-Wall", "-fsyntax-only", "-I" + os.path.join(ROOT, "include")] + macros +
+                              [os.path.join(ROOT, "examples", "map_example.cpp")])
     hdr = open(os.path.join(ROOT, "include", "dsp_dynamic.h")).read()
     for member in ("int update(int point_cloud_num, int size_of_one_point, float* point_cloud_ptr",
                    "void setPredictionVariance(float p_stddev, float v_stddev)", "void setObservationStdDev(",
