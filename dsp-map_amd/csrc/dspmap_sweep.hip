@@ -143,7 +143,7 @@ __device__ __forceinline__ int advance_one(const MapDims& d, const float* s_ph, 
 }
 
 template <int MW, int NW>
-__global__ void __launch_bounds__(NW * 64) k_predict(MapDims d, DevState s, FilterParams fp, int has_vz, int* __restrict__ part,
+__global__ void __launch_bounds__(NW * 64, MW == 2 ? 5 : 1) k_predict(MapDims d, DevState s, FilterParams fp, int has_vz, int* __restrict__ part,
                                                  float4* __restrict__ mv_rec, float4* __restrict__ in_rec, int* __restrict__ in_cnt,
                                                  u64* __restrict__ expmask) {
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
