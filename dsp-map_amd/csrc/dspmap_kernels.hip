@@ -124,6 +124,7 @@ __global__ void __launch_bounds__(256) k_obs_points(MapDims d, DevState s) {
     }
 }
 
+#define GU 16
 // k_obs_gather: one wave per pyramid.  Appends matching points in INPUT order
 // (stable, ballot + prefix popcount) to the pyramid's bin, keeps the first 99
 // (count saturates, :279-284), tracks the max range over ALL matches (:275-277).
@@ -133,15 +134,15 @@ __global__ void k_obs_gather(MapDims d, DevState s) {
     const int l = lane_id();
     int count = 0;
     float maxlen = -1.f;
-    for (int base = 0; base < n_pts; base += 4 * WAVE) {
-        int pid[4];
+    for (int base = 0; base < n_pts; base += GU * WAVE) {
+        int pid[GU];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {  // four independent loads in flight
+        for (int k = 0; k < GU; ++k) {  // GU independent loads in flight: the scan is a chain of L2 round trips
             const int i = base + k * WAVE + l;
             pid[k] = i < n_pts ? s.pt_pyr[i] : -1;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < GU; ++k) {
             const int i = base + k * WAVE + l;
             const bool match = pid[k] == b;
             const u64 m = __ballot(match);
