@@ -777,6 +777,38 @@ def test_checkpoint_restore(dsp, tmp_path):
     a.close(); b.close(); c.close()
 
 
+def test_constructor_prefill_random_particles(dsp, orc):
+    """DSPMap(init_particle_num, init_weight) (:145,594-624): addRandomParticles draws 6 rand() values per particle
+    (position over the map box, velocity in +-1 m/s incl. vz), newborn flag.  Same rand() table -> the same
+    particles; they are first predicted in the SECOND frame, where the velocity-noise branch (:653-659) is live."""
+    cfgkw = dict(nx=30, ny=30, nz=16, ppv=10)
+    o, m = make_pair(dsp, orc, **cfgkw)
+    n = 12000
+    o.L.dspo_add_random_particles(o.h, n, 0.01)
+    m._chk(m.L.dspmap_add_random_particles(m.h, n, 0.01))
+    vo, so, ro = o.export_sparse()
+    vg, sg, rg = gpu_state(m)
+    a_v, a_r = common.sorted_records(vo, ro, cols=(4, 5, 6, 1, 2, 3))
+    b_v, b_r = common.sorted_records(vg, rg, cols=(4, 5, 6, 1, 2, 3))
+    assert len(a_v) == len(b_v) > 0.9 * n
+    assert np.array_equal(a_v, b_v) and np.array_equal(a_r[:, 1:8], b_r[:, 1:8])     # same draws, same voxels
+    assert set(np.unique(rg[:, 0]).tolist()) == {15.0} and np.abs(rg[:, 3]).max() > 0.5   # newborn flag, vz present
+    base = common.wall_cloud(2, n_side=30, dist=1.6, half_w=1.2, half_h=0.7)
+    for f in range(3):
+        assert o.update(base, (0.01 * f, 0, 0), f / 30.0, (1, 0, 0, 0)) == 1
+        assert m.update(base, (0.01 * f, 0, 0), f / 30.0, (1, 0, 0, 0)) == 1
+    vg, sg, rg = gpu_state(m)
+    vo, so, ro = o.export_sparse()
+    assert not rg[:, 3].any()                                   # vz is gone after the first prediction (:661-663)
+    assert abs(len(vg) - len(vo)) <= 0.03 * len(vo)
+    mo, mg = o.results[:, 0].astype(np.float64).sum(), m.results()[:, 0].astype(np.float64).sum()
+    assert abs(mg - mo) < 0.02 * mo
+    # the velocity noise was applied: seeded particles no longer carry their original velocities
+    seeded = rg[np.abs(rg[:, 1]) + np.abs(rg[:, 2]) > 0]
+    assert len(seeded) > 1000
+    o.close(); m.close()
+
+
 def test_graph_replay_with_foreign_kernels_between_frames(dsp):
     """regression: a memset node inside the captured frame graph faulted as soon as another stream ran
     kernels between two replays (large map, ~6 frames).  The frame graph now holds kernel nodes only."""
