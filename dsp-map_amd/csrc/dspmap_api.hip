@@ -137,7 +137,7 @@ static void free_dev(dspmap* m) {
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.nstatic, s.fov_rec, s.fov_slot, s.pyr_cnt, s.mv_rec, s.exp_up, s.exp_down,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.in_rec, m->k.in_cnt, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.expmask,
-                    m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.work_count, m->k.child, m->k.part_birth, m->pts_dev};
+                    m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.work_count, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->pp_box) (void)hipFree(m->pp_box);
     if (m->pp_acc) (void)hipFree(m->pp_acc);
@@ -840,6 +840,7 @@ static int ensure_vz(dspmap* m) {
         const size_t S = (((size_t)m->d.v_loc + 63) / 64) * 64 * m->d.slots;
         HIPCHK(m, dalloc(&m->s.vz0, S));
         HIPCHK(m, hipMemset(m->s.vz0, 0, sizeof(float) * S));
+        if (!m->k.vz_q) HIPCHK(m, dalloc(&m->k.vz_q, (size_t)m->d.v_loc * m->d.mw));
     }
     m->vz_frames = 2;  // seeded (flag 15) particles are first predicted in the second frame
     return DSPMAP_OK;
@@ -917,8 +918,13 @@ extern "C" int dspmap_add_random_particles(dspmap_t* m, int n, float weight) {
     if (n < 0) return DSPMAP_E_ARG;
     int rc = ensure_vz(m);
     if (rc != DSPMAP_OK) return rc;
+    if ((long long)m->d.v_loc >= (1ll << 24)) return dspmap_fail(m, DSPMAP_E_ARG, "constructor pre-fill supports up to 2^24 voxels per handle");
     LaunchCtx c = dspmap_ctx_of(m);
-    launch_add_random(c, n, weight);
+    int* slot_of = nullptr;
+    HIPCHK(m, dalloc(&slot_of, (size_t)(n > 0 ? n : 1)));
+    launch_add_random(c, n, weight, slot_of);
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    (void)hipFree(slot_of);
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
 }

@@ -6,6 +6,7 @@
 // scratch owned by the runtime
 struct KernelScratch {
     float4* mv_rec;     // [ntiles][64*slots][2] per-source-tile staging of k_predict (movers up, in-FOV stayers down)
+    unsigned long long* vz_q;       // [v_loc*mw] (with vz0) slots that draw velocity noise in their first prediction
     float4* in_rec;     // [ntiles][64*slots][2] per-destination-tile inbox of movers (k_predict tail -> k_place)
     int* in_cnt;        // [ntiles] inbox fill; zeroed again by k_place
     u64* expmask;       // [v_loc*mw] particles that left the slab (multi-GPU), or nullptr
@@ -42,6 +43,7 @@ void launch_setup_and_bin(const LaunchCtx& c, int n_pts_grid);
 // mapPrediction (:627-701) incl. re-binning of movers (moveParticle :1206-1274)
 void launch_predict(const LaunchCtx& c);
 void launch_predict_only(const LaunchCtx& c);
+void launch_scan_blocks(const LaunchCtx& c, int nblk);   // exclusive scan of s.blk_cnt[0..nblk), total -> fs->occupied_count
 void launch_claim(const LaunchCtx& c);
 void launch_reduce_counters(const LaunchCtx& c);
 void launch_calib(const LaunchCtx& c, int mode, size_t n);
@@ -66,4 +68,4 @@ void launch_future_combine(const LaunchCtx& c);  // fold the static-particle fut
 void launch_seed_uniform(const LaunchCtx& c, int per_voxel, float weight, unsigned seed, float vmax);
 void launch_import(const LaunchCtx& c, int n, const int* voxel_dev, const int* slot_dev, const float* rec8_dev, int* n_failed_dev);
 void launch_export(const LaunchCtx& c, int* voxel_out, int* slot_out, float* rec8_out, int* count_dev, int cap);
-void launch_add_random(const LaunchCtx& c, int n, float weight);
+void launch_add_random(const LaunchCtx& c, int n, float weight, int* slot_of_tmp /* [n] device scratch */);

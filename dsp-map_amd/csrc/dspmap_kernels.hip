@@ -872,6 +872,9 @@ void launch_birth(const LaunchCtx& c, int n_birth_grid, bool in_frame, bool all_
     launch_birth_plan_insert(c, n_birth_grid, in_frame, all_static);
 }
 
+void launch_scan_blocks(const LaunchCtx& c, int nblk) {
+    hipLaunchKernelGGL(k_occ_scan, dim3(1), dim3(1024), 0, c.stream, c.s, nblk);
+}
 void launch_occupied_compact(const LaunchCtx& c, float thr) {
     const int nblk = (c.d.v_loc + 255) / 256;
     hipLaunchKernelGGL(k_occ_count, dim3(nblk), dim3(256), 0, c.stream, c.d, c.s, thr);

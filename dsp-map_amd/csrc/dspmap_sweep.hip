@@ -126,6 +126,39 @@ __device__ __forceinline__ u64 rows_of_wave(u64 tor, int wave) {
 //   advanced exactly once (the role of flag 7, :649,1219).
 // part[blockIdx*4 + {0,1,2,3}] = {live in, left the map, pyramid full, moved}
 // --------------------------------------------------------------------------
+// First prediction of constructor-seeded particles: the reference draws the velocity noise (:653-659) from the
+// table in SWEEP order (voxel-major, slot-minor), 3 values per particle whose |vx*vy*vz| >= 1e-6.  k_vz_count ranks
+// those particles: per-voxel counts -> exclusive prefix inside a 256-voxel block (vz_pre) + block totals (blk_cnt,
+// scanned by k_occ_scan).  Only runs in the rare frames in which a vz array exists.
+template <int MW>
+__global__ void __launch_bounds__(256) k_vz_count(MapDims d, DevState s, int* __restrict__ vz_pre, u64* __restrict__ vz_q) {
+    __shared__ int s_w[4];
+    const int lv = blockIdx.x * 256 + threadIdx.x;
+    int q = 0;
+    if (lv < d.v_loc) {
+#pragma unroll
+        for (int e = 0; e < MW; ++e) {
+            u64 live = s.mask[(size_t)lv * MW + e] & ~s.nbmask[(size_t)lv * MW + e];
+            u64 qual = 0ull;
+            while (live) {
+                const int b = __ffsll((long long)live) - 1;
+                live &= live - 1ull;
+                const size_t idx = pidx(d, lv, e * 64 + b);
+                const V2 v = ld_vel(s, idx);
+                if (!(fabs((double)(v.x * v.y * s.vz0[idx])) < 1e-6)) { ++q; qual |= 1ull << b; }
+            }
+            vz_q[(size_t)lv * MW + e] = qual;   // which slots draw noise: k_predict ranks with popcounts, no re-reads
+        }
+    }
+    const int inc = wave_incl_scan_i(q);
+    if (lane_id() == 63) s_w[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int off = 0;
+    for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) off += s_w[k];
+    if (lv < d.v_loc) vz_pre[lv] = off + inc - q;
+    if (threadIdx.x == 255) s.blk_cnt[blockIdx.x] = off + inc;
+}
+
 // one particle of mapPrediction: advance (:665-667, vz forced to 0 :662), classify.
 // returns 0 = left the map (:688), 1 = stays in its voxel (pyr = its pyramid or -1), 2 = changed voxel (gv = the
 // new global voxel), 3 = left this rank's slab (multi-GPU)
@@ -145,7 +178,7 @@ __device__ __forceinline__ int advance_one(const MapDims& d, const float* s_ph, 
 template <int MW, int NW>
 __global__ void __launch_bounds__(NW * 64, MW == 2 ? 5 : 1) k_predict(MapDims d, DevState s, FilterParams fp, int has_vz, int* __restrict__ part,
                                                  float4* __restrict__ mv_rec, float4* __restrict__ in_rec, int* __restrict__ in_cnt,
-                                                 u64* __restrict__ expmask) {
+                                                 u64* __restrict__ expmask, const int* __restrict__ vz_pre, const u64* __restrict__ vz_q) {
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
     __shared__ u64 s_keep[MW * 64], s_ex[MW * 64];
@@ -307,7 +340,17 @@ __global__ void __launch_bounds__(NW * 64, MW == 2 ? 5 : 1) k_predict(MapDims d,
                         // constructor-seeded particles on their first step
                         const float vz = s.vz0[idx[r]];
                         if (!(fabs((double)(vx[r] * vy[r] * vz)) < 1e-6)) {
-                            const int c = (int)(((long long)s.fs->v_cur + 3ll * (long long)((size_t)(lv + d.v_base) * d.slots + e * 64 + row[r])) % fp.tab_n);
+                            // rank in the reference's sweep order: qualifying particles of earlier voxels (k_vz_count +
+                            // k_occ_scan) + those in lower slots of this voxel
+                            int rank = s.blk_cnt[lv >> 8] + vz_pre[lv];
+#pragma unroll
+                            for (int e2 = 0; e2 < MW; ++e2) {
+                                u64 qm = vz_q[(size_t)lvs * MW + e2];
+                                if (e2 == e) qm &= (1ull << row[r]) - 1ull;
+                                else if (e2 > e) qm = 0ull;
+                                rank += (int)__popcll(qm);
+                            }
+                            const int c = (int)(((long long)s.fs->v_cur + 3ll * (long long)rank) % fp.tab_n);
                             vx[r] += s.v_tab[c];
                             vy[r] += s.v_tab[(c + 1) % fp.tab_n];
                             st_vel(s, idx[r], vx[r], vy[r]);
@@ -467,7 +510,9 @@ __global__ void __launch_bounds__(NW * 64, MW == 2 ? 5 : 1) k_predict(MapDims d,
 // --------------------------------------------------------------------------
 template <int MW>
 __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const float4* __restrict__ in_rec,
-                                               int* __restrict__ in_cnt, int* __restrict__ part2) {
+                                               int* __restrict__ in_cnt, int* __restrict__ part2, int has_vz, int tab_n) {
+    if (has_vz && blockIdx.x == 0 && threadIdx.x == 0)   // k_predict drew 3 table values per ranked particle (:655-657)
+        s.fs->v_cur = (int)(((long long)s.fs->v_cur + 3ll * (long long)s.fs->occupied_count) % tab_n);
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
     __shared__ u64 s_mask[MW * 64], s_new[MW * 64];
@@ -919,27 +964,79 @@ __device__ __forceinline__ float rand_float_t(const DevState& s, const FilterPar
     const int r = s.r_tab[c % max(fp.rtab_n, 1)];
     return lo + __fdiv_rn((float)r, __fdiv_rn((float)2147483647, (hi - lo)));
 }
-// addRandomParticles :594-624 from the rand() table: 6 draws per particle, newborn flag (addAParticle)
-__global__ void k_add_random(MapDims d, DevState s, FilterParams fp, int n, float weight) {
+// addRandomParticles :594-624 from the rand() table: 6 draws per particle, newborn flag (addAParticle).
+// The reference adds the particles one after another, so particle i takes the first free slot left by particles
+// < i of the same voxel.  Three passes reproduce exactly that placement without a sort: (1) every particle enters
+// its voxel's bucket, (2) it ranks itself among the bucket's particle indices and takes the rank-th free slot of
+// the voxel's occupancy before the call (read-only in this pass), (3) the newborn bits are set.
+#define SEED_BUCKET_CAP 128
+struct SeedDraw { float px, py, pz, vx, vy, vz; int lv; };
+__device__ __forceinline__ SeedDraw seed_draw(const MapDims& d, const DevState& s, const FilterParams& fp, int i) {
+    const int c = s.fs->r_cur + 6 * i;
+    SeedDraw r;
+    r.px = rand_float_t(s, fp, c, -d.half_x, d.half_x);
+    r.py = rand_float_t(s, fp, c + 1, -d.half_y, d.half_y);
+    r.pz = rand_float_t(s, fp, c + 2, -d.half_z, d.half_z);
+    r.vx = rand_float_t(s, fp, c + 3, -1.f, 1.f);
+    r.vy = rand_float_t(s, fp, c + 4, -1.f, 1.f);
+    r.vz = rand_float_t(s, fp, c + 5, -1.f, 1.f);
+    int gv;
+    r.lv = -1;
+    if (voxel_of(d, r.px, r.py, r.pz, gv)) {
+        const int lv = gv - d.v_base;
+        if (lv >= 0 && lv < d.v_loc) r.lv = lv;
+    }
+    return r;
+}
+__global__ void k_add_random_bucket(MapDims d, DevState s, FilterParams fp, int n, int* __restrict__ vb_cnt, int* __restrict__ vb_idx) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int c = s.fs->r_cur + 6 * i;
-    const float px = rand_float_t(s, fp, c, -d.half_x, d.half_x);
-    const float py = rand_float_t(s, fp, c + 1, -d.half_y, d.half_y);
-    const float pz = rand_float_t(s, fp, c + 2, -d.half_z, d.half_z);
-    const float vx = rand_float_t(s, fp, c + 3, -1.f, 1.f);
-    const float vy = rand_float_t(s, fp, c + 4, -1.f, 1.f);
-    const float vz = rand_float_t(s, fp, c + 5, -1.f, 1.f);
-    int gv;
-    if (!voxel_of(d, px, py, pz, gv)) return;
-    const int lv = gv - d.v_base;
-    if (lv < 0 || lv >= d.v_loc) return;
-    const int sl = claim_slot(s.mask, lv, d);
-    if (sl < 0) return;
-    const size_t idx = pidx(d, lv, sl);
-    st_pos(s, idx, px, py, pz); st_vel(s, idx, vx, vy); s.w[idx] = weight;
-    if (s.vz0) s.vz0[idx] = vz;
-    atomicOr(&s.nbmask[(size_t)lv * d.mw + (sl >> 6)], 1ull << (sl & 63));
+    const SeedDraw r = seed_draw(d, s, fp, i);
+    if (r.lv < 0) return;
+    const int pos = atomicAdd(&vb_cnt[r.lv], 1);
+    if (pos < SEED_BUCKET_CAP) vb_idx[(size_t)r.lv * SEED_BUCKET_CAP + pos] = i;
+}
+__global__ void k_add_random_place(MapDims d, DevState s, FilterParams fp, int n, float weight, const int* __restrict__ vb_cnt,
+                                   const int* __restrict__ vb_idx, int* __restrict__ slot_of) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    slot_of[i] = -1;
+    const SeedDraw r = seed_draw(d, s, fp, i);
+    if (r.lv < 0) return;
+    const int nb = min(vb_cnt[r.lv], SEED_BUCKET_CAP);
+    int rank = 0;
+    bool recorded = false;
+    for (int j = 0; j < nb; ++j) {
+        const int o = vb_idx[(size_t)r.lv * SEED_BUCKET_CAP + j];
+        rank += o < i ? 1 : 0;
+        recorded |= o == i;
+    }
+    if (!recorded) return;   // beyond the bucket: more than 128 earlier particles in this voxel -> it is full
+    int sl = -1;
+    for (int e = 0; e < d.mw && sl < 0; ++e) {
+        const int nbits = min(64, d.slots - e * 64);
+        const u64 valid = nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
+        u64 fr = ~(s.mask[(size_t)r.lv * d.mw + e] | s.nbmask[(size_t)r.lv * d.mw + e]) & valid;
+        const int nf = (int)__popcll(fr);
+        if (rank >= nf) { rank -= nf; continue; }
+        for (int q = 0; q < rank; ++q) fr &= fr - 1ull;
+        sl = e * 64 + (__ffsll((long long)fr) - 1);
+    }
+    if (sl < 0) return;      // voxel full :1198-1200
+    const size_t idx = pidx(d, r.lv, sl);
+    st_pos(s, idx, r.px, r.py, r.pz); st_vel(s, idx, r.vx, r.vy); s.w[idx] = weight;
+    if (s.vz0) s.vz0[idx] = r.vz;
+    slot_of[i] = (r.lv << 7) | sl;
+}
+__global__ void k_add_random_commit(MapDims d, DevState s, int n, const int* __restrict__ slot_of) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || slot_of[i] < 0) return;
+    const int lv = slot_of[i] >> 7, sl = slot_of[i] & 127;
+    atomicOr(&s.nbmask[(size_t)lv * d.mw + (sl >> 6)], 1ull << (sl & 63));   // flag 15
+}
+__global__ void k_zero_ints(int* __restrict__ p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
 }
 __global__ void k_advance_rcur(DevState s, FilterParams fp, int by) {
     if (threadIdx.x == 0 && blockIdx.x == 0) s.fs->r_cur = (int)(((long long)s.fs->r_cur + by) % max(fp.rtab_n, 1));
@@ -1099,17 +1196,23 @@ __global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScra
 // ==========================================================================
 void launch_predict_only(const LaunchCtx& c) {
     const KernelScratch* k = &c.k;
+    if (c.s.vz0) {   // constructor-seeded particles take their velocity noise in the reference's sweep order
+        const int nblk = (c.d.v_loc + 255) / 256;
+        if (c.d.mw == 1) hipLaunchKernelGGL(k_vz_count<1>, dim3(nblk), dim3(256), 0, c.stream, c.d, c.s, k->work_list, k->vz_q);
+        else hipLaunchKernelGGL(k_vz_count<2>, dim3(nblk), dim3(256), 0, c.stream, c.d, c.s, k->work_list, k->vz_q);
+        launch_scan_blocks(c, nblk);   // blk_cnt -> exclusive, total -> fs->occupied_count
+    }
     if (c.d.mw == 1)
         hipLaunchKernelGGL((k_predict<1, 4>), dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, c.fp,
-                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask);
+                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q);
     else
         hipLaunchKernelGGL((k_predict<2, 4>), dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, c.fp,
-                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask);
+                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q);
 }
 void launch_claim(const LaunchCtx& c) {
     const KernelScratch* k = &c.k;
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim);
-    else hipLaunchKernelGGL(k_place<2>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim);
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n);
+    else hipLaunchKernelGGL(k_place<2>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n);
 }
 void launch_predict(const LaunchCtx& c) {
     launch_predict_only(c);
@@ -1135,9 +1238,13 @@ void launch_export(const LaunchCtx& c, int* voxel_out, int* slot_out, float* rec
     const size_t total = (size_t)c.d.v_loc * c.d.slots;
     hipLaunchKernelGGL(k_export, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, c.d, c.s, voxel_out, slot_out, rec8_out, count_dev, cap);
 }
-void launch_add_random(const LaunchCtx& c, int n, float weight) {
+void launch_add_random(const LaunchCtx& c, int n, float weight, int* slot_of_tmp) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_add_random, dim3((n + 255) / 256), dim3(256), 0, c.stream, c.d, c.s, c.fp, n, weight);
+    const dim3 g((n + 255) / 256), b(256);
+    hipLaunchKernelGGL(k_add_random_bucket, g, b, 0, c.stream, c.d, c.s, c.fp, n, c.k.vb_cnt, c.k.vb_idx);
+    hipLaunchKernelGGL(k_add_random_place, g, b, 0, c.stream, c.d, c.s, c.fp, n, weight, c.k.vb_cnt, c.k.vb_idx, slot_of_tmp);
+    hipLaunchKernelGGL(k_add_random_commit, g, b, 0, c.stream, c.d, c.s, n, slot_of_tmp);
+    hipLaunchKernelGGL(k_zero_ints, dim3((c.d.v_loc + 255) / 256), b, 0, c.stream, c.k.vb_cnt, c.d.v_loc);   // buckets empty again
     hipLaunchKernelGGL(k_advance_rcur, dim3(1), dim3(64), 0, c.stream, c.s, c.fp, 6 * n);
 }
 void launch_export_slab(const LaunchCtx& c, int dir, float* rec_out, int cap, int* count_dev) {

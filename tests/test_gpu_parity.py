@@ -792,7 +792,24 @@ def test_constructor_prefill_random_particles(dsp, orc):
     b_v, b_r = common.sorted_records(vg, rg, cols=(4, 5, 6, 1, 2, 3))
     assert len(a_v) == len(b_v) > 0.9 * n
     assert np.array_equal(a_v, b_v) and np.array_equal(a_r[:, 1:8], b_r[:, 1:8])     # same draws, same voxels
+    ko, kg = np.lexsort((so, vo)), np.lexsort((sg, vg))
+    assert np.array_equal(so[ko], sg[kg]) and np.array_equal(ro[ko], rg[kg])         # ... in the same slots (sequential order)
     assert set(np.unique(rg[:, 0]).tolist()) == {15.0} and np.abs(rg[:, 3]).max() > 0.5   # newborn flag, vz present
+    # first prediction of the seeded particles, stage by stage: the velocity noise (:653-659) is drawn from the table in
+    # the reference's sweep order (voxel-major, slot-minor) -> velocities, positions and the table cursor are bit-exact
+    o2, m2 = make_pair(dsp, orc, **cfgkw)
+    o2.L.dspo_add_random_particles(o2.h, n, 0.01); m2._chk(m2.L.dspmap_add_random_particles(m2.h, n, 0.01))
+    o2.occupancy_resample(); m2.occupancy_resample()             # newborn flag -> 1 (:968)
+    o2.predict(-0.01, 0.005, 0.0, 1 / 30.0); m2.predict(-0.01, 0.005, 0.0, 1 / 30.0)
+    assert m2.counters()["n_voxel_full"] == 0
+    v1, s1, r1 = o2.export_sparse()
+    v2, s2, r2 = gpu_state(m2)
+    a_v, a_r = common.sorted_records(v1, r1, cols=(4, 5, 6, 1, 2))
+    b_v, b_r = common.sorted_records(v2, r2, cols=(4, 5, 6, 1, 2))
+    assert np.array_equal(a_v, b_v) and np.array_equal(a_r[:, 1:3], b_r[:, 1:3]) and np.array_equal(a_r[:, 4:7], b_r[:, 4:7])
+    assert (r2[:, 1] != 0).sum() > 0.8 * len(r2) and not r2[:, 3].any()
+    assert list(o2.cursors())[1] == m2.cursors()[1] != 0         # the velocity-table cursor advanced identically
+    o2.close(); m2.close()
     base = common.wall_cloud(2, n_side=30, dist=1.6, half_w=1.2, half_h=0.7)
     for f in range(3):
         assert o.update(base, (0.01 * f, 0, 0), f / 30.0, (1, 0, 0, 0)) == 1
