@@ -110,6 +110,8 @@ extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
     if (cfg->z_lo < 0 || cfg->z_hi > cfg->nz || cfg->z_lo > cfg->z_hi) return nullptr;
     if (cfg->pyramid_neighbor_n < 0 || cfg->pyramid_neighbor_n > 2 || cfg->safe_particle_factor < 0) return nullptr;
     if ((cfg->safe_particle_factor > 0 ? cfg->safe_particle_factor : 2) * cfg->max_particle_num_voxel > 128) return nullptr;  // two occupancy words
+    if ((double)cfg->nx * cfg->ny * cfg->nz * (cfg->safe_particle_factor > 0 ? cfg->safe_particle_factor : 2) * cfg->max_particle_num_voxel >= 2147483648.0)
+        return nullptr;  // cell indices and sweep keys are 31-bit
     dspmap* m = new dspmap();
     m->cfg = *cfg;
     derive_dims(m);
@@ -136,7 +138,7 @@ static void free_dev(dspmap* m) {
     void* ptrs[] = {s.fpar, s.obs_ckf, s.part_inv, s.fut_stat, s.mask, s.nbmask, s.pos, s.vel, s.w, s.vz0, s.res4, s.fut, s.obs, s.obs_ck,
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.nstatic, s.fov_rec, s.fov_slot, s.pyr_cnt, s.mv_rec, s.exp_up, s.exp_down,
-                    s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.in_rec, m->k.in_cnt, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.expmask,
+                    s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.expmask,
                     m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.work_count, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->pp_box) (void)hipFree(m->pp_box);
@@ -286,6 +288,8 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&k.mv_rec, ntiles * 64 * d.slots * 2));
     HIPCHK(m, dalloc(&k.in_rec, ntiles * 64 * d.slots * 2));
     HIPCHK(m, dalloc(&k.in_cnt, ntiles));
+    HIPCHK(m, dalloc(&k.omask, W));
+    HIPCHK(m, hipMemset(k.omask, 0, sizeof(u64) * W));
     HIPCHK(m, dalloc(&k.ck_items, (size_t)d.np * ((d.capp + 63) / 64 + 1)));
     HIPCHK(m, dalloc(&k.wu_items, (size_t)d.np * ((d.capp + 31) / 32 + 1)));
     HIPCHK(m, dalloc(&k.n_items, (size_t)2));

@@ -7,6 +7,7 @@
 struct KernelScratch {
     float4* mv_rec;     // [ntiles][64*slots][2] per-source-tile staging of k_predict (movers up, in-FOV stayers down)
     unsigned long long* vz_q;       // [v_loc*mw] (with vz0) slots that draw velocity noise in their first prediction
+    unsigned long long* omask;      // [v_loc*mw] occupancy (mask | nbmask) before the frame's prediction (k_predict -> k_place)
     float4* in_rec;     // [ntiles][64*slots][2] per-destination-tile inbox of movers (k_predict tail -> k_place)
     int* in_cnt;        // [ntiles] inbox fill; zeroed again by k_place
     u64* expmask;       // [v_loc*mw] particles that left the slab (multi-GPU), or nullptr

@@ -176,9 +176,10 @@ __device__ __forceinline__ int advance_one(const MapDims& d, const float* s_ph, 
 }
 
 template <int MW, int NW>
-__global__ void __launch_bounds__(NW * 64, MW == 2 ? 5 : 1) k_predict(MapDims d, DevState s, FilterParams fp, int has_vz, int* __restrict__ part,
+__global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, FilterParams fp, int has_vz, int* __restrict__ part,
                                                  float4* __restrict__ mv_rec, float4* __restrict__ in_rec, int* __restrict__ in_cnt,
-                                                 u64* __restrict__ expmask, const int* __restrict__ vz_pre, const u64* __restrict__ vz_q) {
+                                                 u64* __restrict__ expmask, const int* __restrict__ vz_pre, const u64* __restrict__ vz_q,
+                                                 u64* __restrict__ omask) {
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
     __shared__ u64 s_keep[MW * 64], s_ex[MW * 64];
@@ -213,7 +214,10 @@ __global__ void __launch_bounds__(NW * 64, MW == 2 ? 5 : 1) k_predict(MapDims d,
         if (inr) { mword[e] = s.mask[(size_t)lv * MW + e]; nbword = s.nbmask[(size_t)lv * MW + e]; }
         live[e] = mword[e] & ~nbword;  // particles born/seeded this frame (flag 15) are not predicted (:649)
         any |= live[e] != 0ull;
-        if (wave == 0) { s_keep[e * 64 + l] = live[e]; s_ex[e * 64 + l] = 0ull; }
+        if (wave == 0) {
+            s_keep[e * 64 + l] = live[e]; s_ex[e * 64 + l] = 0ull;
+            if (inr) omask[(size_t)lv * MW + e] = mword[e] | nbword;   // occupancy before this prediction (k_place: arrivals from lower voxels)
+        }
     }
     if (tid == 0) { s_any = 0; s_nmv = 0; s_nst = 0; s_ncell = 0; }
     if (tid < 4) s_cnt[tid] = 0;
@@ -290,7 +294,7 @@ __global__ void __launch_bounds__(NW * 64, MW == 2 ? 5 : 1) k_predict(MapDims d,
             const int km = lds_agg_inc(&s_nmv, kind == 2);
             if (km >= 0) {
                 const float4 a = make_float4(__int_as_float(gv), v2.x, v2.y, px);
-                const float4 b = make_float4(py, pz, w, 0.f);
+                const float4 b = make_float4(py, pz, w, __int_as_float((blockIdx.x * 64 + ln + d.v_base) * d.slots + slot));
                 if (km < LSTG) { s_mv[km * 2] = a; s_mv[km * 2 + 1] = b; }
                 else { const size_t o = (mv_base + km) * 2; mv_rec[o] = a; mv_rec[o + 1] = b; }
             }
@@ -379,7 +383,8 @@ __global__ void __launch_bounds__(NW * 64, MW == 2 ? 5 : 1) k_predict(MapDims d,
                 const int km = lds_agg_inc(&s_nmv, mgv[r] >= 0);
                 if (km >= 0) {
                     const float4 a = make_float4(__int_as_float(mgv[r]), vx[r], vy[r], px[r]);
-                    const float4 b = make_float4(py[r], pz[r], w[r], 0.f);
+                    // .w: source key = sweep position (global voxel, slot) of the particle: k_place serves arrivals in this order
+                    const float4 b = make_float4(py[r], pz[r], w[r], __int_as_float((lv + d.v_base) * d.slots + e * 64 + row[r]));
                     if (km < LSTG) { s_mv[km * 2] = a; s_mv[km * 2 + 1] = b; }
                     else { const size_t o = (mv_base + km) * 2; mv_rec[o] = a; mv_rec[o + 1] = b; }
                 }
@@ -501,27 +506,35 @@ __global__ void __launch_bounds__(NW * 64, MW == 2 ? 5 : 1) k_predict(MapDims d,
 }
 
 // --------------------------------------------------------------------------
-// k_place: the voxel-changing half of moveParticle (:1209-1230).  One workgroup OWNS one destination
-// tile: it reads the tile's inbox (dense lanes, coalesced 32-byte records), ranks the arrivals per
-// destination voxel in LDS and gives arrival r of a voxel the r-th lowest free slot -- the
-// first-free-slot rule (:1214-1215) without a single global atomic on the occupancy words.
-// Destination full -> the particle vanishes (-1, :1227-1229).  Pyramid registration :1233-1259.
+// k_place: the voxel-changing half of moveParticle (:1209-1230), in the reference's ORDER.
+// The reference sweeps voxels in index order and slots inside a voxel in slot order; a particle that changes voxel
+// takes the first free slot of its destination AT THAT MOMENT (:1214-1215).  For a destination voxel D that means:
+//   * arrivals are served in the order of their source (voxel, slot);
+//   * an arrival from a LOWER voxel index comes before D itself is swept: D's own leavers still hold their slots
+//     -> first free slot of (occupancy before the prediction | slots given to earlier arrivals);
+//   * an arrival from a HIGHER index comes after D's sweep: the slots D's leavers (and out-of-map particles) freed
+//     are available -> first free slot of (occupancy after the prediction | slots given to earlier arrivals);
+//   * no free slot -> the particle vanishes (-1, :1227-1229).
+// One workgroup OWNS one destination tile: the inbox records carry their source key; they are bucketed per
+// destination voxel in LDS and every arrival computes its slot in closed form from its rank among the voxel's
+// arrivals -- the same particles end up in the same slots as in the sequential reference, with no global atomic
+// on the occupancy words and no sequential loop.  Pyramid registration :1233-1259.
 // part2[blockIdx*2 + {0,1}] = {voxel full, pyramid full}
 // --------------------------------------------------------------------------
+#define PLACE_MAX 1024   // arrivals of one tile ordered exactly; a tile that receives more falls back to arrival order
 template <int MW>
 __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const float4* __restrict__ in_rec,
-                                               int* __restrict__ in_cnt, int* __restrict__ part2, int has_vz, int tab_n) {
+                                               int* __restrict__ in_cnt, int* __restrict__ part2, int has_vz, int tab_n,
+                                               const u64* __restrict__ omask) {
     if (has_vz && blockIdx.x == 0 && threadIdx.x == 0)   // k_predict drew 3 table values per ranked particle (:655-657)
         s.fs->v_cur = (int)(((long long)s.fs->v_cur + 3ll * (long long)s.fs->occupied_count) % tab_n);
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
-    __shared__ u64 s_mask[MW * 64], s_new[MW * 64];
-    __shared__ int s_rank[64];
+    __shared__ u64 s_cur[MW * 64], s_org[MW * 64], s_new[MW * 64];
+    __shared__ int s_lcnt[64], s_loff[65];
+    __shared__ int s_key[PLACE_MAX];             // source key of arrival i
+    __shared__ unsigned short s_ord[PLACE_MAX];  // arrival indices bucketed by destination lane
     __shared__ int s_cnt[2];
-    // the records of a step are written out sorted by slot row, so that the lanes of one store instruction
-    // fall into few 128-byte lines (a scattered 4-byte store costs one transaction per lane)
-    __shared__ int s_hist[128], s_tot;
-    __shared__ float s_srt[7 * 256];
     const int tid = threadIdx.x;
     const int n_all = in_cnt[blockIdx.x];
     if (n_all == 0) {
@@ -530,14 +543,17 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
     }
     const int cap = 64 * d.slots;
     const int n = min(n_all, cap);
+    const bool exact = n <= PLACE_MAX;
     for (int i = tid; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
     for (int i = tid; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
     if (tid < 64) {
         const int lv = blockIdx.x * 64 + tid;
-        s_rank[tid] = 0;
+        s_lcnt[tid] = 0;
 #pragma unroll
         for (int e = 0; e < MW; ++e) {
-            s_mask[e * 64 + tid] = lv < d.v_loc ? s.mask[(size_t)lv * MW + e] : ~0ull;
+            const bool in = lv < d.v_loc;
+            s_cur[e * 64 + tid] = in ? (s.mask[(size_t)lv * MW + e] | s.nbmask[(size_t)lv * MW + e]) : ~0ull;
+            s_org[e * 64 + tid] = in ? omask[(size_t)lv * MW + e] : ~0ull;
             s_new[e * 64 + tid] = 0ull;
         }
     }
@@ -545,61 +561,115 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * cap;
     int c_vf = tid == 0 ? n_all - n : 0, c_pf = 0;
+    // the first 256 records stay in registers across the phases (most tiles receive fewer): one memory round trip
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), b0 = a0;
+    if (tid < n) { a0 = in_rec[(base + tid) * 2]; b0 = in_rec[(base + tid) * 2 + 1]; }
+    if (exact) {
+        // bucket the arrivals by destination lane
+        for (int i = tid; i < n; i += 256) {
+            const float4 a = i == tid ? a0 : in_rec[(base + i) * 2];
+            const float4 b = i == tid ? b0 : in_rec[(base + i) * 2 + 1];
+            s_key[i] = __float_as_int(b.w);
+            atomicAdd(&s_lcnt[(__float_as_int(a.x) - d.v_base) & 63], 1);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int c = s_lcnt[tid];
+            const int inc = wave_incl_scan_i(c);
+            s_loff[tid] = inc - c;
+            if (tid == 63) s_loff[64] = inc;
+            s_lcnt[tid] = 0;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const int ln = (__float_as_int(i == tid ? a0.x : in_rec[(base + i) * 2].x) - d.v_base) & 63;
+            s_ord[s_loff[ln] + atomicAdd(&s_lcnt[ln], 1)] = (unsigned short)i;
+        }
+        __syncthreads();
+    } else if (tid < 64) {
+        s_lcnt[tid] = 0;   // fallback: arrival order, slots freed by the prediction available to everyone
+    }
+    if (!exact) __syncthreads();
     for (int i0 = 0; i0 < n; i0 += 256) {
         const int i = i0 + tid;
         int key[1] = {-1}, pos[1];
         int ln = 0, nsl = -1;
         size_t nidx = 0;
-        float px = 0, py = 0, pz = 0, w = 0, mvx = 0, mvy = 0;
-        if (tid < 128) s_hist[tid] = 0;
-        __syncthreads();
+        float px = 0, py = 0, pz = 0, w = 0;
         if (i < n) {
-            const float4 a = in_rec[(base + i) * 2], b = in_rec[(base + i) * 2 + 1];
-            px = a.w; py = b.x; pz = b.y; w = b.z; mvx = a.y; mvy = a.z;
+            const float4 a = i == tid ? a0 : in_rec[(base + i) * 2];
+            const float4 b = i == tid ? b0 : in_rec[(base + i) * 2 + 1];
+            px = a.w; py = b.x; pz = b.y; w = b.z;
             ln = (__float_as_int(a.x) - d.v_base) & 63;
-            int r = atomicAdd(&s_rank[ln], 1);
+            if (exact) {
+                // position of this arrival in the reference's service order of its destination voxel, in closed form:
+                // the nF arrivals from lower voxel indices take, in key order, the first free slots of the occupancy
+                // BEFORE the prediction; the others then take the first free slots of the occupancy AFTER it that are
+                // still left
+                const int o0 = s_loff[ln], mm = s_loff[ln + 1] - o0;
+                const int mykey = __float_as_int(b.w);
+                const long long dkey = (long long)(blockIdx.x * 64 + ln + d.v_base) * d.slots;   // key of (D, slot 0)
+                int r = 0, nF = 0;
+                for (int x = 0; x < mm; ++x) {
+                    const int kx = s_key[s_ord[o0 + x]];
+                    r += kx < mykey ? 1 : 0;
+                    nF += (long long)kx < dkey ? 1 : 0;
+                }
+                u64 frO[MW], frC[MW];
+                int avail = 0;
 #pragma unroll
-            for (int e = 0; e < MW; ++e) {
-                u64 fr = ~s_mask[e * 64 + ln] & valid_bits(d, e);
-                const int c = (int)__popcll(fr);
-                if (nsl < 0) {
-                    if (r < c) {
-                        for (; r > 0; --r) fr &= fr - 1ull;
-                        nsl = e * 64 + (__ffsll((long long)fr) - 1);
-                    } else r -= c;
+                for (int e = 0; e < MW; ++e) { frO[e] = ~s_org[e * 64 + ln] & valid_bits(d, e); avail += (int)__popcll(frO[e]); }
+                if (r < nF) {            // forward arrival: r-th free slot of the old occupancy
+                    int q = r;
+#pragma unroll
+                    for (int e = 0; e < MW; ++e) {
+                        const int c = (int)__popcll(frO[e]);
+                        if (nsl < 0) {
+                            if (q < c) { u64 f = frO[e]; for (; q > 0; --q) f &= f - 1ull; nsl = e * 64 + (__ffsll((long long)f) - 1); }
+                            else q -= c;
+                        }
+                    }
+                } else {                 // backward arrival: skip what the forward ones took
+                    int tk = min(nF, avail);   // forward arrivals that found a slot: the first tk free bits of the old occupancy
+#pragma unroll
+                    for (int e = 0; e < MW; ++e) {
+                        u64 f = frO[e], took = 0ull;
+                        for (; tk > 0 && f; --tk) { took |= f & (~f + 1ull); f &= f - 1ull; }
+                        frC[e] = ~s_cur[e * 64 + ln] & valid_bits(d, e) & ~took;
+                    }
+                    int q = r - nF;
+#pragma unroll
+                    for (int e = 0; e < MW; ++e) {
+                        const int c = (int)__popcll(frC[e]);
+                        if (nsl < 0) {
+                            if (q < c) { u64 f = frC[e]; for (; q > 0; --q) f &= f - 1ull; nsl = e * 64 + (__ffsll((long long)f) - 1); }
+                            else q -= c;
+                        }
+                    }
+                }
+            } else {
+                int r = atomicAdd(&s_lcnt[ln], 1);
+#pragma unroll
+                for (int e = 0; e < MW; ++e) {
+                    u64 fr = ~s_cur[e * 64 + ln] & valid_bits(d, e);
+                    const int c = (int)__popcll(fr);
+                    if (nsl < 0) {
+                        if (r < c) {
+                            for (; r > 0; --r) fr &= fr - 1ull;
+                            nsl = e * 64 + (__ffsll((long long)fr) - 1);
+                        } else r -= c;
+                    }
                 }
             }
             if (nsl >= 0) {
                 nidx = pidx(d, blockIdx.x * 64 + ln, nsl);
+                st_pos(s, nidx, px, py, pz);
+                st_vel(s, nidx, a.y, a.z);
+                s.w[nidx] = w;
                 key[0] = pyramid_of(d, s_ph, s_pv, px, py, pz);
             } else {
                 ++c_vf;
             }
-        }
-        // counting sort of the step's placed records by slot row, then row-ordered stores
-        int rk = -1;
-        if (nsl >= 0) rk = atomicAdd(&s_hist[nsl], 1);
-        __syncthreads();
-        if (tid < 64) {
-            const int a0 = s_hist[2 * tid], a1 = s_hist[2 * tid + 1];
-            const int inc = wave_incl_scan_i(a0 + a1);
-            s_hist[2 * tid] = inc - a0 - a1; s_hist[2 * tid + 1] = inc - a1;
-            if (tid == 63) s_tot = inc;
-        }
-        __syncthreads();
-        if (nsl >= 0) {
-            const int q = s_hist[nsl] + rk;
-            s_srt[q] = __int_as_float(nsl * 64 + ln);
-            s_srt[256 + q] = px; s_srt[512 + q] = py; s_srt[768 + q] = pz;
-            s_srt[1024 + q] = mvx; s_srt[1280 + q] = mvy; s_srt[1536 + q] = w;
-        }
-        __syncthreads();
-        if (tid < s_tot) {
-            const int cell = __float_as_int(s_srt[tid]);
-            const size_t o = ((size_t)blockIdx.x * d.slots + (cell >> 6)) * 64 + (cell & 63);
-            st_pos(s, o, s_srt[256 + tid], s_srt[512 + tid], s_srt[768 + tid]);
-            st_vel(s, o, s_srt[1024 + tid], s_srt[1280 + tid]);
-            s.w[o] = s_srt[1536 + tid];
         }
         batch_append<1>(s.pyr_cnt, key, pos);
         if (nsl >= 0) {
@@ -627,7 +697,7 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
         const int lv = blockIdx.x * 64 + tid;
 #pragma unroll
         for (int e = 0; e < MW; ++e)
-            if (s_new[e * 64 + tid]) s.mask[(size_t)lv * MW + e] = s_mask[e * 64 + tid] | s_new[e * 64 + tid];
+            if (s_new[e * 64 + tid]) s.mask[(size_t)lv * MW + e] = s.mask[(size_t)lv * MW + e] | s_new[e * 64 + tid];
     }
     if (tid == 0) in_cnt[blockIdx.x] = 0;   // ready for the next frame
     if (tid < 2) part2[blockIdx.x * 2 + tid] = s_cnt[tid];
@@ -1204,15 +1274,15 @@ void launch_predict_only(const LaunchCtx& c) {
     }
     if (c.d.mw == 1)
         hipLaunchKernelGGL((k_predict<1, 4>), dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, c.fp,
-                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q);
+                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask);
     else
         hipLaunchKernelGGL((k_predict<2, 4>), dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, c.fp,
-                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q);
+                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask);
 }
 void launch_claim(const LaunchCtx& c) {
     const KernelScratch* k = &c.k;
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n);
-    else hipLaunchKernelGGL(k_place<2>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n);
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask);
+    else hipLaunchKernelGGL(k_place<2>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask);
 }
 void launch_predict(const LaunchCtx& c) {
     launch_predict_only(c);
