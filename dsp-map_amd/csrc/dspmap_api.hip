@@ -558,6 +558,8 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     if (m->prof) m->prof_pending = true;
 }
 
+static int upload_birth(dspmap* m, const dspmap_vpoint* pts, int n);
+
 extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* points_dev, int n_birth,
                                     const dspmap_vpoint* birth_dev, const float pos[3], double stamp,
                                     const float q[4]) {
@@ -568,6 +570,27 @@ extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* poin
     int rc = dspmap_ensure_point_cap(m, n_points > n_birth ? n_points : n_birth);
     if (rc != DSPMAP_OK) return rc;
     dspmap_freeze_birth_statics(m);
+    if (!birth_dev && m->use_vel_est && !m->cfg.static_model && n_points > 0) {
+        // device-resident cloud + velocity estimator (DSPMAP_P_VELOCITY_ESTIMATOR): the estimator is the host stage of
+        // velocity_estimator.cpp (reference :1377-1544), so the (<= 60 kB) cloud makes one round trip: D2H, clustering
+        // + matching on the host, H2D of the tagged birth cloud.  The frame then runs with that cloud.
+        if (n_points > m->pts_pin_cap) {
+            if (m->pts_pin) (void)hipHostFree(m->pts_pin);
+            m->pts_pin_cap = n_points + n_points / 2 + 1024;
+            HIPCHK(m, hipHostMalloc((void**)&m->pts_pin, sizeof(float) * 3 * (size_t)m->pts_pin_cap));
+        }
+        HIPCHK(m, hipMemcpyAsync(m->pts_pin, points_dev, sizeof(float) * 3 * (size_t)n_points, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(m, hipStreamSynchronize(m->stream));
+        std::vector<float> view;
+        view.reserve((size_t)n_points * 3);
+        m->vel.rotate_and_filter(m->pts_pin, n_points, q, view);
+        m->vel.run(view, m->cur_pos, dt, m->voxel_filter_res, m->h_birth);
+        m->h_birth_valid = true;
+        n_birth = (int)m->h_birth.size();
+        rc = upload_birth(m, m->h_birth.data(), n_birth);
+        if (rc != DSPMAP_OK) return rc;
+        birth_dev = (const dspmap_vpoint*)m->s.birth;
+    }
     LaunchCtx c = dspmap_ctx_of(m);
     const bool has_vz = m->vz_frames > 0;
     if (!has_vz) c.s.vz0 = nullptr;

@@ -143,7 +143,10 @@ int dspmap_update(dspmap_t* m, int point_cloud_num, int size_of_one_point, const
 /* Same frame with inputs already resident in HBM: `points_dev` = n x 3 floats
  * (sensor frame, packed xyz); `birth_dev`/n_birth = the birth-source cloud
  * (what the velocity estimator would output) or NULL/0 = every in-FOV point is
- * a static source (zero velocity tag).  Asynchronous: returns after enqueue. */
+ * a static source (zero velocity tag) -- unless DSPMAP_P_VELOCITY_ESTIMATOR is 1:
+ * then the cloud makes one round trip to the host estimator (D2H of <= 60 kB,
+ * clustering + matching, H2D of the tagged cloud) before the frame is enqueued.
+ * Asynchronous otherwise: returns after enqueue. */
 int dspmap_update_device(dspmap_t* m, int n_points, const float* points_dev, int n_birth,
                          const dspmap_vpoint* birth_dev, const float sensor_pos[3],
                          double time_stamp_second, const float quat_wxyz[4]);

@@ -836,6 +836,46 @@ def test_constructor_prefill_random_particles(dsp, orc):
     o.close(); m.close()
 
 
+def test_velocity_estimator_with_device_resident_cloud(dsp):
+    """dspmap_update_device + DSPMAP_P_VELOCITY_ESTIMATOR: the cloud makes one round trip to the host estimator; the
+    tagged birth cloud and the resulting map equal those of the host-buffer call dspmap_update"""
+    import torch
+    cfgkw = dict(nx=66, ny=66, nz=40, ppv=9)
+    maps = []
+    for _ in range(2):
+        m = dsp.DSPMap(dsp.make_config(**cfgkw)); m.set_tables(*common.tables(1)); m.useVelocityEstimator(True)
+        maps.append(m)
+    host, dev = maps
+
+    def cloud(t):
+        ys, zs = np.meshgrid(np.arange(-2.0, 2.0, 0.1), np.arange(-0.9, 1.0, 0.1))
+        wall = np.stack([np.full(ys.size, 3.5), ys.ravel(), zs.ravel()], 1)
+        by, bz = np.meshgrid(np.arange(0, 0.4, 0.1), np.arange(-0.9, 0.3, 0.1))
+        box = np.stack([np.full(by.size, 2.0), -1.0 + 1.2 * t + by.ravel(), bz.ravel()], 1)
+        return np.concatenate([wall, box]).astype(np.float32)
+
+    pos = (0.0, 0.0, 1.25)
+    for f in range(4):
+        t = f / 10.0
+        pts = cloud(t)
+        assert host.update(pts, pos, t, (1, 0, 0, 0)) == 1
+        d = torch.from_numpy(pts).cuda()
+        assert dev.update_device(d.data_ptr(), len(pts), pos, t, (1, 0, 0, 0)) == 1
+        dev.sync()
+        g, w = dev.get_birth_cloud(), host.get_birth_cloud()
+        assert len(g) == len(w) > 500
+        for k in ("x", "y", "z", "nx", "ny", "nz"):
+            assert np.array_equal(g[k], w[k]), k          # same estimator on the same points
+        assert np.array_equal(g["intensity"] > 0.01, w["intensity"] > 0.01)   # (the tag value itself is a random colour, :1507)
+        host.clearOccupancyMapPrediction(); dev.clearOccupancyMapPrediction()
+    assert (dev.get_birth_cloud()["intensity"] > 0.01).sum() > 20
+    a, b = host.results()[:, 0].astype(np.float64), dev.results()[:, 0].astype(np.float64)
+    assert abs(a.sum() - b.sum()) < 1e-4 * a.sum() and ((a > 0.2) == (b > 0.2)).mean() > 0.9999
+    vg, sg, rg = gpu_state(dev)
+    assert ((np.abs(rg[:, 2] - 1.2) < 0.5) & (rg[:, 7] > 0)).sum() > 20      # births carry the estimated velocity
+    host.close(); dev.close()
+
+
 def test_graph_replay_with_foreign_kernels_between_frames(dsp):
     """regression: a memset node inside the captured frame graph faulted as soon as another stream ran
     kernels between two replays (large map, ~6 frames).  The frame graph now holds kernel nodes only."""
