@@ -132,28 +132,37 @@ extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
 
 static void free_dev(dspmap* m) {
     if (!m->device_ready) return;
+    const bool dbg = getenv("DSPMAP_DEBUG_DESTROY") != nullptr;
+    auto chk = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && dbg) fprintf(stderr, "[dspmap destroy] %s: %s\n", what, hipGetErrorString(e));
+    };
+    if (m->device >= 0) chk(hipSetDevice(m->device), "hipSetDevice");
+    if (m->stream) chk(hipStreamSynchronize(m->stream), "hipStreamSynchronize");   // nothing of this handle may be in flight
+    if (m->stream2) chk(hipStreamSynchronize(m->stream2), "hipStreamSynchronize(2)");
+    if (m->graph_exec) chk(hipGraphExecDestroy(m->graph_exec), "hipGraphExecDestroy");
+    if (m->graph) chk(hipGraphDestroy(m->graph), "hipGraphDestroy");
     DevState& s = m->s;
     if (m->mgpu_bound) { s.obs_ck = nullptr; s.nstatic = nullptr; }  // caller-owned
-    if (m->mgpu_count) (void)hipFree(m->mgpu_count);
+    if (m->mgpu_count) chk(hipFree(m->mgpu_count), "hipFree");
     void* ptrs[] = {s.fpar, s.obs_ckf, s.part_inv, s.fut_stat, s.mask, s.nbmask, s.pos, s.vel, s.w, s.vz0, s.res4, s.fut, s.obs, s.obs_ck,
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.nstatic, s.fov_rec, s.fov_slot, s.pyr_cnt, s.mv_rec, s.exp_up, s.exp_down,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.expmask,
                     m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.work_count, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev};
-    for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (m->pp_box) (void)hipFree(m->pp_box);
-    if (m->pp_acc) (void)hipFree(m->pp_acc);
-    if (m->pp_blk) (void)hipFree(m->pp_blk);
-    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
-    if (m->graph) (void)hipGraphDestroy(m->graph);
-    if (m->pts_pin) (void)hipHostFree(m->pts_pin);
-    if (m->birth_pin) (void)hipHostFree(m->birth_pin);
-    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
-    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
-    if (m->stream2) (void)hipStreamDestroy(m->stream2);
-    if (m->ev0) (void)hipEventDestroy(m->ev0);
-    if (m->ev1) (void)hipEventDestroy(m->ev1);
-    if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
+    for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
+    if (m->pp_box) chk(hipFree(m->pp_box), "hipFree");
+    if (m->pp_acc) chk(hipFree(m->pp_acc), "hipFree");
+    if (m->pp_blk) chk(hipFree(m->pp_blk), "hipFree");
+    if (m->pts_pin) chk(hipHostFree(m->pts_pin), "hipHostFree");
+    if (m->birth_pin) chk(hipHostFree(m->birth_pin), "hipHostFree");
+    if (m->ev_fork) chk(hipEventDestroy(m->ev_fork), "hipEventDestroy");
+    if (m->ev_join) chk(hipEventDestroy(m->ev_join), "hipEventDestroy");
+    for (hipEvent_t e : m->pev) if (e) chk(hipEventDestroy(e), "hipEventDestroy(prof)");
+    if (m->stream2) chk(hipStreamDestroy(m->stream2), "hipStreamDestroy(2)");
+    if (m->ev0) chk(hipEventDestroy(m->ev0), "hipEventDestroy");
+    if (m->ev1) chk(hipEventDestroy(m->ev1), "hipEventDestroy");
+    if (m->own_stream && m->stream) chk(hipStreamDestroy(m->stream), "hipStreamDestroy");
+    (void)hipGetLastError();   // a failure while tearing this handle down must not surface in another handle's next call
     m->device_ready = false;
 }
 
@@ -614,6 +623,8 @@ extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* poin
             enqueue_frame(m, c, m->pt_cap, m->birth_cap, false, static_birth);  // (fork=true measured slower: HIP replays multi-branch graphs with a much higher launch cost) grids sized for the capacity; kernels bound-check against fpar
             HIPCHK(m, hipStreamEndCapture(m->stream, &m->graph));
             HIPCHK(m, hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(m->graph);   // the executable graph keeps its own copy of the topology
+            m->graph = nullptr;
             m->graph_key = key;
         }
         HIPCHK(m, hipGraphLaunch(m->graph_exec, m->stream));
@@ -634,9 +645,7 @@ static int stage_points(dspmap* m, int n, int stride, const float* pts) {
     int rc = dspmap_ensure_point_cap(m, n);
     if (rc != DSPMAP_OK) return rc;
     if (n > m->pts_pin_cap) {
-        if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
-    if (m->graph) (void)hipGraphDestroy(m->graph);
-    if (m->pts_pin) (void)hipHostFree(m->pts_pin);
+        if (m->pts_pin) (void)hipHostFree(m->pts_pin);
         m->pts_pin_cap = n + n / 2 + 1024;
         HIPCHK(m, hipHostMalloc((void**)&m->pts_pin, sizeof(float) * 3 * (size_t)m->pts_pin_cap));
     }

@@ -876,6 +876,34 @@ def test_velocity_estimator_with_device_resident_cloud(dsp):
     host.close(); dev.close()
 
 
+def test_mixed_api_and_handle_lifecycle(dsp):
+    """regression: the host-buffer call after a device-resident call on the SAME handle used to destroy the captured
+    frame graph without forgetting it (double destroy / use after free); handles are created and destroyed repeatedly
+    without leaking device memory"""
+    import torch
+    base = common.wall_cloud(3, n_side=40, dist=2.2, half_w=1.8, half_h=0.9)
+    d = torch.from_numpy(base).cuda()
+    free_ref = None
+    for it in range(6):
+        m = dsp.DSPMap(dsp.make_config(nx=40, ny=40, nz=20, ppv=12, seed=it + 1))
+        f = 0
+        for kind in ("dev", "dev", "host", "dev", "host", "dev"):
+            pos, t = (0.01 * f, 0.0, 0.0), f / 30.0
+            if kind == "dev":
+                assert m.update_device(d.data_ptr(), len(base), pos, t, (1, 0, 0, 0)) == 1
+            else:
+                assert m.update(base, pos, t, (1, 0, 0, 0)) == 1
+            m.getOccupancyMapWithFutureStatus(0.2)
+            f += 1
+        assert m.counters()["n_live_out"] > 1000
+        m.close()
+        torch.cuda.synchronize()
+        free = torch.cuda.mem_get_info()[0]
+        if it == 1:
+            free_ref = free
+    assert free_ref - free < (8 << 20)
+
+
 def test_graph_replay_with_foreign_kernels_between_frames(dsp):
     """regression: a memset node inside the captured frame graph faulted as soon as another stream ran
     kernels between two replays (large map, ~6 frames).  The frame graph now holds kernel nodes only."""
