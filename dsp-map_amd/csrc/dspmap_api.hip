@@ -146,9 +146,9 @@ static void free_dev(dspmap* m) {
     if (m->mgpu_count) chk(hipFree(m->mgpu_count), "hipFree");
     void* ptrs[] = {s.fpar, s.obs_ckf, s.part_inv, s.fut_stat, s.mask, s.nbmask, s.pos, s.vel, s.w, s.vz0, s.res4, s.fut, s.obs, s.obs_ck,
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
-                    s.birth, s.plan, s.nstatic, s.fov_rec, s.fov_slot, s.pyr_cnt, s.mv_rec, s.exp_up, s.exp_down,
+                    s.birth, s.plan, s.nstatic, s.fov_rec, s.fov_slot, s.pyr_cnt,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.expmask,
-                    m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.work_count, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev};
+                    m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
     if (m->pp_box) chk(hipFree(m->pp_box), "hipFree");
     if (m->pp_acc) chk(hipFree(m->pp_acc), "hipFree");
@@ -293,7 +293,6 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     KernelScratch& k = m->k;
     k.ntiles = (int)ntiles;
     k.nblk_sweep = (int)((ntiles + 3) / 4);  // k_resample: 4 tiles (waves) per 256-thread block
-    k.nblk_resample = (d.v_loc + 255) / 256 < 2048 ? (d.v_loc + 255) / 256 : 2048;  // persistent waves (4 per block)
     HIPCHK(m, dalloc(&k.mv_rec, ntiles * 64 * d.slots * 2));
     HIPCHK(m, dalloc(&k.in_rec, ntiles * 64 * d.slots * 2));
     HIPCHK(m, dalloc(&k.in_cnt, ntiles));
@@ -309,7 +308,6 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&k.part_claim, (size_t)k.ntiles * 2));
     HIPCHK(m, dalloc(&k.part_resample, (size_t)k.nblk_sweep * 4));
     HIPCHK(m, dalloc(&k.work_list, (size_t)d.v_loc));
-    HIPCHK(m, dalloc(&k.work_count, (size_t)1));
     HIPCHK(m, dalloc(&k.vb_cnt, (size_t)d.v_loc));
     HIPCHK(m, dalloc(&k.vb_idx, (size_t)d.v_loc * 128));
     HIPCHK(m, dalloc(&s.blk_cnt, (size_t)(d.v_loc + 255) / 256 + 1));

@@ -13,7 +13,7 @@ struct KernelScratch {
     u64* expmask;       // [v_loc*mw] particles that left the slab (multi-GPU), or nullptr
     int* part_predict;  // [ntiles*4]
     int* part_claim;    // [ntiles*2]
-    int* part_resample; // [nblk_resample*4]
+    int* part_resample; // [ntiles rounded up to 4] live particles per tile after resampling
     int* vb_cnt;        // [v_loc] children per destination voxel this frame (birth ordering)
     int* vb_idx;        // [v_loc*128] their birth indices
     int* ck_items;      // [np * ceil(capp/128)] work items of k_ck_partial (pyramid<<12 | chunk)
@@ -21,10 +21,9 @@ struct KernelScratch {
     int* n_items;       // [2]
     int* part_birth;    // [ceil(birth_cap*32/256)*2] per-block {born, dropped} of k_birth_insert
     float4* child;      // [birth_cap*32] child position + destination voxel of this frame's births
-    int* work_list;     // [v_loc] non-empty voxels of this frame (resample work list)
-    int* work_count;    // [1]
+    int* work_list;     // [v_loc] scratch: per-voxel prefix of the constructor-seeded particles' noise ranks (k_vz_count)
     int ntiles;         // tiles of 64 voxels; k_predict / k_place run one workgroup per tile
-    int nblk_sweep, nblk_resample;
+    int nblk_sweep;
 };
 
 struct LaunchCtx {

@@ -76,7 +76,6 @@ struct FrameScalars {
     int n_born_dropped;
     int n_live_out;
     int n_exp_up, n_exp_down;
-    int mover_count;    // local movers appended by the prediction kernel
     int occupied_count; // readout
     int n_voxel_full_import; // multi-GPU: movers received from a neighbour that found their voxel full
     float expected_newborn;  // expected_new_born_objects :292
@@ -135,10 +134,6 @@ struct DevState {
     float4* fov_rec;   // [np*capp] {x,y,z,w}
     int* fov_slot;     // [np*capp] local slot index (lv*slots+s)
     int* pyr_cnt;      // [np]
-    // movers
-    float* mv_rec;     // [mv_cap*8]
-    float* exp_up;     // [exp_cap*8]
-    float* exp_down;
     // readout scratch
     int* blk_cnt;      // [ceil(v_loc/256)+1]
     float* occ_xyz;    // [v_loc*3] (allocated on first use)
