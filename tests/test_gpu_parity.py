@@ -547,6 +547,34 @@ def test_empty_and_degenerate_inputs(dsp, orc):
     o.close(); m.close()
 
 
+def test_large_and_nonfinite_clouds(dsp, orc):
+    """clouds larger than the initial point capacity (buffers and the frame graph are rebuilt) and non-finite points (which never pass the FOV test, like in the reference: every comparison with NaN is false)"""
+    import torch
+    cfgkw = dict(nx=40, ny=40, nz=20, ppv=12)
+    o, m = make_pair(dsp, orc, **cfgkw)
+    o.L.dspo_use_velocity_estimator(o.h, 2)
+    rng = np.random.default_rng(4)
+    small = common.wall_cloud(3, n_side=30, dist=2.2, half_w=1.8, half_h=0.9)
+    big = np.concatenate([small + rng.normal(0, 0.01, small.shape).astype(np.float32) for _ in range(40)])   # 30 000 points
+    assert len(big) >= 30000
+    d_small, d_big = torch.from_numpy(small).cuda(), torch.from_numpy(big).cuda()
+    assert m.update_device(d_small.data_ptr(), len(small), (0, 0, 0), 0.0, (1, 0, 0, 0)) == 1
+    assert m.update_device(d_big.data_ptr(), len(big), (0.01, 0, 0), 0.03, (1, 0, 0, 0)) == 1     # grows: buffers + graph rebuilt
+    assert m.update_device(d_small.data_ptr(), len(small), (0.02, 0, 0), 0.06, (1, 0, 0, 0)) == 1
+    for pts, pos, t in ((small, (0, 0, 0), 0.0), (big, (0.01, 0, 0), 0.03), (small, (0.02, 0, 0), 0.06)):
+        assert o.update(pts, pos, t, (1, 0, 0, 0)) == 1
+    m.sync()
+    assert m.counters()["n_obs"] == int(o.obs_count.sum())
+    mo, mg = o.results[:, 0].astype(np.float64).sum(), m.results()[:, 0].astype(np.float64).sum()
+    assert abs(mg - mo) < 5e-3 * mo
+    bad = small.copy(); bad[::7] = np.nan; bad[3::11, 1] = np.inf
+    assert m.update(bad, (0.03, 0, 0), 0.09, (1, 0, 0, 0)) == 1 and o.update(bad, (0.03, 0, 0), 0.09, (1, 0, 0, 0)) == 1
+    assert m.counters()["n_obs"] == int(o.obs_count.sum()) > 0
+    vg, sg, rg = gpu_state(m)
+    assert np.isfinite(rg).all()
+    o.close(); m.close()
+
+
 def test_slab_sized_72_slots(dsp, orc):
     """config E shape: 36 particles/voxel -> 72 slots = two occupancy words per voxel"""
     cfgkw = dict(nx=24, ny=24, nz=10, res=0.10, ppv=36)
