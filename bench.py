@@ -130,10 +130,12 @@ def main():
             assert rc == 1, rc
             m.clearOccupancyMapPrediction()  # the reference requires this once per frame (:429-438)
 
-    def measure(w, steps, warmup, prefill, profile=True, solo=False):
+    def measure(w, steps, warmup, prefill, profile=True, solo=False, estimator=False):
         """solo: this rank measures alone (no collective barrier): the single-GPU origin of an N > 1 run"""
         barrier = (lambda: torch.cuda.synchronize()) if solo else globals_barrier
         m = make_map(w)
+        if estimator:
+            m.useVelocityEstimator(True)
         n_total = prefill + warmup + steps + (steps if profile else 0)
         frames = gen_frames(w, n_total, seed=1234 + rank)
         if w["sat"]:
@@ -298,6 +300,21 @@ def main():
                 **out}
         except Exception as e:
             result["rollout_D_132x132x60_T10"] = {"error": repr(e)}
+
+    # ------------------------------------------------------------------ the metric's workload with the velocity estimator in the loop
+    if rank == 0 and not sharded_run and not args.no_extra and wl_name == "B":
+        try:
+            mv, frv, dtv, cv, _ = measure(wl, 150, 15, args.prefill, profile=False, estimator=True)
+            result["with_velocity_estimator"] = {
+                "what": "workload B with DSPMAP_P_VELOCITY_ESTIMATOR = 1: the reference's velocityEstimationThread (:297,311, "
+                        "1377-1544) as the host stage of velocity_estimator.cpp; with device-resident clouds it costs one "
+                        "D2H + H2D round trip per frame (the headline value tags every birth source static instead)",
+                "frames_per_s": round(150 / dtv, 2), "ms_per_step": round(dtv / 150 * 1e3, 4),
+                "n_born": cv["n_born"], "n_live_in": cv["n_live_in"]}
+            mv.close()
+            del frv
+        except Exception as e:
+            result["with_velocity_estimator"] = {"error": repr(e)}
 
     # ------------------------------------------------------------------ next row: the caller's pre-processing on the device
     if rank == 0 and not sharded_run and not args.no_extra and wl_name == "B":
