@@ -317,7 +317,7 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, hipMemset(s.fut, 0, sizeof(float) * (size_t)d.v_loc * (d.T ? d.T : 1)));
     HIPCHK(m, hipMemset(s.fs, 0, sizeof(FrameScalars)));
     HIPCHK(m, hipMemset(s.obs_cnt, 0, sizeof(int) * d.np));
-    HIPCHK(m, hipMemset(s.obs_ck, 0, sizeof(float) * d.np * DSP_OBS_CAP));
+    HIPCHK(m, hipMemset(s.obs_ck, 0, sizeof(long long) * d.np * DSP_OBS_CAP));
     HIPCHK(m, hipMemset(s.pyr_cnt, 0, sizeof(int) * d.np));
     HIPCHK(m, hipMemset(k.part_predict, 0, sizeof(int) * (size_t)k.ntiles * 4));
     HIPCHK(m, hipMemset(k.part_claim, 0, sizeof(int) * (size_t)k.ntiles * 2));
@@ -567,6 +567,61 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
 
 static int upload_birth(dspmap* m, const dspmap_vpoint* pts, int n);
 
+// One frame with the host stages in the loop (velocity estimator and/or a caller-supplied birth cloud): prediction and
+// the weight update are queued first, the host estimator runs while they execute (the reference forks
+// velocityEstimationThread before prediction and joins it before the birth stage, :297,311), then the tagged cloud is
+// uploaded and birth + resampling follow.  `pts_dev` is the frame's cloud on the device, m->pts_pin its host copy (valid
+// once `pts_ready`, if given, has completed).
+static int frame_with_host_stages(dspmap* m, int np, const float* pts_dev, const float q[4], const float dp[3], float dt,
+                                  hipEvent_t pts_ready) {
+    dspmap_freeze_birth_statics(m);
+    LaunchCtx c = dspmap_ctx_of(m);
+    if (m->vz_frames <= 0) c.s.vz0 = nullptr;
+    // dsp_static.h has no velocity estimation: every in-FOV point is a zero-velocity birth source
+    const bool have_cloud = !m->cfg.static_model && (m->use_vel_est || m->h_birth_valid);
+    fill_pose(m, dp, dt);
+    m->hp.n_pts = np; m->hp.n_birth = np; m->hp.static_birth = have_cloud ? 0 : 1;
+    m->hp.pts = pts_dev; m->hp.birth = m->s.birth;
+    int rc = dspmap_push_frame_params(m);
+    if (rc != DSPMAP_OK) return rc;
+    HIPCHK(m, hipEventRecord(m->ev0, m->stream));
+    launch_setup_and_bin(c, np);
+    launch_predict(c);
+    launch_ck_partial(c);
+    launch_weight_update(c);
+    int nb = np;
+    if (m->use_vel_est && !m->cfg.static_model) {
+        if (pts_ready) HIPCHK(m, hipEventSynchronize(pts_ready));
+        std::vector<float> view;
+        view.reserve((size_t)np * 3);
+        m->vel.rotate_and_filter(m->pts_pin, np, q, view);
+        m->vel.run(view, m->cur_pos, dt, m->voxel_filter_res, m->h_birth);
+        m->h_birth_valid = true;
+    }
+    if (have_cloud) {
+        nb = (int)m->h_birth.size();
+        rc = upload_birth(m, m->h_birth.data(), nb);
+        if (rc != DSPMAP_OK) return rc;
+        c.s = m->s;  // pointers may have been re-allocated
+        if (m->vz_frames <= 0) c.s.vz0 = nullptr;
+        m->hp.n_birth = nb; m->hp.birth = m->s.birth;
+        rc = dspmap_push_frame_params(m);
+        if (rc != DSPMAP_OK) return rc;
+    }
+    if (nb > 0) launch_birth(c, nb, true, !have_cloud);  // :314-316
+    else launch_ck_finalize(c);
+    launch_resample(c);
+    if (m->vz_frames > 0) --m->vz_frames;
+    HIPCHK(m, hipEventRecord(m->ev1, m->stream));
+    m->ev_valid = true;
+    m->last_n_points = np;
+    m->last_n_birth = nb;
+    m->last_birth_static = !have_cloud;
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}
+
+
 extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* points_dev, int n_birth,
                                     const dspmap_vpoint* birth_dev, const float pos[3], double stamp,
                                     const float q[4]) {
@@ -579,24 +634,18 @@ extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* poin
     dspmap_freeze_birth_statics(m);
     if (!birth_dev && m->use_vel_est && !m->cfg.static_model && n_points > 0) {
         // device-resident cloud + velocity estimator (DSPMAP_P_VELOCITY_ESTIMATOR): the estimator is the host stage of
-        // velocity_estimator.cpp (reference :1377-1544), so the (<= 60 kB) cloud makes one round trip: D2H, clustering
-        // + matching on the host, H2D of the tagged birth cloud.  The frame then runs with that cloud.
+        // velocity_estimator.cpp (reference :1377-1544), so the (<= 60 kB) cloud is copied to the host, clustered and
+        // matched there WHILE the device predicts and re-weights (the reference's fork/join, :297,311), and the tagged
+        // birth cloud is uploaded for the birth stage.
         if (n_points > m->pts_pin_cap) {
             if (m->pts_pin) (void)hipHostFree(m->pts_pin);
             m->pts_pin_cap = n_points + n_points / 2 + 1024;
             HIPCHK(m, hipHostMalloc((void**)&m->pts_pin, sizeof(float) * 3 * (size_t)m->pts_pin_cap));
         }
         HIPCHK(m, hipMemcpyAsync(m->pts_pin, points_dev, sizeof(float) * 3 * (size_t)n_points, hipMemcpyDeviceToHost, m->stream));
-        HIPCHK(m, hipStreamSynchronize(m->stream));
-        std::vector<float> view;
-        view.reserve((size_t)n_points * 3);
-        m->vel.rotate_and_filter(m->pts_pin, n_points, q, view);
-        m->vel.run(view, m->cur_pos, dt, m->voxel_filter_res, m->h_birth);
-        m->h_birth_valid = true;
-        n_birth = (int)m->h_birth.size();
-        rc = upload_birth(m, m->h_birth.data(), n_birth);
-        if (rc != DSPMAP_OK) return rc;
-        birth_dev = (const dspmap_vpoint*)m->s.birth;
+        HIPCHK(m, hipEventRecord(m->ev_fork, m->stream));
+        dspmap_prof_collect(m);
+        return frame_with_host_stages(m, n_points, points_dev, q, dp, dt, m->ev_fork);
     }
     LaunchCtx c = dspmap_ctx_of(m);
     const bool has_vz = m->vz_frames > 0;
@@ -700,52 +749,7 @@ extern "C" int dspmap_update(dspmap_t* m, int n, int stride, const float* pts, f
     const int np = n > 0 ? n : 0;
     int rc = stage_points(m, np, stride, pts);
     if (rc != DSPMAP_OK) return rc;
-    dspmap_freeze_birth_statics(m);
-    LaunchCtx c = dspmap_ctx_of(m);
-    if (m->vz_frames <= 0) c.s.vz0 = nullptr;
-    // dsp_static.h has no velocity estimation: every in-FOV point is a zero-velocity birth source
-    const bool have_cloud = !m->cfg.static_model && (m->use_vel_est || m->h_birth_valid);
-    fill_pose(m, dp, dt);
-    m->hp.n_pts = np; m->hp.n_birth = np; m->hp.static_birth = have_cloud ? 0 : 1;
-    m->hp.pts = m->pts_dev; m->hp.birth = m->s.birth;
-    rc = dspmap_push_frame_params(m);
-    if (rc != DSPMAP_OK) return rc;
-    HIPCHK(m, hipEventRecord(m->ev0, m->stream));
-    launch_setup_and_bin(c, np);
-    launch_predict(c);
-    launch_ck_partial(c);
-    launch_weight_update(c);
-    int nb = np;
-    if (m->use_vel_est && !m->cfg.static_model) {
-        // the reference forks velocityEstimationThread before prediction and joins before the birth
-        // stage (:297,311); here the host estimator overlaps with the kernels queued above
-        std::vector<float> view;
-        view.reserve((size_t)np * 3);
-        m->vel.rotate_and_filter(m->pts_pin, np, q, view);
-        m->vel.run(view, m->cur_pos, dt, m->voxel_filter_res, m->h_birth);
-        m->h_birth_valid = true;
-    }
-    if (have_cloud) {
-        nb = (int)m->h_birth.size();
-        rc = upload_birth(m, m->h_birth.data(), nb);
-        if (rc != DSPMAP_OK) return rc;
-        c.s = m->s;  // pointers may have been re-allocated
-        if (m->vz_frames <= 0) c.s.vz0 = nullptr;
-        m->hp.n_birth = nb; m->hp.birth = m->s.birth;
-        rc = dspmap_push_frame_params(m);
-        if (rc != DSPMAP_OK) return rc;
-    }
-    if (n >= 0 && nb > 0) launch_birth(c, nb, true, !have_cloud);  // :314-316
-    else launch_ck_finalize(c);
-    launch_resample(c);
-    if (m->vz_frames > 0) --m->vz_frames;
-    HIPCHK(m, hipEventRecord(m->ev1, m->stream));
-    m->ev_valid = true;
-    m->last_n_points = np;
-    m->last_n_birth = nb;
-    m->last_birth_static = !have_cloud;
-    HIPCHK(m, hipGetLastError());
-    return DSPMAP_OK;
+    return frame_with_host_stages(m, np, m->pts_dev, q, dp, dt, nullptr);
 }
 
 extern "C" int dspmap_set_birth_cloud(dspmap_t* m, const dspmap_vpoint* pts, int n) {

@@ -157,6 +157,16 @@ __device__ __forceinline__ bool voxel_of(const MapDims& d, float px, float py, f
 // axis_u returns the LUT index relative to the table centre as a float, u = i - 10000 with
 // i = (int)(z*1000 + 10000) (:1296-1299).  z*1000 + 10000 is positive after the clamp, so the truncation is a
 // floor (one v_floor instead of two conversions) and the clamp is one v_med3.  The axis factor is
+// Ck accumulators are 64-bit fixed point in units of 2^-34 (5.8e-11; range +-5e8).  Ck >= kappa (1e-2 by default), whose
+// fp32 ulp is 9e-10, so the fixed-point grid is finer than the float the sum is read back into, and integer atomics make
+// the sum independent of arrival order (float atomics differ by an ulp from run to run, which the resampler's
+// equal-weight ties amplify into different survivors).
+#define CK_FIX_SCALE 17179869184.0
+// round to the nearest multiple of 2^-34 (magic-number rounding, valid below 2^18): sums of snapped terms are exact in
+// double while they stay below 2^19, far above any Ck the filter can produce
+__device__ __forceinline__ double ck_snap(float a) { return __dsub_rn(__dadd_rn((double)a, 393216.0), 393216.0); }
+__device__ __forceinline__ float ck_from_fix(long long v) { return (float)((double)v * (1.0 / CK_FIX_SCALE)); }
+
 // c * exp(-t^2/2) with t = u * 0.001; pair_gk sums the three u^2 (integers up to 9.8e7, fp32-exact to 6e-8
 // relative) and folds 0.001^2 / 2 and log2(e) into the single exp2: ~30 VALU operations per pair.
 __device__ __forceinline__ float axis_u(float a, float mu, float sigma, float inv_sigma) {

@@ -66,6 +66,8 @@ struct dspmap {
     unsigned graph_epoch = 0;   // bumped whenever a baked-in kernel argument (pointer / parameter) changes
     // multi-GPU split-phase state
     bool mgpu_bound = false;
+    bool mgpu_place_pending = false;   // k_predict ran, k_place waits for the imports
+    int vz_frames_at_begin = 0;
     int mgpu_nstatic_cap = 0;
     int* mgpu_count = nullptr;
     BirthSrc* mgpu_birth = nullptr;

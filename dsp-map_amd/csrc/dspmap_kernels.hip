@@ -47,7 +47,7 @@ __global__ void k_reset(MapDims d, DevState s, int flags) {
     }
     if (flags & RESET_OBS) {
         for (int i = gt; i < d.np; i += gn) { s.obs_cnt[i] = 0; s.obs_maxlen[i] = -1.f; }
-        for (int i = gt; i < d.np * DSP_OBS_CAP; i += gn) s.obs_ck[i] = 0.f;
+        for (int i = gt; i < d.np * DSP_OBS_CAP; i += gn) s.obs_ck[i] = 0;
         if (gt == 0) { s.fs->n_valid = 0; s.fs->n_obs = 0; s.fs->has_expected_override = 0; }
     }
     if (flags & RESET_PRED) {
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) k_obs_points(MapDims d, DevState s) {
             }
         }
         const int gt = blockIdx.x * blockDim.x + threadIdx.x, gn = gridDim.x * blockDim.x;
-        for (int i = gt; i < d.np * DSP_OBS_CAP; i += gn) s.obs_ck[i] = 0.f;       // Ck = 0 (:235-238)
+        for (int i = gt; i < d.np * DSP_OBS_CAP; i += gn) s.obs_ck[i] = 0;         // Ck = 0 (:235-238)
         for (int i = gt; i < d.np; i += gn) s.pyr_cnt[i] = 0;                       // pyramids are rebuilt by prediction (:638-642)
         if (gt == 0) {
             s.fs->cur_pos[0] = cpx; s.fs->cur_pos[1] = cpy; s.fs->cur_pos[2] = cpz;
@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, Fi
         }
         __syncthreads();
         // lanes = (observation, particle group): with few observations the 256 lanes split the particle
-        // chunk G ways so that every lane is busy and the loop is short; partial sums meet in the atomic
+        // chunk G ways so that every lane is busy and the loop is short; partial sums meet in the (fixed-point, order-independent) atomic
         const int opad = O <= 64 ? 64 : (O <= 128 ? 128 : 256);
         const int G = CK_TPB / opad;
         const int g = tid / opad;
@@ -352,12 +352,14 @@ __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, Fi
             for (int q = 1; q < d.nbins; ++q) k += (o >= s_off[q]) ? 1 : 0;
             const int oi = s_bin[k] * DSP_OBS_CAP + (o - s_off[k]);
             const float4 z = s.obs[oi];
-            float acc = 0.f;
+            // every term is snapped to the 2^-34 grid before it is added, so the (double) partial sum is exact and the
+            // total does not depend on the order of the particles in the pyramid's list either (built with atomics)
+            double acc = 0.0;
             for (int i = g; i < npart; i += G) {
                 const float4 p = s_p[i];
-                acc += p.w * pair_gk(p.x, p.y, p.z, z.x, z.y, z.z, fp.sigma_ob, fp.inv_sigma_ob, fp.pdf_c3);
+                acc = __dadd_rn(acc, ck_snap(p.w * pair_gk(p.x, p.y, p.z, z.x, z.y, z.z, fp.sigma_ob, fp.inv_sigma_ob, fp.pdf_c3)));
             }
-            unsafeAtomicAdd(&s.obs_ck[oi], acc);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&s.obs_ck[oi]), (unsigned long long)__double2ll_rn(acc * CK_FIX_SCALE));
         }
     }
 }
@@ -402,7 +404,7 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
             const int nob = s.obs_cnt[b];
             float inv = 0.f;
             if (tid < nob) {
-                const float ck = s.obs_ck[b * DSP_OBS_CAP + tid] + add;
+                const float ck = ck_from_fix(s.obs_ck[b * DSP_OBS_CAP + tid]) + add;
                 s.obs_ckf[b * DSP_OBS_CAP + tid] = ck;
                 inv = __fdiv_rn(1.f, ck);
             }
@@ -422,7 +424,7 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
             for (int q = 1; q < d.nbins; ++q) k += (o >= s_off[q]) ? 1 : 0;
             const int oi = s_bin[k] * DSP_OBS_CAP + (o - s_off[k]);
             float4 z = s.obs[oi];
-            z.w = __fdiv_rn(fp.p_det, s.obs_ck[oi] + add);
+            z.w = __fdiv_rn(fp.p_det, ck_from_fix(s.obs_ck[oi]) + add);
             s_o[o] = z;
         }
         __syncthreads();

@@ -3,7 +3,7 @@
 // issued by the caller through torch.distributed / RCCL on buffers it owns and binds here.
 #include "dspmap_internal.h"
 
-extern "C" int dspmap_mgpu_bind(dspmap_t* m, float* ck_dev, int* nstatic_dev, int nstatic_cap) {
+extern "C" int dspmap_mgpu_bind(dspmap_t* m, long long* ck_dev, int* nstatic_dev, int nstatic_cap) {
     READY(m);
     if (!ck_dev || !nstatic_dev || nstatic_cap <= 0) return dspmap_fail(m, DSPMAP_E_ARG, "bad buffers");
     HIPCHK(m, hipStreamSynchronize(m->stream));
@@ -17,7 +17,7 @@ extern "C" int dspmap_mgpu_bind(dspmap_t* m, float* ck_dev, int* nstatic_dev, in
     m->s.nstatic = nstatic_dev;
     m->mgpu_bound = true;
     m->mgpu_nstatic_cap = nstatic_cap;
-    HIPCHK(m, hipMemsetAsync(ck_dev, 0, sizeof(float) * (size_t)m->d.np * DSP_OBS_CAP, m->stream));
+    HIPCHK(m, hipMemsetAsync(ck_dev, 0, sizeof(long long) * (size_t)m->d.np * DSP_OBS_CAP, m->stream));
     if (!m->k.expmask) {
         const size_t W = (size_t)m->d.v_loc * m->d.mw;
         HIPCHK(m, hipMalloc((void**)&m->k.expmask, sizeof(u64) * W));
@@ -53,7 +53,9 @@ extern "C" int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_
     dspmap_prof_collect(m);
     HIPCHK(m, hipEventRecord(m->ev0, m->stream));
     launch_setup_and_bin(c, n_points);
-    launch_predict(c);
+    launch_predict_only(c);       // k_place follows the exchange: imported movers take part in the sweep-order placement
+    m->mgpu_place_pending = true;
+    m->vz_frames_at_begin = m->vz_frames;
     if (m->vz_frames > 0) --m->vz_frames;
     m->last_n_points = n_points;
     m->last_n_birth = nb;
@@ -109,6 +111,12 @@ extern "C" int dspmap_mgpu_import(dspmap_t* m, int n, const float* rec_dev) {
 extern "C" int dspmap_mgpu_ck_partial(dspmap_t* m) {
     READY(m);
     LaunchCtx c = dspmap_ctx_of(m);
+    if (m->mgpu_place_pending) {
+        if (m->vz_frames_at_begin <= 0) c.s.vz0 = nullptr;
+        launch_claim(c);
+        c = dspmap_ctx_of(m);
+        m->mgpu_place_pending = false;
+    }
     launch_ck_partial(c);
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;

@@ -1114,8 +1114,8 @@ __global__ void k_advance_rcur(DevState s, FilterParams fp, int by) {
 
 // --------------------------------------------------------------------------
 // multi-GPU: particles whose new voxel lies in another Z-slab (marked in expmask by k_predict).
-// k_export_slab compacts those leaving in direction `dir` into the caller's send buffer and frees
-// their slots; k_import_movers places records received from a neighbour.
+// k_export_slab compacts those leaving in direction `dir` into the caller's send buffer (with their source key, the
+// same 2 x float4 record the inboxes hold) and frees their slots.
 // --------------------------------------------------------------------------
 template <int MW>
 __global__ void __launch_bounds__(256) k_export_slab(MapDims d, DevState s, u64* __restrict__ expmask, int dir,
@@ -1148,7 +1148,8 @@ __global__ void __launch_bounds__(256) k_export_slab(MapDims d, DevState s, u64*
             if (mine) {
                 if (pos < cap) {
                     float* r = rec_out + 8 * (size_t)pos;
-                    r[0] = __int_as_float(gv); r[1] = vx; r[2] = vy; r[3] = px; r[4] = py; r[5] = pz; r[6] = w; r[7] = 0.f;
+                    r[0] = __int_as_float(gv); r[1] = vx; r[2] = vy; r[3] = px; r[4] = py; r[5] = pz; r[6] = w;
+                    r[7] = __int_as_float((lv + d.v_base) * d.slots + e * 64 + sb);   // source key: k_place's service order
                 }
                 done |= 1ull << sb;
             }
@@ -1160,43 +1161,25 @@ __global__ void __launch_bounds__(256) k_export_slab(MapDims d, DevState s, u64*
     }
 }
 
-__global__ void __launch_bounds__(256) k_import_movers(MapDims d, DevState s, int n, const float* __restrict__ rec,
-                                                       int* __restrict__ dropped) {
-    __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
-    __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
-    for (int i = threadIdx.x; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
-    for (int i = threadIdx.x; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
-    __syncthreads();
+// Received records join the inbox of their destination tile; k_place (which the slab runs AFTER the exchange) then
+// serves them together with the slab's own movers in the order of their source keys, so a sharded map fills exactly
+// the slots the unsharded one does.
+__global__ void __launch_bounds__(256) k_import_movers(MapDims d, int n, const float* __restrict__ rec, float4* __restrict__ in_rec,
+                                                       int* __restrict__ in_cnt, int* __restrict__ dropped) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int pyr = -1;
-    size_t nidx = 0;
-    int nlv = -1, nsl = -1;
-    float px = 0, py = 0, pz = 0, w = 0;
     bool lost = false;
     if (i < n) {
         const float* r = rec + 8 * (size_t)i;
-        nlv = __float_as_int(r[0]) - d.v_base;
-        px = r[3]; py = r[4]; pz = r[5]; w = r[6];
+        const int nlv = __float_as_int(r[0]) - d.v_base;
         if (nlv >= 0 && nlv < d.v_loc) {
-            nsl = claim_slot(s.mask, nlv, d);
-            if (nsl >= 0) {
-                nidx = pidx(d, nlv, nsl);
-                st_pos(s, nidx, px, py, pz);
-                st_vel(s, nidx, r[1], r[2]); s.w[nidx] = w;
-                pyr = pyramid_of(d, s_ph, s_pv, px, py, pz);
-            } else lost = true;   // destination voxel full (-1, :1227-1229)
+            const int tile = nlv >> 6, cap = 64 * d.slots;
+            const int pos = atomicAdd(&in_cnt[tile], 1);   // beyond cap: k_place counts it as "voxel full"
+            if (pos < cap) {
+                const size_t o = ((size_t)tile * cap + pos) * 2;
+                in_rec[o] = make_float4(r[0], r[1], r[2], r[3]);
+                in_rec[o + 1] = make_float4(r[4], r[5], r[6], r[7]);
+            }
         } else lost = true;       // not a neighbouring slab's voxel (jump larger than a slab)
-    }
-    const int pos = wave_agg_inc(s.pyr_cnt, pyr, pyr >= 0);
-    if (pyr >= 0) {
-        if (pos < d.capp) {
-            const size_t o = (size_t)pyr * d.capp + pos;
-            s.fov_rec[o] = make_float4(px, py, pz, w);
-            s.fov_slot[o] = (int)nidx;
-        } else {
-            lost = true;
-            atomicAnd(&s.mask[(size_t)nlv * d.mw + (nsl >> 6)], ~(1ull << (nsl & 63)));
-        }
     }
     wave_count_add(dropped, lost);
 }
@@ -1324,7 +1307,7 @@ void launch_export_slab(const LaunchCtx& c, int dir, float* rec_out, int cap, in
 }
 void launch_import_movers(const LaunchCtx& c, int n, const float* rec) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_import_movers, dim3((n + 255) / 256), dim3(256), 0, c.stream, c.d, c.s, n, rec, &c.s.fs->n_voxel_full_import);
+    hipLaunchKernelGGL(k_import_movers, dim3((n + 255) / 256), dim3(256), 0, c.stream, c.d, n, rec, c.k.in_rec, c.k.in_cnt, &c.s.fs->n_voxel_full_import);
 }
 void launch_reduce_counters(const LaunchCtx& c) {
     hipLaunchKernelGGL(k_reduce_counters, dim3(1), dim3(1024), 0, c.stream, c.s, c.k, c.d, c.fp.nb_num);

@@ -114,7 +114,9 @@ struct DevState {
     float* fut_stat; // [v_loc]   future mass of static particles (identical for every horizon; folded in at readout)
     // observations
     float4* obs;       // [np*100] {x,y,z,len}
-    float* obs_ck;     // [np*100] sum over particles of P_d*w*g (pass 1), without the frame constant
+    long long* obs_ck; // [np*100] sum over particles of P_d*w*g (pass 1), without the frame constant; fixed point,
+                       // units of 2^-34 (ck_to_fix): integer atomics are associative, so the sum does not depend on the
+                       // order the workgroups (or the ranks of a sharded map) arrive in -- frames are reproducible
     float* obs_ckf;    // [np*100] final Ck = obs_ck + lambda + kappa (:737)
     float* part_inv;   // [np] per-pyramid sum of 1/Ck
     int* obs_cnt;      // [np]

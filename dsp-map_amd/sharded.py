@@ -109,7 +109,7 @@ class HipSlab:
         self.map = dsp.DSPMap(cfg, example_params=example_params)
         m = self.map
         self.z_lo, self.z_hi = z_lo, z_hi
-        self.ck = torch.zeros(m.NP * 100, dtype=torch.float32, device=self.dev)
+        self.ck = torch.zeros(m.NP * 100, dtype=torch.int64, device=self.dev)   # fixed-point Ck sums (include/dspmap.h)
         self.nstatic = torch.zeros(point_cap, dtype=torch.int32, device=self.dev)
         self.point_cap = point_cap
         layer = cfg.nx * cfg.ny * m.slots

@@ -263,8 +263,13 @@ int dspmap_get_pyramid_counts(dspmap_t* m, int* count_out_host /* [NP] */);
  *      ego-motion's z component moves particles across layers, dsp_dynamic.h:661-667);
  *  (2) the per-observation sums Ck, because pyramids cut across slabs (:709-735);
  *  (3) n_static of each birth source, known only to the rank owning the source's voxel (:827-866).
- * Records are 8 floats {global voxel index (int bits), vx, vy, px, py, pz, w, 0}. */
-int dspmap_mgpu_bind(dspmap_t* m, float* ck_dev /* [NP*100] */, int* nstatic_dev, int nstatic_cap);
+ * Records are 8 floats {global voxel index (int bits), vx, vy, px, py, pz, w, source key (int bits)}: the key
+ * (source voxel * slots + slot) orders the arrivals of a voxel as the reference's sequential sweep would serve them;
+ * imported records are placed together with the slab's own movers (the placement pass runs after the import), so
+ * a sharded map fills exactly the slots of the unsharded one.
+ * The Ck buffer holds 64-bit fixed-point sums (units of 2^-34): all-reduce it as int64.  Integer addition is
+ * associative, so a sharded frame computes exactly the Ck of the unsharded one and frames are reproducible. */
+int dspmap_mgpu_bind(dspmap_t* m, long long* ck_dev /* [NP*100] int64 */, int* nstatic_dev, int nstatic_cap);
 int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_dev, int n_birth,
                       const dspmap_vpoint* birth_dev, const float sensor_pos[3],
                       double time_stamp_second, const float quat_wxyz[4]);   /* 1 / 0 like dspmap_update */
