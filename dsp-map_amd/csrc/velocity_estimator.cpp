@@ -6,7 +6,6 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
-#include <unordered_map>
 
 static void quat_mul(const float a[4], const float b[4], float r[4]) {
     r[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
@@ -45,13 +44,23 @@ void VelocityEstimator::rotate_and_filter(const float* pts, int n, const float q
     float h0[3], hN[3], v0[3], vN[3];
     rotate(&ph0_[0], q, h0); rotate(&ph0_[(size_t)np_h_ * 3], q, hN);
     rotate(&pv0_[0], q, v0); rotate(&pv0_[(size_t)np_v_ * 3], q, vN);
+    // rotate() with its per-call constants (|q|^2, the inverse quaternion) hoisted: same operations, same order
+    const float n2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + q[0] * q[0];
+    const float inv[4] = {q[0] / n2, -q[1] / n2, -q[2] / n2, -q[3] / n2};
+    view.resize((size_t)n * 3);
+    size_t k = 0;
     for (int i = 0; i < n; i++) {
-        float r[3];
-        rotate(pts + 3 * (size_t)i, q, r);
+        const float vq[4] = {0.f, pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]};
+        float t[4], rr[4];
+        quat_mul(q, vq, t);
+        quat_mul(t, inv, rr);
+        const float* r = rr + 1;
         if (dot3(r, h0) >= 0.f && dot3(r, hN) <= 0.f && dot3(r, v0) <= 0.f && dot3(r, vN) >= 0.f) {
-            view.push_back(r[0]); view.push_back(r[1]); view.push_back(r[2]);
+            view[k] = r[0]; view[k + 1] = r[1]; view[k + 2] = r[2];
+            k += 3;
         }
     }
+    view.resize(k);
 }
 
 // Kuhn-Munkres, minimum cost, rectangular (padded); assign[r] = c or -1
@@ -114,14 +123,46 @@ void VelocityEstimator::run(const std::vector<float>& view, const float cur[3], 
         // seeds in index order, breadth-first growth by radius search (hash grid, cell = tolerance),
         // clusters returned largest first.
         const float tol = 2 * res_filter, tol2 = tol * tol;
+        // radius search = a uniform grid with cell = tolerance: counting sort of the points into the cells of their
+        // bounding box (CSR), 27 cells per query.  (A cloud spread over more than 2^18 cells falls back to one cell per
+        // axis slab by clamping -- still correct, the distance test decides.)
         auto cell = [&](float x) { return (long long)floorf(x / tol); };
-        auto key = [](long long ix, long long iy, long long iz) {
-            return (ix * 73856093LL) ^ (iy * 19349663LL) ^ (iz * 83492791LL);
-        };
-        std::unordered_map<long long, std::vector<int>> grid;
-        grid.reserve((size_t)n_ng * 2);
-        for (int i = 0; i < n_ng; i++) grid[key(cell(ng[3 * i]), cell(ng[3 * i + 1]), cell(ng[3 * i + 2]))].push_back(i);
+        long long lo[3] = {cell(ng[0]), cell(ng[1]), cell(ng[2])}, hi[3] = {lo[0], lo[1], lo[2]};
+        std::vector<int> cxyz((size_t)n_ng * 3);
+        for (int i = 0; i < n_ng; i++)
+            for (int a = 0; a < 3; a++) {
+                const long long c = cell(ng[3 * i + a]);
+                lo[a] = std::min(lo[a], c); hi[a] = std::max(hi[a], c);
+            }
+        long long dim[3];
+        int shift[3] = {0, 0, 0};   // cells merged 2^shift to one along an axis if the box is huge (keeps the grid small)
+        for (;;) {
+            for (int a = 0; a < 3; a++) dim[a] = ((hi[a] - lo[a]) >> shift[a]) + 1;
+            if (dim[0] * dim[1] * dim[2] <= (1ll << 18)) break;
+            int big = 0;
+            for (int a = 1; a < 3; a++) if (dim[a] > dim[big]) big = a;
+            ++shift[big];
+        }
+        const size_t n_cells = (size_t)(dim[0] * dim[1] * dim[2]);
+        cell_start_.assign(n_cells + 1, 0);
+        std::vector<int> cid(n_ng);
+        for (int i = 0; i < n_ng; i++) {
+            for (int a = 0; a < 3; a++) cxyz[3 * i + a] = (int)((cell(ng[3 * i + a]) - lo[a]) >> shift[a]);
+            cid[i] = (int)(((long long)cxyz[3 * i + 2] * dim[1] + cxyz[3 * i + 1]) * dim[0] + cxyz[3 * i]);
+            ++cell_start_[cid[i] + 1];
+        }
+        for (size_t c = 0; c < n_cells; c++) cell_start_[c + 1] += cell_start_[c];
+        // every cell keeps its UNPROCESSED points in [cell_start, cell_end): a point leaves its cell (swap with the
+        // last active one) the moment it is queued, so a query only ever touches candidates that can still join
+        std::vector<int> cell_pts(n_ng), cell_end(cell_start_.begin(), cell_start_.end() - 1), where(n_ng);
+        for (int i = 0; i < n_ng; i++) { where[i] = cell_end[cid[i]]; cell_pts[cell_end[cid[i]]++] = i; }
         std::vector<char> processed(n_ng, 0);
+        auto retire = [&](int j) {
+            processed[j] = 1;
+            const int last = --cell_end[cid[j]], moved = cell_pts[last];
+            cell_pts[where[j]] = moved; where[moved] = where[j];
+            cell_pts[last] = j; where[j] = last;
+        };
         std::vector<std::vector<int>> clusters;
         std::vector<int> queue;
         std::vector<std::pair<float, int>> nbrs;
@@ -129,26 +170,31 @@ void VelocityEstimator::run(const std::vector<float>& view, const float cur[3], 
             if (processed[i]) continue;
             queue.clear();
             queue.push_back(i);
-            processed[i] = 1;
+            retire(i);
             for (size_t qi = 0; qi < queue.size(); ++qi) {
                 const int c = queue[qi];
                 const float cx = ng[3 * c], cy = ng[3 * c + 1], cz = ng[3 * c + 2];
                 nbrs.clear();
-                for (int dx = -1; dx <= 1; dx++)
-                    for (int dy = -1; dy <= 1; dy++)
-                        for (int dz = -1; dz <= 1; dz++) {
-                            auto it = grid.find(key(cell(cx) + dx, cell(cy) + dy, cell(cz) + dz));
-                            if (it == grid.end()) continue;
-                            for (int j : it->second) {
-                                if (processed[j]) continue;
+                // a merged axis (shift > 0) holds >= 2 tolerance cells per grid cell: +-1 grid cell still covers +-tol
+                for (int dz = -1; dz <= 1; dz++) {
+                    const int z = cxyz[3 * c + 2] + dz;
+                    if (z < 0 || z >= dim[2]) continue;
+                    for (int dy = -1; dy <= 1; dy++) {
+                        const int y = cxyz[3 * c + 1] + dy;
+                        if (y < 0 || y >= dim[1]) continue;
+                        const int x0 = std::max(cxyz[3 * c] - 1, 0), x1 = std::min(cxyz[3 * c] + 1, (int)dim[0] - 1);
+                        const size_t row = ((size_t)z * dim[1] + y) * dim[0];
+                        for (int x = x0; x <= x1; ++x)
+                            for (int k = cell_start_[row + x]; k < cell_end[row + x]; ++k) {
+                                const int j = cell_pts[k];
                                 const float ex = ng[3 * j] - cx, ey = ng[3 * j + 1] - cy, ez = ng[3 * j + 2] - cz;
                                 const float d2 = ex * ex + ey * ey + ez * ez;
                                 if (d2 <= tol2) nbrs.emplace_back(d2, j);
                             }
-                        }
-                std::sort(nbrs.begin(), nbrs.end());
-                for (auto& nb : nbrs)
-                    if (!processed[nb.second]) { processed[nb.second] = 1; queue.push_back(nb.second); }
+                    }
+                }
+                if (nbrs.size() > 1) std::sort(nbrs.begin(), nbrs.end());   // radiusSearch returns sorted by distance
+                for (auto& nb : nbrs) { retire(nb.second); queue.push_back(nb.second); }
             }
             if (queue.size() >= 5 && queue.size() <= 10000) clusters.push_back(queue);
         }

@@ -32,6 +32,7 @@ private:
     std::vector<float> ph0_, pv0_, ph_, pv_;
     std::vector<Cluster> last_;  // clusters_feature_vector_dynamic_last :1401
     bool configured_ = false;
+    std::vector<int> cell_start_;   // clustering grid (kept between frames: no per-frame allocation of the big array)
     friend struct dspmap;
 public:
     bool configured() const { return configured_; }
