@@ -147,7 +147,7 @@ static void free_dev(dspmap* m) {
     void* ptrs[] = {s.fpar, s.obs_ckf, s.part_inv, s.fut_stat, s.mask, s.nbmask, s.pos, s.vel, s.w, s.vz0, s.res4, s.fut, s.obs, s.obs_ck,
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.nstatic, s.fov_rec, s.fov_slot, s.pyr_cnt,
-                    s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.expmask,
+                    s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
                     m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
     if (m->pp_box) chk(hipFree(m->pp_box), "hipFree");
@@ -301,6 +301,7 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&k.ck_items, (size_t)d.np * ((d.capp + 63) / 64 + 1)));
     HIPCHK(m, dalloc(&k.wu_items, (size_t)d.np * ((d.capp + 31) / 32 + 1)));
     HIPCHK(m, dalloc(&k.n_items, (size_t)2));
+    HIPCHK(m, dalloc(&k.nb_tab, (size_t)d.np * NB_TAB_STRIDE));
     HIPCHK(m, hipMemset(k.in_cnt, 0, sizeof(int) * ntiles));
     const bool slab = !(d.z_lo == 0 && d.z_hi == d.nz);
     if (slab) HIPCHK(m, dalloc(&k.expmask, W));

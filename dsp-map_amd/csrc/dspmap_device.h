@@ -157,18 +157,12 @@ __device__ __forceinline__ bool voxel_of(const MapDims& d, float px, float py, f
 // axis_u returns the LUT index relative to the table centre as a float, u = i - 10000 with
 // i = (int)(z*1000 + 10000) (:1296-1299).  z*1000 + 10000 is positive after the clamp, so the truncation is a
 // floor (one v_floor instead of two conversions) and the clamp is one v_med3.  The axis factor is
-// Ck accumulators are 64-bit fixed point in units of 2^-34 (5.8e-11; range +-5e8).  Ck >= kappa (1e-2 by default), whose
-// fp32 ulp is 9e-10, so the fixed-point grid is finer than the float the sum is read back into, and integer atomics make
-// the sum independent of arrival order (float atomics differ by an ulp from run to run, which the resampler's
-// equal-weight ties amplify into different survivors).
-#define CK_FIX_SCALE 17179869184.0
-// round to the nearest multiple of 2^-34 (magic-number rounding, valid below 2^18): sums of snapped terms are exact in
-// double while they stay below 2^19, far above any Ck the filter can produce
-__device__ __forceinline__ double ck_snap(float a) { return __dsub_rn(__dadd_rn((double)a, 393216.0), 393216.0); }
-__device__ __forceinline__ float ck_from_fix(long long v) { return (float)((double)v * (1.0 / CK_FIX_SCALE)); }
-
 // c * exp(-t^2/2) with t = u * 0.001; pair_gk sums the three u^2 (integers up to 9.8e7, fp32-exact to 6e-8
 // relative) and folds 0.001^2 / 2 and log2(e) into the single exp2: ~30 VALU operations per pair.
+// pair_gk2 below does two pairs per lane with packed fp32 (v_pk_add / v_pk_mul / v_pk_fma).  On gfx950 that is NOT a
+// higher FLOP rate (a wave64 fp32 instruction issues in ~2.8 cycles at full occupancy, the packed one in ~5.3,
+// tools/micro/valu_bench.hip) but fewer instructions per pair, which helps when few waves share a SIMD: 3-4 % on the
+// pair kernels at the metric's workload, nothing at saturation.
 __device__ __forceinline__ float axis_u(float a, float mu, float sigma, float inv_sigma) {
     const float dlt = a - mu;
     const float q0 = dlt * inv_sigma;
@@ -186,6 +180,40 @@ __device__ __forceinline__ float pair_gk(float px, float py, float pz, float ox,
     // exp(-0.5 * 1e-6 * s) = exp2(s * (-0.5e-6 * log2(e)))
     return c3 * __builtin_amdgcn_exp2f(s * -7.213475204444817e-07f);
 }
+
+// Exactly the operations of axis_u / pair_gk, component by component: bit-identical results; only the clamp, the floor
+// and the exp2 have no packed form.
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v axis_u2(f2v a, f2v mu, float sigma, float inv_sigma) {
+    const f2v dlt = a - mu;
+    const f2v q0 = dlt * inv_sigma;
+    const f2v rr = __builtin_elementwise_fma(-q0, (f2v)(sigma), dlt);
+    f2v z = __builtin_elementwise_fma(rr, (f2v)(inv_sigma), q0);
+    z.x = __builtin_amdgcn_fmed3f(z.x, -9.9f, 9.9f);
+    z.y = __builtin_amdgcn_fmed3f(z.y, -9.9f, 9.9f);
+    f2v t = z * 1000.f + 10000.f;
+    t.x = floorf(t.x); t.y = floorf(t.y);
+    return t - 10000.f;
+}
+__device__ __forceinline__ f2v pair_gk2(f2v px, f2v py, f2v pz, f2v ox, f2v oy, f2v oz, float sigma, float inv_sigma, float c3) {
+    const f2v ux = axis_u2(px, ox, sigma, inv_sigma);
+    const f2v uy = axis_u2(py, oy, sigma, inv_sigma);
+    const f2v uz = axis_u2(pz, oz, sigma, inv_sigma);
+    const f2v s = (ux * ux + uy * uy + uz * uz) * -7.213475204444817e-07f;
+    f2v e;
+    e.x = __builtin_amdgcn_exp2f(s.x); e.y = __builtin_amdgcn_exp2f(s.y);
+    return e * c3;
+}
+
+// Ck accumulators are 64-bit fixed point in units of 2^-34 (5.8e-11; range +-5e8).  Ck >= kappa (1e-2 by default), whose
+// fp32 ulp is 9e-10, so the fixed-point grid is finer than the float the sum is read back into, and integer atomics make
+// the sum independent of arrival order (float atomics differ by an ulp from run to run, which the resampler's
+// equal-weight ties amplify into different survivors).
+#define CK_FIX_SCALE 17179869184.0
+// round to the nearest multiple of 2^-34 (magic-number rounding, valid below 2^18): sums of snapped terms are exact in
+// double while they stay below 2^19, far above any Ck the filter can produce
+__device__ __forceinline__ double ck_snap(float a) { return __dsub_rn(__dadd_rn((double)a, 393216.0), 393216.0); }
+__device__ __forceinline__ float ck_from_fix(long long v) { return (float)((double)v * (1.0 / CK_FIX_SCALE)); }
 
 // particle storage index: tiles of 64 voxels, slot-major inside a tile (see dspmap_sweep.hip)
 __device__ __forceinline__ size_t pidx(const MapDims& d, int lv, int slot) {

@@ -19,6 +19,8 @@ struct KernelScratch {
     int* ck_items;      // [np * ceil(capp/128)] work items of k_ck_partial (pyramid<<12 | chunk)
     int* wu_items;      // [np * (ceil(capp/256)+1)] work items of k_weight
     int* n_items;       // [2]
+    int* nb_tab;        // [NB_TAB_STRIDE][np] neighbourhood of every pyramid: bins (h-major, -1 padded) + exclusive offsets of
+                        // their observation counts, written by k_pyr_items once per frame
     int* part_birth;    // [ceil(birth_cap*32/256)*2] per-block {born, dropped} of k_birth_insert
     float4* child;      // [birth_cap*32] child position + destination voxel of this frame's births
     int* work_list;     // [v_loc] scratch: per-voxel prefix of the constructor-seeded particles' noise ranks (k_vz_count)

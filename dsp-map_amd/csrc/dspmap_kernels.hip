@@ -241,7 +241,7 @@ __device__ __forceinline__ int block_excl_scan_multi(int (&v)[NB], int* s_tmp) {
 __device__ __forceinline__ int wu_split(int O) { return O <= 64 ? 1 : (O <= 128 ? 2 : (O <= 256 ? 4 : 8)); }
 
 __global__ void __launch_bounds__(512) k_pyr_items(MapDims d, DevState s, int* __restrict__ ck_items, int* __restrict__ wu_items,
-                                                   int* __restrict__ n_items) {
+                                                   int* __restrict__ n_items, int* __restrict__ nb_tab) {
     __shared__ int s_tmp[17];
     const int tid = threadIdx.x;
     int base_ck = 0, base_wu = 0;
@@ -252,12 +252,22 @@ __global__ void __launch_bounds__(512) k_pyr_items(MapDims d, DevState s, int* _
             const int P = min(s.pyr_cnt[b], d.capp);
             // observations in the 3x3 neighbourhood: decides how many lanes share one particle in k_weight
             const int h0 = b / d.np_v, v0 = b % d.np_v;
-            int O = 0;
+            // ... and the neighbourhood table the items of this pyramid read instead of rebuilding it: valid
+            // neighbours compacted in h-major order (findPyramidNeighborIndexInFOV :1128-1147) + offsets
+            int O = 0, nv = 0;
+            int* tab = nb_tab + b;   // entry e of pyramid b at [e * np + b]: lanes = pyramids, coalesced stores
             for (int i = -d.nn; i <= d.nn; ++i)
                 for (int j = -d.nn; j <= d.nn; ++j) {
                     const int h = h0 + i, v = v0 + j;
-                    if (h >= 0 && h < d.np_h && v >= 0 && v < d.np_v) O += s.obs_cnt[h * d.np_v + v];
+                    if (h >= 0 && h < d.np_h && v >= 0 && v < d.np_v) {
+                        tab[(size_t)nv * d.np] = h * d.np_v + v;
+                        tab[(size_t)(DSP_MAX_NBINS + nv) * d.np] = O;
+                        O += s.obs_cnt[h * d.np_v + v];
+                        ++nv;
+                    }
                 }
+            for (; nv < d.nbins; ++nv) { tab[(size_t)nv * d.np] = -1; tab[(size_t)(DSP_MAX_NBINS + nv) * d.np] = O; }
+            tab[(size_t)(DSP_MAX_NBINS + d.nbins) * d.np] = O;
             const int pw = WU_TPB / wu_split(O);      // particles per k_weight item
             nck = O > 0 ? (P + CK_PCH - 1) / CK_PCH : 0;
             nwu = max(1, (P + pw - 1) / pw);          // chunk 0 always exists: it owns the bin's 1/Ck sum
@@ -285,63 +295,43 @@ __device__ __forceinline__ int neighbor_bins(const MapDims& d, int b, int* bins)
 }
 
 // neighbourhood table of a pyramid in LDS: s_bin[nbins] bins, s_off[nbins+1] exclusive offsets of their
-// observation counts (nbins = (2*nn+1)^2 <= 25).  The counts are loaded by nbins lanes at once (one round trip).
-__device__ __forceinline__ void neighbor_setup(const MapDims& d, const DevState& s, int b, int* s_bin, int* s_off) {
+// observation counts (nbins = (2*nn+1)^2 <= 25), copied from k_pyr_items' table: one load, one barrier.
+__device__ __forceinline__ void neighbor_load(const MapDims& d, const int* __restrict__ nb_tab, int b, int* s_bin, int* s_off) {
     const int tid = threadIdx.x;
-    if (tid < 64) {   // first wave (ballot below)
-        const int side = 2 * d.nn + 1;
-        const int h0 = b / d.np_v, v0 = b % d.np_v;
-        const bool lane = tid < d.nbins;
-        const int h = h0 + tid / side - d.nn, v = v0 + tid % side - d.nn;
-        const bool ok = lane && h >= 0 && h < d.np_h && v >= 0 && v < d.np_v;
-        const int bin = ok ? h * d.np_v + v : -1;
-        const int cnt = ok ? s.obs_cnt[bin] : 0;
-        // compact valid neighbours in h-major order (findPyramidNeighborIndexInFOV :1128-1147)
-        const u64 okm = __ballot(ok);
-        const int slot = (int)__popcll(okm & ((1ull << tid) - 1ull));
-        if (lane) s_bin[tid] = -1;
-        __builtin_amdgcn_s_waitcnt(0);
-        if (ok) { s_bin[slot] = bin; s_off[slot] = cnt; }
-    }
-}
-__device__ __forceinline__ void neighbor_prefix(const MapDims& d, int* s_bin, int* s_off) {
-    if (threadIdx.x == 0) {
-        int off = 0;
-        for (int k = 0; k < d.nbins; ++k) {
-            const int c = s_bin[k] >= 0 ? s_off[k] : 0;
-            s_off[k] = off;
-            off += c;
-        }
-        s_off[d.nbins] = off;
-    }
+    const int* tab = nb_tab + b;   // entry e of pyramid b at [e * np + b]
+    if (tid < d.nbins) s_bin[tid] = tab[(size_t)tid * d.np];
+    else if (tid >= 32 && tid - 32 <= d.nbins) s_off[tid - 32] = tab[(size_t)(DSP_MAX_NBINS + tid - 32) * d.np];
 }
 
 __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, FilterParams fp, const int* __restrict__ items,
-                                                       const int* __restrict__ n_items) {
+                                                       const int* __restrict__ n_items, const int* __restrict__ nb_tab) {
     __shared__ float4 s_p[CK_PCH];
     __shared__ int s_bin[DSP_MAX_NBINS];
     __shared__ int s_off[DSP_MAX_NBINS + 1];
     const int tid = threadIdx.x;
     const int total = n_items[0];
+    int item_next = blockIdx.x < total ? items[blockIdx.x] : 0;
     for (int it = blockIdx.x; it < total; it += gridDim.x) {
-        const int item = items[it];
+        // the dependent-load chain of an item is what bounds this kernel (few pairs per lane): everything that only
+        // needs the item id is requested at once -- particle count, neighbourhood table, the chunk's particles (read
+        // unmasked, rows always exist) and the next item's id
+        const int item = item_next;
         const int b = item >> 12, chunk = item & 0xfff;
-        const int P = min(s.pyr_cnt[b], d.capp);
         const int start = chunk * CK_PCH;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < CK_PCH && start + tid < d.capp) r = s.fov_rec[(size_t)b * d.capp + start + tid];
+        const int P = min(s.pyr_cnt[b], d.capp);
+        if (it + (int)gridDim.x < total) item_next = items[it + gridDim.x];
         const int npart = min(CK_PCH, P - start);
         __syncthreads();  // LDS reuse across items
-        neighbor_setup(d, s, b, s_bin, s_off);
-        __syncthreads();
-        neighbor_prefix(d, s_bin, s_off);
+        neighbor_load(d, nb_tab, b, s_bin, s_off);
+        if (tid < CK_PCH) {
+            r.w = fp.p_det * r.w;  // P_detection * weight (pre-update weights), :732
+            s_p[tid] = r;
+        }
         __syncthreads();
         const int O = s_off[d.nbins];
         if (O == 0) continue;
-        for (int i = tid; i < npart; i += CK_TPB) {
-            float4 r = s.fov_rec[(size_t)b * d.capp + start + i];
-            r.w = fp.p_det * r.w;  // P_detection * weight (pre-update weights), :732
-            s_p[i] = r;
-        }
-        __syncthreads();
         // lanes = (observation, particle group): with few observations the 256 lanes split the particle
         // chunk G ways so that every lane is busy and the loop is short; partial sums meet in the (fixed-point, order-independent) atomic
         const int opad = O <= 64 ? 64 : (O <= 128 ? 128 : 256);
@@ -355,7 +345,15 @@ __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, Fi
             // every term is snapped to the 2^-34 grid before it is added, so the (double) partial sum is exact and the
             // total does not depend on the order of the particles in the pyramid's list either (built with atomics)
             double acc = 0.0;
-            for (int i = g; i < npart; i += G) {
+            int i = g;
+            for (; i + G < npart; i += 2 * G) {   // two particles per iteration: packed fp32
+                const float4 p = s_p[i], p2 = s_p[i + G];
+                const f2v gk = pair_gk2(f2v{p.x, p2.x}, f2v{p.y, p2.y}, f2v{p.z, p2.z}, f2v{z.x, z.x}, f2v{z.y, z.y}, f2v{z.z, z.z},
+                                        fp.sigma_ob, fp.inv_sigma_ob, fp.pdf_c3);
+                acc = __dadd_rn(acc, ck_snap(p.w * gk.x));
+                acc = __dadd_rn(acc, ck_snap(p2.w * gk.y));
+            }
+            if (i < npart) {
                 const float4 p = s_p[i];
                 acc = __dadd_rn(acc, ck_snap(p.w * pair_gk(p.x, p.y, p.z, z.x, z.y, z.z, fp.sigma_ob, fp.inv_sigma_ob, fp.pdf_c3)));
             }
@@ -386,7 +384,7 @@ __global__ void __launch_bounds__(512) k_ck_sum(MapDims d, DevState s, FilterPar
 // staged in LDS and broadcast.  The new weight is scattered back to the slot.
 // --------------------------------------------------------------------------
 __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, FilterParams fp, const int* __restrict__ items,
-                                                   const int* __restrict__ n_items) {
+                                                   const int* __restrict__ n_items, const int* __restrict__ nb_tab) {
     extern __shared__ float4 s_o[];   // [nbins * DSP_OBS_CAP]: the neighbourhood's observations {x, y, z, P_d/Ck}
     __shared__ int s_bin[DSP_MAX_NBINS];
     __shared__ int s_off[DSP_MAX_NBINS + 1];
@@ -414,9 +412,7 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
             if (tid == 0) s.part_inv[b] = (s_inv[0] + s_inv[1]) + (s_inv[2] + s_inv[3]);
             if (P == 0) continue;
         }
-        neighbor_setup(d, s, b, s_bin, s_off);
-        __syncthreads();
-        neighbor_prefix(d, s_bin, s_off);
+        neighbor_load(d, nb_tab, b, s_bin, s_off);
         __syncthreads();
         const int O = s_off[d.nbins];
         for (int o = tid; o < O; o += WU_TPB) {
@@ -446,11 +442,20 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
             occluded = maxlen > 0.f && dist > maxlen + fp.occl_margin;  // :761-765
         }
         float sum = 0.f;
-        if (valid && !occluded)
-            for (int o = sub; o < O; o += spl) {
+        if (valid && !occluded) {
+            int o = sub;
+            for (; o + spl < O; o += 2 * spl) {   // two observations per iteration: packed fp32, same summation order
+                const float4 z = s_o[o], z2 = s_o[o + spl];
+                const f2v gk = pair_gk2(f2v{p.x, p.x}, f2v{p.y, p.y}, f2v{p.z, p.z}, f2v{z.x, z2.x}, f2v{z.y, z2.y}, f2v{z.z, z2.z},
+                                        fp.sigma_ob, fp.inv_sigma_ob, fp.pdf_c3);
+                sum += gk.x * z.w;
+                sum += gk.y * z2.w;
+            }
+            if (o < O) {
                 const float4 z = s_o[o];
                 sum += pair_gk(p.x, p.y, p.z, z.x, z.y, z.z, fp.sigma_ob, fp.inv_sigma_ob, fp.pdf_c3) * z.w;
             }
+        }
         if (spl >= 2) sum += __shfl_xor(sum, 1, WAVE);
         if (spl >= 4) sum += __shfl_xor(sum, 2, WAVE);
         if (spl >= 8) sum += __shfl_xor(sum, 4, WAVE);
@@ -832,15 +837,15 @@ void launch_obs_bin(const LaunchCtx& c, int n_pts_grid) {
 }
 
 void launch_ck_partial(const LaunchCtx& c) {
-    hipLaunchKernelGGL(k_pyr_items, dim3(1), dim3(512), 0, c.stream, c.d, c.s, c.k.ck_items, c.k.wu_items, c.k.n_items);
-    hipLaunchKernelGGL(k_ck_partial, dim3(4096), dim3(CK_TPB), 0, c.stream, c.d, c.s, c.fp, c.k.ck_items, c.k.n_items);
+    hipLaunchKernelGGL(k_pyr_items, dim3(1), dim3(512), 0, c.stream, c.d, c.s, c.k.ck_items, c.k.wu_items, c.k.n_items, c.k.nb_tab);
+    hipLaunchKernelGGL(k_ck_partial, dim3(4096), dim3(CK_TPB), 0, c.stream, c.d, c.s, c.fp, c.k.ck_items, c.k.n_items, c.k.nb_tab);
 }
 void launch_ck_finalize(const LaunchCtx& c) {  // after launch_weight_update: reduces the per-pyramid 1/Ck sums
     hipLaunchKernelGGL(k_ck_sum, dim3(1), dim3(512), 0, c.stream, c.d, c.s, c.fp);
 }
 void launch_weight_update(const LaunchCtx& c) {  // after launch_ck_partial (which also builds the item lists)
     hipLaunchKernelGGL(k_weight, dim3(4096), dim3(WU_TPB), sizeof(float4) * (size_t)c.d.nbins * DSP_OBS_CAP, c.stream, c.d, c.s, c.fp,
-                       c.k.wu_items, c.k.n_items);
+                       c.k.wu_items, c.k.n_items, c.k.nb_tab);
 }
 
 // n_birth_grid sizes the launches (>= the frame's n_birth, which the kernels read from FrameParams)

@@ -20,6 +20,7 @@
 
 #define DSP_MAX_PRED 16
 #define DSP_MAX_NBINS 25           // neighbourhood bins supported by the pair kernels (radius <= 2)
+#define NB_TAB_STRIDE (2 * DSP_MAX_NBINS + 2)   // ints per pyramid in KernelScratch::nb_tab: bins, then offsets
 #define DSP_OBS_CAP 100            // observation_max_points_num_one_pyramid :69
 #define DSP_MAX_PLANES_H 129       // np_h + 1 boundary planes
 #define DSP_MAX_PLANES_V 97
