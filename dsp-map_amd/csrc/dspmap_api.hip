@@ -92,6 +92,7 @@ static void derive_dims(dspmap* m) {
     d.half_y = (d.res * (float)c.ny) * 0.5f;
     d.half_z = (d.res * (float)c.nz) * 0.5f;
     for (int i = 0; i < d.T; ++i) d.pred_t[i] = c.prediction_future_time[i];
+    d.rng_inv_bw = (float)PS_NBK / sqrtf(d.half_x * d.half_x + d.half_y * d.half_y + d.half_z * d.half_z);
 }
 
 static void refresh_fp(dspmap* m) {
@@ -100,6 +101,7 @@ static void refresh_fp(dspmap* m) {
     const float pi_2 = 1.57079632679489661923f;
     f.pdf_c = 1.f / sqrtf(2.f * pi_2);  // standardNormalPDF :1284 at 0
     f.pdf_c3 = f.pdf_c * f.pdf_c * f.pdf_c;
+    f.cull_r = 9.f * f.sigma_ob;
 }
 
 extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
@@ -146,7 +148,7 @@ static void free_dev(dspmap* m) {
     if (m->mgpu_count) chk(hipFree(m->mgpu_count), "hipFree");
     void* ptrs[] = {s.fpar, s.obs_ckf, s.part_inv, s.fut_stat, s.mask, s.nbmask, s.pos, s.vel, s.w, s.vz0, s.res4, s.fut, s.obs, s.obs_ck,
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
-                    s.birth, s.plan, s.nstatic, s.fov_rec, s.fov_slot, s.pyr_cnt,
+                    s.birth, s.plan, s.nstatic, s.fov_rec, s.fov_slot, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
                     m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
@@ -286,6 +288,8 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&s.planes_h0, (size_t)(d.np_h + 1) * 3)); HIPCHK(m, dalloc(&s.planes_v0, (size_t)(d.np_v + 1) * 3));
     HIPCHK(m, dalloc(&s.fov_rec, (size_t)d.np * d.capp));
     HIPCHK(m, dalloc(&s.fov_slot, (size_t)d.np * d.capp));
+    HIPCHK(m, dalloc(&s.fov_rec_s, (size_t)d.np * d.capp));
+    HIPCHK(m, dalloc(&s.fov_slot_s, (size_t)d.np * d.capp));
     HIPCHK(m, dalloc(&s.pyr_cnt, (size_t)d.np));
     HIPCHK(m, dalloc(&s.fs, (size_t)1));
     HIPCHK(m, dalloc(&s.fpar, (size_t)1));

@@ -20,6 +20,7 @@
 
 #define DSP_MAX_PRED 16
 #define DSP_MAX_NBINS 25           // neighbourhood bins supported by the pair kernels (radius <= 2)
+#define PS_NBK 128                 // range buckets per pyramid list (k_pyr_sort)
 #define NB_TAB_STRIDE (2 * DSP_MAX_NBINS + 2)   // ints per pyramid in KernelScratch::nb_tab: bins, then offsets
 #define DSP_OBS_CAP 100            // observation_max_points_num_one_pyramid :69
 #define DSP_MAX_PLANES_H 129       // np_h + 1 boundary planes
@@ -44,6 +45,7 @@ struct MapDims {
     int static_model;      // dsp_static.h's motion model: velocities forced to 0 in prediction
     float res;
     float half_x, half_y, half_z; // :528-530
+    float rng_inv_bw;             // range buckets of k_pyr_sort: bucket = (int)(|p| * rng_inv_bw), PS_NBK buckets to the map corner
     float pred_t[DSP_MAX_PRED];
 };
 
@@ -59,6 +61,7 @@ struct FilterParams {
     float pdf_c;           // 1/sqrtf(2*pi/2): centre of the reference's LUT :1284
     float pdf_c3;          // pdf_c^3
     float occl_margin;     // obstacle_thickness_for_occlusion :70
+    float cull_r;          // 9 * sigma_ob: a particle and an observation whose ranges differ by more contribute < 1e-19 (pair kernels)
     int tab_n;             // Gaussian table length :72
     int rtab_n;            // rand table length
 };
@@ -136,6 +139,8 @@ struct DevState {
     // FOV staging
     float4* fov_rec;   // [np*capp] {x,y,z,w}
     int* fov_slot;     // [np*capp] local slot index (lv*slots+s)
+    float4* fov_rec_s; // the same lists ordered by range bucket (k_pyr_sort), read by the pair kernels
+    int* fov_slot_s;
     int* pyr_cnt;      // [np]
     // readout scratch
     int* blk_cnt;      // [ceil(v_loc/256)+1]
