@@ -541,7 +541,7 @@ int dspmap_gate_and_delta(dspmap* m, const float pos[3], double stamp, const flo
 static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid, bool fork, bool all_static) {
     dspmap_prof_mark(m, 0);
     if (!fork) {
-        launch_setup_and_bin(c, pts_grid);
+        launch_setup_and_bin(c, pts_grid, false);   // the gather rides on k_predict's launch
     } else {
         launch_frame_setup(c, true);
         (void)hipEventRecord(m->ev_fork, m->stream);
@@ -552,7 +552,7 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
         (void)hipEventRecord(m->ev_join, m->stream2);
     }
     dspmap_prof_mark(m, 1);
-    launch_predict_only(c);
+    launch_predict_only(c, !fork);
     dspmap_prof_mark(m, 2);
     launch_claim(c);
     if (fork) (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
@@ -590,8 +590,8 @@ static int frame_with_host_stages(dspmap* m, int np, const float* pts_dev, const
     int rc = dspmap_push_frame_params(m);
     if (rc != DSPMAP_OK) return rc;
     HIPCHK(m, hipEventRecord(m->ev0, m->stream));
-    launch_setup_and_bin(c, np);
-    launch_predict(c);
+    launch_setup_and_bin(c, np, false);
+    launch_predict(c, true);
     launch_ck_partial(c);
     launch_weight_update(c);
     int nb = np;

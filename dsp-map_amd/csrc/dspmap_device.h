@@ -215,6 +215,47 @@ __device__ __forceinline__ f2v pair_gk2(f2v px, f2v py, f2v pz, f2v ox, f2v oy, 
 __device__ __forceinline__ double ck_snap(float a) { return __dsub_rn(__dadd_rn((double)a, 393216.0), 393216.0); }
 __device__ __forceinline__ float ck_from_fix(long long v) { return (float)((double)v * (1.0 / CK_FIX_SCALE)); }
 
+#define GU 16
+// obs_gather_wave: one wave per pyramid (k_obs_gather; in a whole frame the extra workgroups of k_predict).  Appends matching points in INPUT order
+// (stable, ballot + prefix popcount) to the pyramid's bin, keeps the first 99
+// (count saturates, :279-284), tracks the max range over ALL matches (:275-277).
+__device__ __forceinline__ void obs_gather_wave(const MapDims& d, const DevState& s, const int b) {
+    const int n_pts = s.fpar->n_pts;
+    const int l = lane_id();
+    int count = 0;
+    float maxlen = -1.f;
+    for (int base = 0; base < n_pts; base += GU * WAVE) {
+        int pid[GU];
+#pragma unroll
+        for (int k = 0; k < GU; ++k) {  // GU independent loads in flight: the scan is a chain of L2 round trips
+            const int i = base + k * WAVE + l;
+            pid[k] = i < n_pts ? s.pt_pyr[i] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < GU; ++k) {
+            const int i = base + k * WAVE + l;
+            const bool match = pid[k] == b;
+            const u64 m = __ballot(match);
+            if (match) {
+                const int pos = count + (int)__popcll(m & lanemask_lt());
+                const float4 p = s.pt_rot[i];
+                if (pos < DSP_OBS_CAP - 1) s.obs[b * DSP_OBS_CAP + pos] = p;
+                maxlen = fmaxf(maxlen, p.w);
+            }
+            count += (int)__popcll(m);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxlen = fmaxf(maxlen, __shfl_xor(maxlen, o, WAVE));
+    if (l == 0) {
+        const int c = min(count, DSP_OBS_CAP - 1);
+        s.obs_cnt[b] = c;
+        s.obs_maxlen[b] = maxlen;
+        if (c) atomicAdd(&s.fs->n_obs, c);
+        if (count) atomicAdd(&s.fs->n_valid, count);   // valid_points :286 counts the overflowed points too
+    }
+}
+
 // particle storage index: tiles of 64 voxels, slot-major inside a tile (see dspmap_sweep.hip)
 __device__ __forceinline__ size_t pidx(const MapDims& d, int lv, int slot) {
     return ((size_t)(lv >> 6) * d.slots + slot) * 64 + (lv & 63);

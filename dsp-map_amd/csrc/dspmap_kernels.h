@@ -41,10 +41,10 @@ struct LaunchCtx {
 void launch_frame_setup(const LaunchCtx& c, bool reset_obs);
 // observation binning (:244-290)
 void launch_obs_bin(const LaunchCtx& c, int n_pts_grid);
-void launch_setup_and_bin(const LaunchCtx& c, int n_pts_grid);
+void launch_setup_and_bin(const LaunchCtx& c, int n_pts_grid, bool gather = true);   // gather = false: launch_predict*(c, true) does it
 // mapPrediction (:627-701) incl. re-binning of movers (moveParticle :1206-1274)
-void launch_predict(const LaunchCtx& c);
-void launch_predict_only(const LaunchCtx& c);
+void launch_predict(const LaunchCtx& c, bool with_gather = false);
+void launch_predict_only(const LaunchCtx& c, bool with_gather = false);
 void launch_scan_blocks(const LaunchCtx& c, int nblk);   // exclusive scan of s.blk_cnt[0..nblk), total -> fs->occupied_count
 void launch_claim(const LaunchCtx& c);
 void launch_reduce_counters(const LaunchCtx& c);

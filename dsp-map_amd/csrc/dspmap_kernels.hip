@@ -123,47 +123,7 @@ __global__ void __launch_bounds__(256) k_obs_points(MapDims d, DevState s) {
     }
 }
 
-#define GU 16
-// k_obs_gather: one wave per pyramid.  Appends matching points in INPUT order
-// (stable, ballot + prefix popcount) to the pyramid's bin, keeps the first 99
-// (count saturates, :279-284), tracks the max range over ALL matches (:275-277).
-__global__ void k_obs_gather(MapDims d, DevState s) {
-    const int n_pts = s.fpar->n_pts;
-    const int b = blockIdx.x;
-    const int l = lane_id();
-    int count = 0;
-    float maxlen = -1.f;
-    for (int base = 0; base < n_pts; base += GU * WAVE) {
-        int pid[GU];
-#pragma unroll
-        for (int k = 0; k < GU; ++k) {  // GU independent loads in flight: the scan is a chain of L2 round trips
-            const int i = base + k * WAVE + l;
-            pid[k] = i < n_pts ? s.pt_pyr[i] : -1;
-        }
-#pragma unroll
-        for (int k = 0; k < GU; ++k) {
-            const int i = base + k * WAVE + l;
-            const bool match = pid[k] == b;
-            const u64 m = __ballot(match);
-            if (match) {
-                const int pos = count + (int)__popcll(m & lanemask_lt());
-                const float4 p = s.pt_rot[i];
-                if (pos < DSP_OBS_CAP - 1) s.obs[b * DSP_OBS_CAP + pos] = p;
-                maxlen = fmaxf(maxlen, p.w);
-            }
-            count += (int)__popcll(m);
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) maxlen = fmaxf(maxlen, __shfl_xor(maxlen, o, WAVE));
-    if (l == 0) {
-        const int c = min(count, DSP_OBS_CAP - 1);
-        s.obs_cnt[b] = c;
-        s.obs_maxlen[b] = maxlen;
-        if (c) atomicAdd(&s.fs->n_obs, c);
-        if (count) atomicAdd(&s.fs->n_valid, count);   // valid_points :286 counts the overflowed points too
-    }
-}
+__global__ void k_obs_gather(MapDims d, DevState s) { obs_gather_wave(d, s, (int)blockIdx.x); }
 
 // --------------------------------------------------------------------------
 // k_pyr_sort: one workgroup per pyramid orders its particle list by RANGE bucket (counting sort in LDS).
@@ -989,10 +949,10 @@ void launch_frame_setup(const LaunchCtx& c, bool reset_obs) {
     hipLaunchKernelGGL(k_reset, dim3(grid), dim3(1024), 0, c.stream, c.d, c.s, flags);
 }
 
-void launch_setup_and_bin(const LaunchCtx& c, int n_pts_grid) {   // whole frame: launch_frame_setup(c, true) + launch_obs_bin
+void launch_setup_and_bin(const LaunchCtx& c, int n_pts_grid, bool gather) {   // whole frame: launch_frame_setup(c, true) + launch_obs_bin
     const int grid = n_pts_grid > 0 ? (n_pts_grid + 255) / 256 : 1;
     hipLaunchKernelGGL(k_obs_points<true>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s);
-    hipLaunchKernelGGL(k_obs_gather, dim3(c.d.np), dim3(WAVE), 0, c.stream, c.d, c.s);
+    if (gather) hipLaunchKernelGGL(k_obs_gather, dim3(c.d.np), dim3(WAVE), 0, c.stream, c.d, c.s);
 }
 void launch_obs_bin(const LaunchCtx& c, int n_pts_grid) {
     if (n_pts_grid > 0) hipLaunchKernelGGL(k_obs_points<false>, dim3((n_pts_grid + 255) / 256), dim3(256), 0, c.stream, c.d, c.s);

@@ -52,8 +52,8 @@ extern "C" int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_
     if (rcp != DSPMAP_OK) return rcp;
     dspmap_prof_collect(m);
     HIPCHK(m, hipEventRecord(m->ev0, m->stream));
-    launch_setup_and_bin(c, n_points);
-    launch_predict_only(c);       // k_place follows the exchange: imported movers take part in the sweep-order placement
+    launch_setup_and_bin(c, n_points, false);
+    launch_predict_only(c, true);       // k_place follows the exchange: imported movers take part in the sweep-order placement
     m->mgpu_place_pending = true;
     m->vz_frames_at_begin = m->vz_frames;
     if (m->vz_frames > 0) --m->vz_frames;

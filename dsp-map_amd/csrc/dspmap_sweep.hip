@@ -196,6 +196,14 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
     const int tid = threadIdx.x;
     const int l = lane_id();
     const int wave = tid >> 6;
+    // whole frame: the observation gather (448 independent waves, a chain of L2 round trips over the frame's points)
+    // rides on this launch as extra workgroups behind the tiles -- it only needs k_obs_points' output, like the tiles
+    const int ntile = (d.v_loc + 63) >> 6;
+    if ((int)blockIdx.x >= ntile) {
+        const int b = ((int)blockIdx.x - ntile) * NW + wave;
+        if (b < d.np) obs_gather_wave(d, s, b);
+        return;
+    }
     const int lv = blockIdx.x * 64 + l;   // all four waves of the block look at the same tile
     if (s.fpar->clear_fut) {
         // clearOccupancyMapPrediction (:431-438) was requested since the last frame: this tile's share of the
@@ -1247,7 +1255,7 @@ __global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScra
 // ==========================================================================
 // launchers
 // ==========================================================================
-void launch_predict_only(const LaunchCtx& c) {
+void launch_predict_only(const LaunchCtx& c, bool with_gather) {
     const KernelScratch* k = &c.k;
     if (c.s.vz0) {   // constructor-seeded particles take their velocity noise in the reference's sweep order
         const int nblk = (c.d.v_loc + 255) / 256;
@@ -1256,10 +1264,10 @@ void launch_predict_only(const LaunchCtx& c) {
         launch_scan_blocks(c, nblk);   // blk_cnt -> exclusive, total -> fs->occupied_count
     }
     if (c.d.mw == 1)
-        hipLaunchKernelGGL((k_predict<1, 4>), dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, c.fp,
+        hipLaunchKernelGGL((k_predict<1, 4>), dim3(k->ntiles + (with_gather ? (c.d.np + 3) / 4 : 0)), dim3(256), 0, c.stream, c.d, c.s, c.fp,
                            c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask);
     else
-        hipLaunchKernelGGL((k_predict<2, 4>), dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, c.fp,
+        hipLaunchKernelGGL((k_predict<2, 4>), dim3(k->ntiles + (with_gather ? (c.d.np + 3) / 4 : 0)), dim3(256), 0, c.stream, c.d, c.s, c.fp,
                            c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask);
 }
 void launch_claim(const LaunchCtx& c) {
@@ -1267,8 +1275,8 @@ void launch_claim(const LaunchCtx& c) {
     if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask);
     else hipLaunchKernelGGL(k_place<2>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask);
 }
-void launch_predict(const LaunchCtx& c) {
-    launch_predict_only(c);
+void launch_predict(const LaunchCtx& c, bool with_gather) {
+    launch_predict_only(c, with_gather);
     launch_claim(c);
 }
 void launch_resample(const LaunchCtx& c) {
