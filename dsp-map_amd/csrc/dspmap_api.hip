@@ -148,7 +148,7 @@ static void free_dev(dspmap* m) {
     if (m->mgpu_count) chk(hipFree(m->mgpu_count), "hipFree");
     void* ptrs[] = {s.fpar, s.obs_ckf, s.part_inv, s.fut_stat, s.mask, s.nbmask, s.pos, s.vel, s.w, s.vz0, s.res4, s.fut, s.obs, s.obs_ck,
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
-                    s.birth, s.plan, s.nstatic, s.fov_rec, s.fov_slot, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt,
+                    s.birth, s.plan, s.plan_pbase, s.nstatic, s.fov_rec, s.fov_slot, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
                     m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
@@ -233,12 +233,13 @@ int dspmap_ensure_point_cap(dspmap* m, int n) {
     DevState& s = m->s;
     const int cap = n + n / 2 + 1024;
     if (m->mgpu_bound) return dspmap_fail(m, DSPMAP_E_ARG, "%d points exceed the capacity bound with dspmap_mgpu_bind", n);
-    void* olds[] = {s.pt_rot, s.pt_pyr, s.birth, s.plan, s.nstatic, m->pts_dev, m->k.child, m->k.part_birth};
+    void* olds[] = {s.pt_rot, s.pt_pyr, s.birth, s.plan, s.plan_pbase, s.nstatic, m->pts_dev, m->k.child, m->k.part_birth};
     for (void* p : olds) if (p) (void)hipFree(p);
     HIPCHK(m, dalloc(&s.pt_rot, (size_t)cap));
     HIPCHK(m, dalloc(&s.pt_pyr, (size_t)cap));
     HIPCHK(m, dalloc(&s.birth, (size_t)cap));
     HIPCHK(m, dalloc(&s.plan, (size_t)cap));
+    HIPCHK(m, dalloc(&s.plan_pbase, (size_t)cap));
     HIPCHK(m, dalloc(&s.nstatic, (size_t)cap));
     HIPCHK(m, dalloc(&m->pts_dev, (size_t)cap * 3));
     HIPCHK(m, dalloc(&m->k.child, (size_t)cap * 32));

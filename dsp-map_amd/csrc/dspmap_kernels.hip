@@ -591,20 +591,22 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
 // k_birth_split: one wave per source point.  Dempster-Shafer static/dynamic
 // split from the mass already in the point's voxel (:827-866), lanes = slots.
 // --------------------------------------------------------------------------
-__global__ void k_birth_split(MapDims d, DevState s, FilterParams fp) {
+// is source point i a birth source, and in which voxel (:818-820, :827 / :847)
+__device__ __forceinline__ bool birth_src_voxel(const MapDims& d, const DevState& s, const BirthSrc& src, float& cx, float& cy, float& cz, int& gv) {
+    cx = src.x - s.fs->cur_pos[0];  // :818-820
+    cy = src.y - s.fs->cur_pos[1];
+    cz = src.z - s.fs->cur_pos[2];
+    return src.intensity > -1.5f && voxel_of(d, cx, cy, cz, gv);  // :827 / :847
+}
+__device__ __forceinline__ void birth_split_wave(const MapDims& d, const DevState& s, const FilterParams& fp, int i) {
     const int n_birth = s.fpar->n_birth;
-    const int wpb = blockDim.x / WAVE;
-    const int i = blockIdx.x * wpb + threadIdx.x / WAVE;
     if (i >= n_birth) return;
     const int l = lane_id();
     const BirthSrc src = s.fpar->birth[i];
     BirthPlan pl;
-    pl.cx = src.x - s.fs->cur_pos[0];  // :818-820
-    pl.cy = src.y - s.fs->cur_pos[1];
-    pl.cz = src.z - s.fs->cur_pos[2];
     pl.gvox = -1; pl.n_static = 0; pl.inside = 0; pl.pbase = pl.vbase = pl.rbase = 0;
     int gv;
-    const bool ok = src.intensity > -1.5f && voxel_of(d, pl.cx, pl.cy, pl.cz, gv);  // :827 / :847
+    const bool ok = birth_src_voxel(d, s, src, pl.cx, pl.cy, pl.cz, gv);
     int n_static = 0;
     if (ok) {
         pl.gvox = gv;
@@ -638,6 +640,9 @@ __global__ void k_birth_split(MapDims d, DevState s, FilterParams fp) {
     pl.n_static = n_static;
     if (l == 0) { s.plan[i] = pl; s.nstatic[i] = n_static; }
 }
+__global__ void k_birth_split(MapDims d, DevState s, FilterParams fp) {
+    birth_split_wave(d, s, fp, (int)(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE));
+}
 
 // The sequential consumption order of the three random streams (:871-873 position table,
 // :884-886 velocity table, :895-897 rand()) is reproduced with block-wide prefix sums over the
@@ -665,7 +670,7 @@ __device__ __forceinline__ void ck_sum_block(const MapDims& d, const DevState& s
         s.fs->newborn_w = fp.nb_weight * s_red[0];  // :805
     }
 }
-__global__ void __launch_bounds__(1024) k_birth_rank(MapDims d, DevState s, FilterParams fp, int with_ck_sum) {
+__device__ __forceinline__ void birth_rank_block(const MapDims& d, const DevState& s, const FilterParams& fp, int with_ck_sum) {
     const int n_birth = s.fpar->n_birth;
     __shared__ int s_tmp[BK * 16 + 1];
     __shared__ float s_red[512];
@@ -680,16 +685,27 @@ __global__ void __launch_bounds__(1024) k_birth_rank(MapDims d, DevState s, Filt
 #pragma unroll
         for (int j = 0; j < BK; ++j) {   // coalesced index, all loads in flight together
             const int i = base + j * 1024 + tid;
-            ok[j] = i < n_birth && s.plan[i].gvox >= 0;
+            // validity straight from the source point (what k_birth_split stores as plan.gvox >= 0): the rank does not
+            // wait for the split
+            float cx, cy, cz; int gv;
+            ok[j] = i < n_birth && birth_src_voxel(d, s, s.fpar->birth[i], cx, cy, cz, gv);
             v[j] = ok[j] ? 1 : 0;
         }
         const int tot = block_excl_scan_multi<BK>(v, s_tmp);
 #pragma unroll
         for (int j = 0; j < BK; ++j)
-            if (ok[j]) s.plan[base + j * 1024 + tid].pbase = (int)(((long long)p_cur + 3ll * nb * (long long)(run + v[j])) % fp.tab_n);
+            if (ok[j]) s.plan_pbase[base + j * 1024 + tid] = (int)(((long long)p_cur + 3ll * nb * (long long)(run + v[j])) % fp.tab_n);
         run += tot;
     }
     if (tid == 0) s.fs->p_cur = (int)(((long long)p_cur + 3ll * nb * run) % fp.tab_n);
+}
+__global__ void __launch_bounds__(1024) k_birth_rank(MapDims d, DevState s, FilterParams fp, int with_ck_sum) {
+    birth_rank_block(d, s, fp, with_ck_sum);
+}
+// whole frame: the split (one wave per source point) and the rank (one workgroup, independent of the split) in ONE launch
+__global__ void __launch_bounds__(1024) k_birth_split_rank(MapDims d, DevState s, FilterParams fp, int with_ck_sum) {
+    if (blockIdx.x == gridDim.x - 1) birth_rank_block(d, s, fp, with_ck_sum);
+    else birth_split_wave(d, s, fp, (int)(blockIdx.x * (1024 / WAVE) + threadIdx.x / WAVE));
 }
 
 // Children are inserted in the reference's sequential order WITHOUT a sort:
@@ -712,7 +728,7 @@ __global__ void k_birth_children(MapDims d, DevState s, FilterParams fp, float4*
     if (i >= n_birth) return;
     const BirthPlan pl = s.plan[i];
     if (pl.gvox < 0) return;
-    const int c = (int)(((long long)pl.pbase + 3 * k) % fp.tab_n);
+    const int c = (int)(((long long)s.plan_pbase[i] + 3 * k) % fp.tab_n);
     const float x = pl.cx + s.p_tab[c];                      // :871-873
     const float y = pl.cy + s.p_tab[(c + 1) % fp.tab_n];
     const float z = pl.cz + s.p_tab[(c + 2) % fp.tab_n];
@@ -986,13 +1002,17 @@ __global__ void k_zero_i32(int* __restrict__ p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0;
 }
+static void birth_children_insert(const LaunchCtx& c, int n_birth_grid, bool in_frame, bool all_static);
 void launch_birth_plan_insert(const LaunchCtx& c, int n_birth_grid, bool in_frame, bool all_static) {
     if (n_birth_grid <= 0) return;
+    // in_frame: k_resample, which follows, zeroes the buckets again, and k_birth_rank also does k_ck_sum's job.
+    hipLaunchKernelGGL(k_birth_rank, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp, in_frame ? 1 : 0);
+    birth_children_insert(c, n_birth_grid, in_frame, all_static);
+}
+static void birth_children_insert(const LaunchCtx& c, int n_birth_grid, bool in_frame, bool all_static) {
     const long long total = (long long)n_birth_grid * c.fp.nb_num;
     const unsigned gb = (unsigned)((total + 255) / 256);
     // invariant: the per-voxel buckets (vb_cnt) are all zero whenever no birth stage is in progress.
-    // in_frame: k_resample, which follows, zeroes them again, and k_birth_rank also does k_ck_sum's job.
-    hipLaunchKernelGGL(k_birth_rank, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp, in_frame ? 1 : 0);
     hipLaunchKernelGGL(k_birth_children, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx);
     // all_static (every birth source has intensity 0, the synthesized cloud): no child draws from the velocity or
     // rand() streams (:877-903), so the cursor kernel has nothing to compute and k_birth_insert never reads its output
@@ -1001,8 +1021,9 @@ void launch_birth_plan_insert(const LaunchCtx& c, int n_birth_grid, bool in_fram
     if (!in_frame) hipLaunchKernelGGL(k_zero_i32, dim3((c.d.v_loc + 255) / 256), dim3(256), 0, c.stream, c.k.vb_cnt, c.d.v_loc);
 }
 void launch_birth(const LaunchCtx& c, int n_birth_grid, bool in_frame, bool all_static) {
-    launch_birth_split(c, n_birth_grid);
-    launch_birth_plan_insert(c, n_birth_grid, in_frame, all_static);
+    if (n_birth_grid <= 0) return;
+    hipLaunchKernelGGL(k_birth_split_rank, dim3((n_birth_grid + 15) / 16 + 1), dim3(1024), 0, c.stream, c.d, c.s, c.fp, in_frame ? 1 : 0);
+    birth_children_insert(c, n_birth_grid, in_frame, all_static);
 }
 
 void launch_scan_blocks(const LaunchCtx& c, int nblk) {

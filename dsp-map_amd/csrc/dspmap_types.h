@@ -135,6 +135,8 @@ struct DevState {
     // birth
     struct BirthSrc* birth; // [birth_cap]
     struct BirthPlan* plan; // [birth_cap]
+    int* plan_pbase;        // [birth_cap] position-table cursor of each source point (k_birth_rank; kept apart from `plan`
+                            // so that the rank and the split can run in the same launch)
     int* nstatic;           // [birth_cap] (multi-GPU all-reduce(max) buffer)
     // FOV staging
     float4* fov_rec;   // [np*capp] {x,y,z,w}
@@ -159,5 +161,5 @@ struct BirthPlan {
     int gvox;           // global voxel of the source point, -1 = outside map / invalid
     int n_static;       // :862-866
     unsigned inside;    // bit k: child k landed inside the map :875 (set with atomicOr)
-    int pbase, vbase, rbase; // table cursors of this point's first draw
+    int pbase, vbase, rbase; // table cursors of this point's first draw (pbase: see DevState::plan_pbase)
 };
