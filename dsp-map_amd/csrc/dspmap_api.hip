@@ -148,7 +148,7 @@ static void free_dev(dspmap* m) {
     if (m->mgpu_count) chk(hipFree(m->mgpu_count), "hipFree");
     void* ptrs[] = {s.fpar, s.obs_ckf, s.part_inv, s.fut_stat, s.mask, s.nbmask, s.pos, s.vel, s.w, s.vz0, s.res4, s.fut, s.obs, s.obs_ck,
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
-                    s.birth, s.plan, s.plan_pbase, s.nstatic, s.fov_rec, s.fov_slot, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt,
+                    s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, s.fov_rec, s.fov_slot, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
                     m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
@@ -233,13 +233,14 @@ int dspmap_ensure_point_cap(dspmap* m, int n) {
     DevState& s = m->s;
     const int cap = n + n / 2 + 1024;
     if (m->mgpu_bound) return dspmap_fail(m, DSPMAP_E_ARG, "%d points exceed the capacity bound with dspmap_mgpu_bind", n);
-    void* olds[] = {s.pt_rot, s.pt_pyr, s.birth, s.plan, s.plan_pbase, s.nstatic, m->pts_dev, m->k.child, m->k.part_birth};
+    void* olds[] = {s.pt_rot, s.pt_pyr, s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, m->pts_dev, m->k.child, m->k.part_birth};
     for (void* p : olds) if (p) (void)hipFree(p);
     HIPCHK(m, dalloc(&s.pt_rot, (size_t)cap));
     HIPCHK(m, dalloc(&s.pt_pyr, (size_t)cap));
     HIPCHK(m, dalloc(&s.birth, (size_t)cap));
     HIPCHK(m, dalloc(&s.plan, (size_t)cap));
     HIPCHK(m, dalloc(&s.plan_pbase, (size_t)cap));
+    HIPCHK(m, dalloc(&s.plan_inside, (size_t)cap));
     HIPCHK(m, dalloc(&s.nstatic, (size_t)cap));
     HIPCHK(m, dalloc(&m->pts_dev, (size_t)cap * 3));
     HIPCHK(m, dalloc(&m->k.child, (size_t)cap * 32));
@@ -553,9 +554,12 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
         (void)hipEventRecord(m->ev_join, m->stream2);
     }
     dspmap_prof_mark(m, 1);
-    launch_predict_only(c, !fork);
+    // births: the rank and the children need nothing but the frame's birth cloud -- they ride on the launches of
+    // k_predict and k_place and leave the frame's critical path; split, cursors and insert follow the weight update
+    const bool early_birth = !fork && birth_grid > 0;
+    launch_predict_only(c, !fork, early_birth);
     dspmap_prof_mark(m, 2);
-    launch_claim(c);
+    launch_claim(c, early_birth ? birth_grid : 0);
     if (fork) (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
     dspmap_prof_mark(m, 3);
     launch_ck_partial(c);
@@ -564,7 +568,8 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     dspmap_prof_mark(m, 5);
     if (birth_grid <= 0) launch_ck_finalize(c);   // otherwise k_birth_rank reduces the 1/Ck sums (one launch less)
     dspmap_prof_mark(m, 6);
-    launch_birth(c, birth_grid, true, all_static);
+    if (early_birth) launch_birth_late(c, birth_grid, all_static);
+    else launch_birth(c, birth_grid, true, all_static);
     dspmap_prof_mark(m, 7);
     launch_resample(c);
     dspmap_prof_mark(m, 8);

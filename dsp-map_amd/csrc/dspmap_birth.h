@@ -1,0 +1,111 @@
+// dspmap_birth.h -- the parts of the birth stage (mapAddNewBornParticlesByObservation :796-921) that depend on nothing
+// but the frame's birth cloud, as device functions: the whole-frame path runs them as extra workgroups of k_predict
+// (rank) and k_place (children) so that they leave the frame's critical path; the stage API and the split-phase
+// multi-GPU path launch them as kernels of their own (dspmap_kernels.hip).
+#pragma once
+#include "dspmap_device.h"
+
+// BK independent exclusive prefix sums over the workgroup at once (two barriers in total).
+// Element order: v[0] of all threads, then v[1] of all threads, ... -- i.e. the order of the
+// coalesced index i = j * blockDim + tid.  Returns the grand total; v[j] becomes the exclusive prefix.
+// s_tmp: BK * 16 + 1 ints.
+template <int NB>
+__device__ __forceinline__ int block_excl_scan_multi(int (&v)[NB], int* s_tmp) {
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, nw = blockDim.x >> 6;
+    int inc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        inc[j] = wave_incl_scan_i(v[j]);
+        if (l == 63) s_tmp[j * 16 + w] = inc[j];
+    }
+    __syncthreads();
+    if (w == 0) {
+        int run = 0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int t = l < nw ? s_tmp[j * 16 + l] : 0;
+            const int ti = wave_incl_scan_i(t);
+            if (l < nw) s_tmp[j * 16 + l] = run + ti - t;
+            run += __builtin_amdgcn_readlane(ti, 63);
+        }
+        if (l == 0) s_tmp[NB * 16] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NB; ++j) v[j] = inc[j] - v[j] + s_tmp[j * 16 + w];
+    const int total = s_tmp[NB * 16];
+    __syncthreads();
+    return total;
+}
+
+
+#define BK 8
+// is source point i a birth source, and in which voxel (:818-820, :827 / :847)
+__device__ __forceinline__ bool birth_src_voxel(const MapDims& d, const DevState& s, const BirthSrc& src, float& cx, float& cy, float& cz, int& gv) {
+    cx = src.x - s.fs->cur_pos[0];  // :818-820
+    cy = src.y - s.fs->cur_pos[1];
+    cz = src.z - s.fs->cur_pos[2];
+    return src.intensity > -1.5f && voxel_of(d, cx, cy, cz, gv);  // :827 / :847
+}
+
+// k_birth_rank's workgroup (any blockDim that is a multiple of 64): rank of every valid source point among the valid
+// ones -> first position-table cursor of the point (3 draws per child, always consumed, :871-873).  Validity comes
+// straight from the source point, so the rank needs nothing but the frame's birth cloud: in a whole frame it rides on
+// k_predict's launch.  Also clears the points' "child inside the map" words for k_birth_children.
+__device__ __forceinline__ void birth_rank_block(const MapDims& d, const DevState& s, const FilterParams& fp) {
+    const int n_birth = s.fpar->n_birth;
+    __shared__ int s_tmp[BK * 16 + 1];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int p_cur = s.fs->p_cur;
+    const int nb = fp.nb_num;
+    int run = 0;
+    for (int base = 0; base < n_birth; base += nt * BK) {
+        int v[BK];
+        bool ok[BK];
+#pragma unroll
+        for (int j = 0; j < BK; ++j) {   // coalesced index, all loads in flight together
+            const int i = base + j * nt + tid;
+            float cx, cy, cz; int gv;
+            ok[j] = i < n_birth && birth_src_voxel(d, s, s.fpar->birth[i], cx, cy, cz, gv);
+            v[j] = ok[j] ? 1 : 0;
+            if (i < n_birth) s.plan_inside[i] = 0u;
+        }
+        const int tot = block_excl_scan_multi<BK>(v, s_tmp);
+#pragma unroll
+        for (int j = 0; j < BK; ++j)
+            if (ok[j]) s.plan_pbase[base + j * nt + tid] = (int)(((long long)p_cur + 3ll * nb * (long long)(run + v[j])) % fp.tab_n);
+        run += tot;
+    }
+    if (tid == 0) s.fs->p_cur = (int)(((long long)p_cur + 3ll * nb * run) % fp.tab_n);
+}
+
+// One thread per (source point, child): the child's position (:871-873) and destination voxel, "inside the map" (:875),
+// and its birth index (point * n_nb + child) in the per-voxel bucket that k_birth_insert ranks.  Needs the birth cloud
+// and the rank only: in a whole frame it rides on k_place's launch.
+#define BIRTH_BUCKET_CAP 128
+__device__ __forceinline__ void birth_child_thread(const MapDims& d, const DevState& s, const FilterParams& fp, float4* __restrict__ child,
+                                                   int* __restrict__ vb_cnt, int* __restrict__ vb_idx, const int t) {
+    const int n_birth = s.fpar->n_birth;
+    const int nb = fp.nb_num;
+    const int i = t / nb, k = t - i * nb;
+    if (i >= n_birth) return;
+    float cx, cy, cz; int gsrc;
+    if (!birth_src_voxel(d, s, s.fpar->birth[i], cx, cy, cz, gsrc)) return;
+    const int c = (int)(((long long)s.plan_pbase[i] + 3 * k) % fp.tab_n);
+    const float x = cx + s.p_tab[c];                         // :871-873
+    const float y = cy + s.p_tab[(c + 1) % fp.tab_n];
+    const float z = cz + s.p_tab[(c + 2) % fp.tab_n];
+    int gv = 0;
+    int lv = -1;
+    if (voxel_of(d, x, y, z, gv)) {                          // :875
+        atomicOr(&s.plan_inside[i], 1u << k);
+        lv = gv - d.v_base;
+        if (lv >= 0 && lv < d.v_loc) {                       // children landing in another slab are inserted by their owner
+            const int pos = atomicAdd(&vb_cnt[lv], 1);
+            if (pos < BIRTH_BUCKET_CAP) vb_idx[(size_t)lv * BIRTH_BUCKET_CAP + pos] = t;
+        } else {
+            lv = -1;
+        }
+    }
+    child[t] = make_float4(x, y, z, __int_as_float(lv));
+}

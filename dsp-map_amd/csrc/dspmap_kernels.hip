@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include "dspmap_device.h"
 #include "dspmap_kernels.h"
+#include "dspmap_birth.h"
 
 #define RESET_PLANES 1
 #define RESET_OBS 2
@@ -223,39 +224,6 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int* s_tmp, int* tota
     return r;
 }
 
-// BK independent exclusive prefix sums over the workgroup at once (two barriers in total).
-// Element order: v[0] of all threads, then v[1] of all threads, ... -- i.e. the order of the
-// coalesced index i = j * blockDim + tid.  Returns the grand total; v[j] becomes the exclusive prefix.
-// s_tmp: BK * 16 + 1 ints.
-template <int NB>
-__device__ __forceinline__ int block_excl_scan_multi(int (&v)[NB], int* s_tmp) {
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, nw = blockDim.x >> 6;
-    int inc[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        inc[j] = wave_incl_scan_i(v[j]);
-        if (l == 63) s_tmp[j * 16 + w] = inc[j];
-    }
-    __syncthreads();
-    if (w == 0) {
-        int run = 0;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int t = l < nw ? s_tmp[j * 16 + l] : 0;
-            const int ti = wave_incl_scan_i(t);
-            if (l < nw) s_tmp[j * 16 + l] = run + ti - t;
-            run += __builtin_amdgcn_readlane(ti, 63);
-        }
-        if (l == 0) s_tmp[NB * 16] = run;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NB; ++j) v[j] = inc[j] - v[j] + s_tmp[j * 16 + w];
-    const int total = s_tmp[NB * 16];
-    __syncthreads();
-    return total;
-}
-
 // lanes sharing one particle in k_weight (sized for the full neighbourhood also where the range cull applies: larger
 // items -- split sized for the culled count -- widen the item's range window and were measured slower)
 __device__ __forceinline__ int wu_split(int O) { return O <= 64 ? 1 : (O <= 128 ? 2 : (O <= 256 ? 4 : 8)); }
@@ -325,6 +293,7 @@ __device__ __forceinline__ void neighbor_load(const MapDims& d, const int* __res
 
 __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, FilterParams fp, const int* __restrict__ items,
                                                        const int* __restrict__ n_items, const int* __restrict__ nb_tab) {
+    const int BX = (int)blockIdx.x, GX = (int)gridDim.x;
     extern __shared__ float4 s_z[];   // [nbins * DSP_OBS_CAP] the neighbourhood's observations within range of the chunk ...
     int* s_oi = reinterpret_cast<int*>(s_z + (size_t)d.nbins * DSP_OBS_CAP);   // ... and their global indices
     __shared__ float4 s_p[CK_PCH];
@@ -334,8 +303,8 @@ __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, Fi
     __shared__ int s_n;
     const int tid = threadIdx.x;
     const int total = n_items[0];
-    int item_next = blockIdx.x < total ? items[blockIdx.x] : 0;
-    for (int it = blockIdx.x; it < total; it += gridDim.x) {
+    int item_next = BX < total ? items[BX] : 0;
+    for (int it = BX; it < total; it += GX) {
         // the dependent-load chain of an item is what bounds this kernel (few pairs per lane): everything that only
         // needs the item id is requested at once -- particle count, neighbourhood table, the chunk's particles (read
         // unmasked, rows always exist) and the next item's id
@@ -345,7 +314,7 @@ __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, Fi
         float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tid < CK_PCH && start + tid < d.capp) r = s.fov_rec_s[(size_t)b * d.capp + start + tid];
         const int P = min(s.pyr_cnt[b], d.capp);
-        if (it + (int)gridDim.x < total) item_next = items[it + gridDim.x];
+        if (it + GX < total) item_next = items[it + GX];
         const int npart = min(CK_PCH, P - start);
         __syncthreads();  // LDS reuse across items
         neighbor_load(d, nb_tab, b, s_bin, s_off);
@@ -591,13 +560,6 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
 // k_birth_split: one wave per source point.  Dempster-Shafer static/dynamic
 // split from the mass already in the point's voxel (:827-866), lanes = slots.
 // --------------------------------------------------------------------------
-// is source point i a birth source, and in which voxel (:818-820, :827 / :847)
-__device__ __forceinline__ bool birth_src_voxel(const MapDims& d, const DevState& s, const BirthSrc& src, float& cx, float& cy, float& cz, int& gv) {
-    cx = src.x - s.fs->cur_pos[0];  // :818-820
-    cy = src.y - s.fs->cur_pos[1];
-    cz = src.z - s.fs->cur_pos[2];
-    return src.intensity > -1.5f && voxel_of(d, cx, cy, cz, gv);  // :827 / :847
-}
 __device__ __forceinline__ void birth_split_wave(const MapDims& d, const DevState& s, const FilterParams& fp, int i) {
     const int n_birth = s.fpar->n_birth;
     if (i >= n_birth) return;
@@ -652,7 +614,6 @@ __global__ void k_birth_split(MapDims d, DevState s, FilterParams fp) {
 // Every thread owns BK consecutive points, so all loads are in flight together and one scan suffices.
 // with_ck_sum: also reduce the per-pyramid 1/Ck sums into the birth normaliser (k_ck_sum's job),
 // which saves a launch per frame.
-#define BK 8
 __device__ __forceinline__ void ck_sum_block(const MapDims& d, const DevState& s, const FilterParams& fp, float* s_red) {
     const int tid = threadIdx.x;
     float acc = 0.f;
@@ -670,42 +631,18 @@ __device__ __forceinline__ void ck_sum_block(const MapDims& d, const DevState& s
         s.fs->newborn_w = fp.nb_weight * s_red[0];  // :805
     }
 }
-__device__ __forceinline__ void birth_rank_block(const MapDims& d, const DevState& s, const FilterParams& fp, int with_ck_sum) {
-    const int n_birth = s.fpar->n_birth;
-    __shared__ int s_tmp[BK * 16 + 1];
-    __shared__ float s_red[512];
-    const int tid = threadIdx.x;
-    if (with_ck_sum) ck_sum_block(d, s, fp, s_red);
-    const int p_cur = s.fs->p_cur;
-    const int nb = fp.nb_num;
-    int run = 0;
-    for (int base = 0; base < n_birth; base += 1024 * BK) {
-        int v[BK];
-        bool ok[BK];
-#pragma unroll
-        for (int j = 0; j < BK; ++j) {   // coalesced index, all loads in flight together
-            const int i = base + j * 1024 + tid;
-            // validity straight from the source point (what k_birth_split stores as plan.gvox >= 0): the rank does not
-            // wait for the split
-            float cx, cy, cz; int gv;
-            ok[j] = i < n_birth && birth_src_voxel(d, s, s.fpar->birth[i], cx, cy, cz, gv);
-            v[j] = ok[j] ? 1 : 0;
-        }
-        const int tot = block_excl_scan_multi<BK>(v, s_tmp);
-#pragma unroll
-        for (int j = 0; j < BK; ++j)
-            if (ok[j]) s.plan_pbase[base + j * 1024 + tid] = (int)(((long long)p_cur + 3ll * nb * (long long)(run + v[j])) % fp.tab_n);
-        run += tot;
-    }
-    if (tid == 0) s.fs->p_cur = (int)(((long long)p_cur + 3ll * nb * run) % fp.tab_n);
-}
 __global__ void __launch_bounds__(1024) k_birth_rank(MapDims d, DevState s, FilterParams fp, int with_ck_sum) {
-    birth_rank_block(d, s, fp, with_ck_sum);
+    __shared__ float s_red[512];
+    if (with_ck_sum) ck_sum_block(d, s, fp, s_red);
+    birth_rank_block(d, s, fp);
 }
 // whole frame: the split (one wave per source point) and the rank (one workgroup, independent of the split) in ONE launch
 __global__ void __launch_bounds__(1024) k_birth_split_rank(MapDims d, DevState s, FilterParams fp, int with_ck_sum) {
-    if (blockIdx.x == gridDim.x - 1) birth_rank_block(d, s, fp, with_ck_sum);
-    else birth_split_wave(d, s, fp, (int)(blockIdx.x * (1024 / WAVE) + threadIdx.x / WAVE));
+    if (blockIdx.x == gridDim.x - 1) {
+        __shared__ float s_red[512];
+        if (with_ck_sum) ck_sum_block(d, s, fp, s_red);
+        birth_rank_block(d, s, fp);
+    } else birth_split_wave(d, s, fp, (int)(blockIdx.x * (1024 / WAVE) + threadIdx.x / WAVE));
 }
 
 // Children are inserted in the reference's sequential order WITHOUT a sort:
@@ -717,34 +654,10 @@ __global__ void __launch_bounds__(1024) k_birth_split_rank(MapDims d, DevState s
 // whose rank exceeds the free slots are dropped, as in the reference (:1198-1200).
 // New particles only set their bit in nbmask (live = mask | nbmask), so the pre-birth word
 // stays stable while the kernel runs.
-#define BIRTH_BUCKET_CAP 128
 
 __global__ void k_birth_children(MapDims d, DevState s, FilterParams fp, float4* __restrict__ child,
                                  int* __restrict__ vb_cnt, int* __restrict__ vb_idx) {
-    const int n_birth = s.fpar->n_birth;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nb = fp.nb_num;
-    const int i = t / nb, k = t - i * nb;
-    if (i >= n_birth) return;
-    const BirthPlan pl = s.plan[i];
-    if (pl.gvox < 0) return;
-    const int c = (int)(((long long)s.plan_pbase[i] + 3 * k) % fp.tab_n);
-    const float x = pl.cx + s.p_tab[c];                      // :871-873
-    const float y = pl.cy + s.p_tab[(c + 1) % fp.tab_n];
-    const float z = pl.cz + s.p_tab[(c + 2) % fp.tab_n];
-    int gv = 0;
-    int lv = -1;
-    if (voxel_of(d, x, y, z, gv)) {                          // :875
-        atomicOr(&s.plan[i].inside, 1u << k);
-        lv = gv - d.v_base;
-        if (lv >= 0 && lv < d.v_loc) {                       // children landing in another slab are inserted by their owner
-            const int pos = atomicAdd(&vb_cnt[lv], 1);
-            if (pos < BIRTH_BUCKET_CAP) vb_idx[(size_t)lv * BIRTH_BUCKET_CAP + pos] = t;
-        } else {
-            lv = -1;
-        }
-    }
-    child[t] = make_float4(x, y, z, __int_as_float(lv));
+    birth_child_thread(d, s, fp, child, vb_cnt, vb_idx, (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }
 
 // k_birth_cursors (one workgroup): velocity-table and rand() cursors per source point (:884-886,:895-897)
@@ -765,7 +678,7 @@ __global__ void __launch_bounds__(1024) k_birth_cursors(MapDims d, DevState s, F
             const int i = base + j * 1024 + tid;
             gvox[j] = -1; nst[j] = 0; inside[j] = 0u; inten[j] = 0.f; snx[j] = 0.f;
             if (i < n_birth) {
-                gvox[j] = s.plan[i].gvox; inside[j] = s.plan[i].inside;
+                gvox[j] = s.plan[i].gvox; inside[j] = s.plan_inside[i];
                 nst[j] = s.nstatic[i];
                 inten[j] = birth[i].intensity; snx[j] = birth[i].nx;
             }
@@ -818,7 +731,8 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, const flo
     bool born = false, dropped = false;
     if (i < n_birth) {
         const BirthPlan pl = s.plan[i];
-        if (pl.gvox >= 0 && ((pl.inside >> k) & 1u)) {
+        const unsigned pl_inside = s.plan_inside[i];
+        if (pl.gvox >= 0 && ((pl_inside >> k) & 1u)) {
             const float4 ch = child[t];
             const int lv = __float_as_int(ch.w);
             if (lv >= 0) {
@@ -827,7 +741,7 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, const flo
                 if (k >= pl.n_static && src.intensity > 0.01f) {
                     const int model_end = src.nx > -100.f ? fp.model_nb : pl.n_static;
                     const unsigned lo_mask = (k >= 32 ? ~0u : ((1u << k) - 1u)) & ~((pl.n_static >= 32) ? ~0u : ((1u << pl.n_static) - 1u));
-                    const unsigned before = pl.inside & lo_mask;  // inside children in [n_static, k)
+                    const unsigned before = pl_inside & lo_mask;  // inside children in [n_static, k)
                     if (k < model_end) {
                         const int rank = __popc(before);
                         const int cv = (int)(((long long)pl.vbase + 3 * rank) % fp.tab_n);
@@ -1019,6 +933,20 @@ static void birth_children_insert(const LaunchCtx& c, int n_birth_grid, bool in_
     if (!all_static) hipLaunchKernelGGL(k_birth_cursors, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
     hipLaunchKernelGGL(k_birth_insert, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx, c.k.part_birth);
     if (!in_frame) hipLaunchKernelGGL(k_zero_i32, dim3((c.d.v_loc + 255) / 256), dim3(256), 0, c.stream, c.k.vb_cnt, c.d.v_loc);
+}
+// split (one wave per source point) and the reduction of the 1/Ck sums (one workgroup) in one launch
+__global__ void __launch_bounds__(1024) k_birth_split_cksum(MapDims d, DevState s, FilterParams fp) {
+    if (blockIdx.x == gridDim.x - 1) {
+        __shared__ float s_red[512];
+        ck_sum_block(d, s, fp, s_red);
+    } else birth_split_wave(d, s, fp, (int)(blockIdx.x * (1024 / WAVE) + threadIdx.x / WAVE));
+}
+void launch_birth_late(const LaunchCtx& c, int n_birth_grid, bool all_static) {
+    if (n_birth_grid <= 0) return;
+    const unsigned gb = (unsigned)(((long long)n_birth_grid * c.fp.nb_num + 255) / 256);
+    hipLaunchKernelGGL(k_birth_split_cksum, dim3((n_birth_grid + 15) / 16 + 1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
+    if (!all_static) hipLaunchKernelGGL(k_birth_cursors, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
+    hipLaunchKernelGGL(k_birth_insert, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx, c.k.part_birth);
 }
 void launch_birth(const LaunchCtx& c, int n_birth_grid, bool in_frame, bool all_static) {
     if (n_birth_grid <= 0) return;

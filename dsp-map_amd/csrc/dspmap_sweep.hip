@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include "dspmap_device.h"
 #include "dspmap_kernels.h"
+#include "dspmap_birth.h"
 
 // OR of a 64-bit value over the wave (DPP network, both halves)
 __device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
@@ -179,7 +180,7 @@ template <int MW, int NW>
 __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, FilterParams fp, int has_vz, int* __restrict__ part,
                                                  float4* __restrict__ mv_rec, float4* __restrict__ in_rec, int* __restrict__ in_cnt,
                                                  u64* __restrict__ expmask, const int* __restrict__ vz_pre, const u64* __restrict__ vz_q,
-                                                 u64* __restrict__ omask) {
+                                                 u64* __restrict__ omask, int extra) {
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
     __shared__ u64 s_keep[MW * 64], s_ex[MW * 64];
@@ -198,17 +199,26 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
     const int wave = tid >> 6;
     // whole frame: the observation gather (448 independent waves, a chain of L2 round trips over the frame's points)
     // rides on this launch as extra workgroups behind the tiles -- it only needs k_obs_points' output, like the tiles
-    const int ntile = (d.v_loc + 63) >> 6;
-    if ((int)blockIdx.x >= ntile) {
-        const int b = ((int)blockIdx.x - ntile) * NW + wave;
-        if (b < d.np) obs_gather_wave(d, s, b);
+    // (extra & 1).  The birth rank -- one workgroup that needs nothing but the frame's birth cloud -- is the last one
+    // (extra & 2).
+    // They come FIRST in the grid so that they run beside the tiles instead of after them.
+    const int ngather = (extra & 1) ? (d.np + NW - 1) / NW : 0, nextra = ngather + ((extra & 2) ? 1 : 0);
+    if ((int)blockIdx.x < nextra) {
+        const int x = (int)blockIdx.x;
+        if (x < ngather) {
+            const int b = x * NW + wave;
+            if (b < d.np) obs_gather_wave(d, s, b);
+        } else {
+            birth_rank_block(d, s, fp);
+        }
         return;
     }
-    const int lv = blockIdx.x * 64 + l;   // all four waves of the block look at the same tile
+    const int BX = (int)blockIdx.x - nextra;   // tile index
+    const int lv = BX * 64 + l;   // all four waves of the block look at the same tile
     if (s.fpar->clear_fut) {
         // clearOccupancyMapPrediction (:431-438) was requested since the last frame: this tile's share of the
         // future accumulators is zeroed here instead of by two extra memset launches per frame
-        const int v0 = blockIdx.x * 64, nv = min(64, d.v_loc - v0);
+        const int v0 = BX * 64, nv = min(64, d.v_loc - v0);
         for (int i = tid; i < nv * d.T; i += NW * 64) s.fut[(size_t)v0 * d.T + i] = 0.f;
         if (tid < nv) s.fut_stat[v0 + tid] = 0.f;
     }
@@ -243,12 +253,12 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
     }
     __syncthreads();
     if (!s_any) {  // empty tile
-        if (tid < 4) part[blockIdx.x * 4 + tid] = 0;
+        if (tid < 4) part[BX * 4 + tid] = 0;
         return;
     }
     const bool dense = s_any == 2;
     const int cap = 64 * d.slots;                       // records per staging area / inbox
-    const size_t mv_base = (size_t)blockIdx.x * cap;    // this tile's staging area (2 float4 per record)
+    const size_t mv_base = (size_t)BX * cap;    // this tile's staging area (2 float4 per record)
     for (int i = tid; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
     for (int i = tid; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
     __syncthreads();
@@ -273,7 +283,7 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
             const bool act = c < ncell;
             const int cell = act ? (int)s_cells[c] : 0;
             const int slot = cell >> 6, ln = cell & 63;
-            const unsigned idx = (unsigned)pidx(d, blockIdx.x * 64 + (act ? ln : l), act ? slot : 0);
+            const unsigned idx = (unsigned)pidx(d, BX * 64 + (act ? ln : l), act ? slot : 0);
             V2 v2 = ld_vel(s, idx);
             const P3 p3 = ld_pos(s, idx);
             const float w = s.w[idx];
@@ -284,7 +294,7 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
                 v2.x = 0.f; v2.y = 0.f;
             }
             if (act) {
-                kind = advance_one(d, s_ph, s_pv, dt, odx, ody, odz, v2.x, v2.y, px, py, pz, blockIdx.x * 64 + ln, pyr, gv);
+                kind = advance_one(d, s_ph, s_pv, dt, odx, ody, odz, v2.x, v2.y, px, py, pz, BX * 64 + ln, pyr, gv);
                 ++c_live;
                 const u64 bit = 1ull << (slot & 63);
                 if (kind != 0) st_pos(s, idx, px, py, pz);
@@ -302,7 +312,7 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
             const int km = lds_agg_inc(&s_nmv, kind == 2);
             if (km >= 0) {
                 const float4 a = make_float4(__int_as_float(gv), v2.x, v2.y, px);
-                const float4 b = make_float4(py, pz, w, __int_as_float((blockIdx.x * 64 + ln + d.v_base) * d.slots + slot));
+                const float4 b = make_float4(py, pz, w, __int_as_float((BX * 64 + ln + d.v_base) * d.slots + slot));
                 if (km < LSTG) { s_mv[km * 2] = a; s_mv[km * 2 + 1] = b; }
                 else { const size_t o = (mv_base + km) * 2; mv_rec[o] = a; mv_rec[o + 1] = b; }
             }
@@ -438,7 +448,7 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
             if (pos < d.capp) {
                 const size_t o = (size_t)pyr * d.capp + pos;
                 s.fov_rec[o] = make_float4(a.z, a.w, b.x, b.y);
-                s.fov_slot[o] = (int)(((size_t)blockIdx.x * d.slots + (sl >> 6)) * 64 + (sl & 63));
+                s.fov_slot[o] = (int)(((size_t)BX * d.slots + (sl >> 6)) * 64 + (sl & 63));
             } else {
                 // pyramid list full: the particle vanishes (-2, :1256-1259)
                 atomicAnd(&s_keep[((sl >> 12) & 1) * 64 + (sl & 63)], ~(1ull << ((sl >> 6) & 63)));
@@ -464,7 +474,7 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
             if (pos[j] < d.capp) {
                 const size_t o = (size_t)key[j] * d.capp + pos[j];
                 s.fov_rec[o] = make_float4(a.z, a.w, b.x, b.y);
-                s.fov_slot[o] = (int)(((size_t)blockIdx.x * d.slots + (sl >> 6)) * 64 + (sl & 63));
+                s.fov_slot[o] = (int)(((size_t)BX * d.slots + (sl >> 6)) * 64 + (sl & 63));
             } else {
                 // pyramid list full: the particle vanishes (-2, :1256-1259)
                 atomicAnd(&s_keep[((sl >> 12) & 1) * 64 + (sl & 63)], ~(1ull << ((sl >> 6) & 63)));
@@ -510,7 +520,7 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
             if (expmask && s_ex[e * 64 + l]) expmask[(size_t)lv * MW + e] = s_ex[e * 64 + l];
         }
     }
-    if (tid < 4) part[blockIdx.x * 4 + tid] = s_cnt[tid];
+    if (tid < 4) part[BX * 4 + tid] = s_cnt[tid];
 }
 
 // --------------------------------------------------------------------------
@@ -533,8 +543,18 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
 template <int MW>
 __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const float4* __restrict__ in_rec,
                                                int* __restrict__ in_cnt, int* __restrict__ part2, int has_vz, int tab_n,
-                                               const u64* __restrict__ omask) {
-    if (has_vz && blockIdx.x == 0 && threadIdx.x == 0)   // k_predict drew 3 table values per ranked particle (:655-657)
+                                               const u64* __restrict__ omask, FilterParams fp, float4* __restrict__ child,
+                                               int* __restrict__ vb_cnt, int* __restrict__ vb_idx) {
+    // whole frame: workgroups behind the tiles generate the frame's newborn children (k_birth_children's job; needs the
+    // birth cloud and the rank only, both done before this launch)
+    // (they come first in the grid: they run beside the tiles, not after them)
+    const int nextra = (int)gridDim.x - ((d.v_loc + 63) >> 6);
+    if ((int)blockIdx.x < nextra) {
+        birth_child_thread(d, s, fp, child, vb_cnt, vb_idx, (int)(blockIdx.x * 256 + threadIdx.x));
+        return;
+    }
+    const int BX = (int)blockIdx.x - nextra;   // tile index
+    if (has_vz && BX == 0 && threadIdx.x == 0)   // k_predict drew 3 table values per ranked particle (:655-657)
         s.fs->v_cur = (int)(((long long)s.fs->v_cur + 3ll * (long long)s.fs->occupied_count) % tab_n);
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
@@ -544,9 +564,9 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
     __shared__ unsigned short s_ord[PLACE_MAX];  // arrival indices bucketed by destination lane
     __shared__ int s_cnt[2];
     const int tid = threadIdx.x;
-    const int n_all = in_cnt[blockIdx.x];
+    const int n_all = in_cnt[BX];
     if (n_all == 0) {
-        if (tid < 2) part2[blockIdx.x * 2 + tid] = 0;
+        if (tid < 2) part2[BX * 2 + tid] = 0;
         return;
     }
     const int cap = 64 * d.slots;
@@ -555,7 +575,7 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
     for (int i = tid; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
     for (int i = tid; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
     if (tid < 64) {
-        const int lv = blockIdx.x * 64 + tid;
+        const int lv = BX * 64 + tid;
         s_lcnt[tid] = 0;
 #pragma unroll
         for (int e = 0; e < MW; ++e) {
@@ -567,7 +587,7 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
     }
     if (tid < 2) s_cnt[tid] = 0;
     __syncthreads();
-    const size_t base = (size_t)blockIdx.x * cap;
+    const size_t base = (size_t)BX * cap;
     int c_vf = tid == 0 ? n_all - n : 0, c_pf = 0;
     // the first 256 records stay in registers across the phases (most tiles receive fewer): one memory round trip
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), b0 = a0;
@@ -616,7 +636,7 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
                 // still left
                 const int o0 = s_loff[ln], mm = s_loff[ln + 1] - o0;
                 const int mykey = __float_as_int(b.w);
-                const long long dkey = (long long)(blockIdx.x * 64 + ln + d.v_base) * d.slots;   // key of (D, slot 0)
+                const long long dkey = (long long)(BX * 64 + ln + d.v_base) * d.slots;   // key of (D, slot 0)
                 int r = 0, nF = 0;
                 for (int x = 0; x < mm; ++x) {
                     const int kx = s_key[s_ord[o0 + x]];
@@ -670,7 +690,7 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
                 }
             }
             if (nsl >= 0) {
-                nidx = pidx(d, blockIdx.x * 64 + ln, nsl);
+                nidx = pidx(d, BX * 64 + ln, nsl);
                 st_pos(s, nidx, px, py, pz);
                 st_vel(s, nidx, a.y, a.z);
                 s.w[nidx] = w;
@@ -702,13 +722,13 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
     }
     __syncthreads();
     if (tid < 64) {
-        const int lv = blockIdx.x * 64 + tid;
+        const int lv = BX * 64 + tid;
 #pragma unroll
         for (int e = 0; e < MW; ++e)
             if (s_new[e * 64 + tid]) s.mask[(size_t)lv * MW + e] = s.mask[(size_t)lv * MW + e] | s_new[e * 64 + tid];
     }
-    if (tid == 0) in_cnt[blockIdx.x] = 0;   // ready for the next frame
-    if (tid < 2) part2[blockIdx.x * 2 + tid] = s_cnt[tid];
+    if (tid == 0) in_cnt[BX] = 0;   // ready for the next frame
+    if (tid < 2) part2[BX * 2 + tid] = s_cnt[tid];
 }
 
 #define RBK 16  // rows per batch of the loads in k_resample
@@ -1255,7 +1275,9 @@ __global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScra
 // ==========================================================================
 // launchers
 // ==========================================================================
-void launch_predict_only(const LaunchCtx& c, bool with_gather) {
+void launch_predict_only(const LaunchCtx& c, bool with_gather, bool with_rank) {
+    const int extra = (with_gather ? 1 : 0) | (with_rank ? 2 : 0);
+    const unsigned xb = (with_gather ? (c.d.np + 3) / 4 : 0) + (with_rank ? 1 : 0);
     const KernelScratch* k = &c.k;
     if (c.s.vz0) {   // constructor-seeded particles take their velocity noise in the reference's sweep order
         const int nblk = (c.d.v_loc + 255) / 256;
@@ -1264,19 +1286,20 @@ void launch_predict_only(const LaunchCtx& c, bool with_gather) {
         launch_scan_blocks(c, nblk);   // blk_cnt -> exclusive, total -> fs->occupied_count
     }
     if (c.d.mw == 1)
-        hipLaunchKernelGGL((k_predict<1, 4>), dim3(k->ntiles + (with_gather ? (c.d.np + 3) / 4 : 0)), dim3(256), 0, c.stream, c.d, c.s, c.fp,
-                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask);
+        hipLaunchKernelGGL((k_predict<1, 4>), dim3(k->ntiles + xb), dim3(256), 0, c.stream, c.d, c.s, c.fp,
+                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask, extra);
     else
-        hipLaunchKernelGGL((k_predict<2, 4>), dim3(k->ntiles + (with_gather ? (c.d.np + 3) / 4 : 0)), dim3(256), 0, c.stream, c.d, c.s, c.fp,
-                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask);
+        hipLaunchKernelGGL((k_predict<2, 4>), dim3(k->ntiles + xb), dim3(256), 0, c.stream, c.d, c.s, c.fp,
+                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask, extra);
 }
-void launch_claim(const LaunchCtx& c) {
+void launch_claim(const LaunchCtx& c, int n_birth_grid) {   // n_birth_grid > 0: the children of that many source points ride along
+    const unsigned xb = n_birth_grid > 0 ? (unsigned)(((long long)n_birth_grid * c.fp.nb_num + 255) / 256) : 0u;
     const KernelScratch* k = &c.k;
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask);
-    else hipLaunchKernelGGL(k_place<2>, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask);
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(k->ntiles + xb), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx);
+    else hipLaunchKernelGGL(k_place<2>, dim3(k->ntiles + xb), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx);
 }
 void launch_predict(const LaunchCtx& c, bool with_gather) {
-    launch_predict_only(c, with_gather);
+    launch_predict_only(c, with_gather, false);
     launch_claim(c);
 }
 void launch_resample(const LaunchCtx& c) {

@@ -135,6 +135,7 @@ struct DevState {
     // birth
     struct BirthSrc* birth; // [birth_cap]
     struct BirthPlan* plan; // [birth_cap]
+    unsigned* plan_inside;  // [birth_cap] bit k = child k of the point lies inside the map (:875), k_birth_children
     int* plan_pbase;        // [birth_cap] position-table cursor of each source point (k_birth_rank; kept apart from `plan`
                             // so that the rank and the split can run in the same launch)
     int* nstatic;           // [birth_cap] (multi-GPU all-reduce(max) buffer)
