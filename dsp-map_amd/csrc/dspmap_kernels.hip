@@ -730,13 +730,19 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, const flo
     const int i = t / nb, k = t - i * nb;
     bool born = false, dropped = false;
     if (i < n_birth) {
+        // this kernel is a chain of dependent loads: everything that only needs (i, t) is requested at once, then
+        // everything that only needs the destination voxel
         const BirthPlan pl = s.plan[i];
         const unsigned pl_inside = s.plan_inside[i];
+        const float4 ch = child[t];          // (garbage for children that were not generated: only used under the tests below)
+        const BirthSrc src = s.fpar->birth[i];
+        const float newborn_w = s.fs->newborn_w;
         if (pl.gvox >= 0 && ((pl_inside >> k) & 1u)) {
-            const float4 ch = child[t];
             const int lv = __float_as_int(ch.w);
             if (lv >= 0) {
-                const BirthSrc src = s.fpar->birth[i];
+                const int n = min(vb_cnt[lv], BIRTH_BUCKET_CAP);
+                u64 occ[2];
+                for (int e = 0; e < d.mw; ++e) occ[e] = s.mask[(size_t)lv * d.mw + e];
                 float vx = 0.f, vy = 0.f;
                 if (k >= pl.n_static && src.intensity > 0.01f) {
                     const int model_end = src.nx > -100.f ? fp.model_nb : pl.n_static;
@@ -756,19 +762,22 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, const flo
                     }
                 }
                 // rank among this voxel's children, by birth index
-                const int n = min(vb_cnt[lv], BIRTH_BUCKET_CAP);
                 int rank = 0;
                 bool recorded = false;
                 const int4* bl4 = reinterpret_cast<const int4*>(vb_idx + (size_t)lv * BIRTH_BUCKET_CAP);
-                for (int j = 0; j < n; j += 8) {  // 2 x 16-byte loads per step, entries beyond n ignored
-                    const int4 a = bl4[j >> 2];
-                    const int4 b = (j + 4 < n) ? bl4[(j >> 2) + 1] : make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);
-                    const int o[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                for (int j = 0; j < n; j += 16) {  // 4 x 16-byte loads in flight per step (the bucket row is 512 B, always readable); entries beyond n ignored
+                    int4 v4[4];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const bool valid = j + q < n;
-                        rank += (valid && o[q] < t) ? 1 : 0;
-                        recorded |= valid && (o[q] == t);
+                    for (int u = 0; u < 4; ++u) v4[u] = bl4[(j >> 2) + u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int o[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const bool valid = j + u * 4 + q < n;
+                            rank += (valid && o[q] < t) ? 1 : 0;
+                            recorded |= valid && (o[q] == t);
+                        }
                     }
                 }
                 int sl = -1;
@@ -777,7 +786,7 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, const flo
                     for (int e = 0; e < d.mw && sl < 0; ++e) {
                         const int nbits = min(64, d.slots - e * 64);
                         const u64 valid = nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
-                        u64 fr = ~s.mask[(size_t)lv * d.mw + e] & valid;
+                        u64 fr = ~occ[e] & valid;
                         const int nf = (int)__popcll(fr);
                         if (r >= nf) { r -= nf; continue; }
                         for (int q = 0; q < r; ++q) fr &= fr - 1ull;
@@ -788,7 +797,7 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, const flo
                     const size_t idx = pidx(d, lv, sl);
                     st_pos(s, idx, ch.x, ch.y, ch.z);
                     st_vel(s, idx, vx, vy);
-                    s.w[idx] = s.fs->newborn_w;
+                    s.w[idx] = newborn_w;
                     atomicOr(&s.nbmask[(size_t)lv * d.mw + (sl >> 6)], 1ull << (sl & 63));  // flag 15
                     born = true;
                 } else {
