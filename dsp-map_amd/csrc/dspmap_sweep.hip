@@ -240,6 +240,9 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
     if (tid == 0) { s_any = 0; s_nmv = 0; s_nst = 0; s_ncell = 0; }
     if (tid < 4) s_cnt[tid] = 0;
     if (d.np <= HIST_NP) for (int b = tid; b < d.np; b += NW * 64) s_hist[b] = 0;
+    // the rotated planes are requested together with the occupancy words (one round trip less for the tiles that have work)
+    for (int i = tid; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
+    for (int i = tid; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
     __syncthreads();
     if (wave == 0 && __ballot(any)) {
         // sparse tile (few live cells per live row): the heavy per-particle work runs on DENSE lanes over a compact
@@ -259,9 +262,6 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
     const bool dense = s_any == 2;
     const int cap = 64 * d.slots;                       // records per staging area / inbox
     const size_t mv_base = (size_t)BX * cap;    // this tile's staging area (2 float4 per record)
-    for (int i = tid; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
-    for (int i = tid; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
-    __syncthreads();
     int c_live = 0, c_out = 0, c_pf = 0, c_mv = 0;
     if (dense) {
         // cell list: every wave compacts its share of the live rows
