@@ -9,4 +9,4 @@ The directory name contains a hyphen (it is fixed by the project layout), so
 import it through the `dsp_map_amd` shim at the repository root.
 """
 from . import capi  # noqa: F401
-from .capi import DSPMap, make_config, load_library  # noqa: F401
+from .capi import DSPMap, make_config, load_library, VPOINT_DTYPE  # noqa: F401

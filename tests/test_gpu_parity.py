@@ -510,6 +510,37 @@ def test_trajectory_statistical_envelope(dsp, orc):
     o.close(); m.close(); m2.close()
 
 
+def test_update_device_with_dynamic_birth_cloud(dsp):
+    """dspmap_update_device with a caller-supplied, device-resident birth cloud that holds dynamic sources (matched and
+    unmatched clusters) -- the captured frame in which the birth rank rides on k_predict's launch, the children on
+    k_place's, and k_birth_cursors runs -- must leave exactly the state of the host-staged path (dspmap_set_birth_cloud +
+    dspmap_update: birth kernels launched on their own after the weight update): every slot, every bit."""
+    import torch
+    cfgkw = dict(nx=50, ny=50, nz=24, ppv=12)
+    a = dsp.DSPMap(dsp.make_config(**cfgkw)); a.set_tables(*common.tables(21))
+    b = dsp.DSPMap(dsp.make_config(**cfgkw)); b.set_tables(*common.tables(21))
+    rng = np.random.default_rng(8)
+    base = common.wall_cloud(13, n_side=30, dist=2.0, half_w=1.5, half_h=0.8)
+    for f in range(6):
+        t = f / 30.0
+        pos = (0.02 * f, 0.01 * f, 0.005 * f)
+        pts = base + rng.normal(0, 0.004, base.shape).astype(np.float32)
+        src = _birth_sources(dsp, rng, pts, pos, n_dyn=60)      # identity attitude: rotated points == points
+        d_pts = torch.from_numpy(pts).cuda()
+        d_src = torch.from_numpy(src.view(np.float32).reshape(-1, 7).copy()).cuda()
+        assert a.update_device(d_pts.data_ptr(), len(pts), pos, t, (1, 0, 0, 0), birth_dev_ptr=d_src.data_ptr(), n_birth=len(src)) == 1
+        b.set_birth_cloud(src)
+        assert b.update(pts, pos, t, (1, 0, 0, 0)) == 1
+        a.clearOccupancyMapPrediction(); b.clearOccupancyMapPrediction()
+        sa, sb = a.export_state(), b.export_state()
+        for x, y in zip(sa, sb):
+            assert np.array_equal(x, y), f
+        assert a.cursors() == b.cursors(), f
+    assert (sa[2][:, 1] != 0).sum() > 50      # dynamic newborns present
+    assert a.counters()["n_born"] == b.counters()["n_born"] > 1000
+    a.close(); b.close()
+
+
 def test_gating_contract(dsp, orc):
     """update() returns 0 and leaves state + 'last pose' untouched for bad input (:193-208)"""
     o, m = make_pair(dsp, orc, nx=20, ny=20, nz=10, ppv=6)
