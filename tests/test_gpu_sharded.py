@@ -78,6 +78,43 @@ def test_slabs_on_one_gpu_match_unsharded(dsp, orc, world, ppv):
     o.close(); full.close()
 
 
+def test_slabs_with_dynamic_birth_cloud_match_unsharded(dsp):
+    """a caller-supplied birth cloud with dynamic sources (velocity-table and rand() cursors, k_birth_cursors) through
+    the split-phase slab path: 3 slabs == the unsharded captured frame, every slot and every bit"""
+    sharded = __import__("dsp-map_amd.sharded", fromlist=["ShardedDSPMap"])
+    cfg = dict(nx=40, ny=40, nz=24, res=0.15, ppv=12)
+    tables = common.tables(11)
+    slabs = []
+    for (z_lo, z_hi) in sharded.slab_ranges(cfg["nz"], 3):
+        s = sharded.HipSlab(dsp, cfg, z_lo, z_hi, 0)
+        s.map.set_tables(*tables)
+        slabs.append(s)
+    sm = sharded.ShardedDSPMap(slabs, sharded.LocalComm())
+    full = dsp.DSPMap(dsp.make_config(**cfg))
+    full.set_tables(*tables)
+    rng = np.random.default_rng(3)
+    for pts, pos, t, q in _stream(6):
+        src = np.zeros(len(pts), dsp.VPOINT_DTYPE)
+        src["x"] = pts[:, 0] + np.float32(pos[0]); src["y"] = pts[:, 1] + np.float32(pos[1]); src["z"] = pts[:, 2] + np.float32(pos[2])
+        dyn = rng.choice(len(src), 80, replace=False)
+        src["intensity"][dyn] = rng.uniform(0.1, 1.0, 80)
+        src["nx"][dyn] = rng.uniform(-1, 1, 80); src["ny"][dyn] = rng.uniform(-1, 1, 80)
+        src["nx"][dyn[:25]] = -10000; src["ny"][dyn[:25]] = -10000; src["nz"][dyn[:25]] = -10000
+        d_pts = torch.from_numpy(pts).cuda()
+        d_src = torch.from_numpy(src.view(np.float32).reshape(-1, 7).copy()).cuda()
+        assert sm.update(d_pts, pos, t, q, birth=d_src) == 1
+        assert full.update_device(d_pts.data_ptr(), len(pts), pos, t, q, birth_dev_ptr=d_src.data_ptr(), n_birth=len(src)) == 1
+        sm.sync()
+    parts = [s.map.export_state() for s in slabs]
+    sv, ss, sr = (np.concatenate([p[k] for p in parts]) for k in range(3))
+    order = np.lexsort((ss, sv))
+    fv, fs_, fr = full.export_state()
+    assert np.array_equal(sv[order], fv) and np.array_equal(ss[order], fs_) and np.array_equal(sr[order], fr)
+    assert (fr[:, 1] != 0).sum() > 50
+    assert all(s.map.cursors() == full.cursors() for s in slabs)
+    full.close()
+
+
 def test_first_frame_slabs_equal_unsharded_exactly(dsp):
     """frame 0 has no exchange and identical Ck -> every slab must hold exactly the unsharded result"""
     sharded = __import__("dsp-map_amd.sharded", fromlist=["ShardedDSPMap"])
