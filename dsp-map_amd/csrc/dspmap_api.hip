@@ -101,7 +101,7 @@ static void refresh_fp(dspmap* m) {
     const float pi_2 = 1.57079632679489661923f;
     f.pdf_c = 1.f / sqrtf(2.f * pi_2);  // standardNormalPDF :1284 at 0
     f.pdf_c3 = f.pdf_c * f.pdf_c * f.pdf_c;
-    f.cull_r = 9.f * f.sigma_ob;
+    f.cull_r = m->cull_sigmas * f.sigma_ob;
 }
 
 extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
@@ -400,6 +400,7 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
         case DSPMAP_P_VELOCITY_ESTIMATOR: m->use_vel_est = v != 0; break;
         case DSPMAP_P_USE_GRAPH: m->use_graph = v != 0; break;
         case DSPMAP_P_OCCLUSION_MARGIN: m->fp.occl_margin = (float)v; break;
+        case DSPMAP_P_PAIR_CULL_SIGMAS: if (!(v > 0)) return dspmap_fail(m, DSPMAP_E_ARG, "pair cull radius must be positive"); m->cull_sigmas = (float)v; refresh_fp(m); break;
         case DSPMAP_P_REGENERATE_TABLES:
             // setPredictionVariance regenerates both tables with a fresh seed (:355-360)
             if (v != 0 && !m->tables_injected) {
@@ -424,6 +425,7 @@ extern "C" double dspmap_get_param(const dspmap_t* m, int key) {
         case DSPMAP_P_DETECTION: return m->fp.p_det;
         case DSPMAP_P_VELOCITY_ESTIMATOR: return m->use_vel_est ? 1 : 0;
         case DSPMAP_P_OCCLUSION_MARGIN: return m->fp.occl_margin;
+        case DSPMAP_P_PAIR_CULL_SIGMAS: return m->cull_sigmas;
         default: return 0;
     }
 }

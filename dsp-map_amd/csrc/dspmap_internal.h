@@ -65,6 +65,7 @@ struct dspmap {
     unsigned long long graph_key = ~0ull;
     unsigned graph_epoch = 0;   // bumped whenever a baked-in kernel argument (pointer / parameter) changes
     // multi-GPU split-phase state
+    float cull_sigmas = 9.f;           // DSPMAP_P_PAIR_CULL_SIGMAS
     bool mgpu_bound = false;
     bool mgpu_place_pending = false;   // k_predict ran, k_place waits for the imports
     int vz_frames_at_begin = 0;

@@ -510,6 +510,37 @@ def test_trajectory_statistical_envelope(dsp, orc):
     o.close(); m.close(); m2.close()
 
 
+def test_range_culling_of_pairs_changes_nothing(dsp, orc):
+    """mapUpdate with the 9-sigma range cull of (particle, observation) pairs vs every pair of the neighbourhood evaluated
+    (DSPMAP_P_PAIR_CULL_SIGMAS = 1e6): Ck must be IDENTICAL bit for bit (dropped terms are zero on the fixed-point grid),
+    the weights equal up to the last bit (dropped terms < 1.5e-17 against 1 - P_d).  Both k_weight variants are covered:
+    the small map evaluates-and-masks, the large one stages only the near observations and branches."""
+    for cfgkw, npart in ((dict(nx=50, ny=50, nz=24, ppv=20), 30000), (dict(nx=132, ny=132, nz=40, ppv=12), 60000)):
+        o, a, pts, q, n = _setup_update_scene(dsp, orc, 77, 0, n_particles=npart, **cfgkw)
+        o.close()
+        v0, s0, r0 = a.export_state()
+        b = dsp.DSPMap(dsp.make_config(**cfgkw)); b.set_tables(*common.tables(77))
+        b.set_param(dsp.capi.P_PAIR_CULL_SIGMAS, 1e6)
+        b.import_state(v0, r0, s0)
+        far = pts.copy(); far[:, 0] += np.float32(1.5)            # a second surface 1.5 m behind: far pairs inside every neighbourhood
+        cloud = np.concatenate([pts, far])
+        for m in (a, b):
+            m.bin_points(cloud, q)
+            m.predict(-0.01, 0.0, 0.002, 1 / 30.0)
+            m.map_update()
+        oa, ca, _, _ = a.observations(); ob, cb, _, _ = b.observations()
+        assert np.array_equal(ca, cb) and ca.sum() > 500
+        assert np.array_equal(oa[:, :, 3], ob[:, :, 3])            # Ck, bit for bit
+        (va, sa, ra), (vb, sb, rb) = a.export_state(), b.export_state()
+        assert np.array_equal(va, vb) and np.array_equal(sa, sb)
+        wa, wb = ra[:, 7].astype(np.float64), rb[:, 7].astype(np.float64)
+        assert a.counters()["n_fov"] > 1000 and a.counters()["n_fov"] == b.counters()["n_fov"]   # the update did something
+        ulp = np.spacing(np.maximum(np.abs(wa), np.abs(wb)).astype(np.float32)).astype(np.float64)
+        assert (np.abs(wa - wb) <= ulp).all()
+        assert (wa != wb).mean() < 1e-3
+        a.close(); b.close()
+
+
 def test_update_device_with_dynamic_birth_cloud(dsp):
     """dspmap_update_device with a caller-supplied, device-resident birth cloud that holds dynamic sources (matched and
     unmatched clusters) -- the captured frame in which the birth rank rides on k_predict's launch, the children on
