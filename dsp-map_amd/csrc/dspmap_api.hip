@@ -734,23 +734,6 @@ static int upload_birth(dspmap* m, const dspmap_vpoint* pts, int n) {
     return DSPMAP_OK;
 }
 
-// host copy of the rotation used for the estimator's input cloud (same operation order as the kernel)
-static void rotate_host(const float v[3], const float q[4], float out[3]) {
-    const float vq[4] = {0.f, v[0], v[1], v[2]};
-    const float n2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + q[0] * q[0];
-    const float inv[4] = {q[0] / n2, -q[1] / n2, -q[2] / n2, -q[3] / n2};
-    auto mul = [](const float a[4], const float b[4], float r[4]) {
-        r[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
-        r[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
-        r[2] = a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3];
-        r[3] = a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1];
-    };
-    float t[4], r[4];
-    mul(q, vq, t);
-    mul(t, inv, r);
-    out[0] = r[1]; out[1] = r[2]; out[2] = r[3];
-}
-
 extern "C" int dspmap_update(dspmap_t* m, int n, int stride, const float* pts, float sx, float sy, float sz,
                              double stamp, float qw, float qx, float qy, float qz) {
     READY(m);

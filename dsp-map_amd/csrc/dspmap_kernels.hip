@@ -2,12 +2,15 @@
 // per-frame loop of the particle-based dynamic occupancy map.
 //
 // Reference behaviour being reproduced: include/dsp_dynamic.h of g-ch/DSP-map
-//   update() preamble      :220-293   -> k_reset, k_obs_points, k_obs_gather
-//   mapPrediction          :627-701   -> k_predict, k_place (moveParticle :1206-1274)
-//   mapUpdate              :704-793   -> k_ck_partial, k_ck_finalize, k_weight
-//   mapAddNewBorn...       :796-921   -> k_birth_split, k_birth_plan, k_birth_insert
-//   mapOccupancy...Resample:924-1057  -> k_resample
-//   getOccupancyMap*       :385-438   -> k_occ_count, k_occ_scan, k_occ_emit, k_clear_future
+//   update() preamble      :220-293   -> k_obs_points (+ k_reset's per-frame resets), k_obs_gather
+//   mapPrediction          :627-701   -> k_predict, k_place (dspmap_sweep.hip; moveParticle :1206-1274)
+//   mapUpdate              :704-793   -> k_pyr_prepare (range sort + work items), k_ck_partial, k_weight, k_ck_sum
+//   mapAddNewBorn...       :796-921   -> k_birth_split, k_birth_rank, k_birth_children (dspmap_birth.h), k_birth_cursors,
+//                                         k_birth_insert
+//   mapOccupancy...Resample:924-1057  -> k_resample (dspmap_sweep.hip)
+//   getOccupancyMap*       :385-438   -> k_occ_count, k_occ_scan, k_occ_emit, k_future_combine
+// In a whole frame independent jobs share a launch (k_predict carries the gather and the birth rank, k_place the
+// children, k_birth_split_cksum the 1/Ck reduction): DESIGN.md section 4.
 // No MFMA: there is no dense contraction on this path; the kernels are
 // HBM-streaming (predict / claim / resample) or LDS+VALU pair loops (update).
 #include <hip/hip_runtime.h>
@@ -268,18 +271,6 @@ __device__ __forceinline__ void pyr_items_block(const MapDims& d, const DevState
         base_ck += tot_ck; base_wu += tot_wu;
     }
     if (tid == 0) { n_items[0] = base_ck; n_items[1] = base_wu; }
-}
-
-__device__ __forceinline__ int neighbor_bins(const MapDims& d, int b, int* bins) {
-    // findPyramidNeighborIndexInFOV :1128-1147 (h-major order, clipped at the FOV edge)
-    const int h0 = b / d.np_v, v0 = b % d.np_v;
-    int n = 0;
-    for (int i = -d.nn; i <= d.nn; ++i)
-        for (int j = -d.nn; j <= d.nn; ++j) {
-            const int h = h0 + i, v = v0 + j;
-            if (h >= 0 && h < d.np_h && v >= 0 && v < d.np_v) bins[n++] = h * d.np_v + v;
-        }
-    return n;
 }
 
 // neighbourhood table of a pyramid in LDS: s_bin[nbins] bins, s_off[nbins+1] exclusive offsets of their

@@ -119,7 +119,7 @@ struct DevState {
     // observations
     float4* obs;       // [np*100] {x,y,z,len}
     long long* obs_ck; // [np*100] sum over particles of P_d*w*g (pass 1), without the frame constant; fixed point,
-                       // units of 2^-34 (ck_to_fix): integer atomics are associative, so the sum does not depend on the
+                       // units of 2^-34 (ck_snap / CK_FIX_SCALE, dspmap_device.h): integer atomics are associative, so the sum does not depend on the
                        // order the workgroups (or the ranks of a sharded map) arrive in -- frames are reproducible
     float* obs_ckf;    // [np*100] final Ck = obs_ck + lambda + kappa (:737)
     float* part_inv;   // [np] per-pyramid sum of 1/Ck
