@@ -111,6 +111,7 @@ SIGNATURES = {
     "dspmap_set_expected_newborn": (_i, [_P, _f]),
     "dspmap_get_pyramid_counts": (_i, [_P, _P]),
     "dspmap_mgpu_bind": (_i, [_P, _P, _P, _i]),
+    "dspmap_mgpu_place_interior": (_i, [_P]),
     "dspmap_mgpu_begin": (_i, [_P, _i, _P, _i, _P, _P, _d, _P]),
     "dspmap_mgpu_export": (_i, [_P, _i, _P, _i, _ip]),
     "dspmap_mgpu_export_both": (_i, [_P, _P, _P, _i, _P]),

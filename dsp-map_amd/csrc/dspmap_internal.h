@@ -67,6 +67,9 @@ struct dspmap {
     // multi-GPU split-phase state
     float cull_sigmas = 9.f;           // DSPMAP_P_PAIR_CULL_SIGMAS
     bool mgpu_bound = false;
+    bool mgpu_birth_early = false;     // rank + children already queued by dspmap_mgpu_export_both
+    bool mgpu_interior_done = false;   // dspmap_mgpu_place_interior placed the tiles [mgpu_tile_lo, mgpu_tile_hi)
+    int mgpu_tile_lo = 0, mgpu_tile_hi = 0;
     bool mgpu_place_pending = false;   // k_predict ran, k_place waits for the imports
     int vz_frames_at_begin = 0;
     int mgpu_nstatic_cap = 0;

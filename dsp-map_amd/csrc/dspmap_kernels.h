@@ -46,7 +46,7 @@ void launch_setup_and_bin(const LaunchCtx& c, int n_pts_grid, bool gather = true
 void launch_predict(const LaunchCtx& c, bool with_gather = false);
 void launch_predict_only(const LaunchCtx& c, bool with_gather = false, bool with_rank = false);   // with_rank: k_birth_rank rides along
 void launch_scan_blocks(const LaunchCtx& c, int nblk);   // exclusive scan of s.blk_cnt[0..nblk), total -> fs->occupied_count
-void launch_claim(const LaunchCtx& c, int n_birth_grid = 0);   // > 0: k_birth_children rides along (after a launch with_rank)
+void launch_claim(const LaunchCtx& c, int n_birth_grid = 0, int part = 0, int tile_lo = 0, int tile_hi = 0);   // part: 0 all tiles, 1 [lo, hi), 2 the rest;   // > 0: k_birth_children rides along (after a launch with_rank)
 void launch_reduce_counters(const LaunchCtx& c);
 void launch_calib(const LaunchCtx& c, int mode, size_t n);
 // multi-GPU: compact particles that left the slab / insert particles received from a neighbour
@@ -59,6 +59,8 @@ void launch_weight_update(const LaunchCtx& c);
 // mapAddNewBornParticlesByObservation (:796-921)
 void launch_birth(const LaunchCtx& c, int n_birth, bool in_frame, bool all_static);  // in_frame: between k_weight and k_resample of a whole frame
 void launch_birth_split(const LaunchCtx& c, int n_birth);
+void launch_birth_early(const LaunchCtx& c, int n_birth);                      // split-phase frame: rank + children right after the prediction
+void launch_birth_finish(const LaunchCtx& c, int n_birth, bool all_static);    // ... cursors + insert at its end
 void launch_birth_late(const LaunchCtx& c, int n_birth, bool all_static);   // whole frame after launch_predict_only(with_rank) + launch_claim(n): split, 1/Ck sum, cursors, insert
 void launch_birth_plan_insert(const LaunchCtx& c, int n_birth, bool in_frame, bool all_static);
 // mapOccupancyCalculationAndResample (:924-1057)

@@ -55,6 +55,8 @@ extern "C" int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_
     launch_setup_and_bin(c, n_points, false);
     launch_predict_only(c, true);       // k_place follows the exchange: imported movers take part in the sweep-order placement
     m->mgpu_place_pending = true;
+    m->mgpu_interior_done = false;
+    m->mgpu_birth_early = false;
     m->vz_frames_at_begin = m->vz_frames;
     if (m->vz_frames > 0) --m->vz_frames;
     m->last_n_points = n_points;
@@ -88,6 +90,31 @@ extern "C" int dspmap_mgpu_export_both(dspmap_t* m, float* up_dev_out, float* do
     HIPCHK(m, hipMemsetAsync(counts_dev, 0, 2 * sizeof(int), m->stream));
     launch_export_slab(c, +1, up_dev_out, cap, counts_dev);
     launch_export_slab(c, -1, down_dev_out, cap, counts_dev + 1);
+    // the caller now synchronises with the host to size the exchange: the birth rank and the newborn children only need
+    // the frame's birth cloud, so they fill that gap instead of sitting in dspmap_mgpu_finish
+    launch_birth_early(c, m->last_n_birth);
+    m->mgpu_birth_early = true;
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}
+// Placement of the movers in the slab's INTERIOR, before the neighbour exchange: a particle changes layer only through
+// the sensor's vertical motion (vz == 0), so records from a neighbour can only land within ceil(|dz| / res) layers of a
+// slab face; every tile farther inside already holds all its arrivals.  dspmap_mgpu_ck_partial then places the boundary
+// tiles.  Gives the GPU work for the time the driver spends synchronising with the host to size the exchange.
+extern "C" int dspmap_mgpu_place_interior(dspmap_t* m) {
+    READY(m);
+    if (!m->mgpu_place_pending || m->mgpu_interior_done) return DSPMAP_OK;
+    if (m->vz_frames_at_begin > 0) return DSPMAP_OK;   // constructor-seeded particles still carry vz: no bound on the layer change
+    const MapDims& d = m->d;
+    const long long L = (long long)d.nx * d.ny;
+    const int reach = (int)ceilf(fabsf(m->hp.od[2]) / d.res) + 1;     // layers an import can reach from a face (+1: rounding)
+    const long long lo_v = L * reach, hi_v = (long long)d.v_loc - L * reach;
+    const int lo = (int)((lo_v + 63) / 64), hi = (int)(hi_v > 0 ? hi_v / 64 : 0);
+    if (hi <= lo) return DSPMAP_OK;
+    LaunchCtx c = dspmap_ctx_of(m);
+    c.s.vz0 = nullptr;
+    launch_claim(c, 0, 1, lo, hi);
+    m->mgpu_interior_done = true; m->mgpu_tile_lo = lo; m->mgpu_tile_hi = hi;
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
 }
@@ -113,7 +140,9 @@ extern "C" int dspmap_mgpu_ck_partial(dspmap_t* m) {
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->mgpu_place_pending) {
         if (m->vz_frames_at_begin <= 0) c.s.vz0 = nullptr;
-        launch_claim(c);
+        if (m->mgpu_interior_done) launch_claim(c, 0, 2, m->mgpu_tile_lo, m->mgpu_tile_hi);
+        else launch_claim(c);
+        m->mgpu_interior_done = false;
         c = dspmap_ctx_of(m);
         m->mgpu_place_pending = false;
     }
@@ -136,7 +165,9 @@ extern "C" int dspmap_mgpu_finish(dspmap_t* m) {
     READY(m);
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
-    launch_birth_plan_insert(c, m->last_n_birth, false, m->last_birth_static);
+    if (m->mgpu_birth_early) launch_birth_finish(c, m->last_n_birth, m->last_birth_static);
+    else launch_birth_plan_insert(c, m->last_n_birth, false, m->last_birth_static);
+    m->mgpu_birth_early = false;
     launch_resample(c);
     HIPCHK(m, hipEventRecord(m->ev1, m->stream));
     m->ev_valid = true;

@@ -544,16 +544,18 @@ template <int MW>
 __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const float4* __restrict__ in_rec,
                                                int* __restrict__ in_cnt, int* __restrict__ part2, int has_vz, int tab_n,
                                                const u64* __restrict__ omask, FilterParams fp, float4* __restrict__ child,
-                                               int* __restrict__ vb_cnt, int* __restrict__ vb_idx) {
+                                               int* __restrict__ vb_cnt, int* __restrict__ vb_idx, int nchild, int t0, int n0, int t1) {
     // whole frame: workgroups behind the tiles generate the frame's newborn children (k_birth_children's job; needs the
     // birth cloud and the rank only, both done before this launch)
-    // (they come first in the grid: they run beside the tiles, not after them)
-    const int nextra = (int)gridDim.x - ((d.v_loc + 63) >> 6);
-    if ((int)blockIdx.x < nextra) {
+    // (the first `nchild` workgroups: they run beside the tiles, not after them).
+    // Tiles of this launch: [t0, t0 + n0) followed by [t1, ...) -- all of them, or (split-phase multi-GPU frame) the slab's
+    // interior before the neighbour exchange and its boundary layers after it.
+    if ((int)blockIdx.x < nchild) {
         birth_child_thread(d, s, fp, child, vb_cnt, vb_idx, (int)(blockIdx.x * 256 + threadIdx.x));
         return;
     }
-    const int BX = (int)blockIdx.x - nextra;   // tile index
+    const int bq = (int)blockIdx.x - nchild;
+    const int BX = bq < n0 ? t0 + bq : t1 + (bq - n0);   // tile index
     if (has_vz && BX == 0 && threadIdx.x == 0)   // k_predict drew 3 table values per ranked particle (:655-657)
         s.fs->v_cur = (int)(((long long)s.fs->v_cur + 3ll * (long long)s.fs->occupied_count) % tab_n);
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
@@ -1292,11 +1294,16 @@ void launch_predict_only(const LaunchCtx& c, bool with_gather, bool with_rank) {
         hipLaunchKernelGGL((k_predict<2, 4>), dim3(k->ntiles + xb), dim3(256), 0, c.stream, c.d, c.s, c.fp,
                            c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask, extra);
 }
-void launch_claim(const LaunchCtx& c, int n_birth_grid) {   // n_birth_grid > 0: the children of that many source points ride along
+void launch_claim(const LaunchCtx& c, int n_birth_grid, int part, int tile_lo, int tile_hi) {   // n_birth_grid > 0: the children of that many source points ride along
     const unsigned xb = n_birth_grid > 0 ? (unsigned)(((long long)n_birth_grid * c.fp.nb_num + 255) / 256) : 0u;
+    const int nt = c.k.ntiles;
+    int t0 = 0, n0 = nt, t1 = nt, n1 = 0;                       // part 0: every tile
+    if (part == 1) { t0 = tile_lo; n0 = tile_hi - tile_lo; }     // part 1: the interior [tile_lo, tile_hi)
+    if (part == 2) { n0 = tile_lo; t1 = tile_hi; n1 = nt - tile_hi; }   // part 2: the rest
+    if (n0 + n1 <= 0 && xb == 0) return;
     const KernelScratch* k = &c.k;
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(k->ntiles + xb), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx);
-    else hipLaunchKernelGGL(k_place<2>, dim3(k->ntiles + xb), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx);
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(n0 + n1 + xb), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1);
+    else hipLaunchKernelGGL(k_place<2>, dim3(n0 + n1 + xb), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1);
 }
 void launch_predict(const LaunchCtx& c, bool with_gather) {
     launch_predict_only(c, with_gather, false);

@@ -48,16 +48,40 @@ class TorchDistComm:
         self.device = device
 
     ordered = False   # True: the slab runs on the torch stream the collectives are issued from (no host syncs needed)
+    _side = None      # side stream + pinned buffer for the one host read of a frame (the gathered export counts)
+    _host_counts = None
 
-    def exchange(self, up, down, counts):
+    def exchange(self, up, down, counts, overlap=None):
         """send the first counts[0] rows of `up` to rank+1 and the first counts[1] rows of `down` to rank-1.
         `counts` is an int32[2] tensor on the communicator's device (it may still be in flight on the stream).
-        Returns (from_below, from_above, (n_up, n_down)).  ONE host synchronisation: reading the gathered counts."""
+        Returns (from_below, from_above, (n_up, n_down)).  ONE host synchronisation: reading the gathered counts.
+        `overlap()` is called once the gather is queued and before the host waits for it: work the caller enqueues there
+        (on the current stream) runs while the counts travel to the host on a side stream."""
         dist = self.dist
         r, w = self.rank, self.world
         allc = [torch.zeros_like(counts) for _ in range(w)]
         dist.all_gather(allc, counts)
-        host = torch.stack(allc).cpu().tolist()
+        stacked = torch.stack(allc)
+        if self.device.type == "cuda" and self.ordered:
+            if self._side is None:
+                self._side = torch.cuda.Stream(self.device)
+                self._host_counts = torch.empty((w, 2), dtype=torch.int32).pin_memory()
+            ready = torch.cuda.Event()
+            ready.record()                                   # the gather + stack on the frame's stream
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ready)
+                self._host_counts.copy_(stacked, non_blocking=True)
+                landed = torch.cuda.Event()
+                landed.record(self._side)
+            stacked.record_stream(self._side)
+            if overlap is not None:
+                overlap()
+            landed.synchronize()
+            host = self._host_counts.tolist()
+        else:
+            if overlap is not None:
+                overlap()
+            host = stacked.cpu().tolist()
         n_up, n_down = int(host[r][0]), int(host[r][1])
         n_from_below = int(host[r - 1][0]) if r > 0 else 0       # what rank-1 sends up
         n_from_above = int(host[r + 1][1]) if r < w - 1 else 0   # what rank+1 sends down
@@ -166,6 +190,10 @@ class HipSlab:
             if not self.ordered:
                 self.map.sync()  # `rec` may be a temporary (ordered mode: same stream as its allocation)
 
+    def place_interior(self):
+        """movers of the slab's interior are placed before the exchange (work for the GPU while the host sizes it)"""
+        self.map._chk(self.map.L.dspmap_mgpu_place_interior(self.map.h))
+
     def ck_partial(self):
         self.map._chk(self.map.L.dspmap_mgpu_ck_partial(self.map.h))
         if not self.ordered:
@@ -228,6 +256,9 @@ class ShardedDSPMap:
         if self.local:
             ups = [s.export(+1) for s in self.slabs]
             downs = [s.export(-1) for s in self.slabs]
+            for s in self.slabs:
+                if hasattr(s, "place_interior"):
+                    s.place_interior()
             for i, s in enumerate(self.slabs):
                 if i > 0:
                     s.import_(ups[i - 1])
@@ -236,7 +267,8 @@ class ShardedDSPMap:
         else:
             slab = self.slabs[0]
             up, down, counts = self._export_both(slab)
-            below, above, (n_up, n_down) = self.comm.exchange(up, down, counts)
+            overlap = slab.place_interior if hasattr(slab, "place_interior") else None
+            below, above, (n_up, n_down) = self.comm.exchange(up, down, counts, overlap)
             if hasattr(slab, "note_exports"):
                 slab.note_exports(n_up, n_down)
             slab.import_(below)

@@ -273,6 +273,9 @@ int dspmap_get_pyramid_counts(dspmap_t* m, int* count_out_host /* [NP] */);
  * The Ck buffer holds 64-bit fixed-point sums (units of 2^-34): all-reduce it as int64.  Integer addition is
  * associative, so a sharded frame computes exactly the Ck of the unsharded one and frames are reproducible. */
 int dspmap_mgpu_bind(dspmap_t* m, long long* ck_dev /* [NP*100] int64 */, int* nstatic_dev, int nstatic_cap);
+/* optional, between the exports and the imports: places the movers of the slab's interior (the tiles no record of a
+ * neighbour can reach this frame) so that the GPU works while the caller sizes the exchange on the host */
+int dspmap_mgpu_place_interior(dspmap_t* m);
 int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_dev, int n_birth,
                       const dspmap_vpoint* birth_dev, const float sensor_pos[3],
                       double time_stamp_second, const float quat_wxyz[4]);   /* 1 / 0 like dspmap_update */
