@@ -50,7 +50,7 @@ void launch_claim(const LaunchCtx& c, int n_birth_grid = 0, int part = 0, int ti
 void launch_reduce_counters(const LaunchCtx& c);
 void launch_calib(const LaunchCtx& c, int mode, size_t n);
 // multi-GPU: compact particles that left the slab / insert particles received from a neighbour
-void launch_export_slab(const LaunchCtx& c, int dir, float* rec_out, int cap, int* count_dev);
+void launch_export_slab(const LaunchCtx& c, int dir, float* rec_out, int cap, int* count_dev, float* rec_out_down = nullptr);   // dir 0: both (up -> rec_out / count[0], down -> rec_out_down / count[1])
 void launch_import_movers(const LaunchCtx& c, int n, const float* rec);  // folds the per-block partial counters into FrameScalars
 // mapUpdate (:704-793)
 void launch_ck_partial(const LaunchCtx& c);
@@ -59,6 +59,7 @@ void launch_weight_update(const LaunchCtx& c);
 // mapAddNewBornParticlesByObservation (:796-921)
 void launch_birth(const LaunchCtx& c, int n_birth, bool in_frame, bool all_static);  // in_frame: between k_weight and k_resample of a whole frame
 void launch_birth_split(const LaunchCtx& c, int n_birth);
+void launch_birth_split_cksum(const LaunchCtx& c, int n_birth);             // split + the 1/Ck reduction in one launch
 void launch_birth_early(const LaunchCtx& c, int n_birth);                      // split-phase frame: rank + children right after the prediction
 void launch_birth_finish(const LaunchCtx& c, int n_birth, bool all_static);    // ... cursors + insert at its end
 void launch_birth_late(const LaunchCtx& c, int n_birth, bool all_static);   // whole frame after launch_predict_only(with_rank) + launch_claim(n): split, 1/Ck sum, cursors, insert

@@ -955,10 +955,13 @@ void launch_birth_finish(const LaunchCtx& c, int n_birth_grid, bool all_static) 
     if (!all_static) hipLaunchKernelGGL(k_birth_cursors, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
     hipLaunchKernelGGL(k_birth_insert, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx, c.k.part_birth);
 }
+void launch_birth_split_cksum(const LaunchCtx& c, int n_birth_grid) {
+    hipLaunchKernelGGL(k_birth_split_cksum, dim3((n_birth_grid + 15) / 16 + 1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
+}
 void launch_birth_late(const LaunchCtx& c, int n_birth_grid, bool all_static) {
     if (n_birth_grid <= 0) return;
     const unsigned gb = (unsigned)(((long long)n_birth_grid * c.fp.nb_num + 255) / 256);
-    hipLaunchKernelGGL(k_birth_split_cksum, dim3((n_birth_grid + 15) / 16 + 1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
+    launch_birth_split_cksum(c, n_birth_grid);
     if (!all_static) hipLaunchKernelGGL(k_birth_cursors, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
     hipLaunchKernelGGL(k_birth_insert, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx, c.k.part_birth);
 }

@@ -88,8 +88,7 @@ extern "C" int dspmap_mgpu_export_both(dspmap_t* m, float* up_dev_out, float* do
     if (!m->mgpu_bound || !up_dev_out || !down_dev_out || cap < 0 || !counts_dev) return dspmap_fail(m, DSPMAP_E_ARG, "bad arguments");
     LaunchCtx c = dspmap_ctx_of(m);
     HIPCHK(m, hipMemsetAsync(counts_dev, 0, 2 * sizeof(int), m->stream));
-    launch_export_slab(c, +1, up_dev_out, cap, counts_dev);
-    launch_export_slab(c, -1, down_dev_out, cap, counts_dev + 1);
+    launch_export_slab(c, 0, up_dev_out, cap, counts_dev, down_dev_out);   // one pass over the slab's occupancy words for both faces
     // the caller now synchronises with the host to size the exchange: the birth rank and the newborn children only need
     // the frame's birth cloud, so they fill that gap instead of sitting in dspmap_mgpu_finish
     launch_birth_early(c, m->last_n_birth);
@@ -155,8 +154,8 @@ extern "C" int dspmap_mgpu_weights_and_split(dspmap_t* m) {
     READY(m);
     LaunchCtx c = dspmap_ctx_of(m);
     launch_weight_update(c);
-    launch_ck_finalize(c);
-    launch_birth_split(c, m->last_n_birth);
+    if (m->last_n_birth > 0) launch_birth_split_cksum(c, m->last_n_birth);   // split + the 1/Ck reduction in one launch
+    else launch_ck_finalize(c);
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
 }

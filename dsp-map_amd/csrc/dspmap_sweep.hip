@@ -1148,8 +1148,11 @@ __global__ void k_advance_rcur(DevState s, FilterParams fp, int by) {
 // same 2 x float4 record the inboxes hold) and frees their slots.
 // --------------------------------------------------------------------------
 template <int MW>
+// dir = +1 / -1: that direction into rec_out / count[0].  dir = 0: both directions in one pass -- up into rec_out /
+// count[0], down into rec_out2 / count[1].
 __global__ void __launch_bounds__(256) k_export_slab(MapDims d, DevState s, u64* __restrict__ expmask, int dir,
-                                                      float* __restrict__ rec_out, int cap, int* __restrict__ count) {
+                                                      float* __restrict__ rec_out, int cap, int* __restrict__ count,
+                                                      float* __restrict__ rec_out2) {
     const int l = lane_id();
     const int lv = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + l;
     const bool inr = lv < d.v_loc;
@@ -1161,7 +1164,7 @@ __global__ void __launch_bounds__(256) k_export_slab(MapDims d, DevState s, u64*
         while (tor) {
             const int sb = __ffsll((long long)tor) - 1;
             tor &= tor - 1ull;
-            bool mine = false;
+            bool mine = false, down = false;
             float px = 0, py = 0, pz = 0, vx = 0, vy = 0, w = 0;
             int gv = 0;
             if (ex & (1ull << sb)) {
@@ -1172,12 +1175,18 @@ __global__ void __launch_bounds__(256) k_export_slab(MapDims d, DevState s, u64*
                 vx = v2.x; vy = v2.y; w = s.w[idx];
                 voxel_of(d, px, py, pz, gv);
                 const int nlv = gv - d.v_base;
-                mine = dir > 0 ? nlv >= d.v_loc : nlv < 0;
+                down = nlv < 0;
+                mine = dir > 0 ? nlv >= d.v_loc : (dir < 0 ? down : (down || nlv >= d.v_loc));
             }
-            const int pos = wave_agg_inc1(count, mine);
+            int pos;
+            if (dir != 0) pos = wave_agg_inc1(count, mine);
+            else {
+                const int pu = wave_agg_inc1(count, mine && !down), pd = wave_agg_inc1(count + 1, mine && down);
+                pos = down ? pd : pu;
+            }
             if (mine) {
                 if (pos < cap) {
-                    float* r = rec_out + 8 * (size_t)pos;
+                    float* r = (dir == 0 && down ? rec_out2 : rec_out) + 8 * (size_t)pos;
                     r[0] = __int_as_float(gv); r[1] = vx; r[2] = vy; r[3] = px; r[4] = py; r[5] = pz; r[6] = w;
                     r[7] = __int_as_float((lv + d.v_base) * d.slots + e * 64 + sb);   // source key: k_place's service order
                 }
@@ -1338,10 +1347,10 @@ void launch_add_random(const LaunchCtx& c, int n, float weight, int* slot_of_tmp
     hipLaunchKernelGGL(k_zero_ints, dim3((c.d.v_loc + 255) / 256), b, 0, c.stream, c.k.vb_cnt, c.d.v_loc);   // buckets empty again
     hipLaunchKernelGGL(k_advance_rcur, dim3(1), dim3(64), 0, c.stream, c.s, c.fp, 6 * n);
 }
-void launch_export_slab(const LaunchCtx& c, int dir, float* rec_out, int cap, int* count_dev) {
+void launch_export_slab(const LaunchCtx& c, int dir, float* rec_out, int cap, int* count_dev, float* rec_out_down) {
     const KernelScratch* k = &c.k;
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_export_slab<1>, dim3(k->nblk_sweep), dim3(256), 0, c.stream, c.d, c.s, k->expmask, dir, rec_out, cap, count_dev);
-    else hipLaunchKernelGGL(k_export_slab<2>, dim3(k->nblk_sweep), dim3(256), 0, c.stream, c.d, c.s, k->expmask, dir, rec_out, cap, count_dev);
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_export_slab<1>, dim3(k->nblk_sweep), dim3(256), 0, c.stream, c.d, c.s, k->expmask, dir, rec_out, cap, count_dev, rec_out_down);
+    else hipLaunchKernelGGL(k_export_slab<2>, dim3(k->nblk_sweep), dim3(256), 0, c.stream, c.d, c.s, k->expmask, dir, rec_out, cap, count_dev, rec_out_down);
 }
 void launch_import_movers(const LaunchCtx& c, int n, const float* rec) {
     if (n <= 0) return;

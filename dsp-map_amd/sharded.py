@@ -46,6 +46,7 @@ class TorchDistComm:
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = device
+        self._into_tensor = dist.get_backend() == "nccl"
 
     ordered = False   # True: the slab runs on the torch stream the collectives are issued from (no host syncs needed)
     _side = None      # side stream + pinned buffer for the one host read of a frame (the gathered export counts)
@@ -59,9 +60,13 @@ class TorchDistComm:
         (on the current stream) runs while the counts travel to the host on a side stream."""
         dist = self.dist
         r, w = self.rank, self.world
-        allc = [torch.zeros_like(counts) for _ in range(w)]
-        dist.all_gather(allc, counts)
-        stacked = torch.stack(allc)
+        if self._into_tensor:
+            stacked = torch.empty((w, 2), dtype=counts.dtype, device=counts.device)
+            dist.all_gather_into_tensor(stacked.view(-1), counts)      # one collective, no stacking kernel
+        else:
+            allc = [torch.zeros_like(counts) for _ in range(w)]
+            dist.all_gather(allc, counts)
+            stacked = torch.stack(allc)
         if self.device.type == "cuda" and self.ordered:
             if self._side is None:
                 self._side = torch.cuda.Stream(self.device)
