@@ -60,7 +60,7 @@ void launch_weight_update(const LaunchCtx& c);
 void launch_birth(const LaunchCtx& c, int n_birth, bool in_frame, bool all_static);  // in_frame: between k_weight and k_resample of a whole frame
 void launch_birth_split(const LaunchCtx& c, int n_birth);
 void launch_birth_split_cksum(const LaunchCtx& c, int n_birth);             // split + the 1/Ck reduction in one launch
-void launch_birth_early(const LaunchCtx& c, int n_birth);                      // split-phase frame: rank + children right after the prediction
+void launch_birth_early(const LaunchCtx& c, int n_birth, bool with_rank = true);                      // split-phase frame: rank + children right after the prediction
 void launch_birth_finish(const LaunchCtx& c, int n_birth, bool all_static);    // ... cursors + insert at its end
 void launch_birth_late(const LaunchCtx& c, int n_birth, bool all_static);   // whole frame after launch_predict_only(with_rank) + launch_claim(n): split, 1/Ck sum, cursors, insert
 void launch_birth_plan_insert(const LaunchCtx& c, int n_birth, bool in_frame, bool all_static);

@@ -943,10 +943,10 @@ __global__ void __launch_bounds__(1024) k_birth_split_cksum(MapDims d, DevState 
 }
 // split-phase (multi-GPU) frame: rank + children as soon as the prediction is queued (they only need the birth cloud; the
 // driver's host synchronisation for the neighbour exchange leaves the GPU idle right there), cursors + insert at the end
-void launch_birth_early(const LaunchCtx& c, int n_birth_grid) {
+void launch_birth_early(const LaunchCtx& c, int n_birth_grid, bool with_rank) {   // with_rank = false: it rode on k_predict's launch
     if (n_birth_grid <= 0) return;
     const unsigned gb = (unsigned)(((long long)n_birth_grid * c.fp.nb_num + 255) / 256);
-    hipLaunchKernelGGL(k_birth_rank, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp, 0);
+    if (with_rank) hipLaunchKernelGGL(k_birth_rank, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp, 0);
     hipLaunchKernelGGL(k_birth_children, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx);
 }
 void launch_birth_finish(const LaunchCtx& c, int n_birth_grid, bool all_static) {

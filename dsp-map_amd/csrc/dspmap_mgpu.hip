@@ -53,7 +53,7 @@ extern "C" int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_
     dspmap_prof_collect(m);
     HIPCHK(m, hipEventRecord(m->ev0, m->stream));
     launch_setup_and_bin(c, n_points, false);
-    launch_predict_only(c, true);       // k_place follows the exchange: imported movers take part in the sweep-order placement
+    launch_predict_only(c, true, nb > 0);   // + gather + birth rank; k_place follows the exchange: imported movers take part in the sweep-order placement
     m->mgpu_place_pending = true;
     m->mgpu_interior_done = false;
     m->mgpu_birth_early = false;
@@ -91,7 +91,7 @@ extern "C" int dspmap_mgpu_export_both(dspmap_t* m, float* up_dev_out, float* do
     launch_export_slab(c, 0, up_dev_out, cap, counts_dev, down_dev_out);   // one pass over the slab's occupancy words for both faces
     // the caller now synchronises with the host to size the exchange: the birth rank and the newborn children only need
     // the frame's birth cloud, so they fill that gap instead of sitting in dspmap_mgpu_finish
-    launch_birth_early(c, m->last_n_birth);
+    launch_birth_early(c, m->last_n_birth, false);   // (the rank rode on k_predict's launch)
     m->mgpu_birth_early = true;
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
@@ -164,8 +164,8 @@ extern "C" int dspmap_mgpu_finish(dspmap_t* m) {
     READY(m);
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
-    if (m->mgpu_birth_early) launch_birth_finish(c, m->last_n_birth, m->last_birth_static);
-    else launch_birth_plan_insert(c, m->last_n_birth, false, m->last_birth_static);
+    if (!m->mgpu_birth_early) launch_birth_early(c, m->last_n_birth, false);   // caller used the per-direction exports
+    launch_birth_finish(c, m->last_n_birth, m->last_birth_static);
     m->mgpu_birth_early = false;
     launch_resample(c);
     HIPCHK(m, hipEventRecord(m->ev1, m->stream));
