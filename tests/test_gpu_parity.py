@@ -665,6 +665,54 @@ def test_slab_sized_72_slots(dsp, orc):
     o.close(); m.close()
 
 
+@pytest.mark.parametrize("cfgkw", [
+    dict(nx=40, ny=40, nz=20, ppv=36),                                         # two occupancy words per voxel
+    dict(nx=44, ny=44, nz=20, ppv=10, angle=1, neighbor_n=2, half_fov_v=27),    # dsp_dynamic_multiple_neighbors.h: 5x5 bins
+    dict(nx=40, ny=40, nz=20, ppv=8, static_model=1, safe_factor=5, pred_times=(0.5,)),   # dsp_static.h
+    dict(nx=132, ny=132, nz=24, ppv=12, pred_times=(0.2, 0.4, 0.6, 0.8, 1.0, 1.2, 1.4, 1.6, 1.8, 2.0)),   # large: k_weight<SKIP>, T = 10
+], ids=["ppv36", "neighbors5x5", "static", "large_T10"])
+def test_captured_frame_equals_direct_launches_across_variants(dsp, cfgkw):
+    """the captured frame -- 9 launches, several of them carrying riders (gather, birth rank, children, 1/Ck sum) -- against
+    the same frame launched kernel by kernel (DSPMAP_P_USE_GRAPH = 0) and against the host-staged path (dspmap_update: no
+    riders at all, birth kernels on their own): the three must leave the same bits in every slot, for every variant of
+    the reference's headers"""
+    import torch
+    maps = []
+    for use_graph in (1, 0, None):
+        m = dsp.DSPMap(dsp.make_config(**cfgkw))
+        m.set_tables(*common.tables(5))
+        if use_graph is not None:
+            m.set_param(dsp.capi.P_USE_GRAPH, use_graph)
+        maps.append(m)
+    half = min(cfgkw["nx"], cfgkw["ny"]) * 0.15 / 2
+    base = common.wall_cloud(19, n_side=40, dist=min(2.4, half * 0.7), half_w=min(1.8, half * 0.6), half_h=0.9)
+    compared = 0
+    for f in range(5):
+        t = f / 30.0
+        pts = base.copy(); pts[:, 0] -= np.float32(0.3 * t)
+        pos, q = (0.3 * t, 0.01 * f, 0.02 * f), (1.0, 0.0, 0.0, 0.0)
+        d = torch.from_numpy(pts).cuda()
+        assert maps[0].update_device(d.data_ptr(), len(pts), pos, t, q) == 1
+        assert maps[1].update_device(d.data_ptr(), len(pts), pos, t, q) == 1
+        assert maps[2].update(pts, pos, t, q) == 1
+        for m in maps:
+            m.clearOccupancyMapPrediction()
+        # which particle a FULL pyramid list turns away depends on the arrival order (the one order-dependent outcome left,
+        # DESIGN.md section 4 "deviations"): frames are compared up to the first such event
+        if any(m.counters()["n_pyramid_full"] for m in maps):
+            break
+        ref = maps[0].export_state()
+        for m in maps[1:]:
+            for a, b in zip(ref, m.export_state()):
+                assert np.array_equal(a, b), f
+            assert np.array_equal(maps[0].results(), m.results()), f
+            assert maps[0].cursors() == m.cursors(), f
+        compared = f + 1
+    assert compared >= 3 and len(ref[0]) > 2000
+    for m in maps:
+        m.close()
+
+
 def test_device_resident_frame_and_graph_replay(dsp, orc):
     """dspmap_update_device (inputs in HBM, frame replayed as a captured HIP graph) == the host-fed
     dspmap_update == the oracle on frame 0, and graph replay on/off agree over a short run"""
