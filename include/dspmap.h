@@ -257,8 +257,8 @@ int dspmap_get_pyramid_counts(dspmap_t* m, int* count_out_host /* [NP] */);
 /* ---- multi-GPU split-phase frame (Z-slab sharding; the single-process reference has no
  * counterpart).  One process per GPU owns the voxel layers [z_lo, z_hi) (dspmap_config).  Every
  * rank is fed the same cloud and pose; per frame the caller runs
- *     begin -> export(+1), export(-1) -> [send to rank+1 / rank-1] -> import
- *           -> ck_partial -> [all-reduce SUM over the bound Ck buffer]
+ *     begin -> export(+1), export(-1) [or export_both] -> (place_interior) -> [send to rank+1 / rank-1] -> import
+ *           -> ck_partial (places the movers, imported ones included, then the Ck pass) -> [all-reduce SUM over the bound Ck buffer]
  *           -> weights_and_split -> [all-reduce MAX over the bound n_static buffer]
  *           -> finish
  * and issues the collectives itself (RCCL through torch.distributed).  What crosses slabs:
