@@ -306,7 +306,7 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, hipMemset(k.omask, 0, sizeof(u64) * W));
     HIPCHK(m, dalloc(&k.ck_items, (size_t)d.np * ((d.capp + 63) / 64 + 1)));
     HIPCHK(m, dalloc(&k.wu_items, (size_t)d.np * ((d.capp + 31) / 32 + 1)));
-    HIPCHK(m, dalloc(&k.n_items, (size_t)2));
+    HIPCHK(m, dalloc(&k.n_items, (size_t)4));
     HIPCHK(m, dalloc(&k.nb_tab, (size_t)d.np * NB_TAB_STRIDE));
     HIPCHK(m, hipMemset(k.in_cnt, 0, sizeof(int) * ntiles));
     const bool slab = !(d.z_lo == 0 && d.z_hi == d.nz);

@@ -201,6 +201,7 @@ __global__ void __launch_bounds__(1024) k_pyr_prepare(MapDims d, DevState s, int
 // --------------------------------------------------------------------------
 #define CK_TPB 256
 #define CK_PCH 64
+#define CK_SMALL_FOV 60000   // particles in the field of view up to which k_ck_partial takes half-size chunks
 #define WU_TPB 256
 
 // Work items of the two pair kernels: (pyramid, chunk of its particle list).  The list lengths are only
@@ -235,6 +236,13 @@ __device__ __forceinline__ void pyr_items_block(const MapDims& d, const DevState
                                                 int* __restrict__ n_items, int* __restrict__ nb_tab) {
     __shared__ int s_tmp[17];
     const int tid = threadIdx.x;
+    // chunk size of k_ck_partial's items: with few particles in the field of view the kernel is one round of workgroups
+    // whose run time is the pair loop of ONE item, so the items are halved (twice as many workgroups, half the loop)
+    int mine = 0;
+    for (int b = tid; b < d.np; b += (int)blockDim.x) mine += min(s.pyr_cnt[b], d.capp);
+    int tot_fov;
+    (void)block_excl_scan_1024(mine, s_tmp, &tot_fov);
+    const int pch = tot_fov <= CK_SMALL_FOV ? CK_PCH / 2 : CK_PCH;
     int base_ck = 0, base_wu = 0;
     for (int b0 = 0; b0 < d.np; b0 += (int)blockDim.x) {
         const int b = b0 + tid;
@@ -260,7 +268,7 @@ __device__ __forceinline__ void pyr_items_block(const MapDims& d, const DevState
             for (; nv < d.nbins; ++nv) { tab[(size_t)nv * d.np] = -1; tab[(size_t)(DSP_MAX_NBINS + nv) * d.np] = O; }
             tab[(size_t)(DSP_MAX_NBINS + d.nbins) * d.np] = O;
             const int pw = WU_TPB / wu_split(O);      // particles per k_weight item
-            nck = O > 0 ? (P + CK_PCH - 1) / CK_PCH : 0;
+            nck = O > 0 ? (P + pch - 1) / pch : 0;
             nwu = max(1, (P + pw - 1) / pw);          // chunk 0 always exists: it owns the bin's 1/Ck sum
         }
         int tot_ck, tot_wu;
@@ -270,7 +278,7 @@ __device__ __forceinline__ void pyr_items_block(const MapDims& d, const DevState
         for (int c = 0; c < nwu; ++c) wu_items[o_wu + c] = (b << 12) | c;
         base_ck += tot_ck; base_wu += tot_wu;
     }
-    if (tid == 0) { n_items[0] = base_ck; n_items[1] = base_wu; }
+    if (tid == 0) { n_items[0] = base_ck; n_items[1] = base_wu; n_items[2] = pch; }
 }
 
 // neighbourhood table of a pyramid in LDS: s_bin[nbins] bins, s_off[nbins+1] exclusive offsets of their
@@ -293,7 +301,7 @@ __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, Fi
     __shared__ float s_rng[2];
     __shared__ int s_n;
     const int tid = threadIdx.x;
-    const int total = n_items[0];
+    const int total = n_items[0], pch = n_items[2];
     int item_next = BX < total ? items[BX] : 0;
     for (int it = BX; it < total; it += GX) {
         // the dependent-load chain of an item is what bounds this kernel (few pairs per lane): everything that only
@@ -301,12 +309,12 @@ __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, Fi
         // unmasked, rows always exist) and the next item's id
         const int item = item_next;
         const int b = item >> 12, chunk = item & 0xfff;
-        const int start = chunk * CK_PCH;
+        const int start = chunk * pch;
         float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tid < CK_PCH && start + tid < d.capp) r = s.fov_rec_s[(size_t)b * d.capp + start + tid];
+        if (tid < pch && start + tid < d.capp) r = s.fov_rec_s[(size_t)b * d.capp + start + tid];
         const int P = min(s.pyr_cnt[b], d.capp);
         if (it + GX < total) item_next = items[it + GX];
-        const int npart = min(CK_PCH, P - start);
+        const int npart = min(pch, P - start);
         __syncthreads();  // LDS reuse across items
         neighbor_load(d, nb_tab, b, s_bin, s_off);
         if (tid < CK_PCH) {   // the first wave holds the chunk: its range interval decides which observations matter
