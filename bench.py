@@ -223,6 +223,9 @@ def main():
                 "traffic_source": "profiles/pmc_traffic_r01.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this workload, "
                                   "corrected: 2*FETCH+WRITE)" if wl_name in traffic_db else None,
                 "kernel_ms": round(dom_ms, 6), "algorithmic_bytes": int(dom_bytes)}
+        if V < 500_000:   # the metric's own size: the frame is 9 dependent launches of 5-35 us, none of them bandwidth-bound
+            roof["note"] = ("at this map size every kernel is a latency chain (one wave per SIMD, ~0.2 TB/s for the whole frame); "
+                            "the HBM-bound case is saturated_132x132x60 in this same line (its roofline block: k_predict)")
     else:  # sharded run: whole-frame algorithmic bytes over all ranks against N x 8 TB/s
         roof = {"bound": "hbm", "kernel": "whole frame (all ranks)", "achieved": round(balg / (ms * 1e-3) / 1e9, 3),
                 "peak": peak * world, "unit": "GB/s", "frac": round(balg / (ms * 1e-3) / 1e9 / (peak * world), 6),
