@@ -14,7 +14,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdspmap_hip.so")
 SOURCES = ["dspmap_kernels.hip", "dspmap_sweep.hip", "dspmap_api.hip", "dspmap_mgpu.hip", "dspmap_preprocess.hip",
            "velocity_estimator.cpp"]
-HEADERS = ["dspmap_internal.h", "dspmap_types.h", "dspmap_device.h", "dspmap_kernels.h", "velocity_estimator.h",
+HEADERS = ["dspmap_internal.h", "dspmap_types.h", "dspmap_device.h", "dspmap_kernels.h", "dspmap_birth.h", "velocity_estimator.h",
            os.path.join("..", "..", "include", "dspmap.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]

@@ -19,7 +19,7 @@ OK, REJECTED = 1, 0
 
 P_POSITION_STDDEV, P_VELOCITY_STDDEV, P_OBSERVATION_STDDEV, P_NEWBORN_WEIGHT, P_NEWBORN_NUMBER, \
     P_VOXEL_FILTER_RES, P_KAPPA, P_DETECTION, P_VELOCITY_ESTIMATOR, P_REGENERATE_TABLES, P_USE_GRAPH, P_OCCLUSION_MARGIN, \
-    P_PAIR_CULL_SIGMAS = range(1, 14)
+    P_PAIR_CULL_SIGMAS, P_UPDATE_TIME, P_UPDATE_COUNTER = range(1, 16)
 
 
 class Config(C.Structure):

@@ -47,6 +47,7 @@ LaunchCtx dspmap_ctx_of(dspmap* m) {
     LaunchCtx c;
     c.d = m->d; c.fp = m->fp; c.s = m->s; c.k = m->k; c.stream = m->stream;
     c.pt_cap = m->pt_cap; c.birth_cap = m->birth_cap;
+    c.k.nbsnap = m->nb_dirty ? m->nbsnap_buf : nullptr;
     return c;
 }
 
@@ -152,6 +153,7 @@ static void free_dev(dspmap* m) {
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
                     m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
+    if (m->nbsnap_buf) chk(hipFree(m->nbsnap_buf), "hipFree");
     if (m->pp_box) chk(hipFree(m->pp_box), "hipFree");
     if (m->pp_acc) chk(hipFree(m->pp_acc), "hipFree");
     if (m->pp_blk) chk(hipFree(m->pp_blk), "hipFree");
@@ -233,11 +235,16 @@ int dspmap_ensure_point_cap(dspmap* m, int n) {
     DevState& s = m->s;
     const int cap = n + n / 2 + 1024;
     if (m->mgpu_bound) return dspmap_fail(m, DSPMAP_E_ARG, "%d points exceed the capacity bound with dspmap_mgpu_bind", n);
-    void* olds[] = {s.pt_rot, s.pt_pyr, s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, m->pts_dev, m->k.child, m->k.part_birth};
+    BirthSrc* old_birth = s.birth;   // holds the cloud of the last non-empty view (re-used by frames with an empty one): carried over
+    void* olds[] = {s.pt_rot, s.pt_pyr, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, m->pts_dev, m->k.child, m->k.part_birth};
     for (void* p : olds) if (p) (void)hipFree(p);
     HIPCHK(m, dalloc(&s.pt_rot, (size_t)cap));
     HIPCHK(m, dalloc(&s.pt_pyr, (size_t)cap));
     HIPCHK(m, dalloc(&s.birth, (size_t)cap));
+    if (old_birth) {
+        if (m->pt_cap > 0) HIPCHK(m, hipMemcpy(s.birth, old_birth, sizeof(BirthSrc) * (size_t)m->pt_cap, hipMemcpyDeviceToDevice));
+        (void)hipFree(old_birth);
+    }
     HIPCHK(m, dalloc(&s.plan, (size_t)cap));
     HIPCHK(m, dalloc(&s.plan_pbase, (size_t)cap));
     HIPCHK(m, dalloc(&s.plan_inside, (size_t)cap));
@@ -426,6 +433,8 @@ extern "C" double dspmap_get_param(const dspmap_t* m, int key) {
         case DSPMAP_P_VELOCITY_ESTIMATOR: return m->use_vel_est ? 1 : 0;
         case DSPMAP_P_OCCLUSION_MARGIN: return m->fp.occl_margin;
         case DSPMAP_P_PAIR_CULL_SIGMAS: return m->cull_sigmas;
+        case DSPMAP_P_UPDATE_TIME: return m->update_time;
+        case DSPMAP_P_UPDATE_COUNTER: return m->update_counter;
         default: return 0;
     }
 }
@@ -508,6 +517,14 @@ int dspmap_push_frame_params(dspmap* m) {
     HIPCHK(m, hipMemcpyAsync(m->s.fpar, &m->hp, sizeof(FrameParams), hipMemcpyHostToDevice, m->stream));
     return DSPMAP_OK;
 }
+// A new cloud is about to be binned: bump the frame epoch (FrameScalars::view_epoch refers to it) and return the
+// bound for the grids of the birth launches of a synthesised cloud.
+int dspmap_begin_cloud(dspmap* m, int n_points, bool static_birth) {
+    m->hp.epoch++;
+    if (!static_birth) return n_points;
+    if (n_points > m->static_hi) m->static_hi = n_points;
+    return m->static_hi;
+}
 static void fill_pose(dspmap* m, const float dp[3], float dt) {
     for (int i = 0; i < 4; i++) m->hp.quat[i] = m->quat[i];
     for (int i = 0; i < 3; i++) { m->hp.cur_pos[i] = m->cur_pos[i]; m->hp.od[i] = -dp[i]; }  // particles move opposite to the sensor (:300)
@@ -534,6 +551,7 @@ int dspmap_gate_and_delta(dspmap* m, const float pos[3], double stamp, const flo
     for (int i = 0; i < 3; i++) m->cur_pos[i] = m->last_p[i] = pos[i];
     m->last_stamp = stamp;
     m->dt_last = *dt;
+    m->update_time += *dt; m->update_counter += 1;   // mapPrediction :634-635
     for (int i = 0; i < 4; i++) m->quat[i] = q[i];
     return 1;
 }
@@ -595,6 +613,7 @@ static int frame_with_host_stages(dspmap* m, int np, const float* pts_dev, const
     fill_pose(m, dp, dt);
     m->hp.n_pts = np; m->hp.n_birth = np; m->hp.static_birth = have_cloud ? 0 : 1;
     m->hp.pts = pts_dev; m->hp.birth = m->s.birth;
+    const int nb_static_grid = dspmap_begin_cloud(m, np, !have_cloud);
     int rc = dspmap_push_frame_params(m);
     if (rc != DSPMAP_OK) return rc;
     HIPCHK(m, hipEventRecord(m->ev0, m->stream));
@@ -602,7 +621,7 @@ static int frame_with_host_stages(dspmap* m, int np, const float* pts_dev, const
     launch_predict(c, true);
     launch_ck_partial(c);
     launch_weight_update(c);
-    int nb = np;
+    int nb = nb_static_grid;
     if (m->use_vel_est && !m->cfg.static_model) {
         if (pts_ready) HIPCHK(m, hipEventSynchronize(pts_ready));
         std::vector<float> view;
@@ -625,6 +644,7 @@ static int frame_with_host_stages(dspmap* m, int np, const float* pts_dev, const
     else launch_ck_finalize(c);
     launch_resample(c);
     if (m->vz_frames > 0) --m->vz_frames;
+    if (m->nb_dirty) { m->nb_dirty = false; m->graph_epoch++; }
     HIPCHK(m, hipEventRecord(m->ev1, m->stream));
     m->ev_valid = true;
     m->last_n_points = np;
@@ -669,6 +689,7 @@ extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* poin
     m->hp.n_pts = n_points; m->hp.n_birth = nb; m->hp.static_birth = static_birth ? 1 : 0;
     m->hp.pts = points_dev;
     m->hp.birth = static_birth ? m->s.birth : (BirthSrc*)birth_dev;
+    const int nb_grid = static_birth ? dspmap_begin_cloud(m, n_points, true) : (dspmap_begin_cloud(m, n_points, false), nb);
     rc = dspmap_push_frame_params(m);
     if (rc != DSPMAP_OK) return rc;
     dspmap_prof_collect(m);
@@ -689,13 +710,14 @@ extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* poin
         }
         HIPCHK(m, hipGraphLaunch(m->graph_exec, m->stream));
     } else {
-        enqueue_frame(m, c, n_points, nb, false, static_birth);
+        enqueue_frame(m, c, n_points, nb_grid, false, static_birth);
     }
     if (m->vz_frames > 0) --m->vz_frames;
+    if (m->nb_dirty) { m->nb_dirty = false; m->graph_epoch++; }
     HIPCHK(m, hipEventRecord(m->ev1, m->stream));
     m->ev_valid = true;
     m->last_n_points = n_points;
-    m->last_n_birth = nb;
+    m->last_n_birth = nb_grid;
     m->last_birth_static = static_birth;
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
@@ -758,8 +780,21 @@ extern "C" int dspmap_get_birth_cloud(dspmap_t* m, dspmap_vpoint* out, int cap, 
     READY(m);
     HIPCHK(m, hipStreamSynchronize(m->stream));
     if (m->last_birth_static) {
-        std::vector<BirthSrc> tmp((size_t)m->last_n_birth);
-        if (m->last_n_birth) HIPCHK(m, hipMemcpy(tmp.data(), m->s.birth, sizeof(BirthSrc) * tmp.size(), hipMemcpyDeviceToHost));
+        // the synthesised cloud is rebuilt from the frame's view (or is the kept cloud of the last non-empty view)
+        BirthSrc* dtmp = nullptr;
+        int* dn = nullptr;
+        const int capb = m->pt_cap > 0 ? m->pt_cap : 1;
+        HIPCHK(m, dalloc(&dtmp, (size_t)capb));
+        HIPCHK(m, dalloc(&dn, (size_t)1));
+        LaunchCtx c = dspmap_ctx_of(m);
+        launch_birth_materialize(c, dtmp, capb, dn);
+        int nsrc = 0;
+        HIPCHK(m, hipMemcpyAsync(&nsrc, dn, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(m, hipStreamSynchronize(m->stream));
+        if (nsrc > capb) nsrc = capb;
+        std::vector<BirthSrc> tmp((size_t)nsrc);
+        if (nsrc) HIPCHK(m, hipMemcpy(tmp.data(), dtmp, sizeof(BirthSrc) * tmp.size(), hipMemcpyDeviceToHost));
+        (void)hipFree(dtmp); (void)hipFree(dn);
         int k = 0;
         for (auto& b : tmp)
             if (b.intensity > -1.5f) { if (out && k < cap) memcpy(&out[k], &b, sizeof(b)); ++k; }
@@ -880,6 +915,13 @@ static int ensure_vz(dspmap* m) {
     return DSPMAP_OK;
 }
 
+int dspmap_mark_nb_dirty(dspmap* m) {
+    if (!m->nbsnap_buf) HIPCHK(m, dalloc(&m->nbsnap_buf, (size_t)m->d.v_loc * m->d.mw));
+    if (!m->nb_dirty) m->graph_epoch++;
+    m->nb_dirty = true;
+    return DSPMAP_OK;
+}
+
 extern "C" int dspmap_clear_state(dspmap_t* m) {
     READY(m);
     const MapDims& d = m->d;
@@ -893,6 +935,7 @@ extern "C" int dspmap_clear_state(dspmap_t* m) {
     HIPCHK(m, hipMemsetAsync(m->s.pyr_cnt, 0, sizeof(int) * d.np, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     m->have_last = false;
+    if (m->nb_dirty) { m->nb_dirty = false; m->graph_epoch++; }
     return DSPMAP_OK;
 }
 
@@ -903,6 +946,9 @@ extern "C" int dspmap_import_state(dspmap_t* m, int n, const int* voxel, const i
     bool any_vz = false;
     for (int i = 0; i < n && !any_vz; i++) any_vz = rec8[8 * (size_t)i + 3] != 0.f;
     if (any_vz) { int rc = ensure_vz(m); if (rc != DSPMAP_OK) return rc; }
+    bool any_nb = false;
+    for (int i = 0; i < n && !any_nb; i++) any_nb = rec8[8 * (size_t)i] > 10.f;
+    if (any_nb) { int rc = dspmap_mark_nb_dirty(m); if (rc != DSPMAP_OK) return rc; }
     int *dv = nullptr, *ds = nullptr, *dfail = nullptr;
     float* dr = nullptr;
     HIPCHK(m, dalloc(&dv, (size_t)n));
@@ -952,6 +998,8 @@ extern "C" int dspmap_add_random_particles(dspmap_t* m, int n, float weight) {
     if (n < 0) return DSPMAP_E_ARG;
     int rc = ensure_vz(m);
     if (rc != DSPMAP_OK) return rc;
+    rc = dspmap_mark_nb_dirty(m);
+    if (rc != DSPMAP_OK) return rc;
     if ((long long)m->d.v_loc >= (1ll << 24)) return dspmap_fail(m, DSPMAP_E_ARG, "constructor pre-fill supports up to 2^24 voxels per handle");
     LaunchCtx c = dspmap_ctx_of(m);
     int* slot_of = nullptr;
@@ -988,12 +1036,13 @@ extern "C" int dspmap_stage_bin_points(dspmap_t* m, int n, int stride, const flo
     for (int i = 0; i < 3; i++) m->hp.cur_pos[i] = m->cur_pos[i];
     m->hp.n_pts = n; m->hp.n_birth = n; m->hp.static_birth = m->h_birth_valid ? 0 : 1;
     m->hp.pts = m->pts_dev; m->hp.birth = m->s.birth;
+    const int nb_grid = dspmap_begin_cloud(m, n, !m->h_birth_valid);
     rc = dspmap_push_frame_params(m);
     if (rc != DSPMAP_OK) return rc;
     launch_frame_setup(c, true);
     launch_obs_bin(c, n);
     m->last_n_points = n;
-    if (!m->h_birth_valid) { m->last_n_birth = n; m->last_birth_static = true; }
+    if (!m->h_birth_valid) { m->last_n_birth = nb_grid; m->last_birth_static = true; }
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
 }
@@ -1009,6 +1058,7 @@ extern "C" int dspmap_stage_predict(dspmap_t* m, float dx, float dy, float dz, f
     for (int i = 0; i < 4; i++) m->hp.quat[i] = m->quat[i];
     for (int i = 0; i < 3; i++) m->hp.cur_pos[i] = m->cur_pos[i];
     m->hp.od[0] = dx; m->hp.od[1] = dy; m->hp.od[2] = dz; m->hp.dt = dt;
+    m->update_time += dt; m->update_counter += 1;   // :634-635
     if (!m->hp.birth) m->hp.birth = m->s.birth;
     { int rc = dspmap_push_frame_params(m); if (rc != DSPMAP_OK) return rc; }
     launch_frame_setup(c, false);
@@ -1044,7 +1094,7 @@ extern "C" int dspmap_stage_birth(dspmap_t* m) {
     { int rc = dspmap_push_frame_params(m); if (rc != DSPMAP_OK) return rc; }
     launch_birth(c, nb, false, false);
     HIPCHK(m, hipGetLastError());
-    return DSPMAP_OK;
+    return dspmap_mark_nb_dirty(m);   // until a resampling turns the newborn flags into 1 (:968)
 }
 extern "C" int dspmap_stage_resample(dspmap_t* m) {
     READY(m);
@@ -1052,6 +1102,7 @@ extern "C" int dspmap_stage_resample(dspmap_t* m) {
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
     launch_resample(c);
+    if (m->nb_dirty) { m->nb_dirty = false; m->graph_epoch++; }
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
 }
@@ -1215,8 +1266,14 @@ extern "C" int dspmap_load_checkpoint(dspmap_t* m, const char* path) {
                 a.half_fov_h == b.half_fov_h && a.half_fov_v == b.half_fov_v && a.prediction_times == b.prediction_times &&
                 a.z_lo == b.z_lo && a.z_hi == b.z_hi && h.v_loc == (long long)m->d.v_loc;
     for (int k = 0; same && k < a.prediction_times; k++) same = a.prediction_future_time[k] == b.prediction_future_time[k];
+    same = same && a.pyramid_neighbor_n == b.pyramid_neighbor_n && a.safe_particle_factor == b.safe_particle_factor &&
+           a.static_model == b.static_model;
     if (!same) { fclose(f); return dspmap_fail(m, DSPMAP_E_ARG, "checkpoint was written by a map with a different configuration"); }
     const int n = h.n_particles;
+    if (n < 0 || (long long)n > (long long)m->d.v_loc * m->d.slots) {
+        fclose(f);
+        return dspmap_fail(m, DSPMAP_E_ARG, "%s: particle count %d outside [0, %lld]", path, n, (long long)m->d.v_loc * m->d.slots);
+    }
     const size_t V = (size_t)m->d.v_loc, T = (size_t)m->d.T;
     std::vector<int> voxel((size_t)n + 1), slot((size_t)n + 1);
     std::vector<float> rec((size_t)n * 8 + 8), res(V * 4), fut(V * (T ? T : 1));
@@ -1233,7 +1290,16 @@ extern "C" int dspmap_load_checkpoint(dspmap_t* m, const char* path) {
     HIPCHK(m, hipMemcpyAsync(m->s.res4, res.data(), sizeof(float4) * V, hipMemcpyHostToDevice, m->stream));
     if (T) HIPCHK(m, hipMemcpyAsync(m->s.fut, fut.data(), sizeof(float) * V * T, hipMemcpyHostToDevice, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
-    m->fp = h.fp;
+    {   // filter parameters and the frozen birth statics come from the checkpoint; the random tables are THIS handle's
+        // (regenerated from its seed or injected by its caller), so their lengths stay, and the pair-cull radius is
+        // re-derived from this handle's DSPMAP_P_PAIR_CULL_SIGMAS
+        FilterParams& f = m->fp;
+        f.sigma_ob = h.fp.sigma_ob; f.kappa = h.fp.kappa; f.p_det = h.fp.p_det;
+        f.nb_weight = h.fp.nb_weight; f.nb_num = h.fp.nb_num;
+        f.min_static_nb = h.fp.min_static_nb; f.model_nb = h.fp.model_nb;
+        f.occl_margin = h.fp.occl_margin;
+        refresh_fp(m);
+    }
     m->nb_frozen = h.nb_frozen != 0; m->have_last = h.have_last != 0; m->vz_frames = h.vz_frames;
     for (int i = 0; i < 3; i++) { m->last_p[i] = h.last_p[i]; m->cur_pos[i] = h.cur_pos[i]; }
     for (int i = 0; i < 4; i++) m->quat[i] = h.quat[i];
@@ -1241,5 +1307,7 @@ extern "C" int dspmap_load_checkpoint(dspmap_t* m, const char* path) {
     m->last_stamp = h.last_stamp;
     m->fut_clear_pending = false;
     m->graph_epoch++;
-    return dspmap_set_cursors(m, h.cursors[0], h.cursors[1], h.cursors[2]);
+    // cursors index THIS handle's tables
+    return dspmap_set_cursors(m, h.cursors[0] % (m->fp.tab_n > 0 ? m->fp.tab_n : 1), h.cursors[1] % (m->fp.tab_n > 0 ? m->fp.tab_n : 1),
+                              h.cursors[2] % (m->fp.rtab_n > 0 ? m->fp.rtab_n : 1));
 }

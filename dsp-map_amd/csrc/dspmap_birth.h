@@ -40,12 +40,52 @@ __device__ __forceinline__ int block_excl_scan_multi(int (&v)[NB], int* s_tmp) {
 
 
 #define BK 8
-// is source point i a birth source, and in which voxel (:818-820, :827 / :847)
+// The frame's birth sources (input_cloud_with_velocity :134).
+//  * caller-supplied / estimator cloud: fpar->birth[0 .. fpar->n_birth)
+//  * synthesised cloud (fpar->static_birth): what velocityEstimationThread emits when it tags nothing dynamic, and what
+//    dsp_static.h:1285-1308 always emits -- every point of the frame's view, world position = rotated + current
+//    position, zero velocity tag, intensity 0.  It is not stored: the readers rebuild entry i from k_obs_points'
+//    output (pt_rot, pt_pyr; intensity -2 marks a point outside the field of view = not a source).  When the view is
+//    EMPTY the reference returns before clearing its previous output (:1379-1381, dsp_static.h:1288-1290) and the
+//    birth stage re-uses the last non-empty view's cloud: that one is kept in DevState::birth (written by
+//    k_birth_insert of every frame with a non-empty view, length in FrameScalars::stale_n).
+struct BirthView {
+    const BirthSrc* stored;
+    const float4* rot;
+    const int* pyr;
+    float cx, cy, cz;
+    int n;
+    bool live;      // rebuild from the frame's view
+};
+__device__ __forceinline__ BirthView birth_view(const DevState& s) {
+    BirthView v;
+    const FrameParams* fp = s.fpar;
+    const bool synth = fp->static_birth != 0;
+    v.live = synth && s.fs->view_epoch == fp->epoch;
+    v.stored = fp->birth; v.rot = s.pt_rot; v.pyr = s.pt_pyr;
+    v.cx = fp->cur_pos[0]; v.cy = fp->cur_pos[1]; v.cz = fp->cur_pos[2];
+    v.n = synth ? (v.live ? fp->n_pts : s.fs->stale_n) : fp->n_birth;
+    return v;
+}
+__device__ __forceinline__ BirthSrc birth_at(const BirthView& v, int i) {
+    if (!v.live) return v.stored[i];
+    const float4 r = v.rot[i];
+    BirthSrc b;
+    b.x = r.x + v.cx; b.y = r.y + v.cy; b.z = r.z + v.cz;   // :1389-1391
+    b.nx = b.ny = b.nz = 0.f;
+    b.intensity = v.pyr[i] >= 0 ? 0.f : -2.f;
+    return b;
+}
+// is source point i a birth source, and in which voxel (:818-820, :827 / :847).  dsp_static.h:797-825 has no voxel
+// lookup for the source: a point outside the map still draws and may place children inside it (gv = 0 then: unused).
 __device__ __forceinline__ bool birth_src_voxel(const MapDims& d, const DevState& s, const BirthSrc& src, float& cx, float& cy, float& cz, int& gv) {
     cx = src.x - s.fs->cur_pos[0];  // :818-820
     cy = src.y - s.fs->cur_pos[1];
     cz = src.z - s.fs->cur_pos[2];
-    return src.intensity > -1.5f && voxel_of(d, cx, cy, cz, gv);  // :827 / :847
+    if (!(src.intensity > -1.5f)) return false;
+    if (voxel_of(d, cx, cy, cz, gv)) return true;  // :827 / :847
+    gv = 0;
+    return d.static_model != 0;
 }
 
 // k_birth_rank's workgroup (any blockDim that is a multiple of 64): rank of every valid source point among the valid
@@ -53,7 +93,8 @@ __device__ __forceinline__ bool birth_src_voxel(const MapDims& d, const DevState
 // straight from the source point, so the rank needs nothing but the frame's birth cloud: in a whole frame it rides on
 // k_predict's launch.  Also clears the points' "child inside the map" words for k_birth_children.
 __device__ __forceinline__ void birth_rank_block(const MapDims& d, const DevState& s, const FilterParams& fp) {
-    const int n_birth = s.fpar->n_birth;
+    const BirthView bv = birth_view(s);
+    const int n_birth = bv.n;
     __shared__ int s_tmp[BK * 16 + 1];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int p_cur = s.fs->p_cur;
@@ -66,7 +107,7 @@ __device__ __forceinline__ void birth_rank_block(const MapDims& d, const DevStat
         for (int j = 0; j < BK; ++j) {   // coalesced index, all loads in flight together
             const int i = base + j * nt + tid;
             float cx, cy, cz; int gv;
-            ok[j] = i < n_birth && birth_src_voxel(d, s, s.fpar->birth[i], cx, cy, cz, gv);
+            ok[j] = i < n_birth && birth_src_voxel(d, s, birth_at(bv, i), cx, cy, cz, gv);
             v[j] = ok[j] ? 1 : 0;
             if (i < n_birth) s.plan_inside[i] = 0u;
         }
@@ -85,12 +126,13 @@ __device__ __forceinline__ void birth_rank_block(const MapDims& d, const DevStat
 #define BIRTH_BUCKET_CAP 128
 __device__ __forceinline__ void birth_child_thread(const MapDims& d, const DevState& s, const FilterParams& fp, float4* __restrict__ child,
                                                    int* __restrict__ vb_cnt, int* __restrict__ vb_idx, const int t) {
-    const int n_birth = s.fpar->n_birth;
+    const BirthView bv = birth_view(s);
+    const int n_birth = bv.n;
     const int nb = fp.nb_num;
     const int i = t / nb, k = t - i * nb;
     if (i >= n_birth) return;
     float cx, cy, cz; int gsrc;
-    if (!birth_src_voxel(d, s, s.fpar->birth[i], cx, cy, cz, gsrc)) return;
+    if (!birth_src_voxel(d, s, birth_at(bv, i), cx, cy, cz, gsrc)) return;
     const int c = (int)(((long long)s.plan_pbase[i] + 3 * k) % fp.tab_n);
     const float x = cx + s.p_tab[c];                         // :871-873
     const float y = cy + s.p_tab[(c + 1) % fp.tab_n];

@@ -40,6 +40,8 @@ struct dspmap {
     float cur_pos[3] = {0, 0, 0};
     float quat[4] = {1, 0, 0, 0};
     float dt_last = 0.f;
+    float update_time = 0.f;         // :634 (fp32 accumulation like the reference)
+    int update_counter = 0;          // :635
     // capacities
     int pt_cap = 0, birth_cap = 0;
     float* pts_dev = nullptr;        // staging for host-fed clouds
@@ -48,9 +50,14 @@ struct dspmap {
     // birth cloud supplied by the caller (estimator off) / produced by the estimator
     std::vector<dspmap_vpoint> h_birth;
     bool h_birth_valid = false;
-    int last_n_birth = 0;            // entries of s.birth used by the last frame
+    int last_n_birth = 0;            // grid bound of the last frame's birth launches (>= the number of birth sources)
+    int static_hi = 0;               // largest synthesised birth cloud so far: a frame with an empty view re-uses the last
+                                     // non-empty one's cloud, which may be longer than the frame's own point count
     bool last_birth_static = false;
     int vz_frames = 0;
+    bool nb_dirty = false;           // newborn bits may be set outside a frame (pre-fill, import of flag-15 records, a birth stage
+                                     // that no resampling followed): the next birth stage snapshots them (KernelScratch::nbsnap)
+    u64* nbsnap_buf = nullptr;
     int last_n_points = 0;
     VelocityEstimator vel;
     // per-frame parameter block (host copy; pushed to s.fpar with one H2D copy per frame)
@@ -98,6 +105,8 @@ void dspmap_freeze_birth_statics(dspmap* m);
 int dspmap_ensure_point_cap(dspmap* m, int n);
 int dspmap_push_frame_params(dspmap* m);
 void dspmap_flush_future_clear(dspmap* m);   // m->hp -> device
+int dspmap_mark_nb_dirty(dspmap* m);
+int dspmap_begin_cloud(dspmap* m, int n_points, bool static_birth);   // bumps the frame epoch; returns the birth grid bound
 
 #define HIPCHK(m, call)                                                                            \
     do {                                                                                           \

@@ -23,6 +23,9 @@ struct KernelScratch {
                         // their observation counts, written by k_pyr_items once per frame
     int* part_birth;    // [ceil(birth_cap*32/256)*2] per-block {born, dropped} of k_birth_insert
     float4* child;      // [birth_cap*32] child position + destination voxel of this frame's births
+    u64* nbsnap;        // [v_loc*mw] newborn bits as they were BEFORE this frame's birth stage, or nullptr when they are known
+                        // to be all zero (every frame after a resampling).  Non-null after a constructor pre-fill / an import of
+                        // flag-15 records / a second birth stage without resampling: addAParticle (:1184-1185) skips those slots
     int* work_list;     // [v_loc] scratch: per-voxel prefix of the constructor-seeded particles' noise ranks (k_vz_count)
     int ntiles;         // tiles of 64 voxels; k_predict / k_place run one workgroup per tile
     int nblk_sweep;
@@ -64,6 +67,7 @@ void launch_birth_early(const LaunchCtx& c, int n_birth, bool with_rank = true);
 void launch_birth_finish(const LaunchCtx& c, int n_birth, bool all_static);    // ... cursors + insert at its end
 void launch_birth_late(const LaunchCtx& c, int n_birth, bool all_static);   // whole frame after launch_predict_only(with_rank) + launch_claim(n): split, 1/Ck sum, cursors, insert
 void launch_birth_plan_insert(const LaunchCtx& c, int n_birth, bool in_frame, bool all_static);
+void launch_birth_materialize(const LaunchCtx& c, BirthSrc* out, int cap, int* n_out);   // the frame's synthesised birth cloud, for host readback
 // mapOccupancyCalculationAndResample (:924-1057)
 void launch_resample(const LaunchCtx& c);
 // readout (:385-438)

@@ -73,6 +73,7 @@ __global__ void __launch_bounds__(256) k_obs_points(MapDims d, DevState s) {
     const float* __restrict__ pts = s.fpar->pts;
     const float qw = s.fpar->quat[0], qx = s.fpar->quat[1], qy = s.fpar->quat[2], qz = s.fpar->quat[3];
     const float cpx = s.fpar->cur_pos[0], cpy = s.fpar->cur_pos[1], cpz = s.fpar->cur_pos[2];
+    (void)cpx; (void)cpy; (void)cpz;
     const int make_static_birth = s.fpar->static_birth;
     const float q[4] = {qw, qx, qy, qz};
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
@@ -115,15 +116,8 @@ __global__ void __launch_bounds__(256) k_obs_points(MapDims d, DevState s) {
         const float len = sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
         s.pt_rot[i] = make_float4(r[0], r[1], r[2], len);
         s.pt_pyr[i] = pyr;
-        if (make_static_birth) {
-            // what velocityEstimationThread emits for a static point (:1389-1391,1529-1540):
-            // world position = rotated + current_position, zero velocity tag, intensity 0
-            BirthSrc b;
-            b.x = r[0] + cpx; b.y = r[1] + cpy; b.z = r[2] + cpz;
-            b.nx = b.ny = b.nz = 0.f;
-            b.intensity = pyr >= 0 ? 0.f : -2.f;  // -2 = not a source (point outside the FOV)
-            s.fpar->birth[i] = b;
-        }
+        // the view is not empty: this frame's synthesised birth cloud is the live one (dspmap_birth.h, BirthView)
+        if (make_static_birth && pyr >= 0) s.fs->view_epoch = s.fpar->epoch;
     }
 }
 
@@ -560,10 +554,10 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
 // split from the mass already in the point's voxel (:827-866), lanes = slots.
 // --------------------------------------------------------------------------
 __device__ __forceinline__ void birth_split_wave(const MapDims& d, const DevState& s, const FilterParams& fp, int i) {
-    const int n_birth = s.fpar->n_birth;
-    if (i >= n_birth) return;
+    const BirthView bv = birth_view(s);
+    if (i >= bv.n) return;
     const int l = lane_id();
-    const BirthSrc src = s.fpar->birth[i];
+    const BirthSrc src = birth_at(bv, i);
     BirthPlan pl;
     pl.gvox = -1; pl.n_static = 0; pl.inside = 0; pl.pbase = pl.vbase = pl.rbase = 0;
     int gv;
@@ -661,12 +655,12 @@ __global__ void k_birth_children(MapDims d, DevState s, FilterParams fp, float4*
 
 // k_birth_cursors (one workgroup): velocity-table and rand() cursors per source point (:884-886,:895-897)
 __global__ void __launch_bounds__(1024) k_birth_cursors(MapDims d, DevState s, FilterParams fp) {
-    const int n_birth = s.fpar->n_birth;
+    const BirthView bv = birth_view(s);
+    const int n_birth = bv.n;
     __shared__ int s_tmp[BK * 16 + 1];
     const int tid = threadIdx.x;
     const int v_cur = s.fs->v_cur, r_cur = s.fs->r_cur;
     const int nb = fp.nb_num;
-    const BirthSrc* __restrict__ birth = s.fpar->birth;
     int run_v = 0, run_r = 0;
     for (int base = 0; base < n_birth; base += 1024 * BK) {
         int gvox[BK], nst[BK];
@@ -679,7 +673,8 @@ __global__ void __launch_bounds__(1024) k_birth_cursors(MapDims d, DevState s, F
             if (i < n_birth) {
                 gvox[j] = s.plan[i].gvox; inside[j] = s.plan_inside[i];
                 nst[j] = s.nstatic[i];
-                inten[j] = birth[i].intensity; snx[j] = birth[i].nx;
+                const BirthSrc b = birth_at(bv, i);
+                inten[j] = b.intensity; snx[j] = b.nx;
             }
         }
         int cv[BK], cr[BK];
@@ -722,26 +717,33 @@ __device__ __forceinline__ float rand_float(const DevState& s, const FilterParam
 // k_birth_insert: one thread per (source point, child): velocity by branch (:877-903); vz = 0
 // (:905-907); weight = the global newborn weight (:909); newborn flag (= nbmask bit).
 __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, const float4* __restrict__ child,
-                               const int* __restrict__ vb_cnt, const int* __restrict__ vb_idx, int* __restrict__ part_birth) {
-    const int n_birth = s.fpar->n_birth;
+                               const int* __restrict__ vb_cnt, const int* __restrict__ vb_idx, int* __restrict__ part_birth,
+                               const u64* __restrict__ nbsnap) {
+    const BirthView bv = birth_view(s);
+    const int n_birth = bv.n;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int nb = fp.nb_num;
     const int i = t / nb, k = t - i * nb;
     bool born = false, dropped = false;
+    if (bv.live && t == 0) s.fs->stale_n = n_birth;
     if (i < n_birth) {
         // this kernel is a chain of dependent loads: everything that only needs (i, t) is requested at once, then
         // everything that only needs the destination voxel
         const BirthPlan pl = s.plan[i];
         const unsigned pl_inside = s.plan_inside[i];
         const float4 ch = child[t];          // (garbage for children that were not generated: only used under the tests below)
-        const BirthSrc src = s.fpar->birth[i];
+        const BirthSrc src = birth_at(bv, i);
+        // a non-empty view's synthesised cloud is kept for the frames whose view is empty (:1379-1381)
+        if (bv.live && k == 0) const_cast<BirthSrc*>(bv.stored)[i] = src;
         const float newborn_w = s.fs->newborn_w;
         if (pl.gvox >= 0 && ((pl_inside >> k) & 1u)) {
             const int lv = __float_as_int(ch.w);
             if (lv >= 0) {
                 const int n = min(vb_cnt[lv], BIRTH_BUCKET_CAP);
                 u64 occ[2];
-                for (int e = 0; e < d.mw; ++e) occ[e] = s.mask[(size_t)lv * d.mw + e];
+                // free = not live and not a newborn of an EARLIER call (flag 15, :1184-1185); this call's own newborns go to
+                // nbmask while the kernel runs, so the pre-birth word is taken from the snapshot
+                for (int e = 0; e < d.mw; ++e) occ[e] = s.mask[(size_t)lv * d.mw + e] | (nbsnap ? nbsnap[(size_t)lv * d.mw + e] : 0ull);
                 float vx = 0.f, vy = 0.f;
                 if (k >= pl.n_static && src.intensity > 0.01f) {
                     const int model_end = src.nx > -100.f ? fp.model_nb : pl.n_static;
@@ -924,6 +926,18 @@ __global__ void k_zero_i32(int* __restrict__ p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0;
 }
+__global__ void k_copy_u64(const u64* __restrict__ src, u64* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+// k_birth_insert, preceded by the snapshot of the newborn bits when earlier newborns may exist (c.k.nbsnap != nullptr)
+static void launch_insert(const LaunchCtx& c, unsigned gb) {
+    if (c.k.nbsnap) {
+        const size_t W = (size_t)c.d.v_loc * c.d.mw;
+        hipLaunchKernelGGL(k_copy_u64, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, c.stream, c.s.nbmask, c.k.nbsnap, W);
+    }
+    hipLaunchKernelGGL(k_birth_insert, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx, c.k.part_birth, c.k.nbsnap);
+}
 static void birth_children_insert(const LaunchCtx& c, int n_birth_grid, bool in_frame, bool all_static);
 void launch_birth_plan_insert(const LaunchCtx& c, int n_birth_grid, bool in_frame, bool all_static) {
     if (n_birth_grid <= 0) return;
@@ -939,7 +953,7 @@ static void birth_children_insert(const LaunchCtx& c, int n_birth_grid, bool in_
     // all_static (every birth source has intensity 0, the synthesized cloud): no child draws from the velocity or
     // rand() streams (:877-903), so the cursor kernel has nothing to compute and k_birth_insert never reads its output
     if (!all_static) hipLaunchKernelGGL(k_birth_cursors, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
-    hipLaunchKernelGGL(k_birth_insert, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx, c.k.part_birth);
+    launch_insert(c, gb);
     if (!in_frame) hipLaunchKernelGGL(k_zero_i32, dim3((c.d.v_loc + 255) / 256), dim3(256), 0, c.stream, c.k.vb_cnt, c.d.v_loc);
 }
 // split (one wave per source point) and the reduction of the 1/Ck sums (one workgroup) in one launch
@@ -961,7 +975,7 @@ void launch_birth_finish(const LaunchCtx& c, int n_birth_grid, bool all_static) 
     if (n_birth_grid <= 0) return;
     const unsigned gb = (unsigned)(((long long)n_birth_grid * c.fp.nb_num + 255) / 256);
     if (!all_static) hipLaunchKernelGGL(k_birth_cursors, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
-    hipLaunchKernelGGL(k_birth_insert, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx, c.k.part_birth);
+    launch_insert(c, gb);
 }
 void launch_birth_split_cksum(const LaunchCtx& c, int n_birth_grid) {
     hipLaunchKernelGGL(k_birth_split_cksum, dim3((n_birth_grid + 15) / 16 + 1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
@@ -971,12 +985,23 @@ void launch_birth_late(const LaunchCtx& c, int n_birth_grid, bool all_static) {
     const unsigned gb = (unsigned)(((long long)n_birth_grid * c.fp.nb_num + 255) / 256);
     launch_birth_split_cksum(c, n_birth_grid);
     if (!all_static) hipLaunchKernelGGL(k_birth_cursors, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
-    hipLaunchKernelGGL(k_birth_insert, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx, c.k.part_birth);
+    launch_insert(c, gb);
 }
 void launch_birth(const LaunchCtx& c, int n_birth_grid, bool in_frame, bool all_static) {
     if (n_birth_grid <= 0) return;
     hipLaunchKernelGGL(k_birth_split_rank, dim3((n_birth_grid + 15) / 16 + 1), dim3(1024), 0, c.stream, c.d, c.s, c.fp, in_frame ? 1 : 0);
     birth_children_insert(c, n_birth_grid, in_frame, all_static);
+}
+
+// host readback of the synthesised birth cloud (dspmap_get_birth_cloud): entry i of the frame's BirthView
+__global__ void k_birth_materialize(DevState s, BirthSrc* __restrict__ out, int cap, int* __restrict__ n_out) {
+    const BirthView bv = birth_view(s);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *n_out = bv.n;
+    if (i < bv.n && i < cap) out[i] = birth_at(bv, i);
+}
+void launch_birth_materialize(const LaunchCtx& c, BirthSrc* out, int cap, int* n_out) {
+    hipLaunchKernelGGL(k_birth_materialize, dim3((cap + 255) / 256), dim3(256), 0, c.stream, c.s, out, cap, n_out);
 }
 
 void launch_scan_blocks(const LaunchCtx& c, int nblk) {

@@ -33,8 +33,8 @@ extern "C" int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_
     READY(m);
     if (!m->mgpu_bound) return dspmap_fail(m, DSPMAP_E_STATE, "call dspmap_mgpu_bind first");
     if (n_points < 0 || (n_points > 0 && !points_dev) || !pos || !q) return dspmap_fail(m, DSPMAP_E_ARG, "bad arguments");
-    const int nb = birth_dev ? n_birth : n_points;
-    if (nb > m->mgpu_nstatic_cap || n_points > m->pt_cap) return dspmap_fail(m, DSPMAP_E_ARG, "more points than the bound capacity");
+    const int nb_own = birth_dev ? n_birth : n_points;
+    if (nb_own > m->mgpu_nstatic_cap || n_points > m->pt_cap) return dspmap_fail(m, DSPMAP_E_ARG, "more points than the bound capacity");
     float dp[3], dt;
     if (!dspmap_gate_and_delta(m, pos, stamp, q, dp, &dt)) return DSPMAP_REJECTED;
     dspmap_freeze_birth_statics(m);
@@ -45,7 +45,9 @@ extern "C" int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_
     for (int i = 0; i < 4; i++) m->hp.quat[i] = m->quat[i];
     for (int i = 0; i < 3; i++) { m->hp.cur_pos[i] = m->cur_pos[i]; m->hp.od[i] = -dp[i]; }
     m->hp.dt = dt;
-    m->hp.n_pts = n_points; m->hp.n_birth = nb; m->hp.static_birth = static_birth ? 1 : 0;
+    m->hp.n_pts = n_points; m->hp.n_birth = nb_own; m->hp.static_birth = static_birth ? 1 : 0;
+    const int nb_grid = dspmap_begin_cloud(m, n_points, static_birth);
+    const int nb = static_birth ? nb_grid : nb_own;   // grid bound of the birth launches
     m->hp.pts = points_dev;
     m->hp.birth = static_birth ? m->s.birth : m->mgpu_birth;
     int rcp = dspmap_push_frame_params(m);
@@ -168,6 +170,7 @@ extern "C" int dspmap_mgpu_finish(dspmap_t* m) {
     launch_birth_finish(c, m->last_n_birth, m->last_birth_static);
     m->mgpu_birth_early = false;
     launch_resample(c);
+    if (m->nb_dirty) { m->nb_dirty = false; m->graph_epoch++; }
     HIPCHK(m, hipEventRecord(m->ev1, m->stream));
     m->ev_valid = true;
     HIPCHK(m, hipGetLastError());

@@ -885,9 +885,14 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
         const float w_after = __fdiv_rn(wsum, (float)n_after);  // :1000
         w_copy = w_after;
         float acc_ori = 0.f, acc_new = w_after * 0.5f;          // :1005-1006
+        // survivors before ANY copy is placed: copies carry flag 0.6 and are not revisited (:1009), also those that
+        // land in a later occupancy word than the one being walked
+        u64 surv[MW];
+#pragma unroll
+        for (int e = 0; e < MW; ++e) surv[e] = m[e];
 #pragma unroll
         for (int e = 0; e < MW; ++e) {
-            u64 todo = m[e];                                    // survivors before any copy (copies are not revisited)
+            u64 todo = surv[e];
             while (todo) {
                 const int row = __ffsll((long long)todo) - 1;
                 todo &= todo - 1ull;
@@ -1250,7 +1255,7 @@ __global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScra
     }
     for (int i = tid; i < k.nblk_sweep * 4; i += 1024) acc[6] += k.part_resample[i];
     int accb[2] = {0, 0};
-    const int nbb = (int)(((long long)s.fpar->n_birth * fp_nb_num + 255) / 256);  // blocks of the last k_birth_insert that covered real children
+    const int nbb = (int)(((long long)birth_view(s).n * fp_nb_num + 255) / 256);  // blocks of the last k_birth_insert that covered real children
     for (int i = tid; i < nbb; i += 1024) { accb[0] += k.part_birth[i * 2]; accb[1] += k.part_birth[i * 2 + 1]; }
     int out[7];
     for (int c = 0; c < 7; ++c) {

@@ -87,6 +87,9 @@ struct FrameScalars {
     float cur_pos[3];        // current_position :131
     int p_cur, v_cur, r_cur; // table cursors :483-484 (+ rand stream)
     int has_expected_override;
+    // synthesised birth cloud (FrameParams::static_birth): frame epoch in which the view held at least one point, and
+    // the length of the last non-empty view's cloud kept in DevState::birth (an empty view re-uses it, :1379-1381)
+    int view_epoch, stale_n;
 };
 
 // Per-frame inputs, written by ONE small H2D copy per frame and read by the kernels from HBM, so that
@@ -98,7 +101,8 @@ struct FrameParams {
     float dt;
     int n_pts;          // points in `pts`
     int n_birth;        // entries in `birth`
-    int static_birth;   // 1: k_obs_points writes the birth cloud (every in-FOV point a static source)
+    int static_birth;   // 1: the birth cloud is synthesised from the frame's view (every in-FOV point a zero-velocity source)
+    int epoch;          // frame counter (bumped whenever a cloud is binned); FrameScalars::view_epoch refers to it
     int clear_fut;      // 1: k_predict zeroes the future accumulators first (a clearOccupancyMapPrediction is pending)
     const float* pts;   // n_pts x 3, sensor frame
     struct BirthSrc* birth;

@@ -193,10 +193,14 @@ void VelocityEstimator::run(const std::vector<float>& view, const float cur[3], 
                             }
                     }
                 }
-                if (nbrs.size() > 1) std::sort(nbrs.begin(), nbrs.end());   // radiusSearch returns sorted by distance
                 for (auto& nb : nbrs) { retire(nb.second); queue.push_back(nb.second); }
             }
-            if (queue.size() >= 5 && queue.size() <= 10000) clusters.push_back(queue);
+            if (queue.size() >= 5 && queue.size() <= 10000) {
+                // PCL returns every cluster's indices sorted ascending (extract_clusters.hpp sorts r.indices): the cluster is the
+                // connected component of the radius graph, the growth order leaves no trace
+                std::sort(queue.begin(), queue.end());
+                clusters.push_back(queue);
+            }
         }
         std::stable_sort(clusters.begin(), clusters.end(),
                          [](const std::vector<int>& a, const std::vector<int>& b) { return a.size() > b.size(); });

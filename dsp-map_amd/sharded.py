@@ -52,7 +52,7 @@ class TorchDistComm:
     _side = None      # side stream + pinned buffer for the one host read of a frame (the gathered export counts)
     _host_counts = None
 
-    def exchange(self, up, down, counts, overlap=None):
+    def exchange(self, up, down, counts, overlap=None, cap=None):
         """send the first counts[0] rows of `up` to rank+1 and the first counts[1] rows of `down` to rank-1.
         `counts` is an int32[2] tensor on the communicator's device (it may still be in flight on the stream).
         Returns (from_below, from_above, (n_up, n_down)).  ONE host synchronisation: reading the gathered counts.
@@ -87,6 +87,12 @@ class TorchDistComm:
             if overlap is not None:
                 overlap()
             host = stacked.cpu().tolist()
+        # every rank sees the same gathered counts: an export that overflowed its buffer (the surplus records were dropped
+        # on the device) is detected by ALL ranks here, before any rank posts a receive its peer cannot fill
+        # (`cap`: the export buffers' capacity in records, the same on every rank since the slabs share one configuration)
+        worst = max(max(int(c[0]), int(c[1])) for c in host)
+        if cap is not None and worst > cap:
+            raise RuntimeError("slab export buffer too small: a rank exported %d records, capacity %d" % (worst, cap))
         n_up, n_down = int(host[r][0]), int(host[r][1])
         n_from_below = int(host[r - 1][0]) if r > 0 else 0       # what rank-1 sends up
         n_from_above = int(host[r + 1][1]) if r < w - 1 else 0   # what rank+1 sends down
@@ -177,6 +183,11 @@ class HipSlab:
         q_a = (C.c_float * 4)(*quat)
         n = int(pts.shape[0])
         self.n_birth = n if birth is None else int(birth.shape[0])
+        if birth is None:
+            # a frame with an empty view re-uses the cloud of the last non-empty one (reference :1379-1381), which may be
+            # longer than this frame's point count: the n_static exchange covers the longest synthesised cloud so far
+            self.n_birth_hi = max(getattr(self, "n_birth_hi", 0), n)
+            self.n_birth = self.n_birth_hi
         bptr = None if birth is None else birth.data_ptr()
         return m._chk(m.L.dspmap_mgpu_begin(m.h, n, pts.data_ptr(), self.n_birth, bptr, C.cast(pos_a, C.c_void_p),
                                             float(stamp), C.cast(q_a, C.c_void_p)))
@@ -273,7 +284,7 @@ class ShardedDSPMap:
             slab = self.slabs[0]
             up, down, counts = self._export_both(slab)
             overlap = slab.place_interior if hasattr(slab, "place_interior") else None
-            below, above, (n_up, n_down) = self.comm.exchange(up, down, counts, overlap)
+            below, above, (n_up, n_down) = self.comm.exchange(up, down, counts, overlap, getattr(slab, "exp_cap", None))
             if hasattr(slab, "note_exports"):
                 slab.note_exports(n_up, n_down)
             slab.import_(below)

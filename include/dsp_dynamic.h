@@ -21,6 +21,7 @@
 #ifndef DSP_DYNAMIC_H_MI355X
 #define DSP_DYNAMIC_H_MI355X
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <ctime>
@@ -109,6 +110,10 @@ static const int VOXEL_NUM = MAP_LENGTH_VOXEL_NUM * MAP_WIDTH_VOXEL_NUM * MAP_HE
 static const int half_fov_h = DSPMAP_HALF_FOV_H;  // :49
 static const int half_fov_v = DSPMAP_HALF_FOV_V;  // :50
 
+#ifndef DSPMAP_NO_SAVE_FOLDER_GLOBAL
+static string particle_save_folder = ".";  // :55 (one per translation unit here: the reference's non-static global could not be included twice)
+#endif
+
 class DSPMap {
 public:
     /* :145-175.  init_particle_num > 0 pre-fills the map with random particles (addRandomParticles
@@ -160,6 +165,15 @@ public:
                                      sensor_pz, time_stamp_second, sensor_quaternion_w, sensor_quaternion_x,
                                      sensor_quaternion_y, sensor_quaternion_z);
         if (rc < 0) { cerr << "DSPMap::update failed: " << dspmap_last_error(h_) << endl; return 0; }
+        if (rc == 1 && record_flag_) {  // :326-350: every frame when the flag is negative, else once after record_time
+            const float update_time = (float)dspmap_get_param(h_, DSPMAP_P_UPDATE_TIME);
+            if (record_flag_ < 0 || (update_time > record_time_ && !recorded_once_)) {
+                recorded_once_ = 1;
+                const int update_counter = (int)dspmap_get_param(h_, DSPMAP_P_UPDATE_COUNTER);
+                writeParticleCsv(particle_save_folder + "/particles_update_t_" + to_string(update_counter) + "_" +
+                                 to_string((int)(update_time * 1000)) + ".csv");
+            }
+        }
         return rc;
     }
 
@@ -171,7 +185,7 @@ public:
     void setObservationStdDev(float ob_stddev) { dspmap_set_param(h_, DSPMAP_P_OBSERVATION_STDDEV, ob_stddev); }  // :362
     void setNewBornParticleWeight(float weight) { dspmap_set_param(h_, DSPMAP_P_NEWBORN_WEIGHT, weight); }        // :366
     void setNewBornParticleNumberofEachPoint(int num) { dspmap_set_param(h_, DSPMAP_P_NEWBORN_NUMBER, num); }      // :370
-    /* :375-378.  The CSV dump (:326-350) is a write-only debugging aid; use writeParticleCsv() explicitly. */
+    /* :375-378.  Arms the particle CSV dump at the end of update() (:326-350); writeParticleCsv() writes one on request. */
     void setParticleRecordFlag(int record_particle_flag, float record_csv_time = 1.f) {
         record_flag_ = record_particle_flag; record_time_ = record_csv_time;
     }
@@ -220,8 +234,13 @@ public:
         std::vector<int> vox((size_t)n), slot((size_t)n);
         std::vector<float> rec((size_t)n * 8);
         if (n) dspmap_export_state(h_, n, vox.data(), slot.data(), rec.data(), &n);
+        // the reference walks voxels, then slots, in ascending order (:337-338); the device compaction is unordered
+        std::vector<int> order((size_t)n);
+        for (int i = 0; i < n; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return vox[a] != vox[b] ? vox[a] < vox[b] : slot[a] < slot[b]; });
         std::ofstream w(file_name, std::ios::out | std::ios::trunc);
-        for (int i = 0; i < n; i++) {
+        for (int q = 0; q < n; q++) {
+            const int i = order[q];
             for (int k = 0; k < 8; k++) w << rec[(size_t)i * 8 + k] << ",";
             w << vox[i] << "\n";
         }
@@ -253,8 +272,9 @@ private:
     dspmap_t* h_ = nullptr;
     int init_particles_;
     float init_weight_;
-    int record_flag_ = 0;
-    float record_time_ = 1.f;
+    int record_flag_ = 0;        // if_record_particle_csv :479
+    float record_time_ = 1.f;    // record_time :480
+    int recorded_once_ = 0;      // recorded_once_flag :326
     std::vector<float> xyz_;
 };
 

@@ -109,6 +109,8 @@ enum dspmap_param {
     DSPMAP_P_REGENERATE_TABLES = 10,/* 1 = setPredictionVariance regenerates the Gaussian tables (:359) */
     DSPMAP_P_USE_GRAPH = 11,        /* 1 (default) = dspmap_update_device replays the frame as a captured HIP graph */
     DSPMAP_P_OCCLUSION_MARGIN = 12, /* obstacle_thickness_for_occlusion :70 (0.3 m); the reference's two other headers use VOXEL_RESOLUTION */
+    DSPMAP_P_UPDATE_TIME = 14,      /* read-only: update_time, the sum of the accepted frames' delt_t (:634) */
+    DSPMAP_P_UPDATE_COUNTER = 15,   /* read-only: update_counter, the number of predictions run (:635) */
     DSPMAP_P_PAIR_CULL_SIGMAS = 13  /* mapUpdate evaluates a (particle, observation) pair only if their ranges differ by at most this many
                                        sigma_ob (default 9: the dropped terms are < 1e-19 and zero on the fixed-point Ck grid);
                                        a huge value evaluates every pair of the neighbourhood like the reference's loops */

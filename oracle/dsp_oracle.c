@@ -688,8 +688,14 @@ void dspo_add_newborn(dsp_oracle* o) {
         float cy = pt->y - o->current_position[1];
         float cz = pt->z - o->current_position[2];
         int n_static;
-        if (!birth_nstatic(o, cx, cy, cz, &n_static)) continue; /* :847 */
-        if (o->nstatic_override) n_static = o->nstatic_override[q];
+        if (o->cfg.static_model) {
+            /* dsp_static.h:797-825: no voxel lookup for the source point (a source outside the map still draws and may
+             * place children inside it) and no static/dynamic split: every child has zero velocity (:813-815) */
+            n_static = n_nb;
+        } else {
+            if (!birth_nstatic(o, cx, cy, cz, &n_static)) continue; /* :847 */
+            if (o->nstatic_override) n_static = o->nstatic_override[q];
+        }
         for (int p = 0; p < n_nb; p++) { /* :868 */
             float px = cx + draw_p(o);
             float py = cy + draw_p(o);
@@ -906,9 +912,13 @@ static int cmp_dist(const void* a, const void* b) {
     if (da > db) return 1;
     return ((const dist_idx*)a)->i - ((const dist_idx*)b)->i;
 }
+static int cmp_int_asc(const void* a, const void* b) { return *(const int*)a - *(const int*)b; }
 typedef struct { int start, size; } cluster_span;
+/* PCL sorts the clusters by size, largest first (std::sort: the order of equal sizes is unspecified there); equal
+ * sizes keep their seed order here */
 static int cmp_cluster_desc(const void* a, const void* b) {
-    return ((const cluster_span*)b)->size - ((const cluster_span*)a)->size;
+    const int d = ((const cluster_span*)b)->size - ((const cluster_span*)a)->size;
+    return d ? d : ((const cluster_span*)a)->start - ((const cluster_span*)b)->start;
 }
 
 void dspo_velocity_estimation(dsp_oracle* o) {
@@ -951,6 +961,10 @@ void dspo_velocity_estimation(dsp_oracle* o) {
                     if (!processed[nbrs[k].i]) { processed[nbrs[k].i] = 1; queue[qn++] = nbrs[k].i; }
             }
             if (qn >= 5 && qn <= 10000) {
+                /* PCL's extractEuclideanClusters sorts (and uniques) the indices of every cluster before it returns them
+                 * (pcl/segmentation/impl/extract_clusters.hpp: std::sort(r.indices.begin(), r.indices.end())), so the points
+                 * of a cluster reach :1424-1429 and :1509-1519 in ascending index order, not in region-growing order */
+                qsort(queue, qn, sizeof(int), cmp_int_asc);
                 spans[n_spans].start = n_order; spans[n_spans].size = qn; n_spans++;
                 memcpy(order + n_order, queue, sizeof(int) * qn);
                 n_order += qn;
@@ -1045,6 +1059,9 @@ void dspo_velocity_estimation(dsp_oracle* o) {
  * format (:1529-1540) without its ground/cluster re-ordering.  This is what
  * libdspmap_hip does when no birth cloud is supplied. */
 void dspo_static_birth_cloud(dsp_oracle* o) {
+    /* dsp_static.h:1285-1290 (and dsp_dynamic.h:1379-1381): an empty view returns BEFORE the previous output is
+     * cleared, so the last non-empty frame's cloud is reused by the birth stage */
+    if (o->cloud_view_n == 0) return;
     birth_reserve(o, o->cloud_view_n);
     o->birth_n = 0;
     for (int i = 0; i < o->cloud_view_n; i++) {

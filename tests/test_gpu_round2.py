@@ -1,0 +1,350 @@
+"""GPU parity tests for the corner cases closed in round 2 (run with `-m gpu` on an MI355X)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import common
+from tests.test_gpu_parity import RTOL, gpu_state, make_pair
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _slots_equal(o, m, cols=(0, 1, 2, 3, 4, 5, 6)):
+    vo, so, ro = o.export_sparse()
+    vg, sg, rg = gpu_state(m)
+    assert len(vo) == len(vg)
+    ko, kg = np.lexsort((so, vo)), np.lexsort((sg, vg))
+    assert np.array_equal(vo[ko], vg[kg]) and np.array_equal(so[ko], sg[kg])
+    for c in cols:
+        assert np.array_equal(ro[ko][:, c], rg[kg][:, c]), c
+    return ro[ko], rg[kg]
+
+
+def test_prefill_then_first_frame_births_skip_prefilled_slots(dsp, orc):
+    """DSPMap(init_particle_num > 0) followed by the first update(): addAParticle (:1184-1185) skips every slot whose flag
+    is >= 0.1 -- including the pre-filled particles, which still carry the newborn flag 15 -- so the first frame's
+    newborns take the free slots BEHIND them.  Birth stage from the pre-filled state: same particles in the same slots."""
+    cfgkw = dict(nx=30, ny=30, nz=16, ppv=10)
+    o, m = make_pair(dsp, orc, **cfgkw)
+    n = 20000
+    o.L.dspo_add_random_particles(o.h, n, 0.01)
+    m._chk(m.L.dspmap_add_random_particles(m.h, n, 0.01))
+    pts = common.wall_cloud(2, n_side=30, dist=1.6, half_w=1.2, half_h=0.7)
+    for x in (o, m):
+        x.bin_points(pts)
+        x.predict(0, 0, 0, 0)         # flag-15 particles are not predicted (:649)
+        x.map_update()
+    o.L.dspo_use_velocity_estimator(o.h, 2)
+    o.L.dspo_static_birth_cloud(o.h)
+    o.add_newborn(); m.add_newborn()
+    ro, rg = _slots_equal(o, m)
+    assert (ro[:, 0] > 10).sum() > n                       # pre-filled + this frame's newborns, all flagged 15
+    assert np.allclose(ro[:, 7], rg[:, 7], rtol=RTOL)
+    # a second birth stage without a resampling in between: the first stage's newborns are skipped as well
+    o.add_newborn(); m.add_newborn()
+    ro, rg = _slots_equal(o, m)
+    # ... and the whole first frames of both, through update()
+    o2, m2 = make_pair(dsp, orc, **cfgkw)
+    o2.L.dspo_add_random_particles(o2.h, n, 0.01)
+    m2._chk(m2.L.dspmap_add_random_particles(m2.h, n, 0.01))
+    o2.L.dspo_use_velocity_estimator(o2.h, 2)
+    assert o2.update(pts, (0, 0, 0), 0.0, (1, 0, 0, 0)) == 1 and m2.update(pts, (0, 0, 0), 0.0, (1, 0, 0, 0)) == 1
+    # (which of a voxel's EQUAL-weight newborns survive the resampling is a threshold tie, see DESIGN "numerics": compare
+    # the per-voxel population and mass, and the pre-filled particles, none of which is resampled away or overwritten)
+    vo, so, r2o = o2.export_sparse()
+    vg, sg, r2g = gpu_state(m2)
+    assert np.array_equal(np.bincount(vo, minlength=o2.V), np.bincount(vg, minlength=o2.V))
+    assert np.allclose(m2.results()[:, 0], o2.results[:, 0], rtol=RTOL, atol=1e-6)
+    pre_o, pre_g = r2o[r2o[:, 3] != 0], r2g[r2g[:, 3] != 0]          # pre-filled particles still carry their vz
+    assert len(pre_o) == len(pre_g) > 0.9 * n
+    a_v, a_r = common.sorted_records(vo[r2o[:, 3] != 0], pre_o, cols=(4, 5, 6, 1, 2, 3))
+    b_v, b_r = common.sorted_records(vg[r2g[:, 3] != 0], pre_g, cols=(4, 5, 6, 1, 2, 3))
+    assert np.array_equal(a_v, b_v) and np.array_equal(a_r[:, 1:7], b_r[:, 1:7])
+    for x in (o, m, o2, m2):
+        x.close()
+
+
+def test_static_model_births_from_sources_outside_the_map(dsp, orc):
+    """dsp_static.h:797-825 has no voxel lookup for the source point: a point of the view that lies outside the map box
+    still draws its 3 x n position values and places the children that land inside.  The map is made shallower than the
+    wall's distance so that sources sit just outside the front face."""
+    cfg = dict(nx=20, ny=30, nz=16, res=0.2, ppv=10, half_fov_v=27, pred_times=(0.05,), safe_factor=5, static_model=1)
+    o, m = make_pair(dsp, orc, **cfg)          # half_x = 2.0
+    pts = common.wall_cloud(4, n_side=40, dist=2.03, half_w=1.6, half_h=0.8, wav=0.04)   # x in ~[1.97, 2.09]: both sides of the face
+    assert (pts[:, 0] > 2.0).sum() > 100 and (pts[:, 0] < 2.0).sum() > 100
+    for x in (o, m):
+        x.bin_points(pts)
+        x.predict(0, 0, 0, 0)
+        x.map_update()
+    o.L.dspo_static_birth_cloud(o.h)
+    o.add_newborn(); m.add_newborn()
+    assert o.cursors() == m.cursors()          # every source consumed its draws, inside the map or not
+    ro, rg = _slots_equal(o, m)
+    assert len(ro) > 5000
+    o.close(); m.close()
+
+
+@pytest.mark.parametrize("static_model", [0, 1])
+def test_empty_view_reuses_previous_birth_cloud(dsp, orc, static_model):
+    """velocityEstimationThread returns before clearing its output when the view is empty (:1379-1381,
+    dsp_static.h:1288-1290): the birth stage then re-uses the last non-empty view's cloud, shifted by the new sensor
+    position"""
+    cfg = dict(nx=30, ny=30, nz=16, res=0.2, ppv=10)
+    if static_model:
+        cfg.update(half_fov_v=27, pred_times=(0.05,), safe_factor=5, static_model=1)
+    o, m = make_pair(dsp, orc, **cfg)
+    o.L.dspo_use_velocity_estimator(o.h, 2)
+    wall = common.wall_cloud(6, n_side=30, dist=1.8, half_w=1.2, half_h=0.7)
+    behind = wall.copy(); behind[:, 0] *= -1.0                      # every point outside the field of view
+    few_behind = behind[:7]
+    clouds = [wall, behind, few_behind, np.zeros((0, 3), np.float32), wall[:500]]
+    for f, pts in enumerate(clouds):
+        pos = (0.02 * f, 0.01 * f, 0.0)
+        assert o.update(pts, pos, f / 30.0, (1, 0, 0, 0)) == 1
+        assert m.update(pts, pos, f / 30.0, (1, 0, 0, 0)) == 1
+        assert o.cursors()[0] == m.cursors()[0], f                     # the stale cloud drew its position values again
+        c = m.counters()
+        if f in (1, 2, 3):
+            assert c["n_valid"] == 0 and c["n_born"] > 1000, (f, c)     # births without a single observation
+        bo, bg = o.get_birth_cloud(), m.get_birth_cloud()
+        assert len(bo) == len(bg) and np.array_equal(bo["x"], bg["x"]) and np.array_equal(bo["z"], bg["z"]), f
+        occ_o, occ_g = o.results[:, 0].astype(np.float64), m.results()[:, 0].astype(np.float64)
+        assert abs(occ_g.sum() - occ_o.sum()) < 2e-3 * occ_o.sum(), f
+        o.get_occupancy_with_future(0.2); m.getOccupancyMapWithFutureStatus(0.2)
+    # the same through the captured device-resident frame
+    import torch
+    m3 = dsp.DSPMap(dsp.make_config(**cfg)); m3.set_tables(*common.tables(1))
+    for f, pts in enumerate(clouds):
+        t = torch.from_numpy(np.ascontiguousarray(pts)).cuda()
+        assert m3.update_device(t.data_ptr(), len(pts), (0.02 * f, 0.01 * f, 0.0), f / 30.0, (1, 0, 0, 0)) == 1
+        m3.getOccupancyMapWithFutureStatus(0.2)
+    for a, b in zip(m.export_state(), m3.export_state()):
+        assert np.array_equal(a, b)
+    o.close(); m.close(); m3.close()
+
+
+def test_resample_copies_into_the_second_occupancy_word(dsp, orc):
+    """more than 64 live particles in a voxel of a 72-slot map: copies made while the first occupancy word is walked land
+    in the second word and must not be revisited there (they carry flag 0.6, :1009)"""
+    cfgkw = dict(nx=10, ny=10, nz=6, res=0.10, ppv=36)
+    o, m = make_pair(dsp, orc, **cfgkw)
+    assert m.slots == 72
+    rng = np.random.default_rng(3)
+    px, py, pz, w = [], [], [], []
+    for k, (cx, cy, cz) in enumerate([(0.05, 0.05, 0.05), (0.15, -0.25, 0.15), (-0.35, 0.25, -0.05)]):
+        n = (66, 70, 40)[k]                                   # 66 / 70 occupy both words; the resampler keeps 36
+        px += list(cx + rng.uniform(-0.04, 0.04, n)); py += list(cy + rng.uniform(-0.04, 0.04, n)); pz += list(cz + rng.uniform(-0.04, 0.04, n))
+        ww = rng.uniform(0.002, 0.01, n)
+        ww[:3] = (0.9, 0.6, 0.4)                              # heavy early particles: several copies each
+        w += list(ww)
+    px, py, pz, w = (np.asarray(a, np.float32) for a in (px, py, pz, w))
+    z = np.zeros(len(px), np.float32)
+    common.inject_both(o, m, px, py, pz, z, z, w)
+    cnt = np.bincount(o.export_sparse()[0], minlength=o.V)
+    assert cnt.max() == 70
+    # free a few low slots so that copies are spread over both words
+    o.occupancy_resample(); m.occupancy_resample()
+    assert np.array_equal(m.results()[:, 0], o.results[:, 0])
+    ro, rg = _slots_equal(o, m, cols=(4, 5, 6))
+    assert np.allclose(ro[:, 7], rg[:, 7], rtol=1e-6)
+    # a second pass over the resampled state (survivors + copies, now all flag 1)
+    o.occupancy_resample(); m.occupancy_resample()
+    ro, rg = _slots_equal(o, m, cols=(4, 5, 6))
+    o.close(); m.close()
+
+
+def test_pyramid_list_overflow_bounds(dsp, orc):
+    """pyramid-list overflow (-2, :1245-1259): a pyramid registers at most SAFE_PARTICLE_NUM_PYRAMID particles; the ones
+    that do not fit are removed.  WHICH of a pyramid's candidates are turned away depends on the order they arrive in (the
+    reference: its voxel/slot sweep; here: the order the workgroups finish in), so the assertion is the multiset bound:
+    same list lengths, same number of removals per pyramid, survivors are a subset of the candidates, everything outside
+    the overflowing pyramids is identical."""
+    cfgkw = dict(nx=40, ny=40, nz=10, res=0.15, ppv=9)
+    o, m = make_pair(dsp, orc, **cfgkw)
+    assert m.capp == o.capp == 66
+    half = common.half_extent(o.cfg)
+    rng = np.random.default_rng(8)
+    n = 90000
+    # inside the field of view (x forward, +-42 / +-24 degrees), spread over the map's depth
+    r = rng.uniform(0.3, half[0] * 0.95, n)
+    az = np.radians(rng.uniform(-40, 40, n)); el = np.radians(rng.uniform(-22, 22, n))
+    px = (r * np.cos(az)).astype(np.float32); py = (r * np.sin(az)).astype(np.float32)
+    pz = (r * np.cos(az) * np.tan(el)).astype(np.float32)
+    keep = (np.abs(py) < half[1] * 0.98) & (np.abs(pz) < half[2] * 0.98) & (np.abs(px) < half[0] * 0.98)
+    px, py, pz = px[keep], py[keep], pz[keep]
+    z = np.zeros(len(px), np.float32)
+    w = rng.uniform(0.01, 0.05, len(px)).astype(np.float32)
+    n_in = common.inject_both(o, m, px, py, pz, z, z, w)
+    empty = np.zeros((0, 3), np.float32)
+    o.bin_points(empty); m.bin_points(empty)
+    vo0, so0, ro0 = o.export_sparse()
+    o.predict(0.0, 0.0, 0.0, 0.0); m.predict(0.0, 0.0, 0.0, 0.0)          # nobody moves: candidates = the particles in view
+    len_o = (o.pyramid_lists[:, :, 0] != 0).sum(1)
+    len_g = m.pyramid_counts()
+    assert np.array_equal(len_o, len_g) and (len_o == o.capp).sum() > 20   # many full lists
+    c = m.counters()
+    vo, so, ro = o.export_sparse()
+    vg, sg, rg = gpu_state(m)
+    assert len(vo) == len(vg) == n_in - c["n_pyramid_full"] and c["n_pyramid_full"] > 500
+    assert c["n_fov"] == int(len_o.sum())
+    # survivors are a subset of the injected particles, at their original slots
+    key0 = set(zip(vo0.tolist(), so0.tolist()))
+    assert set(zip(vg.tolist(), sg.tolist())) <= key0
+    # same number of survivors per pyramid (particles keep their position: classify them with the oracle's geometry)
+    def pyr_of(rec):
+        out = np.full(len(rec), -1)
+        for i, p in enumerate(rec):
+            if o.L.dspo_in_pyramids_area(o.h, float(p[4]), float(p[5]), float(p[6])):
+                out[i] = o.L.dspo_pyramid_h(o.h, float(p[4]), float(p[5]), float(p[6])) * 16 + \
+                    o.L.dspo_pyramid_v(o.h, float(p[4]), float(p[5]), float(p[6]))
+        return out
+    po, pg = pyr_of(ro), pyr_of(rg)
+    assert np.array_equal(np.bincount(po[po >= 0], minlength=o.NP), np.bincount(pg[pg >= 0], minlength=o.NP))
+    assert (po < 0).sum() == (pg < 0).sum()                                # particles outside the view are never removed
+    o.close(); m.close()
+
+
+def test_checkpoint_into_handle_with_other_tables(dsp, tmp_path):
+    """a checkpoint restores the filter parameters but not the saving handle's table lengths: loading into a handle
+    whose injected tables are shorter keeps every cursor inside them"""
+    cfgkw = dict(nx=30, ny=30, nz=16, ppv=10)
+    a = dsp.DSPMap(dsp.make_config(**cfgkw)); a.set_tables(*common.tables(1, n=200003, nrand=50021))
+    pts = common.wall_cloud(2, n_side=30, dist=1.6, half_w=1.2, half_h=0.7)
+    for f in range(3):
+        assert a.update(pts, (0.01 * f, 0, 0), f / 30.0, (1, 0, 0, 0)) == 1
+    path = str(tmp_path / "a.ck")
+    a.save_checkpoint(path)
+    assert a.cursors()[0] > 5003
+    b = dsp.DSPMap(dsp.make_config(**cfgkw)); b.set_tables(*common.tables(2, n=5003, nrand=1009))
+    b.set_param(dsp.capi.P_PAIR_CULL_SIGMAS, 7.0)
+    b.load_checkpoint(path)
+    pc, vc, rc = b.cursors()
+    assert 0 <= pc < 5003 and 0 <= vc < 5003 and 0 <= rc < 1009
+    assert b.L.dspmap_get_param(b.h, dsp.capi.P_PAIR_CULL_SIGMAS) == 7.0
+    for f in range(3, 6):
+        assert b.update(pts, (0.01 * f, 0, 0), f / 30.0, (1, 0, 0, 0)) == 1
+    assert b.counters()["n_live_out"] > 1000
+    # a header with an absurd particle count is rejected, not thrown across the C ABI
+    raw = bytearray(open(path, "rb").read())
+    hdr_n = raw.find(np.int32(len(a.export_state()[0])).tobytes(), 0, 512)
+    assert hdr_n > 0
+    raw[hdr_n:hdr_n + 4] = np.int32(-5).tobytes()
+    bad = str(tmp_path / "bad.ck")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(dsp.capi.DSPMapError):
+        b.load_checkpoint(bad)
+    a.close(); b.close()
+
+
+def _cluster_scene(t, frame):
+    """sensor-frame cloud: ground + six groups of non-ground points (sensor 1.0 m above the ground, identity attitude)"""
+    def box(x0, y0, z0, nx, ny, nz, step=0.1):
+        xs, ys, zs = np.meshgrid(x0 + step * np.arange(nx), y0 + step * np.arange(ny), z0 + step * np.arange(nz), indexing="ij")
+        return np.stack([xs.ravel(), ys.ravel(), zs.ravel()], 1)
+    parts = []
+    gx, gy = np.meshgrid(np.arange(2.3, 3.4, 0.1), np.arange(-1.6, 1.6, 0.1))
+    parts.append(np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, -0.98)], 1))        # ground: z_world = 0.02 <= 0.1
+    parts.append(box(2.0, -1.5 + 1.0 * t, -0.7, 1, 5, 12))                               # A: 60 points, 1 m/s along +y
+    parts.append(box(3.9, 0.9 - 6.0 * t, -0.8, 1, 4, 20))                                # B: 80 points, 6 m/s: > 5 m/s -> zeroed
+    parts.append(box(2.6, -0.2, -0.5, 1, 5, 6) if frame == 0 else box(2.6, -0.2, -0.5, 1, 10, 16))   # C: 30 -> 160 points: gated
+    parts.append(box(4.2, -1.5, -0.8, 1, 30, 9))                                         # D: 270 points (> 200): static
+    parts.append(box(2.2, 0.9, 0.55, 1, 4, 5))                                           # E: centre z_world 1.75 > 1.5: static
+    parts.append(box(1.6, 1.2, -0.3, 1, 1, 3))                                           # F: 3 points: below the minimum size, dropped
+    parts.append(box(3.6, 0.2 + 0.5 * t, -0.6, 1, 3, 8))                                 # G: 24 points, 0.5 m/s
+    return np.concatenate(parts).astype(np.float32)
+
+
+def test_velocity_estimator_multi_cluster_against_oracle(dsp, orc):
+    """a17 on a scene with seven groups of points: four possibly-dynamic clusters (one faster than the 5 m/s limit,
+    :1490-1493; one whose point count changes by more than 100 between frames, :1463), two static ones (> 200 points;
+    centre higher than 1.5 m, :1436), one below the minimum cluster size (:1412): the birth cloud -- points, ORDER
+    (clusters by size, indices ascending inside a cluster, then the static points), tags and velocities -- equals the
+    oracle's restatement of velocityEstimationThread (:1377-1544)"""
+    cfgkw = dict(nx=66, ny=66, nz=40, ppv=9)
+    o, m = make_pair(dsp, orc, **cfgkw)
+    m.useVelocityEstimator(True)
+    o.L.dspo_use_velocity_estimator(o.h, 1)
+    pos = (0.0, 0.0, 1.0)
+    for f in range(3):
+        t = f * 0.1
+        pts = _cluster_scene(t, f)
+        assert m.update(pts, pos, t, (1, 0, 0, 0)) == 1
+        assert o.update(pts, pos, t, (1, 0, 0, 0)) == 1
+        g, w = m.get_birth_cloud(), o.get_birth_cloud()
+        assert len(g) == len(w) == len(pts) - 3, f                   # everything but the 3-point group
+        for k in ("x", "y", "z"):
+            assert np.array_equal(g[k], w[k]), (f, k)                # same points in the same ORDER
+        dyn_g, dyn_w = g["intensity"] > 0.01, w["intensity"] > 0.01
+        assert np.array_equal(dyn_g, dyn_w)
+        n_c = 30 if f == 0 else 160
+        assert dyn_g.sum() == 60 + 80 + n_c + 24, f                  # A, B, C, G are possibly dynamic; D and E are not
+        for k in ("nx", "ny", "nz"):
+            assert np.array_equal(g[k], w[k]), (f, k)
+        # inside a cluster every point carries the same tag
+        first = np.nonzero(dyn_g)[0]
+        if f == 0:
+            assert (g["nx"][dyn_g] < -100).all()                     # nothing to match against: sentinel -10000 (:104-106)
+        else:
+            vy = g["ny"][dyn_g]
+            a = np.isclose(vy, 1.0, atol=0.02).sum(); gsel = np.isclose(vy, 0.5, atol=0.02).sum()
+            assert a == 60 and gsel == 24, (f, a, gsel)              # A and G matched
+            b_pts = (np.abs(g["x"] - 3.9) < 1e-3) & dyn_g
+            assert b_pts.sum() == 80 and (g["nx"][b_pts] == 0).all() and (g["ny"][b_pts] == 0).all()   # B: > 5 m/s -> 0
+            c_pts = (np.abs(g["x"] - 2.6) < 1e-3) & dyn_g
+            if f == 1:
+                assert (g["nx"][c_pts] < -100).all()                 # C: 30 -> 160 points: gate, unmatched
+            else:
+                assert np.allclose(g["ny"][c_pts], 0.0, atol=1e-3)   # 160 -> 160: matched, at rest
+        o.get_occupancy_with_future(0.2); m.getOccupancyMapWithFutureStatus(0.2)
+    o.close(); m.close()
+
+
+def test_particle_csv_of_update(dsp, orc, tmp_path):
+    """setParticleRecordFlag (:375-378) arms the CSV dump at the end of update() (:326-350): the drop-in class writes
+    <folder>/particles_update_t_<counter>_<ms>.csv with the reference's columns flag,vx,vy,vz,px,py,pz,weight,voxel in
+    voxel/slot order; checked against the oracle's particle array after the same frames"""
+    exe = str(tmp_path / "csv_driver")
+    subprocess.check_call(["g++", "-std=c++14", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "csv_driver.cpp"),
+                           "-L" + os.path.join(ROOT, "dsp-map_amd", "lib"), "-ldspmap_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "dsp-map_amd", "lib"), "-o", exe])
+    p, v, r = common.tables(1)
+    pts = common.wall_cloud(3, n_side=40, dist=2.2, half_w=1.8, half_h=0.9)
+    frames = [(pts, (0.01 * f, 0.0, 0.0), f * 0.4, (1.0, 0.0, 0.0, 0.0)) for f in range(4)]
+    path = str(tmp_path / "frames.bin")
+    with open(path, "wb") as fh:
+        np.array([len(frames), p.size, r.size], np.int32).tofile(fh)
+        p.tofile(fh); v.tofile(fh); r.tofile(fh)
+        for c, pos, t, q in frames:
+            np.array([len(c)], np.int32).tofile(fh); np.array(pos, np.float32).tofile(fh)
+            np.array([t], np.float64).tofile(fh); np.array(q, np.float32).tofile(fh); c.astype(np.float32).tofile(fh)
+    out_all = tmp_path / "all"; out_all.mkdir()
+    subprocess.check_call([exe, path, str(out_all), "-1", "1.0"])
+    files = sorted(os.listdir(out_all))
+    # negative flag: one file per frame; names carry update_counter and (int)(update_time * 1000) (:333)
+    assert files == ["particles_update_t_1_0.csv", "particles_update_t_2_400.csv", "particles_update_t_3_800.csv",
+                     "particles_update_t_4_1200.csv"], files
+    o = orc.Oracle(orc.make_config())
+    o.set_tables(p, v, r)
+    o.L.dspo_use_velocity_estimator(o.h, 2)
+    assert o.update(pts, frames[0][1], frames[0][2], frames[0][3]) == 1
+    vo, so, ro = o.export_sparse()
+    rows = [ln.rstrip("\n").split(",") for ln in open(out_all / files[0])]
+    assert len(rows) == len(vo) > 5000 and all(len(x) == 9 for x in rows)
+    fmt = lambda x: "%g" % x                                            # ostream << float: 6 significant digits
+    assert [int(x[8]) for x in rows] == vo.tolist()                     # voxel order of the reference's loops (:337-338)
+    assert all(x[0] == "1" for x in rows) and set(np.unique(ro[:, 0]).tolist()) <= {1.0, np.float32(0.6)}   # copies (0.6) are exported as live (1)
+    # voxels with fewer than 5 particles are not resampled (:986): their rows equal the oracle's, column by column
+    cnt = np.bincount(vo, minlength=o.V)
+    small = np.nonzero(cnt[vo] < 5)[0]
+    assert len(small) > 500
+    for k in small:
+        assert [rows[k][c] for c in range(1, 7)] == [fmt(ro[k][c]) for c in range(1, 7)], k
+        assert float(rows[k][7]) == pytest.approx(float(ro[k][7]), rel=1e-4)
+    # positive flag: once, the first frame whose update_time exceeds record_time (:329)
+    out_once = tmp_path / "once"; out_once.mkdir()
+    subprocess.check_call([exe, path, str(out_once), "1", "0.5"])
+    assert sorted(os.listdir(out_once)) == ["particles_update_t_3_800.csv"]
+    o.close()
