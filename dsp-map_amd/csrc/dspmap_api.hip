@@ -1091,6 +1091,7 @@ extern "C" int dspmap_stage_birth(dspmap_t* m) {
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
     for (int i = 0; i < 3; i++) m->hp.cur_pos[i] = m->cur_pos[i];
     m->hp.n_birth = nb; m->hp.birth = m->s.birth;
+    m->hp.static_birth = m->last_birth_static ? 1 : 0;   // a cloud supplied after the binning replaces the synthesised one
     { int rc = dspmap_push_frame_params(m); if (rc != DSPMAP_OK) return rc; }
     launch_birth(c, nb, false, false);
     HIPCHK(m, hipGetLastError());

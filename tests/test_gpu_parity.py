@@ -459,19 +459,28 @@ def test_single_frame_from_same_state(dsp, orc):
 
 def test_trajectory_statistical_envelope(dsp, orc):
     """30 frames on the reference's default grid (66x66x40, 9 ppv), moving + yawing sensor, empty start.
-    SURVEY 8(c) trajectory envelope: sum of mass within 0.5 % (1.5 % at frame 30), |d occ| <= 0.02 on >= 99 % of voxels.
-    Every stage without a floating-point reduction is slot-exact (see the stage tests) and the one reduction that meets
-    in atomics, Ck, is accumulated on a fixed-point grid (order-independent), so two runs of the HIP path are
-    BIT-IDENTICAL in every slot (asserted below).  HIP and the oracle still drift apart: Ck and the newborn weight
-    w_nb * sum(1/Ck) are sums over ~10^3 terms whose order differs from the oracle's sequential loops (grid-snapped
-    terms, a tree), they land 1 ulp apart, and a voxel that holds n > M EQUAL-weight
-    newborns puts the resampler's running sum exactly on its thresholds -- the tie breaks differently and a different
-    (equally weighted) particle survives.  Measured: Jaccard of the occupied sets 0.999 / 0.98 / 0.96 after 2 / 10 / 30
-    frames, so the occupied-set criterion is Jaccard >= 0.93 and occupied-count within 4 %."""
+
+    SURVEY 8(c)'s trajectory envelope (its figures come from 12 frames of the reference built with -O2 against -O3
+    -ffast-math): sum of mass within 0.5 %, occupied-set Jaccard >= 0.98, |d occ| <= 0.02 on >= 99 % of the voxels --
+    asserted as stated through frame 10.  Beyond that the comparison is made TIE-ROBUST; the statement that replaces the
+    fixed numbers is:
+
+        at every checkpoint the HIP map differs from the oracle by no more than the oracle differs from ITSELF when its
+        new_born_particle_weight is moved by one ulp (Jaccard >= self-Jaccard - 0.01, mass error <= max(0.5 %, 2 x self)).
+
+    Why: every stage without a floating-point reduction is slot-exact (stage tests) and Ck is accumulated on a fixed-point
+    grid, so two HIP runs are BIT-IDENTICAL in every slot (asserted below).  What remains is the newborn weight
+    w_nb * sum(1/Ck), ~10^3 terms summed in a different order than the reference's sequential loop: it lands 1 ulp apart,
+    and a voxel that holds n > M EQUAL-weight newborns puts the resampler's running sum exactly on its thresholds -- the
+    tie breaks differently and a different (equally weighted) particle survives.  The reference has the same sensitivity:
+    one ulp on its own newborn weight moves its occupied set by Jaccard 0.993 / 0.984 / 0.956 after 2 / 10 / 30 frames
+    (measured with the oracle, this scene), which is what HIP-vs-oracle shows (0.999 / 0.98 / 0.96)."""
     cfgkw = dict(nx=66, ny=66, nz=40, ppv=9)
     o, m = make_pair(dsp, orc, seed=9, **cfgkw)
     m2 = dsp.DSPMap(dsp.make_config(**cfgkw)); m2.set_tables(*common.tables(9))   # a second, independent HIP run
-    o.L.dspo_use_velocity_estimator(o.h, 2)
+    o2 = orc.Oracle(orc.make_config(**cfgkw)); o2.set_tables(*common.tables(9))   # the oracle, one ulp on its newborn weight
+    o2.L.dspo_set_newborn_weight(o2.h, float(np.nextafter(np.float32(0.0001), np.float32(1.0))))
+    o.L.dspo_use_velocity_estimator(o.h, 2); o2.L.dspo_use_velocity_estimator(o2.h, 2)
     base = common.wall_cloud(77, n_side=50, dist=2.8, half_w=2.2, half_h=1.1)
     for f in range(30):
         t = f / 30.0
@@ -481,33 +490,44 @@ def test_trajectory_statistical_envelope(dsp, orc):
         pts = base.copy()
         pts[:, 0] -= np.float32(0.5 * t)
         assert o.update(pts, pos, t, q) == 1
+        assert o2.update(pts, pos, t, q) == 1
         assert m.update(pts, pos, t, q) == 1
         assert m2.update(pts, pos, t, q) == 1
         m2.clearOccupancyMapPrediction()
-        if f in (0, 1, 9, 29):
+        if f in (0, 1, 9, 19, 29):
             occ_o = o.results[:, 0].astype(np.float64)
+            occ_s = o2.results[:, 0].astype(np.float64)
             occ_g = m.results()[:, 0].astype(np.float64)
             occ_2 = m2.results()[:, 0].astype(np.float64)
             assert np.array_equal(occ_2, occ_g), f                              # run-to-run: the HIP path is reproducible
             for a, b in zip(m.export_state(), m2.export_state()):
                 assert np.array_equal(a, b), f
-            assert abs(occ_g.sum() - occ_o.sum()) < (5e-3 if f < 29 else 1.5e-2) * occ_o.sum(), f
-            so, sg = occ_o > 0.2, occ_g > 0.2
+            so, sg, ss = occ_o > 0.2, occ_g > 0.2, occ_s > 0.2
             jac = (so & sg).sum() / max(1, (so | sg).sum())
-            assert jac >= (0.999 if f == 0 else 0.93), (f, jac)
-            assert abs(int(so.sum()) - int(sg.sum())) <= 0.04 * so.sum() + 2, f
+            jac_self = (so & ss).sum() / max(1, (so | ss).sum())
+            mass_err = abs(occ_g.sum() - occ_o.sum()) / occ_o.sum()
+            mass_self = abs(occ_s.sum() - occ_o.sum()) / occ_o.sum()
+            print("frame %d: Jaccard HIP/oracle %.4f, oracle/oracle+1ulp %.4f; mass error %.2e (self %.2e)" %
+                  (f, jac, jac_self, mass_err, mass_self))
+            if f <= 9:   # SURVEY 8(c) as stated
+                assert jac >= (0.999 if f == 0 else 0.98), (f, jac)
+                assert mass_err < 5e-3, (f, mass_err)
+            assert jac >= jac_self - 0.01, (f, jac, jac_self)                     # inside the reference's own 1-ulp envelope
+            assert mass_err <= max(5e-3, 2 * mass_self), (f, mass_err, mass_self)
+            assert abs(int(so.sum()) - int(sg.sum())) <= max(0.01 * so.sum() + 2, 2 * abs(int(so.sum()) - int(ss.sum()))), f
             assert (np.abs(occ_g - occ_o) <= 0.02).mean() >= 0.99, f
             if f == 0:  # first frame: same births in the same slots -> per-voxel mass to 1e-4
                 assert np.allclose(occ_g, occ_o, rtol=RTOL, atol=1e-6)
         # both sides must clear the future accumulators every frame (Appendix A-4)
         xo, fo = o.get_occupancy_with_future(0.2)
+        o2.get_occupancy_with_future(0.2)
         ng, xg, fg = m.getOccupancyMapWithFutureStatus(0.2)
         if f == 29:
             assert abs(fg.sum() - fo.sum()) < 2e-2 * fo.sum()
     cg = m.counters()
     live_o = o.L.dspo_count_live(o.h)
-    assert abs(cg["n_live_out"] - live_o) < 0.03 * live_o
-    o.close(); m.close(); m2.close()
+    assert abs(cg["n_live_out"] - live_o) < 0.01 * live_o
+    o.close(); o2.close(); m.close(); m2.close()
 
 
 def test_range_culling_of_pairs_changes_nothing(dsp, orc):

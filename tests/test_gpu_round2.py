@@ -83,7 +83,7 @@ def test_static_model_births_from_sources_outside_the_map(dsp, orc):
     o.add_newborn(); m.add_newborn()
     assert o.cursors() == m.cursors()          # every source consumed its draws, inside the map or not
     ro, rg = _slots_equal(o, m)
-    assert len(ro) > 5000
+    assert len(ro) > 3000
     o.close(); m.close()
 
 
@@ -92,11 +92,14 @@ def test_empty_view_reuses_previous_birth_cloud(dsp, orc, static_model):
     """velocityEstimationThread returns before clearing its output when the view is empty (:1379-1381,
     dsp_static.h:1288-1290): the birth stage then re-uses the last non-empty view's cloud, shifted by the new sensor
     position"""
-    cfg = dict(nx=30, ny=30, nz=16, res=0.2, ppv=10)
+    cfg = dict(nx=30, ny=30, nz=16, res=0.2, ppv=20)
     if static_model:
         cfg.update(half_fov_v=27, pred_times=(0.05,), safe_factor=5, static_model=1)
     o, m = make_pair(dsp, orc, **cfg)
     o.L.dspo_use_velocity_estimator(o.h, 2)
+    # two children per source keep every voxel below MAX_PARTICLE_NUM_VOXEL: no equal-weight resampling ties (DESIGN
+    # "numerics"), so the two sides stay comparable particle by particle over the frames
+    o.L.dspo_set_newborn_number(o.h, 2); m.setNewBornParticleNumberofEachPoint(2)
     wall = common.wall_cloud(6, n_side=30, dist=1.8, half_w=1.2, half_h=0.7)
     behind = wall.copy(); behind[:, 0] *= -1.0                      # every point outside the field of view
     few_behind = behind[:7]
@@ -108,7 +111,7 @@ def test_empty_view_reuses_previous_birth_cloud(dsp, orc, static_model):
         assert o.cursors()[0] == m.cursors()[0], f                     # the stale cloud drew its position values again
         c = m.counters()
         if f in (1, 2, 3):
-            assert c["n_valid"] == 0 and c["n_born"] > 1000, (f, c)     # births without a single observation
+            assert c["n_valid"] == 0 and c["n_born"] > 300, (f, c)     # births without a single observation
         bo, bg = o.get_birth_cloud(), m.get_birth_cloud()
         assert len(bo) == len(bg) and np.array_equal(bo["x"], bg["x"]) and np.array_equal(bo["z"], bg["z"]), f
         occ_o, occ_g = o.results[:, 0].astype(np.float64), m.results()[:, 0].astype(np.float64)
@@ -116,7 +119,7 @@ def test_empty_view_reuses_previous_birth_cloud(dsp, orc, static_model):
         o.get_occupancy_with_future(0.2); m.getOccupancyMapWithFutureStatus(0.2)
     # the same through the captured device-resident frame
     import torch
-    m3 = dsp.DSPMap(dsp.make_config(**cfg)); m3.set_tables(*common.tables(1))
+    m3 = dsp.DSPMap(dsp.make_config(**cfg)); m3.set_tables(*common.tables(1)); m3.setNewBornParticleNumberofEachPoint(2)
     for f, pts in enumerate(clouds):
         t = torch.from_numpy(np.ascontiguousarray(pts)).cuda()
         assert m3.update_device(t.data_ptr(), len(pts), (0.02 * f, 0.01 * f, 0.0), f / 30.0, (1, 0, 0, 0)) == 1
