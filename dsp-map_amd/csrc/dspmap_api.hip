@@ -48,6 +48,7 @@ LaunchCtx dspmap_ctx_of(dspmap* m) {
     c.d = m->d; c.fp = m->fp; c.s = m->s; c.k = m->k; c.stream = m->stream;
     c.pt_cap = m->pt_cap; c.birth_cap = m->birth_cap;
     c.k.nbsnap = m->nb_dirty ? m->nbsnap_buf : nullptr;
+    c.ve = m->ve;
     return c;
 }
 
@@ -154,6 +155,10 @@ static void free_dev(dspmap* m) {
                     m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
     if (m->nbsnap_buf) chk(hipFree(m->nbsnap_buf), "hipFree");
+    {
+        void* vp[] = {m->ve.w, m->ve.parent, m->ve.ng_list, m->ve.root, m->ve.size, m->ve.rank, m->ve.by_rank, m->ve.dyn_list, m->ve.cl, m->ve.last, m->ve.n};
+        for (void* q : vp) if (q) chk(hipFree(q), "hipFree");
+    }
     if (m->pp_box) chk(hipFree(m->pp_box), "hipFree");
     if (m->pp_acc) chk(hipFree(m->pp_acc), "hipFree");
     if (m->pp_blk) chk(hipFree(m->pp_blk), "hipFree");
@@ -350,6 +355,17 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
         HIPCHK(m, hipMemcpy(s.planes_h, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
         HIPCHK(m, hipMemcpy(s.planes_v, v.data(), sizeof(float) * v.size(), hipMemcpyHostToDevice));
     }
+    {   // device velocity estimator (dspmap_velest.hip)
+        VelEst& ve = m->ve;
+        ve.cap = 8192;
+        const size_t nc = (size_t)ve.cap / 5 + 8;
+        HIPCHK(m, dalloc(&ve.w, (size_t)ve.cap)); HIPCHK(m, dalloc(&ve.parent, (size_t)ve.cap));
+        HIPCHK(m, dalloc(&ve.ng_list, (size_t)ve.cap)); HIPCHK(m, dalloc(&ve.root, (size_t)ve.cap));
+        HIPCHK(m, dalloc(&ve.size, (size_t)ve.cap)); HIPCHK(m, dalloc(&ve.rank, nc)); HIPCHK(m, dalloc(&ve.by_rank, nc));
+        HIPCHK(m, dalloc(&ve.dyn_list, nc)); HIPCHK(m, dalloc(&ve.cl, nc)); HIPCHK(m, dalloc(&ve.last, nc * 5));
+        HIPCHK(m, dalloc(&ve.n, (size_t)4));
+        HIPCHK(m, hipMemset(ve.n, 0, sizeof(int) * 4));
+    }
     m->device_ready = true;  // from here on free_dev() releases everything
     unsigned seed = m->cfg.seed ? m->cfg.seed : (unsigned)time(nullptr);  // :586,1151
     if (!m->tables_injected) gen_gauss_tables(m, seed);
@@ -404,7 +420,9 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
         case DSPMAP_P_VOXEL_FILTER_RES: m->voxel_filter_res = (float)v; break;
         case DSPMAP_P_KAPPA: m->fp.kappa = (float)v; break;
         case DSPMAP_P_DETECTION: m->fp.p_det = (float)v; break;
-        case DSPMAP_P_VELOCITY_ESTIMATOR: m->use_vel_est = v != 0; break;
+        case DSPMAP_P_VELOCITY_ESTIMATOR:
+            if (v != 0 && v != 1 && v != 2) return dspmap_fail(m, DSPMAP_E_ARG, "velocity estimator: 0 off, 1 host stage, 2 device");
+            m->use_vel_est = (int)v; break;
         case DSPMAP_P_USE_GRAPH: m->use_graph = v != 0; break;
         case DSPMAP_P_OCCLUSION_MARGIN: m->fp.occl_margin = (float)v; break;
         case DSPMAP_P_PAIR_CULL_SIGMAS: if (!(v > 0)) return dspmap_fail(m, DSPMAP_E_ARG, "pair cull radius must be positive"); m->cull_sigmas = (float)v; refresh_fp(m); break;
@@ -430,7 +448,7 @@ extern "C" double dspmap_get_param(const dspmap_t* m, int key) {
         case DSPMAP_P_VOXEL_FILTER_RES: return m->voxel_filter_res;
         case DSPMAP_P_KAPPA: return m->fp.kappa;
         case DSPMAP_P_DETECTION: return m->fp.p_det;
-        case DSPMAP_P_VELOCITY_ESTIMATOR: return m->use_vel_est ? 1 : 0;
+        case DSPMAP_P_VELOCITY_ESTIMATOR: return m->use_vel_est;
         case DSPMAP_P_OCCLUSION_MARGIN: return m->fp.occl_margin;
         case DSPMAP_P_PAIR_CULL_SIGMAS: return m->cull_sigmas;
         case DSPMAP_P_UPDATE_TIME: return m->update_time;
@@ -529,6 +547,7 @@ static void fill_pose(dspmap* m, const float dp[3], float dt) {
     for (int i = 0; i < 4; i++) m->hp.quat[i] = m->quat[i];
     for (int i = 0; i < 3; i++) { m->hp.cur_pos[i] = m->cur_pos[i]; m->hp.od[i] = -dp[i]; }  // particles move opposite to the sensor (:300)
     m->hp.dt = dt;
+    m->hp.res_filter = m->voxel_filter_res;
 }
 
 // C0 gate + deltas, update() :187-218.  returns 1 (accepted) / 0 (rejected)
@@ -560,10 +579,13 @@ int dspmap_gate_and_delta(dspmap* m, const float pos[3], double stamp, const flo
 // When `fork` is set (graph capture) the observation binning runs on a second stream concurrently with
 // prediction + re-binning: the two only share the rotated planes written by k_reset and meet again at
 // the Ck kernel.
-static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid, bool fork, bool all_static) {
+static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid, bool fork, bool all_static, bool est = false) {
     dspmap_prof_mark(m, 0);
     if (!fork) {
         launch_setup_and_bin(c, pts_grid, false);   // the gather rides on k_predict's launch
+        // the velocity estimator needs the binned view only; its output is the frame's birth cloud, which the birth rank
+        // (a rider of k_predict's launch) reads
+        if (est) launch_velocity_estimator(c, pts_grid);
     } else {
         launch_frame_setup(c, true);
         (void)hipEventRecord(m->ev_fork, m->stream);
@@ -609,7 +631,7 @@ static int frame_with_host_stages(dspmap* m, int np, const float* pts_dev, const
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
     // dsp_static.h has no velocity estimation: every in-FOV point is a zero-velocity birth source
-    const bool have_cloud = !m->cfg.static_model && (m->use_vel_est || m->h_birth_valid);
+    const bool have_cloud = !m->cfg.static_model && (m->use_vel_est != 0 || m->h_birth_valid);
     fill_pose(m, dp, dt);
     m->hp.n_pts = np; m->hp.n_birth = np; m->hp.static_birth = have_cloud ? 0 : 1;
     m->hp.pts = pts_dev; m->hp.birth = m->s.birth;
@@ -622,7 +644,7 @@ static int frame_with_host_stages(dspmap* m, int np, const float* pts_dev, const
     launch_ck_partial(c);
     launch_weight_update(c);
     int nb = nb_static_grid;
-    if (m->use_vel_est && !m->cfg.static_model) {
+    if (m->use_vel_est != 0 && !m->cfg.static_model) {
         if (pts_ready) HIPCHK(m, hipEventSynchronize(pts_ready));
         std::vector<float> view;
         view.reserve((size_t)np * 3);
@@ -655,19 +677,17 @@ static int frame_with_host_stages(dspmap* m, int np, const float* pts_dev, const
 }
 
 
-extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* points_dev, int n_birth,
-                                    const dspmap_vpoint* birth_dev, const float pos[3], double stamp,
-                                    const float q[4]) {
-    READY(m);
-    if (n_points < 0 || (n_points > 0 && !points_dev) || !pos || !q) return dspmap_fail(m, DSPMAP_E_ARG, "bad arguments");
-    float dp[3], dt;
-    if (!dspmap_gate_and_delta(m, pos, stamp, q, dp, &dt)) return DSPMAP_REJECTED;
+// One device-resident frame after the gate (dspmap_update_device; dspmap_update with the device estimator).
+static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_birth, const dspmap_vpoint* birth_dev,
+                        const float dp[3], float dt, const float q[4]) {
     int rc = dspmap_ensure_point_cap(m, n_points > n_birth ? n_points : n_birth);
     if (rc != DSPMAP_OK) return rc;
     dspmap_freeze_birth_statics(m);
-    if (!birth_dev && m->use_vel_est && !m->cfg.static_model && n_points > 0) {
-        // device-resident cloud + velocity estimator (DSPMAP_P_VELOCITY_ESTIMATOR): the estimator is the host stage of
-        // velocity_estimator.cpp (reference :1377-1544), so the (<= 60 kB) cloud is copied to the host, clustered and
+    const bool want_est = !birth_dev && m->use_vel_est != 0 && !m->cfg.static_model;
+    const bool est_dev = want_est && m->use_vel_est == 2 && n_points <= m->ve.cap;
+    if (want_est && !est_dev && n_points > 0) {
+        // device-resident cloud + the HOST velocity estimator (DSPMAP_P_VELOCITY_ESTIMATOR = 1, or a cloud larger than
+        // the device estimator orders in one workgroup): the (<= 60 kB) cloud is copied to the host, clustered and
         // matched there WHILE the device predicts and re-weights (the reference's fork/join, :297,311), and the tagged
         // birth cloud is uploaded for the birth stage.
         if (n_points > m->pts_pin_cap) {
@@ -683,25 +703,27 @@ extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* poin
     LaunchCtx c = dspmap_ctx_of(m);
     const bool has_vz = m->vz_frames > 0;
     if (!has_vz) c.s.vz0 = nullptr;
-    const bool static_birth = birth_dev == nullptr;
-    const int nb = static_birth ? n_points : n_birth;
+    // birth cloud: the caller's (0), synthesised from the view (1: every point in view a static source), or the device
+    // velocity estimator's (2)
+    const int mode = birth_dev ? 0 : (est_dev ? 2 : 1);
+    const int nb = mode == 0 ? n_birth : n_points;
     fill_pose(m, dp, dt);
-    m->hp.n_pts = n_points; m->hp.n_birth = nb; m->hp.static_birth = static_birth ? 1 : 0;
+    m->hp.n_pts = n_points; m->hp.n_birth = nb; m->hp.static_birth = mode;
     m->hp.pts = points_dev;
-    m->hp.birth = static_birth ? m->s.birth : (BirthSrc*)birth_dev;
-    const int nb_grid = static_birth ? dspmap_begin_cloud(m, n_points, true) : (dspmap_begin_cloud(m, n_points, false), nb);
+    m->hp.birth = mode == 0 ? (BirthSrc*)birth_dev : m->s.birth;
+    const int nb_grid = mode != 0 ? dspmap_begin_cloud(m, n_points, true) : (dspmap_begin_cloud(m, n_points, false), nb);
     rc = dspmap_push_frame_params(m);
     if (rc != DSPMAP_OK) return rc;
     dspmap_prof_collect(m);
     HIPCHK(m, hipEventRecord(m->ev0, m->stream));
     if (m->use_graph && !m->prof) {
         // the kernel arguments of a frame are constant (per-frame values live in s.fpar): capture once, replay
-        const unsigned long long key = ((unsigned long long)m->graph_epoch << 8) | (has_vz ? 1u : 0u) | (static_birth ? 2u : 0u);
+        const unsigned long long key = ((unsigned long long)m->graph_epoch << 8) | (has_vz ? 1u : 0u) | ((unsigned)mode << 1);
         if (!m->graph_exec || m->graph_key != key) {
             if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
             if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
             HIPCHK(m, hipStreamBeginCapture(m->stream, hipStreamCaptureModeRelaxed));
-            enqueue_frame(m, c, m->pt_cap, m->birth_cap, false, static_birth);  // (fork=true measured slower: HIP replays multi-branch graphs with a much higher launch cost) grids sized for the capacity; kernels bound-check against fpar
+            enqueue_frame(m, c, m->pt_cap, m->birth_cap, false, mode == 1, mode == 2);  // (fork=true measured slower: HIP replays multi-branch graphs with a much higher launch cost) grids sized for the capacity; kernels bound-check against fpar
             HIPCHK(m, hipStreamEndCapture(m->stream, &m->graph));
             HIPCHK(m, hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
             (void)hipGraphDestroy(m->graph);   // the executable graph keeps its own copy of the topology
@@ -710,7 +732,7 @@ extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* poin
         }
         HIPCHK(m, hipGraphLaunch(m->graph_exec, m->stream));
     } else {
-        enqueue_frame(m, c, n_points, nb_grid, false, static_birth);
+        enqueue_frame(m, c, n_points, nb_grid, false, mode == 1, mode == 2);
     }
     if (m->vz_frames > 0) --m->vz_frames;
     if (m->nb_dirty) { m->nb_dirty = false; m->graph_epoch++; }
@@ -718,9 +740,19 @@ extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* poin
     m->ev_valid = true;
     m->last_n_points = n_points;
     m->last_n_birth = nb_grid;
-    m->last_birth_static = static_birth;
+    m->last_birth_static = mode != 0;   // the cloud lives on the device (dspmap_get_birth_cloud materialises it)
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
+}
+
+extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* points_dev, int n_birth,
+                                    const dspmap_vpoint* birth_dev, const float pos[3], double stamp,
+                                    const float q[4]) {
+    READY(m);
+    if (n_points < 0 || (n_points > 0 && !points_dev) || !pos || !q) return dspmap_fail(m, DSPMAP_E_ARG, "bad arguments");
+    float dp[3], dt;
+    if (!dspmap_gate_and_delta(m, pos, stamp, q, dp, &dt)) return DSPMAP_REJECTED;
+    return device_frame(m, n_points, points_dev, n_birth, birth_dev, dp, dt, q);
 }
 
 static int stage_points(dspmap* m, int n, int stride, const float* pts) {
@@ -767,6 +799,8 @@ extern "C" int dspmap_update(dspmap_t* m, int n, int stride, const float* pts, f
     const int np = n > 0 ? n : 0;
     int rc = stage_points(m, np, stride, pts);
     if (rc != DSPMAP_OK) return rc;
+    if (m->use_vel_est == 2 && !m->cfg.static_model && !m->h_birth_valid && np <= m->ve.cap)
+        return device_frame(m, np, m->pts_dev, 0, nullptr, dp, dt, q);   // velocity estimator on the device: no host stage in the frame
     return frame_with_host_stages(m, np, m->pts_dev, q, dp, dt, nullptr);
 }
 

@@ -60,11 +60,12 @@ struct BirthView {
 __device__ __forceinline__ BirthView birth_view(const DevState& s) {
     BirthView v;
     const FrameParams* fp = s.fpar;
-    const bool synth = fp->static_birth != 0;
-    v.live = synth && s.fs->view_epoch == fp->epoch;
+    const int mode = fp->static_birth;
+    v.live = mode == 1 && s.fs->view_epoch == fp->epoch;
     v.stored = fp->birth; v.rot = s.pt_rot; v.pyr = s.pt_pyr;
     v.cx = fp->cur_pos[0]; v.cy = fp->cur_pos[1]; v.cz = fp->cur_pos[2];
-    v.n = synth ? (v.live ? fp->n_pts : s.fs->stale_n) : fp->n_birth;
+    // mode 2: the device velocity estimator wrote the cloud (and its length) -- or left the previous one (empty view)
+    v.n = mode == 1 ? (v.live ? fp->n_pts : s.fs->stale_n) : (mode == 2 ? s.fs->est_n : fp->n_birth);
     return v;
 }
 __device__ __forceinline__ BirthSrc birth_at(const BirthView& v, int i) {

@@ -25,7 +25,8 @@ struct dspmap {
     // parameters
     float p_stddev = 0.2f, v_stddev = 0.1f;  // :154-155
     float voxel_filter_res = 0.15f;          // :132
-    bool use_vel_est = false;
+    int use_vel_est = 0;             // DSPMAP_P_VELOCITY_ESTIMATOR: 0 off, 1 host stage (velocity_estimator.cpp), 2 device (dspmap_velest.hip)
+    VelEst ve = {};
     bool regen_tables = false;
     bool nb_frozen = false;                  // function statics of the birth stage (:808-811)
     // tables (host copies kept until upload)

@@ -38,6 +38,7 @@ struct LaunchCtx {
     KernelScratch k;
     hipStream_t stream;
     int pt_cap, birth_cap;
+    VelEst ve;
 };
 
 // frame setup: rotate boundary planes (:226-232), reset per-frame counters/bins (:235-238)
@@ -55,6 +56,8 @@ void launch_calib(const LaunchCtx& c, int mode, size_t n);
 // multi-GPU: compact particles that left the slab / insert particles received from a neighbour
 void launch_export_slab(const LaunchCtx& c, int dir, float* rec_out, int cap, int* count_dev, float* rec_out_down = nullptr);   // dir 0: both (up -> rec_out / count[0], down -> rec_out_down / count[1])
 void launch_import_movers(const LaunchCtx& c, int n, const float* rec);  // folds the per-block partial counters into FrameScalars
+// velocityEstimationThread (:1377-1544) on the device: view -> birth cloud in DevState::birth, FrameScalars::est_n
+void launch_velocity_estimator(const LaunchCtx& c, int n_pts_grid);
 // mapUpdate (:704-793)
 void launch_ck_partial(const LaunchCtx& c);
 void launch_ck_finalize(const LaunchCtx& c);

@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256) k_obs_points(MapDims d, DevState s) {
         s.pt_rot[i] = make_float4(r[0], r[1], r[2], len);
         s.pt_pyr[i] = pyr;
         // the view is not empty: this frame's synthesised birth cloud is the live one (dspmap_birth.h, BirthView)
-        if (make_static_birth && pyr >= 0) s.fs->view_epoch = s.fpar->epoch;
+        if (make_static_birth == 1 && pyr >= 0) s.fs->view_epoch = s.fpar->epoch;
     }
 }
 

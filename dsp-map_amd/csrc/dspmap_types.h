@@ -90,6 +90,7 @@ struct FrameScalars {
     // synthesised birth cloud (FrameParams::static_birth): frame epoch in which the view held at least one point, and
     // the length of the last non-empty view's cloud kept in DevState::birth (an empty view re-uses it, :1379-1381)
     int view_epoch, stale_n;
+    int est_n;          // length of the birth cloud the device velocity estimator wrote (kept when a view is empty, :1379)
 };
 
 // Per-frame inputs, written by ONE small H2D copy per frame and read by the kernels from HBM, so that
@@ -101,7 +102,9 @@ struct FrameParams {
     float dt;
     int n_pts;          // points in `pts`
     int n_birth;        // entries in `birth`
-    int static_birth;   // 1: the birth cloud is synthesised from the frame's view (every in-FOV point a zero-velocity source)
+    int static_birth;   // birth cloud: 0 = the caller's / host estimator's (birth, n_birth); 1 = synthesised from the frame's view
+                        // (every in-FOV point a zero-velocity source); 2 = written by the device velocity estimator
+    float res_filter;   // voxel_filtered_resolution :132 (ground split and cluster tolerance of the velocity estimator)
     int epoch;          // frame counter (bumped whenever a cloud is binned); FrameScalars::view_epoch refers to it
     int clear_fut;      // 1: k_predict zeroes the future accumulators first (a clearOccupancyMapPrediction is pending)
     const float* pts;   // n_pts x 3, sensor frame
@@ -156,6 +159,28 @@ struct DevState {
     float* p_tab; float* v_tab; int* r_tab;
     FrameScalars* fs;
     FrameParams* fpar;
+};
+
+// device velocity estimator (dspmap_velest.hip): one cluster = the reference's ClusterFeature :98-109 + bookkeeping
+struct VeCluster {
+    float cx, cy, cz;
+    int point_num;
+    float vx, vy, vz, intensity;
+    int root, start, is_dyn, dyn_idx;
+};
+struct VelEst {
+    float4* w;        // [cap] world position of the view points, in view (= input) order
+    int* parent;      // [cap] union-find over the view points (-1: ground point)
+    int* ng_list;     // [cap] view indices of the non-ground points
+    int* root;        // [cap]
+    int* size;        // [cap]
+    int* rank;        // [cap/5+2]
+    int* by_rank;     // [cap/5+2]
+    int* dyn_list;    // [cap/5+2]
+    VeCluster* cl;    // [cap/5+2]
+    float* last;      // [(cap/5+2) * 5] clusters_feature_vector_dynamic_last :1401: cx, cy, cz, point_num (int bits), intensity
+    int* n;           // [4] view points, non-ground points, kept clusters of the last frame
+    int cap;          // view points the estimator handles (<= 8192: one workgroup orders them in LDS)
 };
 
 struct BirthSrc {   // == dspmap_vpoint
