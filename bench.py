@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default=None)
     ap.add_argument("--prefill", type=int, default=60, help="untimed frames before warmup (steady state)")
+    ap.add_argument("--estimator", type=int, default=2, help="velocity estimator of the realistic workloads: 0 static tags, 1 host stage, 2 device (default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the saturated extra measurements")
     args = ap.parse_args()
@@ -130,12 +131,14 @@ def main():
             assert rc == 1, rc
             m.clearOccupancyMapPrediction()  # the reference requires this once per frame (:429-438)
 
-    def measure(w, steps, warmup, prefill, profile=True, solo=False, estimator=False):
-        """solo: this rank measures alone (no collective barrier): the single-GPU origin of an N > 1 run"""
+    def measure(w, steps, warmup, prefill, profile=True, solo=False, estimator=0):
+        """solo: this rank measures alone (no collective barrier): the single-GPU origin of an N > 1 run
+        estimator: DSPMAP_P_VELOCITY_ESTIMATOR (0 = every point in view is a static birth source, 1 = host stage,
+        2 = on the device, inside the captured frame)"""
         barrier = (lambda: torch.cuda.synchronize()) if solo else globals_barrier
         m = make_map(w)
         if estimator:
-            m.useVelocityEstimator(True)
+            m.set_param(D.capi.P_VELOCITY_ESTIMATOR, estimator)
         n_total = prefill + warmup + steps + (steps if profile else 0)
         frames = gen_frames(w, n_total, seed=1234 + rank)
         if w["sat"]:
@@ -197,7 +200,7 @@ def main():
 
     # ------------------------------------------------------------------ main measurement
     if not sharded_run:
-        m, frames, dt, cnt, stage = measure(wl, args.steps, args.warmup, args.prefill)
+        m, frames, dt, cnt, stage = measure(wl, args.steps, args.warmup, args.prefill, estimator=args.estimator if not wl["sat"] else 0)
     else:
         m, frames, dt, cnt, stage = measure_sharded(wl, args.steps, args.warmup, 5 if wl["sat"] else args.prefill)
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -240,7 +243,9 @@ def main():
                                "(corridor scene, <=5000 points/frame after 0.1 m voxel filter), %s" %
                                (wl_name, wl["nx"], wl["ny"], wl["nz"], wl["res"], wl["ppv"],
                                 "saturated fill" if wl["sat"] else "steady state after %d frames" % args.prefill),
-                   "birth_tags": "static (every in-FOV point is a zero-velocity birth source)",
+                   "birth_tags": ("static (every in-FOV point is a zero-velocity birth source)" if wl["sat"] or args.estimator == 0 else
+                                  "velocityEstimationThread (:1377-1544) %s" % ("on the device, inside the captured frame (dspmap_velest.hip)"
+                                                                               if args.estimator == 2 else "as a host stage (velocity_estimator.cpp)")),
                    "parallelism": "1 GPU" if not sharded_run else "%d Z-slabs (one per GPU), RCCL neighbour exchange + "
                                                                 "2 small all-reduces per frame" % world,
                    "n_points": int(frames[-1][0].shape[0])},
@@ -304,20 +309,23 @@ def main():
         except Exception as e:
             result["rollout_D_132x132x60_T10"] = {"error": repr(e)}
 
-    # ------------------------------------------------------------------ the metric's workload with the velocity estimator in the loop
+    # ------------------------------------------------------------------ the metric's workload with the other birth-tag sources
     if rank == 0 and not sharded_run and not args.no_extra and wl_name == "B":
         try:
-            mv, frv, dtv, cv, _ = measure(wl, 150, 15, args.prefill, profile=False, estimator=True)
-            result["with_velocity_estimator"] = {
-                "what": "workload B with DSPMAP_P_VELOCITY_ESTIMATOR = 1: the reference's velocityEstimationThread (:297,311, "
-                        "1377-1544) as the host stage of velocity_estimator.cpp; with device-resident clouds it costs one "
-                        "D2H + H2D round trip per frame (the headline value tags every birth source static instead)",
-                "frames_per_s": round(150 / dtv, 2), "ms_per_step": round(dtv / 150 * 1e3, 4),
-                "n_born": cv["n_born"], "n_live_in": cv["n_live_in"]}
-            mv.close()
-            del frv
+            var = {}
+            for tag, est in (("static_tags", 0), ("host_estimator", 1)):
+                mv, frv, dtv, cv, _ = measure(wl, 150, 15, args.prefill, profile=False, estimator=est)
+                var[tag] = {"frames_per_s": round(150 / dtv, 2), "ms_per_step": round(dtv / 150 * 1e3, 4),
+                            "n_born": cv["n_born"], "n_live_in": cv["n_live_in"]}
+                mv.close()
+                del frv
+            result["birth_tag_variants"] = {
+                "what": "workload B with the two other sources of the birth tags: static_tags = every point in view is a "
+                        "zero-velocity source (round 1's headline); host_estimator = the reference's helper thread (:297,311) as "
+                        "the host stage of velocity_estimator.cpp (one D2H + H2D round trip of the cloud per frame).  The "
+                        "headline value runs the estimator on the device (dspmap_velest.hip).", **var}
         except Exception as e:
-            result["with_velocity_estimator"] = {"error": repr(e)}
+            result["birth_tag_variants"] = {"error": repr(e)}
 
     # ------------------------------------------------------------------ next row: the caller's pre-processing on the device
     if rank == 0 and not sharded_run and not args.no_extra and wl_name == "B":

@@ -34,7 +34,7 @@ def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
-    cmd = [hipcc] + FLAGS + ["-x", "hip"] + srcs + ["-o", LIB]
+    cmd = [hipcc] + FLAGS + os.environ.get("DSPMAP_EXTRA_FLAGS", "").split() + ["-x", "hip"] + srcs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

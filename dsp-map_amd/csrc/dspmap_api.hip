@@ -156,7 +156,7 @@ static void free_dev(dspmap* m) {
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
     if (m->nbsnap_buf) chk(hipFree(m->nbsnap_buf), "hipFree");
     {
-        void* vp[] = {m->ve.w, m->ve.parent, m->ve.ng_list, m->ve.root, m->ve.size, m->ve.rank, m->ve.by_rank, m->ve.dyn_list, m->ve.cl, m->ve.last, m->ve.n};
+        void* vp[] = {m->ve.ng_view, m->ve.edges, m->ve.ecnt, m->ve.w, m->ve.root, m->ve.rank, m->ve.by_rank, m->ve.dyn_list, m->ve.cl, m->ve.last, m->ve.n};
         for (void* q : vp) if (q) chk(hipFree(q), "hipFree");
     }
     if (m->pp_box) chk(hipFree(m->pp_box), "hipFree");
@@ -357,11 +357,12 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     }
     {   // device velocity estimator (dspmap_velest.hip)
         VelEst& ve = m->ve;
-        ve.cap = 8192;
+        ve.cap = velocity_estimator_capacity();
         const size_t nc = (size_t)ve.cap / 5 + 8;
-        HIPCHK(m, dalloc(&ve.w, (size_t)ve.cap)); HIPCHK(m, dalloc(&ve.parent, (size_t)ve.cap));
-        HIPCHK(m, dalloc(&ve.ng_list, (size_t)ve.cap)); HIPCHK(m, dalloc(&ve.root, (size_t)ve.cap));
-        HIPCHK(m, dalloc(&ve.size, (size_t)ve.cap)); HIPCHK(m, dalloc(&ve.rank, nc)); HIPCHK(m, dalloc(&ve.by_rank, nc));
+        HIPCHK(m, dalloc(&ve.w, (size_t)ve.cap)); HIPCHK(m, dalloc(&ve.root, (size_t)ve.cap));
+        HIPCHK(m, dalloc(&ve.ng_view, (size_t)ve.cap));
+        HIPCHK(m, dalloc(&ve.edges, (size_t)ve.cap * velocity_estimator_slices())); HIPCHK(m, dalloc(&ve.ecnt, (size_t)velocity_estimator_slices()));
+        HIPCHK(m, dalloc(&ve.rank, nc)); HIPCHK(m, dalloc(&ve.by_rank, nc));
         HIPCHK(m, dalloc(&ve.dyn_list, nc)); HIPCHK(m, dalloc(&ve.cl, nc)); HIPCHK(m, dalloc(&ve.last, nc * 5));
         HIPCHK(m, dalloc(&ve.n, (size_t)4));
         HIPCHK(m, hipMemset(ve.n, 0, sizeof(int) * 4));
@@ -583,9 +584,6 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     dspmap_prof_mark(m, 0);
     if (!fork) {
         launch_setup_and_bin(c, pts_grid, false);   // the gather rides on k_predict's launch
-        // the velocity estimator needs the binned view only; its output is the frame's birth cloud, which the birth rank
-        // (a rider of k_predict's launch) reads
-        if (est) launch_velocity_estimator(c, pts_grid);
     } else {
         launch_frame_setup(c, true);
         (void)hipEventRecord(m->ev_fork, m->stream);
@@ -596,6 +594,34 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
         (void)hipEventRecord(m->ev_join, m->stream2);
     }
     dspmap_prof_mark(m, 1);
+    if (est && birth_grid > 0) {
+        // The velocity estimator runs BESIDE prediction and weight update, like the reference's helper thread (:297,311):
+        // a second branch of the frame (side stream; a forked branch of the captured graph) takes the binned view through
+        // k_ve_components -> k_ve_clusters (+ the birth rank) -> the newborn children, and joins before the birth stage.
+        (void)hipEventRecord(m->ev_fork, m->stream);
+        (void)hipStreamWaitEvent(m->stream2, m->ev_fork, 0);
+        LaunchCtx c2 = c;
+        c2.stream = m->stream2;
+        launch_velocity_estimator(c2, true);
+        launch_birth_early(c2, birth_grid, false);   // children (the rank ran inside k_ve_clusters)
+        (void)hipEventRecord(m->ev_join, m->stream2);
+        launch_predict_only(c, true, false);
+        dspmap_prof_mark(m, 2);
+        launch_claim(c, 0);
+        dspmap_prof_mark(m, 3);
+        launch_ck_partial(c);
+        dspmap_prof_mark(m, 4);
+        launch_weight_update(c);
+        dspmap_prof_mark(m, 5);
+        (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
+        dspmap_prof_mark(m, 6);
+        launch_birth_late(c, birth_grid, false);
+        dspmap_prof_mark(m, 7);
+        launch_resample(c);
+        dspmap_prof_mark(m, 8);
+        if (m->prof) m->prof_pending = true;
+        return;
+    }
     // births: the rank and the children need nothing but the frame's birth cloud -- they ride on the launches of
     // k_predict and k_place and leave the frame's critical path; split, cursors and insert follow the weight update
     const bool early_birth = !fork && birth_grid > 0;
@@ -1346,3 +1372,8 @@ extern "C" int dspmap_load_checkpoint(dspmap_t* m, const char* path) {
     return dspmap_set_cursors(m, h.cursors[0] % (m->fp.tab_n > 0 ? m->fp.tab_n : 1), h.cursors[1] % (m->fp.tab_n > 0 ? m->fp.tab_n : 1),
                               h.cursors[2] % (m->fp.rtab_n > 0 ? m->fp.rtab_n : 1));
 }
+
+#ifdef VE_DEBUG
+extern "C" int dspmap_debug_ve(const VelEst* ve, long long* out);
+extern "C" int dspmap_debug_ve_get(dspmap_t* m, long long* out) { hipDeviceSynchronize(); return dspmap_debug_ve(&m->ve, out); }
+#endif

@@ -57,7 +57,9 @@ void launch_calib(const LaunchCtx& c, int mode, size_t n);
 void launch_export_slab(const LaunchCtx& c, int dir, float* rec_out, int cap, int* count_dev, float* rec_out_down = nullptr);   // dir 0: both (up -> rec_out / count[0], down -> rec_out_down / count[1])
 void launch_import_movers(const LaunchCtx& c, int n, const float* rec);  // folds the per-block partial counters into FrameScalars
 // velocityEstimationThread (:1377-1544) on the device: view -> birth cloud in DevState::birth, FrameScalars::est_n
-void launch_velocity_estimator(const LaunchCtx& c, int n_pts_grid);
+void launch_velocity_estimator(const LaunchCtx& c, bool with_rank);   // with_rank: + the birth stage's rank in the same workgroup
+int velocity_estimator_capacity();   // points per frame the device estimator handles
+int velocity_estimator_slices();
 // mapUpdate (:704-793)
 void launch_ck_partial(const LaunchCtx& c);
 void launch_ck_finalize(const LaunchCtx& c);

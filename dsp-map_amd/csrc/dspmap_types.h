@@ -170,17 +170,17 @@ struct VeCluster {
 };
 struct VelEst {
     float4* w;        // [cap] world position of the view points, in view (= input) order
-    int* parent;      // [cap] union-find over the view points (-1: ground point)
-    int* ng_list;     // [cap] view indices of the non-ground points
-    int* root;        // [cap]
-    int* size;        // [cap]
-    int* rank;        // [cap/5+2]
-    int* by_rank;     // [cap/5+2]
-    int* dyn_list;    // [cap/5+2]
-    VeCluster* cl;    // [cap/5+2]
-    float* last;      // [(cap/5+2) * 5] clusters_feature_vector_dynamic_last :1401: cx, cy, cz, point_num (int bits), intensity
+    int* root;        // [cap] view index of the first point of the point's connected component (-1: ground point)
+    int* ng_view;     // [cap] view index of the non-ground points
+    unsigned* edges;  // [slices][cap] spanning-forest edges (g << 16 | root) of every slice of k_ve_components
+    int* ecnt;        // [slices]
+    int* rank;        // [cap/5+8]
+    int* by_rank;     // [cap/5+8]
+    int* dyn_list;    // [cap/5+8]
+    VeCluster* cl;    // [cap/5+8]
+    float* last;      // [(cap/5+8) * 5] clusters_feature_vector_dynamic_last :1401: cx, cy, cz, point_num (int bits), intensity
     int* n;           // [4] view points, non-ground points, kept clusters of the last frame
-    int cap;          // view points the estimator handles (<= 8192: one workgroup orders them in LDS)
+    int cap;          // view points the estimator handles (one workgroup holds them in LDS)
 };
 
 struct BirthSrc {   // == dspmap_vpoint

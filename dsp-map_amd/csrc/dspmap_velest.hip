@@ -11,23 +11,33 @@
 // saebyn/munkres-cpp; versions unpinned by the reference) are replaced by what they COMPUTE, not by how:
 //   * PCL grows a cluster by radius search and returns its indices SORTED ascending; clusters come back sorted by size.
 //     The cluster is therefore the connected component of the "closer than the tolerance" graph and the growth order
-//     leaves no trace.  Here: every pair of non-ground points is tested once (tiles of 256 x 256, the squared distance
-//     in the reference's fp32 arithmetic), close pairs are united in a lock-free union-find whose root is the component's
-//     SMALLEST index (atomicMin hooking), so the result does not depend on the order the pairs are visited in.
+//     leaves no trace.  Here: the non-ground points are hashed into a grid of tolerance-sized cells, every point looks
+//     at the 27 cells around it, close pairs (the squared distance in the reference's fp32 arithmetic) are united in a
+//     lock-free union-find whose root is the component's SMALLEST index (atomicMin hooking): the result does not depend
+//     on the order the pairs are visited in.
 //   * the assignment is the minimum-cost one; the O(n^3) Hungarian algorithm runs in one wavefront with the columns on
 //     the lanes, in double precision and with first-minimum tie breaking = the sequential algorithm, step for step.
 // Everything a cluster sums (centroids) is summed sequentially in ascending point index, the reference's order.
 //
-// Three kernels (launched by launch_velocity_estimator):
-//   k_ve_view     one workgroup: compacts the view in input order, world coordinates, ground split, union-find init
-//   k_ve_pairs    tiles: pair tests + unions
-//   k_ve_clusters one workgroup: components -> clusters -> order -> centroids -> matching -> tags -> birth cloud
+// The cloud is a few thousand points: the whole job is two one-workgroup kernels that live in LDS (positions, hash grid,
+// union-find: ~10^5 dependent steps that cost an LDS access each instead of an L2 round trip):
+//   k_ve_components  view in input order -> world frame -> ground split -> hash grid -> unions -> root of every point
+//   k_ve_clusters    components -> clusters -> PCL's order (stable radix sort) -> centroids -> matching -> tags -> birth cloud
 #include <hip/hip_runtime.h>
 #include "dspmap_device.h"
 #include "dspmap_kernels.h"
+#include "dspmap_birth.h"
 
 #define VE_NT 1024
-#define VE_TILE 256
+#ifdef VE_DEBUG
+#define VE_MARK(k) do { if (threadIdx.x == 0) ((long long*)&ve.cl[VE_CAP / 5 + 2])[k] = (long long)wall_clock64(); } while (0)
+#else
+#define VE_MARK(k) do {} while (0)
+#endif
+#define VE_CAP 6144                 // view points the estimator handles (host: larger clouds go to the host stage)
+#define VE_HB 4096                  // hash buckets
+#define VE_NIL 0xffffu
+#define VE_HMAX (VE_CAP / 5 + 8)    // clusters have >= 5 points
 
 // exclusive prefix sum over a 1024-thread workgroup; s_tmp: 17 ints
 __device__ __forceinline__ int ve_excl_scan(int v, int* s_tmp, int* total) {
@@ -48,91 +58,137 @@ __device__ __forceinline__ int ve_excl_scan(int v, int* s_tmp, int* total) {
     return r;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// k_ve_view: cloud_in_current_view_rotated (:244-257) in input order -> world frame (:1389-1391), ground split (:1393)
-// ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(VE_NT) k_ve_view(DevState s, VelEst ve) {
-    __shared__ int s_tmp[17];
-    const int n_pts = min(s.fpar->n_pts, ve.cap);
-    const float cx = s.fpar->cur_pos[0], cy = s.fpar->cur_pos[1], cz = s.fpar->cur_pos[2];
-    const float res_f = s.fpar->res_filter;
-    const int tid = threadIdx.x;
-    int base_v = 0, base_g = 0;
-    for (int b0 = 0; b0 < n_pts; b0 += VE_NT) {
-        const int i = b0 + tid;
-        const bool in = i < n_pts && s.pt_pyr[i] >= 0;
-        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-        bool ng = false;
-        if (in) {
-            const float4 r = s.pt_rot[i];
-            w.x = r.x + cx; w.y = r.y + cy; w.z = r.z + cz;   // :1389-1391
-            ng = w.z > res_f;                                  // :1393
-        }
-        int tot_v, tot_g;
-        const int pv = base_v + ve_excl_scan(in ? 1 : 0, s_tmp, &tot_v);
-        const int pg = base_g + ve_excl_scan(in && ng ? 1 : 0, s_tmp, &tot_g);
-        if (in) {
-            ve.w[pv] = w;
-            ve.parent[pv] = ng ? pv : -1;     // ground points take no part in the clustering
-            if (ng) ve.ng_list[pg] = pv;
-        }
-        base_v += tot_v; base_g += tot_g;
+// ---- union-find in LDS.  Parents only ever DECREASE (every write is an atomicMin) and always point at a member of the
+// same component, so concurrent finds, path halving and hooking cannot separate what was united.
+__device__ __forceinline__ int ve_find(int* parent, int x) {
+    int p = parent[x];
+    while (p != x) {
+        const int g = parent[p];
+        if (g != p) atomicMin(&parent[x], g);   // path halving
+        x = p; p = g;
     }
-    if (tid == 0) { ve.n[0] = base_v; ve.n[1] = base_g; }
+    return x;
+}
+__device__ __forceinline__ int ve_union(int* parent, int a, int b) {
+    while (true) {
+        a = ve_find(parent, a); b = ve_find(parent, b);
+        if (a == b) return a;
+        const int hi = a > b ? a : b, lo = a > b ? b : a;
+        const int old = atomicMin(&parent[hi], lo);   // hook the larger root under the smaller one
+        if (old == hi) return lo;                     // hi was still a root: done
+        a = old; b = lo;                              // re-parented meanwhile: unite its new parent with lo
+    }
+}
+__device__ __forceinline__ unsigned ve_hash(int cx, int cy, int cz) {
+    return ((unsigned)cx * 73856093u ^ (unsigned)cy * 19349663u ^ (unsigned)cz * 83492791u) & (VE_HB - 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_ve_pairs: every pair of non-ground points once; pairs within the cluster tolerance 2 * voxel_filtered_resolution
-// (:1411) are united.  Root = smallest index of the component.
+// k_ve_components: cloud_in_current_view_rotated (:244-257) in input order -> world frame (:1389-1391), ground split
+// (:1393), and the close pairs of the non-ground points under the cluster tolerance (:1411).
+// VE_NB workgroups.  Every workgroup builds the same picture in its LDS (the cloud is small: compacting it and hashing it
+// costs less than handing it over through memory), then looks for the close pairs of ITS contiguous slice of the
+// non-ground points, unites them in a local union-find and emits the resulting spanning forest (a few hundred edges
+// instead of ~30 close pairs per point); k_ve_clusters merges the forests.  One workgroup alone walks ~10^5 dependent
+// LDS steps (144 us measured); the slices cut that chain by VE_NB.
+// Output: ve.w[v] world position of view point v, ve.root[v] = -1 for ground points, ve.ng_view[g] = view index of
+//         non-ground point g, ve.n[0] = view points, ve.n[1] = non-ground points, ve.edges / ve.ecnt per workgroup.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int ve_find(int* __restrict__ parent, int x) {
-    int p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (p != x) { x = p; p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    return x;
-}
-__device__ __forceinline__ void ve_union(int* __restrict__ parent, int a, int b) {
-    while (true) {
-        a = ve_find(parent, a); b = ve_find(parent, b);
-        if (a == b) return;
-        const int hi = a > b ? a : b, lo = a > b ? b : a;
-        const int old = atomicMin(&parent[hi], lo);   // hook the larger root under the smaller one
-        if (old == hi) return;                        // hi was still a root: done
-        a = old; b = lo;                              // somebody re-parented hi meanwhile: unite its new parent with lo
-    }
-}
-__global__ void __launch_bounds__(VE_TILE) k_ve_pairs(DevState s, VelEst ve, int ntile_cap) {
-    __shared__ float4 s_p[VE_TILE];
-    __shared__ int s_id[VE_TILE];
-    const int n_ng = ve.n[1];
-    const int nt = (n_ng + VE_TILE - 1) / VE_TILE;
-    // block -> (bi <= bj) over the upper triangle of the capacity-sized tile grid
-    int bi = 0, rem = (int)blockIdx.x;
-    while (rem >= ntile_cap - bi) { rem -= ntile_cap - bi; ++bi; }
-    const int bj = bi + rem;
-    if (bi >= nt || bj >= nt) return;
-    const float tol = 2 * s.fpar->res_filter, tol2 = tol * tol;   // :1411
+#define VE_NB 32
+#define VE_IPT ((VE_CAP + VE_NT - 1) / VE_NT)   // consecutive input points per thread
+__global__ void __launch_bounds__(VE_NT) k_ve_components(DevState s, VelEst ve) {
+    __shared__ float sx[VE_CAP], sy[VE_CAP], sz[VE_CAP];   // non-ground points, by non-ground rank g
+    __shared__ int s_parent[VE_CAP];
+    __shared__ unsigned short s_next[VE_CAP];
+    __shared__ int s_head[VE_HB];
+    __shared__ int s_tmp[17];
+    __shared__ int s_ne;
+    const int n_pts = min(s.fpar->n_pts, VE_CAP);
+    const float cx = s.fpar->cur_pos[0], cy = s.fpar->cur_pos[1], cz = s.fpar->cur_pos[2];
+    const float res_f = s.fpar->res_filter;
+    const float tol = 2 * res_f, tol2 = tol * tol;   // :1411
     const int tid = threadIdx.x;
-    const int jj = bj * VE_TILE + tid;
-    if (jj < n_ng) { const int id = ve.ng_list[jj]; s_id[tid] = id; s_p[tid] = ve.w[id]; }
-    __syncthreads();
-    const int ii = bi * VE_TILE + tid;
-    if (ii >= n_ng) return;
-    const int me = ve.ng_list[ii];
-    const float4 p = ve.w[me];
-    const int nj = min(VE_TILE, n_ng - bj * VE_TILE);
-    for (int j = (bi == bj ? tid + 1 : 0); j < nj; ++j) {
-        const float4 q = s_p[j];
-        const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
-        const float d2 = dx * dx + dy * dy + dz * dz;
-        if (d2 <= tol2) ve_union(ve.parent, me, s_id[j]);
+    const bool first = blockIdx.x == 0;
+    for (int h = tid; h < VE_HB; h += VE_NT) s_head[h] = -1;
+    if (tid == 0) s_ne = 0;
+    // ---- the view in input order: thread t owns the input points [t * VE_IPT, (t + 1) * VE_IPT); one scan ranks both the
+    //      view points (low half of the packed count) and the non-ground ones (high half)
+    float wx[VE_IPT], wy[VE_IPT], wz[VE_IPT];
+    int flag[VE_IPT];   // 0 not in view, 1 ground, 2 non-ground
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < VE_IPT; ++k) {
+        const int i = tid * VE_IPT + k;
+        flag[k] = 0; wx[k] = wy[k] = wz[k] = 0.f;
+        if (i < n_pts && s.pt_pyr[i] >= 0) {
+            const float4 r = s.pt_rot[i];
+            wx[k] = r.x + cx; wy[k] = r.y + cy; wz[k] = r.z + cz;   // :1389-1391
+            flag[k] = wz[k] > res_f ? 2 : 1;                          // :1393
+            cnt += flag[k] == 2 ? 0x10001 : 1;
+        }
     }
+    int tot;
+    int off = ve_excl_scan(cnt, s_tmp, &tot);
+    const int n_view = tot & 0xffff, n_ng = tot >> 16;
+    {
+        int pv = off & 0xffff, pg = off >> 16;
+#pragma unroll
+        for (int k = 0; k < VE_IPT; ++k) {
+            if (flag[k]) {
+                if (first) ve.w[pv] = make_float4(wx[k], wy[k], wz[k], 0.f);
+                if (flag[k] == 2) {
+                    sx[pg] = wx[k]; sy[pg] = wy[k]; sz[pg] = wz[k]; s_parent[pg] = pg;
+                    if (first) ve.ng_view[pg] = pv;
+                    ++pg;
+                } else if (first) ve.root[pv] = -1;     // ground points take no part in the clustering
+                ++pv;
+            }
+        }
+    }
+    if (first && tid == 0) { ve.n[0] = n_view; ve.n[1] = n_ng; }
+    __syncthreads();
+    // ---- hash grid of tolerance-sized cells: bucket chains through s_next
+    for (int g = tid; g < n_ng; g += VE_NT) {
+        const int kx = (int)floorf(__fdiv_rn(sx[g], tol)), ky = (int)floorf(__fdiv_rn(sy[g], tol)), kz = (int)floorf(__fdiv_rn(sz[g], tol));
+        const int prev = atomicExch(&s_head[ve_hash(kx, ky, kz)], g);
+        s_next[g] = (unsigned short)(prev < 0 ? VE_NIL : prev);
+    }
+    __syncthreads();
+    // ---- this workgroup's slice; work item = (point of the slice, one of the 27 cells around it): every pair (j < g)
+    //      that may be closer than the tolerance sits in those cells
+    const int per = (n_ng + VE_NB - 1) / VE_NB;
+    const int g_lo = (int)blockIdx.x * per, g_hi = min(n_ng, g_lo + per);
+    for (int it = tid; it < (g_hi - g_lo) * 27; it += VE_NT) {
+        const int g = g_lo + it / 27, c = it % 27;
+        const float px = sx[g], py = sy[g], pz = sz[g];
+        const int kx = (int)floorf(__fdiv_rn(px, tol)) + c % 3 - 1, ky = (int)floorf(__fdiv_rn(py, tol)) + (c / 3) % 3 - 1,
+                  kz = (int)floorf(__fdiv_rn(pz, tol)) + c / 9 - 1;
+        // (two of the 27 cells may share a bucket: its chain is then walked twice and a pair united twice, which changes
+        // nothing; a chain also holds the points of unrelated cells: the distance decides)
+        for (int j = s_head[ve_hash(kx, ky, kz)]; j >= 0; j = (s_next[j] == VE_NIL ? -1 : (int)s_next[j])) {
+            if (j >= g) continue;
+            const float ex = sx[j] - px, ey = sy[j] - py, ez = sz[j] - pz;
+            const float d2 = ex * ex + ey * ey + ez * ez;
+            if (d2 <= tol2) {
+                const int rg = ve_find(s_parent, g), rj = ve_find(s_parent, j);   // most close pairs already share a root
+                if (rg != rj) ve_union(s_parent, rg, rj);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the slice's spanning forest
+    unsigned* edges = ve.edges + (size_t)blockIdx.x * VE_CAP;
+    for (int g = tid; g < n_ng; g += VE_NT) {
+        const int r = ve_find(s_parent, g);
+        if (r != g) edges[atomicAdd(&s_ne, 1)] = ((unsigned)g << 16) | (unsigned)r;
+    }
+    __syncthreads();
+    if (tid == 0) ve.ecnt[blockIdx.x] = s_ne;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_ve_clusters
 // ---------------------------------------------------------------------------------------------------------------
-#define VE_SORT_MAX 8192     // view points the one-workgroup ordering handles (keys in LDS)
-#define VE_HMAX (VE_SORT_MAX / 5 + 8)   // clusters have >= 5 points
 // generateRandomFloat :1551-1553 fed from the tabulated rand() stream (the birth stage's stream, dspmap_kernels.hip)
 __device__ __forceinline__ float ve_rand_float(const DevState& s, int rtab_n, int c, float lo, float hi) {
     const int r = s.r_tab[c % max(rtab_n, 1)];
@@ -149,50 +205,133 @@ __device__ __forceinline__ float ve_cost(const VeCluster& a, const float* __rest
     return __fdiv_rn(d, 1.5f) * 1000.f;
 }
 
-__global__ void __launch_bounds__(VE_NT) k_ve_clusters(DevState s, VelEst ve, FilterParams fp) {
-    __shared__ unsigned s_key[VE_SORT_MAX];
+// lanes of the wave holding the same 6-bit digit as this lane (all lanes active)
+__device__ __forceinline__ u64 ve_match6(unsigned d) {
+    u64 m = ~0ull;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const u64 bal = __ballot((d >> b) & 1u);
+        m &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    return m;
+}
+
+// one stable pass of the radix sort: keys of `src` ordered by ((key >> shift) & 63), equal digits keep their order.
+// The 16 waves own consecutive ranges; s_cnt: [64 digits][16 waves].
+__device__ __forceinline__ void ve_radix_pass(const unsigned* src, unsigned* dst, int npad, int shift, int* s_cnt, int* s_tmp) {
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int per_wave = npad / 16;   // npad is a multiple of 1024
+    s_cnt[tid] = 0;
+    __syncthreads();
+    for (int it = 0; it < per_wave; it += 64) {
+        const unsigned d = (src[w * per_wave + it + l] >> shift) & 63u;
+        const u64 same = ve_match6(d);
+        if (l == __ffsll((long long)same) - 1) s_cnt[d * 16 + w] += (int)__popcll(same);   // this wave's own counters
+    }
+    __syncthreads();
+    int tot;
+    const int off = ve_excl_scan(s_cnt[tid], s_tmp, &tot);   // digit-major, wave-minor = the stable order
+    s_cnt[tid] = off;
+    __syncthreads();
+    for (int it = 0; it < per_wave; it += 64) {
+        const unsigned key = src[w * per_wave + it + l];
+        const unsigned d = (key >> shift) & 63u;
+        const u64 same = ve_match6(d);
+        const int base = s_cnt[d * 16 + w];
+        dst[base + (int)__popcll(same & lanemask_lt())] = key;
+        if (l == __ffsll((long long)same) - 1) s_cnt[d * 16 + w] = base + (int)__popcll(same);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void ve_clusters_block(const DevState& s, const VelEst& ve, const FilterParams& fp) {
+    __shared__ unsigned s_key[2][VE_CAP];   // sort buffers; while the components are counted: s_key[1] = size at the root
     __shared__ double s_hu[VE_HMAX], s_hv[VE_HMAX], s_minv[VE_HMAX];   // Hungarian: potentials, column minima
     __shared__ int s_hp[VE_HMAX], s_way[VE_HMAX], s_used[VE_HMAX];     // row of a column, predecessor column, column used
+    __shared__ int s_cnt[1024];
     __shared__ int s_tmp[17];
     __shared__ int s_k, s_ndyn;
     __shared__ double s_big;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
     const int n = ve.n[0];
     if (n == 0) return;   // :1379: an empty view leaves the previous output (and the previous clusters) untouched
     const int n_ng = ve.n[1];
     VeCluster* cl = ve.cl;
-    int* root_of = ve.root;      // [cap] root of every view point, -1 = ground / not clustered
-    int* size_of = ve.size;      // [cap] component size at its root
-    // ---- components: flatten, count
-    for (int i = tid; i < n; i += VE_NT) size_of[i] = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += VE_NT) {
-        int r = -1;
-        if (ve.parent[i] >= 0) { r = ve_find(ve.parent, i); atomicAdd(&size_of[r], 1); }
-        root_of[i] = r;
+    VE_MARK(0);
+    // ---- merge the spanning forests of k_ve_components' slices: the union-find over the non-ground points lives in
+    //      s_key[0] for the moment; root of a component = its smallest index
+    {
+        int* parent = (int*)s_key[0];
+        for (int g = tid; g < n_ng; g += VE_NT) parent[g] = g;
+        __syncthreads();
+        // all slices' edge counts in one round trip, then one flat loop over the edges (independent loads)
+        if (tid < VE_NB) s_cnt[tid] = ve.ecnt[tid];
+        __syncthreads();
+        if (tid == 0) { int run = 0; for (int b = 0; b < VE_NB; ++b) { const int c = s_cnt[b]; s_cnt[b] = run; run += c; } s_cnt[VE_NB] = run; }
+        __syncthreads();
+        const int n_edges = s_cnt[VE_NB];
+        for (int f = tid; f < n_edges; f += VE_NT) {
+            int b = 0;
+            while (b + 1 < VE_NB && s_cnt[b + 1] <= f) ++b;
+            const unsigned pr = ve.edges[(size_t)b * VE_CAP + (f - s_cnt[b])];
+            ve_union(parent, (int)(pr >> 16), (int)(pr & 0xffffu));
+        }
+        __syncthreads();
+        for (int g = tid; g < n_ng; g += VE_NT) ve.root[ve.ng_view[g]] = ve.ng_view[ve_find(parent, g)];
+        __threadfence_block();
+        __syncthreads();
     }
+    VE_MARK(1);
+    const int* root_of = ve.root;    // [cap] view index of the component's first point, -1 = ground
+    int* size_of = (int*)s_key[1];   // component size at its root; later -1 - (rank of the cluster)
+    // ---- component sizes (one LDS atomic per distinct root of a wavefront's 64 points)
+    for (int i = tid; i < VE_CAP; i += VE_NT) size_of[i] = 0;
     __syncthreads();
-    // ---- clusters = components of 5 .. 10000 points (:1412-1413), listed in seed (= root index) order
-    int base = 0;
     for (int b0 = 0; b0 < n; b0 += VE_NT) {
         const int i = b0 + tid;
-        const bool is_c = i < n && root_of[i] == i && size_of[i] >= 5 && size_of[i] <= 10000;
-        int tot;
-        const int k = base + ve_excl_scan(is_c ? 1 : 0, s_tmp, &tot);
-        if (is_c) {
-            VeCluster c;
-            c.cx = c.cy = c.cz = 0.f; c.point_num = size_of[i];
-            c.vx = c.vy = c.vz = -10000.f; c.intensity = 0.f;   // :104-108
-            c.root = i; c.start = 0; c.is_dyn = 0; c.dyn_idx = -1;
-            cl[k] = c;
+        const int r = i < n ? root_of[i] : -1;
+        u64 todo = __ballot(r >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int rk = __shfl(r, leader, WAVE);
+            const u64 grp = __ballot(r == rk);
+            if (l == leader) atomicAdd(&size_of[rk], (int)__popcll(grp));
+            todo &= ~grp;
         }
-        base += tot;
     }
-    if (tid == 0) s_k = base;
+    __syncthreads();
+    VE_MARK(2);
+    // ---- clusters = components of 5 .. 10000 points (:1412-1413), listed in seed (= root index) order.
+    //      Thread t owns the points [t * VE_IPT, (t + 1) * VE_IPT): one scan for the whole cloud.
+    {
+        int mine = 0;
+        bool is_c[VE_IPT];
+#pragma unroll
+        for (int q = 0; q < VE_IPT; ++q) {
+            const int i = tid * VE_IPT + q;
+            is_c[q] = i < n && root_of[i] == i && size_of[i] >= 5 && size_of[i] <= 10000;
+            mine += is_c[q] ? 1 : 0;
+        }
+        int tot;
+        int k = ve_excl_scan(mine, s_tmp, &tot);
+#pragma unroll
+        for (int q = 0; q < VE_IPT; ++q) {
+            if (is_c[q]) {
+                const int i = tid * VE_IPT + q;
+                VeCluster c;
+                c.cx = c.cy = c.cz = 0.f; c.point_num = size_of[i];
+                c.vx = c.vy = c.vz = -10000.f; c.intensity = 0.f;   // :104-108
+                c.root = i; c.start = 0; c.is_dyn = 0; c.dyn_idx = -1;
+                cl[k++] = c;
+            }
+        }
+        if (tid == 0) s_k = tot;
+    }
     __syncthreads();
     const int K = s_k;
+    VE_MARK(3);
     // ---- PCL returns the clusters largest first (equal sizes: seed order); rank -> position in that order
-    int* rank_of = ve.rank;      // [cap/5+1] rank of cluster k
+    int* rank_of = ve.rank;      // [cap/5+8] rank of cluster k; later its output base
     int* by_rank = ve.by_rank;   // inverse
     for (int k = tid; k < K; k += VE_NT) {
         const int sz = cl[k].point_num;
@@ -201,33 +340,27 @@ __global__ void __launch_bounds__(VE_NT) k_ve_clusters(DevState s, VelEst ve, Fi
         rank_of[k] = r; by_rank[r] = k;
     }
     __syncthreads();
-    // cluster id of a root: write the rank at the root's slot of size_of (no longer needed as a size)
-    for (int k = tid; k < K; k += VE_NT) size_of[cl[k].root] = -1 - rank_of[k];   // negative = "rank follows"
+    for (int k = tid; k < K; k += VE_NT) size_of[cl[k].root] = -1 - rank_of[k];   // negative = "the cluster's rank follows"
     __syncthreads();
-    // ---- order the clustered points by (cluster rank, point index): one bitonic sort of 32-bit keys in LDS
-    int npad = 1;
-    while (npad < n) npad <<= 1;
+    VE_MARK(4);
+    // ---- order the clustered points by (cluster rank, point index): the keys start in index order, so a STABLE sort by
+    //      the 12-bit rank (two 6-bit passes) is enough; points outside every cluster carry the largest rank and go last
+    int npad = ((n + 1023) >> 10) << 10;
     for (int i = tid; i < npad; i += VE_NT) {
         unsigned key = 0xffffffffu;
         if (i < n) {
             const int r = root_of[i];
             if (r >= 0 && size_of[r] < 0) key = ((unsigned)(-1 - size_of[r]) << 13) | (unsigned)i;
         }
-        s_key[i] = key;
+        s_key[0][i] = key;
     }
     __syncthreads();
-    for (int k2 = 2; k2 <= npad; k2 <<= 1)
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < npad; i += VE_NT) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const unsigned a = s_key[i], b = s_key[p];
-                    const bool up = (i & k2) == 0;
-                    if ((a > b) == up) { s_key[i] = b; s_key[p] = a; }
-                }
-            }
-            __syncthreads();
-        }
+    ve_radix_pass(s_key[0], s_key[1], npad, 13, s_cnt, s_tmp);   // (size_of lived in s_key[1]: consumed above)
+    const bool one_pass = K <= 63;   // ranks below 63 and the "no cluster" digit 63: the low digit orders everything
+    if (!one_pass) ve_radix_pass(s_key[1], s_key[0], npad, 19, s_cnt, s_tmp);
+    const unsigned* sorted = one_pass ? s_key[1] : s_key[0];
+    float* s_cost = (float*)(one_pass ? s_key[0] : s_key[1]);   // the free buffer: the Hungarian's cost matrix
+    VE_MARK(5);
     // starts of the clusters in the sorted order
     {
         int run = 0;
@@ -240,25 +373,41 @@ __global__ void __launch_bounds__(VE_NT) k_ve_clusters(DevState s, VelEst ve, Fi
         }
     }
     __syncthreads();
-    // ---- per cluster (in rank order): intensity draw (:1422, every cluster), centroid (:1424-1434), static test (:1436)
+    VE_MARK(6);
+    // ---- per cluster (in rank order): intensity draw (:1422, every cluster), centroid (:1424-1434), static test (:1436).
+    //      One wavefront per cluster: 64 members are fetched at once, then summed one after another in ascending index
+    //      (the reference's fp32 order) by every lane redundantly.
     const int r_cur = s.fs->r_cur;
-    for (int r = tid; r < K; r += VE_NT) {
+    for (int r = wave; r < K; r += VE_NT / 64) {
         VeCluster c = cl[by_rank[r]];
         c.intensity = ve_rand_float(s, fp.rtab_n, r_cur + r, 0.1f, 1.f);
-        bool stat = c.point_num > 200;      // DYNAMIC_CLUSTER_MAX_POINT_NUM :52 (its centroid is never used)
+        bool stat = c.point_num > 200;      // DYNAMIC_CLUSTER_MAX_POINT_NUM :52 (such a cluster's centroid is never used)
         if (!stat) {
-            float sx = 0.f, sy = 0.f, sz = 0.f;
-            for (int j = 0; j < c.point_num; ++j) {     // ascending point index = PCL's sorted indices
-                const float4 p = ve.w[s_key[c.start + j] & 8191u];
-                sx += p.x; sy += p.y; sz += p.z;
+            float ax = 0.f, ay = 0.f, az = 0.f;
+            float4 p[4];   // <= 200 members: all four chunks are requested before the first sum (one memory round trip)
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                const int j = ch * 64 + l;
+                p[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j < c.point_num) p[ch] = ve.w[sorted[c.start + j] & 8191u];
             }
-            c.cx = __fdiv_rn(sx, (float)c.point_num); c.cy = __fdiv_rn(sy, (float)c.point_num); c.cz = __fdiv_rn(sz, (float)c.point_num);
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                const int m = min(64, c.point_num - ch * 64);
+                for (int q = 0; q < m; ++q) {   // q is wave-uniform: v_readlane, no LDS crossbar
+                    ax += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[ch].x), q));
+                    ay += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[ch].y), q));
+                    az += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[ch].z), q));
+                }
+            }
+            c.cx = __fdiv_rn(ax, (float)c.point_num); c.cy = __fdiv_rn(ay, (float)c.point_num); c.cz = __fdiv_rn(az, (float)c.point_num);
             stat = c.cz > 1.5f;             // DYNAMIC_CLUSTER_MAX_CENTER_HEIGHT :53
         }
         c.is_dyn = stat ? 0 : 1;
-        cl[by_rank[r]] = c;
+        if (l == 0) cl[by_rank[r]] = c;
     }
     __syncthreads();
+    VE_MARK(7);
     // possibly-dynamic clusters in rank order -> dyn_idx
     {
         int run = 0;
@@ -275,6 +424,7 @@ __global__ void __launch_bounds__(VE_NT) k_ve_clusters(DevState s, VelEst ve, Fi
     const int n_dyn = s_ndyn;
     const int n_last = ve.n[2];
     const float dt = s.fpar->dt;
+    VE_MARK(8);
     // ---- Hungarian matching (:1454-1499), one wavefront, columns on the lanes
     if (n_last > 0 && n_dyn > 0 && (double)dt > 0.00001 && (double)dt < 10.0) {
         const int nr = n_dyn, nc = n_last, N = max(nr, nc);   // N <= cap / 5 < VE_HMAX
@@ -288,16 +438,24 @@ __global__ void __launch_bounds__(VE_NT) k_ve_clusters(DevState s, VelEst ve, Fi
                 big = fmax(big, (double)ve_cost(cl[ve.dyn_list[e / nc]], ve.last, e % nc, &g));
             }
             for (int o = 32; o > 0; o >>= 1) big = fmax(big, __shfl_xor(big, o, WAVE));
-            if ((tid & 63) == 0) atomicMax((unsigned long long*)&s_big, (unsigned long long)__double_as_longlong(big));   // non-negative doubles order like integers
+            if (l == 0) atomicMax((unsigned long long*)&s_big, (unsigned long long)__double_as_longlong(big));   // non-negative doubles order like integers
         }
         __syncthreads();
         const double big = s_big;
         for (int j = tid; j <= N; j += VE_NT) { s_hu[j] = 0.0; s_hv[j] = 0.0; s_hp[j] = 0; s_way[j] = 0; }
+        // the usual case (a few dozen clusters): the padded cost matrix is laid out in LDS (s_key[1] is free by now)
+        const bool in_lds = N <= 64;
+        if (in_lds)
+            for (int e = tid; e < N * N; e += VE_NT) {
+                const int i0 = e / N, j = e % N;
+                float a = (float)big;
+                if (i0 < nr && j < nc) { bool g; a = ve_cost(cl[ve.dyn_list[i0]], ve.last, j, &g); }
+                s_cost[e] = a;
+            }
         __syncthreads();
         if (tid < 64) {
             // Kuhn-Munkres with potentials (u, v), rows added one at a time; every column j belongs to lane j % 64 in
             // every loop; LDS operations of one wavefront execute in program order, so no barrier is needed inside
-            const int l = tid;
             for (int i = 1; i <= N; ++i) {
                 if (l == 0) s_hp[0] = i;
                 int j0 = 0;
@@ -313,7 +471,8 @@ __global__ void __launch_bounds__(VE_NT) k_ve_clusters(DevState s, VelEst ve, Fi
                     for (int j = l; j <= N; j += 64) {
                         if (j >= 1 && !s_used[j]) {
                             double a = big;
-                            if (i0 <= nr && j <= nc) { bool g; a = (double)ve_cost(cl[ve.dyn_list[i0 - 1]], ve.last, j - 1, &g); }
+                            if (in_lds) a = (double)s_cost[(i0 - 1) * N + (j - 1)];
+                            else if (i0 <= nr && j <= nc) { bool g; a = (double)ve_cost(cl[ve.dyn_list[i0 - 1]], ve.last, j - 1, &g); }
                             const double cur = a - ui0 - s_hv[j];
                             double mv = s_minv[j];
                             if (cur < mv) { mv = cur; s_minv[j] = cur; s_way[j] = j0; }
@@ -361,6 +520,7 @@ __global__ void __launch_bounds__(VE_NT) k_ve_clusters(DevState s, VelEst ve, Fi
         }
         __syncthreads();
     }
+    VE_MARK(9);
     // ---- the birth cloud: dynamic clusters' points (:1505-1524), then the ground points in view order followed by the
     //      static clusters' points, cluster by cluster (static_points: :1396,1438-1441 -> :1529-1540)
     int n_dyn_pts = 0, n_stat_pts = 0;
@@ -384,9 +544,9 @@ __global__ void __launch_bounds__(VE_NT) k_ve_clusters(DevState s, VelEst ve, Fi
     const int n_ground = n - n_ng;
     BirthSrc* out = s.birth;
     // clustered points, from the sorted order
-    int n_clustered = n_dyn_pts + n_stat_pts;
+    const int n_clustered = n_dyn_pts + n_stat_pts;
     for (int p = tid; p < n_clustered; p += VE_NT) {
-        const unsigned key = s_key[p];
+        const unsigned key = sorted[p];
         const int i = (int)(key & 8191u), r = (int)(key >> 13);
         const int kq = by_rank[r];
         const VeCluster c = cl[kq];
@@ -399,41 +559,62 @@ __global__ void __launch_bounds__(VE_NT) k_ve_clusters(DevState s, VelEst ve, Fi
         else { b.nx = b.ny = b.nz = 0.f; b.intensity = 0.f; pos = n_dyn_pts + n_ground + rank_of[kq] + within; }
         out[pos] = b;
     }
-    // ground points in view order
+    // ground points in view order (thread t owns the points [t * VE_IPT, (t + 1) * VE_IPT))
     {
-        int run = 0;
-        for (int b0 = 0; b0 < n; b0 += VE_NT) {
-            const int i = b0 + tid;
-            const bool g = i < n && ve.parent[i] < 0;
-            int tot;
-            const int pg = run + ve_excl_scan(g ? 1 : 0, s_tmp, &tot);
-            if (g) {
+        int mine = 0;
+#pragma unroll
+        for (int q = 0; q < VE_IPT; ++q) { const int i = tid * VE_IPT + q; mine += (i < n && root_of[i] < 0) ? 1 : 0; }
+        int tot;
+        int pg = ve_excl_scan(mine, s_tmp, &tot);
+#pragma unroll
+        for (int q = 0; q < VE_IPT; ++q) {
+            const int i = tid * VE_IPT + q;
+            if (i < n && root_of[i] < 0) {
                 const float4 w = ve.w[i];
                 BirthSrc b;
                 b.x = w.x; b.y = w.y; b.z = w.z; b.nx = b.ny = b.nz = 0.f; b.intensity = 0.f;
-                out[n_dyn_pts + pg] = b;
+                out[n_dyn_pts + pg++] = b;
             }
-            run += tot;
         }
     }
+    VE_MARK(10);
     // ---- clusters_feature_vector_dynamic_last = clusters_feature_vector_dynamic (:1542); the rand() stream moved on by K
     for (int d0 = tid; d0 < n_dyn; d0 += VE_NT) {
         const VeCluster c = cl[ve.dyn_list[d0]];
         ve.last[d0 * 5] = c.cx; ve.last[d0 * 5 + 1] = c.cy; ve.last[d0 * 5 + 2] = c.cz;
         ve.last[d0 * 5 + 3] = __int_as_float(c.point_num); ve.last[d0 * 5 + 4] = c.intensity;
     }
+    VE_MARK(11);
     if (tid == 0) {
+#ifdef VE_DEBUG
+        ((long long*)&ve.cl[VE_CAP / 5 + 2])[12] = K; ((long long*)&ve.cl[VE_CAP / 5 + 2])[13] = n_dyn; ((long long*)&ve.cl[VE_CAP / 5 + 2])[14] = n_last; ((long long*)&ve.cl[VE_CAP / 5 + 2])[15] = n;
+#endif
         ve.n[2] = n_dyn;
         s.fs->est_n = n_dyn_pts + n_ground + n_stat_pts;
         s.fs->r_cur = (int)(((long long)r_cur + K) % max(fp.rtab_n, 1));
     }
 }
 
-void launch_velocity_estimator(const LaunchCtx& c, int n_pts_grid) {
-    const VelEst& ve = c.ve;
-    hipLaunchKernelGGL(k_ve_view, dim3(1), dim3(VE_NT), 0, c.stream, c.s, ve);
-    const int cap = n_pts_grid < ve.cap ? n_pts_grid : ve.cap;
-    const int nt = (cap + VE_TILE - 1) / VE_TILE;
-    if (nt > 0) hipLaunchKernelGGL(k_ve_pairs, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(VE_TILE), 0, c.stream, c.s, ve, nt);
-    hipLaunchKernelGGL(k_ve_clusters, dim3(1), dim3(VE_NT), 0, c.stream, c.s, ve, c.fp);
+// with_rank: the birth stage's rank (k_birth_rank's workgroup job: it needs nothing but the finished birth cloud) follows in
+// the same workgroup, so that the estimator's branch of the frame hands over a cloud whose table cursors are assigned
+__global__ void __launch_bounds__(VE_NT) k_ve_clusters(MapDims d, DevState s, VelEst ve, FilterParams fp, int with_rank) {
+    ve_clusters_block(s, ve, fp);
+    if (with_rank) {
+        __threadfence();
+        __syncthreads();
+        birth_rank_block(d, s, fp);
+    }
 }
+
+void launch_velocity_estimator(const LaunchCtx& c, bool with_rank) {
+    hipLaunchKernelGGL(k_ve_components, dim3(VE_NB), dim3(VE_NT), 0, c.stream, c.s, c.ve);
+    hipLaunchKernelGGL(k_ve_clusters, dim3(1), dim3(VE_NT), 0, c.stream, c.d, c.s, c.ve, c.fp, with_rank ? 1 : 0);
+}
+int velocity_estimator_capacity() { return VE_CAP; }
+int velocity_estimator_slices() { return VE_NB; }
+
+#ifdef VE_DEBUG
+extern "C" int dspmap_debug_ve(const VelEst* ve, long long* out) {
+    return (int)hipMemcpy(out, &ve->cl[VE_CAP / 5 + 2], 16 * sizeof(long long), hipMemcpyDeviceToHost);
+}
+#endif

@@ -359,3 +359,47 @@ def test_particle_csv_of_update(dsp, orc, tmp_path):
     subprocess.check_call([exe, path, str(out_once), "1", "0.5"])
     assert sorted(os.listdir(out_once)) == ["particles_update_t_3_800.csv"]
     o.close()
+
+
+def test_device_estimator_on_the_depth_stream(dsp, orc):
+    """the benchmark's synthetic depth stream (corridor with ground, walls, boxes and walking pedestrians, ~5000 points
+    per frame) through the device velocity estimator: birth cloud == the oracle's restatement of
+    velocityEstimationThread (:1377-1544), frame after frame -- incl. a frame whose view is empty (the previous output
+    is kept, :1379-1381) -- through the host-buffer call, and the captured device-resident frame ends in the same map"""
+    import torch
+    scene_mod = __import__("dsp-map_amd.scene", fromlist=["CorridorScene"])
+    cfgkw = dict(nx=66, ny=66, nz=40, res=0.15, ppv=24)
+    o, m = make_pair(dsp, orc, seed=5, **cfgkw)
+    md = dsp.DSPMap(dsp.make_config(**cfgkw)); md.set_tables(*common.tables(5))
+    for x in (m, md):
+        x.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, 2)
+    o.L.dspo_use_velocity_estimator(o.h, 1)
+    sc = scene_mod.CorridorScene(66 * 0.15, 66 * 0.15, 40 * 0.15, seed=1234, device="cuda")
+    n_dyn_seen = 0
+    for f in range(8):
+        t = f / 30.0
+        pts_t, pos, quat = sc.frame(t)
+        if f == 5:
+            pts_t = pts_t.clone(); pts_t[:, 0] *= -1.0          # everything behind the sensor: an empty view
+        pts = pts_t.cpu().numpy()
+        assert o.update(pts, pos, t, quat) == 1
+        assert m.update(pts, pos, t, quat) == 1
+        assert md.update_device(pts_t.data_ptr(), len(pts), pos, t, quat) == 1
+        g, w = m.get_birth_cloud(), o.get_birth_cloud()
+        assert len(g) == len(w) > 1000, f
+        for k in ("x", "y", "z", "nx", "ny", "nz", "intensity"):
+            assert np.array_equal(g[k], w[k]), (f, k)
+        assert o.cursors()[0] == m.cursors()[0] and o.cursors()[2] == m.cursors()[2], f
+        n_dyn_seen += int((g["intensity"] > 0.01).sum())
+        occ_o, occ_g = o.results[:, 0].astype(np.float64), m.results()[:, 0].astype(np.float64)
+        # (the empty-view frame multiplies every weight in view by 1 - P_d: particles near the 1e-3 cull threshold make the
+        # mass comparison of two trajectories that already differ by resampling ties coarser from there on)
+        assert abs(occ_g.sum() - occ_o.sum()) < (5e-3 if f < 5 else 2e-2) * occ_o.sum(), f
+        o.get_occupancy_with_future(0.2); m.getOccupancyMapWithFutureStatus(0.2); md.getOccupancyMapWithFutureStatus(0.2)
+    assert n_dyn_seen > 200                                     # the pedestrians / boxes were tagged possibly dynamic
+    for a, b in zip(m.export_state(), md.export_state()):
+        assert np.array_equal(a, b)                             # captured frame == host-buffer frame, slot for slot
+    # moving particles exist (newborns of matched clusters carry the estimated velocity)
+    rec = m.export_state()[2]
+    assert (np.abs(rec[:, 1]) + np.abs(rec[:, 2]) > 0.3).sum() > 100
+    o.close(); m.close(); md.close()
