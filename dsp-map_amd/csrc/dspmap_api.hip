@@ -148,10 +148,10 @@ static void free_dev(dspmap* m) {
     DevState& s = m->s;
     if (m->mgpu_bound) { s.obs_ck = nullptr; s.nstatic = nullptr; }  // caller-owned
     if (m->mgpu_count) chk(hipFree(m->mgpu_count), "hipFree");
-    void* ptrs[] = {s.fpar, s.obs_ckf, s.part_inv, s.fut_stat, s.mask, s.nbmask, s.pos, s.vel, s.w, s.vz0, s.res4, s.fut, s.obs, s.obs_ck,
+    void* ptrs[] = {s.fpar, s.obs_ckf, s.part_inv, s.fut_stat, s.mask, s.nbmask, s.pos, s.vel, s.w, s.vz0, s.res4, s.fut, s.fut_out, s.obs, s.obs_ck,
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, s.fov_rec, s.fov_slot, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt,
-                    s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
+                    s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.ro_cnt, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
                     m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
     if (m->nbsnap_buf) chk(hipFree(m->nbsnap_buf), "hipFree");
@@ -286,6 +286,7 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&s.pos, 3 * S)); HIPCHK(m, dalloc(&s.vel, 2 * S)); HIPCHK(m, dalloc(&s.w, S));
     HIPCHK(m, dalloc(&s.res4, (size_t)d.v_loc));
     HIPCHK(m, dalloc(&s.fut, (size_t)d.v_loc * (d.T ? d.T : 1)));
+    HIPCHK(m, dalloc(&s.fut_out, (size_t)d.v_loc * (d.T ? d.T : 1)));
     HIPCHK(m, dalloc(&s.fut_stat, (size_t)d.v_loc));
     HIPCHK(m, hipMemset(s.fut_stat, 0, sizeof(float) * (size_t)d.v_loc));
     HIPCHK(m, hipMemset(s.pos, 0, sizeof(float) * 3 * S)); HIPCHK(m, hipMemset(s.vel, 0, sizeof(float) * 2 * S));
@@ -314,6 +315,9 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&k.mv_rec, ntiles * 64 * d.slots * 2));
     HIPCHK(m, dalloc(&k.in_rec, ntiles * 64 * d.slots * 2));
     HIPCHK(m, dalloc(&k.in_cnt, ntiles));
+    k.ro_rec = k.mv_rec;   // k_predict's staging area is dead once k_predict has ended: k_resample -> k_rollout reuse it
+    HIPCHK(m, dalloc(&k.ro_cnt, ntiles));
+    HIPCHK(m, hipMemset(k.ro_cnt, 0, sizeof(int) * ntiles));
     HIPCHK(m, dalloc(&k.omask, W));
     HIPCHK(m, hipMemset(k.omask, 0, sizeof(u64) * W));
     HIPCHK(m, dalloc(&k.ck_items, (size_t)d.np * ((d.capp + 63) / 64 + 1)));
@@ -884,7 +888,7 @@ static int readout(dspmap* m, float thr, float* xyz, int cap, int* n_out, float*
     if (fut_out && d.T > 0) {
         dspmap_flush_future_clear(m);
         launch_future_combine(c);
-        HIPCHK(m, hipMemcpyAsync(fut_out, m->s.fut, sizeof(float) * (size_t)d.v_loc * d.T, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(m, hipMemcpyAsync(fut_out, m->s.fut_out, sizeof(float) * (size_t)d.v_loc * d.T, hipMemcpyDeviceToHost, m->stream));
     }
     m->fut_clear_pending = true;  // :397-400, :420-424
     HIPCHK(m, hipStreamSynchronize(m->stream));
@@ -914,8 +918,8 @@ extern "C" const float* dspmap_future_device(dspmap_t* m) {
     if (!m || !m->device_ready) return nullptr;
     dspmap_flush_future_clear(m);
     LaunchCtx c = dspmap_ctx_of(m);
-    launch_future_combine(c);  // static-particle mass is kept per voxel and folded in on demand
-    return m->s.fut;
+    launch_future_combine(c);  // [V][T] view of the horizon-major accumulators + the static-particle mass
+    return m->s.fut_out;
 }
 
 extern "C" void dspmap_voxel_center(const dspmap_t* m, int index, float* px, float* py, float* pz) {  // :1556-1572
@@ -1284,7 +1288,7 @@ extern "C" int dspmap_save_checkpoint(dspmap_t* m, const char* path) {
     LaunchCtx c = dspmap_ctx_of(m);
     launch_future_combine(c);   // fold the static-particle mass into the per-horizon accumulators
     HIPCHK(m, hipMemcpyAsync(res.data(), m->s.res4, sizeof(float4) * V, hipMemcpyDeviceToHost, m->stream));
-    if (T) HIPCHK(m, hipMemcpyAsync(fut.data(), m->s.fut, sizeof(float) * V * T, hipMemcpyDeviceToHost, m->stream));
+    if (T) HIPCHK(m, hipMemcpyAsync(fut.data(), m->s.fut_out, sizeof(float) * V * T, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     CkHeader h;
     memset(&h, 0, sizeof(h));
@@ -1349,7 +1353,13 @@ extern "C" int dspmap_load_checkpoint(dspmap_t* m, const char* path) {
     rc = dspmap_import_state(m, n, voxel.data(), slot.data(), rec.data());
     if (rc != DSPMAP_OK) return rc;
     HIPCHK(m, hipMemcpyAsync(m->s.res4, res.data(), sizeof(float4) * V, hipMemcpyHostToDevice, m->stream));
-    if (T) HIPCHK(m, hipMemcpyAsync(m->s.fut, fut.data(), sizeof(float) * V * T, hipMemcpyHostToDevice, m->stream));
+    if (T) {   // the file holds the caller's [V][T] layout (static mass folded in); the accumulators are horizon-major
+        std::vector<float> ft(V * T);
+        for (size_t v = 0; v < V; ++v)
+            for (size_t t = 0; t < T; ++t) ft[t * V + v] = fut[v * T + t];
+        HIPCHK(m, hipMemcpy(m->s.fut, ft.data(), sizeof(float) * V * T, hipMemcpyHostToDevice));
+        HIPCHK(m, hipMemsetAsync(m->s.fut_stat, 0, sizeof(float) * V, m->stream));
+    }
     HIPCHK(m, hipStreamSynchronize(m->stream));
     {   // filter parameters and the frozen birth statics come from the checkpoint; the random tables are THIS handle's
         // (regenerated from its seed or injected by its caller), so their lengths stay, and the pair-cull radius is

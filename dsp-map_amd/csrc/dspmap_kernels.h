@@ -26,6 +26,8 @@ struct KernelScratch {
     u64* nbsnap;        // [v_loc*mw] newborn bits as they were BEFORE this frame's birth stage, or nullptr when they are known
                         // to be all zero (every frame after a resampling).  Non-null after a constructor pre-fill / an import of
                         // flag-15 records / a second birth stage without resampling: addAParticle (:1184-1185) skips those slots
+    float4* ro_rec;     // [ntiles][64*slots][2] the tile's MOVING old particles {px, py, vx, vy}, {w, local voxel} (k_resample -> k_rollout)
+    int* ro_cnt;        // [ntiles]
     int* work_list;     // [v_loc] scratch: per-voxel prefix of the constructor-seeded particles' noise ranks (k_vz_count)
     int ntiles;         // tiles of 64 voxels; k_predict / k_place run one workgroup per tile
     int nblk_sweep;
@@ -74,7 +76,7 @@ void launch_birth_late(const LaunchCtx& c, int n_birth, bool all_static);   // w
 void launch_birth_plan_insert(const LaunchCtx& c, int n_birth, bool in_frame, bool all_static);
 void launch_birth_materialize(const LaunchCtx& c, BirthSrc* out, int cap, int* n_out);   // the frame's synthesised birth cloud, for host readback
 // mapOccupancyCalculationAndResample (:924-1057)
-void launch_resample(const LaunchCtx& c);
+void launch_resample(const LaunchCtx& c);   // + the future rollout of the moving particles (k_rollout)
 // readout (:385-438)
 void launch_occupied_compact(const LaunchCtx& c, float thr);
 void launch_clear_future(const LaunchCtx& c);

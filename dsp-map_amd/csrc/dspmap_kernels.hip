@@ -1013,14 +1013,13 @@ void launch_occupied_compact(const LaunchCtx& c, float thr) {
     hipLaunchKernelGGL(k_occ_scan, dim3(1), dim3(1024), 0, c.stream, c.s, nblk);
     hipLaunchKernelGGL(k_occ_emit, dim3(nblk), dim3(256), 0, c.stream, c.d, c.s, thr, c.d.v_loc);
 }
+// fut_out[v][t] = fut[t][v] + fut_stat[v]: the caller's [V][T] layout from the horizon-major accumulators and the
+// static-particle mass (the same for every horizon).  Pure function of the accumulators: callable any number of times.
 __global__ void k_future_combine(MapDims d, DevState s) {
     const int lv = blockIdx.x * blockDim.x + threadIdx.x;
     if (lv >= d.v_loc) return;
     const float st = s.fut_stat[lv];
-    if (st != 0.f) {
-        for (int t = 0; t < d.T; ++t) s.fut[(size_t)lv * d.T + t] += st;
-        s.fut_stat[lv] = 0.f;
-    }
+    for (int t = 0; t < d.T; ++t) s.fut_out[(size_t)lv * d.T + t] = s.fut[(size_t)t * d.v_loc + lv] + st;
 }
 void launch_future_combine(const LaunchCtx& c) {
     hipLaunchKernelGGL(k_future_combine, dim3((c.d.v_loc + 255) / 256), dim3(256), 0, c.stream, c.d, c.s);

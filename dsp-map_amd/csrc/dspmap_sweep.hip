@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
         // clearOccupancyMapPrediction (:431-438) was requested since the last frame: this tile's share of the
         // future accumulators is zeroed here instead of by two extra memset launches per frame
         const int v0 = BX * 64, nv = min(64, d.v_loc - v0);
-        for (int i = tid; i < nv * d.T; i += NW * 64) s.fut[(size_t)v0 * d.T + i] = 0.f;
+        for (int i = tid; i < nv * d.T; i += NW * 64) s.fut[(size_t)(i / nv) * d.v_loc + v0 + (i % nv)] = 0.f;   // [T][V]
         if (tid < nv) s.fut_stat[v0 + tid] = 0.f;
     }
     const bool inr = lv < d.v_loc;
@@ -752,7 +752,8 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 // dynamic LDS per wave: [slots][64] fp32 weights + [64][M] u16 (source slot, destination slot) of deferred copies
 // --------------------------------------------------------------------------
 template <int MW>
-__global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __restrict__ part_live, int* __restrict__ vb_cnt) {
+__global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __restrict__ part_live, int* __restrict__ vb_cnt,
+                                                  float4* __restrict__ ro_rec, int* __restrict__ ro_cnt) {
     extern __shared__ float s_dyn[];
     const int l = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -777,7 +778,7 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
     if (inr) vb_cnt[lv] = 0;    // birth buckets of this frame are consumed: leave them empty for the next one
     if (!__ballot(nonempty)) {  // whole tile empty
         if (inr) s.res4[lv] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (l == 0 && wave_g * 64 < d.v_loc + 63) part_live[wave_g] = 0;
+        if (l == 0 && wave_g * 64 < d.v_loc + 63) { part_live[wave_g] = 0; ro_cnt[wave_g] = 0; }
         return;
     }
     // every live weight row of the tile -> LDS, all loads in flight together
@@ -794,8 +795,8 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
         }
     }
 #endif
-    const int T = d.T;
-    const int gz = inr ? (lv + d.v_base) / (d.ny * d.nx) : 0;  // z layer never changes in the rollout (vz == 0)
+    int nmv = 0;   // moving old particles of the tile noted for k_rollout so far (wave-uniform)
+    const size_t ro_base = (size_t)wave_g * 64 * d.slots;
     int n = 0, n_old = 0;
     float wsum = 0.f, vxs = 0.f, vys = 0.f, stat_w = 0.f;
 #pragma unroll
@@ -821,14 +822,33 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
                 vv[r] = ld_vel(s, idx);
             }
             float vx[RBK], vy[RBK];
+            bool any_mv = false;
 #pragma unroll
             for (int r = 0; r < RBK; ++r) {
                 const bool old = act[r] && !((nb[e] >> row[r]) & 1ull);
                 vx[r] = old ? vv[r].x : 0.f; vy[r] = old ? vv[r].y : 0.f;
+                any_mv |= vx[r] != 0.f || vy[r] != 0.f;
+            }
+            // the rollout (:950-964) needs the position of the MOVING old particles only: their (x, y) are requested for the
+            // whole batch at once -- one extra memory round trip per batch that holds a moving particle instead of one per
+            // moving particle inside the sequential loop below
+            float mpx[RBK], mpy[RBK];
+            if (__ballot(any_mv)) {
+#pragma unroll
+                for (int r = 0; r < RBK; ++r) {
+                    mpx[r] = 0.f; mpy[r] = 0.f;
+                    if (vx[r] != 0.f || vy[r] != 0.f) {
+                        const float2 q = *reinterpret_cast<const float2*>(s.pos + 3 * pidx(d, lvs, e * 64 + row[r]));
+                        mpx[r] = q.x; mpy[r] = q.y;
+                    }
+                }
             }
 #if RS_DMA
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weight panel (first batch) + this batch's velocities
 #endif
+            bool mv_now[RBK];
+#pragma unroll
+            for (int r = 0; r < RBK; ++r) mv_now[r] = false;
 #pragma unroll
             for (int r = 0; r < RBK; ++r) {
                 if (!act[r]) continue;
@@ -845,31 +865,30 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
                     if (!(nb[e] & bit)) {         // flag < 10 :944
                         ++n_old;
                         vxs += vx[r]; vys += vy[r];
-                        if (vx[r] == 0.f && vy[r] == 0.f) {
-                            stat_w += w;          // p + 0*t stays in this voxel for every horizon
-                        } else {
-                            const size_t idx = pidx(d, lvs, e * 64 + row[r]);
-                            const P3 p3 = ld_pos(s, idx);
-                            const float px = p3.x, py = p3.y;
-                            for (int t = 0; t < T; ++t) {  // :952-963
-                                const float pt = d.pred_t[t];
-                                const float fx = px + vx[r] * pt;
-                                const float fy = py + vy[r] * pt;
-                                if (!(fx >= d.half_x || fx <= -d.half_x || fy >= d.half_y || fy <= -d.half_y)) {
-                                    const int xi = (int)__fdiv_rn(fx + d.half_x, d.res);
-                                    const int yi = (int)__fdiv_rn(fy + d.half_y, d.res);
-                                    const int dl = gz * d.ny * d.nx + yi * d.nx + xi - d.v_base;
-                                    if (dl >= 0 && dl < d.v_loc) unsafeAtomicAdd(&s.fut[(size_t)dl * T + t], w);
-                                }
-                            }
-                        }
+                        if (vx[r] == 0.f && vy[r] == 0.f) stat_w += w;   // p + 0*t stays in this voxel for every horizon
+                        else mv_now[r] = true;                           // the T future positions are k_rollout's job
                     }
                     ++n;
                     wsum += w;                    // :970
                 }
             }
+            // the batch's moving old particles join the tile's rollout list (stable wave-level append, no atomics: one
+            // wave owns the tile)
+            if (__ballot(any_mv)) {
+#pragma unroll
+                for (int r = 0; r < RBK; ++r) {
+                    const u64 mb = __ballot(mv_now[r]);
+                    if (mv_now[r]) {
+                        const size_t o = (ro_base + nmv + (int)__popcll(mb & lanemask_lt())) * 2;
+                        ro_rec[o] = make_float4(mpx[r], mpy[r], vx[r], vy[r]);
+                        ro_rec[o + 1] = make_float4(wr[r], __int_as_float(lv), 0.f, 0.f);
+                    }
+                    nmv += (int)__popcll(mb);
+                }
+            }
         }
     }
+    if (l == 0) ro_cnt[wave_g] = nmv;
     if (inr) {
         float4 res = make_float4(wsum, 0.f, 0.f, 0.f);  // voxels_objects_number[v][0..3] :974-984
         if (n_old > 0) { res.y = __fdiv_rn(vxs, (float)n_old); res.z = __fdiv_rn(vys, (float)n_old); }
@@ -969,6 +988,77 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
     }
     live_out = wave_sum_i(live_out);
     if (l == 0) part_live[wave_g] = live_out;
+}
+
+// --------------------------------------------------------------------------
+// k_rollout: the future-status rollout of mapOccupancyCalculationAndResample (:950-964) for the MOVING old particles
+// (static ones add the same mass to their own voxel for every horizon: fut_stat, k_resample).
+// One workgroup per tile that holds moving particles.  For every horizon t the particle's future voxel (same layer:
+// vz == 0) receives its weight:
+//   * few moving particles (a pedestrian's newborns in an otherwise static map): one float atomic each;
+//   * many (the whole tile moves): the tile's particles land in a band of neighbouring voxels, so the workgroup
+//     accumulates horizon t in an LDS window over the voxel-index range [tile - RO_HALF, tile + 64 + RO_HALF) and
+//     flushes the touched part of it with COALESCED atomics onto the horizon-major accumulators (a scattered float
+//     atomic costs a memory transaction per lane, ~25 G/s device-wide; a row of 64 neighbouring voxels costs two).
+//     Destinations outside the window take the single-atomic path.
+// --------------------------------------------------------------------------
+#define RO_WIN 8192
+#define RO_HALF ((RO_WIN - 64) / 2)
+#define RO_DENSE 192    // moving particles in a tile from which the LDS window pays
+__global__ void __launch_bounds__(256) k_rollout(MapDims d, DevState s, const float4* __restrict__ ro_rec, const int* __restrict__ ro_cnt) {
+    __shared__ float s_win[RO_WIN];
+    __shared__ int s_lohi[2];
+    const int BX = (int)blockIdx.x;
+    const int cnt = ro_cnt[BX];
+    if (cnt == 0) return;
+    const int tid = threadIdx.x;
+    const int T = d.T;
+    const int zc = d.ny * d.nx;
+    const size_t base = (size_t)BX * 64 * d.slots;
+    const size_t V = (size_t)d.v_loc;
+    auto future_voxel = [&](const float4& a, int lv, float pt) -> int {   // local index of the voxel at horizon pt, or -1
+        const float fx = a.x + a.z * pt;      // :954-955
+        const float fy = a.y + a.w * pt;
+        if (fx >= d.half_x || fx <= -d.half_x || fy >= d.half_y || fy <= -d.half_y) return -1;
+        const int xi = (int)__fdiv_rn(fx + d.half_x, d.res);
+        const int yi = (int)__fdiv_rn(fy + d.half_y, d.res);
+        const int gz = (lv + d.v_base) / zc;  // the layer never changes (vz == 0; pz itself is inside the map)
+        const int dl = gz * zc + yi * d.nx + xi - d.v_base;
+        return (dl >= 0 && dl < d.v_loc) ? dl : -1;
+    };
+    if (cnt < RO_DENSE) {
+        for (int i = tid; i < cnt * T; i += 256) {
+            const int q = i / T, t = i - q * T;
+            const float4 a = ro_rec[(base + q) * 2], b = ro_rec[(base + q) * 2 + 1];
+            const int dl = future_voxel(a, __float_as_int(b.y), d.pred_t[t]);
+            if (dl >= 0) unsafeAtomicAdd(&s.fut[(size_t)t * V + dl], b.x);
+        }
+        return;
+    }
+    const int win_lo = BX * 64 - RO_HALF;   // local voxel index of window cell 0
+    for (int i = tid; i < RO_WIN; i += 256) s_win[i] = 0.f;
+    for (int t = 0; t < T; ++t) {
+        if (tid == 0) { s_lohi[0] = RO_WIN; s_lohi[1] = -1; }
+        __syncthreads();
+        const float pt = d.pred_t[t];
+        int lo = RO_WIN, hi = -1;
+        for (int q = tid; q < cnt; q += 256) {
+            const float4 a = ro_rec[(base + q) * 2], b = ro_rec[(base + q) * 2 + 1];
+            const int dl = future_voxel(a, __float_as_int(b.y), pt);
+            if (dl < 0) continue;
+            const int off = dl - win_lo;
+            if (off >= 0 && off < RO_WIN) { atomicAdd(&s_win[off], b.x); lo = min(lo, off); hi = max(hi, off); }
+            else unsafeAtomicAdd(&s.fut[(size_t)t * V + dl], b.x);
+        }
+        if (hi >= 0) { atomicMin(&s_lohi[0], lo); atomicMax(&s_lohi[1], hi); }
+        __syncthreads();
+        const int f_lo = s_lohi[0] & ~63, f_hi = s_lohi[1];
+        for (int off = f_lo + tid; off <= f_hi; off += 256) {
+            const float v = s_win[off];
+            if (v != 0.f) { unsafeAtomicAdd(&s.fut[(size_t)t * V + win_lo + off], v); s_win[off] = 0.f; }
+        }
+        __syncthreads();
+    }
 }
 
 // --------------------------------------------------------------------------
@@ -1328,8 +1418,9 @@ void launch_resample(const LaunchCtx& c) {
     const int nw = 1;   // waves (= tiles) per workgroup; the LDS panel bounds the occupancy, small groups pack best
     const size_t lds = (size_t)nw * (c.d.slots * 64 + (64 * c.d.M + 1) / 2) * sizeof(float);
     const unsigned grid = (unsigned)((k->ntiles + nw - 1) / nw);
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_resample<1>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt);
-    else hipLaunchKernelGGL(k_resample<2>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt);
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_resample<1>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt);
+    else hipLaunchKernelGGL(k_resample<2>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt);
+    if (c.d.T > 0) hipLaunchKernelGGL(k_rollout, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->ro_rec, k->ro_cnt);
 }
 void launch_seed_uniform(const LaunchCtx& c, int per_voxel, float weight, unsigned seed, float vmax) {
     const size_t total = (size_t)c.d.v_loc * c.d.slots;

@@ -121,7 +121,10 @@ struct DevState {
     float* w;     // [S]                   rewritten by the weight update and the resampler
     float* vz0;    // optional, only right after an import with vz != 0 (consumed by the next prediction)
     float4* res4;  // [v_loc] {mass, mean vx, mean vy, mean vz}
-    float* fut;    // [v_loc][T]  future mass scattered by moving particles
+    float* fut;    // [T][v_loc]  future mass scattered by moving particles, HORIZON-major: the rollout flushes whole rows of
+                   //             neighbouring voxels of one horizon (coalesced atomics)
+    float* fut_out; // [v_loc][T] the caller's layout (voxels_objects_number[v][4..], :118-120): fut + fut_stat, written by
+                   //             k_future_combine on demand (readout is not part of update())
     float* fut_stat; // [v_loc]   future mass of static particles (identical for every horizon; folded in at readout)
     // observations
     float4* obs;       // [np*100] {x,y,z,len}
