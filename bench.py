@@ -37,6 +37,7 @@ WORKLOADS = {
     "E8_sat": dict(nx=264, ny=264, nz=10, res=0.10, ppv=36, sat=True),
 }
 REC = 32  # bytes of one live particle record in SURVEY 8(d)'s accounting
+COUNTER_KEYS = ("n_live_in", "n_fov", "n_born", "n_obs", "n_moved", "n_out_of_map", "n_voxel_full", "n_pyramid_full", "n_live_out")
 
 
 def b_alg(c, V, T):
@@ -45,17 +46,61 @@ def b_alg(c, V, T):
         4 * (4 + T) * V + 4 * T * V
 
 
-def kernel_alg_bytes(stage, c, V, T):
-    """per-kernel share of B_alg (DESIGN.md 'roofline accounting')."""
-    if stage in ("predict", "claim"):          # every live record in and out once
+def kernel_alg_bytes(stage, c, V, T, mw=1):
+    """Bytes a kernel has to move per launch IN THIS DESIGN ("bytes per unit"), from the device
+    counters of the same run.  They are what `roofline.achieved` prices the dominant kernel with and are never larger than
+    the kernel's share of SURVEY 8(d)'s B_alg (a kernel is not credited for records it does not have to touch):
+      predict    every live record in and out once                                   2 * 32 * N_live
+      claim      k_place touches the particles that changed voxel only              2 * 32 * N_moved
+      resample   weight + velocity of every particle in (12 B), weight of the kept ones out (4 B), the newborn records
+                 (32 B), result grid (16 B) + static future mass (4 B) + occupancy words (2 x 8 B x words) per voxel;
+                 positions are read for moving particles and copies only and are not counted (lower bound)
+      ck_partial 16 B per particle in view + 20 B per observation
+      weight     20 B per particle in view + 20 B per observation"""
+    if stage == "predict":
         return 2 * REC * c["n_live_in"]
-    if stage == "resample":                    # every live record (incl. newborn) in and out + result grid + accumulators
-        return 2 * REC * c["n_live_in"] + REC * c["n_born"] + 4 * (4 + T) * V + 4 * T * V
+    if stage == "claim":
+        return 2 * REC * c["n_moved"]
+    if stage == "resample":
+        n_in = c["n_live_in"] - c["n_out_of_map"] - c["n_voxel_full"] - c["n_pyramid_full"]
+        return 12 * n_in + 4 * c["n_live_out"] + REC * c["n_born"] + (16 + 4 + 16 * mw) * V
     if stage == "ck_partial":
         return 16 * c["n_fov"] + 20 * c["n_obs"]
     if stage == "weight":
         return 20 * c["n_fov"] + 20 * c["n_obs"]
     return 0
+
+
+FRAME_KERNELS = ("k_obs_points", "k_predict", "k_place", "k_pyr_prepare", "k_ck_partial", "k_weight", "k_birth_split_cksum",
+                 "k_birth_cursors", "k_birth_insert", "k_resample", "k_rollout", "k_ve_components", "k_ve_clusters",
+                 "k_birth_children")
+
+
+def roofline_block(stage_ms, cnt, V, T, mw, traffic_db, wl_name, peak=8000.0):
+    """roofline of the dominant kernel + every kernel's fraction.  A kernel cannot beat the HBM peak on the bytes it has to
+    move: a fraction above 1 means the accounting (or the timer) is wrong and is never printed."""
+    timed = {k: v for k, v in stage_ms.items() if k not in ("setup+bin", "ck_finalize", "birth")}
+    per = {}
+    for k, ms in timed.items():
+        b = kernel_alg_bytes(k, cnt, V, T, mw)
+        fr = b / (ms * 1e-3) / 1e9 / peak if ms > 0 else 0.0
+        per[k] = {"ms": round(ms, 5), "bytes": int(b), "GBps": round(b / (ms * 1e-3) / 1e9, 2) if ms > 0 else 0.0,
+                  "frac": round(fr, 5)}
+        if fr > 1.0:
+            per[k] = {"ms": round(ms, 5), "bytes": int(b), "GBps": None, "frac": None,
+                      "error": "bytes / time exceeds the HBM peak: accounting rejected"}
+    dom = max((k for k in timed if per[k]["frac"] is not None), key=lambda k: timed[k])
+    tdb = traffic_db.get(wl_name, {})
+    name_of = {"claim": "k_place", "weight": "k_weight", "predict": "k_predict", "resample": "k_resample",
+               "ck_partial": "k_ck_partial"}
+    roof = {"bound": "hbm", "kernel": name_of.get(dom, "k_" + dom), "achieved": per[dom]["GBps"], "peak": peak,
+            "unit": "GB/s", "frac": per[dom]["frac"], "traffic": tdb.get(name_of.get(dom, ""), {}).get("hbm_bytes"),
+            "kernel_ms": per[dom]["ms"], "algorithmic_bytes": per[dom]["bytes"], "per_kernel": per}
+    if tdb:
+        roof["traffic_source"] = ("profiles/pmc_traffic*.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
+                                  "corrected 2*FETCH+WRITE per the MI355X guide)")
+        roof["traffic_frame"] = int(sum(v.get("hbm_bytes", 0) for k, v in tdb.items() if k in FRAME_KERNELS))
+    return roof
 
 
 def main():
@@ -64,7 +109,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default=None)
-    ap.add_argument("--prefill", type=int, default=60, help="untimed frames before warmup (steady state)")
+    ap.add_argument("--prefill", type=int, default=300, help="untimed frames before warmup (steady state: the live count of workload B levels off after ~8 s of stream)")
     ap.add_argument("--estimator", type=int, default=2, help="velocity estimator of the realistic workloads: 0 static tags, 1 host stage, 2 device (default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the saturated extra measurements")
@@ -212,23 +257,18 @@ def main():
     ms = dt / args.steps * 1e3
     peak = 8000.0
     traffic_db = {}
-    try:  # HBM bytes per launch from the committed PMC passes of the same command (profiles/r01_c_pmc_traffic.md)
-        traffic_db = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")))["workloads"]
-    except Exception:
-        pass
+    for fn in ("pmc_traffic.json", "pmc_traffic_r01.json"):   # HBM bytes per launch from the committed PMC passes of the same commands
+        try:
+            traffic_db = json.load(open(os.path.join(ROOT, "profiles", fn)))["workloads"]
+            break
+        except Exception:
+            pass
+    mw = (2 * wl["ppv"] + 63) // 64
     if stage is not None:
-        dom = max((k for k in stage if k not in ("setup+bin", "ck_finalize", "birth")), key=lambda k: stage[k])
-        dom_bytes = kernel_alg_bytes(dom, cnt, V, T)
-        dom_ms = stage[dom]
-        roof = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(dom_bytes / (dom_ms * 1e-3) / 1e9, 3),
-                "peak": peak, "unit": "GB/s", "frac": round(dom_bytes / (dom_ms * 1e-3) / 1e9 / peak, 6),
-                "traffic": traffic_db.get(wl_name, {}).get("k_" + dom, {}).get("hbm_bytes"),
-                "traffic_source": "profiles/pmc_traffic_r01.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this workload, "
-                                  "corrected: 2*FETCH+WRITE)" if wl_name in traffic_db else None,
-                "kernel_ms": round(dom_ms, 6), "algorithmic_bytes": int(dom_bytes)}
-        if V < 500_000:   # the metric's own size: the frame is 9 dependent launches of 5-35 us, none of them bandwidth-bound
+        roof = roofline_block(stage, cnt, V, T, mw, traffic_db, wl_name, peak)
+        if V < 500_000:   # the metric's own size: the frame is a chain of dependent launches of 5-35 us, none of them bandwidth-bound
             roof["note"] = ("at this map size every kernel is a latency chain (one wave per SIMD, ~0.2 TB/s for the whole frame); "
-                            "the HBM-bound case is saturated_132x132x60 in this same line (its roofline block: k_predict)")
+                            "the HBM-bound case is saturated_132x132x60 in this same line")
     else:  # sharded run: whole-frame algorithmic bytes over all ranks against N x 8 TB/s
         roof = {"bound": "hbm", "kernel": "whole frame (all ranks)", "achieved": round(balg / (ms * 1e-3) / 1e9, 3),
                 "peak": peak * world, "unit": "GB/s", "frac": round(balg / (ms * 1e-3) / 1e9 / (peak * world), 6),
@@ -254,7 +294,7 @@ def main():
         "frame": {"b_alg_bytes": int(balg), "b_alg_GBps": round(balg / (ms * 1e-3) / 1e9, 3),
                   "frac_of_8TBps": round(balg / (ms * 1e-3) / 1e9 / peak, 6),
                   "stage_ms": {k: round(v, 5) for k, v in stage.items()} if stage else None,
-                  "counters": {k: cnt[k] for k in ("n_live_in", "n_fov", "n_born", "n_obs", "n_moved", "n_live_out")}},
+                  "counters": {k: cnt[k] for k in COUNTER_KEYS}},
     }
 
     # ------------------------------------------------------------------ saturated large map (C_sat): the roofline case
@@ -267,19 +307,14 @@ def main():
             V2, T2 = m2.V_local, m2.T
             ms2 = dt2 / 40 * 1e3
             b2 = b_alg(c2, V2, T2)
-            dom2 = max((k for k in st2 if k not in ("setup+bin", "ck_finalize", "birth")), key=lambda k: st2[k])
-            db2 = kernel_alg_bytes(dom2, c2, V2, T2)
             result["saturated_132x132x60"] = {
                 "workload": "C_sat: 132x132x60 @ 0.15 m, every voxel seeded with 24 zero-velocity particles, same depth stream",
                 "frames_per_s": round(40 / dt2, 2), "ms_per_step": round(ms2, 4),
                 "b_alg_bytes": int(b2), "b_alg_GBps": round(b2 / (ms2 * 1e-3) / 1e9, 2),
                 "frac_of_8TBps": round(b2 / (ms2 * 1e-3) / 1e9 / peak, 5),
-                "roofline": {"bound": "hbm", "kernel": "k_" + dom2, "achieved": round(db2 / (st2[dom2] * 1e-3) / 1e9, 2),
-                             "peak": peak, "unit": "GB/s", "frac": round(db2 / (st2[dom2] * 1e-3) / 1e9 / peak, 5),
-                             "traffic": traffic_db.get("C_sat", {}).get("k_" + dom2, {}).get("hbm_bytes"),
-                             "kernel_ms": round(st2[dom2], 5), "algorithmic_bytes": int(db2)},
+                "roofline": roofline_block(st2, c2, V2, T2, 1, traffic_db, "C_sat", peak),
                 "stage_ms": {k: round(v, 5) for k, v in st2.items()},
-                "counters": {k: c2[k] for k in ("n_live_in", "n_fov", "n_born", "n_obs", "n_moved", "n_live_out")}}
+                "counters": {k: c2[k] for k in COUNTER_KEYS}}
             m2.close()
             del fr2
         except Exception as e:  # the extra line must never break the contract line
