@@ -209,39 +209,44 @@ def main():
         return m, frames, dt, cnt, stage
 
     def measure_sharded(w, steps, warmup, prefill):
-        """N > 1: the map is split in Z-slabs, one per rank (dsp-map_amd/sharded.py); every rank is fed the
-        same cloud; boundary particles go to the neighbour ranks, Ck / n_static are all-reduced (RCCL)."""
-        sharded = __import__("dsp-map_amd.sharded", fromlist=["ShardedDSPMap"])
-        z_lo, z_hi = sharded.slab_ranges(w["nz"], world)[rank]
-        slab = sharded.HipSlab(D, dict(nx=w["nx"], ny=w["ny"], nz=w["nz"], res=w["res"], ppv=w["ppv"], seed=1234),
-                               z_lo, z_hi, local_rank)
-        sm = sharded.ShardedDSPMap([slab], sharded.TorchDistComm(dev))
+        """N > 1: the map is split in Z-slabs, one per rank; every rank is fed the same cloud.  The frame is driven from C++
+        (dspmap_mgpu_update, dspmap_dist.hip): boundary particles go to the neighbour ranks in fixed-size ncclSend / ncclRecv
+        pairs, Ck and n_static are all-reduced, all on the library's stream.  torch.distributed only launches the ranks,
+        hands rank 0's RCCL unique id around once and provides the barriers of the timing contract."""
+        sharded = __import__("dsp-map_amd.sharded", fromlist=["CppShardedRank"])
+
+        def bcast(t):
+            t = t.to(dev)
+            dist.broadcast(t, 0)
+            return t
+        rk = sharded.CppShardedRank(D, dict(nx=w["nx"], ny=w["ny"], nz=w["nz"], res=w["res"], ppv=w["ppv"], seed=1234),
+                                    world, rank, local_rank, broadcast=bcast)
         frames = gen_frames(w, prefill + warmup + steps, seed=1234)  # identical on every rank
         if w["sat"]:
-            slab.map.seed_uniform(w["ppv"], 0.01, 99)
+            rk.map.seed_uniform(w["ppv"], 0.01, 99)
 
         def run(fr):
             for pts, pos, quat, t in fr:
-                assert sm.update(pts, pos, t, quat) == 1
-                slab.map.clearOccupancyMapPrediction()
+                assert rk.update(pts, pos, t, quat) == 1
+                rk.map.clearOccupancyMapPrediction()
         run(frames[:prefill + warmup])
-        slab.sync()
+        rk.sync()
         barrier()
         t0 = time.perf_counter()
         run(frames[prefill + warmup:])
-        slab.sync()
+        rk.sync()
         barrier()
         dt = time.perf_counter() - t0
-        cnt = slab.map.counters()
-        tot = torch.tensor([cnt[k] for k in ("n_live_in", "n_fov", "n_born", "n_obs", "n_moved", "n_live_out",
-                                              "n_exported_up", "n_exported_down")], device=dev, dtype=torch.float64)
+        cnt = rk.map.counters()
+        keys = ("n_live_in", "n_fov", "n_born", "n_obs", "n_moved", "n_out_of_map", "n_voxel_full", "n_pyramid_full", "n_live_out")
+        tot = torch.tensor([cnt[k] for k in keys], device=dev, dtype=torch.float64)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        keys = ("n_live_in", "n_fov", "n_born", "n_obs", "n_moved", "n_live_out", "n_exported_up", "n_exported_down")
         cnt_all = dict(cnt)
         for k, v in zip(keys, tot.tolist()):
             cnt_all[k] = int(v)
         cnt_all["n_obs"] = cnt["n_obs"]  # every rank bins the same observations
-        return slab.map, frames, dt, cnt_all, None
+        cnt_all["message_records"] = rk.map.L.dspmap_mgpu_message_records(rk.map.h)
+        return rk.map, frames, dt, cnt_all, None
 
     # ------------------------------------------------------------------ main measurement
     if not sharded_run:
@@ -286,8 +291,8 @@ def main():
                    "birth_tags": ("static (every in-FOV point is a zero-velocity birth source)" if wl["sat"] or args.estimator == 0 else
                                   "velocityEstimationThread (:1377-1544) %s" % ("on the device, inside the captured frame (dspmap_velest.hip)"
                                                                                if args.estimator == 2 else "as a host stage (velocity_estimator.cpp)")),
-                   "parallelism": "1 GPU" if not sharded_run else "%d Z-slabs (one per GPU), RCCL neighbour exchange + "
-                                                                "2 small all-reduces per frame" % world,
+                   "parallelism": "1 GPU" if not sharded_run else "%d Z-slabs (one per GPU), C++ driver: ncclSend/ncclRecv neighbour "
+                                                                "exchange + 2 small ncclAllReduce per frame on the library's stream" % world,
                    "n_points": int(frames[-1][0].shape[0])},
         "roofline": roof,
         "host_enqueue_ms_per_step": round(getattr(measure, "host_issue_ms", 0.0), 5),

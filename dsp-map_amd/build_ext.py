@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdspmap_hip.so")
-SOURCES = ["dspmap_kernels.hip", "dspmap_sweep.hip", "dspmap_api.hip", "dspmap_mgpu.hip", "dspmap_preprocess.hip", "dspmap_velest.hip",
+SOURCES = ["dspmap_kernels.hip", "dspmap_sweep.hip", "dspmap_api.hip", "dspmap_mgpu.hip", "dspmap_preprocess.hip", "dspmap_velest.hip", "dspmap_dist.hip",
            "velocity_estimator.cpp"]
 HEADERS = ["dspmap_internal.h", "dspmap_types.h", "dspmap_device.h", "dspmap_kernels.h", "dspmap_birth.h", "velocity_estimator.h",
            os.path.join("..", "..", "include", "dspmap.h")]

@@ -85,6 +85,7 @@ SIGNATURES = {
     "dspmap_point_voxel_index": (_i, [_P, _f, _f, _f, _ip]),
     "dspmap_voxel_num": (_i, [_P]),
     "dspmap_local_voxel_num": (_i, [_P]),
+    "dspmap_local_voxel_base": (_i, [_P]),
     "dspmap_slots_per_voxel": (_i, [_P]),
     "dspmap_pyramid_num": (_i, [_P]),
     "dspmap_pyramid_capacity": (_i, [_P]),
@@ -120,6 +121,15 @@ SIGNATURES = {
     "dspmap_mgpu_ck_partial": (_i, [_P]),
     "dspmap_mgpu_weights_and_split": (_i, [_P]),
     "dspmap_mgpu_finish": (_i, [_P]),
+    "dspmap_mgpu_get_unique_id": (_i, [_P]),
+    "dspmap_mgpu_comm_init": (_i, [_P, _i, _i, _P]),
+    "dspmap_mgpu_comm_init_from_env": (_i, [_P]),
+    "dspmap_mgpu_comm_destroy": (_i, [_P]),
+    "dspmap_mgpu_update": (_i, [_P, _i, _P, _i, _P, _P, _d, _P]),
+    "dspmap_mgpu_update_host": (_i, [_P, _i, _i, _P, _f, _f, _f, _d, _f, _f, _f, _f]),
+    "dspmap_mgpu_message_records": (_i, [_P]),
+    "dspmap_mgpu_group_create": (_i, [_P, _i]),
+    "dspmap_mgpu_group_update": (_i, [_P, _i, _i, _P, _i, _P, _P, _d, _P]),
 }
 
 _LIB = None

@@ -146,7 +146,8 @@ static void free_dev(dspmap* m) {
     if (m->graph_exec) chk(hipGraphExecDestroy(m->graph_exec), "hipGraphExecDestroy");
     if (m->graph) chk(hipGraphDestroy(m->graph), "hipGraphDestroy");
     DevState& s = m->s;
-    if (m->mgpu_bound) { s.obs_ck = nullptr; s.nstatic = nullptr; }  // caller-owned
+    dspmap_dist_free(m);
+    if (m->mgpu_bound && !m->mgpu_self_bound) { s.obs_ck = nullptr; s.nstatic = nullptr; }  // caller-owned
     if (m->mgpu_count) chk(hipFree(m->mgpu_count), "hipFree");
     void* ptrs[] = {s.fpar, s.obs_ckf, s.part_inv, s.fut_stat, s.mask, s.nbmask, s.pos, s.vel, s.w, s.vz0, s.res4, s.fut, s.fut_out, s.obs, s.obs_ck,
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
@@ -239,7 +240,7 @@ int dspmap_ensure_point_cap(dspmap* m, int n) {
     HIPCHK(m, hipStreamSynchronize(m->stream));
     DevState& s = m->s;
     const int cap = n + n / 2 + 1024;
-    if (m->mgpu_bound) return dspmap_fail(m, DSPMAP_E_ARG, "%d points exceed the capacity bound with dspmap_mgpu_bind", n);
+    if (m->mgpu_bound && !m->mgpu_self_bound) return dspmap_fail(m, DSPMAP_E_ARG, "%d points exceed the capacity bound with dspmap_mgpu_bind", n);
     BirthSrc* old_birth = s.birth;   // holds the cloud of the last non-empty view (re-used by frames with an empty one): carried over
     void* olds[] = {s.pt_rot, s.pt_pyr, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, m->pts_dev, m->k.child, m->k.part_birth};
     for (void* p : olds) if (p) (void)hipFree(p);
@@ -785,7 +786,7 @@ extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* poin
     return device_frame(m, n_points, points_dev, n_birth, birth_dev, dp, dt, q);
 }
 
-static int stage_points(dspmap* m, int n, int stride, const float* pts) {
+int dspmap_stage_points(dspmap* m, int n, int stride, const float* pts) {
     int rc = dspmap_ensure_point_cap(m, n);
     if (rc != DSPMAP_OK) return rc;
     if (n > m->pts_pin_cap) {
@@ -827,7 +828,7 @@ extern "C" int dspmap_update(dspmap_t* m, int n, int stride, const float* pts, f
     float dp[3], dt;
     if (!dspmap_gate_and_delta(m, pos, stamp, q, dp, &dt)) return DSPMAP_REJECTED;
     const int np = n > 0 ? n : 0;
-    int rc = stage_points(m, np, stride, pts);
+    int rc = dspmap_stage_points(m, np, stride, pts);
     if (rc != DSPMAP_OK) return rc;
     if (m->use_vel_est == 2 && !m->cfg.static_model && !m->h_birth_valid && np <= m->ve.cap)
         return device_frame(m, np, m->pts_dev, 0, nullptr, dp, dt, q);   // velocity estimator on the device: no host stage in the frame
@@ -940,6 +941,7 @@ extern "C" int dspmap_point_voxel_index(const dspmap_t* m, float px, float py, f
 
 extern "C" int dspmap_voxel_num(const dspmap_t* m) { return m ? m->d.v_glob : 0; }
 extern "C" int dspmap_local_voxel_num(const dspmap_t* m) { return m ? m->d.v_loc : 0; }
+extern "C" int dspmap_local_voxel_base(const dspmap_t* m) { return m ? m->d.v_base : 0; }
 extern "C" int dspmap_slots_per_voxel(const dspmap_t* m) { return m ? m->d.slots : 0; }
 extern "C" int dspmap_pyramid_num(const dspmap_t* m) { return m ? m->d.np : 0; }
 extern "C" int dspmap_pyramid_capacity(const dspmap_t* m) { return m ? m->d.capp : 0; }
@@ -1093,7 +1095,7 @@ extern "C" int dspmap_stage_bin_points(dspmap_t* m, int n, int stride, const flo
     READY(m);
     if (n < 0 || (n > 0 && (!pts || stride < 3))) return DSPMAP_E_ARG;
     m->quat[0] = qw; m->quat[1] = qx; m->quat[2] = qy; m->quat[3] = qz;
-    int rc = stage_points(m, n, stride, pts);
+    int rc = dspmap_stage_points(m, n, stride, pts);
     if (rc != DSPMAP_OK) return rc;
     LaunchCtx c = dspmap_ctx_of(m);
     for (int i = 0; i < 4; i++) m->hp.quat[i] = m->quat[i];

@@ -1,0 +1,425 @@
+// dspmap_dist.hip -- the Z-slab frame driven from C++ (north star: "Host code stays C++ ... the voxel grid
+// shards by Z-slab across the 8 GPUs of one node with an RCCL exchange over xGMI for particles that cross slab boundaries").
+//
+// One process per GPU; rank g owns the layers [z_lo, z_hi) of dspmap_config.  dspmap_mgpu_update() runs one whole frame:
+// every collective is enqueued on the library's stream between the phases of dspmap_mgpu.hip, and NO host
+// synchronisation sits inside a frame:
+//   begin (binning, prediction)          -> export of the particles that left the slab, both faces
+//   neighbour exchange                   -> FIXED-SIZE ncclSend / ncclRecv pairs with rank +- 1 (ncclGroup): record 0 of a
+//                                           buffer is its header (the number of records that follow), so the receiver
+//                                           reads the count on the device; the size all ranks use is derived from the
+//                                           largest export of the previous frame (+50 % + 1024), which rides on the
+//                                           n_static all-reduce as one extra MAX slot and reaches the host a frame later;
+//                                           a particle that has to cross more than one slab (|dz| > slab height) is
+//                                           forwarded in further rounds (their number follows from the pose, equal on
+//                                           every rank)
+//   placement, Ck pass                   -> ncclAllReduce(SUM, int64) of the fixed-point Ck sums (<= 358 kB)
+//   weight update, Dempster-Shafer split -> ncclAllReduce(MAX, int32) of n_static per birth source (+ the slot above)
+//   births, resampling, rollout
+// RCCL is loaded with dlopen at the first dspmap_mgpu_comm_init* (libdspmap_hip.so has no link-time dependency on it; a
+// single-GPU process never touches it).  The same frame driver also runs over several slabs inside ONE process
+// (dspmap_mgpu_group_*: device-to-device copies and small reduction kernels in place of the collectives): that is how
+// the tests prove, on one GPU, that a map sharded by this driver is bit-identical to the unsharded one.
+#include "dspmap_internal.h"
+#include "dspmap_device.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+RcclApi* rccl() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return &api;
+    tried = true;
+    // a copy the process already holds (e.g. the one torch.distributed loaded) is reused; otherwise ROCm's
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) { api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (api.lib) break; }
+    if (!api.lib) for (const char* n : names) { api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (api.lib) break; }
+    if (!api.lib) return &api;
+#define LOAD(field, sym) *(void**)(&api.field) = dlsym(api.lib, sym)
+    LOAD(GetUniqueId, "ncclGetUniqueId"); LOAD(CommInitRank, "ncclCommInitRank"); LOAD(CommDestroy, "ncclCommDestroy");
+    LOAD(AllReduce, "ncclAllReduce"); LOAD(Send, "ncclSend"); LOAD(Recv, "ncclRecv");
+    LOAD(GroupStart, "ncclGroupStart"); LOAD(GroupEnd, "ncclGroupEnd"); LOAD(GetErrorString, "ncclGetErrorString");
+#undef LOAD
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.Send && api.Recv && api.GroupStart && api.GroupEnd;
+    return &api;
+}
+}  // namespace
+
+// per-handle state of the C++ driver
+struct dspmap_dist {
+    int world = 1, rank = 0;
+    ncclComm_t comm = nullptr;          // RCCL transport (nullptr inside a one-process group)
+    float* buf[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // [dir 0 up / 1 down][send, recv, forward]: (1 + xcap) records of 8 floats
+    int xcap = 0;                       // records the exchange buffers hold
+    int xsend = 0;                      // records this frame's messages carry (the same on every rank)
+    int* cnt2 = nullptr;                // device: export counts {up, down}
+    int* gmax_pin = nullptr;            // pinned: the largest export of a frame over all ranks
+    hipEvent_t gmax_ev = nullptr;
+    bool gmax_pending = false;
+    int nb_hi = 0;                      // longest birth cloud so far (span of the n_static all-reduce)
+    int min_slab = 1;                   // thinnest slab of the partition, in layers (number of forwarding rounds)
+    long long overflow_frames = 0;
+};
+
+#define NCCLCHK(m, call)                                                                                   \
+    do {                                                                                                   \
+        ncclResult_t r_ = (call);                                                                          \
+        if (r_ != ncclSuccess)                                                                             \
+            return dspmap_fail((m), DSPMAP_E_DEVICE, "%s failed: %s", #call, rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "?"); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ small kernels
+__global__ void k_dist_headers(float* up, float* down, const int* cnt2, int* nstatic, int slot) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        reinterpret_cast<int*>(up)[0] = cnt2[0];
+        reinterpret_cast<int*>(down)[0] = cnt2[1];
+        nstatic[slot] = max(cnt2[0], cnt2[1]);   // rides on the MAX all-reduce: next frames' message size
+    }
+}
+__global__ void k_dist_fwd_reset(float* fwd_up, float* fwd_down) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { reinterpret_cast<int*>(fwd_up)[0] = 0; reinterpret_cast<int*>(fwd_down)[0] = 0; }
+}
+// received records: those of this slab join the inbox of their destination tile (k_place then serves them together with
+// the slab's own movers in the order of their source keys); those that have to travel on go to the forward buffer of the
+// same direction; `xsend` bounds what the message carried.
+__global__ void __launch_bounds__(256) k_dist_import(MapDims d, const float* __restrict__ msg, int xsend, float4* __restrict__ in_rec,
+                                                     int* __restrict__ in_cnt, float* __restrict__ fwd, int fwd_cap, int* __restrict__ lost) {
+    const int n = min(reinterpret_cast<const int*>(msg)[0], xsend);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool gone = false;
+    if (i < n) {
+        const float* r = msg + 8 * (size_t)(i + 1);
+        const int nlv = __float_as_int(r[0]) - d.v_base;
+        if (nlv >= 0 && nlv < d.v_loc) {
+            const int tile = nlv >> 6, cap = 64 * d.slots;
+            const int pos = atomicAdd(&in_cnt[tile], 1);   // beyond cap: k_place counts it as "voxel full"
+            if (pos < cap) {
+                const size_t o = ((size_t)tile * cap + pos) * 2;
+                in_rec[o] = make_float4(r[0], r[1], r[2], r[3]);
+                in_rec[o + 1] = make_float4(r[4], r[5], r[6], r[7]);
+            }
+        } else if (fwd) {
+            const int pos = atomicAdd(reinterpret_cast<int*>(fwd), 1);
+            if (pos < fwd_cap) { float* o = fwd + 8 * (size_t)(pos + 1); for (int k = 0; k < 8; ++k) o[k] = r[k]; }
+        } else gone = true;
+    }
+    wave_count_add(lost, gone);
+}
+// one-process group: element-wise SUM (int64) / MAX (int32) over the members' buffers, written back to all of them
+struct PtrList { void* p[16]; int n; };
+__global__ void k_group_sum_i64(PtrList l, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    long long acc = 0;
+    for (int k = 0; k < l.n; ++k) acc += reinterpret_cast<long long*>(l.p[k])[i];
+    for (int k = 0; k < l.n; ++k) reinterpret_cast<long long*>(l.p[k])[i] = acc;
+}
+__global__ void k_group_max_i32(PtrList l, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    int acc = reinterpret_cast<int*>(l.p[0])[i];
+    for (int k = 1; k < l.n; ++k) acc = max(acc, reinterpret_cast<int*>(l.p[k])[i]);
+    for (int k = 0; k < l.n; ++k) reinterpret_cast<int*>(l.p[k])[i] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ set-up
+static int dist_alloc(dspmap* m, int world, int rank) {
+    if (m->dist) return dspmap_fail(m, DSPMAP_E_STATE, "the handle already belongs to a communicator / group");
+    const MapDims& d = m->d;
+    if (world > 1 && d.z_lo == 0 && d.z_hi == d.nz) return dspmap_fail(m, DSPMAP_E_ARG, "a sharded map needs z_lo / z_hi in its configuration");
+    dspmap_dist* x = new dspmap_dist();
+    x->world = world; x->rank = rank;
+    // capacity: two layers of slots (a frame whose vertical step exceeds two voxels overflows and is reported);
+    // the MESSAGES are sized from the previous frame's exports, not from this capacity
+    const long long layer = (long long)d.nx * d.ny * d.slots;
+    x->xcap = (int)std::min<long long>(std::max<long long>(4096, 2 * layer), 64ll << 20);
+    x->xsend = (int)std::min<long long>(x->xcap, std::max<long long>(4096, layer / 8));
+    for (int dir = 0; dir < 2; ++dir)
+        for (int k = 0; k < 3; ++k) {
+            HIPCHK(m, hipMalloc((void**)&x->buf[dir][k], sizeof(float) * 8 * ((size_t)x->xcap + 1)));
+            HIPCHK(m, hipMemset(x->buf[dir][k], 0, sizeof(float) * 8));
+        }
+    HIPCHK(m, hipMalloc((void**)&x->cnt2, sizeof(int) * 2));
+    HIPCHK(m, hipHostMalloc((void**)&x->gmax_pin, sizeof(int) * 2));
+    x->gmax_pin[0] = 0;
+    HIPCHK(m, hipEventCreateWithFlags(&x->gmax_ev, hipEventDisableTiming));
+    // thinnest slab of an even partition of nz over `world` ranks (dsp-map_amd/sharded.py: slab_ranges)
+    x->min_slab = std::max(1, d.nz / std::max(1, world));
+    if (!m->k.expmask) {
+        const size_t W = (size_t)d.v_loc * d.mw;
+        HIPCHK(m, hipMalloc((void**)&m->k.expmask, sizeof(u64) * W));
+        HIPCHK(m, hipMemsetAsync(m->k.expmask, 0, sizeof(u64) * W, m->stream));
+    }
+    // the split-phase entry points of dspmap_mgpu.hip work on the library's own Ck / n_static buffers here
+    m->mgpu_bound = true; m->mgpu_self_bound = true;
+    m->mgpu_nstatic_cap = m->pt_cap - 1;
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    m->dist = x;
+    return DSPMAP_OK;
+}
+void dspmap_dist_free(dspmap* m) {
+    dspmap_dist* x = m->dist;
+    if (!x) return;
+    if (x->comm && rccl()->ok) (void)rccl()->CommDestroy(x->comm);
+    for (int dir = 0; dir < 2; ++dir) for (int k = 0; k < 3; ++k) if (x->buf[dir][k]) (void)hipFree(x->buf[dir][k]);
+    if (x->cnt2) (void)hipFree(x->cnt2);
+    if (x->gmax_pin) (void)hipHostFree(x->gmax_pin);
+    if (x->gmax_ev) (void)hipEventDestroy(x->gmax_ev);
+    delete x;
+    m->dist = nullptr;
+}
+
+extern "C" int dspmap_mgpu_get_unique_id(char out[DSPMAP_UNIQUE_ID_BYTES]) {
+    if (!out) return DSPMAP_E_ARG;
+    RcclApi* r = rccl();
+    if (!r->ok) return DSPMAP_E_DEVICE;
+    static_assert(sizeof(ncclUniqueId) <= DSPMAP_UNIQUE_ID_BYTES, "id size");
+    ncclUniqueId id;
+    if (r->GetUniqueId(&id) != ncclSuccess) return DSPMAP_E_DEVICE;
+    memset(out, 0, DSPMAP_UNIQUE_ID_BYTES);
+    memcpy(out, &id, sizeof(id));
+    return DSPMAP_OK;
+}
+
+extern "C" int dspmap_mgpu_comm_init(dspmap_t* m, int world, int rank, const char id_bytes[DSPMAP_UNIQUE_ID_BYTES]) {
+    READY(m);
+    if (world < 1 || rank < 0 || rank >= world || !id_bytes) return dspmap_fail(m, DSPMAP_E_ARG, "bad communicator arguments");
+    RcclApi* r = rccl();
+    if (!r->ok) return dspmap_fail(m, DSPMAP_E_DEVICE, "librccl.so could not be loaded (dlopen): %s", dlerror() ? dlerror() : "symbols missing");
+    int rc = dist_alloc(m, world, rank);
+    if (rc != DSPMAP_OK) return rc;
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof(id));
+    NCCLCHK(m, r->CommInitRank(&m->dist->comm, world, id, rank));
+    return DSPMAP_OK;
+}
+
+// rendezvous through a file for launchers that only export RANK / WORLD_SIZE (torchrun, mpirun wrappers): rank 0 writes
+// the unique id, the others wait for it.  DSPMAP_RDZV_FILE names the file (default /tmp/dspmap_rdzv_<MASTER_PORT>).
+extern "C" int dspmap_mgpu_comm_init_from_env(dspmap_t* m) {
+    if (!m) return DSPMAP_E_ARG;
+    const char* wr = getenv("WORLD_SIZE"); const char* rk = getenv("RANK");
+    const int world = wr ? atoi(wr) : 1, rank = rk ? atoi(rk) : 0;
+    char path[512];
+    const char* f = getenv("DSPMAP_RDZV_FILE");
+    if (f) snprintf(path, sizeof(path), "%s", f);
+    else snprintf(path, sizeof(path), "/tmp/dspmap_rdzv_%s", getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0");
+    char id[DSPMAP_UNIQUE_ID_BYTES];
+    if (rank == 0) {
+        int rc = dspmap_mgpu_get_unique_id(id);
+        if (rc != DSPMAP_OK) return dspmap_fail(m, rc, "ncclGetUniqueId failed");
+        char tmp[600];
+        snprintf(tmp, sizeof(tmp), "%s.tmp", path);
+        FILE* fp = fopen(tmp, "wb");
+        if (!fp || fwrite(id, 1, sizeof(id), fp) != sizeof(id)) { if (fp) fclose(fp); return dspmap_fail(m, DSPMAP_E_ARG, "cannot write %s", tmp); }
+        fclose(fp);
+        if (rename(tmp, path) != 0) return dspmap_fail(m, DSPMAP_E_ARG, "cannot publish %s", path);
+    } else {
+        bool got = false;
+        for (int tries = 0; tries < 6000 && !got; ++tries) {   // up to 60 s
+            FILE* fp = fopen(path, "rb");
+            if (fp) { got = fread(id, 1, sizeof(id), fp) == sizeof(id); fclose(fp); }
+            if (!got) usleep(10000);
+        }
+        if (!got) return dspmap_fail(m, DSPMAP_E_STATE, "no unique id appeared in %s", path);
+    }
+    return dspmap_mgpu_comm_init(m, world, rank, id);
+}
+
+extern "C" int dspmap_mgpu_comm_destroy(dspmap_t* m) {
+    if (!m) return DSPMAP_E_ARG;
+    if (m->device_ready) (void)hipStreamSynchronize(m->stream);
+    dspmap_dist_free(m);
+    return DSPMAP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ the frame, phase by phase
+// (every phase only ENQUEUES on the handle's stream)
+static int phase_begin(dspmap* m, int n_points, const float* points_dev, int n_birth, const dspmap_vpoint* birth_dev,
+                       const float pos[3], double stamp, const float q[4]) {
+    dspmap_dist* x = m->dist;
+    // the size of this frame's messages: from the largest export two frames ago at the latest (its copy has landed)
+    if (x->gmax_pending) {
+        HIPCHK(m, hipEventSynchronize(x->gmax_ev));
+        x->gmax_pending = false;
+        const int g = x->gmax_pin[0];
+        if (g > x->xsend) ++x->overflow_frames;   // that frame's messages were too small: particles were lost
+        x->xsend = (int)std::min<long long>(x->xcap, std::max<long long>(4096, (long long)g + g / 2 + 1024));
+    }
+    {   // room for the cloud and for the extra slot of the n_static all-reduce
+        const int rcap = dspmap_ensure_point_cap(m, std::max(n_points, n_birth) + 2);
+        if (rcap != DSPMAP_OK) return rcap;
+        m->mgpu_nstatic_cap = m->pt_cap - 1;
+    }
+    const int rc = dspmap_mgpu_begin(m, n_points, points_dev, n_birth, birth_dev, pos, stamp, q);
+    if (rc != DSPMAP_OK) return rc;
+    x->nb_hi = std::max(x->nb_hi, m->last_n_birth);
+    LaunchCtx c = dspmap_ctx_of(m);
+    HIPCHK(m, hipMemsetAsync(x->cnt2, 0, 2 * sizeof(int), m->stream));
+    launch_export_slab(c, 0, x->buf[0][0] + 8, x->xsend, x->cnt2, x->buf[1][0] + 8);   // both faces in one pass
+    hipLaunchKernelGGL(k_dist_headers, dim3(1), dim3(64), 0, m->stream, x->buf[0][0], x->buf[1][0], x->cnt2, m->s.nstatic, x->nb_hi);
+    launch_birth_early(c, m->last_n_birth, false);   // newborn children: they only need the birth cloud (the rank rode on k_predict)
+    m->mgpu_birth_early = true;
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}
+static int rounds_of(const dspmap* m) {
+    // vz == 0: a particle changes layer through the sensor's vertical step only; it crosses at most
+    // ceil(|dz| / res) + 1 layers, i.e. that many / (thinnest slab) slab faces -- the same number on every rank
+    const dspmap_dist* x = m->dist;
+    if (m->vz_frames_at_begin > 0) return std::max(1, x->world - 1);   // constructor-seeded particles still carry vz
+    const int layers = (int)std::ceil(std::fabs(m->hp.od[2]) / m->d.res) + 1;
+    return std::max(1, std::min(x->world - 1, (layers + x->min_slab - 1) / x->min_slab));
+}
+static void phase_import(dspmap* m, int dir_from /* 0: message came from below (travels up), 1: from above */, bool last_round) {
+    dspmap_dist* x = m->dist;
+    LaunchCtx c = dspmap_ctx_of(m);
+    float* fwd = last_round ? nullptr : x->buf[dir_from][2];
+    hipLaunchKernelGGL(k_dist_import, dim3((x->xsend + 255) / 256), dim3(256), 0, m->stream, m->d, x->buf[dir_from][1], x->xsend,
+                       c.k.in_rec, c.k.in_cnt, fwd, x->xsend, &m->s.fs->n_voxel_full_import);
+}
+static int phase_place_and_ck(dspmap* m) { return dspmap_mgpu_ck_partial(m); }
+static int phase_weights(dspmap* m) { return dspmap_mgpu_weights_and_split(m); }
+static int phase_finish(dspmap* m) {
+    dspmap_dist* x = m->dist;
+    // the frame's largest export (all ranks) travels to the host behind the all-reduce; read at the start of a later frame
+    HIPCHK(m, hipMemcpyAsync(x->gmax_pin, m->s.nstatic + x->nb_hi, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipEventRecord(x->gmax_ev, m->stream));
+    x->gmax_pending = true;
+    return dspmap_mgpu_finish(m);
+}
+
+extern "C" int dspmap_mgpu_update(dspmap_t* m, int n_points, const float* points_dev, int n_birth,
+                                  const dspmap_vpoint* birth_dev, const float pos[3], double stamp, const float q[4]) {
+    READY(m);
+    dspmap_dist* x = m->dist;
+    if (!x || !x->comm) return dspmap_fail(m, DSPMAP_E_STATE, "call dspmap_mgpu_comm_init first");
+    RcclApi* r = rccl();
+    int rc = phase_begin(m, n_points, points_dev, n_birth, birth_dev, pos, stamp, q);
+    if (rc != DSPMAP_OK) return rc;   // rejected frames are rejected on every rank (same pose, same stamps)
+    const size_t n_msg = 8 * ((size_t)x->xsend + 1);
+    const int rounds = rounds_of(m);
+    for (int rd = 0; rd < rounds; ++rd) {
+        if (rd + 1 < rounds) hipLaunchKernelGGL(k_dist_fwd_reset, dim3(1), dim3(64), 0, m->stream, x->buf[0][2], x->buf[1][2]);
+        NCCLCHK(m, r->GroupStart());
+        if (x->rank + 1 < x->world) {
+            NCCLCHK(m, r->Send(x->buf[0][0], n_msg, ncclFloat, x->rank + 1, x->comm, m->stream));   // up
+            NCCLCHK(m, r->Recv(x->buf[1][1], n_msg, ncclFloat, x->rank + 1, x->comm, m->stream));   // what rank + 1 sends down
+        }
+        if (x->rank > 0) {
+            NCCLCHK(m, r->Send(x->buf[1][0], n_msg, ncclFloat, x->rank - 1, x->comm, m->stream));   // down
+            NCCLCHK(m, r->Recv(x->buf[0][1], n_msg, ncclFloat, x->rank - 1, x->comm, m->stream));   // what rank - 1 sends up
+        }
+        NCCLCHK(m, r->GroupEnd());
+        if (x->rank > 0) phase_import(m, 0, rd + 1 == rounds);
+        if (x->rank + 1 < x->world) phase_import(m, 1, rd + 1 == rounds);
+        if (rd + 1 < rounds) { std::swap(x->buf[0][0], x->buf[0][2]); std::swap(x->buf[1][0], x->buf[1][2]); }   // forward what has to travel on
+    }
+    rc = phase_place_and_ck(m);
+    if (rc != DSPMAP_OK) return rc;
+    NCCLCHK(m, r->AllReduce(m->s.obs_ck, m->s.obs_ck, (size_t)m->d.np * DSP_OBS_CAP, ncclInt64, ncclSum, x->comm, m->stream));
+    rc = phase_weights(m);
+    if (rc != DSPMAP_OK) return rc;
+    NCCLCHK(m, r->AllReduce(m->s.nstatic, m->s.nstatic, (size_t)x->nb_hi + 1, ncclInt32, ncclMax, x->comm, m->stream));
+    rc = phase_finish(m);
+    if (rc != DSPMAP_OK) return rc;
+    if (x->overflow_frames) {
+        const long long n = x->overflow_frames;
+        x->overflow_frames = 0;
+        return dspmap_fail(m, DSPMAP_E_STATE, "%lld earlier frame(s) exported more particles across a slab face than the exchange message held "
+                           "(vertical step larger than the previous frames'): those particles were lost; the message size has been raised", n);
+    }
+    return DSPMAP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ one-process group
+extern "C" int dspmap_mgpu_group_create(dspmap_t** hs, int n) {
+    if (!hs || n < 1 || n > 16) return DSPMAP_E_ARG;
+    for (int i = 0; i < n; ++i) {
+        dspmap* m = hs[i];
+        READY(m);
+        if (i > 0) { int rc = dspmap_set_stream(m, (void*)hs[0]->stream); if (rc != DSPMAP_OK) return rc; }   // one stream orders the group
+        int rc = dist_alloc(m, n, i);
+        if (rc != DSPMAP_OK) return rc;
+    }
+    return DSPMAP_OK;
+}
+extern "C" int dspmap_mgpu_group_update(dspmap_t** hs, int n, int n_points, const float* points_dev, int n_birth,
+                                        const dspmap_vpoint* birth_dev, const float pos[3], double stamp, const float q[4]) {
+    if (!hs || n < 1 || n > 16) return DSPMAP_E_ARG;
+    for (int i = 0; i < n; ++i) if (!hs[i] || !hs[i]->dist || hs[i]->dist->comm) return DSPMAP_E_STATE;
+    hipStream_t st = hs[0]->stream;
+    int accepted = 0;
+    for (int i = 0; i < n; ++i) {
+        const int rc = phase_begin(hs[i], n_points, points_dev, n_birth, birth_dev, pos, stamp, q);
+        if (rc < 0) return rc;
+        accepted += rc == DSPMAP_OK ? 1 : 0;
+    }
+    if (accepted == 0) return DSPMAP_REJECTED;
+    if (accepted != n) return dspmap_fail(hs[0], DSPMAP_E_STATE, "the slabs of a group disagree about a frame");
+    const int rounds = rounds_of(hs[0]);
+    const size_t bytes = sizeof(float) * 8 * ((size_t)hs[0]->dist->xsend + 1);
+    for (int rd = 0; rd < rounds; ++rd) {
+        for (int i = 0; i < n; ++i)
+            if (rd + 1 < rounds) hipLaunchKernelGGL(k_dist_fwd_reset, dim3(1), dim3(64), 0, st, hs[i]->dist->buf[0][2], hs[i]->dist->buf[1][2]);
+        for (int i = 0; i < n; ++i) {   // the "send / recv" pairs
+            if (i + 1 < n) (void)hipMemcpyAsync(hs[i + 1]->dist->buf[0][1], hs[i]->dist->buf[0][0], bytes, hipMemcpyDeviceToDevice, st);
+            if (i > 0) (void)hipMemcpyAsync(hs[i - 1]->dist->buf[1][1], hs[i]->dist->buf[1][0], bytes, hipMemcpyDeviceToDevice, st);
+        }
+        for (int i = 0; i < n; ++i) {
+            if (i > 0) phase_import(hs[i], 0, rd + 1 == rounds);
+            if (i + 1 < n) phase_import(hs[i], 1, rd + 1 == rounds);
+            if (rd + 1 < rounds) { std::swap(hs[i]->dist->buf[0][0], hs[i]->dist->buf[0][2]); std::swap(hs[i]->dist->buf[1][0], hs[i]->dist->buf[1][2]); }
+        }
+    }
+    PtrList l;
+    l.n = n;
+    for (int i = 0; i < n; ++i) { const int rc = phase_place_and_ck(hs[i]); if (rc != DSPMAP_OK) return rc; l.p[i] = hs[i]->s.obs_ck; }
+    const int n_ck = hs[0]->d.np * DSP_OBS_CAP;
+    hipLaunchKernelGGL(k_group_sum_i64, dim3((n_ck + 255) / 256), dim3(256), 0, st, l, n_ck);
+    int span = 0;
+    for (int i = 0; i < n; ++i) { const int rc = phase_weights(hs[i]); if (rc != DSPMAP_OK) return rc; l.p[i] = hs[i]->s.nstatic; span = std::max(span, hs[i]->dist->nb_hi + 1); }
+    hipLaunchKernelGGL(k_group_max_i32, dim3((span + 255) / 256), dim3(256), 0, st, l, span);
+    for (int i = 0; i < n; ++i) { const int rc = phase_finish(hs[i]); if (rc != DSPMAP_OK) return rc; }
+    long long ov = 0;
+    for (int i = 0; i < n; ++i) { ov += hs[i]->dist->overflow_frames; hs[i]->dist->overflow_frames = 0; }
+    if (ov) return dspmap_fail(hs[0], DSPMAP_E_STATE, "an earlier frame exported more particles across a slab face than the exchange message held");
+    return DSPMAP_OK;
+}
+extern "C" int dspmap_mgpu_message_records(const dspmap_t* m) { return (m && m->dist) ? m->dist->xsend : 0; }
+
+// the host-buffer twin of dspmap_mgpu_update (what the drop-in class DSPMap calls when it is built with -DDSPMAP_WORLD)
+extern "C" int dspmap_mgpu_update_host(dspmap_t* m, int n, int stride, const float* pts, float sx, float sy, float sz, double stamp,
+                                       float qw, float qx, float qy, float qz) {
+    READY(m);
+    if (n > 0 && (!pts || stride < 3)) return dspmap_fail(m, DSPMAP_E_ARG, "bad point cloud arguments");
+    const int np = n > 0 ? n : 0;
+    int rc = dspmap_ensure_point_cap(m, np + 2);
+    if (rc != DSPMAP_OK) return rc;
+    rc = dspmap_stage_points(m, np, stride, pts);
+    if (rc != DSPMAP_OK) return rc;
+    const float pos[3] = {sx, sy, sz}, q[4] = {qw, qx, qy, qz};
+    return dspmap_mgpu_update(m, np, m->pts_dev, 0, nullptr, pos, stamp, q);
+}

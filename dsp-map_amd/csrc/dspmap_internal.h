@@ -75,6 +75,8 @@ struct dspmap {
     // multi-GPU split-phase state
     float cull_sigmas = 9.f;           // DSPMAP_P_PAIR_CULL_SIGMAS
     bool mgpu_bound = false;
+    bool mgpu_self_bound = false;      // the C++ driver (dspmap_dist.hip) works on the library's own Ck / n_static buffers
+    struct dspmap_dist* dist = nullptr;
     bool mgpu_birth_early = false;     // rank + children already queued by dspmap_mgpu_export_both
     bool mgpu_interior_done = false;   // dspmap_mgpu_place_interior placed the tiles [mgpu_tile_lo, mgpu_tile_hi)
     int mgpu_tile_lo = 0, mgpu_tile_hi = 0;
@@ -107,6 +109,8 @@ int dspmap_ensure_point_cap(dspmap* m, int n);
 int dspmap_push_frame_params(dspmap* m);
 void dspmap_flush_future_clear(dspmap* m);   // m->hp -> device
 int dspmap_mark_nb_dirty(dspmap* m);
+void dspmap_dist_free(dspmap* m);
+int dspmap_stage_points(dspmap* m, int n, int stride, const float* pts);   // host cloud -> m->pts_dev (pinned staging, async copy)
 int dspmap_begin_cloud(dspmap* m, int n_points, bool static_birth);   // bumps the frame epoch; returns the birth grid bound
 
 #define HIPCHK(m, call)                                                                            \

@@ -316,3 +316,81 @@ class ShardedDSPMap:
     def sync(self):
         for s in self.slabs:
             s.sync()
+
+
+# --------------------------------------------------------------------------- the C++ driver (dspmap_dist.hip)
+class CppShardedRank:
+    """one rank of the C++ RCCL driver: dspmap_mgpu_update() issues every collective itself (ncclSend / ncclRecv pairs
+    with rank +- 1, two ncclAllReduce) on the library's stream.  torch.distributed is only used ONCE, to hand rank 0's
+    RCCL unique id to the other ranks."""
+
+    def __init__(self, dsp, cfg_kwargs, world, rank, device_index=0, example_params=True, broadcast=None):
+        self.D = dsp
+        self.world, self.rank = world, rank
+        z_lo, z_hi = slab_ranges(cfg_kwargs["nz"], world)[rank]
+        cfg = dsp.make_config(z_lo=z_lo if world > 1 else 0, z_hi=z_hi if world > 1 else 0, device=device_index, **cfg_kwargs)
+        self.map = dsp.DSPMap(cfg, example_params=example_params)
+        m = self.map
+        m._chk(m.L.dspmap_init_device(m.h))
+        idb = (C.c_char * 128)()
+        if rank == 0:
+            m._chk(m.L.dspmap_mgpu_get_unique_id(C.cast(idb, C.c_void_p)))
+        if world > 1:
+            t = torch.frombuffer(bytearray(idb.raw), dtype=torch.uint8).clone()
+            t = broadcast(t)          # caller-supplied: returns rank 0's tensor on every rank
+            idb = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+        m._chk(m.L.dspmap_mgpu_comm_init(m.h, world, rank, C.cast(idb, C.c_void_p)))
+
+    def update(self, pts_dev, pos, stamp, quat, birth=None):
+        m = self.map
+        pos_a = (C.c_float * 3)(*pos)
+        q_a = (C.c_float * 4)(*quat)
+        nb = 0 if birth is None else int(birth.shape[0])
+        bptr = None if birth is None else birth.data_ptr()
+        return m._chk(m.L.dspmap_mgpu_update(m.h, int(pts_dev.shape[0]), pts_dev.data_ptr(), nb, bptr, C.cast(pos_a, C.c_void_p),
+                                             float(stamp), C.cast(q_a, C.c_void_p)))
+
+    def sync(self):
+        self.map.sync()
+
+
+class CppGroup:
+    """several slabs in ONE process driven by the same C++ frame driver (dspmap_mgpu_group_update): device-to-device
+    copies and small reduction kernels stand in for the collectives"""
+
+    def __init__(self, dsp, cfg_kwargs, world, device_index=0, example_params=True):
+        self.maps = []
+        for (z_lo, z_hi) in slab_ranges(cfg_kwargs["nz"], world):
+            cfg = dsp.make_config(z_lo=z_lo, z_hi=z_hi, device=device_index, **cfg_kwargs)
+            m = dsp.DSPMap(cfg, example_params=example_params)
+            m._chk(m.L.dspmap_init_device(m.h))
+            self.maps.append(m)
+        self.L = self.maps[0].L
+        self.handles = (C.c_void_p * world)(*[m.h for m in self.maps])
+        self.created = False
+
+    def create(self):
+        """after the tables / parameters of the members are set"""
+        rc = self.L.dspmap_mgpu_group_create(C.cast(self.handles, C.c_void_p), len(self.maps))
+        if rc < 0:
+            raise RuntimeError(self.L.dspmap_last_error(self.maps[0].h).decode())
+        self.created = True
+
+    def update(self, pts_dev, pos, stamp, quat):
+        if not self.created:
+            self.create()
+        pos_a = (C.c_float * 3)(*pos)
+        q_a = (C.c_float * 4)(*quat)
+        rc = self.L.dspmap_mgpu_group_update(C.cast(self.handles, C.c_void_p), len(self.maps), int(pts_dev.shape[0]), pts_dev.data_ptr(),
+                                             0, None, C.cast(pos_a, C.c_void_p), float(stamp), C.cast(q_a, C.c_void_p))
+        if rc < 0:
+            raise RuntimeError(self.L.dspmap_last_error(self.maps[0].h).decode())
+        return rc
+
+    def sync(self):
+        for m in self.maps:
+            m.sync()
+
+    def close(self):
+        for m in self.maps:
+            m.close()

@@ -114,6 +114,14 @@ static const int half_fov_v = DSPMAP_HALF_FOV_V;  // :50
 static string particle_save_folder = ".";  // :55 (one per translation unit here: the reference's non-static global could not be included twice)
 #endif
 
+#ifndef DSPMAP_ESTIMATOR_MODE
+#ifdef DSPMAP_WORLD
+#define DSPMAP_ESTIMATOR_MODE 0   /* sharded frames tag every point in view static (the estimator's stage is per process) */
+#else
+#define DSPMAP_ESTIMATOR_MODE 2   /* velocityEstimationThread on the device (dspmap_velest.hip); 1 = the host stage */
+#endif
+#endif
+
 class DSPMap {
 public:
     /* :145-175.  init_particle_num > 0 pre-fills the map with random particles (addRandomParticles
@@ -142,8 +150,24 @@ public:
 #ifdef DSPMAP_STATIC_MODEL
         cfg.static_model = DSPMAP_STATIC_MODEL;
 #endif
+#ifdef DSPMAP_WORLD
+        // Z-slab sharding across the GPUs of one node (-DDSPMAP_WORLD): one process per GPU, started by any launcher that
+        // exports RANK / WORLD_SIZE / LOCAL_RANK (torchrun, mpirun wrappers).  This rank owns the layers [z_lo, z_hi); every
+        // rank is fed the same cloud and pose; update() runs the C++ RCCL frame driver (dspmap_mgpu_update_host).  The
+        // getters return this rank's slab (voxel indices stay global).
+        {
+            const char* wr = getenv("WORLD_SIZE"); const char* rk = getenv("RANK"); const char* lr = getenv("LOCAL_RANK");
+            world_ = wr ? atoi(wr) : 1; rank_ = rk ? atoi(rk) : 0;
+            if (world_ > 1) {
+                const int base = cfg.nz / world_, rem = cfg.nz % world_;
+                cfg.z_lo = rank_ * base + (rank_ < rem ? rank_ : rem);
+                cfg.z_hi = cfg.z_lo + base + (rank_ < rem ? 1 : 0);
+            }
+            cfg.device = lr ? atoi(lr) : -1;
+        }
+#endif
         h_ = dspmap_create(&cfg);
-        if (h_) dspmap_set_param(h_, DSPMAP_P_VELOCITY_ESTIMATOR, 1);  // update() runs the velocity estimator like :297
+        if (h_) dspmap_set_param(h_, DSPMAP_P_VELOCITY_ESTIMATOR, DSPMAP_ESTIMATOR_MODE);  // update() runs the velocity estimator like :297
 #ifdef DSPMAP_OCCLUSION_MARGIN
         if (h_) dspmap_set_param(h_, DSPMAP_P_OCCLUSION_MARGIN, (double)(DSPMAP_OCCLUSION_MARGIN));
 #endif
@@ -161,9 +185,19 @@ public:
                float sensor_pz, double time_stamp_second, float sensor_quaternion_w, float sensor_quaternion_x,
                float sensor_quaternion_y, float sensor_quaternion_z) {
         lazy_prefill();
+#ifdef DSPMAP_WORLD
+        if (!comm_ready_) {   // the communicator is created at the first frame: no HIP / RCCL call during static initialisation
+            if (dspmap_mgpu_comm_init_from_env(h_) != DSPMAP_OK) { cerr << "DSPMap: " << dspmap_last_error(h_) << endl; return 0; }
+            comm_ready_ = true;
+        }
+        const int rc = dspmap_mgpu_update_host(h_, point_cloud_num, size_of_one_point, point_cloud_ptr, sensor_px, sensor_py,
+                                               sensor_pz, time_stamp_second, sensor_quaternion_w, sensor_quaternion_x,
+                                               sensor_quaternion_y, sensor_quaternion_z);
+#else
         const int rc = dspmap_update(h_, point_cloud_num, size_of_one_point, point_cloud_ptr, sensor_px, sensor_py,
                                      sensor_pz, time_stamp_second, sensor_quaternion_w, sensor_quaternion_x,
                                      sensor_quaternion_y, sensor_quaternion_z);
+#endif
         if (rc < 0) { cerr << "DSPMap::update failed: " << dspmap_last_error(h_) << endl; return 0; }
         if (rc == 1 && record_flag_) {  // :326-350: every frame when the flag is negative, else once after record_time
             const float update_time = (float)dspmap_get_param(h_, DSPMAP_P_UPDATE_TIME);
@@ -199,7 +233,7 @@ public:
         fetch(obstacles_num, cloud, future_status, threshold);
     }
     /* north-star name: the V x T future occupancy masses (then cleared, like the getters above) */
-    void getFutureStatus(float* future_status) { sync_params(); dspmap_get_future(h_, future_status); }
+    void getFutureStatus(float* future_status) { sync_params(); dspmap_get_future(h_, future_status + (size_t)dspmap_local_voxel_base(h_) * PREDICTION_TIMES); }
     void clearOccupancyMapPrediction() { dspmap_clear_future(h_); }  // :431-438
 
     void getKMClusterResult(pcl::PointCloud<pcl::PointXYZINormal>& cluster_cloud) {  // :441-445
@@ -257,9 +291,11 @@ private:
         if (init_particles_ > 0) { dspmap_add_random_particles(h_, init_particles_, init_weight_); init_particles_ = 0; }
     }
     void fetch(int& obstacles_num, pcl::PointCloud<pcl::PointXYZ>& cloud, float* future_status, float threshold) {
-        const int v = dspmap_voxel_num(h_);
+        const int v = dspmap_local_voxel_num(h_);
         xyz_.resize((size_t)v * 3);
         int n = 0;
+        // a slab's rows land at their GLOBAL voxel offsets of the caller's [VOXEL_NUM][PREDICTION_TIMES] array
+        if (future_status) future_status += (size_t)dspmap_local_voxel_base(h_) * PREDICTION_TIMES;
         const int rc = future_status ? dspmap_get_occupancy_with_future(h_, threshold, xyz_.data(), v, &n, future_status)
                                      : dspmap_get_occupancy(h_, threshold, xyz_.data(), v, &n);
         obstacles_num = rc == DSPMAP_OK ? n : 0;
@@ -270,6 +306,10 @@ private:
         }
     }
     dspmap_t* h_ = nullptr;
+#ifdef DSPMAP_WORLD
+    int world_ = 1, rank_ = 0;
+    bool comm_ready_ = false;
+#endif
     int init_particles_;
     float init_weight_;
     int record_flag_ = 0;        // if_record_particle_csv :479

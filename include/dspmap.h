@@ -187,6 +187,7 @@ int dspmap_point_voxel_index(const dspmap_t* m, float px, float py, float pz, in
 /* ---- sizes ---- */
 int dspmap_voxel_num(const dspmap_t* m);        /* global VOXEL_NUM :62 */
 int dspmap_local_voxel_num(const dspmap_t* m);  /* voxels in this handle's slab */
+int dspmap_local_voxel_base(const dspmap_t* m); /* global index of the slab's first voxel (0 for an unsharded map) */
 int dspmap_slots_per_voxel(const dspmap_t* m);  /* SAFE_PARTICLE_NUM_VOXEL :65 */
 int dspmap_pyramid_num(const dspmap_t* m);      /* observation_pyramid_num :60 */
 int dspmap_pyramid_capacity(const dspmap_t* m); /* SAFE_PARTICLE_NUM_PYRAMID :66 */
@@ -293,6 +294,36 @@ int dspmap_mgpu_import(dspmap_t* m, int n, const float* rec_dev);
 int dspmap_mgpu_ck_partial(dspmap_t* m);
 int dspmap_mgpu_weights_and_split(dspmap_t* m);
 int dspmap_mgpu_finish(dspmap_t* m);
+
+/* ---- the same frame driven from C++ (dspmap_dist.hip): one call per frame and rank, the collectives are issued by the
+ * library on its own stream through RCCL (dlopen of librccl.so at communicator set-up), no host synchronisation inside a
+ * frame.  Exchange of the boundary particles = fixed-size ncclSend / ncclRecv pairs with rank +- 1 whose first record
+ * is a header carrying the record count; the size is the largest export of an earlier frame (all ranks) + 50 % + 1024,
+ * agreed through one extra slot of the n_static all-reduce (MAX); particles that cross more than one slab are forwarded
+ * in further rounds.  Ck: ncclAllReduce(SUM, int64); n_static: ncclAllReduce(MAX, int32).
+ *   rank 0:      dspmap_mgpu_get_unique_id(id)   -> hand `id` to the other ranks (MPI, torch.distributed, a file, ...)
+ *   every rank:  dspmap_mgpu_comm_init(m, world, rank, id)       [or dspmap_mgpu_comm_init_from_env: RANK / WORLD_SIZE +
+ *                                                                 a rendezvous file, DSPMAP_RDZV_FILE]
+ *   per frame:   dspmap_mgpu_update(m, ...)                       1 / 0 like dspmap_update; same cloud and pose on every rank
+ * The handle's configuration carries the rank's slab [z_lo, z_hi).  dspmap_mgpu_update returns DSPMAP_E_STATE once, a
+ * frame late, if a frame's export did not fit the message (vertical step much larger than the frames before). */
+#define DSPMAP_UNIQUE_ID_BYTES 128
+int dspmap_mgpu_get_unique_id(char id_out[DSPMAP_UNIQUE_ID_BYTES]);
+int dspmap_mgpu_comm_init(dspmap_t* m, int world, int rank, const char id[DSPMAP_UNIQUE_ID_BYTES]);
+int dspmap_mgpu_comm_init_from_env(dspmap_t* m);
+int dspmap_mgpu_comm_destroy(dspmap_t* m);
+int dspmap_mgpu_update(dspmap_t* m, int n_points, const float* points_dev, int n_birth, const dspmap_vpoint* birth_dev,
+                       const float sensor_pos[3], double time_stamp_second, const float quat_wxyz[4]);
+int dspmap_mgpu_update_host(dspmap_t* m, int point_cloud_num, int size_of_one_point, const float* point_cloud_ptr,
+                            float sensor_px, float sensor_py, float sensor_pz, double time_stamp_second,
+                            float qw, float qx, float qy, float qz);
+int dspmap_mgpu_message_records(const dspmap_t* m);   /* records the next frame's exchange messages carry */
+/* the same driver over several slabs inside ONE process (tests, single-GPU debugging): device-to-device copies and small
+ * reduction kernels stand in for the collectives; the handles share the first one's stream */
+int dspmap_mgpu_group_create(dspmap_t** handles, int n);
+int dspmap_mgpu_group_update(dspmap_t** handles, int n, int n_points, const float* points_dev, int n_birth,
+                             const dspmap_vpoint* birth_dev, const float sensor_pos[3], double time_stamp_second,
+                             const float quat_wxyz[4]);
 
 #ifdef __cplusplus
 }

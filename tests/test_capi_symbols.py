@@ -106,7 +106,8 @@ def test_dropin_header_compiles_without_ros(dsp):
                     "-DDSPMAP_OCCLUSION_MARGIN=VOXEL_RESOLUTION"],
                    ["-DMAP_LENGTH_VOXEL_NUM=50", "-DMAP_WIDTH_VOXEL_NUM=50", "-DMAP_HEIGHT_VOXEL_NUM=30", "-DVOXEL_RESOLUTION=0.2",
                     "-DMAX_PARTICLE_NUM_VOXEL=10", "-DDSPMAP_STATIC_MODEL=1", "-DDSPMAP_SAFE_PARTICLE_FACTOR=5",
-                    "-DPREDICTION_TIMES=1", "-DDSPMAP_HALF_FOV_V=27", "-DDSPMAP_OCCLUSION_MARGIN=VOXEL_RESOLUTION"]):
+                    "-DPREDICTION_TIMES=1", "-DDSPMAP_HALF_FOV_V=27", "-DDSPMAP_OCCLUSION_MARGIN=VOXEL_RESOLUTION"],
+                   ["-DDSPMAP_WORLD=1"]):   # the sharded build of the same class (C++ RCCL driver)
         subprocess.check_call(["g++", "-std=c++14", "-Wall", "-fsyntax-only", "-I" + os.path.join(ROOT, "include")] + macros +
                               [os.path.join(ROOT, "examples", "map_example.cpp")])
     hdr = open(os.path.join(ROOT, "include", "dsp_dynamic.h")).read()

@@ -189,3 +189,66 @@ def test_dropin_example_runs(dsp):
     assert "Map is ready to update!" in out and "occupied" in out
     occ = int(out.split("occupied")[1].split()[0])
     assert occ > 50
+
+
+@pytest.mark.parametrize("world,ppv,jump", [(2, 12, 0.0), (4, 36, 0.0), (8, 12, 0.7)])
+def test_cpp_driver_group_matches_unsharded(dsp, world, ppv, jump):
+    """the C++ frame driver (dspmap_dist.hip: header-carrying fixed-size exchange messages, forwarding rounds, the two
+    reductions) over several slabs in one process: BIT-IDENTICAL to the unsharded map, slot for slot.  jump > 0: the sensor
+    steps 0.7 m vertically between two frames -- more than a slab is high (3 layers = 0.45 m) -- so particles cross more
+    than one slab face and are forwarded in a second round."""
+    sharded = __import__("dsp-map_amd.sharded", fromlist=["CppGroup"])
+    cfg = dict(nx=40, ny=40, nz=24, res=0.15, ppv=ppv)
+    tables = common.tables(3)
+    grp = sharded.CppGroup(dsp, cfg, world)
+    for m in grp.maps:
+        m.set_tables(*tables)
+    full = dsp.DSPMap(dsp.make_config(**cfg))
+    full.set_tables(*tables)
+    crossed = 0
+    for f, (pts, pos, t, q) in enumerate(_stream(8)):
+        if jump and f >= 4:
+            pos = (pos[0], pos[1], pos[2] + jump)
+        d = torch.from_numpy(pts).cuda()
+        assert grp.update(d, pos, t, q) == 1
+        assert full.update_device(d.data_ptr(), len(pts), pos, t, q) == 1
+        grp.sync()
+        crossed += sum(m.counters()["n_moved"] for m in grp.maps)
+        for m in grp.maps + [full]:
+            m.clearOccupancyMapPrediction()
+    got = np.concatenate([m.results() for m in grp.maps], 0)
+    assert np.array_equal(got, full.results())
+    parts = [m.export_state() for m in grp.maps]
+    sv, ss, sr = (np.concatenate([p[k] for p in parts]) for k in range(3))
+    order = np.lexsort((ss, sv))
+    fv, fs_, fr = full.export_state()
+    assert len(fv) > 3000
+    assert np.array_equal(sv[order], fv) and np.array_equal(ss[order], fs_) and np.array_equal(sr[order], fr)
+    assert sum(m.counters()["n_live_out"] for m in grp.maps) == full.counters()["n_live_out"]
+    if jump:
+        assert max(m.L.dspmap_mgpu_message_records(m.h) for m in grp.maps) >= 4096
+    grp.close(); full.close()
+
+
+def test_cpp_driver_rccl_single_rank(dsp):
+    """dspmap_mgpu_update on a one-rank RCCL communicator (the library dlopens librccl.so, creates the communicator from a
+    unique id and issues both all-reduces on its own stream): same map as the unsharded device-resident frame"""
+    sharded = __import__("dsp-map_amd.sharded", fromlist=["CppShardedRank"])
+    cfg = dict(nx=40, ny=40, nz=24, res=0.15, ppv=12)
+    tables = common.tables(3)
+    rk = sharded.CppShardedRank(dsp, cfg, 1, 0)
+    rk.map.set_tables(*tables)
+    full = dsp.DSPMap(dsp.make_config(**cfg))
+    full.set_tables(*tables)
+    for pts, pos, t, q in _stream(6):
+        d = torch.from_numpy(pts).cuda()
+        assert rk.update(d, pos, t, q) == 1
+        assert full.update_device(d.data_ptr(), len(pts), pos, t, q) == 1
+        rk.map.clearOccupancyMapPrediction(); full.clearOccupancyMapPrediction()
+    rk.sync()
+    for a, b in zip(rk.map.export_state(), full.export_state()):
+        assert np.array_equal(a, b)
+    assert np.array_equal(rk.map.results(), full.results())
+    assert "librccl" in open("/proc/self/maps").read()
+    rk.map._chk(rk.map.L.dspmap_mgpu_comm_destroy(rk.map.h))
+    rk.map.close(); full.close()
