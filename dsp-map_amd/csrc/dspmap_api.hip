@@ -88,6 +88,7 @@ static void derive_dims(dspmap* m) {
     const int pyramid_num = 360 * 180 / A / A;                         // :63
     const int safe_particle_num = (int)((double)d.v_glob * d.M + 1e5); // :64
     d.capp = safe_particle_num / pyramid_num * 2;                      // :66
+    d.capa = d.capp + d.capp / 4 + 64;
     d.T = c.prediction_times;
     d.res = c.voxel_resolution;
     d.half_x = (d.res * (float)c.nx) * 0.5f;                           // :528-530
@@ -151,7 +152,7 @@ static void free_dev(dspmap* m) {
     if (m->mgpu_count) chk(hipFree(m->mgpu_count), "hipFree");
     void* ptrs[] = {s.fpar, s.obs_ckf, s.part_inv, s.fut_stat, s.mask, s.nbmask, s.pos, s.vel, s.w, s.vz0, s.res4, s.fut, s.fut_out, s.obs, s.obs_ck,
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
-                    s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, s.fov_rec, s.fov_slot, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt,
+                    s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, s.fov_rec, s.fov_slot, s.fov_key, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.ro_cnt, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
                     m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
@@ -302,8 +303,9 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&s.obs_maxlen, (size_t)d.np));
     HIPCHK(m, dalloc(&s.planes_h, (size_t)(d.np_h + 1) * 3)); HIPCHK(m, dalloc(&s.planes_v, (size_t)(d.np_v + 1) * 3));
     HIPCHK(m, dalloc(&s.planes_h0, (size_t)(d.np_h + 1) * 3)); HIPCHK(m, dalloc(&s.planes_v0, (size_t)(d.np_v + 1) * 3));
-    HIPCHK(m, dalloc(&s.fov_rec, (size_t)d.np * d.capp));
-    HIPCHK(m, dalloc(&s.fov_slot, (size_t)d.np * d.capp));
+    HIPCHK(m, dalloc(&s.fov_rec, (size_t)d.np * d.capa));
+    HIPCHK(m, dalloc(&s.fov_slot, (size_t)d.np * d.capa));
+    HIPCHK(m, dalloc(&s.fov_key, (size_t)d.np * d.capa));
     HIPCHK(m, dalloc(&s.fov_rec_s, (size_t)d.np * d.capp));
     HIPCHK(m, dalloc(&s.fov_slot_s, (size_t)d.np * d.capp));
     HIPCHK(m, dalloc(&s.pyr_cnt, (size_t)d.np));
@@ -1129,6 +1131,7 @@ extern "C" int dspmap_stage_predict(dspmap_t* m, float dx, float dy, float dz, f
     { int rc = dspmap_push_frame_params(m); if (rc != DSPMAP_OK) return rc; }
     launch_frame_setup(c, false);
     launch_predict(c);
+    launch_pyr_prepare(c);   // a full pyramid list turns its latest particles (in sweep order) away: part of the prediction (:1256-1259)
     if (m->vz_frames > 0) --m->vz_frames;
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;

@@ -63,7 +63,8 @@ void launch_velocity_estimator(const LaunchCtx& c, bool with_rank);   // with_ra
 int velocity_estimator_capacity();   // points per frame the device estimator handles
 int velocity_estimator_slices();
 // mapUpdate (:704-793)
-void launch_ck_partial(const LaunchCtx& c);
+void launch_pyr_prepare(const LaunchCtx& c);   // range sort + full-list selection of the pyramid lists, work items (idempotent)
+void launch_ck_partial(const LaunchCtx& c);     // launch_pyr_prepare + the Ck pass
 void launch_ck_finalize(const LaunchCtx& c);
 void launch_weight_update(const LaunchCtx& c);
 // mapAddNewBornParticlesByObservation (:796-921)

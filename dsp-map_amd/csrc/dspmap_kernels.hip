@@ -57,7 +57,7 @@ __global__ void k_reset(MapDims d, DevState s, int flags) {
     if (flags & RESET_PRED) {
         for (int i = gt; i < d.np; i += gn) s.pyr_cnt[i] = 0;
         if (gt == 0) {
-            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0;
+            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->n_pyr_removed = 0;
         }
     }
 }
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) k_obs_points(MapDims d, DevState s) {
         if (gt == 0) {
             s.fs->cur_pos[0] = cpx; s.fs->cur_pos[1] = cpy; s.fs->cur_pos[2] = cpz;
             s.fs->n_valid = 0; s.fs->n_obs = 0; s.fs->has_expected_override = 0;   // k_obs_gather accumulates the first two
-            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0;
+            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->n_pyr_removed = 0;
         }
     } else {
         for (int i = threadIdx.x; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
@@ -138,16 +138,92 @@ __device__ __forceinline__ int range_bucket(const MapDims& d, const float4& r) {
     const float len = sqrtf(r.x * r.x + r.y * r.y + r.z * r.z);
     return min(PS_NBK - 1, (int)(len * d.rng_inv_bw));
 }
+__device__ __forceinline__ int block_excl_scan_1024(int v, int* s_tmp, int* total);
 __device__ __forceinline__ void pyr_sort_block(const MapDims& d, const DevState& s, int b) {
     __shared__ int s_hist[PS_NBK], s_base[PS_NBK];
+    __shared__ int s_sel[8192];
+    __shared__ int s_pick[2];
+    __shared__ int s_scan[17];
     const int tid = threadIdx.x;
-    const int P = min(s.pyr_cnt[b], d.capp);
-    if (P == 0) return;
-    const float4* __restrict__ src = s.fov_rec + (size_t)b * d.capp;
-    const int* __restrict__ src_slot = s.fov_slot + (size_t)b * d.capp;
+    const int P_all = min(s.pyr_cnt[b], d.capa);
+    if (P_all == 0) return;
+    const float4* __restrict__ src = s.fov_rec + (size_t)b * d.capa;
+    const int* __restrict__ src_slot = s.fov_slot + (size_t)b * d.capa;
+    int* __restrict__ src_key = s.fov_key + (size_t)b * d.capa;
+    // A full list (:1245-1259): the reference registers a pyramid's particles in the order of its voxel / slot sweep and
+    // turns away what comes after SAFE_PARTICLE_NUM_PYRAMID entries.  The list here was filled in arrival order, but
+    // every entry carries its sweep key: the capp SMALLEST keys stay (radix select of the capp-th key, 4 x 8 bits),
+    // the others lose their slot -- the same particles as in the reference, independent of the arrival order.
+    int kstar = 0x7fffffff;
+    if (P_all > d.capp) {
+        // keys are below v_glob * slots: 13 bits per pass (8192 bins), highest digits first
+        const unsigned kmax = (unsigned)d.v_glob * (unsigned)d.slots;
+        const int nbits = 32 - __clz((int)max(kmax, 2u) - 1);
+        const int npass = (nbits + 12) / 13;
+        unsigned prefix = 0;
+        int want = d.capp;
+        for (int ps = npass - 1; ps >= 0; --ps) {
+            const int shift = ps * 13;
+            for (int q = tid; q < 8192; q += 1024) s_sel[q] = 0;
+            __syncthreads();
+            for (int i0 = 0; i0 < P_all; i0 += 1024) {
+                const int i = i0 + tid;
+                int bin = -1;
+                if (i < P_all) {
+                    const unsigned k = (unsigned)src_key[i];
+                    if (ps == npass - 1 || (k >> (shift + 13)) == (prefix >> (shift + 13))) bin = (int)((k >> shift) & 8191u);
+                }
+                // the keys of a pyramid share their high bits: one LDS atomic per distinct bin of a wavefront, not one per lane
+                u64 todo = __ballot(bin >= 0);
+                while (todo) {
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const int bk = __shfl(bin, leader, WAVE);
+                    const u64 grp = __ballot(bin == bk);
+                    if (lane_id() == leader) atomicAdd(&s_sel[bk], (int)__popcll(grp));
+                    todo &= ~grp;
+                }
+            }
+            __syncthreads();
+            {   // the bin that holds the want-th key: thread t owns bins [8t, 8t + 8); exclusive prefix over the threads
+                int c8[8], mine = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { c8[q] = s_sel[tid * 8 + q]; mine += c8[q]; }
+                int tot;
+                int ex = block_excl_scan_1024(mine, s_scan, &tot);
+                if (ex < want && want <= ex + mine) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (ex < want && want <= ex + c8[q]) { s_pick[0] = tid * 8 + q; s_pick[1] = want - ex; }
+                        ex += c8[q];
+                    }
+                }
+            }
+            __syncthreads();
+            prefix |= (unsigned)s_pick[0] << shift;
+            want = s_pick[1];
+            __syncthreads();
+        }
+        kstar = (int)prefix;
+    }
     if (tid < PS_NBK) s_hist[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < P; i += 1024) atomicAdd(&s_hist[range_bucket(d, src[i])], 1);
+    int removed = 0;
+    for (int i = tid; i < P_all; i += 1024) {
+        const int key_i = src_key[i];
+        const float4 r_i = src[i];   // (requested together with the key: one memory round trip per step)
+        if (key_i <= kstar) atomicAdd(&s_hist[range_bucket(d, r_i)], 1);
+        else if (key_i != 0x7fffffff) {
+            // turned away: the particle vanishes (-2): its cell -> (voxel, slot) -> occupancy bit.  The entry is marked so
+            // that a second preparation of the same lists (stage API: after the prediction and again before the update)
+            // changes nothing.
+            src_key[i] = 0x7fffffff;
+            const int c = src_slot[i];
+            const int tile = c / (64 * d.slots), rem = c - tile * 64 * d.slots, slot = rem >> 6, lv = tile * 64 + (rem & 63);
+            atomicAnd(&s.mask[(size_t)lv * d.mw + (slot >> 6)], ~(1ull << (slot & 63)));
+            ++removed;
+        }
+    }
+    if (__ballot(removed != 0)) { removed = wave_sum_i(removed); if (lane_id() == 0 && removed) atomicAdd(&s.fs->n_pyr_removed, removed); }
     __syncthreads();
     if (tid < PS_NBK) {   // exclusive scan over the 128 buckets: two waves
         const int c = s_hist[tid];
@@ -163,12 +239,15 @@ __device__ __forceinline__ void pyr_sort_block(const MapDims& d, const DevState&
         s_hist[tid] = 0;
     }
     __syncthreads();
-    for (int i = tid; i < P; i += 1024) {
+    for (int i = tid; i < P_all; i += 1024) {
+        const int key_i = src_key[i];
         const float4 r = src[i];
+        const int sl_i = src_slot[i];
+        if (key_i > kstar) continue;
         const int k = range_bucket(d, r);
         const int pos = s_base[k] + atomicAdd(&s_hist[k], 1);
         s.fov_rec_s[(size_t)b * d.capp + pos] = r;
-        s.fov_slot_s[(size_t)b * d.capp + pos] = src_slot[i];
+        s.fov_slot_s[(size_t)b * d.capp + pos] = sl_i;
     }
 }
 __device__ __forceinline__ void pyr_items_block(const MapDims& d, const DevState& s, int* __restrict__ ck_items, int* __restrict__ wu_items,
@@ -901,6 +980,9 @@ void launch_obs_bin(const LaunchCtx& c, int n_pts_grid) {
 
 // map corner farther than 12 cull radii: most pairs are far (28 % at 8 radii, 72 % at 16, measured) -> k_weight<true>
 static bool weight_culls(const LaunchCtx& c) { return (float)PS_NBK / c.d.rng_inv_bw > 12.f * c.fp.cull_r; }
+void launch_pyr_prepare(const LaunchCtx& c) {
+    hipLaunchKernelGGL(k_pyr_prepare, dim3(c.d.np + 1), dim3(1024), 0, c.stream, c.d, c.s, c.k.ck_items, c.k.wu_items, c.k.n_items, c.k.nb_tab);
+}
 void launch_ck_partial(const LaunchCtx& c) {
     hipLaunchKernelGGL(k_pyr_prepare, dim3(c.d.np + 1), dim3(1024), 0, c.stream, c.d, c.s, c.k.ck_items, c.k.wu_items, c.k.n_items, c.k.nb_tab);
     hipLaunchKernelGGL(k_ck_partial, dim3(4096), dim3(CK_TPB), (sizeof(float4) + sizeof(int)) * (size_t)c.d.nbins * DSP_OBS_CAP, c.stream, c.d, c.s, c.fp, c.k.ck_items, c.k.n_items, c.k.nb_tab);

@@ -445,10 +445,11 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
             st_rec(i, a, b);
             const int pyr = __float_as_int(a.x), sl = __float_as_int(a.y);   // sl = (slot << 6) | lane
             const int pos = s_hist[pyr] + __float_as_int(b.z);
-            if (pos < d.capp) {
-                const size_t o = (size_t)pyr * d.capp + pos;
+            if (pos < d.capa) {
+                const size_t o = (size_t)pyr * d.capa + pos;
                 s.fov_rec[o] = make_float4(a.z, a.w, b.x, b.y);
                 s.fov_slot[o] = (int)(((size_t)BX * d.slots + (sl >> 6)) * 64 + (sl & 63));
+                s.fov_key[o] = (BX * 64 + (sl & 63) + d.v_base) * d.slots + (sl >> 6);   // a stayer's sweep key is its own cell
             } else {
                 // pyramid list full: the particle vanishes (-2, :1256-1259)
                 atomicAnd(&s_keep[((sl >> 12) & 1) * 64 + (sl & 63)], ~(1ull << ((sl >> 6) & 63)));
@@ -471,10 +472,11 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
             float4 a, b;
             st_rec(i0 + j * NW * 64 + tid, a, b);
             const int sl = __float_as_int(a.y);   // (slot << 6) | lane
-            if (pos[j] < d.capp) {
-                const size_t o = (size_t)key[j] * d.capp + pos[j];
+            if (pos[j] < d.capa) {
+                const size_t o = (size_t)key[j] * d.capa + pos[j];
                 s.fov_rec[o] = make_float4(a.z, a.w, b.x, b.y);
                 s.fov_slot[o] = (int)(((size_t)BX * d.slots + (sl >> 6)) * 64 + (sl & 63));
+                s.fov_key[o] = (BX * 64 + (sl & 63) + d.v_base) * d.slots + (sl >> 6);
             } else {
                 // pyramid list full: the particle vanishes (-2, :1256-1259)
                 atomicAnd(&s_keep[((sl >> 12) & 1) * 64 + (sl & 63)], ~(1ull << ((sl >> 6) & 63)));
@@ -623,13 +625,14 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
     for (int i0 = 0; i0 < n; i0 += 256) {
         const int i = i0 + tid;
         int key[1] = {-1}, pos[1];
-        int ln = 0, nsl = -1;
+        int ln = 0, nsl = -1, skey = 0;
         size_t nidx = 0;
         float px = 0, py = 0, pz = 0, w = 0;
         if (i < n) {
             const float4 a = i == tid ? a0 : in_rec[(base + i) * 2];
             const float4 b = i == tid ? b0 : in_rec[(base + i) * 2 + 1];
             px = a.w; py = b.x; pz = b.y; w = b.z;
+            skey = __float_as_int(b.w);
             ln = (__float_as_int(a.x) - d.v_base) & 63;
             if (exact) {
                 // position of this arrival in the reference's service order of its destination voxel, in closed form:
@@ -705,10 +708,11 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
         if (nsl >= 0) {
             bool keep = true;
             if (key[0] >= 0) {
-                if (pos[0] < d.capp) {
-                    const size_t o = (size_t)key[0] * d.capp + pos[0];
+                if (pos[0] < d.capa) {
+                    const size_t o = (size_t)key[0] * d.capa + pos[0];
                     s.fov_rec[o] = make_float4(px, py, pz, w);
                     s.fov_slot[o] = (int)nidx;
+                    s.fov_key[o] = skey;   // a mover is registered when the sweep reaches its SOURCE cell
                 } else {
                     ++c_pf;  // :1256-1259
                     keep = false;
@@ -1360,7 +1364,7 @@ __global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScra
     }
     if (tid == 0) {
         s.fs->n_live_in = out[0]; s.fs->n_out_of_map = out[1];
-        s.fs->n_pyramid_full = out[2] + out[5]; s.fs->n_moved = out[3];
+        s.fs->n_pyramid_full = out[2] + out[5] + s.fs->n_pyr_removed; s.fs->n_moved = out[3];
         s.fs->n_voxel_full = out[4] + s.fs->n_voxel_full_import; s.fs->n_live_out = out[6];
         int nf = 0;
         for (int b = 0; b < d.np; ++b) nf += min(s.pyr_cnt[b], d.capp);

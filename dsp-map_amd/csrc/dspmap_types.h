@@ -39,6 +39,7 @@ struct MapDims {
     int M;                 // MAX_PARTICLE_NUM_VOXEL :43
     int np_h, np_v, np;    // pyramids :58-60
     int capp;              // SAFE_PARTICLE_NUM_PYRAMID :66
+    int capa;              // entries a pyramid's UNSORTED list can hold (capp + 25 %): k_pyr_prepare keeps the capp smallest keys
     int T;                 // PREDICTION_TIMES :46
     int nn;                // pyramid neighbourhood radius: 1 = 3x3 (:1135-1136), 2 = 5x5 (dsp_dynamic_multiple_neighbors.h)
     int nbins;             // (2*nn+1)^2
@@ -82,6 +83,7 @@ struct FrameScalars {
     int n_exp_up, n_exp_down;
     int occupied_count; // readout
     int n_voxel_full_import; // multi-GPU: movers received from a neighbour that found their voxel full
+    int n_pyr_removed;  // particles k_pyr_prepare turned away because their pyramid's list was full (-2, :1256-1259)
     float expected_newborn;  // expected_new_born_objects :292
     float newborn_w;         // updated_weight_new_born :805
     float cur_pos[3];        // current_position :131
@@ -150,8 +152,9 @@ struct DevState {
                             // so that the rank and the split can run in the same launch)
     int* nstatic;           // [birth_cap] (multi-GPU all-reduce(max) buffer)
     // FOV staging
-    float4* fov_rec;   // [np*capp] {x,y,z,w}
-    int* fov_slot;     // [np*capp] local slot index (lv*slots+s)
+    float4* fov_rec;   // [np*capa] {x,y,z,w}
+    int* fov_slot;     // [np*capa] cell index of the particle (pidx)
+    int* fov_key;      // [np*capa] its sweep key (source voxel * slots + slot): the reference registers a pyramid's particles in this order
     float4* fov_rec_s; // the same lists ordered by range bucket (k_pyr_sort), read by the pair kernels
     int* fov_slot_s;
     int* pyr_cnt;      // [np]

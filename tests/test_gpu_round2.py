@@ -159,18 +159,9 @@ def test_resample_copies_into_the_second_occupancy_word(dsp, orc):
     o.close(); m.close()
 
 
-def test_pyramid_list_overflow_bounds(dsp, orc):
-    """pyramid-list overflow (-2, :1245-1259): a pyramid registers at most SAFE_PARTICLE_NUM_PYRAMID particles; the ones
-    that do not fit are removed.  WHICH of a pyramid's candidates are turned away depends on the order they arrive in (the
-    reference: its voxel/slot sweep; here: the order the workgroups finish in), so the assertion is the multiset bound:
-    same list lengths, same number of removals per pyramid, survivors are a subset of the candidates, everything outside
-    the overflowing pyramids is identical."""
-    cfgkw = dict(nx=40, ny=40, nz=10, res=0.15, ppv=9)
-    o, m = make_pair(dsp, orc, **cfgkw)
-    assert m.capp == o.capp == 66
+def _fill_view(o, m, n, seed, vmax=0.0):
     half = common.half_extent(o.cfg)
-    rng = np.random.default_rng(8)
-    n = 90000
+    rng = np.random.default_rng(seed)
     # inside the field of view (x forward, +-42 / +-24 degrees), spread over the map's depth
     r = rng.uniform(0.3, half[0] * 0.95, n)
     az = np.radians(rng.uniform(-40, 40, n)); el = np.radians(rng.uniform(-22, 22, n))
@@ -178,35 +169,56 @@ def test_pyramid_list_overflow_bounds(dsp, orc):
     pz = (r * np.cos(az) * np.tan(el)).astype(np.float32)
     keep = (np.abs(py) < half[1] * 0.98) & (np.abs(pz) < half[2] * 0.98) & (np.abs(px) < half[0] * 0.98)
     px, py, pz = px[keep], py[keep], pz[keep]
-    z = np.zeros(len(px), np.float32)
+    vx = (rng.uniform(-vmax, vmax, len(px))).astype(np.float32)
+    vy = (rng.uniform(-vmax, vmax, len(px))).astype(np.float32)
     w = rng.uniform(0.01, 0.05, len(px)).astype(np.float32)
-    n_in = common.inject_both(o, m, px, py, pz, z, z, w)
+    return common.inject_both(o, m, px, py, pz, vx, vy, w)
+
+
+def test_pyramid_list_overflow_in_sweep_order(dsp, orc):
+    """pyramid-list overflow (-2, :1245-1259): a pyramid registers at most SAFE_PARTICLE_NUM_PYRAMID particles, in the
+    order of the reference's voxel / slot sweep; the ones that come later are removed.  Every list entry carries its sweep
+    key and k_pyr_prepare keeps the SAFE_PARTICLE_NUM_PYRAMID smallest keys of a full list: the same particles survive as in
+    the oracle -- in the same slots when nobody changes voxel, and as the same set of particles when they do (a slot freed
+    by a turned-away mover is not re-used by the arrivals behind it in the same sweep; documented deviation)."""
+    cfgkw = dict(nx=40, ny=40, nz=10, res=0.15, ppv=9)
+    o, m = make_pair(dsp, orc, **cfgkw)
+    assert m.capp == o.capp == 66
+    n_in = _fill_view(o, m, 90000, 8)
     empty = np.zeros((0, 3), np.float32)
     o.bin_points(empty); m.bin_points(empty)
-    vo0, so0, ro0 = o.export_sparse()
     o.predict(0.0, 0.0, 0.0, 0.0); m.predict(0.0, 0.0, 0.0, 0.0)          # nobody moves: candidates = the particles in view
     len_o = (o.pyramid_lists[:, :, 0] != 0).sum(1)
-    len_g = m.pyramid_counts()
-    assert np.array_equal(len_o, len_g) and (len_o == o.capp).sum() > 20   # many full lists
+    assert np.array_equal(len_o, m.pyramid_counts()) and (len_o == o.capp).sum() > 20   # many full lists
     c = m.counters()
+    ro, rg = _slots_equal(o, m, cols=(1, 2, 4, 5, 6, 7))                   # the same particles in the same slots
+    assert len(ro) == n_in - c["n_pyramid_full"] and c["n_pyramid_full"] > 500
+    assert c["n_fov"] == int(len_o.sum())
+    # a second frame on the survivors (lists full again), then the weight update on both
+    o.predict(0.0, 0.0, 0.0, 0.0); m.predict(0.0, 0.0, 0.0, 0.0)
+    _slots_equal(o, m, cols=(1, 2, 4, 5, 6, 7))
+    o.close(); m.close()
+    # with motion: movers and stayers compete for the list in sweep order
+    o, m = make_pair(dsp, orc, **cfgkw)
+    n_in = _fill_view(o, m, 90000, 9, vmax=1.5)
+    o.bin_points(empty); m.bin_points(empty)
+    o.predict(-0.03, 0.02, 0.0, 0.1); m.predict(-0.03, 0.02, 0.0, 0.1)
+    len_o = (o.pyramid_lists[:, :, 0] != 0).sum(1)
+    len_g = m.pyramid_counts()
+    assert (len_o == o.capp).sum() >= 5, (len_o == o.capp).sum()
+    # (the documented deviation: in a FULL voxel a slot freed by a turned-away mover is not re-used in the same sweep)
+    assert (len_o != len_g).sum() <= 0.02 * o.NP and np.abs(len_o - len_g).max() <= 2, np.nonzero(len_o != len_g)
+    c = m.counters()
+    assert c["n_moved"] > 1000 and c["n_pyramid_full"] > 50, c
     vo, so, ro = o.export_sparse()
     vg, sg, rg = gpu_state(m)
-    assert len(vo) == len(vg) == n_in - c["n_pyramid_full"] and c["n_pyramid_full"] > 500
-    assert c["n_fov"] == int(len_o.sum())
-    # survivors are a subset of the injected particles, at their original slots
-    key0 = set(zip(vo0.tolist(), so0.tolist()))
-    assert set(zip(vg.tolist(), sg.tolist())) <= key0
-    # same number of survivors per pyramid (particles keep their position: classify them with the oracle's geometry)
-    def pyr_of(rec):
-        out = np.full(len(rec), -1)
-        for i, p in enumerate(rec):
-            if o.L.dspo_in_pyramids_area(o.h, float(p[4]), float(p[5]), float(p[6])):
-                out[i] = o.L.dspo_pyramid_h(o.h, float(p[4]), float(p[5]), float(p[6])) * 16 + \
-                    o.L.dspo_pyramid_v(o.h, float(p[4]), float(p[5]), float(p[6]))
-        return out
-    po, pg = pyr_of(ro), pyr_of(rg)
-    assert np.array_equal(np.bincount(po[po >= 0], minlength=o.NP), np.bincount(pg[pg >= 0], minlength=o.NP))
-    assert (po < 0).sum() == (pg < 0).sum()                                # particles outside the view are never removed
+    a_v, a_r = common.sorted_records(vo, ro, cols=(4, 5, 6, 1, 2, 7))
+    b_v, b_r = common.sorted_records(vg, rg, cols=(4, 5, 6, 1, 2, 7))
+    same = len(a_v) == len(b_v) and np.array_equal(a_v, b_v) and np.array_equal(a_r[:, 1:8], b_r[:, 1:8])
+    if not same:   # the documented deviation can only cost particles in voxels that were full: bound it
+        key_o = set(map(tuple, np.column_stack([vo, ro[:, 4:7].view(np.int32)]).tolist()))
+        key_g = set(map(tuple, np.column_stack([vg, rg[:, 4:7].view(np.int32)]).tolist()))
+        assert len(key_o ^ key_g) <= 0.002 * len(key_o), (len(key_o), len(key_g), len(key_o ^ key_g))
     o.close(); m.close()
 
 
