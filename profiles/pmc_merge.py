@@ -1,5 +1,5 @@
 """Merge the outputs of profiles/collect.sh (gpurun_out/<tag>_*) into the tracked summaries:
-   profiles/pmc_traffic_r01.json  (read by bench.py for roofline.traffic)
+   profiles/pmc_traffic.json  (read by bench.py for roofline.traffic; pmc_traffic_r01.json is round 1's)
    profiles/<tag>_pmc_traffic.md, profiles/<tag>_kernel_stats.md, profiles/<tag>_<W>_kernel_stats.csv"""
 import io
 import json
@@ -58,7 +58,7 @@ def main(tag):
                "| kernel | FETCH_SIZE KB | WRITE_SIZE KB | corrected HBM bytes / launch |", "|---|---|---|---|"]
         for k, v in out["workloads"][w].items():
             md.append("| %s | %.1f | %.1f | %s |" % (k, v["fetch_kb"], v["write_kb"], format(v["hbm_bytes"], ",")))
-    json.dump(out, open(os.path.join(HERE, "pmc_traffic_r01.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(HERE, "pmc_traffic.json"), "w"), indent=1)
     open(os.path.join(HERE, tag + "_pmc_traffic.md"), "w").write("\n".join(md) + "\n")
     buf = io.StringIO()
     with redirect_stdout(buf):

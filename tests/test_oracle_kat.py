@@ -280,3 +280,42 @@ def test_preprocess_voxel_grid_properties(orc):
     face = np.array([[0.0, 0.0, 4.95]], np.float32)                   # z_cam -> x = 4.95 = x_max
     o2, _ = orc.preprocess_cloud(face, leaf, half, swap_axes=True)
     assert len(o2) == 0
+
+
+def test_workload_statistics_match_the_reference_probe(orc):
+    """SURVEY 6.1 records workload statistics of the REAL reference header (66x66x40, M = 24, wavy wall ~3 m ahead filling
+    the field of view, ~1300 observations, sensor 0.5 m/s forward with a +-5 cm bob, steady state after ~20 frames):
+    ~39 k live particles, ~14 % of them change voxel per prediction, fullest voxel = 24 (the cap :993-994), resample copies
+    of the order of 15 % of the live set, no particle lost to overflow.  The probe's exact scene is not recorded, so this is
+    a SOFT pin: the oracle on a scene built from that description must land in the same regime (bounds below), and hit the
+    exact invariants (fullest voxel == M, nothing lost)."""
+    o = orc.Oracle(orc.make_config(nx=66, ny=66, nz=40, res=0.15, ppv=24))
+    p, v, r = common.tables(7, n=2000003)
+    o.set_tables(p, v, r)
+    ys = np.arange(-3.2, 3.2, 0.1); zs = np.arange(-1.6, 1.6, 0.1)
+    Y, Z = np.meshgrid(ys, zs)
+    pts = np.stack([(3.0 + 0.2 * np.sin(2 * Y)).ravel(), Y.ravel(), Z.ravel()], 1).astype(np.float32)
+    stats, last = [], None
+    for f in range(32):
+        t = f / 30.0
+        pos = (0.5 * t, 0.0, 0.05 * np.sin(2 * np.pi * t))
+        last = last or pos
+        dp = [np.float32(pos[i]) - np.float32(last[i]) for i in range(3)]
+        last = pos
+        o.L.dspo_set_current_position(o.h, *[float(x) for x in pos])
+        n_obs = o.bin_points(pts)
+        o.L.dspo_static_birth_cloud(o.h)
+        o.predict(float(-dp[0]), float(-dp[1]), float(-dp[2]), 1 / 30.0 if f else 0.0)
+        fl = o.particles[:, :, 0]
+        live_in, moved = int((fl > 0.1).sum()), int((np.abs(fl - 7) < 0.1).sum())
+        o.map_update(); o.add_newborn(); o.occupancy_resample()
+        fl = o.particles[:, :, 0]
+        stats.append((n_obs, live_in, moved, int((np.abs(fl - 0.6) < 0.05).sum()), int((fl > 0.1).sum()), int((fl > 0.1).sum(1).max())))
+        o.L.dspo_clear_future(o.h)
+    s = np.array(stats[22:], np.float64)
+    assert 1000 < s[:, 0].mean() < 1700                       # ~1300 observations
+    assert 25e3 < s[:, 1].mean() < 60e3                       # ~39 k live particles
+    assert 0.09 < (s[:, 2] / s[:, 1]).mean() < 0.22           # ~14 % change voxel per step
+    assert 0.05 < (s[:, 3] / s[:, 4]).mean() < 0.30           # copies: of the order of 15 % of the live set
+    assert s[:, 5].max() == 24                                # fullest voxel after resampling = MAX_PARTICLE_NUM_VOXEL
+    o.close()
