@@ -38,6 +38,7 @@
 #define VE_HB 4096                  // hash buckets
 #define VE_NIL 0xffffu
 #define VE_HMAX (VE_CAP / 5 + 8)    // clusters have >= 5 points
+#define VE_KLDS 128                 // clusters whose records k_ve_clusters keeps in LDS
 
 // exclusive prefix sum over a 1024-thread workgroup; s_tmp: 17 ints
 __device__ __forceinline__ int ve_excl_scan(int v, int* s_tmp, int* total) {
@@ -250,13 +251,16 @@ __device__ __forceinline__ void ve_clusters_block(const DevState& s, const VelEs
     __shared__ int s_hp[VE_HMAX], s_way[VE_HMAX], s_used[VE_HMAX];     // row of a column, predecessor column, column used
     __shared__ int s_cnt[1024];
     __shared__ int s_tmp[17];
+    __shared__ int s_root[VE_CAP];              // root (view index) of every view point, -1 = ground
+    __shared__ VeCluster s_cl[VE_KLDS];         // the usual few dozen clusters live in LDS (more: the global arrays)
+    __shared__ int s_rank[VE_KLDS], s_byrank[VE_KLDS], s_dyn[VE_KLDS];
     __shared__ int s_k, s_ndyn;
     __shared__ double s_big;
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
     const int n = ve.n[0];
+    const int r_cur = s.fs->r_cur;   // (requested now: the per-cluster draws below need it)
     if (n == 0) return;   // :1379: an empty view leaves the previous output (and the previous clusters) untouched
     const int n_ng = ve.n[1];
-    VeCluster* cl = ve.cl;
     VE_MARK(0);
     // ---- merge the spanning forests of k_ve_components' slices: the union-find over the non-ground points lives in
     //      s_key[0] for the moment; root of a component = its smallest index
@@ -277,12 +281,13 @@ __device__ __forceinline__ void ve_clusters_block(const DevState& s, const VelEs
             ve_union(parent, (int)(pr >> 16), (int)(pr & 0xffffu));
         }
         __syncthreads();
-        for (int g = tid; g < n_ng; g += VE_NT) ve.root[ve.ng_view[g]] = ve.ng_view[ve_find(parent, g)];
-        __threadfence_block();
+        for (int i = tid; i < n; i += VE_NT) s_root[i] = -1;   // ground points take no part in the clustering
+        __syncthreads();
+        for (int g = tid; g < n_ng; g += VE_NT) s_root[ve.ng_view[g]] = ve.ng_view[ve_find(parent, g)];
         __syncthreads();
     }
     VE_MARK(1);
-    const int* root_of = ve.root;    // [cap] view index of the component's first point, -1 = ground
+    const int* root_of = s_root;     // view index of the component's first point, -1 = ground
     int* size_of = (int*)s_key[1];   // component size at its root; later -1 - (rank of the cluster)
     // ---- component sizes (one LDS atomic per distinct root of a wavefront's 64 points)
     for (int i = tid; i < VE_CAP; i += VE_NT) size_of[i] = 0;
@@ -322,17 +327,32 @@ __device__ __forceinline__ void ve_clusters_block(const DevState& s, const VelEs
                 c.cx = c.cy = c.cz = 0.f; c.point_num = size_of[i];
                 c.vx = c.vy = c.vz = -10000.f; c.intensity = 0.f;   // :104-108
                 c.root = i; c.start = 0; c.is_dyn = 0; c.dyn_idx = -1;
-                cl[k++] = c;
+                ve.cl[k++] = c;
             }
         }
         if (tid == 0) s_k = tot;
     }
     __syncthreads();
     const int K = s_k;
+    // the usual few dozen clusters: their records and index arrays move to LDS (the phases below are chains of
+    // dependent reads of these small arrays -- an LDS access each instead of an L2 round trip)
+    const bool k_lds = K <= VE_KLDS;
+    if (k_lds) for (int k = tid; k < K; k += VE_NT) s_cl[k] = ve.cl[k];
+    __syncthreads();
+    VeCluster* cl = k_lds ? s_cl : ve.cl;
+    int* dyn_list = k_lds ? s_dyn : ve.dyn_list;
+    // the clusters' display intensities (:1422: one rand() per cluster, in cluster order) are requested now -- a random
+    // access into the 16 MB table, i.e. an HBM round trip that the ranking and the sort below hide
+    float my_int[(VE_HMAX + VE_NT - 1) / VE_NT];
+#pragma unroll
+    for (int q = 0; q < (VE_HMAX + VE_NT - 1) / VE_NT; ++q) {
+        const int r = q * VE_NT + tid;
+        my_int[q] = r < K ? ve_rand_float(s, fp.rtab_n, r_cur + r, 0.1f, 1.f) : 0.f;
+    }
     VE_MARK(3);
     // ---- PCL returns the clusters largest first (equal sizes: seed order); rank -> position in that order
-    int* rank_of = ve.rank;      // [cap/5+8] rank of cluster k; later its output base
-    int* by_rank = ve.by_rank;   // inverse
+    int* rank_of = k_lds ? s_rank : ve.rank;        // rank of cluster k; later its output base
+    int* by_rank = k_lds ? s_byrank : ve.by_rank;   // inverse
     for (int k = tid; k < K; k += VE_NT) {
         const int sz = cl[k].point_num;
         int r = 0;
@@ -341,6 +361,11 @@ __device__ __forceinline__ void ve_clusters_block(const DevState& s, const VelEs
     }
     __syncthreads();
     for (int k = tid; k < K; k += VE_NT) size_of[cl[k].root] = -1 - rank_of[k];   // negative = "the cluster's rank follows"
+#pragma unroll
+    for (int q = 0; q < (VE_HMAX + VE_NT - 1) / VE_NT; ++q) {
+        const int r = q * VE_NT + tid;
+        if (r < K) cl[by_rank[r]].intensity = my_int[q];
+    }
     __syncthreads();
     VE_MARK(4);
     // ---- order the clustered points by (cluster rank, point index): the keys start in index order, so a STABLE sort by
@@ -377,10 +402,8 @@ __device__ __forceinline__ void ve_clusters_block(const DevState& s, const VelEs
     // ---- per cluster (in rank order): intensity draw (:1422, every cluster), centroid (:1424-1434), static test (:1436).
     //      One wavefront per cluster: 64 members are fetched at once, then summed one after another in ascending index
     //      (the reference's fp32 order) by every lane redundantly.
-    const int r_cur = s.fs->r_cur;
     for (int r = wave; r < K; r += VE_NT / 64) {
         VeCluster c = cl[by_rank[r]];
-        c.intensity = ve_rand_float(s, fp.rtab_n, r_cur + r, 0.1f, 1.f);
         bool stat = c.point_num > 200;      // DYNAMIC_CLUSTER_MAX_POINT_NUM :52 (such a cluster's centroid is never used)
         if (!stat) {
             float ax = 0.f, ay = 0.f, az = 0.f;
@@ -415,7 +438,7 @@ __device__ __forceinline__ void ve_clusters_block(const DevState& s, const VelEs
             const int r = b0 + tid;
             int tot;
             const int di = run + ve_excl_scan(r < K ? cl[by_rank[r]].is_dyn : 0, s_tmp, &tot);
-            if (r < K && cl[by_rank[r]].is_dyn) { cl[by_rank[r]].dyn_idx = di; ve.dyn_list[di] = by_rank[r]; }
+            if (r < K && cl[by_rank[r]].is_dyn) { cl[by_rank[r]].dyn_idx = di; dyn_list[di] = by_rank[r]; }
             run += tot;
         }
         if (tid == 0) s_ndyn = run;
@@ -435,7 +458,7 @@ __device__ __forceinline__ void ve_clusters_block(const DevState& s, const VelEs
             double big = 0.0;
             for (int e = tid; e < nr * nc; e += VE_NT) {
                 bool g;
-                big = fmax(big, (double)ve_cost(cl[ve.dyn_list[e / nc]], ve.last, e % nc, &g));
+                big = fmax(big, (double)ve_cost(cl[dyn_list[e / nc]], ve.last, e % nc, &g));
             }
             for (int o = 32; o > 0; o >>= 1) big = fmax(big, __shfl_xor(big, o, WAVE));
             if (l == 0) atomicMax((unsigned long long*)&s_big, (unsigned long long)__double_as_longlong(big));   // non-negative doubles order like integers
@@ -449,7 +472,7 @@ __device__ __forceinline__ void ve_clusters_block(const DevState& s, const VelEs
             for (int e = tid; e < N * N; e += VE_NT) {
                 const int i0 = e / N, j = e % N;
                 float a = (float)big;
-                if (i0 < nr && j < nc) { bool g; a = ve_cost(cl[ve.dyn_list[i0]], ve.last, j, &g); }
+                if (i0 < nr && j < nc) { bool g; a = ve_cost(cl[dyn_list[i0]], ve.last, j, &g); }
                 s_cost[e] = a;
             }
         __syncthreads();
@@ -472,7 +495,7 @@ __device__ __forceinline__ void ve_clusters_block(const DevState& s, const VelEs
                         if (j >= 1 && !s_used[j]) {
                             double a = big;
                             if (in_lds) a = (double)s_cost[(i0 - 1) * N + (j - 1)];
-                            else if (i0 <= nr && j <= nc) { bool g; a = (double)ve_cost(cl[ve.dyn_list[i0 - 1]], ve.last, j - 1, &g); }
+                            else if (i0 <= nr && j <= nc) { bool g; a = (double)ve_cost(cl[dyn_list[i0 - 1]], ve.last, j - 1, &g); }
                             const double cur = a - ui0 - s_hv[j];
                             double mv = s_minv[j];
                             if (cur < mv) { mv = cur; s_minv[j] = cur; s_way[j] = j0; }
@@ -504,7 +527,7 @@ __device__ __forceinline__ void ve_clusters_block(const DevState& s, const VelEs
         for (int j = 1 + tid; j <= N; j += VE_NT) {
             const int i = s_hp[j];
             if (i >= 1 && i <= nr && j <= nc) {
-                VeCluster c = cl[ve.dyn_list[i - 1]];
+                VeCluster c = cl[dyn_list[i - 1]];
                 bool gate;
                 (void)ve_cost(c, ve.last, j - 1, &gate);
                 if (gate) {
@@ -514,7 +537,7 @@ __device__ __forceinline__ void ve_clusters_block(const DevState& s, const VelEs
                     const float v = sqrtf(c.vx * c.vx + c.vy * c.vy + c.vz * c.vz);
                     c.intensity = ve.last[(j - 1) * 5 + 4];
                     if (v > 5.f) c.vx = c.vy = c.vz = 0.f;
-                    cl[ve.dyn_list[i - 1]] = c;
+                    cl[dyn_list[i - 1]] = c;
                 }
             }
         }
@@ -580,7 +603,7 @@ __device__ __forceinline__ void ve_clusters_block(const DevState& s, const VelEs
     VE_MARK(10);
     // ---- clusters_feature_vector_dynamic_last = clusters_feature_vector_dynamic (:1542); the rand() stream moved on by K
     for (int d0 = tid; d0 < n_dyn; d0 += VE_NT) {
-        const VeCluster c = cl[ve.dyn_list[d0]];
+        const VeCluster c = cl[dyn_list[d0]];
         ve.last[d0 * 5] = c.cx; ve.last[d0 * 5 + 1] = c.cy; ve.last[d0 * 5 + 2] = c.cz;
         ve.last[d0 * 5 + 3] = __int_as_float(c.point_num); ve.last[d0 * 5 + 4] = c.intensity;
     }
