@@ -15,6 +15,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -170,6 +171,13 @@ def main():
         torch.cuda.synchronize()
         return out
 
+    def quiet_host():
+        """The harness is Python, the product's host side is C++ (include/dsp_dynamic.h): a generation-2 pass of the
+        interpreter's collector over torch's object graph takes ~35 ms -- 180 frames of the headline workload -- and would
+        land inside a 20-step timed region at random.  Collect now, keep the collector off until the region ends."""
+        gc.collect()
+        gc.disable()
+
     def run_frames(m, frames):
         for pts, pos, quat, t in frames:
             rc = m.update_device(pts.data_ptr(), pts.shape[0], pos, t, quat)
@@ -190,6 +198,7 @@ def main():
             m.seed_uniform(w["ppv"], 0.01, 99, w.get("vmax", 0.0))  # M zero-velocity particles in every voxel
         run_frames(m, frames[:prefill])
         run_frames(m, frames[prefill:prefill + warmup])
+        quiet_host()
         barrier()
         t0 = time.perf_counter()
         run_frames(m, frames[prefill + warmup:prefill + warmup + steps])
@@ -197,6 +206,7 @@ def main():
         m.sync()
         barrier()
         dt = time.perf_counter() - t0
+        gc.enable()
         measure.host_issue_ms = t_issue / steps * 1e3
         cnt = m.counters()
         stage = None
@@ -231,12 +241,14 @@ def main():
                 rk.map.clearOccupancyMapPrediction()
         run(frames[:prefill + warmup])
         rk.sync()
+        quiet_host()
         barrier()
         t0 = time.perf_counter()
         run(frames[prefill + warmup:])
         rk.sync()
         barrier()
         dt = time.perf_counter() - t0
+        gc.enable()
         cnt = rk.map.counters()
         keys = ("n_live_in", "n_fov", "n_born", "n_obs", "n_moved", "n_out_of_map", "n_voxel_full", "n_pyramid_full", "n_live_out")
         tot = torch.tensor([cnt[k] for k in keys], device=dev, dtype=torch.float64)
