@@ -758,6 +758,7 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
             HIPCHK(m, hipStreamBeginCapture(m->stream, hipStreamCaptureModeRelaxed));
             enqueue_frame(m, c, m->pt_cap, m->birth_cap, false, mode == 1, mode == 2);  // (fork=true measured slower: HIP replays multi-branch graphs with a much higher launch cost) grids sized for the capacity; kernels bound-check against fpar
             HIPCHK(m, hipStreamEndCapture(m->stream, &m->graph));
+            if (const char* dot = getenv("DSPMAP_GRAPH_DOT")) (void)hipGraphDebugDotPrint(m->graph, dot, 0);   // diagnostics: the frame's nodes and edges
             HIPCHK(m, hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
             (void)hipGraphDestroy(m->graph);   // the executable graph keeps its own copy of the topology
             m->graph = nullptr;
