@@ -19,7 +19,7 @@ OK, REJECTED = 1, 0
 
 P_POSITION_STDDEV, P_VELOCITY_STDDEV, P_OBSERVATION_STDDEV, P_NEWBORN_WEIGHT, P_NEWBORN_NUMBER, \
     P_VOXEL_FILTER_RES, P_KAPPA, P_DETECTION, P_VELOCITY_ESTIMATOR, P_REGENERATE_TABLES, P_USE_GRAPH, P_OCCLUSION_MARGIN, \
-    P_PAIR_CULL_SIGMAS, P_UPDATE_TIME, P_UPDATE_COUNTER = range(1, 16)
+    P_PAIR_CULL_SIGMAS, P_UPDATE_TIME, P_UPDATE_COUNTER, P_PLACE_SPLIT_TILES = range(1, 17)
 
 
 class Config(C.Structure):
@@ -93,6 +93,7 @@ SIGNATURES = {
     "dspmap_set_profiling": (_i, [_P, _i]),
     "dspmap_get_stage_ms": (_i, [_P, _fp, _ip]),
     "dspmap_debug_stream": (_i, [_P, _i, C.POINTER(C.c_longlong)]),
+    "dspmap_debug_tile_view": (_i, [_P, C.POINTER(C.c_int), _i]),
     "dspmap_clear_state": (_i, [_P]),
     "dspmap_import_state": (_i, [_P, _i, _P, _P, _P]),
     "dspmap_export_state": (_i, [_P, _i, _P, _P, _P, _ip]),
@@ -337,6 +338,14 @@ class DSPMap:
         idx = C.c_int()
         ok = self.L.dspmap_point_voxel_index(self.h, px, py, pz, C.byref(idx))
         return ok, idx.value
+
+    def debug_tile_fov(self):
+        n = (self.V_local + 63) // 64
+        out = np.zeros(n, np.int32)
+        got = self.L.dspmap_debug_tile_view(self.h, out.ctypes.data_as(C.POINTER(C.c_int)), n)
+        if got < 0:
+            self._chk(got)
+        return out[:got]
 
     def counters(self):
         c = Counters()

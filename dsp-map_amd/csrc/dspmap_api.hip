@@ -5,6 +5,7 @@
 // compute path here: without a usable HIP device every entry point fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -46,7 +47,7 @@ int dspmap_fail(dspmap* m, int code, const char* fmt, ...) {
 LaunchCtx dspmap_ctx_of(dspmap* m) {
     LaunchCtx c;
     c.d = m->d; c.fp = m->fp; c.s = m->s; c.k = m->k; c.stream = m->stream;
-    c.pt_cap = m->pt_cap; c.birth_cap = m->birth_cap;
+    c.pt_cap = m->pt_cap; c.birth_cap = m->birth_cap; c.n_cu = m->n_cu;
     c.k.nbsnap = m->nb_dirty ? m->nbsnap_buf : nullptr;
     c.ve = m->ve;
     return c;
@@ -132,6 +133,7 @@ extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
     refresh_fp(m);
     m->device = cfg->device;
     m->vel.configure(cfg->half_fov_h, cfg->half_fov_v, cfg->angle_resolution);
+    if (const char* e = getenv("DSPMAP_PLACE_SPLIT_TILES")) { const long v = atol(e); if (v > 0) m->place_split_tiles = (int)std::min(v, 2000000000l); }
     return m;
 }
 
@@ -154,7 +156,7 @@ static void free_dev(dspmap* m) {
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, s.fov_rec, s.fov_slot, s.fov_key, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.ro_cnt, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
-                    m->k.part_predict, m->k.part_claim, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev};
+                    m->k.part_predict, m->k.part_claim, m->k.tile_fov, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
     if (m->nbsnap_buf) chk(hipFree(m->nbsnap_buf), "hipFree");
     {
@@ -168,6 +170,7 @@ static void free_dev(dspmap* m) {
     if (m->birth_pin) chk(hipHostFree(m->birth_pin), "hipHostFree");
     if (m->ev_fork) chk(hipEventDestroy(m->ev_fork), "hipEventDestroy");
     if (m->ev_join) chk(hipEventDestroy(m->ev_join), "hipEventDestroy");
+    if (m->ev_fork2) chk(hipEventDestroy(m->ev_fork2), "hipEventDestroy");
     for (hipEvent_t e : m->pev) if (e) chk(hipEventDestroy(e), "hipEventDestroy(prof)");
     if (m->stream2) chk(hipStreamDestroy(m->stream2), "hipStreamDestroy(2)");
     if (m->ev0) chk(hipEventDestroy(m->ev0), "hipEventDestroy");
@@ -278,6 +281,8 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
     HIPCHK(m, hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     HIPCHK(m, hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    HIPCHK(m, hipEventCreateWithFlags(&m->ev_fork2, hipEventDisableTiming));
+    { int dev = 0, cu = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) m->n_cu = cu; }
     HIPCHK(m, hipEventCreate(&m->ev0));
     HIPCHK(m, hipEventCreate(&m->ev1));
     const MapDims& d = m->d;
@@ -332,6 +337,8 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     if (slab) HIPCHK(m, dalloc(&k.expmask, W));
     HIPCHK(m, dalloc(&k.part_predict, (size_t)k.ntiles * 4));
     HIPCHK(m, dalloc(&k.part_claim, (size_t)k.ntiles * 2));
+    HIPCHK(m, dalloc(&k.tile_fov, (size_t)k.ntiles));
+    HIPCHK(m, hipMemset(k.tile_fov, 0, sizeof(int) * (size_t)k.ntiles));
     HIPCHK(m, dalloc(&k.part_resample, (size_t)k.nblk_sweep * 4));
     HIPCHK(m, dalloc(&k.work_list, (size_t)d.v_loc));
     HIPCHK(m, dalloc(&k.vb_cnt, (size_t)d.v_loc));
@@ -432,6 +439,7 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
             if (v != 0 && v != 1 && v != 2) return dspmap_fail(m, DSPMAP_E_ARG, "velocity estimator: 0 off, 1 host stage, 2 device");
             m->use_vel_est = (int)v; break;
         case DSPMAP_P_USE_GRAPH: m->use_graph = v != 0; break;
+        case DSPMAP_P_PLACE_SPLIT_TILES: m->place_split_tiles = v < 1 ? 1 : (v > 2e9 ? 2000000000 : (int)v); m->graph_epoch++; break;
         case DSPMAP_P_OCCLUSION_MARGIN: m->fp.occl_margin = (float)v; break;
         case DSPMAP_P_PAIR_CULL_SIGMAS: if (!(v > 0)) return dspmap_fail(m, DSPMAP_E_ARG, "pair cull radius must be positive"); m->cull_sigmas = (float)v; refresh_fp(m); break;
         case DSPMAP_P_REGENERATE_TABLES:
@@ -461,6 +469,7 @@ extern "C" double dspmap_get_param(const dspmap_t* m, int key) {
         case DSPMAP_P_PAIR_CULL_SIGMAS: return m->cull_sigmas;
         case DSPMAP_P_UPDATE_TIME: return m->update_time;
         case DSPMAP_P_UPDATE_COUNTER: return m->update_counter;
+        case DSPMAP_P_PLACE_SPLIT_TILES: return m->place_split_tiles;
         default: return 0;
     }
 }
@@ -588,6 +597,7 @@ int dspmap_gate_and_delta(dspmap* m, const float pos[3], double stamp, const flo
 // prediction + re-binning: the two only share the rotated planes written by k_reset and meet again at
 // the Ck kernel.
 static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid, bool fork, bool all_static, bool est = false) {
+    const bool split = !fork && !m->prof && c.k.ntiles >= m->place_split_tiles;   // (per-stage timing keeps the frame on one stream)
     dspmap_prof_mark(m, 0);
     if (!fork) {
         launch_setup_and_bin(c, pts_grid, false);   // the gather rides on k_predict's launch
@@ -614,9 +624,16 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
         (void)hipEventRecord(m->ev_join, m->stream2);
         launch_predict_only(c, true, false);
         dspmap_prof_mark(m, 2);
-        launch_claim(c, 0);
+        launch_claim(c, 0, 0, 0, 0, split ? 1 : -1);
+        if (split) {   // the side stream places the arrivals of the tiles outside the field of view (behind the estimator's kernels)
+            launch_pyr_prepare(c);
+            (void)hipEventRecord(m->ev_fork2, m->stream);
+            (void)hipStreamWaitEvent(m->stream2, m->ev_fork2, 0);
+            launch_claim(c2, 0, 0, 0, 0, 0);
+            (void)hipEventRecord(m->ev_join, m->stream2);
+        }
         dspmap_prof_mark(m, 3);
-        launch_ck_partial(c);
+        launch_ck_partial(c, split);
         dspmap_prof_mark(m, 4);
         launch_weight_update(c);
         dspmap_prof_mark(m, 5);
@@ -634,12 +651,25 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     const bool early_birth = !fork && birth_grid > 0;
     launch_predict_only(c, !fork, early_birth);
     dspmap_prof_mark(m, 2);
-    launch_claim(c, early_birth ? birth_grid : 0);
+    launch_claim(c, early_birth ? birth_grid : 0, 0, 0, 0, split ? 1 : -1);
+    if (split) {
+        // Only the arrivals of tiles that can see the field of view are registered in pyramids, so only their placement
+        // has to precede the weight update: the others get their slots on the side stream WHILE the pair kernels run
+        // (VALU-bound; the list preparation before them is itself a scatter and would only share the memory system).
+        launch_pyr_prepare(c);
+        (void)hipEventRecord(m->ev_fork2, m->stream);
+        (void)hipStreamWaitEvent(m->stream2, m->ev_fork2, 0);
+        LaunchCtx c2 = c;
+        c2.stream = m->stream2;
+        launch_claim(c2, 0, 0, 0, 0, 0);
+        (void)hipEventRecord(m->ev_join, m->stream2);
+    }
     if (fork) (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
     dspmap_prof_mark(m, 3);
-    launch_ck_partial(c);
+    launch_ck_partial(c, split);
     dspmap_prof_mark(m, 4);
     launch_weight_update(c);
+    if (split) (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
     dspmap_prof_mark(m, 5);
     if (birth_grid <= 0) launch_ck_finalize(c);   // otherwise k_birth_rank reduces the 1/Ck sums (one launch less)
     dspmap_prof_mark(m, 6);
@@ -1225,6 +1255,13 @@ extern "C" int dspmap_debug_stream(dspmap_t* m, int mode, long long* bytes_out) 
     HIPCHK(m, hipStreamSynchronize(m->stream));
     if (bytes_out) *bytes_out = (long long)(mode == 0 ? S * 24 : S * 4);
     return DSPMAP_OK;
+}
+extern "C" int dspmap_debug_tile_view(dspmap_t* m, int* out, int cap) {
+    READY(m);
+    if (!out || cap < m->k.ntiles) return dspmap_fail(m, DSPMAP_E_ARG, "buffer of %d ints needed", m->k.ntiles);
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    HIPCHK(m, hipMemcpy(out, m->k.tile_fov, sizeof(int) * (size_t)m->k.ntiles, hipMemcpyDeviceToHost));
+    return m->k.ntiles;
 }
 extern "C" int dspmap_get_pyramid_counts(dspmap_t* m, int* out) {
     READY(m);

@@ -67,7 +67,10 @@ struct dspmap {
     bool use_graph = true;
     bool fut_clear_pending = false;   // clearOccupancyMapPrediction is lazy: done by the next frame's k_predict, or by the next reader
     hipStream_t stream2 = nullptr;   // fork/join branch inside the captured frame
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr;
+    int n_cu = 256;
+    int place_split_tiles = 8192;    // maps with at least this many tiles place the arrivals of the tiles outside the field of view
+                                     // on the side stream, beside the pair kernels (DSPMAP_P_PLACE_SPLIT_TILES)
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     unsigned long long graph_key = ~0ull;

@@ -13,6 +13,8 @@ struct KernelScratch {
     u64* expmask;       // [v_loc*mw] particles that left the slab (multi-GPU), or nullptr
     int* part_predict;  // [ntiles*4]
     int* part_claim;    // [ntiles*2]
+    int* tile_fov;      // [ntiles] 1 = a particle inside this tile may lie in the field of view (k_predict, conservative box test):
+                        // the placement of the other tiles registers nothing in a pyramid and may run beside the pair kernels
     int* part_resample; // [ntiles rounded up to 4] live particles per tile after resampling
     int* vb_cnt;        // [v_loc] children per destination voxel this frame (birth ordering)
     int* vb_idx;        // [v_loc*128] their birth indices
@@ -41,6 +43,7 @@ struct LaunchCtx {
     hipStream_t stream;
     int pt_cap, birth_cap;
     VelEst ve;
+    int n_cu = 256;      // compute units of the device (sizes launches that are meant to occupy only a share of it)
 };
 
 // frame setup: rotate boundary planes (:226-232), reset per-frame counters/bins (:235-238)
@@ -52,7 +55,7 @@ void launch_setup_and_bin(const LaunchCtx& c, int n_pts_grid, bool gather = true
 void launch_predict(const LaunchCtx& c, bool with_gather = false);
 void launch_predict_only(const LaunchCtx& c, bool with_gather = false, bool with_rank = false);   // with_rank: k_birth_rank rides along
 void launch_scan_blocks(const LaunchCtx& c, int nblk);   // exclusive scan of s.blk_cnt[0..nblk), total -> fs->occupied_count
-void launch_claim(const LaunchCtx& c, int n_birth_grid = 0, int part = 0, int tile_lo = 0, int tile_hi = 0);   // part: 0 all tiles, 1 [lo, hi), 2 the rest;   // > 0: k_birth_children rides along (after a launch with_rank)
+void launch_claim(const LaunchCtx& c, int n_birth_grid = 0, int part = 0, int tile_lo = 0, int tile_hi = 0, int sel = -1);   // sel: -1 every tile of the part, 1 / 0 only the tiles with / without a view on the sensor's field of view (tile_fov)   // part: 0 all tiles, 1 [lo, hi), 2 the rest;   // > 0: k_birth_children rides along (after a launch with_rank)
 void launch_reduce_counters(const LaunchCtx& c);
 void launch_calib(const LaunchCtx& c, int mode, size_t n);
 // multi-GPU: compact particles that left the slab / insert particles received from a neighbour
@@ -64,7 +67,7 @@ int velocity_estimator_capacity();   // points per frame the device estimator ha
 int velocity_estimator_slices();
 // mapUpdate (:704-793)
 void launch_pyr_prepare(const LaunchCtx& c);   // range sort + full-list selection of the pyramid lists, work items (idempotent)
-void launch_ck_partial(const LaunchCtx& c);     // launch_pyr_prepare + the Ck pass
+void launch_ck_partial(const LaunchCtx& c, bool prepared = false);     // launch_pyr_prepare (unless already queued) + the Ck pass
 void launch_ck_finalize(const LaunchCtx& c);
 void launch_weight_update(const LaunchCtx& c);
 // mapAddNewBornParticlesByObservation (:796-921)

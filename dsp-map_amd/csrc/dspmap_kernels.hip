@@ -983,8 +983,8 @@ static bool weight_culls(const LaunchCtx& c) { return (float)PS_NBK / c.d.rng_in
 void launch_pyr_prepare(const LaunchCtx& c) {
     hipLaunchKernelGGL(k_pyr_prepare, dim3(c.d.np + 1), dim3(1024), 0, c.stream, c.d, c.s, c.k.ck_items, c.k.wu_items, c.k.n_items, c.k.nb_tab);
 }
-void launch_ck_partial(const LaunchCtx& c) {
-    hipLaunchKernelGGL(k_pyr_prepare, dim3(c.d.np + 1), dim3(1024), 0, c.stream, c.d, c.s, c.k.ck_items, c.k.wu_items, c.k.n_items, c.k.nb_tab);
+void launch_ck_partial(const LaunchCtx& c, bool prepared) {
+    if (!prepared) hipLaunchKernelGGL(k_pyr_prepare, dim3(c.d.np + 1), dim3(1024), 0, c.stream, c.d, c.s, c.k.ck_items, c.k.wu_items, c.k.n_items, c.k.nb_tab);
     hipLaunchKernelGGL(k_ck_partial, dim3(4096), dim3(CK_TPB), (sizeof(float4) + sizeof(int)) * (size_t)c.d.nbins * DSP_OBS_CAP, c.stream, c.d, c.s, c.fp, c.k.ck_items, c.k.n_items, c.k.nb_tab);
 }
 void launch_ck_finalize(const LaunchCtx& c) {  // after launch_weight_update: reduces the per-pyramid 1/Ck sums

@@ -16,6 +16,7 @@
 //     and at saturation every lane is busy (a wave-per-voxel mapping keeps 24 of
 //     64 lanes busy at 24 particles/voxel).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "dspmap_device.h"
 #include "dspmap_kernels.h"
 #include "dspmap_birth.h"
@@ -180,7 +181,7 @@ template <int MW, int NW>
 __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, FilterParams fp, int has_vz, int* __restrict__ part,
                                                  float4* __restrict__ mv_rec, float4* __restrict__ in_rec, int* __restrict__ in_cnt,
                                                  u64* __restrict__ expmask, const int* __restrict__ vz_pre, const u64* __restrict__ vz_q,
-                                                 u64* __restrict__ omask, int extra) {
+                                                 u64* __restrict__ omask, int extra, int* __restrict__ tile_fov) {
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
     __shared__ u64 s_keep[MW * 64], s_ex[MW * 64];
@@ -244,6 +245,37 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
     for (int i = tid; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
     for (int i = tid; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
     __syncthreads();
+    if (wave == NW - 1) {
+        // Can a particle inside this tile lie in the field of view?  The tile's voxels fill one box (a run of x inside a
+        // row) or two (the tail of one row and the head of the next; lanes 0-7 / 8-15 hold the corners); every plane test of
+        // pyramid_of is a dot product that is monotone in each coordinate even after rounding, so its extreme over a box
+        // sits at a corner: if all 8 corners fail the same boundary plane, no particle of the box passes ifInPyramidsArea
+        // (:1329-1339).  k_place of such tiles registers nothing and is free to run beside the pair kernels.
+        const int g0 = d.v_base + BX * 64, g1 = d.v_base + min(BX * 64 + 63, d.v_loc - 1);
+        const int zc = d.nx * d.ny;
+        const int r0 = g0 / d.nx, r1 = g1 / d.nx;          // first and last x-row the tile touches
+        const int bx = (l >> 3) & 1;
+        int x0 = g0 % d.nx, x1 = g1 % d.nx, y0 = (g0 % zc) / d.nx, y1 = (g1 % zc) / d.nx, z0 = g0 / zc, z1 = g1 / zc;
+        bool two = false;
+        if (r1 - r0 == 1) {
+            two = true;
+            if (bx == 0) { x1 = d.nx - 1; y1 = y0; z1 = z0; } else { x0 = 0; y0 = y1; z0 = z1; }
+        } else if (r1 - r0 > 1) {                          // nx < 64: whole rows (layers)
+            x0 = 0; x1 = d.nx - 1;
+            if (z0 != z1) { y0 = 0; y1 = d.ny - 1; }
+        }
+        const float mg = d.res * 0.01f;   // a particle of voxel x has (int)((p + half) / res) == x: p may sit a rounding below the face
+        const float cx = (l & 1) ? (float)(x1 + 1) * d.res - d.half_x + mg : (float)x0 * d.res - d.half_x - mg;
+        const float cy = (l & 2) ? (float)(y1 + 1) * d.res - d.half_y + mg : (float)y0 * d.res - d.half_y - mg;
+        const float cz = (l & 4) ? (float)(z1 + 1) * d.res - d.half_z + mg : (float)z0 * d.res - d.half_z - mg;
+        const bool c8 = l < (two ? 16 : 8);
+        const u64 b0 = __ballot(c8 && dot3(cx, cy, cz, s_ph) >= 0.f);
+        const u64 b1 = __ballot(c8 && dot3(cx, cy, cz, s_ph + 3 * d.np_h) <= 0.f);
+        const u64 b2 = __ballot(c8 && dot3(cx, cy, cz, s_pv) <= 0.f);
+        const u64 b3 = __ballot(c8 && dot3(cx, cy, cz, s_pv + 3 * d.np_v) >= 0.f);
+        auto box_in = [&](int sh) { return ((b0 >> sh) & 0xffull) && ((b1 >> sh) & 0xffull) && ((b2 >> sh) & 0xffull) && ((b3 >> sh) & 0xffull); };
+        if (l == 0) tile_fov[BX] = (box_in(0) || box_in(8)) ? 1 : 0;
+    }
     if (wave == 0 && __ballot(any)) {
         // sparse tile (few live cells per live row): the heavy per-particle work runs on DENSE lanes over a compact
         // cell list instead of row by row with mostly idle lanes -- what a realistic map (particles near surfaces
@@ -541,23 +573,13 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
 // on the occupancy words and no sequential loop.  Pyramid registration :1233-1259.
 // part2[blockIdx*2 + {0,1}] = {voxel full, pyramid full}
 // --------------------------------------------------------------------------
+#ifndef PLACE_SIDE_WG
+#define PLACE_SIDE_WG 3   // workgroups per CU of the side-stream placement
+#endif
 #define PLACE_MAX 1024   // arrivals of one tile ordered exactly; a tile that receives more falls back to arrival order
 template <int MW>
-__global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const float4* __restrict__ in_rec,
-                                               int* __restrict__ in_cnt, int* __restrict__ part2, int has_vz, int tab_n,
-                                               const u64* __restrict__ omask, FilterParams fp, float4* __restrict__ child,
-                                               int* __restrict__ vb_cnt, int* __restrict__ vb_idx, int nchild, int t0, int n0, int t1) {
-    // whole frame: workgroups behind the tiles generate the frame's newborn children (k_birth_children's job; needs the
-    // birth cloud and the rank only, both done before this launch)
-    // (the first `nchild` workgroups: they run beside the tiles, not after them).
-    // Tiles of this launch: [t0, t0 + n0) followed by [t1, ...) -- all of them, or (split-phase multi-GPU frame) the slab's
-    // interior before the neighbour exchange and its boundary layers after it.
-    if ((int)blockIdx.x < nchild) {
-        birth_child_thread(d, s, fp, child, vb_cnt, vb_idx, (int)(blockIdx.x * 256 + threadIdx.x));
-        return;
-    }
-    const int bq = (int)blockIdx.x - nchild;
-    const int BX = bq < n0 ? t0 + bq : t1 + (bq - n0);   // tile index
+__device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, const float4* __restrict__ in_rec, int* __restrict__ in_cnt,
+                                           int* __restrict__ part2, int has_vz, int tab_n, const u64* __restrict__ omask, const int BX) {
     if (has_vz && BX == 0 && threadIdx.x == 0)   // k_predict drew 3 table values per ranked particle (:655-657)
         s.fs->v_cur = (int)(((long long)s.fs->v_cur + 3ll * (long long)s.fs->occupied_count) % tab_n);
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
@@ -735,6 +757,30 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
     }
     if (tid == 0) in_cnt[BX] = 0;   // ready for the next frame
     if (tid < 2) part2[BX * 2 + tid] = s_cnt[tid];
+}
+
+template <int MW>
+__global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const float4* __restrict__ in_rec,
+                                               int* __restrict__ in_cnt, int* __restrict__ part2, int has_vz, int tab_n,
+                                               const u64* __restrict__ omask, FilterParams fp, float4* __restrict__ child,
+                                               int* __restrict__ vb_cnt, int* __restrict__ vb_idx, int nchild, int t0, int n0, int t1, int n1,
+                                               const int* __restrict__ tile_fov, int sel) {
+    // whole frame: workgroups behind the tiles generate the frame's newborn children (k_birth_children's job; needs the
+    // birth cloud and the rank only, both done before this launch)
+    // (the first `nchild` workgroups: they run beside the tiles, not after them).
+    // Tiles of this launch: [t0, t0 + n0) followed by [t1, t1 + n1) -- all of them, or (split-phase multi-GPU frame) the slab's
+    // interior before the neighbour exchange and its boundary layers after it.  A launch with fewer workgroups than tiles
+    // walks them with the grid's stride (the side-stream placement keeps a small footprint that way).
+    if ((int)blockIdx.x < nchild) {
+        birth_child_thread(d, s, fp, child, vb_cnt, vb_idx, (int)(blockIdx.x * 256 + threadIdx.x));
+        return;
+    }
+    for (int bq = (int)blockIdx.x - nchild; bq < n0 + n1; bq += (int)gridDim.x - nchild) {
+        const int BX = bq < n0 ? t0 + bq : t1 + (bq - n0);   // tile index
+        if (sel >= 0 && (tile_fov[BX] != 0) != (sel != 0)) continue;   // the other launch of a split placement owns this tile
+        place_tile<MW>(d, s, in_rec, in_cnt, part2, has_vz, tab_n, omask, BX);
+        __syncthreads();   // the tile's LDS tables are re-used by the next one
+    }
 }
 
 #define RBK 16  // rows per batch of the loads in k_resample
@@ -1397,12 +1443,12 @@ void launch_predict_only(const LaunchCtx& c, bool with_gather, bool with_rank) {
     }
     if (c.d.mw == 1)
         hipLaunchKernelGGL((k_predict<1, 4>), dim3(k->ntiles + xb), dim3(256), 0, c.stream, c.d, c.s, c.fp,
-                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask, extra);
+                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask, extra, k->tile_fov);
     else
         hipLaunchKernelGGL((k_predict<2, 4>), dim3(k->ntiles + xb), dim3(256), 0, c.stream, c.d, c.s, c.fp,
-                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask, extra);
+                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask, extra, k->tile_fov);
 }
-void launch_claim(const LaunchCtx& c, int n_birth_grid, int part, int tile_lo, int tile_hi) {   // n_birth_grid > 0: the children of that many source points ride along
+void launch_claim(const LaunchCtx& c, int n_birth_grid, int part, int tile_lo, int tile_hi, int sel) {   // n_birth_grid > 0: the children of that many source points ride along
     const unsigned xb = n_birth_grid > 0 ? (unsigned)(((long long)n_birth_grid * c.fp.nb_num + 255) / 256) : 0u;
     const int nt = c.k.ntiles;
     int t0 = 0, n0 = nt, t1 = nt, n1 = 0;                       // part 0: every tile
@@ -1410,8 +1456,13 @@ void launch_claim(const LaunchCtx& c, int n_birth_grid, int part, int tile_lo, i
     if (part == 2) { n0 = tile_lo; t1 = tile_hi; n1 = nt - tile_hi; }   // part 2: the rest
     if (n0 + n1 <= 0 && xb == 0) return;
     const KernelScratch* k = &c.k;
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(n0 + n1 + xb), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1);
-    else hipLaunchKernelGGL(k_place<2>, dim3(n0 + n1 + xb), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1);
+    // sel == 0 runs beside the pair kernels with a small footprint: PLACE_SIDE_WG workgroups per CU walk the tiles -- the
+    // scattered stores that bound this kernel are saturated from there (measured: 7 -> 3 resident workgroups, same time),
+    // and the wave slots, registers and LDS it leaves free are what the pair kernels run in
+    unsigned grid = (unsigned)(n0 + n1) + xb;
+    if (sel == 0) grid = std::min(grid, (unsigned)(PLACE_SIDE_WG * c.n_cu));
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel);
+    else hipLaunchKernelGGL(k_place<2>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel);
 }
 void launch_predict(const LaunchCtx& c, bool with_gather) {
     launch_predict_only(c, with_gather, false);

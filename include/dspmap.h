@@ -111,6 +111,9 @@ enum dspmap_param {
     DSPMAP_P_OCCLUSION_MARGIN = 12, /* obstacle_thickness_for_occlusion :70 (0.3 m); the reference's two other headers use VOXEL_RESOLUTION */
     DSPMAP_P_UPDATE_TIME = 14,      /* read-only: update_time, the sum of the accepted frames' delt_t (:634) */
     DSPMAP_P_UPDATE_COUNTER = 15,   /* read-only: update_counter, the number of predictions run (:635) */
+    DSPMAP_P_PLACE_SPLIT_TILES = 16,/* maps with at least this many 64-voxel tiles (default 8192) give the voxel-changing particles of the tiles
+                                       that cannot see the sensor's field of view their slots on a side stream, beside the weight update
+                                       (same result; a scheduling knob: 1 = always, a huge value = never) */
     DSPMAP_P_PAIR_CULL_SIGMAS = 13  /* mapUpdate evaluates a (particle, observation) pair only if their ranges differ by at most this many
                                        sigma_ob (default 9: the dropped terms are < 1e-19 and zero on the fixed-point Ck grid);
                                        a huge value evaluates every pair of the neighbourhood like the reference's loops */
@@ -205,6 +208,9 @@ int dspmap_get_stage_ms(dspmap_t* m, float ms_sum_out[DSPMAP_N_STAGES], int* n_f
  * (4 B per lane, 256 B per wave) -- mode 0 reads them (known byte count = 6*4*capacity), mode 1
  * rewrites px in place -- to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE for this pattern. */
 int dspmap_debug_stream(dspmap_t* m, int mode, long long* bytes_out);
+/* diagnostics: out[t] = 1 if a particle inside 64-voxel tile t could lie in the field of view of the last frame
+ * (the conservative box test behind DSPMAP_P_PLACE_SPLIT_TILES); returns the number of tiles or an error */
+int dspmap_debug_tile_view(dspmap_t* m, int* out, int cap);
 
 /* ---- state access (the reference's equivalent is direct access to its
  * file-scope arrays, dsp_dynamic.h:116).  A record is 8 floats

@@ -415,3 +415,48 @@ def test_device_estimator_on_the_depth_stream(dsp, orc):
     rec = m.export_state()[2]
     assert (np.abs(rec[:, 1]) + np.abs(rec[:, 2]) > 0.3).sum() > 100
     o.close(); m.close(); md.close()
+
+
+@pytest.mark.parametrize("est,quat", [(0, (1.0, 0.0, 0.0, 0.0)), (2, (0.9659258, 0.0, 0.0, 0.258819)), (0, (0.9238795, 0.0, 0.3826834, 0.0))])
+def test_split_placement_changes_nothing(dsp, est, quat):
+    """Large maps give the arrivals of the tiles that cannot see the field of view their slots on a side stream, beside the
+    pair kernels (k_predict's conservative box test decides per tile; DSPMAP_P_PLACE_SPLIT_TILES).  Forced on for a small map
+    and compared with the single-stream frame: every slot, every float and every counter equal -- with the sensor looking
+    along x, yawed by 30 degrees (with the device estimator's branch sharing the side stream), and pitched by 45 degrees --
+    and some tiles really are placed on each side."""
+    import torch
+    cfg = dict(nx=56, ny=88, nz=12, res=0.15, ppv=24)   # tiles straddle two rows; rows beyond the view's width exist
+    tables = common.tables(5)
+    maps = []
+    for split in (1, 2_000_000_000):
+        m = dsp.DSPMap(dsp.make_config(**cfg)); m.set_tables(*tables)
+        m.L.dspmap_init_device(m.h)
+        m.set_param(dsp.capi.P_PLACE_SPLIT_TILES, split)
+        if est:
+            m.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, est)
+        maps.append(m)
+    for m in maps:   # (sparse enough that no pyramid list exceeds its hard capacity: beyond it, arrival order decides)
+        m.seed_uniform(2, 0.01, 11, 0.0)
+    rng = np.random.default_rng(3)
+    ys, zs = np.meshgrid(np.linspace(-2.0, 2.0, 41), np.linspace(-0.9, 0.9, 19))
+    base = np.stack([np.full(ys.size, 2.3) + 0.2 * np.sin(2 * ys.ravel()), ys.ravel(), zs.ravel()], 1).astype(np.float32)
+    moved = 0
+    for f in range(6):
+        t = f / 30.0
+        pts = torch.from_numpy(base + rng.normal(0, 0.004, base.shape).astype(np.float32)).cuda()
+        pos = (0.9 * t, 0.5 * t, 0.1 * np.sin(5 * t))
+        for m in maps:
+            assert m.update_device(pts.data_ptr(), len(base), pos, t, quat) == 1
+            m.clearOccupancyMapPrediction()
+        ca, cb = maps[0].counters(), maps[1].counters()
+        ca.pop("update_ms"); cb.pop("update_ms")
+        assert ca == cb, (f, ca, cb)
+        moved += ca["n_moved"]
+    assert moved > 20000
+    for a, b in zip(maps[0].export_state(), maps[1].export_state()):
+        assert np.array_equal(a, b)
+    assert np.array_equal(maps[0].results(), maps[1].results())
+    got = maps[0].debug_tile_fov()
+    assert 0 < got.sum() < len(got), got.sum()      # both launches had tiles to place
+    for m in maps:
+        m.close()
