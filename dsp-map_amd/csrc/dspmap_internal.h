@@ -9,6 +9,7 @@
 #include "dspmap_kernels.h"
 #include "velocity_estimator.h"
 
+#define DSPMAP_RING 1024   // slots of the pinned frame-parameter ring (power of two)
 struct dspmap {
     dspmap_config cfg;
     MapDims d;
@@ -69,6 +70,15 @@ struct dspmap {
     hipStream_t stream2 = nullptr;   // fork/join branch inside the captured frame
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr;
     int n_cu = 256;
+    // pinned parameter ring of the captured frames: slot (ring_head % DSPMAP_RING) is written by the host, read by the
+    // frame's first kernel; ring_ev[q] marks the end of the last frame that used quarter q
+
+    bool frame_ring = false;         // the frame being enqueued reads its parameters from the ring
+    FrameParams* ring_host = nullptr;
+    const FrameParams* ring_dev = nullptr;
+    unsigned ring_head = 0;
+    hipEvent_t ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ring_ev_set[4] = {false, false, false, false};
     int place_split_tiles = 8192;    // maps with at least this many tiles place the arrivals of the tiles outside the field of view
                                      // on the side stream, beside the pair kernels (DSPMAP_P_PLACE_SPLIT_TILES)
     hipGraph_t graph = nullptr;

@@ -50,7 +50,7 @@ struct LaunchCtx {
 void launch_frame_setup(const LaunchCtx& c, bool reset_obs);
 // observation binning (:244-290)
 void launch_obs_bin(const LaunchCtx& c, int n_pts_grid);
-void launch_setup_and_bin(const LaunchCtx& c, int n_pts_grid, bool gather = true);   // gather = false: launch_predict*(c, true) does it
+void launch_setup_and_bin(const LaunchCtx& c, int n_pts_grid, bool gather = true, const FrameParams* ring = nullptr, int ring_mask = 0);   // ring: the frame's parameter block is read from this pinned ring   // gather = false: launch_predict*(c, true) does it
 // mapPrediction (:627-701) incl. re-binning of movers (moveParticle :1206-1274)
 void launch_predict(const LaunchCtx& c, bool with_gather = false);
 void launch_predict_only(const LaunchCtx& c, bool with_gather = false, bool with_rank = false);   // with_rank: k_birth_rank rides along

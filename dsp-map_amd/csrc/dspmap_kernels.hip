@@ -68,13 +68,23 @@ __global__ void k_reset(MapDims d, DevState s, int flags) {
 // sensor-centred frame (:247), FOV test (:250), pyramid cell (:260-263), range (:266).
 // --------------------------------------------------------------------------
 template <bool FUSED>
-__global__ void __launch_bounds__(256) k_obs_points(MapDims d, DevState s) {
-    const int n_pts = s.fpar->n_pts;
-    const float* __restrict__ pts = s.fpar->pts;
-    const float qw = s.fpar->quat[0], qx = s.fpar->quat[1], qy = s.fpar->quat[2], qz = s.fpar->quat[3];
-    const float cpx = s.fpar->cur_pos[0], cpy = s.fpar->cur_pos[1], cpz = s.fpar->cur_pos[2];
+__global__ void __launch_bounds__(256) k_obs_points(MapDims d, DevState s, const FrameParams* __restrict__ ring, int ring_mask) {
+    // A captured frame takes its parameter block straight from the pinned host ring the caller filled (no copy node in
+    // front of the graph): every workgroup of this -- the frame's first -- kernel reads the slot over the bus, workgroup 0
+    // also stores it in HBM for the kernels that follow.  The ring's read position is advanced by k_predict, after every
+    // workgroup here has used it.
+    const FrameParams* __restrict__ fpp = s.fpar;
+    if (FUSED && ring) {
+        fpp = ring + (*s.ring_seq & ring_mask);
+        if (blockIdx.x == 0 && threadIdx.x < sizeof(FrameParams) / 4)
+            reinterpret_cast<int*>(s.fpar)[threadIdx.x] = reinterpret_cast<const int*>(fpp)[threadIdx.x];
+    }
+    const int n_pts = fpp->n_pts;
+    const float* __restrict__ pts = fpp->pts;
+    const float qw = fpp->quat[0], qx = fpp->quat[1], qy = fpp->quat[2], qz = fpp->quat[3];
+    const float cpx = fpp->cur_pos[0], cpy = fpp->cur_pos[1], cpz = fpp->cur_pos[2];
     (void)cpx; (void)cpy; (void)cpz;
-    const int make_static_birth = s.fpar->static_birth;
+    const int make_static_birth = fpp->static_birth;
     const float q[4] = {qw, qx, qy, qz};
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
@@ -117,7 +127,7 @@ __global__ void __launch_bounds__(256) k_obs_points(MapDims d, DevState s) {
         s.pt_rot[i] = make_float4(r[0], r[1], r[2], len);
         s.pt_pyr[i] = pyr;
         // the view is not empty: this frame's synthesised birth cloud is the live one (dspmap_birth.h, BirthView)
-        if (make_static_birth == 1 && pyr >= 0) s.fs->view_epoch = s.fpar->epoch;
+        if (make_static_birth == 1 && pyr >= 0) s.fs->view_epoch = fpp->epoch;
     }
 }
 
@@ -968,13 +978,13 @@ void launch_frame_setup(const LaunchCtx& c, bool reset_obs) {
     hipLaunchKernelGGL(k_reset, dim3(grid), dim3(1024), 0, c.stream, c.d, c.s, flags);
 }
 
-void launch_setup_and_bin(const LaunchCtx& c, int n_pts_grid, bool gather) {   // whole frame: launch_frame_setup(c, true) + launch_obs_bin
+void launch_setup_and_bin(const LaunchCtx& c, int n_pts_grid, bool gather, const FrameParams* ring, int ring_mask) {   // whole frame: launch_frame_setup(c, true) + launch_obs_bin
     const int grid = n_pts_grid > 0 ? (n_pts_grid + 255) / 256 : 1;
-    hipLaunchKernelGGL(k_obs_points<true>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s);
+    hipLaunchKernelGGL(k_obs_points<true>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, ring, ring_mask);
     if (gather) hipLaunchKernelGGL(k_obs_gather, dim3(c.d.np), dim3(WAVE), 0, c.stream, c.d, c.s);
 }
 void launch_obs_bin(const LaunchCtx& c, int n_pts_grid) {
-    if (n_pts_grid > 0) hipLaunchKernelGGL(k_obs_points<false>, dim3((n_pts_grid + 255) / 256), dim3(256), 0, c.stream, c.d, c.s);
+    if (n_pts_grid > 0) hipLaunchKernelGGL(k_obs_points<false>, dim3((n_pts_grid + 255) / 256), dim3(256), 0, c.stream, c.d, c.s, (const FrameParams*)nullptr, 0);
     hipLaunchKernelGGL(k_obs_gather, dim3(c.d.np), dim3(WAVE), 0, c.stream, c.d, c.s);
 }
 

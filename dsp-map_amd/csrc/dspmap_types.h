@@ -39,7 +39,7 @@ struct MapDims {
     int M;                 // MAX_PARTICLE_NUM_VOXEL :43
     int np_h, np_v, np;    // pyramids :58-60
     int capp;              // SAFE_PARTICLE_NUM_PYRAMID :66
-    int capa;              // entries a pyramid's UNSORTED list can hold (capp + 25 %): k_pyr_prepare keeps the capp smallest keys
+    int capa;              // entries a pyramid's UNSORTED list can hold (2 x capp + 64): k_pyr_prepare keeps the capp smallest keys
     int T;                 // PREDICTION_TIMES :46
     int nn;                // pyramid neighbourhood radius: 1 = 3x3 (:1135-1136), 2 = 5x5 (dsp_dynamic_multiple_neighbors.h)
     int nbins;             // (2*nn+1)^2
@@ -109,6 +109,7 @@ struct FrameParams {
     float res_filter;   // voxel_filtered_resolution :132 (ground split and cluster tolerance of the velocity estimator)
     int epoch;          // frame counter (bumped whenever a cloud is binned); FrameScalars::view_epoch refers to it
     int clear_fut;      // 1: k_predict zeroes the future accumulators first (a clearOccupancyMapPrediction is pending)
+    int from_ring;      // 1: this block came through the pinned parameter ring (k_predict advances the ring's read position)
     const float* pts;   // n_pts x 3, sensor frame
     struct BirthSrc* birth;
 };
@@ -165,6 +166,7 @@ struct DevState {
     float* p_tab; float* v_tab; int* r_tab;
     FrameScalars* fs;
     FrameParams* fpar;
+    int* ring_seq;      // read position of the pinned parameter ring (frames replayed as a captured graph)
 };
 
 // device velocity estimator (dspmap_velest.hip): one cluster = the reference's ClusterFeature :98-109 + bookkeeping
