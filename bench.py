@@ -337,6 +337,23 @@ def main():
         except Exception as e:  # the extra line must never break the contract line
             result["saturated_132x132x60"] = {"error": repr(e)}
 
+    # ------------------------------------------------------------------ C and E with a REALISTIC fill
+    if rank == 0 and not sharded_run and not args.no_extra and wl_name == "B":
+        try:
+            out = {"what": "the large grids filled by the depth stream itself (empty start, particles only near surfaces) instead "
+                           "of the saturated fill: what a deployed map looks like; device velocity estimator in the frame"}
+            for tag, wn, st in (("132x132x60", "C", 150), ("264x264x80", "E", 100)):
+                mr, frr, dtr, cr, _ = measure(WORKLOADS[wn], st, 10, args.prefill, profile=False, estimator=args.estimator)
+                br = b_alg(cr, mr.V_local, mr.T)
+                out[tag] = {"frames_per_s": round(st / dtr, 2), "ms_per_step": round(dtr / st * 1e3, 4),
+                            "n_live_in": cr["n_live_in"], "n_fov": cr["n_fov"], "n_born": cr["n_born"], "n_moved": cr["n_moved"],
+                            "b_alg_bytes": int(br)}
+                mr.close()
+                del frr
+            result["realistic_fill"] = out
+        except Exception as e:
+            result["realistic_fill"] = {"error": repr(e)}
+
     # ------------------------------------------------------------------ config D: the future-status rollout, T = 10
     if rank == 0 and not sharded_run and not args.no_extra and wl_name == "B":
         try:

@@ -889,6 +889,7 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, const flo
                     st_vel(s, idx, vx, vy);
                     s.w[idx] = newborn_w;
                     atomicOr(&s.nbmask[(size_t)lv * d.mw + (sl >> 6)], 1ull << (sl & 63));  // flag 15
+                    s.tile_live[lv >> 6] = 1;   // (the tile may have been empty: the sweeps must visit it again)
                     born = true;
                 } else {
                     dropped = true;

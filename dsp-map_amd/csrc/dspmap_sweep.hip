@@ -224,29 +224,9 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
         for (int i = tid; i < nv * d.T; i += NW * 64) s.fut[(size_t)(i / nv) * d.v_loc + v0 + (i % nv)] = 0.f;   // [T][V]
         if (tid < nv) s.fut_stat[v0 + tid] = 0.f;
     }
-    const bool inr = lv < d.v_loc;
-    const int lvs = inr ? lv : 0;
-    u64 mword[MW], live[MW];
-    bool any = false;
-#pragma unroll
-    for (int e = 0; e < MW; ++e) {
-        mword[e] = 0ull; u64 nbword = 0ull;
-        if (inr) { mword[e] = s.mask[(size_t)lv * MW + e]; nbword = s.nbmask[(size_t)lv * MW + e]; }
-        live[e] = mword[e] & ~nbword;  // particles born/seeded this frame (flag 15) are not predicted (:649)
-        any |= live[e] != 0ull;
-        if (wave == 0) {
-            s_keep[e * 64 + l] = live[e]; s_ex[e * 64 + l] = 0ull;
-            if (inr) omask[(size_t)lv * MW + e] = mword[e] | nbword;   // occupancy before this prediction (k_place: arrivals from lower voxels)
-        }
-    }
-    if (tid == 0) { s_any = 0; s_nmv = 0; s_nst = 0; s_ncell = 0; }
-    if (tid < 4) s_cnt[tid] = 0;
-    if (d.np <= HIST_NP) for (int b = tid; b < d.np; b += NW * 64) s_hist[b] = 0;
-    // the rotated planes are requested together with the occupancy words (one round trip less for the tiles that have work)
-    for (int i = tid; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
-    for (int i = tid; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
-    __syncthreads();
     if (wave == NW - 1) {
+        const float* __restrict__ gph = s.planes_h;   // (rotated by k_obs_points; uniform addresses: scalar loads)
+        const float* __restrict__ gpv = s.planes_v;
         // Can a particle inside this tile lie in the field of view?  The tile's voxels fill one box (a run of x inside a
         // row) or two (the tail of one row and the head of the next; lanes 0-7 / 8-15 hold the corners); every plane test of
         // pyramid_of is a dot product that is monotone in each coordinate even after rounding, so its extreme over a box
@@ -270,13 +250,39 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
         const float cy = (l & 2) ? (float)(y1 + 1) * d.res - d.half_y + mg : (float)y0 * d.res - d.half_y - mg;
         const float cz = (l & 4) ? (float)(z1 + 1) * d.res - d.half_z + mg : (float)z0 * d.res - d.half_z - mg;
         const bool c8 = l < (two ? 16 : 8);
-        const u64 b0 = __ballot(c8 && dot3(cx, cy, cz, s_ph) >= 0.f);
-        const u64 b1 = __ballot(c8 && dot3(cx, cy, cz, s_ph + 3 * d.np_h) <= 0.f);
-        const u64 b2 = __ballot(c8 && dot3(cx, cy, cz, s_pv) <= 0.f);
-        const u64 b3 = __ballot(c8 && dot3(cx, cy, cz, s_pv + 3 * d.np_v) >= 0.f);
+        const u64 b0 = __ballot(c8 && dot3(cx, cy, cz, gph) >= 0.f);
+        const u64 b1 = __ballot(c8 && dot3(cx, cy, cz, gph + 3 * d.np_h) <= 0.f);
+        const u64 b2 = __ballot(c8 && dot3(cx, cy, cz, gpv) <= 0.f);
+        const u64 b3 = __ballot(c8 && dot3(cx, cy, cz, gpv + 3 * d.np_v) >= 0.f);
         auto box_in = [&](int sh) { return ((b0 >> sh) & 0xffull) && ((b1 >> sh) & 0xffull) && ((b2 >> sh) & 0xffull) && ((b3 >> sh) & 0xffull); };
         if (l == 0) tile_fov[BX] = (box_in(0) || box_in(8)) ? 1 : 0;
     }
+    if (!s.tile_live[BX]) {   // nothing lives here (k_resample saw it empty; no arrival, birth or import since)
+        if (tid < 4) part[BX * 4 + tid] = 0;
+        return;
+    }
+    const bool inr = lv < d.v_loc;
+    const int lvs = inr ? lv : 0;
+    u64 mword[MW], live[MW];
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < MW; ++e) {
+        mword[e] = 0ull; u64 nbword = 0ull;
+        if (inr) { mword[e] = s.mask[(size_t)lv * MW + e]; nbword = s.nbmask[(size_t)lv * MW + e]; }
+        live[e] = mword[e] & ~nbword;  // particles born/seeded this frame (flag 15) are not predicted (:649)
+        any |= live[e] != 0ull;
+        if (wave == 0) {
+            s_keep[e * 64 + l] = live[e]; s_ex[e * 64 + l] = 0ull;
+            if (inr) omask[(size_t)lv * MW + e] = mword[e] | nbword;   // occupancy before this prediction (k_place: arrivals from lower voxels)
+        }
+    }
+    if (tid == 0) { s_any = 0; s_nmv = 0; s_nst = 0; s_ncell = 0; }
+    if (tid < 4) s_cnt[tid] = 0;
+    if (d.np <= HIST_NP) for (int b = tid; b < d.np; b += NW * 64) s_hist[b] = 0;
+    // the rotated planes are requested together with the occupancy words (one round trip less for the tiles that have work)
+    for (int i = tid; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
+    for (int i = tid; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
+    __syncthreads();
     if (wave == 0 && __ballot(any)) {
         // sparse tile (few live cells per live row): the heavy per-particle work runs on DENSE lanes over a compact
         // cell list instead of row by row with mostly idle lanes -- what a realistic map (particles near surfaces
@@ -596,6 +602,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
         if (tid < 2) part2[BX * 2 + tid] = 0;
         return;
     }
+    const bool was_live = s.tile_live[BX] != 0;   // an empty tile was skipped by k_predict: its omask words are stale (and zero in truth)
     const int cap = 64 * d.slots;
     const int n = min(n_all, cap);
     const bool exact = n <= PLACE_MAX;
@@ -608,7 +615,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
         for (int e = 0; e < MW; ++e) {
             const bool in = lv < d.v_loc;
             s_cur[e * 64 + tid] = in ? (s.mask[(size_t)lv * MW + e] | s.nbmask[(size_t)lv * MW + e]) : ~0ull;
-            s_org[e * 64 + tid] = in ? omask[(size_t)lv * MW + e] : ~0ull;
+            s_org[e * 64 + tid] = in ? (was_live ? omask[(size_t)lv * MW + e] : 0ull) : ~0ull;
             s_new[e * 64 + tid] = 0ull;
         }
     }
@@ -756,7 +763,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
         for (int e = 0; e < MW; ++e)
             if (s_new[e * 64 + tid]) s.mask[(size_t)lv * MW + e] = s.mask[(size_t)lv * MW + e] | s_new[e * 64 + tid];
     }
-    if (tid == 0) in_cnt[BX] = 0;   // ready for the next frame
+    if (tid == 0) { in_cnt[BX] = 0; s.tile_live[BX] = 1; }   // ready for the next frame; the tile holds particles now
     if (tid < 2) part2[BX * 2 + tid] = s_cnt[tid];
 }
 
@@ -813,6 +820,7 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
     unsigned short* s_cp = (unsigned short*)(s_w + d.slots * 64);
     const int wave_g = blockIdx.x * (blockDim.x >> 6) + wave;
     const int lv = wave_g * 64 + l;
+    if (wave_g * 64 >= d.v_loc || !s.tile_live[wave_g]) return;   // empty since its last visit: result, buckets and lists are already zero
     const bool inr = lv < d.v_loc;
     const int lvs = inr ? lv : 0;
     u64 m[MW], nb[MW];
@@ -829,7 +837,7 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
     if (inr) vb_cnt[lv] = 0;    // birth buckets of this frame are consumed: leave them empty for the next one
     if (!__ballot(nonempty)) {  // whole tile empty
         if (inr) s.res4[lv] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (l == 0 && wave_g * 64 < d.v_loc + 63) { part_live[wave_g] = 0; ro_cnt[wave_g] = 0; }
+        if (l == 0 && wave_g * 64 < d.v_loc + 63) { part_live[wave_g] = 0; ro_cnt[wave_g] = 0; s.tile_live[wave_g] = 0; }
         return;
     }
     // every live weight row of the tile -> LDS, all loads in flight together
@@ -1038,7 +1046,7 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
         }
     }
     live_out = wave_sum_i(live_out);
-    if (l == 0) part_live[wave_g] = live_out;
+    if (l == 0) { part_live[wave_g] = live_out; s.tile_live[wave_g] = live_out > 0 ? 1 : 0; }
 }
 
 // --------------------------------------------------------------------------
@@ -1478,12 +1486,17 @@ void launch_resample(const LaunchCtx& c) {
     else hipLaunchKernelGGL(k_resample<2>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt);
     if (c.d.T > 0) hipLaunchKernelGGL(k_rollout, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->ro_rec, k->ro_cnt);
 }
+static void mark_all_live(const LaunchCtx& c) {   // particles were written outside a frame: every tile may hold some
+    (void)hipMemsetAsync(c.s.tile_live, 1, sizeof(int) * (size_t)c.k.ntiles, c.stream);
+}
 void launch_seed_uniform(const LaunchCtx& c, int per_voxel, float weight, unsigned seed, float vmax) {
+    mark_all_live(c);
     const size_t total = (size_t)c.d.v_loc * c.d.slots;
     hipLaunchKernelGGL(k_seed_uniform, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, c.d, c.s, per_voxel, weight, seed, vmax);
 }
 void launch_import(const LaunchCtx& c, int n, const int* voxel_dev, const int* slot_dev, const float* rec8_dev, int* n_failed_dev) {
     if (n <= 0) return;
+    mark_all_live(c);
     hipLaunchKernelGGL(k_import, dim3((n + 255) / 256), dim3(256), 0, c.stream, c.d, c.s, n, voxel_dev, slot_dev, rec8_dev, n_failed_dev);
 }
 void launch_export(const LaunchCtx& c, int* voxel_out, int* slot_out, float* rec8_out, int* count_dev, int cap) {
@@ -1492,6 +1505,7 @@ void launch_export(const LaunchCtx& c, int* voxel_out, int* slot_out, float* rec
 }
 void launch_add_random(const LaunchCtx& c, int n, float weight, int* slot_of_tmp) {
     if (n <= 0) return;
+    mark_all_live(c);
     const dim3 g((n + 255) / 256), b(256);
     hipLaunchKernelGGL(k_add_random_bucket, g, b, 0, c.stream, c.d, c.s, c.fp, n, c.k.vb_cnt, c.k.vb_idx);
     hipLaunchKernelGGL(k_add_random_place, g, b, 0, c.stream, c.d, c.s, c.fp, n, weight, c.k.vb_cnt, c.k.vb_idx, slot_of_tmp);

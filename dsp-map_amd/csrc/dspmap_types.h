@@ -167,6 +167,9 @@ struct DevState {
     FrameScalars* fs;
     FrameParams* fpar;
     int* ring_seq;      // read position of the pinned parameter ring (frames replayed as a captured graph)
+    int* tile_live;     // [tiles] 0 = the 64-voxel tile holds no particle (k_resample found it empty and nothing was placed, born or
+                        // imported there since): the sweeps skip it without reading its occupancy words.  Conservative: nonzero
+                        // does not promise a particle.
 };
 
 // device velocity estimator (dspmap_velest.hip): one cluster = the reference's ClusterFeature :98-109 + bookkeeping
