@@ -628,25 +628,27 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
         // The velocity estimator runs BESIDE prediction and weight update, like the reference's helper thread (:297,311):
         // a second branch of the frame (side stream; a forked branch of the captured graph) takes the binned view through
         // k_ve_components -> k_ve_clusters (+ the birth rank) -> the newborn children, and joins before the birth stage.
+        // (The main chain's next kernel is queued BEFORE the side branch's: the branch whose node comes first after the
+        // fork stays on the parent's hardware queue, the other one pays the cross-queue hand-over.)
         (void)hipEventRecord(m->ev_fork, m->stream);
+        launch_predict_only(c, true, false);
         (void)hipStreamWaitEvent(m->stream2, m->ev_fork, 0);
         LaunchCtx c2 = c;
         c2.stream = m->stream2;
         launch_velocity_estimator(c2, true);
         launch_birth_early(c2, birth_grid, false);   // children (the rank ran inside k_ve_clusters)
         (void)hipEventRecord(m->ev_join, m->stream2);
-        launch_predict_only(c, true, false);
         dspmap_prof_mark(m, 2);
         launch_claim(c, 0, 0, 0, 0, split ? 1 : -1);
+        if (split) launch_pyr_prepare(c);
+        dspmap_prof_mark(m, 3);
+        if (split) (void)hipEventRecord(m->ev_fork2, m->stream);
+        launch_ck_partial(c, split);
         if (split) {   // the side stream places the arrivals of the tiles outside the field of view (behind the estimator's kernels)
-            launch_pyr_prepare(c);
-            (void)hipEventRecord(m->ev_fork2, m->stream);
             (void)hipStreamWaitEvent(m->stream2, m->ev_fork2, 0);
             launch_claim(c2, 0, 0, 0, 0, 0);
             (void)hipEventRecord(m->ev_join, m->stream2);
         }
-        dspmap_prof_mark(m, 3);
-        launch_ck_partial(c, split);
         dspmap_prof_mark(m, 4);
         launch_weight_update(c);
         dspmap_prof_mark(m, 5);
@@ -671,15 +673,17 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
         // (VALU-bound; the list preparation before them is itself a scatter and would only share the memory system).
         launch_pyr_prepare(c);
         (void)hipEventRecord(m->ev_fork2, m->stream);
+    }
+    if (fork) (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
+    dspmap_prof_mark(m, 3);
+    launch_ck_partial(c, split);
+    if (split) {   // (queued behind the main chain's next kernel, see the estimator's fork above)
         (void)hipStreamWaitEvent(m->stream2, m->ev_fork2, 0);
         LaunchCtx c2 = c;
         c2.stream = m->stream2;
         launch_claim(c2, 0, 0, 0, 0, 0);
         (void)hipEventRecord(m->ev_join, m->stream2);
     }
-    if (fork) (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
-    dspmap_prof_mark(m, 3);
-    launch_ck_partial(c, split);
     dspmap_prof_mark(m, 4);
     launch_weight_update(c);
     if (split) (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
@@ -804,7 +808,11 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
         if (rc != DSPMAP_OK) return rc;
     }
     dspmap_prof_collect(m);
-    HIPCHK(m, hipEventRecord(m->ev0, m->stream));
+    // update_ms (dspmap_get_counters): an event record between two graph launches costs ~5 us of device time each (measured:
+    // 0.162 -> 0.150 ms per frame at the metric's workload without them), so a replayed frame carries the pair only every
+    // 32nd time; direct launches (profiling, DSPMAP_P_USE_GRAPH = 0) are timed every frame
+    const bool timed = !(m->use_graph && !m->prof) || (m->frame_no++ % 32u) == 0;
+    if (timed) HIPCHK(m, hipEventRecord(m->ev0, m->stream));
     if (m->use_graph && !m->prof) {
         // the kernel arguments of a frame are constant (per-frame values live in s.fpar): capture once, replay
         const unsigned long long key = ((unsigned long long)m->graph_epoch << 8) | (has_vz ? 1u : 0u) | ((unsigned)mode << 1);
@@ -834,8 +842,7 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
     }
     if (m->vz_frames > 0) --m->vz_frames;
     if (m->nb_dirty) { m->nb_dirty = false; m->graph_epoch++; }
-    HIPCHK(m, hipEventRecord(m->ev1, m->stream));
-    m->ev_valid = true;
+    if (timed) { HIPCHK(m, hipEventRecord(m->ev1, m->stream)); m->ev_valid = true; }
     m->last_n_points = n_points;
     m->last_n_birth = nb_grid;
     m->last_birth_static = mode != 0;   // the cloud lives on the device (dspmap_get_birth_cloud materialises it)

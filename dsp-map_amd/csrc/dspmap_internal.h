@@ -21,6 +21,7 @@ struct dspmap {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
+    unsigned frame_no = 0;           // replayed frames so far (every 32nd one is timed)
     int device = -1;
     std::string err;
     // parameters

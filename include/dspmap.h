@@ -92,7 +92,8 @@ typedef struct dspmap_counters {
     int n_live_out;        /* live particles after resampling */
     int n_exported_up, n_exported_down; /* multi-GPU: left the slab through z_hi / z_lo */
     float newborn_weight;  /* updated_weight_new_born :805 */
-    float update_ms;       /* device time of the last update (HIP events) */
+    float update_ms;       /* device time of the last TIMED update (HIP events): every frame of the host-staged path, every 32nd frame
+                              of dspmap_update_device's replayed graph (an event record between two replays costs ~5 us) */
 } dspmap_counters;
 
 enum dspmap_param {
