@@ -802,6 +802,7 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
         m->hp.clear_fut = m->fut_clear_pending ? 1 : 0;
         m->fut_clear_pending = false;
         m->hp.from_ring = 1;
+        m->hp.ring_pos = m->ring_head;
         m->ring_host[m->ring_head % DSPMAP_RING] = m->hp;
     } else {
         rc = dspmap_push_frame_params(m);

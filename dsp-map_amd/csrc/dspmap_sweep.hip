@@ -203,7 +203,8 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
     // (extra & 1).  The birth rank -- one workgroup that needs nothing but the frame's birth cloud -- is the last one
     // (extra & 2).
     // They come FIRST in the grid so that they run beside the tiles instead of after them.
-    if (blockIdx.x == 0 && tid == 0 && s.fpar->from_ring) *s.ring_seq += 1;   // k_obs_points is done with the ring slot
+    if (blockIdx.x == 0 && tid == 0 && s.fpar->from_ring && (unsigned)*s.ring_seq == s.fpar->ring_pos)
+        *s.ring_seq = (int)(s.fpar->ring_pos + 1u);   // k_obs_points is done with the ring slot
     const int ngather = (extra & 1) ? (d.np + NW - 1) / NW : 0, nextra = ngather + ((extra & 2) ? 1 : 0);
     if ((int)blockIdx.x < nextra) {
         const int x = (int)blockIdx.x;

@@ -109,7 +109,9 @@ struct FrameParams {
     float res_filter;   // voxel_filtered_resolution :132 (ground split and cluster tolerance of the velocity estimator)
     int epoch;          // frame counter (bumped whenever a cloud is binned); FrameScalars::view_epoch refers to it
     int clear_fut;      // 1: k_predict zeroes the future accumulators first (a clearOccupancyMapPrediction is pending)
-    int from_ring;      // 1: this block came through the pinned parameter ring (k_predict advances the ring's read position)
+    int from_ring;      // 1: this block came through the pinned parameter ring
+    unsigned ring_pos;  // its position in the ring: k_predict moves the ring's read position from ring_pos to ring_pos + 1 (once,
+                        // whatever else replays a stale block afterwards)
     const float* pts;   // n_pts x 3, sensor frame
     struct BirthSrc* birth;
 };
