@@ -231,7 +231,20 @@ def main():
             return t
         rk = sharded.CppShardedRank(D, dict(nx=w["nx"], ny=w["ny"], nz=w["nz"], res=w["res"], ppv=w["ppv"], seed=1234),
                                     world, rank, local_rank, broadcast=bcast)
-        frames = gen_frames(w, prefill + warmup + steps, seed=1234)  # identical on every rank
+        # every rank must be fed the SAME cloud, bit for bit (the ranks bin the same observations and all-reduce arrays whose
+        # length follows the point count): the scene's voxel filter sums with float atomics, so rank 0 generates the
+        # frames and hands them to the others once, before anything is timed
+        frames = gen_frames(w, prefill + warmup + steps, seed=1234)
+        if world > 1:
+            shared = []
+            for pts, pos, quat, t in frames:
+                n = torch.tensor([pts.shape[0]], device=dev, dtype=torch.int64)
+                dist.broadcast(n, 0)
+                buf = pts.contiguous() if rank == 0 else torch.empty((int(n.item()), 3), device=dev, dtype=torch.float32)
+                dist.broadcast(buf, 0)
+                shared.append((buf, pos, quat, t))
+            frames = shared
+            torch.cuda.synchronize()
         if w["sat"]:
             rk.map.seed_uniform(w["ppv"], 0.01, 99)
 
