@@ -460,3 +460,51 @@ def test_split_placement_changes_nothing(dsp, est, quat):
     assert 0 < got.sum() < len(got), got.sum()      # both launches had tiles to place
     for m in maps:
         m.close()
+
+
+def test_parameter_ring_wraps_and_empty_tiles_come_back(dsp):
+    """2 300 replayed frames on a small map -- more than twice the 1 024 slots of the pinned parameter ring the captured
+    frame reads its per-frame values from (the slots' guard events get used) -- against the same frames through direct
+    launches (DSPMAP_P_USE_GRAPH = 0: the parameter block is copied, no ring): every slot, float and counter equal at
+    the end.  The sensor looks at a wall, steps 5 m aside and receives empty clouds for 250 frames (the map runs empty: its
+    tiles are skipped by the sweeps) and looks at a wall again (the tiles must be visited again), twice; the device
+    estimator's branch is on."""
+    import torch
+    cfg = dict(nx=24, ny=24, nz=10, res=0.15, ppv=9)
+    tables = common.tables(11)
+    maps = []
+    for graph in (1, 0):
+        m = dsp.DSPMap(dsp.make_config(**cfg)); m.set_tables(*tables)
+        m.L.dspmap_init_device(m.h)
+        m.set_param(dsp.capi.P_USE_GRAPH, graph)
+        m.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, 2)
+        maps.append(m)
+    rng = np.random.default_rng(8)
+    ys, zs = np.meshgrid(np.linspace(-0.9, 0.9, 13), np.linspace(-0.4, 0.4, 7))
+    base = np.stack([np.full(ys.size, 1.2), ys.ravel(), zs.ravel()], 1).astype(np.float32)
+    away = (0.0, 0.0, 0.0, 1.0)      # looking along -x: nothing in view
+    front = (1.0, 0.0, 0.0, 0.0)
+    clouds = [torch.from_numpy(base + rng.normal(0, 0.003, base.shape).astype(np.float32)).cuda() for _ in range(16)]
+    live = []
+    for f in range(2300):
+        t = f / 30.0
+        blind = 600 <= f < 850 or 1700 <= f < 1950
+        q = away if blind else front
+        pts = clouds[f % 16]
+        hop = 5.0 * ((f >= 600) + (f >= 1700))   # a 5 m side step: every particle leaves the 3.6 m map
+        pos = (0.05 * np.sin(0.7 * t), hop, 0.03 * np.sin(2.0 * t))
+        for m in maps:
+            assert m.update_device(pts.data_ptr(), 0 if blind else len(base), pos, t, q) == 1
+            m.clearOccupancyMapPrediction()
+        if f in (599, 849, 1200, 1949, 2299):
+            ca, cb = maps[0].counters(), maps[1].counters()
+            ca.pop("update_ms"); cb.pop("update_ms")
+            assert ca == cb, (f, ca, cb)
+            live.append(ca["n_live_out"])
+    assert live[0] > 500 and live[2] > 500 and live[4] > 500, live     # a map at the wall ...
+    assert live[1] == 0 and live[3] == 0, live                         # ... that is empty after the side step
+    for a, b in zip(maps[0].export_state(), maps[1].export_state()):
+        assert np.array_equal(a, b)
+    assert np.array_equal(maps[0].results(), maps[1].results())
+    for m in maps:
+        m.close()
