@@ -793,20 +793,15 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
 }
 
 #define RBK 16  // rows per batch of the loads in k_resample
-#define RS_DMA 0
 #define CPB 8   // deferred copies per step
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 // --------------------------------------------------------------------------
 // k_resample: mapOccupancyCalculationAndResample :924-1057.  One wave per tile, one lane per voxel.
-//   * the WEIGHT rows of the tile go straight from HBM into the wave's LDS panel with
-//     global_load_lds (no staging registers, every row in flight at once): both sequential passes
-//     (cull/mass :938-984, systematic resampling :986-1053) then read weights from LDS, so the
-//     second pass costs no memory round trip and the weights cross HBM once;
-//   * velocities stream through registers in batches of RBK rows; positions are read only for moving
-//     particles (the rollout :950-964) and for copies;
+//   * the first pass (cull / mass :938-984) stores every WEIGHT it reads into the wave's LDS panel; the second pass
+//     (systematic resampling :986-1053) reads the weights from there, so it costs no memory round trip and the
+//     weights cross HBM once (4-byte LDS-DMA loads for the panel were slower than load + ds_write);
+//   * weights and velocities stream through registers in batches of RBK rows; positions are read only for moving
+//     particles (noted for k_rollout :950-964) and for copies;
 //   * all per-voxel sums run sequentially per lane in slot order = the reference's operation order.
 // dynamic LDS per wave: [slots][64] fp32 weights + [64][M] u16 (source slot, destination slot) of deferred copies
 // --------------------------------------------------------------------------
@@ -842,19 +837,6 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
         return;
     }
     // every live weight row of the tile -> LDS, all loads in flight together
-#if RS_DMA
-#pragma unroll
-    for (int e = 0; e < MW; ++e) {
-        u64 tor = wave_or_u64(m[e]);
-        while (tor) {
-            const int row = __ffsll((long long)tor) - 1;
-            tor &= tor - 1ull;
-            if ((m[e] >> row) & 1ull)
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(s.w + pidx(d, lvs, e * 64 + row)),
-                                                 (lds_ptr_t)(s_w + (e * 64 + row) * 64), 4, 0, 0);
-        }
-    }
-#endif
     int nmv = 0;   // moving old particles of the tile noted for k_rollout so far (wave-uniform)
     const size_t ro_base = (size_t)wave_g * 64 * d.slots;
     int n = 0, n_old = 0;
@@ -865,9 +847,7 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
         while (tor) {
             int row[RBK];
             V2 vv[RBK];
-#if !RS_DMA
             float wr[RBK];
-#endif
             bool act[RBK];
 #pragma unroll
             for (int r = 0; r < RBK; ++r) {
@@ -876,9 +856,7 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
                 act[r] = row[r] >= 0 && ((m[e] >> (row[r] & 63)) & 1ull);
                 // unconditional loads, see k_predict
                 const size_t idx = pidx(d, lvs, e * 64 + (row[r] < 0 ? 0 : row[r]));
-#if !RS_DMA
                 wr[r] = s.w[idx];
-#endif
                 vv[r] = ld_vel(s, idx);
             }
             float vx[RBK], vy[RBK];
@@ -903,9 +881,6 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
                     }
                 }
             }
-#if RS_DMA
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // weight panel (first batch) + this batch's velocities
-#endif
             bool mv_now[RBK];
 #pragma unroll
             for (int r = 0; r < RBK; ++r) mv_now[r] = false;
@@ -913,12 +888,8 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
             for (int r = 0; r < RBK; ++r) {
                 if (!act[r]) continue;
                 const u64 bit = 1ull << row[r];
-#if RS_DMA
-                const float w = s_w[(e * 64 + row[r]) * 64 + l];
-#else
                 const float w = wr[r];
                 s_w[(e * 64 + row[r]) * 64 + l] = w;   // the resampling pass below reads the weights from LDS
-#endif
                 if (w < 1e-3f) {                  // :941
                     m[e] &= ~bit;
                 } else {
