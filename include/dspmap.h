@@ -105,8 +105,10 @@ enum dspmap_param {
     DSPMAP_P_VOXEL_FILTER_RES = 6,  /* setOriginalVoxelFilterResolution :380 */
     DSPMAP_P_KAPPA = 7,             /* kappa :157 */
     DSPMAP_P_DETECTION = 8,         /* P_detection :158 */
-    DSPMAP_P_VELOCITY_ESTIMATOR = 9,/* 1 = run the host velocity estimator inside dspmap_update (:297),
-                                       0 = births use the caller's cloud / all-static tags */
+    DSPMAP_P_VELOCITY_ESTIMATOR = 9,/* velocityEstimationThread (:297,1377-1544) inside update(): 2 = on the device, a side branch of the
+                                       captured frame (dspmap_velest.hip; the drop-in class's default); 1 = host stage overlapped
+                                       with the kernels (velocity_estimator.cpp); 0 = births use the caller's cloud, or tag every
+                                       point in view as a static source */
     DSPMAP_P_REGENERATE_TABLES = 10,/* 1 = setPredictionVariance regenerates the Gaussian tables (:359) */
     DSPMAP_P_USE_GRAPH = 11,        /* 1 (default) = dspmap_update_device replays the frame as a captured HIP graph */
     DSPMAP_P_OCCLUSION_MARGIN = 12, /* obstacle_thickness_for_occlusion :70 (0.3 m); the reference's two other headers use VOXEL_RESOLUTION */
@@ -152,10 +154,11 @@ int dspmap_update(dspmap_t* m, int point_cloud_num, int size_of_one_point, const
 /* Same frame with inputs already resident in HBM: `points_dev` = n x 3 floats
  * (sensor frame, packed xyz); `birth_dev`/n_birth = the birth-source cloud
  * (what the velocity estimator would output) or NULL/0 = every in-FOV point is
- * a static source (zero velocity tag) -- unless DSPMAP_P_VELOCITY_ESTIMATOR is 1:
- * then the cloud makes one round trip to the host estimator (D2H of <= 60 kB,
- * clustering + matching, H2D of the tagged cloud) before the frame is enqueued.
- * Asynchronous otherwise: returns after enqueue. */
+ * a static source (zero velocity tag) -- unless DSPMAP_P_VELOCITY_ESTIMATOR is set:
+ * 2 = the device estimator tags the cloud inside the captured frame (still
+ * asynchronous); 1 = the cloud makes one round trip to the host estimator (D2H of
+ * <= 60 kB, clustering + matching while the prediction and weight kernels run, H2D
+ * of the tagged cloud).  Asynchronous otherwise: returns after enqueue. */
 int dspmap_update_device(dspmap_t* m, int n_points, const float* points_dev, int n_birth,
                          const dspmap_vpoint* birth_dev, const float sensor_pos[3],
                          double time_stamp_second, const float quat_wxyz[4]);
