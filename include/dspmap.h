@@ -116,7 +116,8 @@ enum dspmap_param {
     DSPMAP_P_UPDATE_COUNTER = 15,   /* read-only: update_counter, the number of predictions run (:635) */
     DSPMAP_P_PLACE_SPLIT_TILES = 16,/* maps with at least this many 64-voxel tiles (default 8192) give the voxel-changing particles of the tiles
                                        that cannot see the sensor's field of view their slots on a side stream, beside the weight update
-                                       (same result; a scheduling knob: 1 = always, a huge value = never) */
+                                       (same result; a scheduling knob: 1 = always, a huge value = never; the environment variable
+                                       DSPMAP_PLACE_SPLIT_TILES presets it at dspmap_create) */
     DSPMAP_P_PAIR_CULL_SIGMAS = 13  /* mapUpdate evaluates a (particle, observation) pair only if their ranges differ by at most this many
                                        sigma_ob (default 9: the dropped terms are < 1e-19 and zero on the fixed-point Ck grid);
                                        a huge value evaluates every pair of the neighbourhood like the reference's loops */
