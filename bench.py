@@ -412,6 +412,42 @@ def main():
         except Exception as e:
             result["birth_tag_variants"] = {"error": repr(e)}
 
+    # ------------------------------------------------------------------ the reference node's loop: update() + the getter
+    if rank == 0 and not sharded_run and not args.no_extra and wl_name == "B":
+        try:
+            mn = make_map(wl)
+            if args.estimator:
+                mn.set_param(D.capi.P_VELOCITY_ESTIMATOR, args.estimator)
+            frn = gen_frames(wl, args.prefill + 110, seed=1234)
+            run_frames(mn, frn[:args.prefill])
+            xyz = np.zeros((mn.V_local, 3), np.float32)
+            futb = np.zeros((mn.V_local, mn.T), np.float32)
+            nocc = C.c_int()
+            pxyz, pfut = xyz.ctypes.data_as(C.c_void_p), futb.ctypes.data_as(C.c_void_p)
+
+            def node_frame(fr):
+                pts, pos, quat, t = fr
+                assert mn.update_device(pts.data_ptr(), pts.shape[0], pos, t, quat) == 1
+                # src/map_sim_example.cpp:378: occupied voxels + the [V][T] future status into host arrays (also clears the accumulators)
+                mn._chk(mn.L.dspmap_get_occupancy_with_future(mn.h, 0.2, pxyz, mn.V_local, C.byref(nocc), pfut))
+            for fr in frn[args.prefill:args.prefill + 10]:
+                node_frame(fr)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for fr in frn[args.prefill + 10:]:
+                node_frame(fr)
+            dtn = (time.perf_counter() - t0) / 100
+            result["node_loop_66x66x40"] = {
+                "what": "what the reference's node does per cloud (src/map_sim_example.cpp:345-384): update() and then "
+                        "getOccupancyMapWithFutureStatus into host arrays -- a synchronous call that compacts the occupied voxels on "
+                        "the device and copies them and the [V][T] future status (4.2 MB) over PCIe into pageable memory; never the "
+                        "contract line's value",
+                "frames_per_s": round(1.0 / dtn, 1), "ms_per_frame": round(dtn * 1e3, 4), "occupied_voxels": int(nocc.value)}
+            mn.close()
+            del frn
+        except Exception as e:
+            result["node_loop_66x66x40"] = {"error": repr(e)}
+
     # ------------------------------------------------------------------ next row: the caller's pre-processing on the device
     if rank == 0 and not sharded_run and not args.no_extra and wl_name == "B":
         try:
