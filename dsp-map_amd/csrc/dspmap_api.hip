@@ -166,8 +166,14 @@ static void free_dev(dspmap* m) {
     if (m->pp_box) chk(hipFree(m->pp_box), "hipFree");
     if (m->pp_acc) chk(hipFree(m->pp_acc), "hipFree");
     if (m->pp_blk) chk(hipFree(m->pp_blk), "hipFree");
-    if (m->pts_pin) chk(hipHostFree(m->pts_pin), "hipHostFree");
+    for (int k = 0; k < DSPMAP_PTS_RING; ++k) {
+        if (m->pts_ring[k]) chk(hipHostFree(m->pts_ring[k]), "hipHostFree");
+        if (m->pts_ring_ev[k]) chk(hipEventDestroy(m->pts_ring_ev[k]), "hipEventDestroy");
+        m->pts_ring[k] = nullptr; m->pts_ring_ev[k] = nullptr; m->pts_ring_busy[k] = false; m->pts_ring_cap[k] = 0;
+    }
+    m->pts_pin = nullptr; m->pts_pin_cap = 0;
     if (m->birth_pin) chk(hipHostFree(m->birth_pin), "hipHostFree");
+    if (m->birth_ev) { chk(hipEventDestroy(m->birth_ev), "hipEventDestroy"); m->birth_ev = nullptr; m->birth_ev_set = false; }
     if (m->ev_fork) chk(hipEventDestroy(m->ev_fork), "hipEventDestroy");
     if (m->ev_join) chk(hipEventDestroy(m->ev_join), "hipEventDestroy");
     if (m->ev_fork2) chk(hipEventDestroy(m->ev_fork2), "hipEventDestroy");
@@ -770,12 +776,11 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
         // the device estimator orders in one workgroup): the (<= 60 kB) cloud is copied to the host, clustered and
         // matched there WHILE the device predicts and re-weights (the reference's fork/join, :297,311), and the tagged
         // birth cloud is uploaded for the birth stage.
-        if (n_points > m->pts_pin_cap) {
-            if (m->pts_pin) (void)hipHostFree(m->pts_pin);
-            m->pts_pin_cap = n_points + n_points / 2 + 1024;
-            HIPCHK(m, hipHostMalloc((void**)&m->pts_pin, sizeof(float) * 3 * (size_t)m->pts_pin_cap));
-        }
+        rc = dspmap_pts_slot_acquire(m, n_points);
+        if (rc != DSPMAP_OK) return rc;
         HIPCHK(m, hipMemcpyAsync(m->pts_pin, points_dev, sizeof(float) * 3 * (size_t)n_points, hipMemcpyDeviceToHost, m->stream));
+        rc = dspmap_pts_slot_release(m);
+        if (rc != DSPMAP_OK) return rc;
         HIPCHK(m, hipEventRecord(m->ev_fork, m->stream));
         dspmap_prof_collect(m);
         return frame_with_host_stages(m, n_points, points_dev, q, dp, dt, m->ev_fork);
@@ -861,20 +866,43 @@ extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* poin
     return device_frame(m, n_points, points_dev, n_birth, birth_dev, dp, dt, q);
 }
 
+// The pinned staging buffers rotate: the copy queued from (or into) a slot may still be waiting behind a whole frame when
+// the caller comes back with its next cloud, so a slot is refilled only after the event behind its last copy has completed.
+int dspmap_pts_slot_acquire(dspmap* m, int n) {
+    const unsigned k = m->pts_ring_pos++ % DSPMAP_PTS_RING;
+    if (m->pts_ring_busy[k]) { HIPCHK(m, hipEventSynchronize(m->pts_ring_ev[k])); m->pts_ring_busy[k] = false; }
+    if (!m->pts_ring_ev[k]) HIPCHK(m, hipEventCreateWithFlags(&m->pts_ring_ev[k], hipEventDisableTiming));
+    if (n > m->pts_ring_cap[k] || !m->pts_ring[k]) {
+        if (m->pts_ring[k]) (void)hipHostFree(m->pts_ring[k]);
+        m->pts_ring[k] = nullptr;
+        m->pts_ring_cap[k] = n + n / 2 + 1024;
+        HIPCHK(m, hipHostMalloc((void**)&m->pts_ring[k], sizeof(float) * 3 * (size_t)m->pts_ring_cap[k]));
+    }
+    m->pts_pin = m->pts_ring[k];
+    m->pts_pin_cap = m->pts_ring_cap[k];
+    return DSPMAP_OK;
+}
+int dspmap_pts_slot_release(dspmap* m) {
+    const unsigned k = (m->pts_ring_pos - 1u) % DSPMAP_PTS_RING;
+    HIPCHK(m, hipEventRecord(m->pts_ring_ev[k], m->stream));
+    m->pts_ring_busy[k] = true;
+    return DSPMAP_OK;
+}
 int dspmap_stage_points(dspmap* m, int n, int stride, const float* pts) {
     int rc = dspmap_ensure_point_cap(m, n);
     if (rc != DSPMAP_OK) return rc;
-    if (n > m->pts_pin_cap) {
-        if (m->pts_pin) (void)hipHostFree(m->pts_pin);
-        m->pts_pin_cap = n + n / 2 + 1024;
-        HIPCHK(m, hipHostMalloc((void**)&m->pts_pin, sizeof(float) * 3 * (size_t)m->pts_pin_cap));
-    }
+    rc = dspmap_pts_slot_acquire(m, n);
+    if (rc != DSPMAP_OK) return rc;
     for (int i = 0; i < n; i++) {  // xyz are the first three floats of each point (:247,289)
         m->pts_pin[3 * i] = pts[(size_t)i * stride];
         m->pts_pin[3 * i + 1] = pts[(size_t)i * stride + 1];
         m->pts_pin[3 * i + 2] = pts[(size_t)i * stride + 2];
     }
-    if (n > 0) HIPCHK(m, hipMemcpyAsync(m->pts_dev, m->pts_pin, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, m->stream));
+    if (n > 0) {
+        HIPCHK(m, hipMemcpyAsync(m->pts_dev, m->pts_pin, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, m->stream));
+        rc = dspmap_pts_slot_release(m);
+        if (rc != DSPMAP_OK) return rc;
+    }
     return DSPMAP_OK;
 }
 
@@ -882,14 +910,20 @@ static int upload_birth(dspmap* m, const dspmap_vpoint* pts, int n) {
     int rc = dspmap_ensure_point_cap(m, n);
     if (rc != DSPMAP_OK) return rc;
     if (n > m->birth_pin_cap) {
+        if (m->birth_ev_set) { HIPCHK(m, hipEventSynchronize(m->birth_ev)); m->birth_ev_set = false; }
         if (m->birth_pin) (void)hipHostFree(m->birth_pin);
         m->birth_pin_cap = n + n / 2 + 1024;
         HIPCHK(m, hipHostMalloc((void**)&m->birth_pin, sizeof(BirthSrc) * (size_t)m->birth_pin_cap));
     }
     static_assert(sizeof(BirthSrc) == sizeof(dspmap_vpoint), "layout");
     if (n > 0) {
+        // the previous frame's copy out of this buffer may still be queued behind that frame's kernels
+        if (m->birth_ev_set) { HIPCHK(m, hipEventSynchronize(m->birth_ev)); m->birth_ev_set = false; }
+        if (!m->birth_ev) HIPCHK(m, hipEventCreateWithFlags(&m->birth_ev, hipEventDisableTiming));
         memcpy(m->birth_pin, pts, sizeof(BirthSrc) * (size_t)n);
         HIPCHK(m, hipMemcpyAsync(m->s.birth, m->birth_pin, sizeof(BirthSrc) * (size_t)n, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(m, hipEventRecord(m->birth_ev, m->stream));
+        m->birth_ev_set = true;
     }
     return DSPMAP_OK;
 }

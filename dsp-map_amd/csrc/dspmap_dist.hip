@@ -24,6 +24,9 @@
 #include "dspmap_device.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <sys/types.h>
 #include <rccl/rccl.h>
 #include <unistd.h>
 
@@ -123,6 +126,7 @@ __global__ void __launch_bounds__(256) k_dist_import(MapDims d, const float* __r
         } else if (fwd) {
             const int pos = atomicAdd(reinterpret_cast<int*>(fwd), 1);
             if (pos < fwd_cap) { float* o = fwd + 8 * (size_t)(pos + 1); for (int k = 0; k < 8; ++k) o[k] = r[k]; }
+            else gone = true;   // the forward buffer is full: counted like every other lost import (n_voxel_full)
         } else gone = true;
     }
     wave_count_add(lost, gone);
@@ -217,7 +221,23 @@ extern "C" int dspmap_mgpu_comm_init(dspmap_t* m, int world, int rank, const cha
 }
 
 // rendezvous through a file for launchers that only export RANK / WORLD_SIZE (torchrun, mpirun wrappers): rank 0 writes
-// the unique id, the others wait for it.  DSPMAP_RDZV_FILE names the file (default /tmp/dspmap_rdzv_<MASTER_PORT>).
+// the unique id, the others wait for it.  DSPMAP_RDZV_FILE names the file (default /tmp/dspmap_rdzv_<uid>_<MASTER_PORT>).
+// The file carries a NONCE that only the ranks of this launch share (the launcher's run id and its process id, i.e. the
+// ranks' common parent), so that a file left behind by an earlier run on the same port is never taken for this run's:
+// rank 0 unlinks whatever is there, creates its file exclusively (O_EXCL | O_NOFOLLOW, mode 0600: nobody else can have
+// pre-created it or pointed a link at it) and removes it again once the communicator exists (every rank has read it by then).
+namespace {
+struct RdzvRecord {
+    char magic[8];
+    char nonce[120];
+    char id[DSPMAP_UNIQUE_ID_BYTES];
+};
+void rdzv_nonce(char out[120]) {
+    const char* run = getenv("DSPMAP_RDZV_NONCE");
+    if (!run) run = getenv("TORCHELASTIC_RUN_ID");
+    snprintf(out, 120, "%s:%ld", run ? run : "-", (long)getppid());
+}
+}  // namespace
 extern "C" int dspmap_mgpu_comm_init_from_env(dspmap_t* m) {
     if (!m) return DSPMAP_E_ARG;
     const char* wr = getenv("WORLD_SIZE"); const char* rk = getenv("RANK");
@@ -225,27 +245,46 @@ extern "C" int dspmap_mgpu_comm_init_from_env(dspmap_t* m) {
     char path[512];
     const char* f = getenv("DSPMAP_RDZV_FILE");
     if (f) snprintf(path, sizeof(path), "%s", f);
-    else snprintf(path, sizeof(path), "/tmp/dspmap_rdzv_%s", getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0");
-    char id[DSPMAP_UNIQUE_ID_BYTES];
+    else snprintf(path, sizeof(path), "/tmp/dspmap_rdzv_%ld_%s", (long)getuid(), getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0");
+    RdzvRecord rec;
+    memset(&rec, 0, sizeof(rec));
+    char nonce[120];
+    rdzv_nonce(nonce);
     if (rank == 0) {
-        int rc = dspmap_mgpu_get_unique_id(id);
+        int rc = dspmap_mgpu_get_unique_id(rec.id);
         if (rc != DSPMAP_OK) return dspmap_fail(m, rc, "ncclGetUniqueId failed");
+        memcpy(rec.magic, "DSPRDZV1", 8);
+        memcpy(rec.nonce, nonce, sizeof(rec.nonce));
         char tmp[600];
-        snprintf(tmp, sizeof(tmp), "%s.tmp", path);
-        FILE* fp = fopen(tmp, "wb");
-        if (!fp || fwrite(id, 1, sizeof(id), fp) != sizeof(id)) { if (fp) fclose(fp); return dspmap_fail(m, DSPMAP_E_ARG, "cannot write %s", tmp); }
-        fclose(fp);
-        if (rename(tmp, path) != 0) return dspmap_fail(m, DSPMAP_E_ARG, "cannot publish %s", path);
+        snprintf(tmp, sizeof(tmp), "%s.%ld.tmp", path, (long)getpid());
+        (void)unlink(path);   // a previous run's file (its nonce would not match anyway)
+        (void)unlink(tmp);
+        const int fd = open(tmp, O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+        if (fd < 0) return dspmap_fail(m, DSPMAP_E_ARG, "cannot create %s", tmp);
+        const bool ok = write(fd, &rec, sizeof(rec)) == (ssize_t)sizeof(rec);
+        close(fd);
+        if (!ok) { (void)unlink(tmp); return dspmap_fail(m, DSPMAP_E_ARG, "cannot write %s", tmp); }
+        if (rename(tmp, path) != 0) { (void)unlink(tmp); return dspmap_fail(m, DSPMAP_E_ARG, "cannot publish %s", path); }
     } else {
         bool got = false;
         for (int tries = 0; tries < 6000 && !got; ++tries) {   // up to 60 s
-            FILE* fp = fopen(path, "rb");
-            if (fp) { got = fread(id, 1, sizeof(id), fp) == sizeof(id); fclose(fp); }
+            const int fd = open(path, O_RDONLY | O_NOFOLLOW);
+            if (fd >= 0) {
+                struct stat st;
+                RdzvRecord r2;
+                got = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == getuid() &&
+                      read(fd, &r2, sizeof(r2)) == (ssize_t)sizeof(r2) && memcmp(r2.magic, "DSPRDZV1", 8) == 0 &&
+                      memcmp(r2.nonce, nonce, sizeof(r2.nonce)) == 0;   // this launch's file, not a leftover
+                if (got) rec = r2;
+                close(fd);
+            }
             if (!got) usleep(10000);
         }
-        if (!got) return dspmap_fail(m, DSPMAP_E_STATE, "no unique id appeared in %s", path);
+        if (!got) return dspmap_fail(m, DSPMAP_E_STATE, "no unique id of this launch (nonce %s) appeared in %s", nonce, path);
     }
-    return dspmap_mgpu_comm_init(m, world, rank, id);
+    const int rc = dspmap_mgpu_comm_init(m, world, rank, rec.id);
+    if (rank == 0) (void)unlink(path);   // ncclCommInitRank returned: every rank has joined, i.e. has read the file
+    return rc;
 }
 
 extern "C" int dspmap_mgpu_comm_destroy(dspmap_t* m) {

@@ -9,6 +9,7 @@
 #include "dspmap_kernels.h"
 #include "velocity_estimator.h"
 
+#define DSPMAP_PTS_RING 4  // pinned cloud staging buffers in rotation
 #define DSPMAP_RING 1024   // slots of the pinned frame-parameter ring (power of two)
 struct dspmap {
     dspmap_config cfg;
@@ -48,8 +49,15 @@ struct dspmap {
     // capacities
     int pt_cap = 0, birth_cap = 0;
     float* pts_dev = nullptr;        // staging for host-fed clouds
+    // pinned staging of host-fed clouds: a RING of buffers, each guarded by an event recorded behind its copy -- update()
+    // returns while the frame (and the H2D copy in front of it) is still queued, and the caller may refill its cloud and
+    // call again at once (the parameter ring lets the host run many frames ahead); pts_pin = the slot in use
     float* pts_pin = nullptr; int pts_pin_cap = 0;
+    float* pts_ring[DSPMAP_PTS_RING] = {}; int pts_ring_cap[DSPMAP_PTS_RING] = {};
+    hipEvent_t pts_ring_ev[DSPMAP_PTS_RING] = {}; bool pts_ring_busy[DSPMAP_PTS_RING] = {};
+    unsigned pts_ring_pos = 0;
     BirthSrc* birth_pin = nullptr; int birth_pin_cap = 0;
+    hipEvent_t birth_ev = nullptr; bool birth_ev_set = false;   // behind the last copy out of birth_pin
     // birth cloud supplied by the caller (estimator off) / produced by the estimator
     std::vector<dspmap_vpoint> h_birth;
     bool h_birth_valid = false;
@@ -91,6 +99,7 @@ struct dspmap {
     bool mgpu_bound = false;
     bool mgpu_self_bound = false;      // the C++ driver (dspmap_dist.hip) works on the library's own Ck / n_static buffers
     struct dspmap_dist* dist = nullptr;
+    bool mgpu_all_static = false;      // every birth source of the frame carries a zero-velocity tag: no velocity / rand() draws (:877-903)
     bool mgpu_birth_early = false;     // rank + children already queued by dspmap_mgpu_export_both
     bool mgpu_interior_done = false;   // dspmap_mgpu_place_interior placed the tiles [mgpu_tile_lo, mgpu_tile_hi)
     int mgpu_tile_lo = 0, mgpu_tile_hi = 0;
@@ -124,6 +133,8 @@ int dspmap_push_frame_params(dspmap* m);
 void dspmap_flush_future_clear(dspmap* m);   // m->hp -> device
 int dspmap_mark_nb_dirty(dspmap* m);
 void dspmap_dist_free(dspmap* m);
+int dspmap_pts_slot_acquire(dspmap* m, int n);   // next pinned staging slot (waits for the copy that last used it) -> m->pts_pin
+int dspmap_pts_slot_release(dspmap* m);          // after queueing the copy that reads / writes m->pts_pin
 int dspmap_stage_points(dspmap* m, int n, int stride, const float* pts);   // host cloud -> m->pts_dev (pinned staging, async copy)
 int dspmap_begin_cloud(dspmap* m, int n_points, bool static_birth);   // bumps the frame epoch; returns the birth grid bound
 

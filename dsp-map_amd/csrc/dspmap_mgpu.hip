@@ -35,17 +35,27 @@ extern "C" int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_
     if (n_points < 0 || (n_points > 0 && !points_dev) || !pos || !q) return dspmap_fail(m, DSPMAP_E_ARG, "bad arguments");
     const int nb_own = birth_dev ? n_birth : n_points;
     if (nb_own > m->mgpu_nstatic_cap || n_points > m->pt_cap) return dspmap_fail(m, DSPMAP_E_ARG, "more points than the bound capacity");
+    // birth cloud: the caller's (mode 0), every point in view a static source (1), or -- DSPMAP_P_VELOCITY_ESTIMATOR = 2 -- the
+    // device velocity estimator's (2).  The estimator (velocityEstimationThread :1377-1544, forked and joined by every
+    // update() :297,311) works on the frame's cloud, which every rank holds, and is deterministic: every rank runs it
+    // redundantly and gets the same tagged cloud bit for bit, exactly like the rank / children of the birth stage.
+    const bool want_est = !birth_dev && m->use_vel_est != 0 && !m->cfg.static_model;
+    if (want_est && (m->use_vel_est != 2 || n_points > m->ve.cap))
+        return dspmap_fail(m, DSPMAP_E_ARG, "a sharded frame runs the velocity estimator on the device (DSPMAP_P_VELOCITY_ESTIMATOR = 2, "
+                           "clouds of at most %d points); got mode %d, %d points", m->ve.cap, m->use_vel_est, n_points);
     float dp[3], dt;
     if (!dspmap_gate_and_delta(m, pos, stamp, q, dp, &dt)) return DSPMAP_REJECTED;
     dspmap_freeze_birth_statics(m);
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
-    const bool static_birth = birth_dev == nullptr;
+    const int mode = birth_dev ? 0 : (want_est ? 2 : 1);
+    const bool static_birth = mode != 0;     // the cloud lives on the device (synthesised or estimated)
     m->mgpu_birth = static_birth ? nullptr : (BirthSrc*)birth_dev;
     for (int i = 0; i < 4; i++) m->hp.quat[i] = m->quat[i];
     for (int i = 0; i < 3; i++) { m->hp.cur_pos[i] = m->cur_pos[i]; m->hp.od[i] = -dp[i]; }
     m->hp.dt = dt;
-    m->hp.n_pts = n_points; m->hp.n_birth = nb_own; m->hp.static_birth = static_birth ? 1 : 0;
+    m->hp.res_filter = m->voxel_filter_res;
+    m->hp.n_pts = n_points; m->hp.n_birth = nb_own; m->hp.static_birth = mode;
     const int nb_grid = dspmap_begin_cloud(m, n_points, static_birth);
     const int nb = static_birth ? nb_grid : nb_own;   // grid bound of the birth launches
     m->hp.pts = points_dev;
@@ -55,7 +65,10 @@ extern "C" int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_
     dspmap_prof_collect(m);
     HIPCHK(m, hipEventRecord(m->ev0, m->stream));
     launch_setup_and_bin(c, n_points, false);
-    launch_predict_only(c, true, nb > 0);   // + gather + birth rank; k_place follows the exchange: imported movers take part in the sweep-order placement
+    // + gather + (static tags) the birth rank; k_place follows the exchange: imported movers take part in the sweep-order placement
+    launch_predict_only(c, true, nb > 0 && mode != 2);
+    if (mode == 2 && nb > 0) launch_velocity_estimator(c, true);   // ... with the estimator the rank rides on k_ve_clusters
+    m->mgpu_all_static = mode == 1;
     m->mgpu_place_pending = true;
     m->mgpu_interior_done = false;
     m->mgpu_birth_early = false;
@@ -167,7 +180,7 @@ extern "C" int dspmap_mgpu_finish(dspmap_t* m) {
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
     if (!m->mgpu_birth_early) launch_birth_early(c, m->last_n_birth, false);   // caller used the per-direction exports
-    launch_birth_finish(c, m->last_n_birth, m->last_birth_static);
+    launch_birth_finish(c, m->last_n_birth, m->mgpu_all_static);
     m->mgpu_birth_early = false;
     launch_resample(c);
     if (m->nb_dirty) { m->nb_dirty = false; m->graph_epoch++; }

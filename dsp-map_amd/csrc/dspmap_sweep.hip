@@ -584,18 +584,19 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
 #ifndef PLACE_SIDE_WG
 #define PLACE_SIDE_WG 3   // workgroups per CU of the side-stream placement
 #endif
-#define PLACE_MAX 1024   // arrivals of one tile ordered exactly; a tile that receives more falls back to arrival order
+#define PLACE_MAX 1024   // arrivals of one tile whose bucketed keys fit the LDS table; a tile that receives more (up to its
+                         // capacity of 64 * slots records) keeps them in its own staging area of k_predict, which is dead by now
 template <int MW>
 __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, const float4* __restrict__ in_rec, int* __restrict__ in_cnt,
-                                           int* __restrict__ part2, int has_vz, int tab_n, const u64* __restrict__ omask, const int BX) {
+                                           int* __restrict__ part2, int has_vz, int tab_n, const u64* __restrict__ omask,
+                                           float4* __restrict__ stage, const int BX) {
     if (has_vz && BX == 0 && threadIdx.x == 0)   // k_predict drew 3 table values per ranked particle (:655-657)
         s.fs->v_cur = (int)(((long long)s.fs->v_cur + 3ll * (long long)s.fs->occupied_count) % tab_n);
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
     __shared__ u64 s_cur[MW * 64], s_org[MW * 64], s_new[MW * 64];
     __shared__ int s_lcnt[64], s_loff[65];
-    __shared__ int s_key[PLACE_MAX];             // source key of arrival i
-    __shared__ unsigned short s_ord[PLACE_MAX];  // arrival indices bucketed by destination lane
+    __shared__ int s_bk[PLACE_MAX];              // source keys of the arrivals, bucketed by destination lane
     __shared__ int s_cnt[2];
     const int tid = threadIdx.x;
     const int n_all = in_cnt[BX];
@@ -606,7 +607,8 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
     const bool was_live = s.tile_live[BX] != 0;   // an empty tile was skipped by k_predict: its omask words are stale (and zero in truth)
     const int cap = 64 * d.slots;
     const int n = min(n_all, cap);
-    const bool exact = n <= PLACE_MAX;
+    const bool in_lds = n <= PLACE_MAX;
+    int* const gbk = reinterpret_cast<int*>(stage + (size_t)BX * cap * 2);   // (cap * 8 ints; cap are used)
     for (int i = tid; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
     for (int i = tid; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
     if (tid < 64) {
@@ -627,108 +629,97 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
     // the first 256 records stay in registers across the phases (most tiles receive fewer): one memory round trip
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), b0 = a0;
     if (tid < n) { a0 = in_rec[(base + tid) * 2]; b0 = in_rec[(base + tid) * 2 + 1]; }
-    if (exact) {
-        // bucket the arrivals by destination lane
-        for (int i = tid; i < n; i += 256) {
-            const float4 a = i == tid ? a0 : in_rec[(base + i) * 2];
-            const float4 b = i == tid ? b0 : in_rec[(base + i) * 2 + 1];
-            s_key[i] = __float_as_int(b.w);
-            atomicAdd(&s_lcnt[(__float_as_int(a.x) - d.v_base) & 63], 1);
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const int c = s_lcnt[tid];
-            const int inc = wave_incl_scan_i(c);
-            s_loff[tid] = inc - c;
-            if (tid == 63) s_loff[64] = inc;
-            s_lcnt[tid] = 0;
-        }
-        __syncthreads();
-        for (int i = tid; i < n; i += 256) {
-            const int ln = (__float_as_int(i == tid ? a0.x : in_rec[(base + i) * 2].x) - d.v_base) & 63;
-            s_ord[s_loff[ln] + atomicAdd(&s_lcnt[ln], 1)] = (unsigned short)i;
-        }
-        __syncthreads();
-    } else if (tid < 64) {
-        s_lcnt[tid] = 0;   // fallback: arrival order, slots freed by the prediction available to everyone
+    // bucket the arrivals' source keys by destination lane: counts, offsets, then every key into its lane's run
+    for (int i = tid; i < n; i += 256) {
+        const int gv = __float_as_int(i == tid ? a0.x : in_rec[(base + i) * 2].x);
+        atomicAdd(&s_lcnt[(gv - d.v_base) & 63], 1);
     }
-    if (!exact) __syncthreads();
+    __syncthreads();
+    if (tid < 64) {
+        const int c = s_lcnt[tid];
+        const int inc = wave_incl_scan_i(c);
+        s_loff[tid] = inc - c;
+        if (tid == 63) s_loff[64] = inc;
+        s_lcnt[tid] = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int gv = __float_as_int(i == tid ? a0.x : in_rec[(base + i) * 2].x);
+        const int key = __float_as_int(i == tid ? b0.w : in_rec[(base + i) * 2 + 1].w);
+        const int ln = (gv - d.v_base) & 63;
+        const int o = s_loff[ln] + atomicAdd(&s_lcnt[ln], 1);
+        if (in_lds) s_bk[o] = key;
+        else __hip_atomic_store(&gbk[o], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
     for (int i0 = 0; i0 < n; i0 += 256) {
         const int i = i0 + tid;
         int key[1] = {-1}, pos[1];
         int ln = 0, nsl = -1, skey = 0;
         size_t nidx = 0;
-        float px = 0, py = 0, pz = 0, w = 0;
+        float px = 0, py = 0, pz = 0, w = 0, avx = 0, avy = 0;
         if (i < n) {
             const float4 a = i == tid ? a0 : in_rec[(base + i) * 2];
             const float4 b = i == tid ? b0 : in_rec[(base + i) * 2 + 1];
-            px = a.w; py = b.x; pz = b.y; w = b.z;
+            px = a.w; py = b.x; pz = b.y; w = b.z; avx = a.y; avy = a.z;
             skey = __float_as_int(b.w);
             ln = (__float_as_int(a.x) - d.v_base) & 63;
-            if (exact) {
-                // position of this arrival in the reference's service order of its destination voxel, in closed form:
-                // the nF arrivals from lower voxel indices take, in key order, the first free slots of the occupancy
-                // BEFORE the prediction; the others then take the first free slots of the occupancy AFTER it that are
-                // still left
-                const int o0 = s_loff[ln], mm = s_loff[ln + 1] - o0;
-                const int mykey = __float_as_int(b.w);
-                const long long dkey = (long long)(BX * 64 + ln + d.v_base) * d.slots;   // key of (D, slot 0)
-                int r = 0, nF = 0;
+            // position of this arrival in the reference's service order of its destination voxel, in closed form:
+            // the nF arrivals from lower voxel indices take, in key order, the first free slots of the occupancy
+            // BEFORE the prediction; the others then take the first free slots of the occupancy AFTER it that are
+            // still left
+            const int o0 = s_loff[ln], mm = s_loff[ln + 1] - o0;
+            const long long dkey = (long long)(BX * 64 + ln + d.v_base) * d.slots;   // key of (D, slot 0)
+            int r = 0, nF = 0;
+            if (in_lds) {
                 for (int x = 0; x < mm; ++x) {
-                    const int kx = s_key[s_ord[o0 + x]];
-                    r += kx < mykey ? 1 : 0;
+                    const int kx = s_bk[o0 + x];
+                    r += kx < skey ? 1 : 0;
                     nF += (long long)kx < dkey ? 1 : 0;
                 }
-                u64 frO[MW], frC[MW];
-                int avail = 0;
-#pragma unroll
-                for (int e = 0; e < MW; ++e) { frO[e] = ~s_org[e * 64 + ln] & valid_bits(d, e); avail += (int)__popcll(frO[e]); }
-                if (r < nF) {            // forward arrival: r-th free slot of the old occupancy
-                    int q = r;
-#pragma unroll
-                    for (int e = 0; e < MW; ++e) {
-                        const int c = (int)__popcll(frO[e]);
-                        if (nsl < 0) {
-                            if (q < c) { u64 f = frO[e]; for (; q > 0; --q) f &= f - 1ull; nsl = e * 64 + (__ffsll((long long)f) - 1); }
-                            else q -= c;
-                        }
-                    }
-                } else {                 // backward arrival: skip what the forward ones took
-                    int tk = min(nF, avail);   // forward arrivals that found a slot: the first tk free bits of the old occupancy
-#pragma unroll
-                    for (int e = 0; e < MW; ++e) {
-                        u64 f = frO[e], took = 0ull;
-                        for (; tk > 0 && f; --tk) { took |= f & (~f + 1ull); f &= f - 1ull; }
-                        frC[e] = ~s_cur[e * 64 + ln] & valid_bits(d, e) & ~took;
-                    }
-                    int q = r - nF;
-#pragma unroll
-                    for (int e = 0; e < MW; ++e) {
-                        const int c = (int)__popcll(frC[e]);
-                        if (nsl < 0) {
-                            if (q < c) { u64 f = frC[e]; for (; q > 0; --q) f &= f - 1ull; nsl = e * 64 + (__ffsll((long long)f) - 1); }
-                            else q -= c;
-                        }
-                    }
-                }
             } else {
-                int r = atomicAdd(&s_lcnt[ln], 1);
+                for (int x = 0; x < mm; ++x) {   // (agent-scope loads: served by the L2 the stores above went to)
+                    const int kx = __hip_atomic_load(&gbk[o0 + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    r += kx < skey ? 1 : 0;
+                    nF += (long long)kx < dkey ? 1 : 0;
+                }
+            }
+            u64 frO[MW], frC[MW];
+            int avail = 0;
+#pragma unroll
+            for (int e = 0; e < MW; ++e) { frO[e] = ~s_org[e * 64 + ln] & valid_bits(d, e); avail += (int)__popcll(frO[e]); }
+            if (r < nF) {            // forward arrival: r-th free slot of the old occupancy
+                int q = r;
 #pragma unroll
                 for (int e = 0; e < MW; ++e) {
-                    u64 fr = ~s_cur[e * 64 + ln] & valid_bits(d, e);
-                    const int c = (int)__popcll(fr);
+                    const int c = (int)__popcll(frO[e]);
                     if (nsl < 0) {
-                        if (r < c) {
-                            for (; r > 0; --r) fr &= fr - 1ull;
-                            nsl = e * 64 + (__ffsll((long long)fr) - 1);
-                        } else r -= c;
+                        if (q < c) { u64 f = frO[e]; for (; q > 0; --q) f &= f - 1ull; nsl = e * 64 + (__ffsll((long long)f) - 1); }
+                        else q -= c;
+                    }
+                }
+            } else {                 // backward arrival: skip what the forward ones took
+                int tk = min(nF, avail);   // forward arrivals that found a slot: the first tk free bits of the old occupancy
+#pragma unroll
+                for (int e = 0; e < MW; ++e) {
+                    u64 f = frO[e], took = 0ull;
+                    for (; tk > 0 && f; --tk) { took |= f & (~f + 1ull); f &= f - 1ull; }
+                    frC[e] = ~s_cur[e * 64 + ln] & valid_bits(d, e) & ~took;
+                }
+                int q = r - nF;
+#pragma unroll
+                for (int e = 0; e < MW; ++e) {
+                    const int c = (int)__popcll(frC[e]);
+                    if (nsl < 0) {
+                        if (q < c) { u64 f = frC[e]; for (; q > 0; --q) f &= f - 1ull; nsl = e * 64 + (__ffsll((long long)f) - 1); }
+                        else q -= c;
                     }
                 }
             }
             if (nsl >= 0) {
                 nidx = pidx(d, BX * 64 + ln, nsl);
                 st_pos(s, nidx, px, py, pz);
-                st_vel(s, nidx, a.y, a.z);
+                st_vel(s, nidx, avx, avy);
                 s.w[nidx] = w;
                 key[0] = pyramid_of(d, s_ph, s_pv, px, py, pz);
             } else {
@@ -773,7 +764,7 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
                                                int* __restrict__ in_cnt, int* __restrict__ part2, int has_vz, int tab_n,
                                                const u64* __restrict__ omask, FilterParams fp, float4* __restrict__ child,
                                                int* __restrict__ vb_cnt, int* __restrict__ vb_idx, int nchild, int t0, int n0, int t1, int n1,
-                                               const int* __restrict__ tile_fov, int sel) {
+                                               const int* __restrict__ tile_fov, int sel, float4* __restrict__ stage) {
     // whole frame: workgroups behind the tiles generate the frame's newborn children (k_birth_children's job; needs the
     // birth cloud and the rank only, both done before this launch)
     // (the first `nchild` workgroups: they run beside the tiles, not after them).
@@ -787,7 +778,7 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
     for (int bq = (int)blockIdx.x - nchild; bq < n0 + n1; bq += (int)gridDim.x - nchild) {
         const int BX = bq < n0 ? t0 + bq : t1 + (bq - n0);   // tile index
         if (sel >= 0 && (tile_fov[BX] != 0) != (sel != 0)) continue;   // the other launch of a split placement owns this tile
-        place_tile<MW>(d, s, in_rec, in_cnt, part2, has_vz, tab_n, omask, BX);
+        place_tile<MW>(d, s, in_rec, in_cnt, part2, has_vz, tab_n, omask, stage, BX);
         __syncthreads();   // the tile's LDS tables are re-used by the next one
     }
 }
@@ -1442,8 +1433,8 @@ void launch_claim(const LaunchCtx& c, int n_birth_grid, int part, int tile_lo, i
     // and the wave slots, registers and LDS it leaves free are what the pair kernels run in
     unsigned grid = (unsigned)(n0 + n1) + xb;
     if (sel == 0) grid = std::min(grid, (unsigned)(PLACE_SIDE_WG * c.n_cu));
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel);
-    else hipLaunchKernelGGL(k_place<2>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel);
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec);
+    else hipLaunchKernelGGL(k_place<2>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec);
 }
 void launch_predict(const LaunchCtx& c, bool with_gather) {
     launch_predict_only(c, with_gather, false);

@@ -115,11 +115,8 @@ static string particle_save_folder = ".";  // :55 (one per translation unit here
 #endif
 
 #ifndef DSPMAP_ESTIMATOR_MODE
-#ifdef DSPMAP_WORLD
-#define DSPMAP_ESTIMATOR_MODE 0   /* sharded frames tag every point in view static (the estimator's stage is per process) */
-#else
-#define DSPMAP_ESTIMATOR_MODE 2   /* velocityEstimationThread on the device (dspmap_velest.hip); 1 = the host stage */
-#endif
+#define DSPMAP_ESTIMATOR_MODE 2   /* velocityEstimationThread on the device (dspmap_velest.hip); 1 = the host stage.  A sharded map
+                                     (-DDSPMAP_WORLD) runs the device estimator on every rank: same cloud, same tagged birth cloud */
 #endif
 
 class DSPMap {

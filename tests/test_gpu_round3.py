@@ -1,0 +1,198 @@
+"""GPU parity tests added in round 3 (run with `-m gpu`): heavy mover traffic through k_place, the device velocity
+estimator inside the sharded C++ frame, the 10-horizon rollout on config D's grid shape."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests import common
+from tests.test_gpu_parity import gpu_state, make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+# sensor pitched 90 degrees: the field of view leaves these flat maps through the top face after ~0.4 m, so that no pyramid
+# list overflows (a full LIST is a different rule, :1256-1259, tested on its own)
+UP = (0.70710678, 0.0, -0.70710678, 0.0)
+
+
+def _saturated(o, m, ppv, seed, vmax=0.0, moving_frac=0.0):
+    """every voxel holds exactly `ppv` particles (slots 0..ppv-1 on both sides), positions uniform inside the voxel and
+    2 % away from its faces"""
+    cfg = o.cfg
+    nx, ny, nz, res = cfg.nx, cfg.ny, cfg.nz, np.float32(cfg.voxel_resolution)
+    half = common.half_extent(cfg)
+    rng = np.random.default_rng(seed)
+    V = nx * ny * nz
+    idx = np.repeat(np.arange(V), ppv)
+    zi, rest = idx // (nx * ny), idx % (nx * ny)
+    yi, xi = rest // nx, rest % nx
+    u = 0.02 + 0.96 * rng.random((3, len(idx)))
+    px = ((xi + u[0]) * res - half[0]).astype(np.float32)
+    py = ((yi + u[1]) * res - half[1]).astype(np.float32)
+    pz = ((zi + u[2]) * res - half[2]).astype(np.float32)
+    mv = rng.random(len(idx)) < moving_frac
+    vx = (rng.uniform(-vmax, vmax, len(idx)) * mv).astype(np.float32)
+    vy = (rng.uniform(-vmax, vmax, len(idx)) * mv).astype(np.float32)
+    w = rng.uniform(0.005, 0.02, len(idx)).astype(np.float32)
+    n = common.inject_both(o, m, px, py, pz, vx, vy, w)
+    assert n == V * ppv
+    return n
+
+
+@pytest.mark.parametrize("case", ["shift_x", "shift_back_diag", "mixed_overflow", "two_words"])
+def test_heavy_mover_traffic_is_slot_exact(dsp, orc, case):
+    """moveParticle's first-free-in-sweep-order rule (:1209-1230) when a 64-voxel tile receives far more arrivals than the
+    1 024 whose keys fit k_place's LDS table (a saturated 24-particles-per-voxel tile holds 1 536): an ego step of one whole
+    voxel moves EVERY particle; the same particles must end up in the same slots as in the oracle, two runs must agree bit
+    for bit."""
+    ppv = 36 if case == "two_words" else 24
+    cfgkw = dict(nx=32, ny=16, nz=4, res=0.15 if ppv == 24 else 0.10, ppv=ppv)
+    res = cfgkw["res"]
+    step = {"shift_x": (res, 0.0, 0.0, 1 / 30.0),                      # everybody one voxel up in x: forward arrivals only
+            "shift_back_diag": (-0.7 * res, -0.6 * res, 0.0, 1 / 30.0),  # most move, to LOWER voxel indices: backward arrivals
+            "mixed_overflow": (0.4 * res, 0.0, 0.3 * res, 0.1),          # + random velocities: both directions, full voxels
+            "two_words": (res, res, 0.0, 1 / 30.0)}[case]
+    runs = []
+    for rep in range(2):
+        o, m = make_pair(dsp, orc, **cfgkw)
+        n = _saturated(o, m, ppv, 11, vmax=6.0 if case == "mixed_overflow" else 0.0,
+                       moving_frac=0.7 if case == "mixed_overflow" else 0.0)
+        empty = np.zeros((0, 3), np.float32)
+        m.bin_points(empty, UP)
+        m.predict(*step)
+        vg, sg, rg = gpu_state(m)
+        c = m.counters()
+        kg = np.lexsort((sg, vg))
+        runs.append((vg[kg], sg[kg], rg[kg]))
+        if rep == 0:
+            o.bin_points(empty, UP)
+            o.predict(*step)
+            vo, so, ro = o.export_sparse()
+            ko = np.lexsort((so, vo))
+            assert c["n_live_in"] == n
+            assert c["n_moved"] > 0.55 * n, c
+            # arrivals per 64-voxel tile: well beyond the LDS table
+            assert c["n_moved"] / (m.V / 64) > 1100 or case == "mixed_overflow", c
+            if case == "mixed_overflow":
+                assert c["n_voxel_full"] > 10, c
+            assert c["n_pyramid_full"] == 0 and c["n_fov"] > 0, c
+            assert len(vg) == len(vo) == n - c["n_out_of_map"] - c["n_voxel_full"]
+            assert np.array_equal(vo[ko], vg[kg]) and np.array_equal(so[ko], sg[kg])
+            for col in (1, 2, 4, 5, 6, 7):
+                assert np.array_equal(ro[ko][:, col], rg[kg][:, col]), col
+        o.close(); m.close()
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(a, b)
+
+
+def test_rollout_ten_horizons_on_config_d_grid_shape(dsp, orc):
+    """config D's own grid shape (132 x 132 voxels per layer, 24 particles per voxel, PREDICTION_TIMES = 10, horizons
+    0.2 (k + 1) s) against the oracle (:950-964): tiles with hundreds of moving particles take k_rollout's LDS-window path
+    (a row of the grid is 132 voxels: the 8 192-voxel window covers +-30 rows), particles faster than 2.3 m/s leave the
+    window within the 2 s horizon and take the straggler path, sparse tiles the direct one"""
+    pred = tuple(0.2 * (k + 1) for k in range(10))
+    cfgkw = dict(nx=132, ny=132, nz=12, res=0.15, ppv=24, pred_times=pred)
+    o, m = make_pair(dsp, orc, seed=7, **cfgkw)
+    assert m.T == 10
+    half = common.half_extent(o.cfg)
+    px, py, pz, vx, vy, w = common.random_particles(31, 340000, (half[0] * 0.4, half[1] * 0.4, half[2] * 0.95),
+                                                    vmax=3.0, static_frac=0.2, wlo=0.002, whi=0.05)
+    bx, by, bz, bvx, bvy, bw = common.random_particles(32, 60000, half, vmax=1.5, static_frac=0.5)
+    px = np.concatenate([px, bx]); py = np.concatenate([py, by]); pz = np.concatenate([pz, bz])
+    vx = np.concatenate([vx, bvx]); vy = np.concatenate([vy, bvy]); w = np.concatenate([w, bw])
+    n = common.inject_both(o, m, px, py, pz, vx, vy, w, np.ones_like(w))
+    vo, so, ro = o.export_sparse()
+    moving = (ro[:, 1] != 0) | (ro[:, 2] != 0)
+    per_tile = np.bincount(vo[moving] >> 6, minlength=(o.V + 63) // 64)
+    assert (per_tile >= 192).sum() > 300 and ((per_tile > 0) & (per_tile < 192)).sum() > 300      # both rollout paths
+    far = np.abs(ro[moving, 2]) * 2.0 / 0.15 > 31                                                   # > 30 rows away at 2 s
+    assert far.sum() > 10000                                                                        # stragglers exist
+    o.occupancy_resample(); m.occupancy_resample()
+    res_o = o.results
+    assert np.array_equal(m.results()[:, 0], res_o[:, 0])
+    fut_g = m.getFutureStatus()
+    assert fut_g.shape == (m.V, 10)
+    assert np.allclose(fut_g, res_o[:, 4:14], rtol=1e-4, atol=1e-6)
+    tot_g, tot_o = fut_g.astype(np.float64).sum(axis=0), res_o[:, 4:14].astype(np.float64).sum(axis=0)
+    assert np.allclose(tot_g, tot_o, rtol=1e-6) and tot_o[-1] < 0.99 * tot_o[0]                     # mass leaves the map over time
+    o.close(); m.close()
+
+
+def _group_vs_full(dsp, world, cfg, frames, seed=3):
+    """the C++ frame driver over `world` slabs in one process and the unsharded map, both with the DEVICE velocity
+    estimator in the frame, fed the same frames: every slot and every float must be equal"""
+    sharded = __import__("dsp-map_amd.sharded", fromlist=["CppGroup"])
+    tables = common.tables(seed)
+    grp = sharded.CppGroup(dsp, cfg, world)
+    full = dsp.DSPMap(dsp.make_config(**cfg))
+    for x in grp.maps + [full]:
+        x.set_tables(*tables)
+        x.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, 2)
+    clouds = []
+    for pts, pos, t, q in frames:
+        d = torch.from_numpy(np.ascontiguousarray(pts, np.float32)).cuda()
+        assert grp.update(d, pos, t, q) == 1
+        assert full.update_device(d.data_ptr(), len(pts), pos, t, q) == 1
+        grp.sync()
+        clouds.append([x.get_birth_cloud() for x in (grp.maps[0], grp.maps[-1], full)])
+        for x in grp.maps + [full]:
+            x.clearOccupancyMapPrediction()
+    got = np.concatenate([x.results() for x in grp.maps], 0)
+    assert np.array_equal(got, full.results())
+    parts = [x.export_state() for x in grp.maps]
+    sv, ss, sr = (np.concatenate([p[k] for p in parts]) for k in range(3))
+    order = np.lexsort((ss, sv))
+    fv, fs_, fr = full.export_state()
+    assert np.array_equal(sv[order], fv) and np.array_equal(ss[order], fs_) and np.array_equal(sr[order], fr)
+    assert sum(x.counters()["n_live_out"] for x in grp.maps) == full.counters()["n_live_out"]
+    cur = [x.cursors() for x in grp.maps + [full]]
+    assert all(c == cur[0] for c in cur)                    # every rank consumed the three random streams alike
+    holding = sum(1 for p in parts if len(p[0]) > 0)         # slabs that hold particles
+    grp.close(); full.close()
+    return clouds, fr, holding
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_frame_runs_the_velocity_estimator_multi_cluster(dsp, world):
+    """the reference forks / joins velocityEstimationThread in EVERY update() (:297,311,1377-1544): a sharded frame
+    (dspmap_mgpu_update's phases) runs the device estimator redundantly on every slab -- same cloud, deterministic
+    kernels, same tagged birth cloud -- so that a sharded map is the same filter as the unsharded one: bit-identical on
+    the seven-group scene (moving, too fast, gated, static clusters), dynamic newborn velocities included"""
+    from tests.test_gpu_round2 import _cluster_scene
+    cfg = dict(nx=66, ny=66, nz=40, res=0.15, ppv=12)
+    frames = []
+    for f in range(4):
+        t = f * 0.1
+        frames.append((_cluster_scene(t, f), (0.0, 0.0, 1.0 + 0.04 * f), t, (1.0, 0.0, 0.0, 0.0)))
+    clouds, rec, holding = _group_vs_full(dsp, world, cfg, frames)
+    for f, (a, b, c) in enumerate(clouds):
+        assert len(a) == len(b) == len(c) > 500
+        for k in ("x", "y", "z", "nx", "ny", "nz", "intensity"):
+            assert np.array_equal(a[k], c[k]) and np.array_equal(b[k], c[k]), (f, k)
+    g = clouds[-1][2]
+    dyn = g["intensity"] > 0.01
+    assert dyn.sum() > 200 and np.isclose(g["ny"][dyn], 1.0, atol=0.02).sum() == 60      # cluster A matched at 1 m/s
+    assert (np.abs(rec[:, 1]) + np.abs(rec[:, 2]) > 0.3).sum() > 100                     # moving newborns in the map
+    assert holding >= 2                                                                  # the scene spans several slabs
+
+
+def test_sharded_frame_runs_the_velocity_estimator_depth_stream(dsp):
+    """the benchmark's depth stream (pedestrians, boxes, ~5000 points per frame) through 4 slabs with the device estimator
+    in the frame, incl. a frame with an empty view (the previous birth cloud is re-used, :1379-1381): == unsharded"""
+    scene_mod = __import__("dsp-map_amd.scene", fromlist=["CorridorScene"])
+    cfg = dict(nx=66, ny=66, nz=40, res=0.15, ppv=24)
+    sc = scene_mod.CorridorScene(66 * 0.15, 66 * 0.15, 40 * 0.15, seed=1234, device="cuda")
+    frames = []
+    for f in range(7):
+        t = f / 30.0
+        pts_t, pos, quat = sc.frame(t)
+        pts = pts_t.cpu().numpy().copy()
+        if f == 4:
+            pts[:, 0] *= -1.0
+        frames.append((pts, pos, t, quat))
+    clouds, rec, holding = _group_vs_full(dsp, 4, cfg, frames, seed=5)
+    assert sum(int((c[2]["intensity"] > 0.01).sum()) for c in clouds) > 200
+    assert len(clouds[4][2]) == len(clouds[3][2])            # empty view: the previous cloud
+    assert (np.abs(rec[:, 1]) + np.abs(rec[:, 2]) > 0.3).sum() > 100
