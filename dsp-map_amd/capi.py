@@ -19,7 +19,7 @@ OK, REJECTED = 1, 0
 
 P_POSITION_STDDEV, P_VELOCITY_STDDEV, P_OBSERVATION_STDDEV, P_NEWBORN_WEIGHT, P_NEWBORN_NUMBER, \
     P_VOXEL_FILTER_RES, P_KAPPA, P_DETECTION, P_VELOCITY_ESTIMATOR, P_REGENERATE_TABLES, P_USE_GRAPH, P_OCCLUSION_MARGIN, \
-    P_PAIR_CULL_SIGMAS, P_UPDATE_TIME, P_UPDATE_COUNTER, P_PLACE_SPLIT_TILES = range(1, 17)
+    P_PAIR_CULL_SIGMAS, P_UPDATE_TIME, P_UPDATE_COUNTER, P_PLACE_SPLIT_TILES, P_FAST_DIVISION = range(1, 18)
 
 
 class Config(C.Structure):
@@ -93,6 +93,7 @@ SIGNATURES = {
     "dspmap_set_profiling": (_i, [_P, _i]),
     "dspmap_get_stage_ms": (_i, [_P, _fp, _ip]),
     "dspmap_debug_stream": (_i, [_P, _i, C.POINTER(C.c_longlong)]),
+    "dspmap_debug_sweep_probe": (_i, [_P, _i, _i, _i, _i, _fp, C.POINTER(C.c_longlong)]),
     "dspmap_debug_tile_view": (_i, [_P, C.POINTER(C.c_int), _i]),
     "dspmap_clear_state": (_i, [_P]),
     "dspmap_import_state": (_i, [_P, _i, _P, _P, _P]),

@@ -15,6 +15,8 @@
 #include <ctime>
 #include <random>
 #include <string>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "dspmap_internal.h"
@@ -111,6 +113,7 @@ static void refresh_fp(dspmap* m) {
 extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
     if (!cfg) return nullptr;
     if (cfg->nx <= 0 || cfg->ny <= 0 || cfg->nz <= 0 || cfg->voxel_resolution <= 0.f) return nullptr;
+    if ((long long)cfg->nx * cfg->ny >= (1ll << 24) || cfg->nz >= (1 << 24)) return nullptr;   // voxel_of multiplies 24-bit factors
     if (cfg->angle_resolution <= 0 || cfg->max_particle_num_voxel <= 0 || cfg->max_particle_num_voxel > 64) return nullptr;
     if (cfg->prediction_times < 0 || cfg->prediction_times > DSPMAP_MAX_PRED_TIMES) return nullptr;
     if (cfg->z_lo < 0 || cfg->z_hi > cfg->nz || cfg->z_lo > cfg->z_hi) return nullptr;
@@ -156,7 +159,7 @@ static void free_dev(dspmap* m) {
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, s.fov_rec, s.fov_slot, s.fov_key, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.ro_cnt, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
-                    m->k.part_predict, m->k.part_claim, m->k.tile_fov, s.tile_live, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev};
+                    m->k.part_predict, m->k.part_claim, m->k.tile_fov, s.tile_live, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
     if (m->nbsnap_buf) chk(hipFree(m->nbsnap_buf), "hipFree");
     {
@@ -255,7 +258,7 @@ int dspmap_ensure_point_cap(dspmap* m, int n) {
     const int cap = n + n / 2 + 1024;
     if (m->mgpu_bound && !m->mgpu_self_bound) return dspmap_fail(m, DSPMAP_E_ARG, "%d points exceed the capacity bound with dspmap_mgpu_bind", n);
     BirthSrc* old_birth = s.birth;   // holds the cloud of the last non-empty view (re-used by frames with an empty one): carried over
-    void* olds[] = {s.pt_rot, s.pt_pyr, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, m->pts_dev, m->k.child, m->k.part_birth};
+    void* olds[] = {s.pt_rot, s.pt_pyr, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, m->pts_dev, m->k.child, m->k.part_birth, s.birth_ovf};
     for (void* p : olds) if (p) (void)hipFree(p);
     HIPCHK(m, dalloc(&s.pt_rot, (size_t)cap));
     HIPCHK(m, dalloc(&s.pt_pyr, (size_t)cap));
@@ -270,6 +273,7 @@ int dspmap_ensure_point_cap(dspmap* m, int n) {
     HIPCHK(m, dalloc(&s.nstatic, (size_t)cap));
     HIPCHK(m, dalloc(&m->pts_dev, (size_t)cap * 3));
     HIPCHK(m, dalloc(&m->k.child, (size_t)cap * 32));
+    HIPCHK(m, dalloc(&s.birth_ovf, (size_t)cap * 32));
     HIPCHK(m, dalloc(&m->k.part_birth, ((size_t)cap * 32 + 255) / 256 * 2));
     HIPCHK(m, hipMemset(m->k.part_birth, 0, sizeof(int) * (((size_t)cap * 32 + 255) / 256 * 2)));
     m->pt_cap = cap; m->birth_cap = cap;
@@ -399,6 +403,30 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
         HIPCHK(m, dalloc(&ve.n, (size_t)4));
         HIPCHK(m, hipMemset(ve.n, 0, sizeof(int) * 4));
     }
+    {   // may a / res be computed as reciprocal + two FMAs?  Compared with the IEEE quotient on the device (k_verify_div), once
+        // per resolution and process
+        static std::mutex mu;
+        static std::map<std::pair<unsigned, unsigned>, int> known;
+        m->d.rcp_res = 1.0f / m->d.res;
+        m->d.div_ok = 0;
+        const float amax = 2.f * std::max(m->d.half_x, std::max(m->d.half_y, m->d.half_z));
+        unsigned rb, ab;
+        memcpy(&rb, &m->d.res, 4); memcpy(&ab, &amax, 4);
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = known.find({rb, ab});
+        if (it == known.end()) {
+            int* bad = nullptr;
+            HIPCHK(m, hipMalloc((void**)&bad, sizeof(int)));
+            HIPCHK(m, hipMemsetAsync(bad, 0, sizeof(int), m->stream));
+            launch_verify_div(m->stream, m->d.res, m->d.rcp_res, amax, bad);
+            int nbad = 1;
+            HIPCHK(m, hipMemcpyAsync(&nbad, bad, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+            HIPCHK(m, hipStreamSynchronize(m->stream));
+            (void)hipFree(bad);
+            it = known.emplace(std::make_pair(rb, ab), nbad == 0 ? 1 : 0).first;
+        }
+        m->d.div_ok = m->div_forced_off ? 0 : it->second;
+    }
     m->device_ready = true;  // from here on free_dev() releases everything
     unsigned seed = m->cfg.seed ? m->cfg.seed : (unsigned)time(nullptr);  // :586,1151
     if (!m->tables_injected) gen_gauss_tables(m, seed);
@@ -457,6 +485,7 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
             if (v != 0 && v != 1 && v != 2) return dspmap_fail(m, DSPMAP_E_ARG, "velocity estimator: 0 off, 1 host stage, 2 device");
             m->use_vel_est = (int)v; break;
         case DSPMAP_P_USE_GRAPH: m->use_graph = v != 0; break;
+        case DSPMAP_P_FAST_DIVISION: if (v == 0) { m->d.div_ok = 0; m->div_forced_off = true; m->graph_epoch++; } break;
         case DSPMAP_P_PLACE_SPLIT_TILES: m->place_split_tiles = v < 1 ? 1 : (v > 2e9 ? 2000000000 : (int)v); m->graph_epoch++; break;
         case DSPMAP_P_OCCLUSION_MARGIN: m->fp.occl_margin = (float)v; break;
         case DSPMAP_P_PAIR_CULL_SIGMAS: if (!(v > 0)) return dspmap_fail(m, DSPMAP_E_ARG, "pair cull radius must be positive"); m->cull_sigmas = (float)v; refresh_fp(m); break;
@@ -488,6 +517,7 @@ extern "C" double dspmap_get_param(const dspmap_t* m, int key) {
         case DSPMAP_P_UPDATE_TIME: return m->update_time;
         case DSPMAP_P_UPDATE_COUNTER: return m->update_counter;
         case DSPMAP_P_PLACE_SPLIT_TILES: return m->place_split_tiles;
+        case DSPMAP_P_FAST_DIVISION: return m->d.div_ok;
         default: return 0;
     }
 }
@@ -1330,6 +1360,22 @@ extern "C" int dspmap_debug_stream(dspmap_t* m, int mode, long long* bytes_out) 
     launch_calib(c, mode, S);
     HIPCHK(m, hipStreamSynchronize(m->stream));
     if (bytes_out) *bytes_out = (long long)(mode == 0 ? S * 24 : S * 4);
+    return DSPMAP_OK;
+}
+extern "C" int dspmap_debug_sweep_probe(dspmap_t* m, int what, int rows, int rows_per_batch, int reps, float* ms_out, long long* bytes_out) {
+    READY(m);
+    if (rows < 1 || rows > m->d.slots || reps < 1) return dspmap_fail(m, DSPMAP_E_ARG, "bad probe arguments");
+    LaunchCtx c = dspmap_ctx_of(m);
+    launch_sweep_probe(c, what, rows, rows_per_batch);   // warm-up
+    HIPCHK(m, hipEventRecord(m->ev0, m->stream));
+    for (int i = 0; i < reps; ++i) launch_sweep_probe(c, what, rows, rows_per_batch);
+    HIPCHK(m, hipEventRecord(m->ev1, m->stream));
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    float ms = 0.f;
+    HIPCHK(m, hipEventElapsedTime(&ms, m->ev0, m->ev1));
+    if (ms_out) *ms_out = ms / (float)reps;
+    const long long per_cell = ((what & 1) ? 12 : 0) + ((what & 2) ? 8 : 0) + ((what & 4) ? 4 : 0) + ((what & 8) ? 12 : 0);
+    if (bytes_out) *bytes_out = (long long)m->k.ntiles * 64ll * rows * per_cell;
     return DSPMAP_OK;
 }
 extern "C" int dspmap_debug_tile_view(dspmap_t* m, int* out, int cap) {

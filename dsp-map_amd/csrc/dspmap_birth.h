@@ -118,7 +118,7 @@ __device__ __forceinline__ void birth_rank_block(const MapDims& d, const DevStat
             if (ok[j]) s.plan_pbase[base + j * nt + tid] = (int)(((long long)p_cur + 3ll * nb * (long long)(run + v[j])) % fp.tab_n);
         run += tot;
     }
-    if (tid == 0) s.fs->p_cur = (int)(((long long)p_cur + 3ll * nb * run) % fp.tab_n);
+    if (tid == 0) { s.fs->p_cur = (int)(((long long)p_cur + 3ll * nb * run) % fp.tab_n); s.fs->n_birth_ovf = 0; }
 }
 
 // One thread per (source point, child): the child's position (:871-873) and destination voxel, "inside the map" (:875),
@@ -146,6 +146,8 @@ __device__ __forceinline__ void birth_child_thread(const MapDims& d, const DevSt
         if (lv >= 0 && lv < d.v_loc) {                       // children landing in another slab are inserted by their owner
             const int pos = atomicAdd(&vb_cnt[lv], 1);
             if (pos < BIRTH_BUCKET_CAP) vb_idx[(size_t)lv * BIRTH_BUCKET_CAP + pos] = t;
+            else s.birth_ovf[atomicAdd(&s.fs->n_birth_ovf, 1)] = t;   // bucket full: WHICH children land in it depends on the arrival
+                                                                      // order, so the others are kept too (k_birth_insert ranks over both)
         } else {
             lv = -1;
         }

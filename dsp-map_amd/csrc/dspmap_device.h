@@ -131,17 +131,28 @@ __device__ __forceinline__ int pyramid_of(const MapDims& d, const float* ph, con
 }
 
 // ---- getParticleVoxelsIndex :1076-1088 + ifParticleIsOut :1118-1125.
-// True fp32 division by the resolution (Appendix A-10: a reciprocal multiply
-// would move particles that sit on voxel faces).  Returns the GLOBAL index.
+// (int)((p + half) / res) needs the CORRECTLY ROUNDED fp32 quotient (Appendix A-10: a plain reciprocal multiply would move
+// particles that sit on voxel faces).  The IEEE division costs ~11 VALU instructions; with y = RN(1 / res) the sequence
+//   q0 = a * y;  r = fma(-q0, res, a);  q = fma(r, y, q0)
+// (Markstein) returns the same correctly rounded quotient in 3.  MapDims::div_ok is set only after a kernel has compared
+// the two, bit for bit, for EVERY float a in [0, 2 * half] the map can produce (k_verify_div at device initialisation);
+// otherwise the IEEE division stays.  Returns the GLOBAL index.
+__device__ __forceinline__ float div_res(const MapDims& d, float a) {
+    if (d.div_ok) {
+        const float q0 = a * d.rcp_res;
+        const float r = __fmaf_rn(-q0, d.res, a);
+        return __fmaf_rn(r, d.rcp_res, q0);
+    }
+    return __fdiv_rn(a, d.res);
+}
 __device__ __forceinline__ bool voxel_of(const MapDims& d, float px, float py, float pz, int& gidx) {
-    if (px >= d.half_x || px <= -d.half_x || py >= d.half_y || py <= -d.half_y ||
-        pz >= d.half_z || pz <= -d.half_z)
-        return false;
-    const int x = (int)__fdiv_rn(px + d.half_x, d.res);
-    const int y = (int)__fdiv_rn(py + d.half_y, d.res);
-    const int z = (int)__fdiv_rn(pz + d.half_z, d.res);
-    gidx = z * d.ny * d.nx + y * d.nx + x;
-    return gidx >= 0 && gidx < d.v_glob;
+    if (fabsf(px) >= d.half_x || fabsf(py) >= d.half_y || fabsf(pz) >= d.half_z) return false;   // (no NaN ever gets here: >= is false, as in :1118-1125)
+    const int x = (int)div_res(d, px + d.half_x);
+    const int y = (int)div_res(d, py + d.half_y);
+    const int z = (int)div_res(d, pz + d.half_z);
+    // z * ny * nx + y * nx + x, all factors below 2^24 (z * ny * nx < v_glob < 2^31; 24-bit multiplies are full rate)
+    gidx = (int)(__umul24((unsigned)z, (unsigned)(d.ny * d.nx)) + __umul24((unsigned)y, (unsigned)d.nx) + (unsigned)x);
+    return (unsigned)gidx < (unsigned)d.v_glob;
 }
 
 // ---- queryNormalPDF :1294-1301 reproduced arithmetically.  The reference's
@@ -273,6 +284,31 @@ __device__ __forceinline__ void st_pos(const DevState& s, size_t idx, float x, f
 __device__ __forceinline__ void st_vel(const DevState& s, size_t idx, float x, float y) {
     V2 v; v.x = x; v.y = y;
     reinterpret_cast<V2*>(s.vel)[idx] = v;
+}
+
+// The same records through a buffer descriptor of one tile's cells: the lane's byte offset is a single register whatever
+// the row, the row enters as a wave-uniform scalar offset (cells before the row) -- no 64-bit address per load, so a whole
+// batch of rows can be in flight without an address register pair each.
+typedef __amdgpu_buffer_rsrc_t brsrc;
+typedef float f3v __attribute__((ext_vector_type(3)));
+typedef float f2w __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ P3 bl_pos(brsrc r, int lane, int srow_cells) {
+    const f3v v = __builtin_bit_cast(f3v, __builtin_amdgcn_raw_buffer_load_b96(r, lane * 12, srow_cells * 12, 0));
+    P3 p; p.x = v.x; p.y = v.y; p.z = v.z;
+    return p;
+}
+__device__ __forceinline__ V2 bl_vel(brsrc r, int lane, int srow_cells) {
+    const f2w v = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(r, lane * 8, srow_cells * 8, 0));
+    V2 p; p.x = v.x; p.y = v.y;
+    return p;
+}
+__device__ __forceinline__ float bl_w(brsrc r, int lane, int srow_cells) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, srow_cells * 4, 0));
+}
+__device__ __forceinline__ void bs_pos(brsrc r, int lane, int srow_cells, float x, float y, float z) {
+    f3v v; v.x = x; v.y = y; v.z = z;
+    typedef unsigned u3v __attribute__((ext_vector_type(3)));
+    __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u3v, v), r, lane * 12, srow_cells * 12, 0);
 }
 
 // claim the lowest free slot of a voxel: first-free-slot rule of addAParticle /

@@ -31,6 +31,7 @@ struct dspmap {
     int use_vel_est = 0;             // DSPMAP_P_VELOCITY_ESTIMATOR: 0 off, 1 host stage (velocity_estimator.cpp), 2 device (dspmap_velest.hip)
     VelEst ve = {};
     bool regen_tables = false;
+    bool div_forced_off = false;     // DSPMAP_P_FAST_DIVISION = 0
     bool nb_frozen = false;                  // function statics of the birth stage (:808-811)
     // tables (host copies kept until upload)
     std::vector<float> h_ptab, h_vtab;

@@ -58,6 +58,9 @@ void launch_scan_blocks(const LaunchCtx& c, int nblk);   // exclusive scan of s.
 void launch_claim(const LaunchCtx& c, int n_birth_grid = 0, int part = 0, int tile_lo = 0, int tile_hi = 0, int sel = -1);   // sel: -1 every tile of the part, 1 / 0 only the tiles with / without a view on the sensor's field of view (tile_fov)   // part: 0 all tiles, 1 [lo, hi), 2 the rest;   // > 0: k_birth_children rides along (after a launch with_rank)
 void launch_reduce_counters(const LaunchCtx& c);
 void launch_calib(const LaunchCtx& c, int mode, size_t n);
+void launch_sweep_probe(const LaunchCtx& c, int what, int rows, int rows_per_batch);
+// every float a in [0, amax]: does reciprocal + two FMAs give the IEEE quotient a / res?  *bad counts the exceptions
+void launch_verify_div(hipStream_t stream, float res, float rcp_res, float amax, int* bad);
 // multi-GPU: compact particles that left the slab / insert particles received from a neighbour
 void launch_export_slab(const LaunchCtx& c, int dir, float* rec_out, int cap, int* count_dev, float* rec_out_down = nullptr);   // dir 0: both (up -> rec_out / count[0], down -> rec_out_down / count[1])
 void launch_import_movers(const LaunchCtx& c, int n, const float* rec);  // folds the per-block partial counters into FrameScalars

@@ -853,7 +853,8 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, const flo
                 }
                 // rank among this voxel's children, by birth index
                 int rank = 0;
-                bool recorded = false;
+                const int n_all = vb_cnt[lv];
+                bool recorded = n_all > BIRTH_BUCKET_CAP;   // (then every child of the voxel is in the bucket or in the overflow list)
                 const int4* bl4 = reinterpret_cast<const int4*>(vb_idx + (size_t)lv * BIRTH_BUCKET_CAP);
                 for (int j = 0; j < n; j += 16) {  // 4 x 16-byte loads in flight per step (the bucket row is 512 B, always readable); entries beyond n ignored
                     int4 v4[4];
@@ -868,6 +869,15 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, const flo
                             rank += (valid && o[q] < t) ? 1 : 0;
                             recorded |= valid && (o[q] == t);
                         }
+                    }
+                }
+                if (n_all > BIRTH_BUCKET_CAP) {
+                    // more children than the bucket holds (a dense cloud into one voxel): the bucket kept whichever arrived first,
+                    // the rest are in the overflow list -- ranking over both gives the reference's order whatever the arrival order
+                    const int n_ovf = s.fs->n_birth_ovf;
+                    for (int j = 0; j < n_ovf; ++j) {
+                        const int o = s.birth_ovf[j];
+                        rank += (o < t && __float_as_int(child[o].w) == lv) ? 1 : 0;
                     }
                 }
                 int sl = -1;

@@ -17,6 +17,7 @@
 //     64 lanes busy at 24 particles/voxel).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstring>
 #include "dspmap_device.h"
 #include "dspmap_kernels.h"
 #include "dspmap_birth.h"
@@ -41,11 +42,19 @@ __device__ __forceinline__ u64 valid_bits(const MapDims& d, int e) {
 
 // rows of a tile are processed in batches of RB: all loads of a batch are issued before any is
 // consumed, so a wave pays one memory round trip per batch instead of one per row
+#ifndef RB
 #define RB 2
+#endif
 #define TB 2      // records per thread and step in the tails of k_predict / k_place
-#define DENSE_MAX 4096  // live cells up to which k_predict may take the dense-lane path
+#ifndef DENSE_MAX
+#define DENSE_MAX 2048
+#endif
+// DENSE_MAX: live cells up to which k_predict may take the dense-lane path
 #define HIST_NP 1024   // pyramids up to which k_predict ranks its stayers with an LDS histogram
-#define LSTG 224  // records of each kind a workgroup of k_predict notes in LDS before spilling to HBM
+#ifndef LSTG
+#define LSTG 96
+#endif
+// LSTG: records of each kind a workgroup of k_predict notes in LDS before spilling to HBM
 
 // Deferred wave-aggregated append of up to N items per lane into counted lists
 // (pyramids_in_fov registration :1245-1254, mover routing): one global atomic per DISTINCT key of
@@ -163,22 +172,52 @@ __global__ void __launch_bounds__(256) k_vz_count(MapDims d, DevState s, int* __
 
 // one particle of mapPrediction: advance (:665-667, vz forced to 0 :662), classify.
 // returns 0 = left the map (:688), 1 = stays in its voxel (pyr = its pyramid or -1), 2 = changed voxel (gv = the
-// new global voxel), 3 = left this rank's slab (multi-GPU)
+// new global voxel), 3 = left this rank's slab (multi-GPU).  zadd = dt * 0.f + odz (:667, the same for every particle).
+// VIEW = false: no particle of the tile can lie in the field of view (the tile's box test), a stayer needs no pyramid.
+template <bool VIEW>
 __device__ __forceinline__ int advance_one(const MapDims& d, const float* s_ph, const float* s_pv, float dt, float odx, float ody,
-                                           float odz, float vx, float vy, float& px, float& py, float& pz, int lvp, int& pyr, int& gv) {
+                                           float zadd, float vx, float vy, float& px, float& py, float& pz, int lvp, int& pyr, int& gv) {
     px += dt * vx + odx;   // :665
     py += dt * vy + ody;   // :666
-    pz += dt * 0.f + odz;  // :667
+    pz += zadd;            // :667
     pyr = -1;
     if (!voxel_of(d, px, py, pz, gv)) return 0;
     const int nlv = gv - d.v_base;
-    if (nlv == lvp) { pyr = pyramid_of(d, s_ph, s_pv, px, py, pz); return 1; }
-    if (nlv < 0 || nlv >= d.v_loc) return 3;
+    if (nlv == lvp) { if (VIEW) pyr = pyramid_of(d, s_ph, s_pv, px, py, pz); return 1; }
+    if ((unsigned)nlv >= (unsigned)d.v_loc) return 3;
     return 2;
 }
 
-template <int MW, int NW>
-__global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, FilterParams fp, int has_vz, int* __restrict__ part,
+// velocity process noise of constructor-seeded particles on their first prediction (:653-659): only
+// when |vx*vy*vz| >= 1e-6, drawn from the table in SWEEP order.  Rare: only the HASVZ instantiation of k_predict holds it.
+__device__ __forceinline__ void vz_noise(const MapDims& d, const DevState& s, const FilterParams& fp, const int* __restrict__ vz_pre,
+                                      const u64* __restrict__ vz_q, int mw, int lv, int e, int row, size_t idx, float* vxy) {
+    const float vz = s.vz0[idx];
+    if (!(fabs((double)(vxy[0] * vxy[1] * vz)) < 1e-6)) {
+        // rank in the reference's sweep order: qualifying particles of earlier voxels (k_vz_count + k_occ_scan) + those in
+        // lower slots of this voxel
+        int rank = s.blk_cnt[lv >> 8] + vz_pre[lv];
+        for (int e2 = 0; e2 <= e; ++e2) {
+            u64 qm = vz_q[(size_t)lv * mw + e2];
+            if (e2 == e) qm &= (1ull << row) - 1ull;
+            rank += (int)__popcll(qm);
+        }
+        const int c = (int)(((long long)s.fs->v_cur + 3ll * (long long)rank) % fp.tab_n);
+        vxy[0] += s.v_tab[c];
+        vxy[1] += s.v_tab[(c + 1) % fp.tab_n];
+        st_vel(s, idx, vxy[0], vxy[1]);
+    }
+    s.vz0[idx] = 0.f;
+}
+
+// eight workgroups per CU: the sweep is a chain of phases (occupancy words, rows, tails) and only the workgroups that are in
+// their row phase keep the memory system busy -- residency, not per-wave batch depth, is what moved this kernel (measured:
+// 5 -> 7 -> 8 resident workgroups 0.274 -> 0.239 -> 0.224 ms at 132x132x60 saturated; 2 / 3 / 4 / 6 rows per batch all alike)
+#ifndef PRED_LB
+#define PRED_LB 8
+#endif
+template <int MW, int NW, bool HASVZ>
+__global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevState s, FilterParams fp, int has_vz, int* __restrict__ part,
                                                  float4* __restrict__ mv_rec, float4* __restrict__ in_rec, int* __restrict__ in_cnt,
                                                  u64* __restrict__ expmask, const int* __restrict__ vz_pre, const u64* __restrict__ vz_q,
                                                  u64* __restrict__ omask, int extra, int* __restrict__ tile_fov) {
@@ -187,7 +226,7 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
     __shared__ u64 s_keep[MW * 64], s_ex[MW * 64];
     __shared__ int s_nmv, s_nst;
     __shared__ int s_cnt[4];
-    __shared__ int s_any;
+    __shared__ int s_any, s_view;
     // the first LSTG movers / stayers of the tile are noted in LDS (free: registers, not LDS, bound the
     // occupancy of this kernel), the rest in the tile's staging area in HBM
     __shared__ float4 s_mv[LSTG * 2], s_st[LSTG * 2];
@@ -197,7 +236,7 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
     const float odx = s.fpar->od[0], ody = s.fpar->od[1], odz = s.fpar->od[2], dt = s.fpar->dt;
     const int tid = threadIdx.x;
     const int l = lane_id();
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and known to be: the row loops below become scalar control flow)
     // whole frame: the observation gather (448 independent waves, a chain of L2 round trips over the frame's points)
     // rides on this launch as extra workgroups behind the tiles -- it only needs k_obs_points' output, like the tiles
     // (extra & 1).  The birth rank -- one workgroup that needs nothing but the frame's birth cloud -- is the last one
@@ -222,7 +261,7 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
         // clearOccupancyMapPrediction (:431-438) was requested since the last frame: this tile's share of the
         // future accumulators is zeroed here instead of by two extra memset launches per frame
         const int v0 = BX * 64, nv = min(64, d.v_loc - v0);
-        for (int i = tid; i < nv * d.T; i += NW * 64) s.fut[(size_t)(i / nv) * d.v_loc + v0 + (i % nv)] = 0.f;   // [T][V]
+        for (int t = wave; t < d.T; t += NW) if (l < nv) s.fut[(size_t)t * d.v_loc + v0 + l] = 0.f;   // [T][V]: one row of 64 per wave and horizon
         if (tid < nv) s.fut_stat[v0 + tid] = 0.f;
     }
     if (wave == NW - 1) {
@@ -256,7 +295,7 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
         const u64 b2 = __ballot(c8 && dot3(cx, cy, cz, gpv) <= 0.f);
         const u64 b3 = __ballot(c8 && dot3(cx, cy, cz, gpv + 3 * d.np_v) >= 0.f);
         auto box_in = [&](int sh) { return ((b0 >> sh) & 0xffull) && ((b1 >> sh) & 0xffull) && ((b2 >> sh) & 0xffull) && ((b3 >> sh) & 0xffull); };
-        if (l == 0) tile_fov[BX] = (box_in(0) || box_in(8)) ? 1 : 0;
+        if (l == 0) { const int v = (box_in(0) || box_in(8)) ? 1 : 0; tile_fov[BX] = v; s_view = v; }
     }
     if (!s.tile_live[BX]) {   // nothing lives here (k_resample saw it empty; no arrival, birth or import since)
         if (tid < 4) part[BX * 4 + tid] = 0;
@@ -292,17 +331,54 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
 #pragma unroll
         for (int e = 0; e < MW; ++e) { cl += (int)__popcll(live[e]); nrows += (int)__popcll(wave_or_u64(live[e])); }
         const int nlive = wave_sum_i(cl);
-        if (l == 0) s_any = (!has_vz && nlive <= DENSE_MAX && nlive * 5 < nrows * 64 * 3) ? 2 : 1;
+#ifdef EXP_NO_DENSE
+        if (l == 0) s_any = 1;
+#else
+        if (l == 0) s_any = (!HASVZ && nlive <= DENSE_MAX && nlive * 5 < nrows * 64 * 3) ? 2 : 1;
+#endif
     }
     __syncthreads();
     if (!s_any) {  // empty tile
         if (tid < 4) part[BX * 4 + tid] = 0;
         return;
     }
+#ifdef EXP_NO_DENSE
+    const bool dense = false;
+#else
     const bool dense = s_any == 2;
+#endif
     const int cap = 64 * d.slots;                       // records per staging area / inbox
     const size_t mv_base = (size_t)BX * cap;    // this tile's staging area (2 float4 per record)
-    int c_live = 0, c_out = 0, c_pf = 0, c_mv = 0;
+    int c_live = 0, c_out = 0, c_pf = 0, c_mv = 0;   // c_live / c_out / c_mv: wave-uniform (sums of ballots), c_pf: per lane
+    const bool view = s_view != 0;                    // can a particle of this tile lie in the field of view at all?
+    const float zadd = dt * 0.f + odz;                // :667, the same for every particle
+    // buffer descriptors of this tile's share of the three field arrays (the tile's cells are contiguous: [slot][64]): a
+    // lane's byte offset is ONE register whatever the row, the row enters as a scalar offset
+    const size_t tcell = (size_t)BX * d.slots * 64;
+    const int tcells = d.slots * 64;
+    const brsrc rs_pos = __builtin_amdgcn_make_buffer_rsrc((void*)(s.pos + 3 * tcell), 0, tcells * 12, 0x00020000);
+    const brsrc rs_vel = __builtin_amdgcn_make_buffer_rsrc((void*)(s.vel + 2 * tcell), 0, tcells * 8, 0x00020000);
+    const brsrc rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(s.w + tcell), 0, tcells * 4, 0x00020000);
+    // notes a stayer that needs a pyramid entry (top of the staging area, downwards) / a mover (bottom, upwards)
+    auto note_stayer = [&](bool on, int pyr, int cell, float px, float py, float pz, float w) {
+        const int ks = lds_agg_inc(&s_nst, on);
+        if (ks >= 0) {
+            const float4 a = make_float4(__int_as_float(pyr), __int_as_float(cell), px, py);
+            const float4 b = make_float4(pz, w, 0.f, 0.f);
+            if (ks < LSTG) { s_st[ks * 2] = a; s_st[ks * 2 + 1] = b; }
+            else { const size_t o = (mv_base + cap - 1 - ks) * 2; mv_rec[o] = a; mv_rec[o + 1] = b; }
+        }
+    };
+    auto note_mover = [&](bool on, int gv, int cell, float vx, float vy, float px, float py, float pz, float w) {
+        const int km = lds_agg_inc(&s_nmv, on);
+        if (km >= 0) {
+            const float4 a = make_float4(__int_as_float(gv), vx, vy, px);
+            // .w: source key = sweep position (global voxel, slot) of the particle: k_place serves arrivals in this order
+            const float4 b = make_float4(py, pz, w, __int_as_float((BX * 64 + (cell & 63) + d.v_base) * d.slots + (cell >> 6)));
+            if (km < LSTG) { s_mv[km * 2] = a; s_mv[km * 2 + 1] = b; }
+            else { const size_t o = (mv_base + km) * 2; mv_rec[o] = a; mv_rec[o + 1] = b; }
+        }
+    };
     if (dense) {
         // cell list: every wave compacts its share of the live rows
 #pragma unroll
@@ -321,135 +397,89 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
         for (int c0 = 0; c0 < ncell; c0 += NW * 64) {
             const int c = c0 + tid;
             const bool act = c < ncell;
-            const int cell = act ? (int)s_cells[c] : 0;
+            const int cell = act ? (int)s_cells[c] : l;   // (a valid cell of the tile for the idle lanes too)
             const int slot = cell >> 6, ln = cell & 63;
-            const unsigned idx = (unsigned)pidx(d, BX * 64 + (act ? ln : l), act ? slot : 0);
-            V2 v2 = ld_vel(s, idx);
-            const P3 p3 = ld_pos(s, idx);
-            const float w = s.w[idx];
+            const int coff = slot * 64 + ln;              // the cell inside the tile
+            V2 v2 = bl_vel(rs_vel, coff, 0);
+            const P3 p3 = bl_pos(rs_pos, coff, 0);
+            const float w = bl_w(rs_w, coff, 0);
             float px = p3.x, py = p3.y, pz = p3.z;
             int pyr = -1, gv = -1, kind = -1;
             if (d.static_model) {   // dsp_static.h:640-646
-                if (act && (v2.x != 0.f || v2.y != 0.f)) st_vel(s, idx, 0.f, 0.f);
+                if (act && (v2.x != 0.f || v2.y != 0.f)) st_vel(s, tcell + coff, 0.f, 0.f);
                 v2.x = 0.f; v2.y = 0.f;
             }
             if (act) {
-                kind = advance_one(d, s_ph, s_pv, dt, odx, ody, odz, v2.x, v2.y, px, py, pz, BX * 64 + ln, pyr, gv);
-                ++c_live;
+                kind = view ? advance_one<true>(d, s_ph, s_pv, dt, odx, ody, zadd, v2.x, v2.y, px, py, pz, BX * 64 + ln, pyr, gv)
+                            : advance_one<false>(d, s_ph, s_pv, dt, odx, ody, zadd, v2.x, v2.y, px, py, pz, BX * 64 + ln, pyr, gv);
                 const u64 bit = 1ull << (slot & 63);
-                if (kind != 0) st_pos(s, idx, px, py, pz);
-                if (kind == 0) { ++c_out; atomicAnd(&s_keep[(slot >> 6) * 64 + ln], ~bit); }
-                else if (kind == 2) { ++c_mv; atomicAnd(&s_keep[(slot >> 6) * 64 + ln], ~bit); }
+                if (kind == 1 || kind == 3) bs_pos(rs_pos, coff, 0, px, py, pz);   // (a mover's cell is dead: its record carries the position)
+                if (kind == 0 || kind == 2) atomicAnd(&s_keep[(slot >> 6) * 64 + ln], ~bit);
                 else if (kind == 3) atomicOr(&s_ex[(slot >> 6) * 64 + ln], bit);
             }
-            const int ks = lds_agg_inc(&s_nst, kind == 1 && pyr >= 0);
-            if (ks >= 0) {
-                const float4 a = make_float4(__int_as_float(pyr), __int_as_float(cell), px, py);
-                const float4 b = make_float4(pz, w, 0.f, 0.f);
-                if (ks < LSTG) { s_st[ks * 2] = a; s_st[ks * 2 + 1] = b; }
-                else { const size_t o = (mv_base + cap - 1 - ks) * 2; mv_rec[o] = a; mv_rec[o + 1] = b; }
-            }
-            const int km = lds_agg_inc(&s_nmv, kind == 2);
-            if (km >= 0) {
-                const float4 a = make_float4(__int_as_float(gv), v2.x, v2.y, px);
-                const float4 b = make_float4(py, pz, w, __int_as_float((BX * 64 + ln + d.v_base) * d.slots + slot));
-                if (km < LSTG) { s_mv[km * 2] = a; s_mv[km * 2 + 1] = b; }
-                else { const size_t o = (mv_base + km) * 2; mv_rec[o] = a; mv_rec[o + 1] = b; }
-            }
+            c_live += (int)__popcll(__ballot(act));
+            c_out += (int)__popcll(__ballot(kind == 0));
+            c_mv += (int)__popcll(__ballot(kind == 2));
+            note_stayer(kind == 1 && pyr >= 0, pyr, cell, px, py, pz, w);
+            note_mover(kind == 2, gv, cell, v2.x, v2.y, px, py, pz, w);
         }
-    } else
+    } else {
 #pragma unroll
     for (int e = 0; e < MW; ++e) {
-        u64 keep_clr = 0ull, ex = 0ull;
-        u64 tor = rows_of_wave<NW>(wave_or_u64(live[e]), wave);
+        unsigned kc_lo = 0u, kc_hi = 0u, ex_lo = 0u, ex_hi = 0u;   // slots to free / to export, this lane's voxel
+        const unsigned live_lo = (unsigned)live[e], live_hi = (unsigned)(live[e] >> 32);
+        u64 tor = rows_of_wave<NW>(wave_or_u64(live[e]), wave);   // wave-uniform: scalar control flow from here on
         while (tor) {
             int row[RB];
             P3 pp[RB];
             V2 vv[RB];
             float w[RB];
-            bool act[RB];
-            unsigned idx[RB];   // slot index fits 31 bits (fov_slot is an int; checked at create)
 #pragma unroll
             for (int r = 0; r < RB; ++r) {  // issue every load of the batch
                 row[r] = tor ? __ffsll((long long)tor) - 1 : -1;
                 if (tor) tor &= tor - 1ull;
-                act[r] = row[r] >= 0 && ((live[e] >> (row[r] & 63)) & 1ull);
-                idx[r] = (unsigned)pidx(d, lvs, e * 64 + (row[r] < 0 ? 0 : row[r]));
-                // unconditional loads (idx is always a valid cell of this lane's voxel; dead cells share the row's
-                // cache lines): a predicated vector load makes the compiler wait for it before issuing the next row
-                vv[r] = ld_vel(s, idx[r]);
-                pp[r] = ld_pos(s, idx[r]);
-                w[r] = s.w[idx[r]];
+                // unconditional loads (always a valid cell of this lane's voxel; dead cells share the row's cache lines): a
+                // predicated vector load makes the compiler wait for it before issuing the next row
+                const int srow = (e * 64 + (row[r] < 0 ? 0 : row[r])) * 64;   // cells before this row inside the tile (wave-uniform)
+                vv[r] = bl_vel(rs_vel, l, srow);
+                pp[r] = bl_pos(rs_pos, l, srow);
+                w[r] = bl_w(rs_w, l, srow);
             }
-            float vx[RB], vy[RB], px[RB], py[RB], pz[RB];
-#pragma unroll
-            for (int r = 0; r < RB; ++r) { vx[r] = vv[r].x; vy[r] = vv[r].y; px[r] = pp[r].x; py[r] = pp[r].y; pz[r] = pp[r].z; }
-            if (d.static_model) {   // dsp_static.h:640-646: velocities forced to zero, positions follow the ego-motion only
-#pragma unroll
-                for (int r = 0; r < RB; ++r) {
-                    if (act[r] && (vx[r] != 0.f || vy[r] != 0.f)) st_vel(s, idx[r], 0.f, 0.f);
-                    vx[r] = 0.f; vy[r] = 0.f;
-                }
-            }
-            int pyr[RB], mgv[RB];
+            // every row of the batch is advanced, stored and noted before the next one is touched
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                pyr[r] = -1; mgv[r] = -1;
-                if (act[r]) {
-                    const u64 bit = 1ull << row[r];
-                    if (has_vz) {
-                        // velocity process noise only when |vx*vy*vz| >= 1e-6 (:653-659): reachable only for
-                        // constructor-seeded particles on their first step
-                        const float vz = s.vz0[idx[r]];
-                        if (!(fabs((double)(vx[r] * vy[r] * vz)) < 1e-6)) {
-                            // rank in the reference's sweep order: qualifying particles of earlier voxels (k_vz_count +
-                            // k_occ_scan) + those in lower slots of this voxel
-                            int rank = s.blk_cnt[lv >> 8] + vz_pre[lv];
-#pragma unroll
-                            for (int e2 = 0; e2 < MW; ++e2) {
-                                u64 qm = vz_q[(size_t)lvs * MW + e2];
-                                if (e2 == e) qm &= (1ull << row[r]) - 1ull;
-                                else if (e2 > e) qm = 0ull;
-                                rank += (int)__popcll(qm);
-                            }
-                            const int c = (int)(((long long)s.fs->v_cur + 3ll * (long long)rank) % fp.tab_n);
-                            vx[r] += s.v_tab[c];
-                            vy[r] += s.v_tab[(c + 1) % fp.tab_n];
-                            st_vel(s, idx[r], vx[r], vy[r]);
-                        }
-                        s.vz0[idx[r]] = 0.f;
-                    }
-                    int gv;
-                    ++c_live;
-                    const int kind = advance_one(d, s_ph, s_pv, dt, odx, ody, odz, vx[r], vy[r], px[r], py[r], pz[r], lv, pyr[r], gv);
-                    if (kind != 0) st_pos(s, idx[r], px[r], py[r], pz[r]);
-                    if (kind == 0) { keep_clr |= bit; ++c_out; }            // left the map :688
-                    else if (kind == 3) ex |= bit;                          // left the slab (multi-GPU)
-                    else if (kind == 2) { mgv[r] = gv; keep_clr |= bit; ++c_mv; }   // voxel changed: the slot is freed now, the record travels
+                if (row[r] < 0) continue;   // (scalar)
+                const int rw = row[r];
+                const int srow = (e * 64 + rw) * 64;
+                const bool act = (((rw < 32 ? live_lo : live_hi) >> (rw & 31)) & 1u) != 0u;
+                float vx = vv[r].x, vy = vv[r].y, px = pp[r].x, py = pp[r].y, pz = pp[r].z;
+                if (d.static_model) {   // dsp_static.h:640-646: velocities forced to zero, positions follow the ego-motion only
+                    if (act && (vx != 0.f || vy != 0.f)) st_vel(s, tcell + srow + l, 0.f, 0.f);
+                    vx = 0.f; vy = 0.f;
                 }
-            }
-            // note stayers that need a pyramid entry (top of the staging area, downwards) and movers (bottom, upwards)
-#pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                const int ks = lds_agg_inc(&s_nst, pyr[r] >= 0);
-                if (ks >= 0) {
-                    const float4 a = make_float4(__int_as_float(pyr[r]), __int_as_float(((e * 64 + row[r]) << 6) | l), px[r], py[r]);
-                    const float4 b = make_float4(pz[r], w[r], 0.f, 0.f);
-                    if (ks < LSTG) { s_st[ks * 2] = a; s_st[ks * 2 + 1] = b; }
-                    else { const size_t o = (mv_base + cap - 1 - ks) * 2; mv_rec[o] = a; mv_rec[o + 1] = b; }
+                if (HASVZ) {
+                    if (act) { float vxy[2] = {vx, vy}; vz_noise(d, s, fp, vz_pre, vz_q, MW, lvs, e, rw, tcell + srow + l, vxy); vx = vxy[0]; vy = vxy[1]; }
                 }
-                const int km = lds_agg_inc(&s_nmv, mgv[r] >= 0);
-                if (km >= 0) {
-                    const float4 a = make_float4(__int_as_float(mgv[r]), vx[r], vy[r], px[r]);
-                    // .w: source key = sweep position (global voxel, slot) of the particle: k_place serves arrivals in this order
-                    const float4 b = make_float4(py[r], pz[r], w[r], __int_as_float((lv + d.v_base) * d.slots + e * 64 + row[r]));
-                    if (km < LSTG) { s_mv[km * 2] = a; s_mv[km * 2 + 1] = b; }
-                    else { const size_t o = (mv_base + km) * 2; mv_rec[o] = a; mv_rec[o + 1] = b; }
-                }
+                int pyr = -1, gv = -1;
+                int kind = view ? advance_one<true>(d, s_ph, s_pv, dt, odx, ody, zadd, vx, vy, px, py, pz, lv, pyr, gv)
+                                : advance_one<false>(d, s_ph, s_pv, dt, odx, ody, zadd, vx, vy, px, py, pz, lv, pyr, gv);
+                if (!act) kind = -1;
+                if (kind == 1 || kind == 3) bs_pos(rs_pos, l, srow, px, py, pz);   // (a mover's cell is dead: its record carries the position)
+                const unsigned bit = 1u << (rw & 31);
+                const unsigned fr = (kind == 0 || kind == 2) ? bit : 0u, xp = kind == 3 ? bit : 0u;   // left the map :688 / changed voxel; left the slab
+                if (rw < 32) { kc_lo |= fr; ex_lo |= xp; } else { kc_hi |= fr; ex_hi |= xp; }
+                c_live += (int)__popcll(__ballot(act));
+                c_out += (int)__popcll(__ballot(kind == 0));
+                c_mv += (int)__popcll(__ballot(kind == 2));
+                const int cell = ((e * 64 + rw) << 6) | l;
+                if (view) note_stayer(kind == 1 && pyr >= 0, pyr, cell, px, py, pz, w[r]);
+                note_mover(kind == 2, gv, cell, vx, vy, px, py, pz, w[r]);
             }
         }
+        const u64 keep_clr = ((u64)kc_hi << 32) | kc_lo, ex = ((u64)ex_hi << 32) | ex_lo;
         if (keep_clr) atomicAnd(&s_keep[e * 64 + l], ~keep_clr);
         if (ex) atomicOr(&s_ex[e * 64 + l], ex);
+    }
     }
     // workgroup-scope ordering is enough for the read-back below: the waves of a workgroup share the
     // CU's write-through L1 (an agent-scope fence would write back the XCD's whole L2)
@@ -545,7 +575,7 @@ __global__ void __launch_bounds__(NW * 64, 5) k_predict(MapDims d, DevState s, F
         }
     }
     // per-block statistics (reduced lazily by the host; no global atomics here)
-    c_live = wave_sum_i(c_live); c_out = wave_sum_i(c_out); c_pf = wave_sum_i(c_pf); c_mv = wave_sum_i(c_mv);
+    c_pf = wave_sum_i(c_pf);   // (the other three are sums of ballots already)
     if (l == 0) {
         if (c_live) atomicAdd(&s_cnt[0], c_live);
         if (c_out) atomicAdd(&s_cnt[1], c_out);
@@ -801,7 +831,7 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
                                                   float4* __restrict__ ro_rec, int* __restrict__ ro_cnt) {
     extern __shared__ float s_dyn[];
     const int l = lane_id();
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int cpmax = d.M;   // a voxel makes at most M copies
     float* s_w = s_dyn + (size_t)wave * (d.slots * 64 + (64 * cpmax + 1) / 2);
     unsigned short* s_cp = (unsigned short*)(s_w + d.slots * 64);
@@ -1042,8 +1072,8 @@ __global__ void __launch_bounds__(256) k_rollout(MapDims d, DevState s, const fl
         const float fx = a.x + a.z * pt;      // :954-955
         const float fy = a.y + a.w * pt;
         if (fx >= d.half_x || fx <= -d.half_x || fy >= d.half_y || fy <= -d.half_y) return -1;
-        const int xi = (int)__fdiv_rn(fx + d.half_x, d.res);
-        const int yi = (int)__fdiv_rn(fy + d.half_y, d.res);
+        const int xi = (int)div_res(d, fx + d.half_x);
+        const int yi = (int)div_res(d, fy + d.half_y);
         const int gz = (lv + d.v_base) / zc;  // the layer never changes (vz == 0; pz itself is inside the map)
         const int dl = gz * zc + yi * d.nx + xi - d.v_base;
         return (dl >= 0 && dl < d.v_loc) ? dl : -1;
@@ -1340,6 +1370,74 @@ __global__ void __launch_bounds__(256) k_import_movers(MapDims d, int n, const f
     wave_count_add(dropped, lost);
 }
 
+// the memory skeleton of k_predict's row sweep (dspmap_debug_sweep_probe)
+template <int NB>
+__global__ void __launch_bounds__(256) k_sweep_probe(MapDims d, DevState s, int what, int rows) {
+    const int l = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const size_t tcell = (size_t)blockIdx.x * d.slots * 64;
+    const int tcells = d.slots * 64;
+    const brsrc rs_pos = __builtin_amdgcn_make_buffer_rsrc((void*)(s.pos + 3 * tcell), 0, tcells * 12, 0x00020000);
+    const brsrc rs_vel = __builtin_amdgcn_make_buffer_rsrc((void*)(s.vel + 2 * tcell), 0, tcells * 8, 0x00020000);
+    const brsrc rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(s.w + tcell), 0, tcells * 4, 0x00020000);
+    float acc = 0.f;
+    for (int r0 = wave; r0 < rows; r0 += 4 * NB) {
+        P3 pp[NB]; V2 vv[NB]; float w[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int row = min(r0 + 4 * k, rows - 1);
+            pp[k].x = pp[k].y = pp[k].z = 0.f; vv[k].x = vv[k].y = 0.f; w[k] = 0.f;
+            if (what & 2) vv[k] = bl_vel(rs_vel, l, row * 64);
+            if (what & 1) pp[k] = bl_pos(rs_pos, l, row * 64);
+            if (what & 4) w[k] = bl_w(rs_w, l, row * 64);
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int row = r0 + 4 * k;
+            if (row >= rows) continue;
+            acc += vv[k].x + vv[k].y + w[k];
+            if (what & 8) bs_pos(rs_pos, l, row * 64, pp[k].x + 0.f, pp[k].y + 0.f, pp[k].z + 0.f);
+            else acc += pp[k].x + pp[k].y + pp[k].z;
+        }
+    }
+    if (acc == 1.2345e-30f) s.fs->n_valid = 1;
+}
+void launch_sweep_probe(const LaunchCtx& c, int what, int rows, int rows_per_batch) {
+    const dim3 g(c.k.ntiles), b(256);
+    if (rows_per_batch <= 1) hipLaunchKernelGGL(k_sweep_probe<1>, g, b, 0, c.stream, c.d, c.s, what, rows);
+    else if (rows_per_batch == 2) hipLaunchKernelGGL(k_sweep_probe<2>, g, b, 0, c.stream, c.d, c.s, what, rows);
+    else if (rows_per_batch == 3) hipLaunchKernelGGL(k_sweep_probe<3>, g, b, 0, c.stream, c.d, c.s, what, rows);
+    else hipLaunchKernelGGL(k_sweep_probe<6>, g, b, 0, c.stream, c.d, c.s, what, rows);
+}
+
+// div_res (dspmap_device.h): comparison of the 3-instruction quotient with the IEEE division, bit for bit, over
+//   * EVERY float of one binade, a in [1, 2) -- 2^23 values.  All three operations (a * y, fma(-q0, res, a), fma(r, y, q0)) and
+//     the division itself commute with a scaling of `a` by a power of two as long as nothing leaves the normal range, so this
+//     proves every binade the map divides in (a >= res / 2; below that both quotients are < 1 and the voxel coordinate is 0);
+//   * every `stride`-th float of the whole range [0, amax] as a direct check of exactly that argument.
+__global__ void __launch_bounds__(256) k_verify_div(float res, float rcp, unsigned lo_bits, unsigned hi_bits, unsigned stride, int* __restrict__ bad) {
+    int nb = 0;
+    const unsigned step = gridDim.x * 256u * stride;
+    for (unsigned b = lo_bits + (blockIdx.x * 256u + threadIdx.x) * stride; b <= hi_bits; b += step) {
+        const float a = __uint_as_float(b);
+        const float q0 = a * rcp;
+        const float r = __fmaf_rn(-q0, res, a);
+        const float q = __fmaf_rn(r, rcp, q0);
+        const float qi = __fdiv_rn(a, res);
+        // identical quotient, or at least the identical voxel coordinate where the quotient is denormal-small
+        nb += (__float_as_uint(q) != __float_as_uint(qi) && !(qi < 1.f && q < 1.f && q >= 0.f)) ? 1 : 0;
+        if (b > 0xffffffffu - step) break;
+    }
+    nb = wave_sum_i(nb);
+    if (lane_id() == 0 && nb) atomicAdd(bad, nb);
+}
+void launch_verify_div(hipStream_t stream, float res, float rcp_res, float amax, int* bad) {
+    unsigned bits;
+    memcpy(&bits, &amax, sizeof(bits));
+    hipLaunchKernelGGL(k_verify_div, dim3(2048), dim3(256), 0, stream, res, rcp_res, 0x3f800000u, 0x3fffffffu, 1u, bad);   // [1, 2)
+    hipLaunchKernelGGL(k_verify_div, dim3(2048), dim3(256), 0, stream, res, rcp_res, 0u, bits, 97u, bad);                 // the range, sampled
+}
+
 // PMC calibration: stream the field arrays with the sweeps' 4-byte-per-lane pattern
 __global__ void __launch_bounds__(256) k_calib_read(DevState s, size_t n, float* __restrict__ sink) {
     float acc = 0.f;
@@ -1413,12 +1511,11 @@ void launch_predict_only(const LaunchCtx& c, bool with_gather, bool with_rank) {
         else hipLaunchKernelGGL(k_vz_count<2>, dim3(nblk), dim3(256), 0, c.stream, c.d, c.s, k->work_list, k->vz_q);
         launch_scan_blocks(c, nblk);   // blk_cnt -> exclusive, total -> fs->occupied_count
     }
-    if (c.d.mw == 1)
-        hipLaunchKernelGGL((k_predict<1, 4>), dim3(k->ntiles + xb), dim3(256), 0, c.stream, c.d, c.s, c.fp,
-                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask, extra, k->tile_fov);
-    else
-        hipLaunchKernelGGL((k_predict<2, 4>), dim3(k->ntiles + xb), dim3(256), 0, c.stream, c.d, c.s, c.fp,
-                           c.s.vz0 ? 1 : 0, k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask, extra, k->tile_fov);
+#define PRED_LAUNCH(MWV, VZ) hipLaunchKernelGGL((k_predict<MWV, 4, VZ>), dim3(k->ntiles + xb), dim3(256), 0, c.stream, c.d, c.s, c.fp, VZ ? 1 : 0, \
+                                                k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask, extra, k->tile_fov)
+    if (c.d.mw == 1) { if (c.s.vz0) PRED_LAUNCH(1, true); else PRED_LAUNCH(1, false); }
+    else { if (c.s.vz0) PRED_LAUNCH(2, true); else PRED_LAUNCH(2, false); }
+#undef PRED_LAUNCH
 }
 void launch_claim(const LaunchCtx& c, int n_birth_grid, int part, int tile_lo, int tile_hi, int sel) {   // n_birth_grid > 0: the children of that many source points ride along
     const unsigned xb = n_birth_grid > 0 ? (unsigned)(((long long)n_birth_grid * c.fp.nb_num + 255) / 256) : 0u;

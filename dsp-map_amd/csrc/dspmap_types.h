@@ -45,6 +45,8 @@ struct MapDims {
     int nbins;             // (2*nn+1)^2
     int static_model;      // dsp_static.h's motion model: velocities forced to 0 in prediction
     float res;
+    float rcp_res;         // RN(1 / res)
+    int div_ok;            // 1: a / res may be computed as reciprocal + two FMAs (verified exhaustively on the device, dspmap_device.h: div_res)
     float half_x, half_y, half_z; // :528-530
     float rng_inv_bw;             // range buckets of k_pyr_sort: bucket = (int)(|p| * rng_inv_bw), PS_NBK buckets to the map corner
     float pred_t[DSP_MAX_PRED];
@@ -92,6 +94,7 @@ struct FrameScalars {
     // synthesised birth cloud (FrameParams::static_birth): frame epoch in which the view held at least one point, and
     // the length of the last non-empty view's cloud kept in DevState::birth (an empty view re-uses it, :1379-1381)
     int view_epoch, stale_n;
+    int n_birth_ovf;    // entries of DevState::birth_ovf (reset by the birth rank, which precedes every generation of children)
     int est_n;          // length of the birth cloud the device velocity estimator wrote (kept when a view is empty, :1379)
 };
 
@@ -154,6 +157,8 @@ struct DevState {
     int* plan_pbase;        // [birth_cap] position-table cursor of each source point (k_birth_rank; kept apart from `plan`
                             // so that the rank and the split can run in the same launch)
     int* nstatic;           // [birth_cap] (multi-GPU all-reduce(max) buffer)
+    int* birth_ovf;         // [birth_cap*32] birth indices of the children that found their destination voxel's bucket full
+                            // (FrameScalars::n_birth_ovf entries; their voxel is in KernelScratch::child)
     // FOV staging
     float4* fov_rec;   // [np*capa] {x,y,z,w}
     int* fov_slot;     // [np*capa] cell index of the particle (pidx)

@@ -118,6 +118,9 @@ enum dspmap_param {
                                        that cannot see the sensor's field of view their slots on a side stream, beside the weight update
                                        (same result; a scheduling knob: 1 = always, a huge value = never; the environment variable
                                        DSPMAP_PLACE_SPLIT_TILES presets it at dspmap_create) */
+    DSPMAP_P_FAST_DIVISION = 17,    /* read: 1 if (p + half) / VOXEL_RESOLUTION (:1062-1088) is computed as reciprocal + two FMAs -- only after a
+                                       kernel has compared that quotient with the IEEE division, bit for bit, for this resolution
+                                       (device initialisation); write 0: force the IEEE division (same results by construction) */
     DSPMAP_P_PAIR_CULL_SIGMAS = 13  /* mapUpdate evaluates a (particle, observation) pair only if their ranges differ by at most this many
                                        sigma_ob (default 9: the dropped terms are < 1e-19 and zero on the fixed-point Ck grid);
                                        a huge value evaluates every pair of the neighbourhood like the reference's loops */
@@ -213,6 +216,11 @@ int dspmap_get_stage_ms(dspmap_t* m, float ms_sum_out[DSPMAP_N_STAGES], int* n_f
  * (4 B per lane, 256 B per wave) -- mode 0 reads them (known byte count = 6*4*capacity), mode 1
  * rewrites px in place -- to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE for this pattern. */
 int dspmap_debug_stream(dspmap_t* m, int mode, long long* bytes_out);
+/* profiling aid: the bare memory skeleton of the prediction sweep -- one workgroup per 64-voxel tile, the first `rows` slot
+ * rows of every tile, nothing computed -- timed with events over `reps` launches: what the memory system sustains for
+ * this access pattern.  what: bit 0 read positions (12 B), bit 1 read velocities (8 B), bit 2 read weights (4 B),
+ * bit 3 write positions back (12 B); rows_per_batch = rows a wave keeps in flight.  *bytes_out = bytes per launch. */
+int dspmap_debug_sweep_probe(dspmap_t* m, int what, int rows, int rows_per_batch, int reps, float* ms_out, long long* bytes_out);
 /* diagnostics: out[t] = 1 if a particle inside 64-voxel tile t could lie in the field of view of the last frame
  * (the conservative box test behind DSPMAP_P_PLACE_SPLIT_TILES); returns the number of tiles or an error */
 int dspmap_debug_tile_view(dspmap_t* m, int* out, int cap);

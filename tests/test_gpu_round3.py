@@ -196,3 +196,71 @@ def test_sharded_frame_runs_the_velocity_estimator_depth_stream(dsp):
     assert sum(int((c[2]["intensity"] > 0.01).sum()) for c in clouds) > 200
     assert len(clouds[4][2]) == len(clouds[3][2])            # empty view: the previous cloud
     assert (np.abs(rec[:, 1]) + np.abs(rec[:, 2]) > 0.3).sum() > 100
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_saturated_map_stepping_a_voxel_per_frame(dsp, world):
+    """a saturated 24-particles-per-voxel map whose sensor advances one whole voxel per frame (every particle changes
+    voxel: ~1 500 arrivals per tile, beyond k_place's LDS table) and climbs a fifth of a voxel per frame (a layer of
+    particles changes slab every few frames): the sharded map is the unsharded one, slot for slot and bit for bit.  (The
+    sensor looks straight up: its field of view leaves this flat map after 0.6 m and no pyramid list overflows -- a full
+    list is cut per slab, the one documented difference between a sharded and an unsharded map)"""
+    sharded = __import__("dsp-map_amd.sharded", fromlist=["CppGroup"])
+    cfg = dict(nx=32, ny=16, nz=8, res=0.15, ppv=24)
+    tables = common.tables(9)
+    grp = sharded.CppGroup(dsp, cfg, world)
+    full = dsp.DSPMap(dsp.make_config(**cfg))
+    for x in grp.maps + [full]:
+        x.set_tables(*tables)
+        x.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, 2)
+        x.seed_uniform(24, weight=0.01, seed=99)
+    yy, zz = np.meshgrid(np.linspace(-0.3, 0.3, 25), np.linspace(-0.2, 0.2, 17))
+    pts = np.stack([np.full(yy.size, 0.42) + 0.02 * np.sin(7 * yy.ravel()), yy.ravel(), zz.ravel()], 1).astype(np.float32)   # a patch 0.4 m in front of (= above) the sensor
+    d = torch.from_numpy(pts).cuda()
+    moved = 0
+    for f in range(5):
+        pos = (0.15 * f, 0.0, 0.03 * f)
+        assert grp.update(d, pos, f / 30.0, UP) == 1
+        assert full.update_device(d.data_ptr(), len(pts), pos, f / 30.0, UP) == 1
+        grp.sync()
+        moved = max(moved, full.counters()["n_moved"])
+        for x in grp.maps + [full]:
+            x.clearOccupancyMapPrediction()
+    assert moved > 0.8 * 24 * 31 * 16 * 8 * 0.9, moved          # (nearly) every particle changed voxel in a frame
+    got = np.concatenate([x.results() for x in grp.maps], 0)
+    assert np.array_equal(got, full.results())
+    parts = [x.export_state() for x in grp.maps]
+    sv, ss, sr = (np.concatenate([p[k] for p in parts]) for k in range(3))
+    order = np.lexsort((ss, sv))
+    fv, fs_, fr = full.export_state()
+    assert len(fv) > 20000 and full.counters()["n_pyramid_full"] == 0
+    assert np.array_equal(sv[order], fv) and np.array_equal(ss[order], fs_) and np.array_equal(sr[order], fr)
+    grp.close(); full.close()
+
+
+@pytest.mark.parametrize("res", [0.15, 0.10, 0.2, 0.073])
+def test_fast_voxel_division_is_the_ieee_division(dsp, res):
+    """(int)((p + half) / res) (:1062-1088) is computed as reciprocal + two FMAs only after a kernel has compared that
+    quotient with the IEEE division bit for bit (all 2^23 floats of a binade -- the sequence commutes with scaling by
+    powers of two -- plus a sample of the whole range): DSPMAP_P_FAST_DIVISION reports it; forcing the IEEE division
+    gives the same map, slot for slot, after a prediction that moves most particles"""
+    cfgkw = dict(nx=48, ny=40, nz=12, res=res, ppv=12)
+    outs = []
+    for force_ieee in (False, True):
+        m = dsp.DSPMap(dsp.make_config(**cfgkw))
+        m._chk(m.L.dspmap_init_device(m.h))
+        assert m.L.dspmap_get_param(m.h, dsp.capi.P_FAST_DIVISION) == 1.0     # verified for this resolution
+        if force_ieee:
+            m.set_param(dsp.capi.P_FAST_DIVISION, 0)
+            assert m.L.dspmap_get_param(m.h, dsp.capi.P_FAST_DIVISION) == 0.0
+        m.seed_uniform(10, weight=0.01, seed=5, vmax=2.0)
+        m.bin_points(np.zeros((0, 3), np.float32), common.EX_QUATS[1])
+        m.predict(0.37 * res, -0.81 * res, 0.23 * res, 0.11)
+        c = m.counters()
+        assert c["n_moved"] > 0.5 * c["n_live_in"]
+        v, s, r = m.export_state()
+        k = np.lexsort((s, v))
+        outs.append((v[k], s[k], r[k]))
+        m.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
