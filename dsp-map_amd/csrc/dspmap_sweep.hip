@@ -17,6 +17,7 @@
 //     64 lanes busy at 24 particles/voxel).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include "dspmap_device.h"
 #include "dspmap_kernels.h"
@@ -1043,6 +1044,263 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
 }
 
 // --------------------------------------------------------------------------
+// k_resample_wg: the same stage with FOUR waves per tile, for maps whose frame is a chain of latencies (the metric's size:
+// a few hundred live tiles, one wave per SIMD -- the longest tile IS the kernel; one-word occupancy, slots <= 48).
+// Only the per-voxel sums and the resampling walk are sequential in slot order (:938-1053); everything around them is not:
+//   phase 1  all four waves load the tile's live rows in ONE batch (weights, velocities, x / y; rows split over the waves),
+//            cull (:941) and COMPACT: every voxel's surviving particles go to consecutive entries j = 0 .. n-1 of the
+//            LDS panels in slot order (j = number of the voxel's survivors in lower slots), and the MOVING old ones are
+//            noted for k_rollout;
+//   phase 2  one wave, one lane per voxel, walks ITS OWN n entries -- mass / mean velocity, then the systematic resampling --
+//            in batches of four LDS reads: the reference's operation order, bit for bit; the loop runs as long as the tile's
+//            fullest voxel, not as long as its highest occupied slot, and has no memory access in the chain;
+//   phase 3  all four waves write the kept particles' new weights back and carry out the deferred copies.
+// dynamic LDS: [slots][64] fp32 panels w, vx, vy + [slots][64] u8 slot of entry j + [64][M] u16 copy notes.
+// --------------------------------------------------------------------------
+#ifdef RESAMPLE_PROF
+__device__ long long g_rprof[4 * 65536];
+extern "C" int dspmap_debug_resample_prof(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rprof), sizeof(long long) * (size_t)n); }
+#endif
+#define RWB 12  // rows per wave: 4 x 12 = 48 slots, the whole tile in one batch
+__global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int* __restrict__ part_live, int* __restrict__ vb_cnt,
+                                                     float4* __restrict__ ro_rec, int* __restrict__ ro_cnt) {
+    extern __shared__ float s_dyn[];
+    __shared__ u64 s_surv[64], s_oldc[64], s_keptc[64];
+    __shared__ int s_ncp[64];
+    __shared__ float s_wcp[64];
+    __shared__ int s_nmv;
+    const int l = lane_id();
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int BX = (int)blockIdx.x;
+    const int cells = d.slots * 64;
+    float* cw = s_dyn;
+    float* cvx = cw + cells;
+    float* cvy = cvx + cells;
+    unsigned char* cs = (unsigned char*)(cvy + cells);
+    const int cpmax = d.M;   // a voxel makes at most M copies
+    unsigned short* s_cp = (unsigned short*)(cs + cells);
+    const int lv = BX * 64 + l;
+    const bool inr = lv < d.v_loc;
+    const int t_live = s.tile_live[BX];   // (requested together with the occupancy words: one round trip)
+    u64 nb = 0ull, m = 0ull;
+    if (inr) {
+        nb = s.nbmask[lv];
+        m = s.mask[lv] | nb;  // newborns live only in nbmask until now
+    }
+    if (!t_live) return;   // empty since its last visit: result, buckets and lists are already zero
+#ifdef RESAMPLE_PROF
+    long long t_s0 = __builtin_readcyclecounter(), t_s1 = 0, t_s2 = 0, t_s3 = 0, t_s4 = 0;
+#endif
+    if (wave == 0 && inr) vb_cnt[lv] = 0;    // birth buckets of this frame are consumed: leave them empty for the next one
+    if (tid == 0) s_nmv = 0;
+    if (tid < 64) { s_surv[tid] = 0ull; s_oldc[tid] = 0ull; }
+    if (!__ballot(m != 0ull)) {  // whole tile empty (the same answer in every wave)
+        if (wave == 0) {
+            if (inr) s.res4[lv] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (l == 0) { part_live[BX] = 0; ro_cnt[BX] = 0; s.tile_live[BX] = 0; }
+        }
+        return;
+    }
+    const size_t tcell = (size_t)BX * cells;
+    const brsrc rs_pos = __builtin_amdgcn_make_buffer_rsrc((void*)(s.pos + 3 * tcell), 0, cells * 12, 0x00020000);
+    const brsrc rs_vel = __builtin_amdgcn_make_buffer_rsrc((void*)(s.vel + 2 * tcell), 0, cells * 8, 0x00020000);
+    const brsrc rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(s.w + tcell), 0, cells * 4, 0x00020000);
+    // ---- phase 1: this wave's rows, all in flight together
+    const unsigned m_lo = (unsigned)m, m_hi = (unsigned)(m >> 32), nb_lo = (unsigned)nb, nb_hi = (unsigned)(nb >> 32);
+    int row[RWB];
+    V2 vv[RWB];
+    float wr[RWB];
+    float2 pq[RWB];
+    {
+        u64 tor = rows_of_wave<4>(wave_or_u64(m), wave);   // (at most 12 of the 48 rows)
+#pragma unroll
+        for (int r = 0; r < RWB; ++r) {
+            row[r] = tor ? __ffsll((long long)tor) - 1 : -1;
+            if (tor) tor &= tor - 1ull;
+            const int srow = (row[r] < 0 ? 0 : row[r]) * 64;
+            wr[r] = bl_w(rs_w, l, srow);
+            vv[r] = bl_vel(rs_vel, l, srow);
+            // (x, y) of every cell too: only the moving particles need them (rollout), but asking afterwards would be a second
+            // dependent round trip
+            const f2w q = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(rs_pos, l * 12, srow * 12, 0));
+            pq[r] = make_float2(q.x, q.y);
+        }
+    }
+    __syncthreads();   // (s_surv / s_oldc / s_nmv are zero)
+    // which cells survive the cull (:941), per voxel
+    unsigned sv_lo = 0u, sv_hi = 0u;
+#pragma unroll
+    for (int r = 0; r < RWB; ++r) {
+        if (row[r] < 0) continue;
+        const int rw = row[r], sh = rw & 31;
+        const bool act = (((rw < 32 ? m_lo : m_hi) >> sh) & 1u) != 0u;
+        const unsigned b = (act && !(wr[r] < 1e-3f)) ? (1u << sh) : 0u;
+        if (rw < 32) sv_lo |= b; else sv_hi |= b;
+    }
+    const u64 sv_mine = ((u64)sv_hi << 32) | sv_lo;
+    if (sv_mine) atomicOr(&s_surv[l], sv_mine);
+    __syncthreads();
+    const u64 surv = s_surv[l];   // the voxel's survivors, all rows
+    const size_t ro_base = (size_t)BX * cells;
+    u64 oldc_mine = 0ull;
+#pragma unroll
+    for (int r = 0; r < RWB; ++r) {
+        if (row[r] < 0) continue;
+        const int rw = row[r], sh = rw & 31;
+        const bool on = (((rw < 32 ? sv_lo : sv_hi) >> sh) & 1u) != 0u;
+        const bool old = on && (((rw < 32 ? nb_lo : nb_hi) >> sh) & 1u) == 0u;
+        const float vx = old ? vv[r].x : 0.f, vy = old ? vv[r].y : 0.f;
+        if (on) {
+            const int j = (int)__popcll(surv & ((1ull << rw) - 1ull));   // survivors of this voxel in lower slots
+            const int c = j * 64 + l;
+            cw[c] = wr[r]; cvx[c] = vx; cvy[c] = vy; cs[c] = (unsigned char)rw;
+            if (old) oldc_mine |= 1ull << j;
+        }
+        // the rollout (:950-964) needs the MOVING old survivors: noted here, their future positions are k_rollout's job
+        const bool mv = vx != 0.f || vy != 0.f;
+        const int k = lds_agg_inc(&s_nmv, mv);
+        if (k >= 0) {
+            const size_t o = (ro_base + k) * 2;
+            ro_rec[o] = make_float4(pq[r].x, pq[r].y, vx, vy);
+            ro_rec[o + 1] = make_float4(wr[r], __int_as_float(lv), 0.f, 0.f);
+        }
+    }
+    if (oldc_mine) atomicOr(&s_oldc[l], oldc_mine);
+    __syncthreads();
+#ifdef RESAMPLE_PROF
+    t_s1 = __builtin_readcyclecounter();
+#endif
+    // ---- phase 2: one lane per voxel over its own n entries, LDS only
+    if (wave == 0) {
+        if (l == 0) ro_cnt[BX] = s_nmv;
+        const u64 oldc = s_oldc[l];
+        const int n = (int)__popcll(surv);
+        int nmax = n;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, WAVE));
+        int n_old = 0;
+        float wsum = 0.f, vxs = 0.f, vys = 0.f, stat_w = 0.f;
+        for (int j0 = 0; j0 < nmax; j0 += 4) {
+            float w4[4], x4[4], y4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int c = min(j0 + q, d.slots - 1) * 64 + l; w4[q] = cw[c]; x4[q] = cvx[c]; y4[q] = cvy[c]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (j0 + q < n) {
+                    if ((oldc >> (j0 + q)) & 1ull) {          // flag < 10 :944
+                        ++n_old;
+                        vxs += x4[q]; vys += y4[q];
+                        if (x4[q] == 0.f && y4[q] == 0.f) stat_w += w4[q];   // p + 0*t stays in this voxel for every horizon
+                    }
+                    wsum += w4[q];                            // :970
+                }
+            }
+        }
+        if (inr) {
+            float4 res = make_float4(wsum, 0.f, 0.f, 0.f);  // voxels_objects_number[v][0..3] :974-984
+            if (n_old > 0) { res.y = __fdiv_rn(vxs, (float)n_old); res.z = __fdiv_rn(vys, (float)n_old); }
+            s.res4[lv] = res;
+            if (stat_w != 0.f) s.fut_stat[lv] += stat_w;  // only this lane ever writes fut_stat[lv]
+        }
+#ifdef RESAMPLE_PROF
+        t_s2 = __builtin_readcyclecounter();
+#endif
+        // systematic resampling :986-1053
+        int ncp = 0;
+        float w_copy = 0.f;
+        u64 mfin = surv, keptc = 0ull;
+        const u64 valid = valid_bits(d, 0);
+        if (n >= 5) {
+            const int n_after = n > d.M ? d.M : n;                  // :992-997
+            const float w_after = __fdiv_rn(wsum, (float)n_after);  // :1000
+            w_copy = w_after;
+            float acc_ori = 0.f, acc_new = w_after * 0.5f;          // :1005-1006
+            // (copies go to the free slots of `mfin` and are not revisited: the walk covers the n survivors only, :1009)
+            for (int j0 = 0; j0 < n; j0 += 4) {
+                float w4[4];
+                int sl4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int c = min(j0 + q, d.slots - 1) * 64 + l; w4[q] = cw[c]; sl4[q] = (int)cs[c]; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (j0 + q >= n) continue;
+                    acc_ori += w4[q];                               // :1011
+                    if (acc_ori > acc_new) {
+                        float wn = w_after;                         // keep, new weight :1014
+                        acc_new += w_after;
+                        bool full = false;
+                        while (acc_ori > acc_new) {                 // copy heavy particles :1021
+                            const u64 fr = ~mfin & valid;
+                            if (!full && fr) {
+                                const int fslot = __ffsll((long long)fr) - 1;
+                                mfin |= fr & (~fr + 1ull);
+                                // the copy itself is deferred: only (source, destination) is noted here
+                                if (ncp < cpmax) s_cp[l * cpmax + ncp] = (unsigned short)((sl4[q] << 8) | fslot);
+                                ++ncp;
+                            } else {
+                                wn += w_after;                      // no free slot: fold the weight back :1037-1041
+                                full = true;
+                            }
+                            acc_new += w_after;
+                        }
+                        cw[(j0 + q) * 64 + l] = wn;                 // written back by phase 3
+                        keptc |= 1ull << (j0 + q);
+                    } else {
+                        mfin &= ~(1ull << sl4[q]);                  // remove :1046-1049
+                    }
+                }
+            }
+        }
+        if (ncp > cpmax) ncp = cpmax;  // cannot happen: a voxel makes at most M copies
+        s_ncp[l] = ncp;
+        s_wcp[l] = w_copy;
+        s_keptc[l] = keptc;
+        if (inr) {
+            s.mask[lv] = mfin;
+            if (nb) s.nbmask[lv] = 0ull;  // newborn flag -> 1 (:968)
+        }
+        const int live_out = wave_sum_i(inr ? (int)__popcll(mfin) : 0);
+        if (l == 0) { part_live[BX] = live_out; s.tile_live[BX] = live_out > 0 ? 1 : 0; }
+    }
+    __syncthreads();
+#ifdef RESAMPLE_PROF
+    t_s3 = __builtin_readcyclecounter();
+#endif
+    // ---- phase 3: new weights of the kept particles (entry j of every voxel, j split over the waves), then the copies (:1026-1031)
+    {
+        const u64 kp = s_keptc[l];
+        u64 tor = rows_of_wave<4>(wave_or_u64(kp), wave);
+        while (tor) {
+            const int j = __ffsll((long long)tor) - 1;
+            tor &= tor - 1ull;
+            if ((kp >> j) & 1ull) s.w[tcell + (size_t)cs[j * 64 + l] * 64 + l] = cw[j * 64 + l];
+        }
+    }
+    const int ncp = s_ncp[l];
+    const float w_copy = s_wcp[l];
+    int maxcp = ncp;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxcp = max(maxcp, __shfl_xor(maxcp, o, WAVE));
+    for (int k = wave; k < maxcp; k += 4) {
+        if (k < ncp) {
+            const unsigned pr = s_cp[l * cpmax + k];
+            const size_t sidx = tcell + (size_t)(pr >> 8) * 64 + l, didx = tcell + (size_t)(pr & 0xff) * 64 + l;
+            const P3 cp = ld_pos(s, sidx);
+            const V2 cv = ld_vel(s, sidx);
+            st_pos(s, didx, cp.x, cp.y, cp.z);
+            st_vel(s, didx, cv.x, cv.y);
+            if (s.vz0) s.vz0[didx] = s.vz0[sidx];
+            s.w[didx] = w_copy;
+        }
+    }
+#ifdef RESAMPLE_PROF
+    t_s4 = __builtin_readcyclecounter();
+    if (tid == 0 && BX < 65536) { g_rprof[BX * 4] = t_s1 - t_s0; g_rprof[BX * 4 + 1] = t_s2 - t_s1; g_rprof[BX * 4 + 2] = t_s3 - t_s2; g_rprof[BX * 4 + 3] = t_s4 - t_s3; }
+#endif
+}
+
+// --------------------------------------------------------------------------
 // k_rollout: the future-status rollout of mapOccupancyCalculationAndResample (:950-964) for the MOVING old particles
 // (static ones add the same mass to their own voxel for every horizon: fut_stat, k_resample).
 // One workgroup per tile that holds moving particles.  For every horizon t the particle's future voxel (same layer:
@@ -1542,7 +1800,13 @@ void launch_resample(const LaunchCtx& c) {
     const int nw = 1;   // waves (= tiles) per workgroup; the LDS panel bounds the occupancy, small groups pack best
     const size_t lds = (size_t)nw * (c.d.slots * 64 + (64 * c.d.M + 1) / 2) * sizeof(float);
     const unsigned grid = (unsigned)((k->ntiles + nw - 1) / nw);
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_resample<1>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt);
+    // maps of the metric's size run the four-waves-per-tile variant: their frame is a chain of latencies and the longest tile is
+    // the kernel; large maps keep one wave per tile (more tiles in flight per CU)
+    static const int wg_tiles = getenv("DSPMAP_RESAMPLE_WG_TILES") ? atoi(getenv("DSPMAP_RESAMPLE_WG_TILES")) : 8192;
+    if (k->ntiles < wg_tiles && c.d.mw == 1 && c.d.slots <= 4 * RWB) {
+        const size_t lds4 = (size_t)(3 * c.d.slots * 64) * sizeof(float) + (size_t)c.d.slots * 64 + (size_t)64 * c.d.M * 2;
+        hipLaunchKernelGGL(k_resample_wg, dim3(k->ntiles), dim3(256), lds4, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt);
+    } else if (c.d.mw == 1) hipLaunchKernelGGL(k_resample<1>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt);
     else hipLaunchKernelGGL(k_resample<2>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt);
     if (c.d.T > 0) hipLaunchKernelGGL(k_rollout, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->ro_rec, k->ro_cnt);
 }
