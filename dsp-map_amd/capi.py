@@ -43,7 +43,7 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "n_points_in", "n_valid", "n_obs", "n_live_in", "n_moved", "n_out_of_map", "n_voxel_full",
         "n_pyramid_full", "n_fov", "n_born", "n_born_dropped", "n_live_out", "n_exported_up",
-        "n_exported_down")] + [("newborn_weight", C.c_float), ("update_ms", C.c_float)]
+        "n_exported_down", "n_reslotted", "n_overflow_inexact")] + [("newborn_weight", C.c_float), ("update_ms", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

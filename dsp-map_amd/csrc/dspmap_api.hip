@@ -157,7 +157,7 @@ static void free_dev(dspmap* m) {
     if (m->mgpu_count) chk(hipFree(m->mgpu_count), "hipFree");
     void* ptrs[] = {s.fpar, s.obs_ckf, s.part_inv, s.fut_stat, s.mask, s.nbmask, s.pos, s.vel, s.w, s.vz0, s.res4, s.fut, s.fut_out, s.obs, s.obs_ck,
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
-                    s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, s.fov_rec, s.fov_slot, s.fov_key, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt,
+                    s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, s.fov_rec, s.fov_slot, s.fov_key, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt, s.in_n, s.pmask, s.ta, s.dflag, s.dirty,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.ro_cnt, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
                     m->k.part_predict, m->k.part_claim, m->k.tile_fov, s.tile_live, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
@@ -343,6 +343,10 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&k.mv_rec, ntiles * 64 * d.slots * 2));
     HIPCHK(m, dalloc(&k.in_rec, ntiles * 64 * d.slots * 2));
     HIPCHK(m, dalloc(&k.in_cnt, ntiles));
+    HIPCHK(m, dalloc(&s.in_n, ntiles));
+    HIPCHK(m, hipMemset(s.in_n, 0, sizeof(int) * ntiles));
+    HIPCHK(m, dalloc(&s.pmask, W)); HIPCHK(m, dalloc(&s.ta, W)); HIPCHK(m, dalloc(&s.dflag, (size_t)d.v_loc)); HIPCHK(m, dalloc(&s.dirty, (size_t)DSP_DIRTY_CAP));
+    HIPCHK(m, hipMemset(s.pmask, 0, sizeof(u64) * W)); HIPCHK(m, hipMemset(s.ta, 0, sizeof(u64) * W)); HIPCHK(m, hipMemset(s.dflag, 0, sizeof(int) * (size_t)d.v_loc));
     k.ro_rec = k.mv_rec;   // k_predict's staging area is dead once k_predict has ended: k_resample -> k_rollout reuse it
     HIPCHK(m, dalloc(&k.ro_cnt, ntiles));
     HIPCHK(m, hipMemset(k.ro_cnt, 0, sizeof(int) * ntiles));
@@ -1099,6 +1103,7 @@ extern "C" int dspmap_get_counters(dspmap_t* m, dspmap_counters* out) {
     out->n_out_of_map = fs.n_out_of_map; out->n_voxel_full = fs.n_voxel_full; out->n_pyramid_full = fs.n_pyramid_full;
     out->n_fov = fs.n_fov; out->n_born = fs.n_born; out->n_born_dropped = fs.n_born_dropped;
     out->n_live_out = fs.n_live_out; out->n_exported_up = m->last_exp[1]; out->n_exported_down = m->last_exp[0];
+    out->n_reslotted = fs.n_dirty; out->n_overflow_inexact = fs.n_overflow_inexact;
     out->newborn_weight = fs.newborn_w;
     if (m->ev_valid) {
         float ms = 0.f;
@@ -1269,6 +1274,7 @@ extern "C" int dspmap_stage_predict(dspmap_t* m, float dx, float dy, float dz, f
     launch_frame_setup(c, false);
     launch_predict(c);
     launch_pyr_prepare(c);   // a full pyramid list turns its latest particles (in sweep order) away: part of the prediction (:1256-1259)
+    launch_place_fix(c);     // ... and the arrivals behind a turned-away particle take the slot it hands back
     if (m->vz_frames > 0) --m->vz_frames;
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;

@@ -83,6 +83,19 @@ __device__ __forceinline__ void wave_count_add(int* cnt, bool active) {
     if (grp && lane_id() == __ffsll((long long)grp) - 1) atomicAdd(cnt, (int)__popcll(grp));
 }
 
+// OR of a 64-bit value over the wave (DPP network, both halves)
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ u64 wave_or_u64(u64 v) {
+    return ((u64)wave_or_u32((unsigned)(v >> 32)) << 32) | (u64)wave_or_u32((unsigned)v);
+}
 // ---- quaternion rotation: rotateVectorByQuaternion dsp_dynamic.h:1303-1322
 // (att * (0,v) * att.inverse(); Hamilton product in Eigen's generic operand order)
 __device__ __forceinline__ void quat_mul(const float a[4], const float b[4], float r[4]) {

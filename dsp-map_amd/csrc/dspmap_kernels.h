@@ -69,6 +69,7 @@ void launch_velocity_estimator(const LaunchCtx& c, bool with_rank);   // with_ra
 int velocity_estimator_capacity();   // points per frame the device estimator handles
 int velocity_estimator_slices();
 // mapUpdate (:704-793)
+void launch_place_fix(const LaunchCtx& c);     // re-slots the arrivals of voxels in which a full pyramid list turned a particle away (after launch_pyr_prepare)
 void launch_pyr_prepare(const LaunchCtx& c);   // range sort + full-list selection of the pyramid lists, work items (idempotent)
 void launch_ck_partial(const LaunchCtx& c, bool prepared = false);     // launch_pyr_prepare (unless already queued) + the Ck pass
 void launch_ck_finalize(const LaunchCtx& c);

@@ -57,7 +57,7 @@ __global__ void k_reset(MapDims d, DevState s, int flags) {
     if (flags & RESET_PRED) {
         for (int i = gt; i < d.np; i += gn) s.pyr_cnt[i] = 0;
         if (gt == 0) {
-            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->n_pyr_removed = 0;
+            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->n_pyr_removed = 0; s.fs->n_dirty = 0; s.fs->n_overflow_inexact = 0;
         }
     }
 }
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) k_obs_points(MapDims d, DevState s, const
         if (gt == 0) {
             s.fs->cur_pos[0] = cpx; s.fs->cur_pos[1] = cpy; s.fs->cur_pos[2] = cpz;
             s.fs->n_valid = 0; s.fs->n_obs = 0; s.fs->has_expected_override = 0;   // k_obs_gather accumulates the first two
-            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->n_pyr_removed = 0;
+            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->n_pyr_removed = 0; s.fs->n_dirty = 0; s.fs->n_overflow_inexact = 0;
         }
     } else {
         for (int i = threadIdx.x; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
@@ -230,6 +230,13 @@ __device__ __forceinline__ void pyr_sort_block(const MapDims& d, const DevState&
             const int c = src_slot[i];
             const int tile = c / (64 * d.slots), rem = c - tile * 64 * d.slots, slot = rem >> 6, lv = tile * 64 + (rem & 63);
             atomicAnd(&s.mask[(size_t)lv * d.mw + (slot >> 6)], ~(1ull << (slot & 63)));
+            // the reference hands the slot back AT ONCE (:1256-1259): the arrivals that the sweep serves after this particle may
+            // take it.  k_place ran before the lists were cut, so the voxel is noted for k_place_fix, which re-slots its arrivals
+            atomicOr(&s.ta[(size_t)lv * d.mw + (slot >> 6)], 1ull << (slot & 63));
+            if (atomicExch(&s.dflag[lv], 1) == 0) {
+                const int q = atomicAdd(&s.fs->n_dirty, 1);
+                if (q < DSP_DIRTY_CAP) s.dirty[q] = lv; else atomicAdd(&s.fs->n_overflow_inexact, 1);
+            }
             ++removed;
         }
     }
@@ -268,6 +275,192 @@ __global__ void __launch_bounds__(1024) k_pyr_prepare(MapDims d, DevState s, int
                                                       int* __restrict__ n_items, int* __restrict__ nb_tab) {
     if ((int)blockIdx.x == d.np) pyr_items_block(d, s, ck_items, wu_items, n_items, nb_tab);
     else pyr_sort_block(d, s, (int)blockIdx.x);
+}
+
+// --------------------------------------------------------------------------
+// k_place_fix: a particle that its pyramid's full list turns away gives its slot back AT ONCE (:1256-1259), so the arrivals
+// that the reference's sweep serves after it may take that slot.  k_place gives out the slots before the lists are cut
+// (k_pyr_prepare), i.e. as if nobody were turned away; this pass re-slots the arrivals of the (few) voxels in which that
+// made a difference -- the voxels the cut noted in DevState::dirty:
+//   * the voxel's arrivals are collected from its tile's inbox and put in sweep order (source key);
+//   * the reference's walk is replayed twice, lane 0, a few dozen steps: as k_place did it (which slot holds which
+//     arrival now), and with the turned-away particles handing their slots back -- arrivals from lower voxel indices
+//     against the occupancy before the prediction, then the voxel's own turned-away particles leave, then the arrivals
+//     from higher indices against the occupancy after it;
+//   * an arrival whose slot differs is moved (position, velocity, weight), the occupancy word follows, and its entry in
+//     the range-sorted pyramid list is pointed to the new cell (the weight update writes through that entry).
+// One wave per dirty voxel.  Runs between k_pyr_prepare and the weight update's write-back: as the first workgroups of
+// k_ck_partial's launch in a frame (that kernel reads the sorted COPIES of the particles, not their cells), or on its own
+// (stage API).  Idempotent: a second run finds nothing turned away.
+// Not treated (counted in n_overflow_inexact): an arrival that found its voxel FULL in k_place and would fit now.
+// --------------------------------------------------------------------------
+#define PF_MAXA 128   // arrivals of one voxel the pass orders (a voxel has at most 72 slots)
+__device__ __forceinline__ int first_free(const u64* occ, int mw, int slots) {
+    for (int e = 0; e < mw; ++e) {
+        const int nbits = min(64, slots - e * 64);
+        const u64 valid = nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
+        const u64 fr = ~occ[e] & valid;
+        if (fr) return e * 64 + (__ffsll((long long)fr) - 1);
+    }
+    return -1;
+}
+__device__ __forceinline__ void place_fix_wave(const MapDims& d, const DevState& s, const float4* __restrict__ in_rec, const u64* __restrict__ omask,
+                                               const int lv, int* s_key, int* s_idx, int* s_s1, int* s_s2) {
+    const int l = lane_id();
+    const int tile = lv >> 6, cap = 64 * d.slots;
+    const int n = min(s.in_n[tile], cap);
+    const size_t base = (size_t)tile * cap;
+    const int gD = lv + d.v_base;
+    int m = 0;   // (wave-uniform)
+    // lanes hand data to each other through LDS below: the wave runs in lockstep, but the COMPILER must not move a lane's
+    // load above another lane's store -- a wavefront-scope fence between the steps
+    auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    // the voxel's arrivals
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + l;
+        bool mine = false;
+        int key = 0;
+        if (i < n) {
+            mine = __float_as_int(in_rec[(base + i) * 2].x) == gD;
+            key = __float_as_int(in_rec[(base + i) * 2 + 1].w);
+        }
+        const u64 g = __ballot(mine);
+        const int k = m + (int)__popcll(g & lanemask_lt());
+        if (mine && k < PF_MAXA) { s_key[k] = key; s_idx[k] = i; }
+        m += (int)__popcll(g);
+    }
+    wave_sync();
+    u64 tw[2] = {0ull, 0ull};
+    for (int e = 0; e < d.mw; ++e) tw[e] = s.ta[(size_t)lv * d.mw + e];
+    if (m > PF_MAXA) {
+        if (l == 0) atomicAdd(&s.fs->n_overflow_inexact, 1);
+    } else if (m > 0 && (tw[0] | tw[1])) {
+        // sweep order: rank of every arrival among the voxel's arrivals (keys are distinct)
+        int rk[2] = {0, 0};
+        for (int j = 0; j < 2; ++j) {
+            const int a = l + 64 * j;
+            if (a < m) { const int ka = s_key[a]; for (int x = 0; x < m; ++x) rk[j] += s_key[x] < ka ? 1 : 0; }
+        }
+        int ka[2], ia[2];
+        for (int j = 0; j < 2; ++j) { const int a = l + 64 * j; ka[j] = a < m ? s_key[a] : 0; ia[j] = a < m ? s_idx[a] : 0; }
+        wave_sync();
+        for (int j = 0; j < 2; ++j) { const int a = l + 64 * j; if (a < m) { s_key[rk[j]] = ka[j]; s_idx[rk[j]] = ia[j]; } }   // (one wave: reads above are done)
+        wave_sync();
+        // the two walks (lane 0)
+        if (l == 0) {
+            u64 org[2] = {0ull, 0ull}, cur0[2] = {0ull, 0ull};
+            for (int e = 0; e < d.mw; ++e) { org[e] = omask[(size_t)lv * d.mw + e]; cur0[e] = s.pmask[(size_t)lv * d.mw + e]; }
+            const long long dkey = (long long)gD * d.slots;   // key of (D, slot 0): arrivals below it come before D's own sweep
+            // as placed: nobody hands a slot back
+            {
+                u64 occ[2] = {org[0], org[1]}, took[2] = {0ull, 0ull};
+                int a = 0;
+                for (; a < m && (long long)s_key[a] < dkey; ++a) {
+                    const int sl = first_free(occ, d.mw, d.slots);
+                    s_s1[a] = sl;
+                    if (sl >= 0) { occ[sl >> 6] |= 1ull << (sl & 63); took[sl >> 6] |= 1ull << (sl & 63); }
+                }
+                occ[0] = cur0[0] | took[0]; occ[1] = cur0[1] | took[1];
+                for (; a < m; ++a) {
+                    const int sl = first_free(occ, d.mw, d.slots);
+                    s_s1[a] = sl;
+                    if (sl >= 0) occ[sl >> 6] |= 1ull << (sl & 63);
+                }
+            }
+            // the reference: a turned-away particle takes its slot and hands it back at once
+            {
+                u64 occ[2] = {org[0], org[1]}, held[2] = {0ull, 0ull};
+                int a = 0;
+                for (; a < m && (long long)s_key[a] < dkey; ++a) {
+                    const int s1 = s_s1[a];
+                    const bool away = s1 >= 0 && ((tw[s1 >> 6] >> (s1 & 63)) & 1ull);
+                    const int sl = s1 >= 0 ? first_free(occ, d.mw, d.slots) : -1;   // (an arrival k_place found no slot for stays dropped)
+                    s_s2[a] = away ? -2 : sl;
+                    if (!away && sl >= 0) { occ[sl >> 6] |= 1ull << (sl & 63); held[sl >> 6] |= 1ull << (sl & 63); }
+                    if (s1 < 0 && first_free(occ, d.mw, d.slots) >= 0) atomicAdd(&s.fs->n_overflow_inexact, 1);
+                }
+                // the voxel's own sweep: its turned-away particles (cells occupied after the prediction) are gone
+                occ[0] = (cur0[0] & ~tw[0]) | held[0]; occ[1] = (cur0[1] & ~tw[1]) | held[1];
+                for (; a < m; ++a) {
+                    const int s1 = s_s1[a];
+                    const bool away = s1 >= 0 && ((tw[s1 >> 6] >> (s1 & 63)) & 1ull);
+                    const int sl = s1 >= 0 ? first_free(occ, d.mw, d.slots) : -1;
+                    s_s2[a] = away ? -2 : sl;
+                    if (!away && sl >= 0) occ[sl >> 6] |= 1ull << (sl & 63);
+                    if (s1 < 0 && first_free(occ, d.mw, d.slots) >= 0) atomicAdd(&s.fs->n_overflow_inexact, 1);
+                }
+            }
+        }
+        wave_sync();
+        // moves: every source is read before any destination is written (a destination may be another mover's source)
+        const size_t tcell = (size_t)tile * cap;
+        const int ln = lv & 63;
+        P3 mp[2]; V2 mvv[2]; float mw_[2], mz[2];
+        bool mvd[2];
+        int from[2], to[2];
+        for (int j = 0; j < 2; ++j) {
+            const int a = l + 64 * j;
+            mvd[j] = false; from[j] = to[j] = -1;
+            if (a < m) { from[j] = s_s1[a]; to[j] = s_s2[a]; mvd[j] = from[j] >= 0 && to[j] >= 0 && to[j] != from[j]; }
+            if (mvd[j]) {
+                const size_t sidx = tcell + (size_t)from[j] * 64 + ln;
+                mp[j] = ld_pos(s, sidx); mvv[j] = ld_vel(s, sidx); mw_[j] = s.w[sidx]; mz[j] = s.vz0 ? s.vz0[sidx] : 0.f;
+            }
+        }
+        u64 clr[2] = {0ull, 0ull}, setb[2] = {0ull, 0ull};
+        for (int j = 0; j < 2; ++j) {
+            if (mvd[j]) {
+                const size_t didx = tcell + (size_t)to[j] * 64 + ln;
+                st_pos(s, didx, mp[j].x, mp[j].y, mp[j].z); st_vel(s, didx, mvv[j].x, mvv[j].y); s.w[didx] = mw_[j];
+                if (s.vz0) s.vz0[didx] = mz[j];
+                clr[from[j] >> 6] |= 1ull << (from[j] & 63);
+                setb[to[j] >> 6] |= 1ull << (to[j] & 63);
+            }
+        }
+        for (int e = 0; e < d.mw; ++e) {
+            const u64 c = wave_or_u64(clr[e]), st = wave_or_u64(setb[e]);
+            if (l == 0 && (c | st)) s.mask[(size_t)lv * d.mw + e] = (s.mask[(size_t)lv * d.mw + e] & ~c) | st;   // (arrivals live in `mask`; this wave owns the voxel now)
+        }
+        // the moved arrivals' entries in their pyramids' sorted lists
+        const float* __restrict__ gph = s.planes_h;
+        const float* __restrict__ gpv = s.planes_v;
+        for (int a = 0; a < m; ++a) {
+            const int s1 = s_s1[a], s2 = s_s2[a];
+            if (!(s1 >= 0 && s2 >= 0 && s1 != s2)) continue;   // (uniform: LDS values)
+            const size_t didx = tcell + (size_t)s2 * 64 + ln;
+            const P3 p = ld_pos(s, didx);
+            const int pyr = pyramid_of(d, gph, gpv, p.x, p.y, p.z);
+            if (pyr < 0) continue;
+            const int old_cell = (int)(tcell + (size_t)s1 * 64 + ln);
+            const int P = min(s.pyr_cnt[pyr], d.capp), P_all = min(s.pyr_cnt[pyr], d.capa);
+            for (int q0 = 0; q0 < P; q0 += 64) {
+                const int q = q0 + l;
+                if (q < P && s.fov_slot_s[(size_t)pyr * d.capp + q] == old_cell) s.fov_slot_s[(size_t)pyr * d.capp + q] = (int)didx;
+            }
+            for (int q0 = 0; q0 < P_all; q0 += 64) {   // (the unsorted list too: a later preparation of the same lists starts from it)
+                const int q = q0 + l;
+                if (q < P_all && s.fov_slot[(size_t)pyr * d.capa + q] == old_cell && s.fov_key[(size_t)pyr * d.capa + q] != 0x7fffffff)
+                    s.fov_slot[(size_t)pyr * d.capa + q] = (int)didx;
+            }
+        }
+    }
+    // the voxel is clean again
+    if (l == 0) {
+        for (int e = 0; e < d.mw; ++e) s.ta[(size_t)lv * d.mw + e] = 0ull;
+        s.dflag[lv] = 0;
+    }
+}
+// the pass as a workgroup function: wave w of workgroup g (of ng) takes the dirty voxels w + 4 g, + 4 ng, ...
+__device__ __forceinline__ void place_fix_block(const MapDims& d, const DevState& s, const float4* __restrict__ in_rec, const u64* __restrict__ omask,
+                                                int g, int ng) {
+    __shared__ int s_key[4][PF_MAXA], s_idx[4][PF_MAXA], s_s1[4][PF_MAXA], s_s2[4][PF_MAXA];
+    const int nd = min(s.fs->n_dirty, DSP_DIRTY_CAP);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (int q = g * 4 + w; q < nd; q += ng * 4) place_fix_wave(d, s, in_rec, omask, s.dirty[q], s_key[w], s_idx[w], s_s1[w], s_s2[w]);
+}
+#define PF_WG 32   // workgroups of the pass (the first ones of k_ck_partial's launch in a frame)
+__global__ void __launch_bounds__(256) k_place_fix(MapDims d, DevState s, const float4* __restrict__ in_rec, const u64* __restrict__ omask) {
+    place_fix_block(d, s, in_rec, omask, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // --------------------------------------------------------------------------
@@ -374,8 +567,12 @@ __device__ __forceinline__ void neighbor_load(const MapDims& d, const int* __res
 }
 
 __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, FilterParams fp, const int* __restrict__ items,
-                                                       const int* __restrict__ n_items, const int* __restrict__ nb_tab) {
-    const int BX = (int)blockIdx.x, GX = (int)gridDim.x;
+                                                       const int* __restrict__ n_items, const int* __restrict__ nb_tab,
+                                                       const float4* __restrict__ in_rec, const u64* __restrict__ omask) {
+    // the first PF_WG workgroups re-slot the arrivals of the voxels in which a full pyramid list turned a particle away
+    // (k_place_fix: nothing to do in most frames); the pair items do not depend on it
+    if ((int)blockIdx.x < PF_WG) { place_fix_block(d, s, in_rec, omask, (int)blockIdx.x, PF_WG); return; }
+    const int BX = (int)blockIdx.x - PF_WG, GX = (int)gridDim.x - PF_WG;
     extern __shared__ float4 s_z[];   // [nbins * DSP_OBS_CAP] the neighbourhood's observations within range of the chunk ...
     int* s_oi = reinterpret_cast<int*>(s_z + (size_t)d.nbins * DSP_OBS_CAP);   // ... and their global indices
     __shared__ float4 s_p[CK_PCH];
@@ -1001,12 +1198,16 @@ void launch_obs_bin(const LaunchCtx& c, int n_pts_grid) {
 
 // map corner farther than 12 cull radii: most pairs are far (28 % at 8 radii, 72 % at 16, measured) -> k_weight<true>
 static bool weight_culls(const LaunchCtx& c) { return (float)PS_NBK / c.d.rng_inv_bw > 12.f * c.fp.cull_r; }
+void launch_place_fix(const LaunchCtx& c) {   // stage API: after launch_pyr_prepare (a frame's k_ck_partial launch carries the pass)
+    hipLaunchKernelGGL(k_place_fix, dim3(PF_WG), dim3(256), 0, c.stream, c.d, c.s, c.k.in_rec, c.k.omask);
+}
 void launch_pyr_prepare(const LaunchCtx& c) {
     hipLaunchKernelGGL(k_pyr_prepare, dim3(c.d.np + 1), dim3(1024), 0, c.stream, c.d, c.s, c.k.ck_items, c.k.wu_items, c.k.n_items, c.k.nb_tab);
 }
 void launch_ck_partial(const LaunchCtx& c, bool prepared) {
     if (!prepared) hipLaunchKernelGGL(k_pyr_prepare, dim3(c.d.np + 1), dim3(1024), 0, c.stream, c.d, c.s, c.k.ck_items, c.k.wu_items, c.k.n_items, c.k.nb_tab);
-    hipLaunchKernelGGL(k_ck_partial, dim3(4096), dim3(CK_TPB), (sizeof(float4) + sizeof(int)) * (size_t)c.d.nbins * DSP_OBS_CAP, c.stream, c.d, c.s, c.fp, c.k.ck_items, c.k.n_items, c.k.nb_tab);
+    hipLaunchKernelGGL(k_ck_partial, dim3(4096 + PF_WG), dim3(CK_TPB), (sizeof(float4) + sizeof(int)) * (size_t)c.d.nbins * DSP_OBS_CAP, c.stream, c.d, c.s, c.fp, c.k.ck_items, c.k.n_items, c.k.nb_tab,
+                       c.k.in_rec, c.k.omask);
 }
 void launch_ck_finalize(const LaunchCtx& c) {  // after launch_weight_update: reduces the per-pyramid 1/Ck sums
     hipLaunchKernelGGL(k_ck_sum, dim3(1), dim3(512), 0, c.stream, c.d, c.s, c.fp);

@@ -23,19 +23,6 @@
 #include "dspmap_kernels.h"
 #include "dspmap_birth.h"
 
-// OR of a 64-bit value over the wave (DPP network, both halves)
-__device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
-    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
-    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
-    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
-    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
-    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
-    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-__device__ __forceinline__ u64 wave_or_u64(u64 v) {
-    return ((u64)wave_or_u32((unsigned)(v >> 32)) << 32) | (u64)wave_or_u32((unsigned)v);
-}
 __device__ __forceinline__ u64 valid_bits(const MapDims& d, int e) {
     const int nbits = min(64, d.slots - e * 64);
     return nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
@@ -633,6 +620,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
     const int n_all = in_cnt[BX];
     if (n_all == 0) {
         if (tid < 2) part2[BX * 2 + tid] = 0;
+        if (tid == 0) s.in_n[BX] = 0;
         return;
     }
     const bool was_live = s.tile_live[BX] != 0;   // an empty tile was skipped by k_predict: its omask words are stale (and zero in truth)
@@ -651,6 +639,10 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
             s_cur[e * 64 + tid] = in ? (s.mask[(size_t)lv * MW + e] | s.nbmask[(size_t)lv * MW + e]) : ~0ull;
             s_org[e * 64 + tid] = in ? (was_live ? omask[(size_t)lv * MW + e] : 0ull) : ~0ull;
             s_new[e * 64 + tid] = 0ull;
+            if (in) {   // what k_place_fix needs should a pyramid list turn arrivals of this tile away: both occupancies as used here
+                s.pmask[(size_t)lv * MW + e] = s_cur[e * 64 + tid];
+                if (!was_live) const_cast<u64*>(omask)[(size_t)lv * MW + e] = 0ull;
+            }
         }
     }
     if (tid < 2) s_cnt[tid] = 0;
@@ -786,7 +778,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
         for (int e = 0; e < MW; ++e)
             if (s_new[e * 64 + tid]) s.mask[(size_t)lv * MW + e] = s.mask[(size_t)lv * MW + e] | s_new[e * 64 + tid];
     }
-    if (tid == 0) { in_cnt[BX] = 0; s.tile_live[BX] = 1; }   // ready for the next frame; the tile holds particles now
+    if (tid == 0) { in_cnt[BX] = 0; s.in_n[BX] = n; s.tile_live[BX] = 1; }   // ready for the next frame; the tile holds particles now
     if (tid < 2) part2[BX * 2 + tid] = s_cnt[tid];
 }
 

@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #define DSP_MAX_PRED 16
+#define DSP_DIRTY_CAP 65536          // voxels per frame that can be re-slotted after a pyramid list overflow
 #define DSP_MAX_NBINS 25           // neighbourhood bins supported by the pair kernels (radius <= 2)
 #define PS_NBK 128                 // range buckets per pyramid list (k_pyr_sort)
 #define NB_TAB_STRIDE (2 * DSP_MAX_NBINS + 2)   // ints per pyramid in KernelScratch::nb_tab: bins, then offsets
@@ -85,6 +86,8 @@ struct FrameScalars {
     int n_exp_up, n_exp_down;
     int occupied_count; // readout
     int n_voxel_full_import; // multi-GPU: movers received from a neighbour that found their voxel full
+    int n_dirty;            // entries of DevState::dirty
+    int n_overflow_inexact; // diagnostics: voxels / arrivals the re-slotting pass could not treat exactly (see k_place_fix)
     int n_pyr_removed;  // particles k_pyr_prepare turned away because their pyramid's list was full (-2, :1256-1259)
     float expected_newborn;  // expected_new_born_objects :292
     float newborn_w;         // updated_weight_new_born :805
@@ -174,6 +177,12 @@ struct DevState {
     FrameScalars* fs;
     FrameParams* fpar;
     int* ring_seq;      // read position of the pinned parameter ring (frames replayed as a captured graph)
+    // re-slotting after a full pyramid list has turned particles away (k_place_fix, dspmap_kernels.hip)
+    u64* pmask;         // [v_loc*mw] occupancy after the prediction, before any arrival was placed (tiles with arrivals; k_place)
+    u64* ta;            // [v_loc*mw] cells whose particle its pyramid's full list turned away this frame (all zero between frames)
+    int* dflag;         // [v_loc] 1 = the voxel is in the dirty list
+    int* dirty;         // [DSP_DIRTY_CAP] local voxels that lost a particle to a full pyramid list this frame
+    int* in_n;          // [tiles] arrivals the last placement served per tile
     int* tile_live;     // [tiles] 0 = the 64-voxel tile holds no particle (k_resample found it empty and nothing was placed, born or
                         // imported there since): the sweeps skip it without reading its occupancy words.  Conservative: nonzero
                         // does not promise a particle.

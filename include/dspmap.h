@@ -91,6 +91,8 @@ typedef struct dspmap_counters {
     int n_born_dropped;    /* newborn dropped: voxel full :1198 */
     int n_live_out;        /* live particles after resampling */
     int n_exported_up, n_exported_down; /* multi-GPU: left the slab through z_hi / z_lo */
+    int n_reslotted;       /* voxels whose arrivals were re-slotted because a full pyramid list turned a particle away (:1256-1259) */
+    int n_overflow_inexact;/* diagnostics: arrivals / voxels that pass could not treat exactly (destination voxel full AND list full) */
     float newborn_weight;  /* updated_weight_new_born :805 */
     float update_ms;       /* device time of the last TIMED update (HIP events): every frame of the host-staged path, every 32nd frame
                               of dspmap_update_device's replayed graph (an event record between two replays costs ~5 us) */

@@ -179,8 +179,8 @@ def test_pyramid_list_overflow_in_sweep_order(dsp, orc):
     """pyramid-list overflow (-2, :1245-1259): a pyramid registers at most SAFE_PARTICLE_NUM_PYRAMID particles, in the
     order of the reference's voxel / slot sweep; the ones that come later are removed.  Every list entry carries its sweep
     key and k_pyr_prepare keeps the SAFE_PARTICLE_NUM_PYRAMID smallest keys of a full list: the same particles survive as in
-    the oracle -- in the same slots when nobody changes voxel, and as the same set of particles when they do (a slot freed
-    by a turned-away mover is not re-used by the arrivals behind it in the same sweep; documented deviation)."""
+    the oracle, in the same slots -- also when particles change voxel: a slot handed back by a turned-away particle is
+    re-used by the arrivals behind it in the sweep (k_place_fix)."""
     cfgkw = dict(nx=40, ny=40, nz=10, res=0.15, ppv=9)
     o, m = make_pair(dsp, orc, **cfgkw)
     assert m.capp == o.capp == 66
@@ -206,19 +206,23 @@ def test_pyramid_list_overflow_in_sweep_order(dsp, orc):
     len_o = (o.pyramid_lists[:, :, 0] != 0).sum(1)
     len_g = m.pyramid_counts()
     assert (len_o == o.capp).sum() >= 5, (len_o == o.capp).sum()
-    # (the documented deviation: in a FULL voxel a slot freed by a turned-away mover is not re-used in the same sweep)
-    assert (len_o != len_g).sum() <= 0.02 * o.NP and np.abs(len_o - len_g).max() <= 2, np.nonzero(len_o != len_g)
     c = m.counters()
-    assert c["n_moved"] > 1000 and c["n_pyramid_full"] > 50, c
+    assert c["n_moved"] > 1000 and c["n_pyramid_full"] > 50 and c["n_reslotted"] > 5, c
     vo, so, ro = o.export_sparse()
     vg, sg, rg = gpu_state(m)
-    a_v, a_r = common.sorted_records(vo, ro, cols=(4, 5, 6, 1, 2, 7))
-    b_v, b_r = common.sorted_records(vg, rg, cols=(4, 5, 6, 1, 2, 7))
-    same = len(a_v) == len(b_v) and np.array_equal(a_v, b_v) and np.array_equal(a_r[:, 1:8], b_r[:, 1:8])
-    if not same:   # the documented deviation can only cost particles in voxels that were full: bound it
+    ko, kg = np.lexsort((so, vo)), np.lexsort((sg, vg))
+    same = len(vo) == len(vg) and np.array_equal(vo[ko], vg[kg]) and np.array_equal(so[ko], sg[kg]) and \
+        np.array_equal(ro[ko][:, 1:8], rg[kg][:, 1:8])
+    if c["n_overflow_inexact"] == 0:
+        # k_place_fix hands the slots of turned-away particles to the arrivals behind them: lists and SLOTS as in the oracle
+        assert np.array_equal(len_o, len_g) and same
+    else:
+        # the one coincidence the pass does not treat (an arrival that found its voxel full before the lists were cut and
+        # would fit afterwards): counted, and bounded here
+        assert (len_o != len_g).sum() <= 0.02 * o.NP and np.abs(len_o - len_g).max() <= 2, np.nonzero(len_o != len_g)
         key_o = set(map(tuple, np.column_stack([vo, ro[:, 4:7].view(np.int32)]).tolist()))
         key_g = set(map(tuple, np.column_stack([vg, rg[:, 4:7].view(np.int32)]).tolist()))
-        assert len(key_o ^ key_g) <= 0.002 * len(key_o), (len(key_o), len(key_g), len(key_o ^ key_g))
+        assert len(key_o ^ key_g) <= 0.002 * len(key_o), (len(key_o), len(key_g), len(key_o ^ key_g), c["n_overflow_inexact"])
     o.close(); m.close()
 
 

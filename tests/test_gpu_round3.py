@@ -264,3 +264,53 @@ def test_fast_voxel_division_is_the_ieee_division(dsp, res):
         m.close()
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+def _fill_view_uniform(o, m, n, seed, vmax):
+    """n particles uniform over the map box, those inside the field of view kept (uniform density: no pile-up in the voxels
+    next to the sensor), all with a velocity"""
+    half = common.half_extent(o.cfg)
+    rng = np.random.default_rng(seed)
+    px = rng.uniform(0.3, half[0] * 0.97, n); py = rng.uniform(-half[1] * 0.97, half[1] * 0.97, n); pz = rng.uniform(-half[2] * 0.97, half[2] * 0.97, n)
+    keep = (np.abs(np.degrees(np.arctan2(py, px))) < 40.0) & (np.abs(np.degrees(np.arctan2(pz, px))) < 22.0)
+    px, py, pz = (a[keep].astype(np.float32) for a in (px, py, pz))
+    vx = (rng.uniform(-vmax, vmax, len(px))).astype(np.float32)
+    vy = (rng.uniform(-vmax, vmax, len(px))).astype(np.float32)
+    w = rng.uniform(0.01, 0.05, len(px)).astype(np.float32)
+    return common.inject_both(o, m, px, py, pz, vx, vy, w)
+
+
+@pytest.mark.parametrize("ppv,n,seed", [(24, 227000, 9), (36, 303000, 4)])
+def test_turned_away_movers_hand_their_slot_back_at_once(dsp, orc, ppv, n, seed):
+    """a particle that changes voxel and finds its pyramid's list full takes a slot and hands it back at once (:1256-1259):
+    the arrivals that the sweep serves after it use that slot; likewise the slot of a turned-away particle that stayed in
+    its voxel is free for the arrivals from higher voxel indices.  k_place gives the slots out before the lists are cut;
+    k_place_fix re-slots the arrivals of the voxels concerned: lists AND slots equal the oracle's sequential sweep exactly --
+    one and two occupancy words.  (Not treated, and counted in n_overflow_inexact: an arrival that found its voxel full
+    before the lists were cut and would fit afterwards -- see test_pyramid_list_overflow_in_sweep_order.)"""
+    cfgkw = dict(nx=40, ny=40, nz=16, res=0.15 if ppv == 24 else 0.10, ppv=ppv)
+    o, m = make_pair(dsp, orc, **cfgkw)
+    n_in = _fill_view_uniform(o, m, n, seed, vmax=1.5)
+    pts = common.wall_cloud(3, n_side=40, dist=2.2 if ppv == 24 else 1.5, half_w=1.8 if ppv == 24 else 1.2, half_h=0.6)
+    o.bin_points(pts); m.bin_points(pts)
+    o.predict(-0.03, 0.02, 0.0, 0.1); m.predict(-0.03, 0.02, 0.0, 0.1)
+    len_o = (o.pyramid_lists[:, :, 0] != 0).sum(1)
+    c = m.counters()
+    assert c["n_moved"] > 5000 and c["n_reslotted"] > 5 and c["n_overflow_inexact"] == 0, c
+    assert (len_o == o.capp).sum() >= 10 and c["n_pyramid_full"] > 100, ((len_o == o.capp).sum(), c)
+    assert np.array_equal(len_o, m.pyramid_counts())
+    vo, so, ro = o.export_sparse()
+    vg, sg, rg = gpu_state(m)
+    assert len(vo) == len(vg) == n_in - c["n_out_of_map"] - c["n_pyramid_full"] - c["n_voxel_full"]
+    ko, kg = np.lexsort((so, vo)), np.lexsort((sg, vg))
+    assert np.array_equal(vo[ko], vg[kg]) and np.array_equal(so[ko], sg[kg])      # the same particles in the SAME SLOTS
+    for col in (1, 2, 4, 5, 6, 7):
+        assert np.array_equal(ro[ko][:, col], rg[kg][:, col]), col
+    # the weight update writes through the re-pointed list entries: weights against the oracle after mapUpdate
+    o.map_update(); m.map_update()
+    vo, so, ro = o.export_sparse()
+    vg, sg, rg = gpu_state(m)
+    ko, kg = np.lexsort((so, vo)), np.lexsort((sg, vg))
+    assert np.array_equal(vo[ko], vg[kg]) and np.array_equal(so[ko], sg[kg])
+    assert np.allclose(ro[ko][:, 7], rg[kg][:, 7], rtol=1e-4, atol=1e-9)
+    o.close(); m.close()
