@@ -157,7 +157,7 @@ static void free_dev(dspmap* m) {
     if (m->mgpu_count) chk(hipFree(m->mgpu_count), "hipFree");
     void* ptrs[] = {s.fpar, s.obs_ckf, s.part_inv, s.fut_stat, s.mask, s.nbmask, s.pos, s.vel, s.w, s.vz0, s.res4, s.fut, s.fut_out, s.obs, s.obs_ck,
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
-                    s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, s.fov_rec, s.fov_slot, s.fov_key, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt, s.in_n, s.pmask, s.ta, s.dflag, s.dirty,
+                    s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, s.fov_rec, s.fov_slot, s.fov_key, s.fov_spos, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt, s.in_n, s.pmask, s.ta, s.dflag, s.dirty,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.ro_cnt, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
                     m->k.part_predict, m->k.part_claim, m->k.tile_fov, s.tile_live, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
@@ -331,6 +331,7 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&s.fov_rec, (size_t)d.np * d.capa));
     HIPCHK(m, dalloc(&s.fov_slot, (size_t)d.np * d.capa));
     HIPCHK(m, dalloc(&s.fov_key, (size_t)d.np * d.capa));
+    HIPCHK(m, dalloc(&s.fov_spos, (size_t)d.np * d.capa));
     HIPCHK(m, dalloc(&s.fov_rec_s, (size_t)d.np * d.capp));
     HIPCHK(m, dalloc(&s.fov_slot_s, (size_t)d.np * d.capp));
     HIPCHK(m, dalloc(&s.pyr_cnt, (size_t)d.np));

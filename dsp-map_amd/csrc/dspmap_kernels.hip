@@ -265,6 +265,7 @@ __device__ __forceinline__ void pyr_sort_block(const MapDims& d, const DevState&
         const int pos = s_base[k] + atomicAdd(&s_hist[k], 1);
         s.fov_rec_s[(size_t)b * d.capp + pos] = r;
         s.fov_slot_s[(size_t)b * d.capp + pos] = sl_i;
+        s.fov_spos[(size_t)b * d.capa + i] = pos;   // (k_place_fix re-points the entries of particles it moves)
     }
 }
 __device__ __forceinline__ void pyr_items_block(const MapDims& d, const DevState& s, int* __restrict__ ck_items, int* __restrict__ wu_items,
@@ -305,7 +306,7 @@ __device__ __forceinline__ int first_free(const u64* occ, int mw, int slots) {
     return -1;
 }
 __device__ __forceinline__ void place_fix_wave(const MapDims& d, const DevState& s, const float4* __restrict__ in_rec, const u64* __restrict__ omask,
-                                               const int lv, int* s_key, int* s_idx, int* s_s1, int* s_s2) {
+                                               const int* __restrict__ refs, const int lv, int* s_key, int* s_idx, int* s_s1, int* s_s2) {
     const int l = lane_id();
     const int tile = lv >> 6, cap = 64 * d.slots;
     const int n = min(s.in_n[tile], cap);
@@ -421,26 +422,17 @@ __device__ __forceinline__ void place_fix_wave(const MapDims& d, const DevState&
             const u64 c = wave_or_u64(clr[e]), st = wave_or_u64(setb[e]);
             if (l == 0 && (c | st)) s.mask[(size_t)lv * d.mw + e] = (s.mask[(size_t)lv * d.mw + e] & ~c) | st;   // (arrivals live in `mask`; this wave owns the voxel now)
         }
-        // the moved arrivals' entries in their pyramids' sorted lists
-        const float* __restrict__ gph = s.planes_h;
-        const float* __restrict__ gpv = s.planes_v;
-        for (int a = 0; a < m; ++a) {
-            const int s1 = s_s1[a], s2 = s_s2[a];
-            if (!(s1 >= 0 && s2 >= 0 && s1 != s2)) continue;   // (uniform: LDS values)
-            const size_t didx = tcell + (size_t)s2 * 64 + ln;
-            const P3 p = ld_pos(s, didx);
-            const int pyr = pyramid_of(d, gph, gpv, p.x, p.y, p.z);
-            if (pyr < 0) continue;
-            const int old_cell = (int)(tcell + (size_t)s1 * 64 + ln);
-            const int P = min(s.pyr_cnt[pyr], d.capp), P_all = min(s.pyr_cnt[pyr], d.capa);
-            for (int q0 = 0; q0 < P; q0 += 64) {
-                const int q = q0 + l;
-                if (q < P && s.fov_slot_s[(size_t)pyr * d.capp + q] == old_cell) s.fov_slot_s[(size_t)pyr * d.capp + q] = (int)didx;
-            }
-            for (int q0 = 0; q0 < P_all; q0 += 64) {   // (the unsorted list too: a later preparation of the same lists starts from it)
-                const int q = q0 + l;
-                if (q < P_all && s.fov_slot[(size_t)pyr * d.capa + q] == old_cell && s.fov_key[(size_t)pyr * d.capa + q] != 0x7fffffff)
-                    s.fov_slot[(size_t)pyr * d.capa + q] = (int)didx;
+        // the moved arrivals' entries in their pyramids' lists (k_place noted the entry beside the inbox record; the range sort
+        // noted where it put it)
+        for (int j = 0; j < 2; ++j) {
+            if (mvd[j]) {
+                const int ref = refs[(size_t)tile * cap * 8 + cap + s_idx[l + 64 * j]];
+                if (ref >= 0 && s.fov_key[ref] != 0x7fffffff) {
+                    const int didx = (int)(tcell + (size_t)to[j] * 64 + ln);
+                    s.fov_slot[ref] = didx;
+                    const int b = ref / d.capa, sp = s.fov_spos[ref];
+                    if (sp >= 0 && sp < d.capp) s.fov_slot_s[(size_t)b * d.capp + sp] = didx;
+                }
             }
         }
     }
@@ -451,16 +443,21 @@ __device__ __forceinline__ void place_fix_wave(const MapDims& d, const DevState&
     }
 }
 // the pass as a workgroup function: wave w of workgroup g (of ng) takes the dirty voxels w + 4 g, + 4 ng, ...
+// lds: 4 x 4 x PF_MAXA ints (the caller's dynamic LDS)
+#define PF_LDS_BYTES (4 * 4 * PF_MAXA * 4)
 __device__ __forceinline__ void place_fix_block(const MapDims& d, const DevState& s, const float4* __restrict__ in_rec, const u64* __restrict__ omask,
-                                                int g, int ng) {
-    __shared__ int s_key[4][PF_MAXA], s_idx[4][PF_MAXA], s_s1[4][PF_MAXA], s_s2[4][PF_MAXA];
+                                                const int* __restrict__ refs, int* lds, int g, int ng) {
     const int nd = min(s.fs->n_dirty, DSP_DIRTY_CAP);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    for (int q = g * 4 + w; q < nd; q += ng * 4) place_fix_wave(d, s, in_rec, omask, s.dirty[q], s_key[w], s_idx[w], s_s1[w], s_s2[w]);
+    int* mine = lds + w * 4 * PF_MAXA;
+    for (int q = g * 4 + w; q < nd; q += ng * 4)
+        place_fix_wave(d, s, in_rec, omask, refs, s.dirty[q], mine, mine + PF_MAXA, mine + 2 * PF_MAXA, mine + 3 * PF_MAXA);
 }
-#define PF_WG 32   // workgroups of the pass (the first ones of k_ck_partial's launch in a frame)
-__global__ void __launch_bounds__(256) k_place_fix(MapDims d, DevState s, const float4* __restrict__ in_rec, const u64* __restrict__ omask) {
-    place_fix_block(d, s, in_rec, omask, (int)blockIdx.x, (int)gridDim.x);
+#define PF_WG 128   // workgroups of the pass (the first ones of k_ck_partial's launch in a frame): one dirty voxel per wave
+__global__ void __launch_bounds__(256) k_place_fix(MapDims d, DevState s, const float4* __restrict__ in_rec, const u64* __restrict__ omask,
+                                                   const int* __restrict__ refs) {
+    extern __shared__ int s_pf[];
+    place_fix_block(d, s, in_rec, omask, refs, s_pf, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // --------------------------------------------------------------------------
@@ -568,12 +565,12 @@ __device__ __forceinline__ void neighbor_load(const MapDims& d, const int* __res
 
 __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, FilterParams fp, const int* __restrict__ items,
                                                        const int* __restrict__ n_items, const int* __restrict__ nb_tab,
-                                                       const float4* __restrict__ in_rec, const u64* __restrict__ omask) {
+                                                       const float4* __restrict__ in_rec, const u64* __restrict__ omask, const int* __restrict__ refs) {
     // the first PF_WG workgroups re-slot the arrivals of the voxels in which a full pyramid list turned a particle away
     // (k_place_fix: nothing to do in most frames); the pair items do not depend on it
-    if ((int)blockIdx.x < PF_WG) { place_fix_block(d, s, in_rec, omask, (int)blockIdx.x, PF_WG); return; }
-    const int BX = (int)blockIdx.x - PF_WG, GX = (int)gridDim.x - PF_WG;
-    extern __shared__ float4 s_z[];   // [nbins * DSP_OBS_CAP] the neighbourhood's observations within range of the chunk ...
+    extern __shared__ float4 s_z[];
+    if ((int)blockIdx.x < PF_WG) { place_fix_block(d, s, in_rec, omask, refs, reinterpret_cast<int*>(s_z), (int)blockIdx.x, PF_WG); return; }
+    const int BX = (int)blockIdx.x - PF_WG, GX = (int)gridDim.x - PF_WG;   // [nbins * DSP_OBS_CAP] the neighbourhood's observations within range of the chunk ...
     int* s_oi = reinterpret_cast<int*>(s_z + (size_t)d.nbins * DSP_OBS_CAP);   // ... and their global indices
     __shared__ float4 s_p[CK_PCH];
     __shared__ int s_bin[DSP_MAX_NBINS];
@@ -1199,7 +1196,7 @@ void launch_obs_bin(const LaunchCtx& c, int n_pts_grid) {
 // map corner farther than 12 cull radii: most pairs are far (28 % at 8 radii, 72 % at 16, measured) -> k_weight<true>
 static bool weight_culls(const LaunchCtx& c) { return (float)PS_NBK / c.d.rng_inv_bw > 12.f * c.fp.cull_r; }
 void launch_place_fix(const LaunchCtx& c) {   // stage API: after launch_pyr_prepare (a frame's k_ck_partial launch carries the pass)
-    hipLaunchKernelGGL(k_place_fix, dim3(PF_WG), dim3(256), 0, c.stream, c.d, c.s, c.k.in_rec, c.k.omask);
+    hipLaunchKernelGGL(k_place_fix, dim3(PF_WG), dim3(256), PF_LDS_BYTES, c.stream, c.d, c.s, c.k.in_rec, c.k.omask, reinterpret_cast<const int*>(c.k.mv_rec));
 }
 void launch_pyr_prepare(const LaunchCtx& c) {
     hipLaunchKernelGGL(k_pyr_prepare, dim3(c.d.np + 1), dim3(1024), 0, c.stream, c.d, c.s, c.k.ck_items, c.k.wu_items, c.k.n_items, c.k.nb_tab);
@@ -1207,7 +1204,7 @@ void launch_pyr_prepare(const LaunchCtx& c) {
 void launch_ck_partial(const LaunchCtx& c, bool prepared) {
     if (!prepared) hipLaunchKernelGGL(k_pyr_prepare, dim3(c.d.np + 1), dim3(1024), 0, c.stream, c.d, c.s, c.k.ck_items, c.k.wu_items, c.k.n_items, c.k.nb_tab);
     hipLaunchKernelGGL(k_ck_partial, dim3(4096 + PF_WG), dim3(CK_TPB), (sizeof(float4) + sizeof(int)) * (size_t)c.d.nbins * DSP_OBS_CAP, c.stream, c.d, c.s, c.fp, c.k.ck_items, c.k.n_items, c.k.nb_tab,
-                       c.k.in_rec, c.k.omask);
+                       c.k.in_rec, c.k.omask, reinterpret_cast<const int*>(c.k.mv_rec));
 }
 void launch_ck_finalize(const LaunchCtx& c) {  // after launch_weight_update: reduces the per-pyramid 1/Ck sums
     hipLaunchKernelGGL(k_ck_sum, dim3(1), dim3(512), 0, c.stream, c.d, c.s, c.fp);

@@ -752,17 +752,20 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
         batch_append<1>(s.pyr_cnt, key, pos);
         if (nsl >= 0) {
             bool keep = true;
+            int ref = -1;
             if (key[0] >= 0) {
                 if (pos[0] < d.capa) {
                     const size_t o = (size_t)key[0] * d.capa + pos[0];
                     s.fov_rec[o] = make_float4(px, py, pz, w);
                     s.fov_slot[o] = (int)nidx;
                     s.fov_key[o] = skey;   // a mover is registered when the sweep reaches its SOURCE cell
+                    ref = (int)o;
                 } else {
                     ++c_pf;  // :1256-1259
                     keep = false;
                 }
             }
+            gbk[cap + i] = ref;   // the arrival's list entry, beside its inbox record (k_place_fix re-points it if the arrival is moved)
             if (keep) atomicOr(&s_new[(nsl >> 6) * 64 + ln], 1ull << (nsl & 63));
         }
     }

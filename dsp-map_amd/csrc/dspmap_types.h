@@ -165,6 +165,7 @@ struct DevState {
     // FOV staging
     float4* fov_rec;   // [np*capa] {x,y,z,w}
     int* fov_slot;     // [np*capa] cell index of the particle (pidx)
+    int* fov_spos;     // [np*capa] where the range sort put the entry (index into fov_rec_s / fov_slot_s of its pyramid), -1 = not kept
     int* fov_key;      // [np*capa] its sweep key (source voxel * slots + slot): the reference registers a pyramid's particles in this order
     float4* fov_rec_s; // the same lists ordered by range bucket (k_pyr_sort), read by the pair kernels
     int* fov_slot_s;
