@@ -36,6 +36,9 @@ WORKLOADS = {
     "E_sat": dict(nx=264, ny=264, nz=80, res=0.10, ppv=36, sat=True),
     # one rank's share of E_sat on 8 GPUs (10 of the 80 layers) as a stand-alone map: driver-overhead studies
     "E8_sat": dict(nx=264, ny=264, nz=10, res=0.10, ppv=36, sat=True),
+    # config D (the 10-horizon rollout on C's saturated grid), static / moving fill, as workloads of their own for profiling
+    "D_sat": dict(nx=132, ny=132, nz=60, res=0.15, ppv=24, sat=True, pred_times=tuple(0.2 * (k + 1) for k in range(10))),
+    "D_mov": dict(nx=132, ny=132, nz=60, res=0.15, ppv=24, sat=True, pred_times=tuple(0.2 * (k + 1) for k in range(10)), vmax=1.0),
 }
 REC = 32  # bytes of one live particle record in SURVEY 8(d)'s accounting
 COUNTER_KEYS = ("n_live_in", "n_fov", "n_born", "n_obs", "n_moved", "n_out_of_map", "n_voxel_full", "n_pyramid_full", "n_live_out")

@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdlib>
+#include <climits>
+#include <cmath>
 #include <cstring>
 #include "dspmap_device.h"
 #include "dspmap_kernels.h"
@@ -1307,62 +1309,84 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
 //     atomic costs a memory transaction per lane, ~25 G/s device-wide; a row of 64 neighbouring voxels costs two).
 //     Destinations outside the window take the single-atomic path.
 // --------------------------------------------------------------------------
-#define RO_WIN 8192
-#define RO_HALF ((RO_WIN - 64) / 2)
-#define RO_DENSE 192    // moving particles in a tile from which the LDS window pays
-__global__ void __launch_bounds__(256) k_rollout(MapDims d, DevState s, const float4* __restrict__ ro_rec, const int* __restrict__ ro_cnt) {
-    __shared__ float s_win[RO_WIN];
-    __shared__ int s_lohi[2];
-    const int BX = (int)blockIdx.x;
-    const int cnt = ro_cnt[BX];
-    if (cnt == 0) return;
+#define RO_G 8           // tiles per workgroup: their particles share the LDS windows
+#define RO_DENSE 384     // moving particles in a GROUP of tiles from which the LDS windows pay
+#define RO_TPB 1024
+#define RO_LDS_CELLS 30000   // fp32 cells of all windows together (120 kB: one workgroup per CU)
+struct RolloutPlan {
+    int halo[DSP_MAX_PRED];      // rows of the grid a horizon's window reaches beyond the group's voxels, either side
+    int woff[DSP_MAX_PRED + 1];  // first cell of every horizon's window in the workgroup's LDS
+};
+__global__ void __launch_bounds__(RO_TPB) k_rollout(MapDims d, DevState s, const float4* __restrict__ ro_rec, const int* __restrict__ ro_cnt, int ntiles,
+                                                    RolloutPlan pl) {
+    // One workgroup per group of RO_G consecutive tiles (512 voxels: a few rows of a layer).  EVERY particle is read once and
+    // adds its weight to its future voxel at all T horizons (reading the particles once per horizon was what bound this kernel
+    // with every particle moving: 10 x 0.5 GB at 132x132x60).  Horizon t has its own LDS window over the voxel-index range the
+    // group's particles reach at a design speed -- halo[t] rows of the grid either side -- so that the footprints of the group's
+    // tiles, which overlap almost completely, cost ONE global atomic per touched cell and horizon; faster particles fall outside
+    // and take the single-atomic path.  Windows are flushed with coalesced atomics onto the horizon-major accumulators.
+    extern __shared__ float s_win[];
+    __shared__ int s_cnt[RO_G + 1];
+    const int G0 = (int)blockIdx.x * RO_G;
+    const int ng = min(RO_G, ntiles - G0);
     const int tid = threadIdx.x;
+    if (tid < RO_G) s_cnt[tid] = tid < ng ? ro_cnt[G0 + tid] : 0;
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int k = 0; k < RO_G; ++k) { const int c = s_cnt[k]; s_cnt[k] = t; t += c; } s_cnt[RO_G] = t; }   // exclusive prefix
+    __syncthreads();
+    const int total = s_cnt[RO_G];
+    if (total == 0) return;
     const int T = d.T;
     const int zc = d.ny * d.nx;
-    const size_t base = (size_t)BX * 64 * d.slots;
+    const int cap = 64 * d.slots;
     const size_t V = (size_t)d.v_loc;
-    auto future_voxel = [&](const float4& a, int lv, float pt) -> int {   // local index of the voxel at horizon pt, or -1
-        const float fx = a.x + a.z * pt;      // :954-955
-        const float fy = a.y + a.w * pt;
-        if (fx >= d.half_x || fx <= -d.half_x || fy >= d.half_y || fy <= -d.half_y) return -1;
-        const int xi = (int)div_res(d, fx + d.half_x);
-        const int yi = (int)div_res(d, fy + d.half_y);
-        const int gz = (lv + d.v_base) / zc;  // the layer never changes (vz == 0; pz itself is inside the map)
-        const int dl = gz * zc + yi * d.nx + xi - d.v_base;
-        return (dl >= 0 && dl < d.v_loc) ? dl : -1;
+    // particle `it` of the group -> its record
+    auto rec_of = [&](int it, float4& a, float4& b) {
+        int g = 0;
+#pragma unroll
+        for (int k = 1; k < RO_G; ++k) g += it >= s_cnt[k] ? 1 : 0;
+        const size_t o = ((size_t)(G0 + g) * cap + (it - s_cnt[g])) * 2;
+        a = ro_rec[o]; b = ro_rec[o + 1];
     };
-    if (cnt < RO_DENSE) {
-        for (int i = tid; i < cnt * T; i += 256) {
-            const int q = i / T, t = i - q * T;
-            const float4 a = ro_rec[(base + q) * 2], b = ro_rec[(base + q) * 2 + 1];
-            const int dl = future_voxel(a, __float_as_int(b.y), d.pred_t[t]);
-            if (dl >= 0) unsafeAtomicAdd(&s.fut[(size_t)t * V + dl], b.x);
+    const bool dense = total >= RO_DENSE;
+    const int ncell = pl.woff[T];
+    if (dense) for (int i = tid; i < ncell; i += RO_TPB) s_win[i] = 0.f;
+    __syncthreads();
+    for (int it0 = tid; it0 < total; it0 += RO_TPB * 3) {   // three particles per step: their records are requested together
+        float4 a[3], b[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            a[u] = make_float4(0.f, 0.f, 0.f, 0.f); b[u] = a[u];
+            if (it0 + u * RO_TPB < total) rec_of(it0 + u * RO_TPB, a[u], b[u]);
         }
-        return;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            if (it0 + u * RO_TPB >= total) continue;
+            const int lbase = ((__float_as_int(b[u].y) + d.v_base) / zc) * zc - d.v_base;   // voxel (x 0, y 0) of the particle's layer: it never changes (vz == 0)
+            for (int t = 0; t < T; ++t) {
+                const float pt = d.pred_t[t];
+                const float fx = a[u].x + a[u].z * pt;      // :954-955
+                const float fy = a[u].y + a[u].w * pt;
+                if (fabsf(fx) >= d.half_x || fabsf(fy) >= d.half_y) continue;
+                const int xi = (int)div_res(d, fx + d.half_x);
+                const int yi = (int)div_res(d, fy + d.half_y);
+                const int dl = lbase + (int)__umul24((unsigned)yi, (unsigned)d.nx) + xi;
+                if (dl < 0 || dl >= d.v_loc) continue;
+                const int off = dl - (G0 * 64 - pl.halo[t] * d.nx);
+                if (dense && off >= 0 && off < pl.woff[t + 1] - pl.woff[t]) atomicAdd(&s_win[pl.woff[t] + off], b[u].x);
+                else unsafeAtomicAdd(&s.fut[(size_t)t * V + dl], b[u].x);
+            }
+        }
     }
-    const int win_lo = BX * 64 - RO_HALF;   // local voxel index of window cell 0
-    for (int i = tid; i < RO_WIN; i += 256) s_win[i] = 0.f;
+    if (!dense) return;
+    __syncthreads();
     for (int t = 0; t < T; ++t) {
-        if (tid == 0) { s_lohi[0] = RO_WIN; s_lohi[1] = -1; }
-        __syncthreads();
-        const float pt = d.pred_t[t];
-        int lo = RO_WIN, hi = -1;
-        for (int q = tid; q < cnt; q += 256) {
-            const float4 a = ro_rec[(base + q) * 2], b = ro_rec[(base + q) * 2 + 1];
-            const int dl = future_voxel(a, __float_as_int(b.y), pt);
-            if (dl < 0) continue;
-            const int off = dl - win_lo;
-            if (off >= 0 && off < RO_WIN) { atomicAdd(&s_win[off], b.x); lo = min(lo, off); hi = max(hi, off); }
-            else unsafeAtomicAdd(&s.fut[(size_t)t * V + dl], b.x);
+        const int w0 = pl.woff[t], wn = pl.woff[t + 1] - w0;
+        const int g0 = G0 * 64 - pl.halo[t] * d.nx;   // local voxel index of the window's first cell (cells outside the slab stay zero)
+        for (int i = tid; i < wn; i += RO_TPB) {
+            const float v = s_win[w0 + i];
+            if (v != 0.f) unsafeAtomicAdd(&s.fut[(size_t)t * V + g0 + i], v);
         }
-        if (hi >= 0) { atomicMin(&s_lohi[0], lo); atomicMax(&s_lohi[1], hi); }
-        __syncthreads();
-        const int f_lo = s_lohi[0] & ~63, f_hi = s_lohi[1];
-        for (int off = f_lo + tid; off <= f_hi; off += 256) {
-            const float v = s_win[off];
-            if (v != 0.f) { unsafeAtomicAdd(&s.fut[(size_t)t * V + win_lo + off], v); s_win[off] = 0.f; }
-        }
-        __syncthreads();
     }
 }
 
@@ -1803,7 +1827,31 @@ void launch_resample(const LaunchCtx& c) {
         hipLaunchKernelGGL(k_resample_wg, dim3(k->ntiles), dim3(256), lds4, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt);
     } else if (c.d.mw == 1) hipLaunchKernelGGL(k_resample<1>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt);
     else hipLaunchKernelGGL(k_resample<2>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt);
-    if (c.d.T > 0) hipLaunchKernelGGL(k_rollout, dim3(k->ntiles), dim3(256), 0, c.stream, c.d, c.s, k->ro_rec, k->ro_cnt);
+    if (c.d.T > 0) {
+        // windows: the rows a particle reaches at a design speed (1.5 m/s, a brisk pedestrian), lowered until all T windows fit the LDS
+        RolloutPlan pl;
+        float vdes = 1.5f;
+        for (;;) {
+            int tot = 0;
+            for (int t = 0; t < c.d.T; ++t) {
+                pl.halo[t] = (int)ceilf(vdes * fabsf(c.d.pred_t[t]) / c.d.res) + 1;
+                pl.woff[t] = tot;
+                tot += RO_G * 64 + 2 * pl.halo[t] * c.d.nx;
+            }
+            pl.woff[c.d.T] = tot;
+            if (tot <= RO_LDS_CELLS || vdes < 0.02f) break;
+            vdes *= 0.8f;
+        }
+        if (pl.woff[c.d.T] > RO_LDS_CELLS) {   // (a grid too wide even for one-row halos: every window collapses to the group itself)
+            int tot = 0;
+            for (int t = 0; t < c.d.T; ++t) { pl.halo[t] = 0; pl.woff[t] = tot; tot += RO_G * 64; }
+            pl.woff[c.d.T] = tot;
+        }
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_rollout, hipFuncAttributeMaxDynamicSharedMemorySize, RO_LDS_CELLS * 4); attr_set = true; }
+        hipLaunchKernelGGL(k_rollout, dim3((k->ntiles + RO_G - 1) / RO_G), dim3(RO_TPB), (size_t)pl.woff[c.d.T] * 4, c.stream, c.d, c.s, k->ro_rec, k->ro_cnt,
+                           k->ntiles, pl);
+    }
 }
 static void mark_all_live(const LaunchCtx& c) {   // particles were written outside a frame: every tile may hold some
     (void)hipMemsetAsync(c.s.tile_live, 1, sizeof(int) * (size_t)c.k.ntiles, c.stream);
