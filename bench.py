@@ -44,6 +44,29 @@ REC = 32  # bytes of one live particle record in SURVEY 8(d)'s accounting
 COUNTER_KEYS = ("n_live_in", "n_fov", "n_born", "n_obs", "n_moved", "n_out_of_map", "n_voxel_full", "n_pyramid_full", "n_live_out")
 
 
+def csrc_fingerprint():
+    """sha256 over the kernel sources (dsp-map_amd/csrc + include/dspmap.h): the PMC traffic figures committed under profiles/
+    carry the fingerprint of the sources they were measured on; bench.py prints them only while it still matches"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "dsp-map_amd", "csrc")
+    for fn in sorted(os.listdir(d)) + [os.path.join("..", "..", "include", "dspmap.h")]:
+        fp = os.path.join(d, fn)
+        if os.path.isfile(fp):
+            h.update(fn.encode()); h.update(open(fp, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def b_alg(c, V, T):
     """algorithmic bytes of one frame."""
     return 4 * REC * c["n_live_in"] + 36 * c["n_fov"] + REC * c["n_born"] + 40 * c["n_obs"] + \
@@ -80,7 +103,7 @@ FRAME_KERNELS = ("k_obs_points", "k_predict", "k_place", "k_pyr_prepare", "k_ck_
                  "k_birth_children")
 
 
-def roofline_block(stage_ms, cnt, V, T, mw, traffic_db, wl_name, peak=8000.0):
+def roofline_block(stage_ms, cnt, V, T, mw, traffic_db, wl_name, peak=8000.0, traffic_meta=None):
     """roofline of the dominant kernel + every kernel's fraction.  A kernel cannot beat the HBM peak on the bytes it has to
     move: a fraction above 1 means the accounting (or the timer) is wrong and is never printed."""
     timed = {k: v for k, v in stage_ms.items() if k not in ("setup+bin", "ck_finalize", "birth")}
@@ -101,9 +124,20 @@ def roofline_block(stage_ms, cnt, V, T, mw, traffic_db, wl_name, peak=8000.0):
             "unit": "GB/s", "frac": per[dom]["frac"], "traffic": tdb.get(name_of.get(dom, ""), {}).get("hbm_bytes"),
             "kernel_ms": per[dom]["ms"], "algorithmic_bytes": per[dom]["bytes"], "per_kernel": per}
     if tdb:
-        roof["traffic_source"] = ("profiles/pmc_traffic*.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
-                                  "corrected 2*FETCH+WRITE per the MI355X guide)")
+        meta = traffic_meta or {}
+        roof["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload "
+                                  "(corrected 2*FETCH+WRITE per the MI355X guide), measured at commit %s on the sources with "
+                                  "fingerprint %s = the sources of this run" % (meta.get("commit", "?"), meta.get("csrc_sha16", "?")))
         roof["traffic_frame"] = int(sum(v.get("hbm_bytes", 0) for k, v in tdb.items() if k in FRAME_KERNELS))
+        # beside the contract fraction (algorithmic bytes / 8 TB/s): the bytes the kernel really moved against what a float4
+        # copy sustains on this part (6.3 TB/s, MI355X guide)
+        for k, v in per.items():
+            pb = tdb.get(name_of.get(k, ""), {}).get("hbm_bytes")
+            if pb and v.get("ms"):
+                v["pmc_bytes"] = int(pb)
+                v["frac_of_6.3TBps_on_pmc_bytes"] = round(pb / (v["ms"] * 1e-3) / 1e9 / 6300.0, 4)
+    elif traffic_meta and traffic_meta.get("stale"):
+        roof["traffic_source"] = traffic_meta["stale"]
     return roof
 
 
@@ -289,16 +323,21 @@ def main():
     balg = b_alg(cnt, V, T)
     ms = dt / args.steps * 1e3
     peak = 8000.0
-    traffic_db = {}
-    for fn in ("pmc_traffic.json", "pmc_traffic_r01.json"):   # HBM bytes per launch from the committed PMC passes of the same commands
-        try:
-            traffic_db = json.load(open(os.path.join(ROOT, "profiles", fn)))["workloads"]
-            break
-        except Exception:
-            pass
+    traffic_db, traffic_meta = {}, {}
+    try:   # HBM bytes per launch from the committed PMC passes of the same commands -- only if measured on THESE sources
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        fp_now = csrc_fingerprint()
+        if tj.get("csrc_sha16") == fp_now:
+            traffic_db = tj["workloads"]
+            traffic_meta = {"commit": tj.get("commit"), "csrc_sha16": fp_now}
+        else:
+            traffic_meta = {"stale": "profiles/pmc_traffic.json was measured on other kernel sources (fingerprint %s, commit %s; this "
+                                     "run: %s): traffic not reported" % (tj.get("csrc_sha16"), tj.get("commit"), fp_now)}
+    except Exception:
+        pass
     mw = (2 * wl["ppv"] + 63) // 64
     if stage is not None:
-        roof = roofline_block(stage, cnt, V, T, mw, traffic_db, wl_name, peak)
+        roof = roofline_block(stage, cnt, V, T, mw, traffic_db, wl_name, peak, traffic_meta)
         if V < 500_000:   # the metric's own size: the frame is a chain of dependent launches of 5-35 us, none of them bandwidth-bound
             roof["note"] = ("at this map size every kernel is a latency chain (one wave per SIMD, ~0.2 TB/s for the whole frame); "
                             "the HBM-bound case is saturated_132x132x60 in this same line")
@@ -307,7 +346,10 @@ def main():
                 "peak": peak * world, "unit": "GB/s", "frac": round(balg / (ms * 1e-3) / 1e9 / (peak * world), 6),
                 "traffic": None, "algorithmic_bytes": int(balg)}
     result = {
-        "metric": "map update() frames/sec @ 66x66x40, 24 particles/voxel; achieved HBM GB/s",
+        "metric": ("map update() frames/sec @ 66x66x40, 24 particles/voxel; achieved HBM GB/s" if wl_name == "B" else
+                   "map update() frames/sec @ %dx%dx%d, %d particles/voxel (workload %s, NOT the 66x66x40 headline); achieved HBM GB/s"
+                   % (wl["nx"], wl["ny"], wl["nz"], wl["ppv"], wl_name)),
+        "workload_id": wl_name,
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 5), "higher_is_better": True, "scaling": "weak" if not sharded_run else "strong",
         "vs_baseline": None,
@@ -345,7 +387,7 @@ def main():
                 "frames_per_s": round(40 / dt2, 2), "ms_per_step": round(ms2, 4),
                 "b_alg_bytes": int(b2), "b_alg_GBps": round(b2 / (ms2 * 1e-3) / 1e9, 2),
                 "frac_of_8TBps": round(b2 / (ms2 * 1e-3) / 1e9 / peak, 5),
-                "roofline": roofline_block(st2, c2, V2, T2, 1, traffic_db, "C_sat", peak),
+                "roofline": roofline_block(st2, c2, V2, T2, 1, traffic_db, "C_sat", peak, traffic_meta),
                 "stage_ms": {k: round(v, 5) for k, v in st2.items()},
                 "counters": {k: c2[k] for k in COUNTER_KEYS}}
             m2.close()
@@ -531,7 +573,8 @@ def main():
                 if t_acc > 25.0:
                     break
             result["cpu_baseline"] = {
-                "value": round(n_acc / t_acc, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                "value": round(n_acc / t_acc, 3), "unit": "frames/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
+                "host_cores_available": os.cpu_count(),
                 "sample": "oracle/dsp_oracle.c (reference-faithful dense AoS restatement, reference flags "
                           "-O3 -ffast-math -march=native, 1 thread) on frames 30..%d of the same stream" % (29 + n_acc),
                 "ms_per_frame": round(t_acc / n_acc * 1e3, 2)}

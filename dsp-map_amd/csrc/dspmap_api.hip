@@ -741,6 +741,34 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
 
 static int upload_birth(dspmap* m, const dspmap_vpoint* pts, int n);
 
+// The reference keeps ONE clusters_feature_vector_dynamic_last (a function static, :1401,1542).  Here the device estimator
+// (dspmap_velest.hip) and the host stage (velocity_estimator.cpp: clouds beyond the device estimator's capacity, or
+// DSPMAP_P_VELOCITY_ESTIMATOR = 1) each hold a copy: whenever a frame is about to run on the one that does not hold the
+// newer copy, the state is handed over first.
+static int ve_state_to_host(dspmap* m) {
+    if (m->ve_last_at != 2) return DSPMAP_OK;
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    int n3[4] = {0, 0, 0, 0};
+    HIPCHK(m, hipMemcpy(n3, m->ve.n, sizeof(n3), hipMemcpyDeviceToHost));
+    const int n = std::max(0, std::min(n3[2], m->ve.cap / 5 + 8));
+    std::vector<float> buf((size_t)n * 5 + 1);
+    if (n > 0) HIPCHK(m, hipMemcpy(buf.data(), m->ve.last, sizeof(float) * 5 * (size_t)n, hipMemcpyDeviceToHost));
+    m->vel.import_last(buf.data(), n);
+    m->ve_last_at = 1;
+    return DSPMAP_OK;
+}
+static int ve_state_to_device(dspmap* m) {
+    if (m->ve_last_at != 1) return DSPMAP_OK;
+    const int cap = m->ve.cap / 5 + 8;
+    std::vector<float> buf((size_t)cap * 5);
+    const int n = m->vel.export_last(buf.data(), cap);
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (n > 0) HIPCHK(m, hipMemcpy(m->ve.last, buf.data(), sizeof(float) * 5 * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHK(m, hipMemcpy(m->ve.n + 2, &n, sizeof(int), hipMemcpyHostToDevice));
+    m->ve_last_at = 2;
+    return DSPMAP_OK;
+}
+
 // One frame with the host stages in the loop (velocity estimator and/or a caller-supplied birth cloud): prediction and
 // the weight update are queued first, the host estimator runs while they execute (the reference forks
 // velocityEstimationThread before prediction and joins it before the birth stage, :297,311), then the tagged cloud is
@@ -770,7 +798,9 @@ static int frame_with_host_stages(dspmap* m, int np, const float* pts_dev, const
         std::vector<float> view;
         view.reserve((size_t)np * 3);
         m->vel.rotate_and_filter(m->pts_pin, np, q, view);
+        { const int rcs = ve_state_to_host(m); if (rcs != DSPMAP_OK) return rcs; }
         m->vel.run(view, m->cur_pos, dt, m->voxel_filter_res, m->h_birth);
+        m->ve_last_at = 1;
         m->h_birth_valid = true;
     }
     if (have_cloud) {
@@ -818,8 +848,11 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
         if (rc != DSPMAP_OK) return rc;
         HIPCHK(m, hipEventRecord(m->ev_fork, m->stream));
         dspmap_prof_collect(m);
+        rc = ve_state_to_host(m);   // (the device estimator may hold the previous frame's clusters)
+        if (rc != DSPMAP_OK) return rc;
         return frame_with_host_stages(m, n_points, points_dev, q, dp, dt, m->ev_fork);
     }
+    if (est_dev) { rc = ve_state_to_device(m); if (rc != DSPMAP_OK) return rc; m->ve_last_at = 2; }
     LaunchCtx c = dspmap_ctx_of(m);
     const bool has_vz = m->vz_frames > 0;
     if (!has_vz) c.s.vz0 = nullptr;

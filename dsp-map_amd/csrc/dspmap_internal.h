@@ -30,6 +30,7 @@ struct dspmap {
     float voxel_filter_res = 0.15f;          // :132
     int use_vel_est = 0;             // DSPMAP_P_VELOCITY_ESTIMATOR: 0 off, 1 host stage (velocity_estimator.cpp), 2 device (dspmap_velest.hip)
     VelEst ve = {};
+    int ve_last_at = 0;              // where clusters_feature_vector_dynamic_last (:1401) lives: 0 nowhere yet, 1 host estimator, 2 device
     bool regen_tables = false;
     bool div_forced_off = false;     // DSPMAP_P_FAST_DIVISION = 0
     bool nb_frozen = false;                  // function statics of the birth stage (:808-811)

@@ -67,7 +67,7 @@ extern "C" int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_
     launch_setup_and_bin(c, n_points, false);
     // + gather + (static tags) the birth rank; k_place follows the exchange: imported movers take part in the sweep-order placement
     launch_predict_only(c, true, nb > 0 && mode != 2);
-    if (mode == 2 && nb > 0) launch_velocity_estimator(c, true);   // ... with the estimator the rank rides on k_ve_clusters
+    if (mode == 2 && nb > 0) { launch_velocity_estimator(c, true); m->ve_last_at = 2; }   // ... with the estimator the rank rides on k_ve_clusters
     m->mgpu_all_static = mode == 1;
     m->mgpu_place_pending = true;
     m->mgpu_interior_done = false;

@@ -267,3 +267,21 @@ void VelocityEstimator::run(const std::vector<float>& view, const float cur[3], 
     }
     last_ = dyn;  // :1542
 }
+
+int VelocityEstimator::export_last(float* out5, int cap) const {
+    const int n = std::min((int)last_.size(), cap);
+    for (int i = 0; i < n; ++i) {
+        out5[i * 5] = last_[i].cx; out5[i * 5 + 1] = last_[i].cy; out5[i * 5 + 2] = last_[i].cz;
+        memcpy(&out5[i * 5 + 3], &last_[i].point_num, sizeof(int));
+        out5[i * 5 + 4] = last_[i].intensity;
+    }
+    return n;
+}
+void VelocityEstimator::import_last(const float* in5, int n) {
+    last_.assign((size_t)std::max(n, 0), Cluster());
+    for (int i = 0; i < n; ++i) {
+        last_[i].cx = in5[i * 5]; last_[i].cy = in5[i * 5 + 1]; last_[i].cz = in5[i * 5 + 2];
+        memcpy(&last_[i].point_num, &in5[i * 5 + 3], sizeof(int));
+        last_[i].intensity = in5[i * 5 + 4];
+    }
+}

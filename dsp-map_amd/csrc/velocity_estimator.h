@@ -19,6 +19,11 @@ public:
     // velocityEstimationThread :1377-1544; `out` keeps its previous content when `view` is empty (:1379)
     void run(const std::vector<float>& view, const float cur_pos[3], float dt, float voxel_filtered_resolution,
              std::vector<dspmap_vpoint>& out);
+    // clusters_feature_vector_dynamic_last (:1401,1542) as 5 floats per cluster {cx, cy, cz, point_num (int bits), intensity}: the
+    // layout of the device estimator's copy (VelEst::last) -- the two implementations hand the state to each other when a frame
+    // has to switch between them, so that there is ONE `last` like the reference's function static
+    int export_last(float* out5, int cap) const;
+    void import_last(const float* in5, int n);
     const float* planes_h() const { return ph_.data(); }
     const float* planes_v() const { return pv_.data(); }
 

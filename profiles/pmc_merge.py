@@ -58,7 +58,45 @@ def main(tag):
                "| kernel | FETCH_SIZE KB | WRITE_SIZE KB | corrected HBM bytes / launch |", "|---|---|---|---|"]
         for k, v in out["workloads"][w].items():
             md.append("| %s | %.1f | %.1f | %s |" % (k, v["fetch_kb"], v["write_kb"], format(v["hbm_bytes"], ",")))
+    # the sources the passes ran on, and the commit that holds them
+    try:
+        out["csrc_sha16"] = open(os.path.join(g, tag + "_csrc_sha16.txt")).read().strip()
+    except OSError:
+        out["csrc_sha16"] = None
+    try:
+        import subprocess
+        out["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip()
+        sys.path.insert(0, ROOT)
+        import bench
+        if out["csrc_sha16"] != bench.csrc_fingerprint():
+            print("WARNING: the kernel sources changed since the PMC passes (%s vs %s): bench.py will not print this traffic"
+                  % (out["csrc_sha16"], bench.csrc_fingerprint()))
+    except Exception as e:  # noqa: BLE001
+        out["commit"] = None
+        print("commit not recorded:", e)
+    out["tag"] = tag
     json.dump(out, open(os.path.join(HERE, "pmc_traffic.json"), "w"), indent=1)
+    # issue-slot picture (SQ counters)
+    sq = ["# %s -- issue slots of the frame's kernels (SQ counters)\n" % tag,
+          "`rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU "
+          "SQ_INSTS_SALU --kernel-trace` on the bench commands of the PMC passes; averages per dispatch, summed over the device. "
+          "SQ_WAVE_CYCLES / SQ_WAIT_ANY / SQ_ACTIVE_INST_* count in units of 4 cycles. `VALU issue` = 4 x SQ_ACTIVE_INST_VALU / "
+          "(SQ_BUSY_CYCLES / 32 shader engines x 1024 SIMDs): the share of all VALU issue slots of the chip the kernel used while it "
+          "ran; `waiting` = SQ_WAIT_ANY / SQ_WAVE_CYCLES: the share of its waves' lifetime spent in s_waitcnt / barriers.\n"]
+    for w in ("B", "C_sat"):
+        try:
+            js = json.load(open(os.path.join(g, "%s_sq_%s.json" % (tag, w))))
+        except OSError:
+            continue
+        sq += ["\n## workload %s\n" % w, "| kernel | waves | VALU inst / wave | SALU inst / wave | VALU issue | waiting |", "|---|---|---|---|---|---|"]
+        for k, v in sorted(js.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", {}).get("avg", 0)):
+            a = {c: v.get(c, {}).get("avg", 0.0) for c in ("SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU")}
+            if a["SQ_WAVES"] <= 0 or a["SQ_BUSY_CYCLES"] <= 0:
+                continue
+            sq.append("| %s | %d | %.0f | %.0f | %.2f | %.2f |" % (base(k), a["SQ_WAVES"], a["SQ_INSTS_VALU"] / a["SQ_WAVES"], a["SQ_INSTS_SALU"] / a["SQ_WAVES"],
+                                                                4.0 * a["SQ_ACTIVE_INST_VALU"] / (a["SQ_BUSY_CYCLES"] / 32.0 * 1024.0),
+                                                                a["SQ_WAIT_ANY"] / max(a["SQ_WAVE_CYCLES"], 1.0)))
+    open(os.path.join(HERE, tag + "_sq_issue.md"), "w").write("\n".join(sq) + "\n")
     open(os.path.join(HERE, tag + "_pmc_traffic.md"), "w").write("\n".join(md) + "\n")
     buf = io.StringIO()
     with redirect_stdout(buf):

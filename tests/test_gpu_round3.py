@@ -314,3 +314,42 @@ def test_turned_away_movers_hand_their_slot_back_at_once(dsp, orc, ppv, n, seed)
     assert np.array_equal(vo[ko], vg[kg]) and np.array_equal(so[ko], sg[kg])
     assert np.allclose(ro[ko][:, 7], rg[kg][:, 7], rtol=1e-4, atol=1e-9)
     o.close(); m.close()
+
+
+def test_estimator_keeps_one_last_state_across_host_and_device(dsp):
+    """the reference matches every frame's clusters against ONE `clusters_feature_vector_dynamic_last` (a function static,
+    :1401,1542).  A cloud beyond the device estimator's capacity (6144 points) is clustered by the host stage: the two
+    implementations hand that state to each other, so a stream whose cloud sizes straddle the capacity gets the same
+    velocity tags as the host stage alone (frame 2 here is padded with ground points to 7000 points)"""
+    from tests.test_gpu_round2 import _cluster_scene
+    cfgkw = dict(nx=66, ny=66, nz=40, ppv=9)
+    maps = []
+    for mode in (2, 1):
+        m = dsp.DSPMap(dsp.make_config(**cfgkw))
+        m.set_tables(*common.tables(1))
+        m.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, mode)
+        maps.append(m)
+    rng = np.random.default_rng(0)
+    pos = (0.0, 0.0, 1.0)
+    for f in range(4):
+        t = f * 0.1
+        pts = _cluster_scene(t, f)
+        if f == 2:
+            pad = np.stack([rng.uniform(2.3, 3.4, 6400), rng.uniform(-1.6, 1.6, 6400), np.full(6400, -0.98)], 1).astype(np.float32)
+            pts = np.concatenate([pts, pad])
+            assert len(pts) > 6144
+        clouds = []
+        for m in maps:
+            assert m.update(pts, pos, t, (1, 0, 0, 0)) == 1
+            clouds.append(m.get_birth_cloud())
+            m.getOccupancyMapWithFutureStatus(0.2)
+        g, w = clouds
+        assert len(g) == len(w), f
+        for k in ("x", "y", "z", "nx", "ny", "nz"):
+            assert np.array_equal(g[k], w[k]), (f, k)
+        assert np.array_equal(g["intensity"] > 0.01, w["intensity"] > 0.01)
+        if f >= 1:
+            dyn = g["intensity"] > 0.01
+            assert np.isclose(g["ny"][dyn], 1.0, atol=0.02).sum() == 60, f      # cluster A keeps its 1 m/s through the switches
+    for m in maps:
+        m.close()
