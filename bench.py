@@ -99,8 +99,12 @@ def kernel_alg_bytes(stage, c, V, T, mw=1):
 
 
 FRAME_KERNELS = ("k_obs_points", "k_predict", "k_place", "k_pyr_prepare", "k_ck_partial", "k_weight", "k_birth_split_cksum",
-                 "k_birth_cursors", "k_birth_insert", "k_resample", "k_rollout", "k_ve_components", "k_ve_clusters",
+                 "k_birth_cursors", "k_birth_insert", "k_resample", "k_resample_wg", "k_rollout", "k_ve_components", "k_ve_clusters",
                  "k_birth_children")
+# the kernels behind each timed stage (the resampling stage runs the one-wave-per-tile kernel on large maps, the four-waves-per-tile
+# one on small ones, and the rollout of the moving particles behind either)
+STAGE_KERNELS = {"predict": ("k_predict",), "claim": ("k_place",), "ck_partial": ("k_ck_partial",), "weight": ("k_weight",),
+                 "resample": ("k_resample", "k_resample_wg", "k_rollout")}
 
 
 def roofline_block(stage_ms, cnt, V, T, mw, traffic_db, wl_name, peak=8000.0, traffic_meta=None):
@@ -120,8 +124,12 @@ def roofline_block(stage_ms, cnt, V, T, mw, traffic_db, wl_name, peak=8000.0, tr
     tdb = traffic_db.get(wl_name, {})
     name_of = {"claim": "k_place", "weight": "k_weight", "predict": "k_predict", "resample": "k_resample",
                "ck_partial": "k_ck_partial"}
+
+    def pmc_of(stage):
+        tot = sum(tdb.get(k, {}).get("hbm_bytes", 0) for k in STAGE_KERNELS.get(stage, ()))
+        return int(tot) if tot else None
     roof = {"bound": "hbm", "kernel": name_of.get(dom, "k_" + dom), "achieved": per[dom]["GBps"], "peak": peak,
-            "unit": "GB/s", "frac": per[dom]["frac"], "traffic": tdb.get(name_of.get(dom, ""), {}).get("hbm_bytes"),
+            "unit": "GB/s", "frac": per[dom]["frac"], "traffic": pmc_of(dom),
             "kernel_ms": per[dom]["ms"], "algorithmic_bytes": per[dom]["bytes"], "per_kernel": per}
     if tdb:
         meta = traffic_meta or {}
@@ -132,7 +140,7 @@ def roofline_block(stage_ms, cnt, V, T, mw, traffic_db, wl_name, peak=8000.0, tr
         # beside the contract fraction (algorithmic bytes / 8 TB/s): the bytes the kernel really moved against what a float4
         # copy sustains on this part (6.3 TB/s, MI355X guide)
         for k, v in per.items():
-            pb = tdb.get(name_of.get(k, ""), {}).get("hbm_bytes")
+            pb = pmc_of(k)
             if pb and v.get("ms"):
                 v["pmc_bytes"] = int(pb)
                 v["frac_of_6.3TBps_on_pmc_bytes"] = round(pb / (v["ms"] * 1e-3) / 1e9 / 6300.0, 4)

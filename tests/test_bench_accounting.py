@@ -55,12 +55,31 @@ def test_no_fraction_above_the_peak_is_printed():
 
 def test_traffic_comes_from_the_committed_pmc_summary():
     b = _bench()
-    db = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["workloads"]
+    tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    db = tj["workloads"]
     V, T = 66 * 66 * 40, 6
+    meta = {"commit": tj.get("commit"), "csrc_sha16": tj.get("csrc_sha16")}
     r = b.roofline_block({"predict": 0.04, "claim": 0.017, "ck_partial": 0.026, "weight": 0.018, "resample": 0.045},
-                         B_RUN, V, T, 1, db, "B")
-    assert r["kernel"] == "k_resample" and r["traffic"] == db["B"]["k_resample"]["hbm_bytes"]
-    assert r["traffic_frame"] >= r["traffic"]
+                         B_RUN, V, T, 1, db, "B", traffic_meta=meta)
+    # the stage's kernels: the resampler of this map size + the rollout behind it
+    assert r["kernel"] == "k_resample" and r["traffic"] == sum(db["B"].get(k, {}).get("hbm_bytes", 0) for k in b.STAGE_KERNELS["resample"])
+    assert r["traffic_frame"] >= (r["traffic"] or 0)
+    # every kernel with a PMC figure also reports the bytes it really moved against the sustained copy rate of the part
+    assert "frac_of_6.3TBps_on_pmc_bytes" in r["per_kernel"]["predict"] and 0 < r["per_kernel"]["predict"]["frac_of_6.3TBps_on_pmc_bytes"] < 1
+    assert str(tj.get("csrc_sha16")) in r["traffic_source"]
     # the measured traffic of the dominant saturated kernel is close to what it has to move (no wasted re-reads)
     c = db["C_sat"]["k_predict"]["hbm_bytes"]
     assert 0.8 < c / b.kernel_alg_bytes("predict", C_SAT, 132 * 132 * 60, 6) < 1.3
+
+
+def test_traffic_is_withheld_when_the_kernel_sources_changed():
+    """profiles/pmc_traffic.json carries the fingerprint of the kernel sources its passes ran on (collect.sh) and the commit
+    (pmc_merge.py); a bench run on other sources must not print those figures as its own"""
+    b = _bench()
+    tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert tj.get("csrc_sha16") and tj.get("commit") and len(b.csrc_fingerprint()) == 16
+    V, T = 66 * 66 * 40, 6
+    stale = {"stale": "profiles/pmc_traffic.json was measured on other kernel sources"}
+    r = b.roofline_block({"predict": 0.04, "claim": 0.017, "ck_partial": 0.026, "weight": 0.018, "resample": 0.045},
+                         B_RUN, V, T, 1, {}, "B", traffic_meta=stale)
+    assert r["traffic"] is None and "other kernel sources" in r["traffic_source"] and "traffic_frame" not in r
