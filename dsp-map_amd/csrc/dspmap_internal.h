@@ -106,6 +106,7 @@ struct dspmap {
     bool mgpu_interior_done = false;   // dspmap_mgpu_place_interior placed the tiles [mgpu_tile_lo, mgpu_tile_hi)
     int mgpu_tile_lo = 0, mgpu_tile_hi = 0;
     bool mgpu_place_pending = false;   // k_predict ran, k_place waits for the imports
+    bool mgpu_side_pending = false;    // the placement of the tiles without a view runs on the side stream (joined before the birth split)
     int vz_frames_at_begin = 0;
     int mgpu_nstatic_cap = 0;
     int* mgpu_count = nullptr;

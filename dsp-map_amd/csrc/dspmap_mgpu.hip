@@ -154,11 +154,29 @@ extern "C" int dspmap_mgpu_ck_partial(dspmap_t* m) {
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->mgpu_place_pending) {
         if (m->vz_frames_at_begin <= 0) c.s.vz0 = nullptr;
+        // a large slab: only the arrivals of tiles that can see the field of view are registered in pyramids, so only their
+        // placement has to precede the weight update -- the others get their slots on the side stream, beside the pair kernels
+        // AND the Ck all-reduce that follows this phase (the same split as the unsharded frame, dspmap_api.hip: enqueue_frame)
+        const bool split = !m->mgpu_interior_done && c.k.ntiles >= m->place_split_tiles;
         if (m->mgpu_interior_done) launch_claim(c, 0, 2, m->mgpu_tile_lo, m->mgpu_tile_hi);
-        else launch_claim(c);
+        else launch_claim(c, 0, 0, 0, 0, split ? 1 : -1);
         m->mgpu_interior_done = false;
-        c = dspmap_ctx_of(m);
         m->mgpu_place_pending = false;
+        if (split) {
+            launch_pyr_prepare(c);
+            HIPCHK(m, hipEventRecord(m->ev_fork2, m->stream));
+            LaunchCtx cm = dspmap_ctx_of(m);
+            launch_ck_partial(cm, true);
+            HIPCHK(m, hipStreamWaitEvent(m->stream2, m->ev_fork2, 0));
+            LaunchCtx c2 = c;
+            c2.stream = m->stream2;
+            launch_claim(c2, 0, 0, 0, 0, 0);
+            HIPCHK(m, hipEventRecord(m->ev_join, m->stream2));
+            m->mgpu_side_pending = true;
+            HIPCHK(m, hipGetLastError());
+            return DSPMAP_OK;
+        }
+        c = dspmap_ctx_of(m);
     }
     launch_ck_partial(c);
     HIPCHK(m, hipGetLastError());
@@ -169,6 +187,7 @@ extern "C" int dspmap_mgpu_weights_and_split(dspmap_t* m) {
     READY(m);
     LaunchCtx c = dspmap_ctx_of(m);
     launch_weight_update(c);
+    if (m->mgpu_side_pending) { HIPCHK(m, hipStreamWaitEvent(m->stream, m->ev_join, 0)); m->mgpu_side_pending = false; }   // the side placement
     if (m->last_n_birth > 0) launch_birth_split_cksum(c, m->last_n_birth);   // split + the 1/Ck reduction in one launch
     else launch_ck_finalize(c);
     HIPCHK(m, hipGetLastError());

@@ -353,3 +353,35 @@ def test_estimator_keeps_one_last_state_across_host_and_device(dsp):
             assert np.isclose(g["ny"][dyn], 1.0, atol=0.02).sum() == 60, f      # cluster A keeps its 1 m/s through the switches
     for m in maps:
         m.close()
+
+
+def test_sharded_frame_with_split_placement_matches_unsharded(dsp):
+    """large slabs place the arrivals of the tiles that cannot see the field of view on a side stream, beside the pair kernels
+    and the Ck all-reduce (dspmap_mgpu_ck_partial); forced on here for a small map: 4 slabs == the unsharded map"""
+    sharded = __import__("dsp-map_amd.sharded", fromlist=["CppGroup"])
+    from tests.test_gpu_sharded import _stream
+    cfg = dict(nx=40, ny=40, nz=24, res=0.15, ppv=12)
+    tables = common.tables(3)
+    grp = sharded.CppGroup(dsp, cfg, 4)
+    full = dsp.DSPMap(dsp.make_config(**cfg))
+    for x in grp.maps + [full]:
+        x.set_tables(*tables)
+        x.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, 2)
+    for x in grp.maps:
+        x.set_param(dsp.capi.P_PLACE_SPLIT_TILES, 1)
+    for pts, pos, t, q in _stream(8):
+        d = torch.from_numpy(pts).cuda()
+        assert grp.update(d, pos, t, q) == 1
+        assert full.update_device(d.data_ptr(), len(pts), pos, t, q) == 1
+        grp.sync()
+        for x in grp.maps + [full]:
+            x.clearOccupancyMapPrediction()
+    got = np.concatenate([x.results() for x in grp.maps], 0)
+    assert np.array_equal(got, full.results())
+    parts = [x.export_state() for x in grp.maps]
+    sv, ss, sr = (np.concatenate([p[k] for p in parts]) for k in range(3))
+    order = np.lexsort((ss, sv))
+    fv, fs_, fr = full.export_state()
+    assert len(fv) > 3000
+    assert np.array_equal(sv[order], fv) and np.array_equal(ss[order], fs_) and np.array_equal(sr[order], fr)
+    grp.close(); full.close()
