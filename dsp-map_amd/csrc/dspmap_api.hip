@@ -52,6 +52,14 @@ LaunchCtx dspmap_ctx_of(dspmap* m) {
     c.pt_cap = m->pt_cap; c.birth_cap = m->birth_cap; c.n_cu = m->n_cu;
     c.k.nbsnap = m->nb_dirty ? m->nbsnap_buf : nullptr;
     c.ve = m->ve;
+    // which k_predict: the SPARSE variant while most tiles are empty (both give the same result; the estimate is a few frames old)
+    if (m->sparse_force >= 0) m->sparse_mode = m->sparse_force != 0;
+    else if (m->hint_host && m->k.ntiles >= 4096) {
+        const long long est = 64ll * *m->hint_host;
+        if (!m->sparse_mode && est * 4 < m->k.ntiles) m->sparse_mode = true;
+        else if (m->sparse_mode && est * 2 > m->k.ntiles) m->sparse_mode = false;
+    }
+    c.sparse = m->sparse_mode;
     return c;
 }
 
@@ -159,7 +167,7 @@ static void free_dev(dspmap* m) {
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, s.fov_rec, s.fov_slot, s.fov_key, s.fov_spos, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt, s.in_n, s.pmask, s.ta, s.dflag, s.dirty,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.ro_cnt, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
-                    m->k.part_predict, m->k.part_claim, m->k.tile_fov, s.tile_live, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf};
+                    m->k.part_predict, m->k.tile_fov, s.tile_live, s.fut_dirty, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
     if (m->nbsnap_buf) chk(hipFree(m->nbsnap_buf), "hipFree");
     {
@@ -182,6 +190,7 @@ static void free_dev(dspmap* m) {
     if (m->ev_fork2) chk(hipEventDestroy(m->ev_fork2), "hipEventDestroy");
     for (hipEvent_t& e : m->ring_ev) if (e) { chk(hipEventDestroy(e), "hipEventDestroy"); e = nullptr; }
     if (m->ring_host) { chk(hipHostFree(m->ring_host), "hipHostFree"); m->ring_host = nullptr; }
+    if (m->hint_host) { chk(hipHostFree((void*)m->hint_host), "hipHostFree"); m->hint_host = nullptr; }
     if (m->s.ring_seq) { chk(hipFree(m->s.ring_seq), "hipFree"); m->s.ring_seq = nullptr; }
     for (hipEvent_t e : m->pev) if (e) chk(hipEventDestroy(e), "hipEventDestroy(prof)");
     if (m->stream2) chk(hipStreamDestroy(m->stream2), "hipStreamDestroy(2)");
@@ -299,6 +308,9 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, hipHostMalloc((void**)&m->ring_host, sizeof(FrameParams) * DSPMAP_RING, hipHostMallocMapped));
     memset(m->ring_host, 0, sizeof(FrameParams) * DSPMAP_RING);
     { void* dp = nullptr; HIPCHK(m, hipHostGetDevicePointer(&dp, m->ring_host, 0)); m->ring_dev = (const FrameParams*)dp; }
+    HIPCHK(m, hipHostMalloc((void**)&m->hint_host, sizeof(int), hipHostMallocMapped));
+    *m->hint_host = 1 << 24;   // (nothing known yet: not sparse)
+    { void* dp = nullptr; HIPCHK(m, hipHostGetDevicePointer(&dp, (void*)m->hint_host, 0)); m->s.hint_out = (int*)dp; }
     HIPCHK(m, hipMalloc((void**)&m->s.ring_seq, sizeof(int)));
     HIPCHK(m, hipMemset(m->s.ring_seq, 0, sizeof(int)));
     m->ring_head = 0;
@@ -361,11 +373,12 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     const bool slab = !(d.z_lo == 0 && d.z_hi == d.nz);
     if (slab) HIPCHK(m, dalloc(&k.expmask, W));
     HIPCHK(m, dalloc(&k.part_predict, (size_t)k.ntiles * 4));
-    HIPCHK(m, dalloc(&k.part_claim, (size_t)k.ntiles * 2));
     HIPCHK(m, dalloc(&s.tile_live, (size_t)k.ntiles));
     HIPCHK(m, hipMemset(s.tile_live, 1, sizeof(int) * (size_t)k.ntiles));
+    HIPCHK(m, dalloc(&s.fut_dirty, (size_t)k.ntiles));
+    HIPCHK(m, hipMemset(s.fut_dirty, 0, sizeof(int) * (size_t)k.ntiles));   // (the accumulators start zeroed)
     HIPCHK(m, dalloc(&k.tile_fov, (size_t)k.ntiles));
-    HIPCHK(m, hipMemset(k.tile_fov, 0, sizeof(int) * (size_t)k.ntiles));
+    HIPCHK(m, hipMemset(k.tile_fov, 0xff, sizeof(int) * (size_t)k.ntiles));   // no frame's tag
     HIPCHK(m, dalloc(&k.part_resample, (size_t)k.nblk_sweep * 4));
     HIPCHK(m, dalloc(&k.work_list, (size_t)d.v_loc));
     HIPCHK(m, dalloc(&k.vb_cnt, (size_t)d.v_loc));
@@ -380,7 +393,6 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, hipMemset(s.obs_ck, 0, sizeof(long long) * d.np * DSP_OBS_CAP));
     HIPCHK(m, hipMemset(s.pyr_cnt, 0, sizeof(int) * d.np));
     HIPCHK(m, hipMemset(k.part_predict, 0, sizeof(int) * (size_t)k.ntiles * 4));
-    HIPCHK(m, hipMemset(k.part_claim, 0, sizeof(int) * (size_t)k.ntiles * 2));
     HIPCHK(m, hipMemset(k.part_resample, 0, sizeof(int) * (size_t)k.nblk_sweep * 4));
     HIPCHK(m, hipMemset(k.vb_cnt, 0, sizeof(int) * (size_t)d.v_loc));   // invariant: empty outside a birth stage
     {   // boundary-plane normals, sensor frame (:563-578; float sin/cos like the C++ overloads)
@@ -490,6 +502,7 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
             if (v != 0 && v != 1 && v != 2) return dspmap_fail(m, DSPMAP_E_ARG, "velocity estimator: 0 off, 1 host stage, 2 device");
             m->use_vel_est = (int)v; break;
         case DSPMAP_P_USE_GRAPH: m->use_graph = v != 0; break;
+        case DSPMAP_P_SPARSE_SWEEP: m->sparse_force = v < 0 ? -1 : (v != 0 ? 1 : 0); break;
         case DSPMAP_P_FAST_DIVISION: if (v == 0) { m->d.div_ok = 0; m->div_forced_off = true; m->graph_epoch++; } break;
         case DSPMAP_P_PLACE_SPLIT_TILES: m->place_split_tiles = v < 1 ? 1 : (v > 2e9 ? 2000000000 : (int)v); m->graph_epoch++; break;
         case DSPMAP_P_OCCLUSION_MARGIN: m->fp.occl_margin = (float)v; break;
@@ -522,6 +535,7 @@ extern "C" double dspmap_get_param(const dspmap_t* m, int key) {
         case DSPMAP_P_UPDATE_TIME: return m->update_time;
         case DSPMAP_P_UPDATE_COUNTER: return m->update_counter;
         case DSPMAP_P_PLACE_SPLIT_TILES: return m->place_split_tiles;
+        case DSPMAP_P_SPARSE_SWEEP: return m->sparse_mode ? 1 : 0;
         case DSPMAP_P_FAST_DIVISION: return m->d.div_ok;
         default: return 0;
     }
@@ -889,7 +903,7 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
     if (timed) HIPCHK(m, hipEventRecord(m->ev0, m->stream));
     if (m->use_graph && !m->prof) {
         // the kernel arguments of a frame are constant (per-frame values live in s.fpar): capture once, replay
-        const unsigned long long key = ((unsigned long long)m->graph_epoch << 8) | (has_vz ? 1u : 0u) | ((unsigned)mode << 1);
+        const unsigned long long key = ((unsigned long long)m->graph_epoch << 8) | (has_vz ? 1u : 0u) | ((unsigned)mode << 1) | (c.sparse ? 8u : 0u);
         if (!m->graph_exec || m->graph_key != key) {
             if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
             if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
@@ -1423,6 +1437,7 @@ extern "C" int dspmap_debug_tile_view(dspmap_t* m, int* out, int cap) {
     if (!out || cap < m->k.ntiles) return dspmap_fail(m, DSPMAP_E_ARG, "buffer of %d ints needed", m->k.ntiles);
     HIPCHK(m, hipStreamSynchronize(m->stream));
     HIPCHK(m, hipMemcpy(out, m->k.tile_fov, sizeof(int) * (size_t)m->k.ntiles, hipMemcpyDeviceToHost));
+    for (int i = 0; i < m->k.ntiles; ++i) out[i] = (out[i] >> 1) == m->hp.epoch ? (out[i] & 1) : -1;   // -1: not visited by the last k_predict (empty)
     return m->k.ntiles;
 }
 extern "C" int dspmap_get_pyramid_counts(dspmap_t* m, int* out) {
@@ -1564,6 +1579,7 @@ extern "C" int dspmap_load_checkpoint(dspmap_t* m, const char* path) {
             for (size_t t = 0; t < T; ++t) ft[t * V + v] = fut[v * T + t];
         HIPCHK(m, hipMemcpy(m->s.fut, ft.data(), sizeof(float) * V * T, hipMemcpyHostToDevice));
         HIPCHK(m, hipMemsetAsync(m->s.fut_stat, 0, sizeof(float) * V, m->stream));
+        HIPCHK(m, hipMemsetAsync(m->s.fut_dirty, 1, sizeof(int) * (size_t)m->k.ntiles, m->stream));   // (any tile may hold mass now)
     }
     HIPCHK(m, hipStreamSynchronize(m->stream));
     {   // filter parameters and the frozen birth statics come from the checkpoint; the random tables are THIS handle's

@@ -9,6 +9,17 @@
 #define WAVE 64
 
 __device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
+// one int at a wave-uniform address through the scalar unit, waited for (the compiler takes the vector path for memory that
+// kernels write; the scalar cache is invalidated at every launch, so values of EARLIER kernels are seen)
+__device__ __forceinline__ int sload_i(const int* p) {
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+    return v;
+}
+__device__ __forceinline__ void sload_i3(const int* p0, const int* p1, const int* p2, int& v0, int& v1, int& v2) {   // three at once: one round trip
+    asm volatile("s_load_dword %0, %3, 0x0\n\ts_load_dword %1, %4, 0x0\n\ts_load_dword %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(v0), "=&s"(v1), "=&s"(v2) : "s"(p0), "s"(p1), "s"(p2));
+}
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
 // ---- wavefront scan / reduction on the DPP network (no LDS traffic).

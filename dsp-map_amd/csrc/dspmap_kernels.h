@@ -12,7 +12,6 @@ struct KernelScratch {
     int* in_cnt;        // [ntiles] inbox fill; zeroed again by k_place
     u64* expmask;       // [v_loc*mw] particles that left the slab (multi-GPU), or nullptr
     int* part_predict;  // [ntiles*4]
-    int* part_claim;    // [ntiles*2]
     int* tile_fov;      // [ntiles] 1 = a particle inside this tile may lie in the field of view (k_predict, conservative box test):
                         // the placement of the other tiles registers nothing in a pyramid and may run beside the pair kernels
     int* part_resample; // [ntiles rounded up to 4] live particles per tile after resampling
@@ -44,6 +43,7 @@ struct LaunchCtx {
     int pt_cap, birth_cap;
     VelEst ve;
     int n_cu = 256;      // compute units of the device (sizes launches that are meant to occupy only a share of it)
+    bool sparse = false; // most tiles hold nothing (dspmap::sparse_mode): k_predict's variant that leaves such tiles first
 };
 
 // frame setup: rotate boundary planes (:226-232), reset per-frame counters/bins (:235-238)

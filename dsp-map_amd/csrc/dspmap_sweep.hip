@@ -200,13 +200,46 @@ __device__ __forceinline__ void vz_noise(const MapDims& d, const DevState& s, co
     s.vz0[idx] = 0.f;
 }
 
+// Can a particle inside tile BX lie in the field of view?  (one wave; lanes 0-15 hold the corners.)  The tile's voxels fill one
+// box (a run of x inside a row) or two (the tail of one row and the head of the next; lanes 0-7 / 8-15 hold the corners); every
+// plane test of pyramid_of is a dot product that is monotone in each coordinate even after rounding, so its extreme over a box
+// sits at a corner: if all 8 corners fail the same boundary plane, no particle of the box passes ifInPyramidsArea (:1329-1339).
+// k_place of such tiles registers nothing and is free to run beside the pair kernels.
+__device__ __forceinline__ int tile_view_test(const MapDims& d, const DevState& s, const int BX, const int l) {
+    const float* __restrict__ gph = s.planes_h;   // (rotated by k_obs_points; uniform addresses: scalar loads)
+    const float* __restrict__ gpv = s.planes_v;
+    const int g0 = d.v_base + BX * 64, g1 = d.v_base + min(BX * 64 + 63, d.v_loc - 1);
+    const int zc = d.nx * d.ny;
+    const int r0 = g0 / d.nx, r1 = g1 / d.nx;          // first and last x-row the tile touches
+    const int bx = (l >> 3) & 1;
+    int x0 = g0 % d.nx, x1 = g1 % d.nx, y0 = (g0 % zc) / d.nx, y1 = (g1 % zc) / d.nx, z0 = g0 / zc, z1 = g1 / zc;
+    bool two = false;
+    if (r1 - r0 == 1) {
+        two = true;
+        if (bx == 0) { x1 = d.nx - 1; y1 = y0; z1 = z0; } else { x0 = 0; y0 = y1; z0 = z1; }
+    } else if (r1 - r0 > 1) {                          // nx < 64: whole rows (layers)
+        x0 = 0; x1 = d.nx - 1;
+        if (z0 != z1) { y0 = 0; y1 = d.ny - 1; }
+    }
+    const float mg = d.res * 0.01f;   // a particle of voxel x has (int)((p + half) / res) == x: p may sit a rounding below the face
+    const float cx = (l & 1) ? (float)(x1 + 1) * d.res - d.half_x + mg : (float)x0 * d.res - d.half_x - mg;
+    const float cy = (l & 2) ? (float)(y1 + 1) * d.res - d.half_y + mg : (float)y0 * d.res - d.half_y - mg;
+    const float cz = (l & 4) ? (float)(z1 + 1) * d.res - d.half_z + mg : (float)z0 * d.res - d.half_z - mg;
+    const bool c8 = l < (two ? 16 : 8);
+    const u64 b0 = __ballot(c8 && dot3(cx, cy, cz, gph) >= 0.f);
+    const u64 b1 = __ballot(c8 && dot3(cx, cy, cz, gph + 3 * d.np_h) <= 0.f);
+    const u64 b2 = __ballot(c8 && dot3(cx, cy, cz, gpv) <= 0.f);
+    const u64 b3 = __ballot(c8 && dot3(cx, cy, cz, gpv + 3 * d.np_v) >= 0.f);
+    auto box_in = [&](int sh) { return ((b0 >> sh) & 0xffull) && ((b1 >> sh) & 0xffull) && ((b2 >> sh) & 0xffull) && ((b3 >> sh) & 0xffull); };
+    return (box_in(0) || box_in(8)) ? 1 : 0;
+}
 // eight workgroups per CU: the sweep is a chain of phases (occupancy words, rows, tails) and only the workgroups that are in
 // their row phase keep the memory system busy -- residency, not per-wave batch depth, is what moved this kernel (measured:
 // 5 -> 7 -> 8 resident workgroups 0.274 -> 0.239 -> 0.224 ms at 132x132x60 saturated; 2 / 3 / 4 / 6 rows per batch all alike)
 #ifndef PRED_LB
 #define PRED_LB 8
 #endif
-template <int MW, int NW, bool HASVZ>
+template <int MW, int NW, bool HASVZ, bool SPARSE>
 __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevState s, FilterParams fp, int has_vz, int* __restrict__ part,
                                                  float4* __restrict__ mv_rec, float4* __restrict__ in_rec, int* __restrict__ in_cnt,
                                                  u64* __restrict__ expmask, const int* __restrict__ vz_pre, const u64* __restrict__ vz_q,
@@ -223,8 +256,28 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
     __shared__ int s_hist[HIST_NP];   // stayers per pyramid of this tile, then the base of the tile's run in each list
     __shared__ unsigned short s_cells[DENSE_MAX];   // sparse tiles: compact list of live cells ((slot << 6) | lane)
     __shared__ int s_ncell;
-    const float odx = s.fpar->od[0], ody = s.fpar->od[1], odz = s.fpar->od[2], dt = s.fpar->dt;
     const int tid = threadIdx.x;
+    // SPARSE: a tile that holds nothing (k_resample saw it empty; no arrival, birth or import since) and whose future
+    // accumulators need no zeroing is left at once: a sparse map is mostly such tiles, and what they cost is the time a resident
+    // workgroup stays -- one scalar round trip here, before anything else of the kernel's arguments is looked at.
+    // (The caller launches this variant while the map IS sparse -- FrameScalars::live_hint: on a saturated map the same flags
+    // arrive with the tile's occupancy words, and asking first costs every tile a round trip and the kernel some registers:
+    // +2-3 % at 132x132x60 saturated.)
+    int tflags = -1;   // bit 0: the tile holds particles, bit 1: its future accumulators are to be zeroed; -1: not looked at yet
+    if (SPARSE) {
+        const int nextra0 = ((extra & 1) ? (d.np + NW - 1) / NW : 0) + ((extra & 2) ? 1 : 0);
+        if ((int)blockIdx.x >= nextra0) {
+            const int bx0 = (int)blockIdx.x - nextra0;
+            int t_live, f_dirty, f_clear;
+            sload_i3(s.tile_live + bx0, s.fut_dirty + bx0, &s.fpar->clear_fut, t_live, f_dirty, f_clear);
+            tflags = (t_live ? 1 : 0) | ((f_clear && f_dirty) ? 2 : 0);
+            if (!tflags) {
+                if (tid < 4) part[bx0 * 4 + tid] = 0;
+                return;
+            }
+        }
+    }
+    const float odx = s.fpar->od[0], ody = s.fpar->od[1], odz = s.fpar->od[2], dt = s.fpar->dt;
     const int l = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and known to be: the row loops below become scalar control flow)
     // whole frame: the observation gather (448 independent waves, a chain of L2 round trips over the frame's points)
@@ -247,49 +300,25 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
     }
     const int BX = (int)blockIdx.x - nextra;   // tile index
     const int lv = BX * 64 + l;   // all four waves of the block look at the same tile
-    if (s.fpar->clear_fut) {
+    if (!SPARSE) tflags = (s.tile_live[BX] ? 1 : 0) | (s.fpar->clear_fut ? 2 : 0);   // (a dense map: nearly every tile's accumulators were added to -- not worth a look at fut_dirty)
+    if (tflags & 2) {
         // clearOccupancyMapPrediction (:431-438) was requested since the last frame: this tile's share of the
-        // future accumulators is zeroed here instead of by two extra memset launches per frame
+        // future accumulators is zeroed here instead of by two extra memset launches per frame -- if anything was added to
+        // it since it was zeroed last (fut_dirty: set by whoever adds)
+        if (tid == 0) s.fut_dirty[BX] = 0;
         const int v0 = BX * 64, nv = min(64, d.v_loc - v0);
         for (int t = wave; t < d.T; t += NW) if (l < nv) s.fut[(size_t)t * d.v_loc + v0 + l] = 0.f;   // [T][V]: one row of 64 per wave and horizon
         if (tid < nv) s.fut_stat[v0 + tid] = 0.f;
     }
-    if (wave == NW - 1) {
-        const float* __restrict__ gph = s.planes_h;   // (rotated by k_obs_points; uniform addresses: scalar loads)
-        const float* __restrict__ gpv = s.planes_v;
-        // Can a particle inside this tile lie in the field of view?  The tile's voxels fill one box (a run of x inside a
-        // row) or two (the tail of one row and the head of the next; lanes 0-7 / 8-15 hold the corners); every plane test of
-        // pyramid_of is a dot product that is monotone in each coordinate even after rounding, so its extreme over a box
-        // sits at a corner: if all 8 corners fail the same boundary plane, no particle of the box passes ifInPyramidsArea
-        // (:1329-1339).  k_place of such tiles registers nothing and is free to run beside the pair kernels.
-        const int g0 = d.v_base + BX * 64, g1 = d.v_base + min(BX * 64 + 63, d.v_loc - 1);
-        const int zc = d.nx * d.ny;
-        const int r0 = g0 / d.nx, r1 = g1 / d.nx;          // first and last x-row the tile touches
-        const int bx = (l >> 3) & 1;
-        int x0 = g0 % d.nx, x1 = g1 % d.nx, y0 = (g0 % zc) / d.nx, y1 = (g1 % zc) / d.nx, z0 = g0 / zc, z1 = g1 / zc;
-        bool two = false;
-        if (r1 - r0 == 1) {
-            two = true;
-            if (bx == 0) { x1 = d.nx - 1; y1 = y0; z1 = z0; } else { x0 = 0; y0 = y1; z0 = z1; }
-        } else if (r1 - r0 > 1) {                          // nx < 64: whole rows (layers)
-            x0 = 0; x1 = d.nx - 1;
-            if (z0 != z1) { y0 = 0; y1 = d.ny - 1; }
-        }
-        const float mg = d.res * 0.01f;   // a particle of voxel x has (int)((p + half) / res) == x: p may sit a rounding below the face
-        const float cx = (l & 1) ? (float)(x1 + 1) * d.res - d.half_x + mg : (float)x0 * d.res - d.half_x - mg;
-        const float cy = (l & 2) ? (float)(y1 + 1) * d.res - d.half_y + mg : (float)y0 * d.res - d.half_y - mg;
-        const float cz = (l & 4) ? (float)(z1 + 1) * d.res - d.half_z + mg : (float)z0 * d.res - d.half_z - mg;
-        const bool c8 = l < (two ? 16 : 8);
-        const u64 b0 = __ballot(c8 && dot3(cx, cy, cz, gph) >= 0.f);
-        const u64 b1 = __ballot(c8 && dot3(cx, cy, cz, gph + 3 * d.np_h) <= 0.f);
-        const u64 b2 = __ballot(c8 && dot3(cx, cy, cz, gpv) <= 0.f);
-        const u64 b3 = __ballot(c8 && dot3(cx, cy, cz, gpv + 3 * d.np_v) >= 0.f);
-        auto box_in = [&](int sh) { return ((b0 >> sh) & 0xffull) && ((b1 >> sh) & 0xffull) && ((b2 >> sh) & 0xffull) && ((b3 >> sh) & 0xffull); };
-        if (l == 0) { const int v = (box_in(0) || box_in(8)) ? 1 : 0; tile_fov[BX] = v; s_view = v; }
-    }
-    if (!s.tile_live[BX]) {   // nothing lives here (k_resample saw it empty; no arrival, birth or import since)
+    if (!(tflags & 1)) {   // (empty, but its accumulators had to be zeroed)
         if (tid < 4) part[BX * 4 + tid] = 0;
         return;
+    }
+    if (wave == NW - 1) {
+        // the tile's view on the field of view, tagged with the frame: a tile that was skipped here and receives arrivals is
+        // tested by k_place itself
+        const int v = tile_view_test(d, s, BX, l);
+        if (l == 0) { tile_fov[BX] = (s.fpar->epoch << 1) | v; s_view = v; }
     }
     const bool inr = lv < d.v_loc;
     const int lvs = inr ? lv : 0;
@@ -599,7 +628,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
 // destination voxel in LDS and every arrival computes its slot in closed form from its rank among the voxel's
 // arrivals -- the same particles end up in the same slots as in the sequential reference, with no global atomic
 // on the occupancy words and no sequential loop.  Pyramid registration :1233-1259.
-// part2[blockIdx*2 + {0,1}] = {voxel full, pyramid full}
+// FrameScalars::n_place_vf / n_place_pf += {voxel full, pyramid full}
 // --------------------------------------------------------------------------
 #ifndef PLACE_SIDE_WG
 #define PLACE_SIDE_WG 3   // workgroups per CU of the side-stream placement
@@ -608,10 +637,8 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
                          // capacity of 64 * slots records) keeps them in its own staging area of k_predict, which is dead by now
 template <int MW>
 __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, const float4* __restrict__ in_rec, int* __restrict__ in_cnt,
-                                           int* __restrict__ part2, int has_vz, int tab_n, const u64* __restrict__ omask,
+                                           const u64* __restrict__ omask,
                                            float4* __restrict__ stage, const int BX) {
-    if (has_vz && BX == 0 && threadIdx.x == 0)   // k_predict drew 3 table values per ranked particle (:655-657)
-        s.fs->v_cur = (int)(((long long)s.fs->v_cur + 3ll * (long long)s.fs->occupied_count) % tab_n);
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
     __shared__ u64 s_cur[MW * 64], s_org[MW * 64], s_new[MW * 64];
@@ -620,11 +647,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
     __shared__ int s_cnt[2];
     const int tid = threadIdx.x;
     const int n_all = in_cnt[BX];
-    if (n_all == 0) {
-        if (tid < 2) part2[BX * 2 + tid] = 0;
-        if (tid == 0) s.in_n[BX] = 0;
-        return;
-    }
+    if (n_all == 0) return;   // (nothing to reset: in_n is read for tiles with arrivals only, the counts below are the frame's)
     const bool was_live = s.tile_live[BX] != 0;   // an empty tile was skipped by k_predict: its omask words are stale (and zero in truth)
     const int cap = 64 * d.slots;
     const int n = min(n_all, cap);
@@ -783,13 +806,16 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
         for (int e = 0; e < MW; ++e)
             if (s_new[e * 64 + tid]) s.mask[(size_t)lv * MW + e] = s.mask[(size_t)lv * MW + e] | s_new[e * 64 + tid];
     }
-    if (tid == 0) { in_cnt[BX] = 0; s.in_n[BX] = n; s.tile_live[BX] = 1; }   // ready for the next frame; the tile holds particles now
-    if (tid < 2) part2[BX * 2 + tid] = s_cnt[tid];
+    if (tid == 0) {
+        in_cnt[BX] = 0; s.in_n[BX] = n; s.tile_live[BX] = 1;   // ready for the next frame; the tile holds particles now
+        if (s_cnt[0]) atomicAdd(&s.fs->n_place_vf, s_cnt[0]);   // (rare events: the frame's counts, reset with the pyramid lists)
+        if (s_cnt[1]) atomicAdd(&s.fs->n_place_pf, s_cnt[1]);
+    }
 }
 
 template <int MW>
 __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const float4* __restrict__ in_rec,
-                                               int* __restrict__ in_cnt, int* __restrict__ part2, int has_vz, int tab_n,
+                                               int* __restrict__ in_cnt, int has_vz, int tab_n,
                                                const u64* __restrict__ omask, FilterParams fp, float4* __restrict__ child,
                                                int* __restrict__ vb_cnt, int* __restrict__ vb_idx, int nchild, int t0, int n0, int t1, int n1,
                                                const int* __restrict__ tile_fov, int sel, float4* __restrict__ stage) {
@@ -805,8 +831,17 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
     }
     for (int bq = (int)blockIdx.x - nchild; bq < n0 + n1; bq += (int)gridDim.x - nchild) {
         const int BX = bq < n0 ? t0 + bq : t1 + (bq - n0);   // tile index
-        if (sel >= 0 && (tile_fov[BX] != 0) != (sel != 0)) continue;   // the other launch of a split placement owns this tile
-        place_tile<MW>(d, s, in_rec, in_cnt, part2, has_vz, tab_n, omask, stage, BX);
+        if (has_vz && BX == 0 && sel != 0 && threadIdx.x == 0)   // k_predict drew 3 table values per ranked particle (:655-657)
+            s.fs->v_cur = (int)(((long long)s.fs->v_cur + 3ll * (long long)s.fs->occupied_count) % tab_n);
+        if (sload_i(in_cnt + BX) == 0) continue;   // (no arrivals -- or the tile's owner is done with them)
+        if (sel >= 0) {   // a split placement: the other launch owns the tiles of the other kind
+            const int tf = tile_fov[BX];
+            int fv = tf & 1;
+            // k_predict skipped the tile (empty) and particles arrive in it: its view is tested here, by both launches alike
+            if ((tf >> 1) != s.fpar->epoch) fv = tile_view_test(d, s, BX, lane_id());
+            if ((fv != 0) != (sel != 0)) continue;
+        }
+        place_tile<MW>(d, s, in_rec, in_cnt, omask, stage, BX);
         __syncthreads();   // the tile's LDS tables are re-used by the next one
     }
 }
@@ -945,6 +980,7 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
         s.res4[lv] = res;
         if (stat_w != 0.f) s.fut_stat[lv] += stat_w;  // only this lane ever writes fut_stat[lv]
     }
+    if (__ballot(inr && stat_w != 0.f) && l == 0) s.fut_dirty[wave_g] = 1;   // (k_predict zeroes the tile's accumulators on the next clear)
     // ---- systematic resampling :986-1053 (weights from the LDS panel)
     int ncp = 0;
     float w_copy = 0.f;
@@ -1037,7 +1073,10 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
         }
     }
     live_out = wave_sum_i(live_out);
-    if (l == 0) { part_live[wave_g] = live_out; s.tile_live[wave_g] = live_out > 0 ? 1 : 0; }
+    if (l == 0) {
+        part_live[wave_g] = live_out; s.tile_live[wave_g] = live_out > 0 ? 1 : 0;
+        if ((wave_g & 63) == 0 && live_out > 0) atomicAdd(&s.fs->live_acc, 1);   // (a 1-in-64 sample of the non-empty tiles: k_predict's hint)
+    }
 }
 
 // --------------------------------------------------------------------------
@@ -1200,6 +1239,7 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
             s.res4[lv] = res;
             if (stat_w != 0.f) s.fut_stat[lv] += stat_w;  // only this lane ever writes fut_stat[lv]
         }
+        if (__ballot(inr && stat_w != 0.f) && l == 0) s.fut_dirty[BX] = 1;   // (k_predict zeroes the tile's accumulators on the next clear)
 #ifdef RESAMPLE_PROF
         t_s2 = __builtin_readcyclecounter();
 #endif
@@ -1258,7 +1298,10 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
             if (nb) s.nbmask[lv] = 0ull;  // newborn flag -> 1 (:968)
         }
         const int live_out = wave_sum_i(inr ? (int)__popcll(mfin) : 0);
-        if (l == 0) { part_live[BX] = live_out; s.tile_live[BX] = live_out > 0 ? 1 : 0; }
+        if (l == 0) {
+            part_live[BX] = live_out; s.tile_live[BX] = live_out > 0 ? 1 : 0;
+            if ((BX & 63) == 0 && live_out > 0) atomicAdd(&s.fs->live_acc, 1);   // (a 1-in-64 sample of the non-empty tiles: k_predict's hint)
+        }
     }
     __syncthreads();
 #ifdef RESAMPLE_PROF
@@ -1374,7 +1417,7 @@ __global__ void __launch_bounds__(RO_TPB) k_rollout(MapDims d, DevState s, const
                 if (dl < 0 || dl >= d.v_loc) continue;
                 const int off = dl - (G0 * 64 - pl.halo[t] * d.nx);
                 if (dense && off >= 0 && off < pl.woff[t + 1] - pl.woff[t]) atomicAdd(&s_win[pl.woff[t] + off], b[u].x);
-                else unsafeAtomicAdd(&s.fut[(size_t)t * V + dl], b[u].x);
+                else { unsafeAtomicAdd(&s.fut[(size_t)t * V + dl], b[u].x); s.fut_dirty[dl >> 6] = 1; }
             }
         }
     }
@@ -1385,7 +1428,7 @@ __global__ void __launch_bounds__(RO_TPB) k_rollout(MapDims d, DevState s, const
         const int g0 = G0 * 64 - pl.halo[t] * d.nx;   // local voxel index of the window's first cell (cells outside the slab stay zero)
         for (int i = tid; i < wn; i += RO_TPB) {
             const float v = s_win[w0 + i];
-            if (v != 0.f) unsafeAtomicAdd(&s.fut[(size_t)t * V + g0 + i], v);
+            if (v != 0.f) { unsafeAtomicAdd(&s.fut[(size_t)t * V + g0 + i], v); s.fut_dirty[(g0 + i) >> 6] = 1; }
         }
     }
 }
@@ -1738,7 +1781,6 @@ __global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScra
     for (int i = tid; i < k.ntiles; i += 1024) {
         acc[0] += k.part_predict[i * 4]; acc[1] += k.part_predict[i * 4 + 1];
         acc[2] += k.part_predict[i * 4 + 2]; acc[3] += k.part_predict[i * 4 + 3];
-        acc[4] += k.part_claim[i * 2]; acc[5] += k.part_claim[i * 2 + 1];
     }
     for (int i = tid; i < k.nblk_sweep * 4; i += 1024) acc[6] += k.part_resample[i];
     int accb[2] = {0, 0};
@@ -1757,8 +1799,8 @@ __global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScra
     }
     if (tid == 0) {
         s.fs->n_live_in = out[0]; s.fs->n_out_of_map = out[1];
-        s.fs->n_pyramid_full = out[2] + out[5] + s.fs->n_pyr_removed; s.fs->n_moved = out[3];
-        s.fs->n_voxel_full = out[4] + s.fs->n_voxel_full_import; s.fs->n_live_out = out[6];
+        s.fs->n_pyramid_full = out[2] + s.fs->n_place_pf + s.fs->n_pyr_removed; s.fs->n_moved = out[3];
+        s.fs->n_voxel_full = s.fs->n_place_vf + s.fs->n_voxel_full_import; s.fs->n_live_out = out[6];
         int nf = 0;
         for (int b = 0; b < d.np; ++b) nf += min(s.pyr_cnt[b], d.capp);
         s.fs->n_fov = nf;
@@ -1788,10 +1830,12 @@ void launch_predict_only(const LaunchCtx& c, bool with_gather, bool with_rank) {
         else hipLaunchKernelGGL(k_vz_count<2>, dim3(nblk), dim3(256), 0, c.stream, c.d, c.s, k->work_list, k->vz_q);
         launch_scan_blocks(c, nblk);   // blk_cnt -> exclusive, total -> fs->occupied_count
     }
-#define PRED_LAUNCH(MWV, VZ) hipLaunchKernelGGL((k_predict<MWV, 4, VZ>), dim3(k->ntiles + xb), dim3(256), 0, c.stream, c.d, c.s, c.fp, VZ ? 1 : 0, \
+#define PRED_LAUNCH(MWV, VZ, SP) hipLaunchKernelGGL((k_predict<MWV, 4, VZ, SP>), dim3(k->ntiles + xb), dim3(256), 0, c.stream, c.d, c.s, c.fp, VZ ? 1 : 0, \
                                                 k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask, extra, k->tile_fov)
-    if (c.d.mw == 1) { if (c.s.vz0) PRED_LAUNCH(1, true); else PRED_LAUNCH(1, false); }
-    else { if (c.s.vz0) PRED_LAUNCH(2, true); else PRED_LAUNCH(2, false); }
+#define PRED_LAUNCH2(MWV, VZ) do { if (c.sparse) PRED_LAUNCH(MWV, VZ, true); else PRED_LAUNCH(MWV, VZ, false); } while (0)
+    if (c.d.mw == 1) { if (c.s.vz0) PRED_LAUNCH2(1, true); else PRED_LAUNCH2(1, false); }
+    else { if (c.s.vz0) PRED_LAUNCH2(2, true); else PRED_LAUNCH2(2, false); }
+#undef PRED_LAUNCH2
 #undef PRED_LAUNCH
 }
 void launch_claim(const LaunchCtx& c, int n_birth_grid, int part, int tile_lo, int tile_hi, int sel) {   // n_birth_grid > 0: the children of that many source points ride along
@@ -1807,8 +1851,8 @@ void launch_claim(const LaunchCtx& c, int n_birth_grid, int part, int tile_lo, i
     // and the wave slots, registers and LDS it leaves free are what the pair kernels run in
     unsigned grid = (unsigned)(n0 + n1) + xb;
     if (sel == 0) grid = std::min(grid, (unsigned)(PLACE_SIDE_WG * c.n_cu));
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec);
-    else hipLaunchKernelGGL(k_place<2>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, k->part_claim, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec);
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec);
+    else hipLaunchKernelGGL(k_place<2>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec);
 }
 void launch_predict(const LaunchCtx& c, bool with_gather) {
     launch_predict_only(c, with_gather, false);

@@ -88,6 +88,9 @@ struct FrameScalars {
     int n_voxel_full_import; // multi-GPU: movers received from a neighbour that found their voxel full
     int n_dirty;            // entries of DevState::dirty
     int n_overflow_inexact; // diagnostics: voxels / arrivals the re-slotting pass could not treat exactly (see k_place_fix)
+    int live_acc, live_hint;   // every 64th tile that k_resample leaves non-empty counts itself in live_acc; the next frame's first kernel
+                               // moves the count to live_hint: k_predict's estimate of how sparse the map is (a hint, never a result)
+    int n_place_vf, n_place_pf;   // arrivals k_place turned away: voxel full (:1227-1229) / pyramid list full (:1256-1259)
     int n_pyr_removed;  // particles k_pyr_prepare turned away because their pyramid's list was full (-2, :1256-1259)
     float expected_newborn;  // expected_new_born_objects :292
     float newborn_w;         // updated_weight_new_born :805
@@ -177,6 +180,7 @@ struct DevState {
     float* p_tab; float* v_tab; int* r_tab;
     FrameScalars* fs;
     FrameParams* fpar;
+    int* hint_out;      // host-mapped word: FrameScalars::live_hint for the caller's thread (which k_predict variant to launch)
     int* ring_seq;      // read position of the pinned parameter ring (frames replayed as a captured graph)
     // re-slotting after a full pyramid list has turned particles away (k_place_fix, dspmap_kernels.hip)
     u64* pmask;         // [v_loc*mw] occupancy after the prediction, before any arrival was placed (tiles with arrivals; k_place)
@@ -184,6 +188,7 @@ struct DevState {
     int* dflag;         // [v_loc] 1 = the voxel is in the dirty list
     int* dirty;         // [DSP_DIRTY_CAP] local voxels that lost a particle to a full pyramid list this frame
     int* in_n;          // [tiles] arrivals the last placement served per tile
+    int* fut_dirty;     // [tiles] 1 = something was added to the tile's future accumulators (fut, fut_stat) since they were zeroed
     int* tile_live;     // [tiles] 0 = the 64-voxel tile holds no particle (k_resample found it empty and nothing was placed, born or
                         // imported there since): the sweeps skip it without reading its occupancy words.  Conservative: nonzero
                         // does not promise a particle.

@@ -123,6 +123,9 @@ enum dspmap_param {
     DSPMAP_P_FAST_DIVISION = 17,    /* read: 1 if (p + half) / VOXEL_RESOLUTION (:1062-1088) is computed as reciprocal + two FMAs -- only after a
                                        kernel has compared that quotient with the IEEE division, bit for bit, for this resolution
                                        (device initialisation); write 0: force the IEEE division (same results by construction) */
+    DSPMAP_P_SPARSE_SWEEP = 18,     /* which variant of the prediction sweep runs: -1 (default) the handle decides from a running estimate of how
+                                       many 64-voxel tiles hold particles (most empty: empty tiles are left after one scalar load), 0 / 1 force
+                                       one (same result either way; read: the variant of the last frame) */
     DSPMAP_P_PAIR_CULL_SIGMAS = 13  /* mapUpdate evaluates a (particle, observation) pair only if their ranges differ by at most this many
                                        sigma_ob (default 9: the dropped terms are < 1e-19 and zero on the fixed-point Ck grid);
                                        a huge value evaluates every pair of the neighbourhood like the reference's loops */

@@ -385,3 +385,57 @@ def test_sharded_frame_with_split_placement_matches_unsharded(dsp):
     assert len(fv) > 3000
     assert np.array_equal(sv[order], fv) and np.array_equal(ss[order], fs_) and np.array_equal(sr[order], fr)
     grp.close(); full.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("quat", [(1.0, 0.0, 0.0, 0.0), (0.9659258, 0.0, 0.0, 0.258819)])
+def test_sparse_sweep_variant_changes_nothing(dsp, quat):
+    """A map filled by the depth stream is mostly empty tiles; k_predict's SPARSE variant leaves such a tile after one scalar
+    load (no view test, no zeroing of future accumulators nobody added to: DevState::fut_dirty), and k_place tests the view of
+    a skipped tile that receives arrivals itself.  Forced on / forced off / chosen by the handle (DSPMAP_P_SPARSE_SWEEP), with
+    the split placement forced on, from an EMPTY map under a moving sensor (particles keep arriving in tiles that were empty),
+    with clearOccupancyMapPrediction skipped on every third frame (the accumulators then add up over two frames): every slot,
+    every float, every counter and every future-status value equal, frame after frame."""
+    cfg = dict(nx=56, ny=88, nz=12, res=0.15, ppv=24)
+    tables = common.tables(5)
+    maps = []
+    for force in (1, 0, -1):
+        m = dsp.DSPMap(dsp.make_config(**cfg)); m.set_tables(*tables)
+        m.L.dspmap_init_device(m.h)
+        m.set_param(dsp.capi.P_PLACE_SPLIT_TILES, 1)
+        m.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, 2)
+        m.set_param(dsp.capi.P_SPARSE_SWEEP, force)
+        maps.append(m)
+    rng = np.random.default_rng(3)
+    ys, zs = np.meshgrid(np.linspace(-2.0, 2.0, 41), np.linspace(-0.7, 0.7, 15))
+    base = np.stack([np.full(ys.size, 2.3) + 0.2 * np.sin(2 * ys.ravel()), ys.ravel(), zs.ravel()], 1).astype(np.float32)
+    moved = 0
+    for f in range(36):
+        t = f / 30.0
+        pts = torch.from_numpy(base + rng.normal(0, 0.004, base.shape).astype(np.float32)).cuda()
+        pos = (0.9 * t, 0.5 * t, 0.1 * np.sin(5 * t))
+        for m in maps:
+            assert m.update_device(pts.data_ptr(), len(base), pos, t, quat) == 1
+        cs = [m.counters() for m in maps]
+        for c in cs:
+            c.pop("update_ms")
+        assert cs[0] == cs[1] == cs[2], (f, cs)
+        moved += cs[0]["n_moved"]
+        if f % 6 == 5:
+            futs = [m.getFutureStatus() for m in maps]
+            assert np.array_equal(futs[0], futs[1]) and np.array_equal(futs[0], futs[2]), f
+            assert futs[0].sum() > 0
+        if f % 3 != 2:
+            for m in maps:
+                m.clearOccupancyMapPrediction()
+    assert moved > 2000
+    assert maps[0].get_param(dsp.capi.P_SPARSE_SWEEP) == 1 and maps[1].get_param(dsp.capi.P_SPARSE_SWEEP) == 0
+    live_tiles = (maps[0].export_state()[0] // 64)
+    assert len(np.unique(live_tiles)) < 0.5 * (cfg["nx"] * cfg["ny"] * cfg["nz"] // 64)    # the map IS mostly empty tiles
+    ref = maps[0].export_state()
+    for m in maps[1:]:
+        for a, b in zip(ref, m.export_state()):
+            assert np.array_equal(a, b)
+        assert np.array_equal(maps[0].results(), m.results())
+    for m in maps:
+        m.close()
