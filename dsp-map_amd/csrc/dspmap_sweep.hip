@@ -638,21 +638,24 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
 template <int MW>
 __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, const float4* __restrict__ in_rec, int* __restrict__ in_cnt,
                                            const u64* __restrict__ omask,
-                                           float4* __restrict__ stage, const int BX) {
+                                           float4* __restrict__ stage, const int BX, const int n_all) {   // n_all = in_cnt[BX] > 0
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
-    __shared__ u64 s_cur[MW * 64], s_org[MW * 64], s_new[MW * 64];
+    __shared__ u64 s_cur[MW * 64], s_org[MW * 64], s_new[MW * 64], s_own[MW * 64];
     __shared__ int s_lcnt[64], s_loff[65];
     __shared__ int s_bk[PLACE_MAX];              // source keys of the arrivals, bucketed by destination lane
     __shared__ int s_cnt[2];
     const int tid = threadIdx.x;
-    const int n_all = in_cnt[BX];
-    if (n_all == 0) return;   // (nothing to reset: in_n is read for tiles with arrivals only, the counts below are the frame's)
     const bool was_live = s.tile_live[BX] != 0;   // an empty tile was skipped by k_predict: its omask words are stale (and zero in truth)
     const int cap = 64 * d.slots;
     const int n = min(n_all, cap);
     const bool in_lds = n <= PLACE_MAX;
     int* const gbk = reinterpret_cast<int*>(stage + (size_t)BX * cap * 2);   // (cap * 8 ints; cap are used)
+    const size_t base = (size_t)BX * cap;
+    // the first 256 records stay in registers across the phases (most tiles receive fewer): requested together with the
+    // occupancy words, one memory round trip
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), b0 = a0;
+    if (tid < n) { a0 = in_rec[(base + tid) * 2]; b0 = in_rec[(base + tid) * 2 + 1]; }
     for (int i = tid; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
     for (int i = tid; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
     if (tid < 64) {
@@ -661,8 +664,11 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
 #pragma unroll
         for (int e = 0; e < MW; ++e) {
             const bool in = lv < d.v_loc;
-            s_cur[e * 64 + tid] = in ? (s.mask[(size_t)lv * MW + e] | s.nbmask[(size_t)lv * MW + e]) : ~0ull;
-            s_org[e * 64 + tid] = in ? (was_live ? omask[(size_t)lv * MW + e] : 0ull) : ~0ull;
+            const u64 own = in ? s.mask[(size_t)lv * MW + e] : 0ull;
+            s_own[e * 64 + tid] = own;   // the voxel's occupancy word as the placement found it: nobody else writes it meanwhile
+            s_cur[e * 64 + tid] = in ? (own | s.nbmask[(size_t)lv * MW + e]) : ~0ull;
+            const u64 org = in ? omask[(size_t)lv * MW + e] : 0ull;   // (unconditional: the flag and the word arrive together)
+            s_org[e * 64 + tid] = in ? (was_live ? org : 0ull) : ~0ull;
             s_new[e * 64 + tid] = 0ull;
             if (in) {   // what k_place_fix needs should a pyramid list turn arrivals of this tile away: both occupancies as used here
                 s.pmask[(size_t)lv * MW + e] = s_cur[e * 64 + tid];
@@ -671,12 +677,8 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
         }
     }
     if (tid < 2) s_cnt[tid] = 0;
-    __syncthreads();
-    const size_t base = (size_t)BX * cap;
     int c_vf = tid == 0 ? n_all - n : 0, c_pf = 0;
-    // the first 256 records stay in registers across the phases (most tiles receive fewer): one memory round trip
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), b0 = a0;
-    if (tid < n) { a0 = in_rec[(base + tid) * 2]; b0 = in_rec[(base + tid) * 2 + 1]; }
+    __syncthreads();
     // bucket the arrivals' source keys by destination lane: counts, offsets, then every key into its lane's run
     for (int i = tid; i < n; i += 256) {
         const int gv = __float_as_int(i == tid ? a0.x : in_rec[(base + i) * 2].x);
@@ -804,7 +806,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
         const int lv = BX * 64 + tid;
 #pragma unroll
         for (int e = 0; e < MW; ++e)
-            if (s_new[e * 64 + tid]) s.mask[(size_t)lv * MW + e] = s.mask[(size_t)lv * MW + e] | s_new[e * 64 + tid];
+            if (s_new[e * 64 + tid]) s.mask[(size_t)lv * MW + e] = s_own[e * 64 + tid] | s_new[e * 64 + tid];
     }
     if (tid == 0) {
         in_cnt[BX] = 0; s.in_n[BX] = n; s.tile_live[BX] = 1;   // ready for the next frame; the tile holds particles now
@@ -814,7 +816,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
 }
 
 template <int MW>
-__global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const float4* __restrict__ in_rec,
+__global__ void __launch_bounds__(256, 7) k_place(MapDims d, DevState s, const float4* __restrict__ in_rec,
                                                int* __restrict__ in_cnt, int has_vz, int tab_n,
                                                const u64* __restrict__ omask, FilterParams fp, float4* __restrict__ child,
                                                int* __restrict__ vb_cnt, int* __restrict__ vb_idx, int nchild, int t0, int n0, int t1, int n1,
@@ -833,7 +835,8 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
         const int BX = bq < n0 ? t0 + bq : t1 + (bq - n0);   // tile index
         if (has_vz && BX == 0 && sel != 0 && threadIdx.x == 0)   // k_predict drew 3 table values per ranked particle (:655-657)
             s.fs->v_cur = (int)(((long long)s.fs->v_cur + 3ll * (long long)s.fs->occupied_count) % tab_n);
-        if (sload_i(in_cnt + BX) == 0) continue;   // (no arrivals -- or the tile's owner is done with them)
+        const int n_in = sload_i(in_cnt + BX);
+        if (n_in == 0) continue;   // (no arrivals -- or the tile's owner is done with them)
         if (sel >= 0) {   // a split placement: the other launch owns the tiles of the other kind
             const int tf = tile_fov[BX];
             int fv = tf & 1;
@@ -841,7 +844,7 @@ __global__ void __launch_bounds__(256) k_place(MapDims d, DevState s, const floa
             if ((tf >> 1) != s.fpar->epoch) fv = tile_view_test(d, s, BX, lane_id());
             if ((fv != 0) != (sel != 0)) continue;
         }
-        place_tile<MW>(d, s, in_rec, in_cnt, omask, stage, BX);
+        place_tile<MW>(d, s, in_rec, in_cnt, omask, stage, BX, n_in);   // (the owner's view of in_cnt is stable: only the owner resets it)
         __syncthreads();   // the tile's LDS tables are re-used by the next one
     }
 }
