@@ -361,8 +361,8 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&s.pmask, W)); HIPCHK(m, dalloc(&s.ta, W)); HIPCHK(m, dalloc(&s.dflag, (size_t)d.v_loc)); HIPCHK(m, dalloc(&s.dirty, (size_t)DSP_DIRTY_CAP));
     HIPCHK(m, hipMemset(s.pmask, 0, sizeof(u64) * W)); HIPCHK(m, hipMemset(s.ta, 0, sizeof(u64) * W)); HIPCHK(m, hipMemset(s.dflag, 0, sizeof(int) * (size_t)d.v_loc));
     k.ro_rec = k.mv_rec;   // k_predict's staging area is dead once k_predict has ended: k_resample -> k_rollout reuse it
-    HIPCHK(m, dalloc(&k.ro_cnt, ntiles));
-    HIPCHK(m, hipMemset(k.ro_cnt, 0, sizeof(int) * ntiles));
+    HIPCHK(m, dalloc(&k.ro_cnt, 2 * ntiles));   // [ntiles] counts, then [ntiles] the float bits of the tiles' moving weight
+    HIPCHK(m, hipMemset(k.ro_cnt, 0, sizeof(int) * 2 * ntiles));
     HIPCHK(m, dalloc(&k.omask, W));
     HIPCHK(m, hipMemset(k.omask, 0, sizeof(u64) * W));
     HIPCHK(m, dalloc(&k.ck_items, (size_t)d.np * ((d.capp + 63) / 64 + 1)));

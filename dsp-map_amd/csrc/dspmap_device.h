@@ -56,6 +56,11 @@ __device__ __forceinline__ int wave_incl_scan_i(int v) {
 __device__ __forceinline__ float wave_sum(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_incl_scan(v)), 63));
 }
+__device__ __forceinline__ float wave_sum_f(float v) {   // butterfly: the same order on every run, the total in every lane
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
 __device__ __forceinline__ int wave_sum_i(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_i(v), 63); }
 
 // Wave-aggregated "append": every active lane gets a distinct position in the

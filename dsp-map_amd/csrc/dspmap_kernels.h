@@ -28,7 +28,7 @@ struct KernelScratch {
                         // to be all zero (every frame after a resampling).  Non-null after a constructor pre-fill / an import of
                         // flag-15 records / a second birth stage without resampling: addAParticle (:1184-1185) skips those slots
     float4* ro_rec;     // [ntiles][64*slots][2] the tile's MOVING old particles {px, py, vx, vy}, {w, local voxel} (k_resample -> k_rollout)
-    int* ro_cnt;        // [ntiles]
+    int* ro_cnt;        // [2 * ntiles] per tile: records in ro_rec; then the float bits of their summed weight
     int* work_list;     // [v_loc] scratch: per-voxel prefix of the constructor-seeded particles' noise ranks (k_vz_count)
     int ntiles;         // tiles of 64 voxels; k_predict / k_place run one workgroup per tile
     int nblk_sweep;

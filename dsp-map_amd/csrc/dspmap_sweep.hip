@@ -895,6 +895,7 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
     }
     // every live weight row of the tile -> LDS, all loads in flight together
     int nmv = 0;   // moving old particles of the tile noted for k_rollout so far (wave-uniform)
+    float mvw = 0.f;   // ... and this lane's share of their weight (k_rollout scales its fixed-point windows with the total)
     const size_t ro_base = (size_t)wave_g * 64 * d.slots;
     int n = 0, n_old = 0;
     float wsum = 0.f, vxs = 0.f, vys = 0.f, stat_w = 0.f;
@@ -970,13 +971,15 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
                         const size_t o = (ro_base + nmv + (int)__popcll(mb & lanemask_lt())) * 2;
                         ro_rec[o] = make_float4(mpx[r], mpy[r], vx[r], vy[r]);
                         ro_rec[o + 1] = make_float4(wr[r], __int_as_float(lv), 0.f, 0.f);
+                        mvw += wr[r];
                     }
                     nmv += (int)__popcll(mb);
                 }
             }
         }
     }
-    if (l == 0) ro_cnt[wave_g] = nmv;
+    if (nmv) mvw = wave_sum_f(mvw);
+    if (l == 0) { ro_cnt[wave_g] = nmv; ro_cnt[((d.v_loc + 63) >> 6) + wave_g] = __float_as_int(mvw); }
     if (inr) {
         float4 res = make_float4(wsum, 0.f, 0.f, 0.f);  // voxels_objects_number[v][0..3] :974-984
         if (n_old > 0) { res.y = __fdiv_rn(vxs, (float)n_old); res.z = __fdiv_rn(vys, (float)n_old); }
@@ -1108,6 +1111,7 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
     __shared__ int s_ncp[64];
     __shared__ float s_wcp[64];
     __shared__ int s_nmv;
+    __shared__ float s_mvw[4];   // weight of the moving old particles each wave noted
     const int l = lane_id();
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1183,6 +1187,7 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
     const u64 surv = s_surv[l];   // the voxel's survivors, all rows
     const size_t ro_base = (size_t)BX * cells;
     u64 oldc_mine = 0ull;
+    float mvw = 0.f;
 #pragma unroll
     for (int r = 0; r < RWB; ++r) {
         if (row[r] < 0) continue;
@@ -1203,8 +1208,11 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
             const size_t o = (ro_base + k) * 2;
             ro_rec[o] = make_float4(pq[r].x, pq[r].y, vx, vy);
             ro_rec[o + 1] = make_float4(wr[r], __int_as_float(lv), 0.f, 0.f);
+            mvw += wr[r];
         }
     }
+    mvw = wave_sum_f(mvw);
+    if (l == 0) s_mvw[wave] = mvw;
     if (oldc_mine) atomicOr(&s_oldc[l], oldc_mine);
     __syncthreads();
 #ifdef RESAMPLE_PROF
@@ -1212,7 +1220,7 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
 #endif
     // ---- phase 2: one lane per voxel over its own n entries, LDS only
     if (wave == 0) {
-        if (l == 0) ro_cnt[BX] = s_nmv;
+        if (l == 0) { ro_cnt[BX] = s_nmv; ro_cnt[((d.v_loc + 63) >> 6) + BX] = __float_as_int((s_mvw[0] + s_mvw[1]) + (s_mvw[2] + s_mvw[3])); }
         const u64 oldc = s_oldc[l];
         const int n = (int)__popcll(surv);
         int nmax = n;
@@ -1371,17 +1379,32 @@ __global__ void __launch_bounds__(RO_TPB) k_rollout(MapDims d, DevState s, const
     // group's particles reach at a design speed -- halo[t] rows of the grid either side -- so that the footprints of the group's
     // tiles, which overlap almost completely, cost ONE global atomic per touched cell and horizon; faster particles fall outside
     // and take the single-atomic path.  Windows are flushed with coalesced atomics onto the horizon-major accumulators.
-    extern __shared__ float s_win[];
+    // The windows are FIXED-POINT (unsigned, 2^kexp per unit of weight): ds_add_f32 runs at a third of a lane per clock and CU
+    // on this chip, ds_add_u32 eight times faster (tools/micro/lds_atomic_bench.hip), and integer sums do not depend on the order of
+    // the adds.  No cell can receive more than the group's whole moving weight W (k_resample's per-tile sums), so the scale is the
+    // largest power of two with W * 2^kexp < 2^31: a resolution of W * 2^-31 per add, finer than a float accumulator's.
+    extern __shared__ unsigned s_win[];
     __shared__ int s_cnt[RO_G + 1];
+    __shared__ float s_wtot;
     const int G0 = (int)blockIdx.x * RO_G;
     const int ng = min(RO_G, ntiles - G0);
     const int tid = threadIdx.x;
     if (tid < RO_G) s_cnt[tid] = tid < ng ? ro_cnt[G0 + tid] : 0;
     __syncthreads();
-    if (tid == 0) { int t = 0; for (int k = 0; k < RO_G; ++k) { const int c = s_cnt[k]; s_cnt[k] = t; t += c; } s_cnt[RO_G] = t; }   // exclusive prefix
+    if (tid == 0) {
+        int t = 0; float w = 0.f;
+        for (int k = 0; k < RO_G; ++k) {   // exclusive prefix of the counts; the weights in tile order
+            const int c = s_cnt[k]; s_cnt[k] = t; t += c;
+            if (c > 0) w += __int_as_float(ro_cnt[ntiles + G0 + k]);
+        }
+        s_cnt[RO_G] = t; s_wtot = w;
+    }
     __syncthreads();
     const int total = s_cnt[RO_G];
     if (total == 0) return;
+    int kexp = 0;
+    { int e; (void)frexpf(fmaxf(s_wtot, 1e-30f), &e); kexp = 31 - e; }   // W < 2^e
+    const float fscale = ldexpf(1.f, kexp), finv = ldexpf(1.f, -kexp);
     const int T = d.T;
     const int zc = d.ny * d.nx;
     const int cap = 64 * d.slots;
@@ -1396,10 +1419,11 @@ __global__ void __launch_bounds__(RO_TPB) k_rollout(MapDims d, DevState s, const
     };
     const bool dense = total >= RO_DENSE;
     const int ncell = pl.woff[T];
-    if (dense) for (int i = tid; i < ncell; i += RO_TPB) s_win[i] = 0.f;
+    if (dense) for (int i = tid; i < ncell; i += RO_TPB) s_win[i] = 0u;
     __syncthreads();
     for (int it0 = tid; it0 < total; it0 += RO_TPB * 3) {   // three particles per step: their records are requested together
         float4 a[3], b[3];
+        unsigned wq[3];
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             a[u] = make_float4(0.f, 0.f, 0.f, 0.f); b[u] = a[u];
@@ -1409,6 +1433,7 @@ __global__ void __launch_bounds__(RO_TPB) k_rollout(MapDims d, DevState s, const
         for (int u = 0; u < 3; ++u) {
             if (it0 + u * RO_TPB >= total) continue;
             const int lbase = ((__float_as_int(b[u].y) + d.v_base) / zc) * zc - d.v_base;   // voxel (x 0, y 0) of the particle's layer: it never changes (vz == 0)
+            wq[u] = __float2uint_rn(b[u].x * fscale);
             for (int t = 0; t < T; ++t) {
                 const float pt = d.pred_t[t];
                 const float fx = a[u].x + a[u].z * pt;      // :954-955
@@ -1419,7 +1444,7 @@ __global__ void __launch_bounds__(RO_TPB) k_rollout(MapDims d, DevState s, const
                 const int dl = lbase + (int)__umul24((unsigned)yi, (unsigned)d.nx) + xi;
                 if (dl < 0 || dl >= d.v_loc) continue;
                 const int off = dl - (G0 * 64 - pl.halo[t] * d.nx);
-                if (dense && off >= 0 && off < pl.woff[t + 1] - pl.woff[t]) atomicAdd(&s_win[pl.woff[t] + off], b[u].x);
+                if (dense && off >= 0 && off < pl.woff[t + 1] - pl.woff[t]) atomicAdd(&s_win[pl.woff[t] + off], wq[u]);
                 else { unsafeAtomicAdd(&s.fut[(size_t)t * V + dl], b[u].x); s.fut_dirty[dl >> 6] = 1; }
             }
         }
@@ -1430,8 +1455,8 @@ __global__ void __launch_bounds__(RO_TPB) k_rollout(MapDims d, DevState s, const
         const int w0 = pl.woff[t], wn = pl.woff[t + 1] - w0;
         const int g0 = G0 * 64 - pl.halo[t] * d.nx;   // local voxel index of the window's first cell (cells outside the slab stay zero)
         for (int i = tid; i < wn; i += RO_TPB) {
-            const float v = s_win[w0 + i];
-            if (v != 0.f) { unsafeAtomicAdd(&s.fut[(size_t)t * V + g0 + i], v); s.fut_dirty[(g0 + i) >> 6] = 1; }
+            const unsigned q = s_win[w0 + i];
+            if (q) { unsafeAtomicAdd(&s.fut[(size_t)t * V + g0 + i], (float)q * finv); s.fut_dirty[(g0 + i) >> 6] = 1; }
         }
     }
 }
