@@ -120,7 +120,7 @@ def test_rollout_ten_horizons_on_config_d_grid_shape(dsp, orc):
     o.close(); m.close()
 
 
-def _group_vs_full(dsp, world, cfg, frames, seed=3):
+def _group_vs_full(dsp, world, cfg, frames, seed=3, sparse=None):
     """the C++ frame driver over `world` slabs in one process and the unsharded map, both with the DEVICE velocity
     estimator in the frame, fed the same frames: every slot and every float must be equal"""
     sharded = __import__("dsp-map_amd.sharded", fromlist=["CppGroup"])
@@ -130,6 +130,10 @@ def _group_vs_full(dsp, world, cfg, frames, seed=3):
     for x in grp.maps + [full]:
         x.set_tables(*tables)
         x.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, 2)
+    if sparse is not None:          # the slabs run k_predict's SPARSE variant, the unsharded map the other one
+        for x in grp.maps:
+            x.set_param(dsp.capi.P_SPARSE_SWEEP, sparse)
+        full.set_param(dsp.capi.P_SPARSE_SWEEP, 1 - sparse)
     clouds = []
     for pts, pos, t, q in frames:
         d = torch.from_numpy(np.ascontiguousarray(pts, np.float32)).cuda()
@@ -439,3 +443,20 @@ def test_sparse_sweep_variant_changes_nothing(dsp, quat):
         assert np.array_equal(maps[0].results(), m.results())
     for m in maps:
         m.close()
+
+
+@pytest.mark.gpu
+def test_sharded_frame_with_the_sparse_sweep_variant(dsp):
+    """the slabs of a sharded map run k_predict's SPARSE variant (empty tiles are left after one scalar load; arrivals into
+    skipped tiles -- also those imported from the neighbouring slab -- have their view tested by k_place), the unsharded map
+    the dense one: the depth stream from an empty map through 4 slabs, 10 frames, == unsharded, bit for bit"""
+    scene_mod = __import__("dsp-map_amd.scene", fromlist=["CorridorScene"])
+    cfg = dict(nx=66, ny=66, nz=40, res=0.15, ppv=24)
+    sc = scene_mod.CorridorScene(66 * 0.15, 66 * 0.15, 40 * 0.15, seed=77, device="cuda")
+    frames = []
+    for f in range(10):
+        t = f / 30.0
+        pts_t, pos, quat = sc.frame(t)
+        frames.append((pts_t.cpu().numpy().copy(), pos, t, quat))
+    clouds, rec, holding = _group_vs_full(dsp, 4, cfg, frames, seed=9, sparse=1)
+    assert holding >= 2 and len(rec) > 20000
