@@ -167,7 +167,7 @@ static void free_dev(dspmap* m) {
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, s.fov_rec, s.fov_slot, s.fov_key, s.fov_spos, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt, s.in_n, s.pmask, s.ta, s.dflag, s.dirty,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.ro_cnt, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
-                    m->k.part_predict, m->k.tile_fov, s.tile_live, s.fut_dirty, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf};
+                    m->k.part_predict, m->k.tile_fov, s.tile_live, s.fut_dirty, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf, s.birth_cvr};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
     if (m->nbsnap_buf) chk(hipFree(m->nbsnap_buf), "hipFree");
     {
@@ -267,7 +267,7 @@ int dspmap_ensure_point_cap(dspmap* m, int n) {
     const int cap = n + n / 2 + 1024;
     if (m->mgpu_bound && !m->mgpu_self_bound) return dspmap_fail(m, DSPMAP_E_ARG, "%d points exceed the capacity bound with dspmap_mgpu_bind", n);
     BirthSrc* old_birth = s.birth;   // holds the cloud of the last non-empty view (re-used by frames with an empty one): carried over
-    void* olds[] = {s.pt_rot, s.pt_pyr, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, m->pts_dev, m->k.child, m->k.part_birth, s.birth_ovf};
+    void* olds[] = {s.pt_rot, s.pt_pyr, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, m->pts_dev, m->k.child, m->k.part_birth, s.birth_ovf, s.birth_cvr};
     for (void* p : olds) if (p) (void)hipFree(p);
     HIPCHK(m, dalloc(&s.pt_rot, (size_t)cap));
     HIPCHK(m, dalloc(&s.pt_pyr, (size_t)cap));
@@ -280,6 +280,7 @@ int dspmap_ensure_point_cap(dspmap* m, int n) {
     HIPCHK(m, dalloc(&s.plan_pbase, (size_t)cap));
     HIPCHK(m, dalloc(&s.plan_inside, (size_t)cap));
     HIPCHK(m, dalloc(&s.nstatic, (size_t)cap));
+    HIPCHK(m, dalloc(&s.birth_cvr, (size_t)cap + (size_t)cap / 16 + 2));
     HIPCHK(m, dalloc(&m->pts_dev, (size_t)cap * 3));
     HIPCHK(m, dalloc(&m->k.child, (size_t)cap * 32));
     HIPCHK(m, dalloc(&s.birth_ovf, (size_t)cap * 32));

@@ -836,8 +836,12 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
 // k_birth_split: one wave per source point.  Dempster-Shafer static/dynamic
 // split from the mass already in the point's voxel (:827-866), lanes = slots.
 // --------------------------------------------------------------------------
-__device__ __forceinline__ void birth_split_wave(const MapDims& d, const DevState& s, const FilterParams& fp, int i) {
+// cvr (whole frame, the children are done): also the point's draws from the velocity table / the rand() stream (:884-886,
+// :895-897: three per child inside the map beyond the static ones, by branch) -- what k_birth_cursors would count, for the
+// insertion kernel that computes its cursors itself
+__device__ __forceinline__ void birth_split_wave(const MapDims& d, const DevState& s, const FilterParams& fp, int i, int2* cvr = nullptr) {
     const BirthView bv = birth_view(s);
+    if (cvr) *cvr = make_int2(0, 0);
     if (i >= bv.n) return;
     const int l = lane_id();
     const BirthSrc src = birth_at(bv, i);
@@ -877,6 +881,14 @@ __device__ __forceinline__ void birth_split_wave(const MapDims& d, const DevStat
     }
     pl.n_static = n_static;
     if (l == 0) { s.plan[i] = pl; s.nstatic[i] = n_static; }
+    if (cvr && ok && src.intensity > 0.01f) {
+        const unsigned inside = s.plan_inside[i];
+        const int nb = fp.nb_num;
+        const int model_end = src.nx > -100.f ? fp.model_nb : n_static;  // :881
+        auto below = [](int k) { return k >= 32 ? ~0u : ((1u << k) - 1u); };   // bits [0, k)
+        const int lo = min(n_static, nb), mid = min(max(model_end, lo), nb);
+        *cvr = make_int2(3 * __popc(inside & below(mid) & ~below(lo)), 3 * __popc(inside & below(nb) & ~below(mid)));
+    }
 }
 __global__ void k_birth_split(MapDims d, DevState s, FilterParams fp) {
     birth_split_wave(d, s, fp, (int)(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE));
@@ -999,15 +1011,47 @@ __device__ __forceinline__ float rand_float(const DevState& s, const FilterParam
 
 // k_birth_insert: one thread per (source point, child): velocity by branch (:877-903); vz = 0
 // (:905-907); weight = the global newborn weight (:909); newborn flag (= nbmask bit).
-__global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, const float4* __restrict__ child,
+// FUSED: the cursors of the point's draws (k_birth_cursors' job) are computed here, from the draw counts k_birth_split_cksum_cvr
+// left: the sums of the split's workgroups before this block's first point (a block-wide reduction over at most a few hundred
+// entries) plus the points in between.  Block 0 writes the new cursors; everybody reads the copies taken before the births.
+template <bool FUSED>
+__global__ void __launch_bounds__(256) k_birth_insert(MapDims d, DevState s, FilterParams fp, const float4* __restrict__ child,
                                const int* __restrict__ vb_cnt, const int* __restrict__ vb_idx, int* __restrict__ part_birth,
-                               const u64* __restrict__ nbsnap) {
+                               const u64* __restrict__ nbsnap, int wg_off) {
     const BirthView bv = birth_view(s);
     const int n_birth = bv.n;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int nb = fp.nb_num;
     const int i = t / nb, k = t - i * nb;
     bool born = false, dropped = false;
+    int f_vbase = 0, f_rbase = 0;
+    if (FUSED) {
+        __shared__ int s_part[4][4];
+        const int tid = (int)threadIdx.x;
+        const int i_first = (int)((blockIdx.x * blockDim.x) / (unsigned)nb);
+        const int G = min(i_first, n_birth) >> 4;     // workgroups of the split (16 points each) wholly before this block's first point
+        const int ngr = (n_birth + 15) >> 4;
+        int acc[4] = {0, 0, 0, 0};                    // {velocity draws before, rand() draws before, all velocity draws, all rand() draws}
+        for (int g = tid; g < ngr; g += 256) {
+            const int2 w = s.birth_cvr[wg_off + g];
+            acc[2] += w.x; acc[3] += w.y;
+            if (g < G) { acc[0] += w.x; acc[1] += w.y; }
+        }
+        int2 loc = make_int2(0, 0);
+        for (int j = G << 4; j < min(i, n_birth); ++j) { const int2 c = s.birth_cvr[j]; loc.x += c.x; loc.y += c.y; }   // (at most 15 + 256 / nb points)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { acc[q] = wave_sum_i(acc[q]); if (lane_id() == 0) s_part[tid >> 6][q] = acc[q]; }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = (s_part[0][q] + s_part[1][q]) + (s_part[2][q] + s_part[3][q]);
+        const int v0 = s.fs->v_cur_in, r0 = s.fs->r_cur_in;
+        f_vbase = (int)(((long long)v0 + acc[0] + loc.x) % fp.tab_n);
+        f_rbase = (int)(((long long)r0 + acc[1] + loc.y) % max(fp.rtab_n, 1));
+        if (t == 0) {
+            s.fs->v_cur = (int)(((long long)v0 + acc[2]) % fp.tab_n);
+            s.fs->r_cur = (int)(((long long)r0 + acc[3]) % max(fp.rtab_n, 1));
+        }
+    }
     if (bv.live && t == 0) s.fs->stale_n = n_birth;
     if (i < n_birth) {
         // this kernel is a chain of dependent loads: everything that only needs (i, t) is requested at once, then
@@ -1034,13 +1078,13 @@ __global__ void k_birth_insert(MapDims d, DevState s, FilterParams fp, const flo
                     const unsigned before = pl_inside & lo_mask;  // inside children in [n_static, k)
                     if (k < model_end) {
                         const int rank = __popc(before);
-                        const int cv = (int)(((long long)pl.vbase + 3 * rank) % fp.tab_n);
+                        const int cv = (int)(((long long)(FUSED ? f_vbase : pl.vbase) + 3 * rank) % fp.tab_n);
                         vx = src.nx + 4 * s.v_tab[cv];                        // :884
                         vy = src.ny + 4 * s.v_tab[(cv + 1) % fp.tab_n];      // :885
                     } else {
                         const unsigned model_bits = (model_end >= 32) ? ~0u : ((1u << model_end) - 1u);
                         const int rank = __popc(before & ~model_bits);
-                        const int cr = pl.rbase + 3 * rank;
+                        const int cr = (FUSED ? f_rbase : pl.rbase) + 3 * rank;
                         vx = rand_float(s, fp, cr, -1.5f, 1.5f);              // :895
                         vy = rand_float(s, fp, cr + 1, -1.5f, 1.5f);          // :896
                     }
@@ -1232,12 +1276,13 @@ __global__ void k_copy_u64(const u64* __restrict__ src, u64* __restrict__ dst, s
     if (i < n) dst[i] = src[i];
 }
 // k_birth_insert, preceded by the snapshot of the newborn bits when earlier newborns may exist (c.k.nbsnap != nullptr)
-static void launch_insert(const LaunchCtx& c, unsigned gb) {
+static void launch_insert(const LaunchCtx& c, unsigned gb, bool fused = false) {
     if (c.k.nbsnap) {
         const size_t W = (size_t)c.d.v_loc * c.d.mw;
         hipLaunchKernelGGL(k_copy_u64, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, c.stream, c.s.nbmask, c.k.nbsnap, W);
     }
-    hipLaunchKernelGGL(k_birth_insert, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx, c.k.part_birth, c.k.nbsnap);
+    if (fused) hipLaunchKernelGGL(k_birth_insert<true>, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx, c.k.part_birth, c.k.nbsnap, c.birth_cap);
+    else hipLaunchKernelGGL(k_birth_insert<false>, dim3(gb), dim3(256), 0, c.stream, c.d, c.s, c.fp, c.k.child, c.k.vb_cnt, c.k.vb_idx, c.k.part_birth, c.k.nbsnap, c.birth_cap);
 }
 static void birth_children_insert(const LaunchCtx& c, int n_birth_grid, bool in_frame, bool all_static);
 void launch_birth_plan_insert(const LaunchCtx& c, int n_birth_grid, bool in_frame, bool all_static) {
@@ -1264,6 +1309,29 @@ __global__ void __launch_bounds__(1024) k_birth_split_cksum(MapDims d, DevState 
         ck_sum_block(d, s, fp, s_red);
     } else birth_split_wave(d, s, fp, (int)(blockIdx.x * (1024 / WAVE) + threadIdx.x / WAVE));
 }
+// ... and, for the insertion kernel that computes the velocity-table / rand() cursors itself (one launch less: a kernel of this
+// chain costs ~5 us however little it does): every point's draw counts, their sums per workgroup (16 points), and a copy of the
+// two cursors as they stand before the frame's births
+__global__ void __launch_bounds__(1024) k_birth_split_cksum_cvr(MapDims d, DevState s, FilterParams fp, int wg_off) {
+    __shared__ int2 s_c[1024 / WAVE];
+    if (blockIdx.x == gridDim.x - 1) {
+        __shared__ float s_red[512];
+        ck_sum_block(d, s, fp, s_red);
+        if (threadIdx.x == 0) { s.fs->v_cur_in = s.fs->v_cur; s.fs->r_cur_in = s.fs->r_cur; }
+        return;
+    }
+    const int wave = (int)threadIdx.x / WAVE;
+    const int i = (int)(blockIdx.x * (1024 / WAVE)) + wave;
+    int2 c;
+    birth_split_wave(d, s, fp, i, &c);
+    if (lane_id() == 0) { s_c[wave] = c; if (i < birth_view(s).n) s.birth_cvr[i] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int2 t = make_int2(0, 0);
+        for (int w = 0; w < 1024 / WAVE; ++w) { t.x += s_c[w].x; t.y += s_c[w].y; }
+        s.birth_cvr[wg_off + blockIdx.x] = t;
+    }
+}
 // split-phase (multi-GPU) frame: rank + children as soon as the prediction is queued (they only need the birth cloud; the
 // driver's host synchronisation for the neighbour exchange leaves the GPU idle right there), cursors + insert at the end
 void launch_birth_early(const LaunchCtx& c, int n_birth_grid, bool with_rank) {   // with_rank = false: it rode on k_predict's launch
@@ -1284,9 +1352,13 @@ void launch_birth_split_cksum(const LaunchCtx& c, int n_birth_grid) {
 void launch_birth_late(const LaunchCtx& c, int n_birth_grid, bool all_static) {
     if (n_birth_grid <= 0) return;
     const unsigned gb = (unsigned)(((long long)n_birth_grid * c.fp.nb_num + 255) / 256);
-    launch_birth_split_cksum(c, n_birth_grid);
-    if (!all_static) hipLaunchKernelGGL(k_birth_cursors, dim3(1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
-    launch_insert(c, gb);
+    if (all_static) {   // (no child draws from the velocity or rand() streams: no cursors)
+        launch_birth_split_cksum(c, n_birth_grid);
+        launch_insert(c, gb);
+    } else {            // the children are done (they rode on earlier launches): the insertion computes its cursors itself
+        hipLaunchKernelGGL(k_birth_split_cksum_cvr, dim3((n_birth_grid + 15) / 16 + 1), dim3(1024), 0, c.stream, c.d, c.s, c.fp, c.birth_cap);
+        launch_insert(c, gb, true);
+    }
 }
 void launch_birth(const LaunchCtx& c, int n_birth_grid, bool in_frame, bool all_static) {
     if (n_birth_grid <= 0) return;

@@ -90,6 +90,7 @@ struct FrameScalars {
     int n_overflow_inexact; // diagnostics: voxels / arrivals the re-slotting pass could not treat exactly (see k_place_fix)
     int live_acc, live_hint;   // every 64th tile that k_resample leaves non-empty counts itself in live_acc; the next frame's first kernel
                                // moves the count to live_hint: k_predict's estimate of how sparse the map is (a hint, never a result)
+    int v_cur_in, r_cur_in;    // the velocity-table / rand() cursors before the frame's births (the fused insertion reads these, one workgroup writes the new ones)
     int n_place_vf, n_place_pf;   // arrivals k_place turned away: voxel full (:1227-1229) / pyramid list full (:1256-1259)
     int n_pyr_removed;  // particles k_pyr_prepare turned away because their pyramid's list was full (-2, :1256-1259)
     float expected_newborn;  // expected_new_born_objects :292
@@ -159,6 +160,8 @@ struct DevState {
     // birth
     struct BirthSrc* birth; // [birth_cap]
     struct BirthPlan* plan; // [birth_cap]
+    int2* birth_cvr;        // [birth_cap] draws of the point's children from the velocity table / the rand() stream (x, y); then, from
+                            // index birth_cap on, the sums over the 16 points of each workgroup of the split (the fused insertion's prefix)
     unsigned* plan_inside;  // [birth_cap] bit k = child k of the point lies inside the map (:875), k_birth_children
     int* plan_pbase;        // [birth_cap] position-table cursor of each source point (k_birth_rank; kept apart from `plan`
                             // so that the rank and the split can run in the same launch)
