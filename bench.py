@@ -30,6 +30,8 @@ WORKLOADS = {
     "A": dict(nx=66, ny=66, nz=40, res=0.15, ppv=9, sat=False),
     "B": dict(nx=66, ny=66, nz=40, res=0.15, ppv=24, sat=False),
     "B_sat": dict(nx=66, ny=66, nz=40, res=0.15, ppv=24, sat=True),
+    # the metric's grid saturated with moving particles (every particle +-1 m/s): the worst case of the inline rollout of small maps
+    "B_mov": dict(nx=66, ny=66, nz=40, res=0.15, ppv=24, sat=True, vmax=1.0),
     "C": dict(nx=132, ny=132, nz=60, res=0.15, ppv=24, sat=False),
     "C_sat": dict(nx=132, ny=132, nz=60, res=0.15, ppv=24, sat=True),
     "E": dict(nx=264, ny=264, nz=80, res=0.10, ppv=36, sat=False),

@@ -19,7 +19,7 @@ OK, REJECTED = 1, 0
 
 P_POSITION_STDDEV, P_VELOCITY_STDDEV, P_OBSERVATION_STDDEV, P_NEWBORN_WEIGHT, P_NEWBORN_NUMBER, \
     P_VOXEL_FILTER_RES, P_KAPPA, P_DETECTION, P_VELOCITY_ESTIMATOR, P_REGENERATE_TABLES, P_USE_GRAPH, P_OCCLUSION_MARGIN, \
-    P_PAIR_CULL_SIGMAS, P_UPDATE_TIME, P_UPDATE_COUNTER, P_PLACE_SPLIT_TILES, P_FAST_DIVISION, P_SPARSE_SWEEP = range(1, 19)
+    P_PAIR_CULL_SIGMAS, P_UPDATE_TIME, P_UPDATE_COUNTER, P_PLACE_SPLIT_TILES, P_FAST_DIVISION, P_SPARSE_SWEEP, P_ROLLOUT_INLINE = range(1, 20)
 
 
 class Config(C.Structure):

@@ -60,6 +60,13 @@ LaunchCtx dspmap_ctx_of(dspmap* m) {
         else if (m->sparse_mode && est * 2 > m->k.ntiles) m->sparse_mode = false;
     }
     c.sparse = m->sparse_mode;
+    if (m->ro_force >= 0) m->ro_kernel = m->ro_force == 0;
+    else if (m->hint_host) {
+        const int heavy = m->hint_host[1];
+        if (!m->ro_kernel && heavy * 32 > m->k.ntiles) m->ro_kernel = true;
+        else if (m->ro_kernel && heavy * 128 < m->k.ntiles) m->ro_kernel = false;
+    }
+    c.ro_inline = !m->ro_kernel;
     return c;
 }
 
@@ -309,8 +316,9 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, hipHostMalloc((void**)&m->ring_host, sizeof(FrameParams) * DSPMAP_RING, hipHostMallocMapped));
     memset(m->ring_host, 0, sizeof(FrameParams) * DSPMAP_RING);
     { void* dp = nullptr; HIPCHK(m, hipHostGetDevicePointer(&dp, m->ring_host, 0)); m->ring_dev = (const FrameParams*)dp; }
-    HIPCHK(m, hipHostMalloc((void**)&m->hint_host, sizeof(int), hipHostMallocMapped));
-    *m->hint_host = 1 << 24;   // (nothing known yet: not sparse)
+    HIPCHK(m, hipHostMalloc((void**)&m->hint_host, 2 * sizeof(int), hipHostMallocMapped));
+    m->hint_host[0] = 1 << 24;   // (nothing known yet: not sparse)
+    m->hint_host[1] = 0;
     { void* dp = nullptr; HIPCHK(m, hipHostGetDevicePointer(&dp, (void*)m->hint_host, 0)); m->s.hint_out = (int*)dp; }
     HIPCHK(m, hipMalloc((void**)&m->s.ring_seq, sizeof(int)));
     HIPCHK(m, hipMemset(m->s.ring_seq, 0, sizeof(int)));
@@ -504,6 +512,7 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
             m->use_vel_est = (int)v; break;
         case DSPMAP_P_USE_GRAPH: m->use_graph = v != 0; break;
         case DSPMAP_P_SPARSE_SWEEP: m->sparse_force = v < 0 ? -1 : (v != 0 ? 1 : 0); break;
+        case DSPMAP_P_ROLLOUT_INLINE: m->ro_force = v < 0 ? -1 : (v != 0 ? 1 : 0); break;
         case DSPMAP_P_FAST_DIVISION: if (v == 0) { m->d.div_ok = 0; m->div_forced_off = true; m->graph_epoch++; } break;
         case DSPMAP_P_PLACE_SPLIT_TILES: m->place_split_tiles = v < 1 ? 1 : (v > 2e9 ? 2000000000 : (int)v); m->graph_epoch++; break;
         case DSPMAP_P_OCCLUSION_MARGIN: m->fp.occl_margin = (float)v; break;
@@ -537,6 +546,7 @@ extern "C" double dspmap_get_param(const dspmap_t* m, int key) {
         case DSPMAP_P_UPDATE_COUNTER: return m->update_counter;
         case DSPMAP_P_PLACE_SPLIT_TILES: return m->place_split_tiles;
         case DSPMAP_P_SPARSE_SWEEP: return m->sparse_mode ? 1 : 0;
+        case DSPMAP_P_ROLLOUT_INLINE: return m->ro_kernel ? 0 : 1;
         case DSPMAP_P_FAST_DIVISION: return m->d.div_ok;
         default: return 0;
     }
@@ -904,7 +914,7 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
     if (timed) HIPCHK(m, hipEventRecord(m->ev0, m->stream));
     if (m->use_graph && !m->prof) {
         // the kernel arguments of a frame are constant (per-frame values live in s.fpar): capture once, replay
-        const unsigned long long key = ((unsigned long long)m->graph_epoch << 8) | (has_vz ? 1u : 0u) | ((unsigned)mode << 1) | (c.sparse ? 8u : 0u);
+        const unsigned long long key = ((unsigned long long)m->graph_epoch << 8) | (has_vz ? 1u : 0u) | ((unsigned)mode << 1) | (c.sparse ? 8u : 0u) | (c.ro_inline ? 16u : 0u);
         if (!m->graph_exec || m->graph_key != key) {
             if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
             if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }

@@ -91,6 +91,8 @@ struct dspmap {
     hipEvent_t ring_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ring_ev_set[4] = {false, false, false, false};
     volatile int* hint_host = nullptr;   // written by the device at every frame's start: 1-in-64 sample count of the non-empty tiles
+    bool ro_kernel = false;          // small maps: launch k_rollout (many tiles hold hundreds of moving particles) instead of the inline rollout
+    int ro_force = -1;               // DSPMAP_P_ROLLOUT_INLINE: -1 from the hint, 0 / 1 forced
     bool sparse_mode = false;        // launch k_predict's SPARSE variant (dspmap_pick_sweep_mode: from the hint, with hysteresis)
     int sparse_force = -1;           // DSPMAP_P_SPARSE_SWEEP: -1 from the hint, 0 / 1 forced
     int place_split_tiles = 8192;    // maps with at least this many tiles place the arrivals of the tiles outside the field of view

@@ -43,6 +43,7 @@ struct LaunchCtx {
     int pt_cap, birth_cap;
     VelEst ve;
     int n_cu = 256;      // compute units of the device (sizes launches that are meant to occupy only a share of it)
+    bool ro_inline = true; // small maps (k_resample_wg): the tiles roll their moving particles out themselves, no k_rollout launch
     bool sparse = false; // most tiles hold nothing (dspmap::sparse_mode): k_predict's variant that leaves such tiles first
 };
 

@@ -1086,6 +1086,27 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
 }
 
 // --------------------------------------------------------------------------
+#define RO_INLINE_MAX 384   // moving particles of a tile beyond which the tile counts as "heavy" for the choice inline rollout / k_rollout
+// One moving old particle's future status (:950-964), one float atomic per horizon: record {px, py, vx, vy}, {w, local voxel}.
+// (k_rollout's path for tiles with few moving particles; k_resample_wg's waves 1-3 run it for their tile while wave 0 resamples.)
+__device__ __forceinline__ void rollout_direct(const MapDims& d, const DevState& s, const float4 a, const float4 b) {
+    const int zc = d.ny * d.nx;
+    const size_t V = (size_t)d.v_loc;
+    const int lbase = ((__float_as_int(b.y) + d.v_base) / zc) * zc - d.v_base;   // voxel (x 0, y 0) of the particle's layer: it never changes (vz == 0)
+    for (int t = 0; t < d.T; ++t) {
+        const float pt = d.pred_t[t];
+        const float fx = a.x + a.z * pt;      // :954-955
+        const float fy = a.y + a.w * pt;
+        if (fabsf(fx) >= d.half_x || fabsf(fy) >= d.half_y) continue;
+        const int xi = (int)div_res(d, fx + d.half_x);
+        const int yi = (int)div_res(d, fy + d.half_y);
+        const int dl = lbase + (int)__umul24((unsigned)yi, (unsigned)d.nx) + xi;
+        if (dl < 0 || dl >= d.v_loc) continue;
+        unsafeAtomicAdd(&s.fut[(size_t)t * V + dl], b.x);
+        s.fut_dirty[dl >> 6] = 1;
+    }
+}
+
 // k_resample_wg: the same stage with FOUR waves per tile, for maps whose frame is a chain of latencies (the metric's size:
 // a few hundred live tiles, one wave per SIMD -- the longest tile IS the kernel; one-word occupancy, slots <= 48).
 // Only the per-voxel sums and the resampling walk are sequential in slot order (:938-1053); everything around them is not:
@@ -1105,7 +1126,7 @@ extern "C" int dspmap_debug_resample_prof(long long* out, int n) { return (int)h
 #endif
 #define RWB 12  // rows per wave: 4 x 12 = 48 slots, the whole tile in one batch
 __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int* __restrict__ part_live, int* __restrict__ vb_cnt,
-                                                     float4* __restrict__ ro_rec, int* __restrict__ ro_cnt) {
+                                                     float4* __restrict__ ro_rec, int* __restrict__ ro_cnt, int inline_ro) {
     extern __shared__ float s_dyn[];
     __shared__ u64 s_surv[64], s_oldc[64], s_keptc[64];
     __shared__ int s_ncp[64];
@@ -1220,7 +1241,10 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
 #endif
     // ---- phase 2: one lane per voxel over its own n entries, LDS only
     if (wave == 0) {
-        if (l == 0) { ro_cnt[BX] = s_nmv; ro_cnt[((d.v_loc + 63) >> 6) + BX] = __float_as_int((s_mvw[0] + s_mvw[1]) + (s_mvw[2] + s_mvw[3])); }
+        if (l == 0) {
+            ro_cnt[BX] = inline_ro ? 0 : s_nmv; ro_cnt[((d.v_loc + 63) >> 6) + BX] = __float_as_int((s_mvw[0] + s_mvw[1]) + (s_mvw[2] + s_mvw[3]));
+            if (s_nmv > RO_INLINE_MAX) atomicAdd(&s.fs->mv_acc, 1);   // (the caller's hint: with many such tiles k_rollout's LDS windows pay)
+        }
         const u64 oldc = s_oldc[l];
         const int n = (int)__popcll(surv);
         int nmax = n;
@@ -1313,6 +1337,11 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
             part_live[BX] = live_out; s.tile_live[BX] = live_out > 0 ? 1 : 0;
             if ((BX & 63) == 0 && live_out > 0) atomicAdd(&s.fs->live_acc, 1);   // (a 1-in-64 sample of the non-empty tiles: k_predict's hint)
         }
+    } else if (inline_ro) {
+        // the rollout of the tile's moving old particles (noted above, visible after the barrier) while wave 0 walks the voxels:
+        // a map of this size is a chain of short kernels, and k_rollout's launch (~7 us) costs more than these atomics
+        const int nmv = s_nmv;
+        for (int it = tid - 64; it < nmv; it += 192) rollout_direct(d, s, ro_rec[(ro_base + it) * 2], ro_rec[(ro_base + it) * 2 + 1]);
     }
     __syncthreads();
 #ifdef RESAMPLE_PROF
@@ -1896,7 +1925,13 @@ void launch_resample(const LaunchCtx& c) {
     static const int wg_tiles = getenv("DSPMAP_RESAMPLE_WG_TILES") ? atoi(getenv("DSPMAP_RESAMPLE_WG_TILES")) : 8192;
     if (k->ntiles < wg_tiles && c.d.mw == 1 && c.d.slots <= 4 * RWB) {
         const size_t lds4 = (size_t)(3 * c.d.slots * 64) * sizeof(float) + (size_t)c.d.slots * 64 + (size_t)64 * c.d.M * 2;
-        hipLaunchKernelGGL(k_resample_wg, dim3(k->ntiles), dim3(256), lds4, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt);
+        // ... and roll their moving particles out themselves (one float atomic per particle and horizon from the waves that wait for
+        // the sequential walk anyway): no k_rollout launch
+        // -- unless many tiles hold hundreds of moving particles (c.ro_inline, the handle's choice from last frame's count):
+        // then k_rollout's LDS windows are worth their launch (66x66x40 saturated, every particle moving: 0.11 vs 0.27 ms)
+        const int inline_ro = c.ro_inline ? 1 : 0;
+        hipLaunchKernelGGL(k_resample_wg, dim3(k->ntiles), dim3(256), lds4, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, inline_ro);
+        if (inline_ro) return;
     } else if (c.d.mw == 1) hipLaunchKernelGGL(k_resample<1>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt);
     else hipLaunchKernelGGL(k_resample<2>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt);
     if (c.d.T > 0) {

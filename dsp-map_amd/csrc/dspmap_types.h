@@ -88,6 +88,7 @@ struct FrameScalars {
     int n_voxel_full_import; // multi-GPU: movers received from a neighbour that found their voxel full
     int n_dirty;            // entries of DevState::dirty
     int n_overflow_inexact; // diagnostics: voxels / arrivals the re-slotting pass could not treat exactly (see k_place_fix)
+    int mv_acc;                // tiles in which k_resample_wg noted more than RO_INLINE_MAX moving particles (moved to hint_out[1] like live_acc)
     int live_acc, live_hint;   // every 64th tile that k_resample leaves non-empty counts itself in live_acc; the next frame's first kernel
                                // moves the count to live_hint: k_predict's estimate of how sparse the map is (a hint, never a result)
     int v_cur_in, r_cur_in;    // the velocity-table / rand() cursors before the frame's births (the fused insertion reads these, one workgroup writes the new ones)
@@ -183,7 +184,8 @@ struct DevState {
     float* p_tab; float* v_tab; int* r_tab;
     FrameScalars* fs;
     FrameParams* fpar;
-    int* hint_out;      // host-mapped word: FrameScalars::live_hint for the caller's thread (which k_predict variant to launch)
+    int* hint_out;      // host-mapped words for the caller's thread: [0] FrameScalars::live_hint (which k_predict variant to launch),
+                        // [1] last frame's tiles with many moving particles (inline rollout or k_rollout)
     int* ring_seq;      // read position of the pinned parameter ring (frames replayed as a captured graph)
     // re-slotting after a full pyramid list has turned particles away (k_place_fix, dspmap_kernels.hip)
     u64* pmask;         // [v_loc*mw] occupancy after the prediction, before any arrival was placed (tiles with arrivals; k_place)

@@ -126,6 +126,10 @@ enum dspmap_param {
     DSPMAP_P_SPARSE_SWEEP = 18,     /* which variant of the prediction sweep runs: -1 (default) the handle decides from a running estimate of how
                                        many 64-voxel tiles hold particles (most empty: empty tiles are left after one scalar load), 0 / 1 force
                                        one (same result either way; read: the variant of the last frame) */
+    DSPMAP_P_ROLLOUT_INLINE = 19,   /* maps small enough for the four-waves-per-tile resampler: 1 = its tiles add their moving particles' future
+                                       status themselves (one float atomic per particle and horizon; no k_rollout launch), 0 = k_rollout's LDS
+                                       windows, -1 (default) the handle decides from the number of tiles with hundreds of moving particles
+                                       (same result up to the order of float additions; read: the last frame's choice) */
     DSPMAP_P_PAIR_CULL_SIGMAS = 13  /* mapUpdate evaluates a (particle, observation) pair only if their ranges differ by at most this many
                                        sigma_ob (default 9: the dropped terms are < 1e-19 and zero on the fixed-point Ck grid);
                                        a huge value evaluates every pair of the neighbourhood like the reference's loops */

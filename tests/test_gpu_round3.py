@@ -460,3 +460,38 @@ def test_sharded_frame_with_the_sparse_sweep_variant(dsp):
         frames.append((pts_t.cpu().numpy().copy(), pos, t, quat))
     clouds, rec, holding = _group_vs_full(dsp, 4, cfg, frames, seed=9, sparse=1)
     assert holding >= 2 and len(rec) > 20000
+
+
+@pytest.mark.gpu
+def test_inline_rollout_equals_k_rollout(dsp):
+    """maps small enough for the four-waves-per-tile resampler add the future status of their moving particles from inside
+    k_resample_wg (no k_rollout launch) unless many tiles hold hundreds of moving particles (DSPMAP_P_ROLLOUT_INLINE: the
+    handle's choice from last frame's count): forced on / forced off / chosen, with every seeded particle moving -- the same
+    particles in the same slots, the same future status up to the order of the float additions, and the handle's own choice
+    ends up at k_rollout on this (pathological) fill"""
+    cfg = dict(nx=40, ny=36, nz=12, res=0.15, ppv=24)
+    tables = common.tables(4)
+    maps = []
+    for force in (1, 0, -1):
+        m = dsp.DSPMap(dsp.make_config(**cfg)); m.set_tables(*tables)
+        m.L.dspmap_init_device(m.h)
+        m.set_param(dsp.capi.P_ROLLOUT_INLINE, force)
+        m.seed_uniform(20, 0.01, 6, 1.0)
+        maps.append(m)
+    pts = common.wall_cloud(3, n_side=30, dist=2.0, half_w=1.5, half_h=0.6)
+    d = torch.from_numpy(np.ascontiguousarray(pts, np.float32)).cuda()
+    for f in range(4):
+        for m in maps:
+            assert m.update_device(d.data_ptr(), len(pts), (0.02 * f, 0.0, 0.0), f / 30.0, (1.0, 0.0, 0.0, 0.0)) == 1
+        futs = [m.getFutureStatus() for m in maps]
+        assert futs[0].sum() > 100
+        assert np.allclose(futs[0], futs[1], rtol=1e-5, atol=1e-6) and np.allclose(futs[2], futs[1], rtol=1e-5, atol=1e-6), f
+        for m in maps:
+            m.clearOccupancyMapPrediction()
+    assert [int(m.get_param(dsp.capi.P_ROLLOUT_INLINE)) for m in maps] == [1, 0, 0]
+    ref = maps[0].export_state()
+    for m in maps[1:]:
+        for a, b in zip(ref, m.export_state()):
+            assert np.array_equal(a, b)
+    for m in maps:
+        m.close()
