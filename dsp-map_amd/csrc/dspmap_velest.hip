@@ -417,10 +417,17 @@ __device__ __forceinline__ void ve_clusters_block(const DevState& s, const VelEs
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) {
                 const int m = min(64, c.point_num - ch * 64);
-                for (int q = 0; q < m; ++q) {   // q is wave-uniform: v_readlane, no LDS crossbar
-                    ax += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[ch].x), q));
-                    ay += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[ch].y), q));
-                    az += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[ch].z), q));
+                for (int q0 = 0; q0 < m; q0 += 8) {   // lane indices are wave-uniform: v_readlane, no LDS crossbar; eight members are
+                    float xs[8], ys[8], zs[8];        // fetched ahead of the three dependent chains of additions
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        xs[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[ch].x), q0 + u));
+                        ys[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[ch].y), q0 + u));
+                        zs[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[ch].z), q0 + u));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (q0 + u < m) { ax += xs[u]; ay += ys[u]; az += zs[u]; }
                 }
             }
             c.cx = __fdiv_rn(ax, (float)c.point_num); c.cy = __fdiv_rn(ay, (float)c.point_num); c.cz = __fdiv_rn(az, (float)c.point_num);
@@ -623,7 +630,9 @@ __device__ __forceinline__ void ve_clusters_block(const DevState& s, const VelEs
 __global__ void __launch_bounds__(VE_NT) k_ve_clusters(MapDims d, DevState s, VelEst ve, FilterParams fp, int with_rank) {
     ve_clusters_block(s, ve, fp);
     if (with_rank) {
-        __threadfence();
+        // (the cloud was written by THIS workgroup: its stores have to be complete, not written back across the chip --
+        // an agent-scope fence flushes the XCD's L2 on this part and costs microseconds on the frame's longer branch)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __syncthreads();
         birth_rank_block(d, s, fp);
     }
