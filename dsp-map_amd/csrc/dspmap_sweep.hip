@@ -1960,8 +1960,11 @@ void launch_resample(const LaunchCtx& c) {
                            k->ntiles, pl);
     }
 }
+__global__ void k_set_live_sample(DevState s, int v) { s.fs->live_acc = v; }
 static void mark_all_live(const LaunchCtx& c) {   // particles were written outside a frame: every tile may hold some
     (void)hipMemsetAsync(c.s.tile_live, 1, sizeof(int) * (size_t)c.k.ntiles, c.stream);
+    // ... and the next frame's estimate of the non-empty tiles (FrameScalars::live_hint) says so too
+    hipLaunchKernelGGL(k_set_live_sample, dim3(1), dim3(1), 0, c.stream, c.s, (c.k.ntiles + 63) / 64);
 }
 void launch_seed_uniform(const LaunchCtx& c, int per_voxel, float weight, unsigned seed, float vmax) {
     mark_all_live(c);
