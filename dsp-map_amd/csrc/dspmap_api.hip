@@ -702,7 +702,10 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
         LaunchCtx c2 = c;
         c2.stream = m->stream2;
         launch_velocity_estimator(c2, true);
-        launch_birth_early(c2, birth_grid, false);   // children (the rank ran inside k_ve_clusters)
+        // the children (the rank ran inside k_ve_clusters): on the side branch when it goes on with the placement of the tiles without
+        // a view (large maps); otherwise the branch -- the longer one at the metric's size -- ends here and the waves of the split
+        // generate them (launch_birth_late)
+        if (split) launch_birth_early(c2, birth_grid, false);
         (void)hipEventRecord(m->ev_join, m->stream2);
         dspmap_prof_mark(m, 2);
         launch_claim(c, 0, 0, 0, 0, split ? 1 : -1);
@@ -720,7 +723,7 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
         dspmap_prof_mark(m, 5);
         (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
         dspmap_prof_mark(m, 6);
-        launch_birth_late(c, birth_grid, false);
+        launch_birth_late(c, birth_grid, false, !split);
         dspmap_prof_mark(m, 7);
         launch_resample(c);
         dspmap_prof_mark(m, 8);

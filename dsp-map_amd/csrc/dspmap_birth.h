@@ -125,8 +125,9 @@ __device__ __forceinline__ void birth_rank_block(const MapDims& d, const DevStat
 // and its birth index (point * n_nb + child) in the per-voxel bucket that k_birth_insert ranks.  Needs the birth cloud
 // and the rank only: in a whole frame it rides on k_place's launch.
 #define BIRTH_BUCKET_CAP 128
+// inside_out: the caller collects the "inside the map" bits itself (a wave that generates all children of one point: a ballot)
 __device__ __forceinline__ void birth_child_thread(const MapDims& d, const DevState& s, const FilterParams& fp, float4* __restrict__ child,
-                                                   int* __restrict__ vb_cnt, int* __restrict__ vb_idx, const int t) {
+                                                   int* __restrict__ vb_cnt, int* __restrict__ vb_idx, const int t, bool* inside_out = nullptr) {
     const BirthView bv = birth_view(s);
     const int n_birth = bv.n;
     const int nb = fp.nb_num;
@@ -141,7 +142,7 @@ __device__ __forceinline__ void birth_child_thread(const MapDims& d, const DevSt
     int gv = 0;
     int lv = -1;
     if (voxel_of(d, x, y, z, gv)) {                          // :875
-        atomicOr(&s.plan_inside[i], 1u << k);
+        if (inside_out) *inside_out = true; else atomicOr(&s.plan_inside[i], 1u << k);
         lv = gv - d.v_base;
         if (lv >= 0 && lv < d.v_loc) {                       // children landing in another slab are inserted by their owner
             const int pos = atomicAdd(&vb_cnt[lv], 1);

@@ -81,7 +81,7 @@ void launch_birth_split(const LaunchCtx& c, int n_birth);
 void launch_birth_split_cksum(const LaunchCtx& c, int n_birth);             // split + the 1/Ck reduction in one launch
 void launch_birth_early(const LaunchCtx& c, int n_birth, bool with_rank = true);                      // split-phase frame: rank + children right after the prediction
 void launch_birth_finish(const LaunchCtx& c, int n_birth, bool all_static);    // ... cursors + insert at its end
-void launch_birth_late(const LaunchCtx& c, int n_birth, bool all_static);   // whole frame after launch_predict_only(with_rank) + launch_claim(n): split, 1/Ck sum, cursors, insert
+void launch_birth_late(const LaunchCtx& c, int n_birth, bool all_static, bool with_children = false);   // with_children: no k_birth_children launch preceded (the split's waves generate them);   // whole frame after launch_predict_only(with_rank) + launch_claim(n): split, 1/Ck sum, cursors, insert
 void launch_birth_plan_insert(const LaunchCtx& c, int n_birth, bool in_frame, bool all_static);
 void launch_birth_materialize(const LaunchCtx& c, BirthSrc* out, int cap, int* n_out);   // the frame's synthesised birth cloud, for host readback
 // mapOccupancyCalculationAndResample (:924-1057)

@@ -839,7 +839,8 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
 // cvr (whole frame, the children are done): also the point's draws from the velocity table / the rand() stream (:884-886,
 // :895-897: three per child inside the map beyond the static ones, by branch) -- what k_birth_cursors would count, for the
 // insertion kernel that computes its cursors itself
-__device__ __forceinline__ void birth_split_wave(const MapDims& d, const DevState& s, const FilterParams& fp, int i, int2* cvr = nullptr) {
+__device__ __forceinline__ void birth_split_wave(const MapDims& d, const DevState& s, const FilterParams& fp, int i, int2* cvr = nullptr,
+                                                 const unsigned* inside_in = nullptr) {   // inside_in: the point's "inside the map" bits, if the caller has them
     const BirthView bv = birth_view(s);
     if (cvr) *cvr = make_int2(0, 0);
     if (i >= bv.n) return;
@@ -882,7 +883,7 @@ __device__ __forceinline__ void birth_split_wave(const MapDims& d, const DevStat
     pl.n_static = n_static;
     if (l == 0) { s.plan[i] = pl; s.nstatic[i] = n_static; }
     if (cvr && ok && src.intensity > 0.01f) {
-        const unsigned inside = s.plan_inside[i];
+        const unsigned inside = inside_in ? *inside_in : s.plan_inside[i];
         const int nb = fp.nb_num;
         const int model_end = src.nx > -100.f ? fp.model_nb : n_static;  // :881
         auto below = [](int k) { return k >= 32 ? ~0u : ((1u << k) - 1u); };   // bits [0, k)
@@ -1312,7 +1313,12 @@ __global__ void __launch_bounds__(1024) k_birth_split_cksum(MapDims d, DevState 
 // ... and, for the insertion kernel that computes the velocity-table / rand() cursors itself (one launch less: a kernel of this
 // chain costs ~5 us however little it does): every point's draw counts, their sums per workgroup (16 points), and a copy of the
 // two cursors as they stand before the frame's births
-__global__ void __launch_bounds__(1024) k_birth_split_cksum_cvr(MapDims d, DevState s, FilterParams fp, int wg_off) {
+// CHILDREN (frame with the device estimator on a map without the split placement): the point's wave also generates its newborn
+// children first (k_birth_children's job; the "inside the map" bits are a ballot) -- the estimator's branch of the frame, the
+// longer one at the metric's size, ends with k_ve_clusters instead of a third kernel
+template <bool CHILDREN>
+__global__ void __launch_bounds__(1024) k_birth_split_cksum_cvr(MapDims d, DevState s, FilterParams fp, int wg_off, float4* __restrict__ child,
+                                                                int* __restrict__ vb_cnt, int* __restrict__ vb_idx) {
     __shared__ int2 s_c[1024 / WAVE];
     if (blockIdx.x == gridDim.x - 1) {
         __shared__ float s_red[512];
@@ -1323,7 +1329,14 @@ __global__ void __launch_bounds__(1024) k_birth_split_cksum_cvr(MapDims d, DevSt
     const int wave = (int)threadIdx.x / WAVE;
     const int i = (int)(blockIdx.x * (1024 / WAVE)) + wave;
     int2 c;
-    birth_split_wave(d, s, fp, i, &c);
+    if (CHILDREN) {
+        bool in = false;
+        const int l = lane_id();
+        if (l < fp.nb_num && i < birth_view(s).n) birth_child_thread(d, s, fp, child, vb_cnt, vb_idx, i * fp.nb_num + l, &in);
+        const unsigned inside = (unsigned)__ballot(in);
+        if (l == 0 && i < birth_view(s).n) s.plan_inside[i] = inside;
+        birth_split_wave(d, s, fp, i, &c, &inside);
+    } else birth_split_wave(d, s, fp, i, &c);
     if (lane_id() == 0) { s_c[wave] = c; if (i < birth_view(s).n) s.birth_cvr[i] = c; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1349,14 +1362,15 @@ void launch_birth_finish(const LaunchCtx& c, int n_birth_grid, bool all_static) 
 void launch_birth_split_cksum(const LaunchCtx& c, int n_birth_grid) {
     hipLaunchKernelGGL(k_birth_split_cksum, dim3((n_birth_grid + 15) / 16 + 1), dim3(1024), 0, c.stream, c.d, c.s, c.fp);
 }
-void launch_birth_late(const LaunchCtx& c, int n_birth_grid, bool all_static) {
+void launch_birth_late(const LaunchCtx& c, int n_birth_grid, bool all_static, bool with_children) {
     if (n_birth_grid <= 0) return;
     const unsigned gb = (unsigned)(((long long)n_birth_grid * c.fp.nb_num + 255) / 256);
     if (all_static) {   // (no child draws from the velocity or rand() streams: no cursors)
         launch_birth_split_cksum(c, n_birth_grid);
         launch_insert(c, gb);
     } else {            // the children are done (they rode on earlier launches): the insertion computes its cursors itself
-        hipLaunchKernelGGL(k_birth_split_cksum_cvr, dim3((n_birth_grid + 15) / 16 + 1), dim3(1024), 0, c.stream, c.d, c.s, c.fp, c.birth_cap);
+        if (with_children) hipLaunchKernelGGL(k_birth_split_cksum_cvr<true>, dim3((n_birth_grid + 15) / 16 + 1), dim3(1024), 0, c.stream, c.d, c.s, c.fp, c.birth_cap, c.k.child, c.k.vb_cnt, c.k.vb_idx);
+        else hipLaunchKernelGGL(k_birth_split_cksum_cvr<false>, dim3((n_birth_grid + 15) / 16 + 1), dim3(1024), 0, c.stream, c.d, c.s, c.fp, c.birth_cap, c.k.child, c.k.vb_cnt, c.k.vb_idx);
         launch_insert(c, gb, true);
     }
 }
