@@ -849,6 +849,7 @@ __global__ void __launch_bounds__(256, 7) k_place(MapDims d, DevState s, const f
     }
 }
 
+#define RO_INLINE_MAX 384   // moving particles of a tile beyond which the tile counts as "heavy" for the choice inline rollout / k_rollout
 #define RBK 16  // rows per batch of the loads in k_resample
 #define CPB 8   // deferred copies per step
 
@@ -979,7 +980,10 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
         }
     }
     if (nmv) mvw = wave_sum_f(mvw);
-    if (l == 0) { ro_cnt[wave_g] = nmv; ro_cnt[((d.v_loc + 63) >> 6) + wave_g] = __float_as_int(mvw); }
+    if (l == 0) {
+        ro_cnt[wave_g] = nmv; ro_cnt[((d.v_loc + 63) >> 6) + wave_g] = __float_as_int(mvw);
+        if (nmv > RO_INLINE_MAX && (wave_g & 15) == 0) atomicAdd(&s.fs->mv_acc, 16);   // (the caller's hint, from every 16th tile: with many such tiles k_rollout's LDS windows pay)
+    }
     if (inr) {
         float4 res = make_float4(wsum, 0.f, 0.f, 0.f);  // voxels_objects_number[v][0..3] :974-984
         if (n_old > 0) { res.y = __fdiv_rn(vxs, (float)n_old); res.z = __fdiv_rn(vys, (float)n_old); }
@@ -1086,7 +1090,6 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
 }
 
 // --------------------------------------------------------------------------
-#define RO_INLINE_MAX 384   // moving particles of a tile beyond which the tile counts as "heavy" for the choice inline rollout / k_rollout
 // One moving old particle's future status (:950-964), one float atomic per horizon: record {px, py, vx, vy}, {w, local voxel}.
 // (k_rollout's path for tiles with few moving particles; k_resample_wg's waves 1-3 run it for their tile while wave 0 resamples.)
 __device__ __forceinline__ void rollout_direct(const MapDims& d, const DevState& s, const float4 a, const float4 b) {
@@ -1243,7 +1246,7 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
     if (wave == 0) {
         if (l == 0) {
             ro_cnt[BX] = inline_ro ? 0 : s_nmv; ro_cnt[((d.v_loc + 63) >> 6) + BX] = __float_as_int((s_mvw[0] + s_mvw[1]) + (s_mvw[2] + s_mvw[3]));
-            if (s_nmv > RO_INLINE_MAX) atomicAdd(&s.fs->mv_acc, 1);   // (the caller's hint: with many such tiles k_rollout's LDS windows pay)
+            if (s_nmv > RO_INLINE_MAX && (BX & 15) == 0) atomicAdd(&s.fs->mv_acc, 16);   // (the caller's hint, from every 16th tile: with many such tiles k_rollout's LDS windows pay)
         }
         const u64 oldc = s_oldc[l];
         const int n = (int)__popcll(surv);
@@ -1400,7 +1403,12 @@ struct RolloutPlan {
     int halo[DSP_MAX_PRED];      // rows of the grid a horizon's window reaches beyond the group's voxels, either side
     int woff[DSP_MAX_PRED + 1];  // first cell of every horizon's window in the workgroup's LDS
 };
-__global__ void __launch_bounds__(RO_TPB) k_rollout(MapDims d, DevState s, const float4* __restrict__ ro_rec, const int* __restrict__ ro_cnt, int ntiles,
+// LIGHT: no LDS windows at all -- 256 threads, every contribution a float atomic.  A map with few moving particles (what the
+// depth stream builds: newborns of matched clusters) holds no group that would use the windows, and the 120 kB of LDS they take
+// let ONE workgroup per CU start at a time: 10 890 groups at 264x264x80 cost 25 us although next to none has anything to do.
+// The handle launches this variant while last frame's count of tiles with hundreds of moving particles is low (c.ro_inline).
+template <int TPB, bool LIGHT>
+__global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const float4* __restrict__ ro_rec, const int* __restrict__ ro_cnt, int ntiles,
                                                     RolloutPlan pl) {
     // One workgroup per group of RO_G consecutive tiles (512 voxels: a few rows of a layer).  EVERY particle is read once and
     // adds its weight to its future voxel at all T horizons (reading the particles once per horizon was what bound this kernel
@@ -1446,21 +1454,21 @@ __global__ void __launch_bounds__(RO_TPB) k_rollout(MapDims d, DevState s, const
         const size_t o = ((size_t)(G0 + g) * cap + (it - s_cnt[g])) * 2;
         a = ro_rec[o]; b = ro_rec[o + 1];
     };
-    const bool dense = total >= RO_DENSE;
+    const bool dense = !LIGHT && total >= RO_DENSE;
     const int ncell = pl.woff[T];
-    if (dense) for (int i = tid; i < ncell; i += RO_TPB) s_win[i] = 0u;
+    if (dense) for (int i = tid; i < ncell; i += TPB) s_win[i] = 0u;
     __syncthreads();
-    for (int it0 = tid; it0 < total; it0 += RO_TPB * 3) {   // three particles per step: their records are requested together
+    for (int it0 = tid; it0 < total; it0 += TPB * 3) {   // three particles per step: their records are requested together
         float4 a[3], b[3];
         unsigned wq[3];
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             a[u] = make_float4(0.f, 0.f, 0.f, 0.f); b[u] = a[u];
-            if (it0 + u * RO_TPB < total) rec_of(it0 + u * RO_TPB, a[u], b[u]);
+            if (it0 + u * TPB < total) rec_of(it0 + u * TPB, a[u], b[u]);
         }
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-            if (it0 + u * RO_TPB >= total) continue;
+            if (it0 + u * TPB >= total) continue;
             const int lbase = ((__float_as_int(b[u].y) + d.v_base) / zc) * zc - d.v_base;   // voxel (x 0, y 0) of the particle's layer: it never changes (vz == 0)
             wq[u] = __float2uint_rn(b[u].x * fscale);
             for (int t = 0; t < T; ++t) {
@@ -1483,7 +1491,7 @@ __global__ void __launch_bounds__(RO_TPB) k_rollout(MapDims d, DevState s, const
     for (int t = 0; t < T; ++t) {
         const int w0 = pl.woff[t], wn = pl.woff[t + 1] - w0;
         const int g0 = G0 * 64 - pl.halo[t] * d.nx;   // local voxel index of the window's first cell (cells outside the slab stay zero)
-        for (int i = tid; i < wn; i += RO_TPB) {
+        for (int i = tid; i < wn; i += TPB) {
             const unsigned q = s_win[w0 + i];
             if (q) { unsafeAtomicAdd(&s.fut[(size_t)t * V + g0 + i], (float)q * finv); s.fut_dirty[(g0 + i) >> 6] = 1; }
         }
@@ -1955,9 +1963,11 @@ void launch_resample(const LaunchCtx& c) {
             pl.woff[c.d.T] = tot;
         }
         static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_rollout, hipFuncAttributeMaxDynamicSharedMemorySize, RO_LDS_CELLS * 4); attr_set = true; }
-        hipLaunchKernelGGL(k_rollout, dim3((k->ntiles + RO_G - 1) / RO_G), dim3(RO_TPB), (size_t)pl.woff[c.d.T] * 4, c.stream, c.d, c.s, k->ro_rec, k->ro_cnt,
-                           k->ntiles, pl);
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_rollout<RO_TPB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RO_LDS_CELLS * 4); attr_set = true; }
+        if (c.ro_inline) hipLaunchKernelGGL((k_rollout<256, true>), dim3((k->ntiles + RO_G - 1) / RO_G), dim3(256), 0, c.stream, c.d, c.s, k->ro_rec, k->ro_cnt,
+                                            k->ntiles, pl);
+        else hipLaunchKernelGGL((k_rollout<RO_TPB, false>), dim3((k->ntiles + RO_G - 1) / RO_G), dim3(RO_TPB), (size_t)pl.woff[c.d.T] * 4, c.stream, c.d, c.s, k->ro_rec, k->ro_cnt,
+                                k->ntiles, pl);
     }
 }
 __global__ void k_set_live_sample(DevState s, int v) { s.fs->live_acc = v; }
