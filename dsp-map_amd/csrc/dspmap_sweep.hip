@@ -874,7 +874,7 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
     unsigned short* s_cp = (unsigned short*)(s_w + d.slots * 64);
     const int wave_g = blockIdx.x * (blockDim.x >> 6) + wave;
     const int lv = wave_g * 64 + l;
-    if (wave_g * 64 >= d.v_loc || !s.tile_live[wave_g]) return;   // empty since its last visit: result, buckets and lists are already zero
+    if (wave_g * 64 >= d.v_loc || !sload_i(s.tile_live + wave_g)) return;   // empty since its last visit: result, buckets and lists are already zero (one scalar round trip)
     const bool inr = lv < d.v_loc;
     const int lvs = inr ? lv : 0;
     u64 m[MW], nb[MW];
