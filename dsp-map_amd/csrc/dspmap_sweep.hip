@@ -1131,7 +1131,7 @@ extern "C" int dspmap_debug_resample_prof(long long* out, int n) { return (int)h
 __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int* __restrict__ part_live, int* __restrict__ vb_cnt,
                                                      float4* __restrict__ ro_rec, int* __restrict__ ro_cnt, int inline_ro) {
     extern __shared__ float s_dyn[];
-    __shared__ u64 s_surv[64], s_oldc[64], s_keptc[64];
+    __shared__ u64 s_surv[64], s_oldc[64];
     __shared__ int s_ncp[64];
     __shared__ float s_wcp[64];
     __shared__ int s_nmv;
@@ -1248,43 +1248,28 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
             ro_cnt[BX] = inline_ro ? 0 : s_nmv; ro_cnt[((d.v_loc + 63) >> 6) + BX] = __float_as_int((s_mvw[0] + s_mvw[1]) + (s_mvw[2] + s_mvw[3]));
             if (s_nmv > RO_INLINE_MAX && (BX & 15) == 0) atomicAdd(&s.fs->mv_acc, 16);   // (the caller's hint, from every 16th tile: with many such tiles k_rollout's LDS windows pay)
         }
-        const u64 oldc = s_oldc[l];
+        // (the voxel's mass only: the walk needs it; mean velocity, static future mass and the result record are wave 1's job below --
+        // the same sums in the same order, off this wave's chain)
         const int n = (int)__popcll(surv);
         int nmax = n;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, WAVE));
-        int n_old = 0;
-        float wsum = 0.f, vxs = 0.f, vys = 0.f, stat_w = 0.f;
+        float wsum = 0.f;
         for (int j0 = 0; j0 < nmax; j0 += 4) {
-            float w4[4], x4[4], y4[4];
+            float w4[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const int c = min(j0 + q, d.slots - 1) * 64 + l; w4[q] = cw[c]; x4[q] = cvx[c]; y4[q] = cvy[c]; }
+            for (int q = 0; q < 4; ++q) w4[q] = cw[min(j0 + q, d.slots - 1) * 64 + l];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (j0 + q < n) {
-                    if ((oldc >> (j0 + q)) & 1ull) {          // flag < 10 :944
-                        ++n_old;
-                        vxs += x4[q]; vys += y4[q];
-                        if (x4[q] == 0.f && y4[q] == 0.f) stat_w += w4[q];   // p + 0*t stays in this voxel for every horizon
-                    }
-                    wsum += w4[q];                            // :970
-                }
-            }
+            for (int q = 0; q < 4; ++q)
+                if (j0 + q < n) wsum += w4[q];                // :970
         }
-        if (inr) {
-            float4 res = make_float4(wsum, 0.f, 0.f, 0.f);  // voxels_objects_number[v][0..3] :974-984
-            if (n_old > 0) { res.y = __fdiv_rn(vxs, (float)n_old); res.z = __fdiv_rn(vys, (float)n_old); }
-            s.res4[lv] = res;
-            if (stat_w != 0.f) s.fut_stat[lv] += stat_w;  // only this lane ever writes fut_stat[lv]
-        }
-        if (__ballot(inr && stat_w != 0.f) && l == 0) s.fut_dirty[BX] = 1;   // (k_predict zeroes the tile's accumulators on the next clear)
 #ifdef RESAMPLE_PROF
         t_s2 = __builtin_readcyclecounter();
 #endif
         // systematic resampling :986-1053
         int ncp = 0;
         float w_copy = 0.f;
-        u64 mfin = surv, keptc = 0ull;
+        u64 mfin = surv;
         const u64 valid = valid_bits(d, 0);
         if (n >= 5) {
             const int n_after = n > d.M ? d.M : n;                  // :992-997
@@ -1319,8 +1304,7 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
                             }
                             acc_new += w_after;
                         }
-                        cw[(j0 + q) * 64 + l] = wn;                 // written back by phase 3
-                        keptc |= 1ull << (j0 + q);
+                        s.w[tcell + (size_t)sl4[q] * 64 + l] = wn;   // (a store the walk does not wait for; the panels stay as wave 1 reads them)
                     } else {
                         mfin &= ~(1ull << sl4[q]);                  // remove :1046-1049
                     }
@@ -1330,7 +1314,6 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
         if (ncp > cpmax) ncp = cpmax;  // cannot happen: a voxel makes at most M copies
         s_ncp[l] = ncp;
         s_wcp[l] = w_copy;
-        s_keptc[l] = keptc;
         if (inr) {
             s.mask[lv] = mfin;
             if (nb) s.nbmask[lv] = 0ull;  // newborn flag -> 1 (:968)
@@ -1340,26 +1323,53 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
             part_live[BX] = live_out; s.tile_live[BX] = live_out > 0 ? 1 : 0;
             if ((BX & 63) == 0 && live_out > 0) atomicAdd(&s.fs->live_acc, 1);   // (a 1-in-64 sample of the non-empty tiles: k_predict's hint)
         }
-    } else if (inline_ro) {
-        // the rollout of the tile's moving old particles (noted above, visible after the barrier) while wave 0 walks the voxels:
-        // a map of this size is a chain of short kernels, and k_rollout's launch (~7 us) costs more than these atomics
-        const int nmv = s_nmv;
-        for (int it = tid - 64; it < nmv; it += 192) rollout_direct(d, s, ro_rec[(ro_base + it) * 2], ro_rec[(ro_base + it) * 2 + 1]);
+    } else {
+        if (wave == 1) {
+            // the voxel's result record (:970-984) and its static future mass, beside wave 0's walk (which leaves the compacted
+            // panels untouched: it stores the new weights straight to their cells)
+            const u64 oldc = s_oldc[l];
+            const int n = (int)__popcll(surv);
+            int nmax = n;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, WAVE));
+            int n_old = 0;
+            float wsum = 0.f, vxs = 0.f, vys = 0.f, stat_w = 0.f;
+            for (int j0 = 0; j0 < nmax; j0 += 4) {
+                float w4[4], x4[4], y4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int c = min(j0 + q, d.slots - 1) * 64 + l; w4[q] = cw[c]; x4[q] = cvx[c]; y4[q] = cvy[c]; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (j0 + q < n) {
+                        if ((oldc >> (j0 + q)) & 1ull) {          // flag < 10 :944
+                            ++n_old;
+                            vxs += x4[q]; vys += y4[q];
+                            if (x4[q] == 0.f && y4[q] == 0.f) stat_w += w4[q];   // p + 0*t stays in this voxel for every horizon
+                        }
+                        wsum += w4[q];                            // :970
+                    }
+                }
+            }
+            if (inr) {
+                float4 res = make_float4(wsum, 0.f, 0.f, 0.f);  // voxels_objects_number[v][0..3] :974-984
+                if (n_old > 0) { res.y = __fdiv_rn(vxs, (float)n_old); res.z = __fdiv_rn(vys, (float)n_old); }
+                s.res4[lv] = res;
+                if (stat_w != 0.f) s.fut_stat[lv] += stat_w;  // only this lane ever writes fut_stat[lv]
+            }
+            if (__ballot(inr && stat_w != 0.f) && l == 0) s.fut_dirty[BX] = 1;   // (k_predict zeroes the tile's accumulators on the next clear)
+        }
+        if (inline_ro) {
+            // the rollout of the tile's moving old particles (noted above, visible after the barrier) while wave 0 walks the voxels:
+            // a map of this size is a chain of short kernels, and k_rollout's launch (~7 us) costs more than these atomics
+            const int nmv = s_nmv;
+            for (int it = tid - 64; it < nmv; it += 192) rollout_direct(d, s, ro_rec[(ro_base + it) * 2], ro_rec[(ro_base + it) * 2 + 1]);
+        }
     }
     __syncthreads();
 #ifdef RESAMPLE_PROF
     t_s3 = __builtin_readcyclecounter();
 #endif
-    // ---- phase 3: new weights of the kept particles (entry j of every voxel, j split over the waves), then the copies (:1026-1031)
-    {
-        const u64 kp = s_keptc[l];
-        u64 tor = rows_of_wave<4>(wave_or_u64(kp), wave);
-        while (tor) {
-            const int j = __ffsll((long long)tor) - 1;
-            tor &= tor - 1ull;
-            if ((kp >> j) & 1ull) s.w[tcell + (size_t)cs[j * 64 + l] * 64 + l] = cw[j * 64 + l];
-        }
-    }
+    // ---- phase 3: the copies (:1026-1031), split over the waves (the kept particles' new weights were stored by the walk)
     const int ncp = s_ncp[l];
     const float w_copy = s_wcp[l];
     int maxcp = ncp;
