@@ -895,6 +895,99 @@ __global__ void k_birth_split(MapDims d, DevState s, FilterParams fp) {
     birth_split_wave(d, s, fp, (int)(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE));
 }
 
+// One wave = one source point of a frame whose children were not generated yet: the children (birth_child_thread's job, lanes =
+// children, "inside the map" bits by ballot) AND the split (birth_split_wave's job, lanes = slots), the same arithmetic in the same
+// order, with their loads in common stages -- {source point, position cursor} -> {table draws, occupancy words} -> {the slot's
+// particle, the child's bucket}: three round trips instead of five on a kernel that is nothing but its round trips.
+__device__ __forceinline__ void birth_point_wave(const MapDims& d, const DevState& s, const FilterParams& fp, int i, float4* __restrict__ child,
+                                                 int* __restrict__ vb_cnt, int* __restrict__ vb_idx, int2* cvr) {
+    const BirthView bv = birth_view(s);
+    *cvr = make_int2(0, 0);
+    if (i >= bv.n) return;
+    const int l = lane_id(), nb = fp.nb_num;
+    // stage 1
+    const BirthSrc src = birth_at(bv, i);
+    const int pb = s.plan_pbase[i];
+    BirthPlan pl;
+    pl.gvox = -1; pl.n_static = 0; pl.inside = 0; pl.pbase = pl.vbase = pl.rbase = 0;
+    int gv;
+    const bool ok = birth_src_voxel(d, s, src, pl.cx, pl.cy, pl.cz, gv);
+    if (!ok) {   // not a birth source: no children, an empty plan
+        if (l == 0) { s.plan[i] = pl; s.nstatic[i] = 0; s.plan_inside[i] = 0u; }
+        return;
+    }
+    pl.gvox = gv;
+    const int lvs = gv - d.v_base;
+    const bool own = lvs >= 0 && lvs < d.v_loc;   // (else: the source voxel belongs to another slab; that rank supplies n_static)
+    const int lvq = own ? lvs : 0;
+    // stage 2
+    const int c = (int)(((long long)pb + 3 * min(l, nb - 1)) % fp.tab_n);
+    const float t0 = s.p_tab[c], t1 = s.p_tab[(c + 1) % fp.tab_n], t2 = s.p_tab[(c + 2) % fp.tab_n];
+    u64 mwd[2] = {0ull, 0ull};
+    for (int e = 0; e < d.mw; ++e) mwd[e] = s.mask[(size_t)lvq * d.mw + e] & ~s.nbmask[(size_t)lvq * d.mw + e];  // 0.9<flag<14 :830
+    // stage 3: this lane's slot of the source voxel (requested whether or not it is live: the address is valid) ...
+    V2 pv[2];
+    float pw[2];
+    bool on[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int sl = e * 64 + l;
+        on[e] = own && e < d.mw && sl < d.slots && ((mwd[e] >> l) & 1ull);
+        const size_t idx = pidx(d, lvq, on[e] ? sl : 0);
+        pv[e] = ld_vel(s, idx);
+        pw[e] = s.w[idx];
+    }
+    // ... and this lane's child (:871-875)
+    bool in = false;
+    if (l < nb) {
+        const int t = i * nb + l;
+        const float x = pl.cx + t0, y = pl.cy + t1, z = pl.cz + t2;
+        int gvc = 0, lvc = -1;
+        if (voxel_of(d, x, y, z, gvc)) {
+            in = true;
+            lvc = gvc - d.v_base;
+            if (lvc >= 0 && lvc < d.v_loc) {                     // children landing in another slab are inserted by their owner
+                const int pos = atomicAdd(&vb_cnt[lvc], 1);
+                if (pos < BIRTH_BUCKET_CAP) vb_idx[(size_t)lvc * BIRTH_BUCKET_CAP + pos] = t;
+                else s.birth_ovf[atomicAdd(&s.fs->n_birth_ovf, 1)] = t;
+            } else {
+                lvc = -1;
+            }
+        }
+        child[t] = make_float4(x, y, z, __int_as_float(lvc));
+    }
+    const unsigned inside = (unsigned)__ballot(in);
+    // the split (:827-866)
+    int n_static = 0;
+    if (own) {
+        float ws = 0.f, wsd = 0.f, wd = 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (on[e]) {
+                const float vabs = fabsf(pv[e].x) + fabsf(pv[e].y) + 0.f;  // vz == 0
+                if (vabs < 0.1f) ws += pw[e]; else if (vabs < 0.5f) wsd += pw[e]; else wd += pw[e];
+            }
+        }
+        ws = wave_sum(ws); wsd = wave_sum(wsd); wd = wave_sum(wd);
+        const float total = ws + wd + wsd;
+        const float m_s = __fdiv_rn(ws, total), m_d = __fdiv_rn(wd, total), m_sd = __fdiv_rn(wsd, total);
+        const float p_s = (m_s + m_s + m_sd) * 0.5f;
+        const float p_d = (m_d + m_d + m_sd) * 0.5f;
+        const float p_s_n = __fdiv_rn(p_s, p_s + p_d);
+        const float f = (float)fp.model_nb * p_s_n;
+        const int ns = (f != f) ? 0 : (int)f;  // empty voxel -> NaN -> minimum applies (Appendix A-8)
+        n_static = max(fp.min_static_nb, ns);
+    }
+    pl.n_static = n_static;
+    if (l == 0) { s.plan[i] = pl; s.nstatic[i] = n_static; s.plan_inside[i] = inside; }
+    if (src.intensity > 0.01f) {
+        const int model_end = src.nx > -100.f ? fp.model_nb : n_static;  // :881
+        auto below = [](int k) { return k >= 32 ? ~0u : ((1u << k) - 1u); };   // bits [0, k)
+        const int lo = min(n_static, nb), mid = min(max(model_end, lo), nb);
+        *cvr = make_int2(3 * __popc(inside & below(mid) & ~below(lo)), 3 * __popc(inside & below(nb) & ~below(mid)));
+    }
+}
+
 // The sequential consumption order of the three random streams (:871-873 position table,
 // :884-886 velocity table, :895-897 rand()) is reproduced with block-wide prefix sums over the
 // source points: draws of point i start at cursor + (draws of all earlier points).
@@ -1329,14 +1422,8 @@ __global__ void __launch_bounds__(1024) k_birth_split_cksum_cvr(MapDims d, DevSt
     const int wave = (int)threadIdx.x / WAVE;
     const int i = (int)(blockIdx.x * (1024 / WAVE)) + wave;
     int2 c;
-    if (CHILDREN) {
-        bool in = false;
-        const int l = lane_id();
-        if (l < fp.nb_num && i < birth_view(s).n) birth_child_thread(d, s, fp, child, vb_cnt, vb_idx, i * fp.nb_num + l, &in);
-        const unsigned inside = (unsigned)__ballot(in);
-        if (l == 0 && i < birth_view(s).n) s.plan_inside[i] = inside;
-        birth_split_wave(d, s, fp, i, &c, &inside);
-    } else birth_split_wave(d, s, fp, i, &c);
+    if (CHILDREN) birth_point_wave(d, s, fp, i, child, vb_cnt, vb_idx, &c);
+    else birth_split_wave(d, s, fp, i, &c);
     if (lane_id() == 0) { s_c[wave] = c; if (i < birth_view(s).n) s.birth_cvr[i] = c; }
     __syncthreads();
     if (threadIdx.x == 0) {
