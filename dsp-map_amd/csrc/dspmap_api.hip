@@ -919,7 +919,10 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
         // the kernel arguments of a frame are constant (per-frame values live in s.fpar): capture once, replay
         const unsigned long long key = ((unsigned long long)m->graph_epoch << 8) | (has_vz ? 1u : 0u) | ((unsigned)mode << 1) | (c.sparse ? 8u : 0u) | (c.ro_inline ? 16u : 0u);
         if (!m->graph_exec || m->graph_key != key) {
-            if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+            if (m->graph_exec) {   // (replays of the old executable graph may still be queued: let them finish before it goes)
+                HIPCHK(m, hipStreamSynchronize(m->stream));
+                (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr;
+            }
             if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
             HIPCHK(m, hipStreamBeginCapture(m->stream, hipStreamCaptureModeRelaxed));
             enqueue_frame(m, c, m->pt_cap, m->birth_cap, false, mode == 1, mode == 2);  // (fork=true measured slower: HIP replays multi-branch graphs with a much higher launch cost) grids sized for the capacity; kernels bound-check against fpar
