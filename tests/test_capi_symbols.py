@@ -120,3 +120,20 @@ def test_dropin_header_compiles_without_ros(dsp):
                    "void mapAddNewBornParticlesByObservation()", "static float generateRandomFloat(",
                    "void getVoxelPositionFromIndexPublic(", "int getPointVoxelsIndexPublic(", "void getFutureStatus("):
         assert member in hdr, member
+
+
+def test_parameter_ids_of_the_binding_match_the_header(dsp):
+    """every DSPMAP_P_* enumerator of include/dspmap.h has a P_* constant of the same value in the ctypes binding (a new
+    parameter that is added to one side only would silently address another one), and the scheduling knobs are plain
+    host state: settable and readable without a device"""
+    text = open(os.path.join(ROOT, "include", "dspmap.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    ids = dict((k, int(v)) for k, v in re.findall(r"\bDSPMAP_P_([A-Z_0-9]+)\s*=\s*(\d+)", text))
+    assert len(ids) >= 19 and len(set(ids.values())) == len(ids)
+    for name, val in ids.items():
+        assert getattr(dsp.capi, "P_" + name) == val, name
+    m = dsp.DSPMap(dsp.make_config(ppv=24))
+    for key in (dsp.capi.P_SPARSE_SWEEP, dsp.capi.P_ROLLOUT_INLINE):
+        for v in (1, 0, -1):
+            assert m.L.dspmap_set_param(m.h, key, float(v)) == 1
+    m.close()
