@@ -1121,7 +1121,7 @@ __device__ __forceinline__ void rollout_direct(const MapDims& d, const DevState&
 //            in batches of four LDS reads: the reference's operation order, bit for bit; the loop runs as long as the tile's
 //            fullest voxel, not as long as its highest occupied slot, and has no memory access in the chain;
 //   phase 3  all four waves write the kept particles' new weights back and carry out the deferred copies.
-// dynamic LDS: [slots][64] fp32 panels w, vx, vy + [slots][64] u8 slot of entry j + [64][M] u16 copy notes.
+// dynamic LDS: [slots][64] fp32 panel w + [slots][64] u8 slot of entry j + [64][M] u16 copy notes.
 // --------------------------------------------------------------------------
 #ifdef RESAMPLE_PROF
 __device__ long long g_rprof[4 * 65536];
@@ -1142,9 +1142,7 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
     const int BX = (int)blockIdx.x;
     const int cells = d.slots * 64;
     float* cw = s_dyn;
-    float* cvx = cw + cells;
-    float* cvy = cvx + cells;
-    unsigned char* cs = (unsigned char*)(cvy + cells);
+    unsigned char* cs = (unsigned char*)(cw + cells);
     const int cpmax = d.M;   // a voxel makes at most M copies
     unsigned short* s_cp = (unsigned short*)(cs + cells);
     const int lv = BX * 64 + l;
@@ -1222,7 +1220,7 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
         if (on) {
             const int j = (int)__popcll(surv & ((1ull << rw) - 1ull));   // survivors of this voxel in lower slots
             const int c = j * 64 + l;
-            cw[c] = wr[r]; cvx[c] = vx; cvy[c] = vy; cs[c] = (unsigned char)rw;
+            cw[c] = wr[r]; cs[c] = (unsigned char)rw;
             if (old) oldc_mine |= 1ull << j;
         }
         // the rollout (:950-964) needs the MOVING old survivors: noted here, their future positions are k_rollout's job
@@ -1326,7 +1324,9 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
     } else {
         if (wave == 1) {
             // the voxel's result record (:970-984) and its static future mass, beside wave 0's walk (which leaves the compacted
-            // panels untouched: it stores the new weights straight to their cells)
+            // panel untouched: it stores the new weights straight to their cells).  The velocities of the entries are re-read from
+            // their cells (eight at a time, warm in the L2 since phase 1; nobody writes them before phase 3): keeping them in LDS
+            // beside the weights made the panels 42 kB per tile, three tiles per CU; 18 kB lets the registers decide (five)
             const u64 oldc = s_oldc[l];
             const int n = (int)__popcll(surv);
             int nmax = n;
@@ -1334,19 +1334,26 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
             for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, WAVE));
             int n_old = 0;
             float wsum = 0.f, vxs = 0.f, vys = 0.f, stat_w = 0.f;
-            for (int j0 = 0; j0 < nmax; j0 += 4) {
-                float w4[4], x4[4], y4[4];
+            for (int j0 = 0; j0 < nmax; j0 += 8) {
+                float w8[8];
+                V2 v8[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { const int c = min(j0 + q, d.slots - 1) * 64 + l; w4[q] = cw[c]; x4[q] = cvx[c]; y4[q] = cvy[c]; }
+                for (int q = 0; q < 8; ++q) {
+                    const int c = min(j0 + q, d.slots - 1) * 64 + l;
+                    w8[q] = cw[c];
+                    const int sl = j0 + q < n ? (int)cs[c] : 0;
+                    const f2w v = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(rs_vel, (sl * 64 + l) * 8, 0, 0));
+                    v8[q].x = v.x; v8[q].y = v.y;
+                }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < 8; ++q) {
                     if (j0 + q < n) {
                         if ((oldc >> (j0 + q)) & 1ull) {          // flag < 10 :944
                             ++n_old;
-                            vxs += x4[q]; vys += y4[q];
-                            if (x4[q] == 0.f && y4[q] == 0.f) stat_w += w4[q];   // p + 0*t stays in this voxel for every horizon
+                            vxs += v8[q].x; vys += v8[q].y;
+                            if (v8[q].x == 0.f && v8[q].y == 0.f) stat_w += w8[q];   // p + 0*t stays in this voxel for every horizon
                         }
-                        wsum += w4[q];                            // :970
+                        wsum += w8[q];                            // :970
                     }
                 }
             }
@@ -1942,7 +1949,7 @@ void launch_resample(const LaunchCtx& c) {
     // the kernel; large maps keep one wave per tile (more tiles in flight per CU)
     static const int wg_tiles = getenv("DSPMAP_RESAMPLE_WG_TILES") ? atoi(getenv("DSPMAP_RESAMPLE_WG_TILES")) : 8192;
     if (k->ntiles < wg_tiles && c.d.mw == 1 && c.d.slots <= 4 * RWB) {
-        const size_t lds4 = (size_t)(3 * c.d.slots * 64) * sizeof(float) + (size_t)c.d.slots * 64 + (size_t)64 * c.d.M * 2;
+        const size_t lds4 = (size_t)(c.d.slots * 64) * sizeof(float) + (size_t)c.d.slots * 64 + (size_t)64 * c.d.M * 2;
         // ... and roll their moving particles out themselves (one float atomic per particle and horizon from the waves that wait for
         // the sequential walk anyway): no k_rollout launch
         // -- unless many tiles hold hundreds of moving particles (c.ro_inline, the handle's choice from last frame's count):
