@@ -19,7 +19,8 @@ OK, REJECTED = 1, 0
 
 P_POSITION_STDDEV, P_VELOCITY_STDDEV, P_OBSERVATION_STDDEV, P_NEWBORN_WEIGHT, P_NEWBORN_NUMBER, \
     P_VOXEL_FILTER_RES, P_KAPPA, P_DETECTION, P_VELOCITY_ESTIMATOR, P_REGENERATE_TABLES, P_USE_GRAPH, P_OCCLUSION_MARGIN, \
-    P_PAIR_CULL_SIGMAS, P_UPDATE_TIME, P_UPDATE_COUNTER, P_PLACE_SPLIT_TILES, P_FAST_DIVISION, P_SPARSE_SWEEP, P_ROLLOUT_INLINE = range(1, 20)
+    P_PAIR_CULL_SIGMAS, P_UPDATE_TIME, P_UPDATE_COUNTER, P_PLACE_SPLIT_TILES, P_FAST_DIVISION, P_SPARSE_SWEEP, P_ROLLOUT_INLINE, \
+    P_RESAMPLE_WG_TILES, P_SWEEP_ALTERNATE = range(1, 22)
 
 
 class Config(C.Structure):
@@ -95,6 +96,9 @@ SIGNATURES = {
     "dspmap_debug_stream": (_i, [_P, _i, C.POINTER(C.c_longlong)]),
     "dspmap_debug_sweep_probe": (_i, [_P, _i, _i, _i, _i, _fp, C.POINTER(C.c_longlong)]),
     "dspmap_debug_tile_view": (_i, [_P, C.POINTER(C.c_int), _i]),
+    "dspmap_debug_rollout_paths": (_i, [_P, C.POINTER(C.c_longlong)]),
+    "dspmap_debug_rdzv_publish": (_i, [C.c_char_p, C.c_char_p]),
+    "dspmap_debug_rdzv_wait": (_i, [C.c_char_p, _i, C.c_char_p]),
     "dspmap_clear_state": (_i, [_P]),
     "dspmap_import_state": (_i, [_P, _i, _P, _P, _P]),
     "dspmap_export_state": (_i, [_P, _i, _P, _P, _P, _ip]),
@@ -242,6 +246,13 @@ class DSPMap:
 
     def get_param(self, key):
         return self.L.dspmap_get_param(self.h, key)
+
+    def rollout_paths(self):
+        """(variant, adds through k_rollout's LDS windows, single-atomic adds of k_rollout) of the last resampling stage;
+        variant: bit 0 = k_resample_wg, bits 1-2 = rollout 0 inline / 1 k_rollout light / 2 k_rollout windows / 3 none"""
+        out = (C.c_longlong * 3)()
+        self._chk(self.L.dspmap_debug_rollout_paths(self.h, out))
+        return int(out[0]), int(out[1]), int(out[2])
 
     # -- reference setters (dsp_dynamic.h:355-382)
     def setPredictionVariance(self, p_stddev, v_stddev):

@@ -46,6 +46,11 @@ int dspmap_fail(dspmap* m, int code, const char* fmt, ...) {
 }
 
 
+void dspmap_resample(dspmap* m, const LaunchCtx& c) {   // the stage's launches + which variant they were (dspmap_debug_rollout_paths)
+    m->last_resample_variant = resample_variant(c);
+    launch_resample(c);
+}
+
 LaunchCtx dspmap_ctx_of(dspmap* m) {
     LaunchCtx c;
     c.d = m->d; c.fp = m->fp; c.s = m->s; c.k = m->k; c.stream = m->stream;
@@ -67,6 +72,8 @@ LaunchCtx dspmap_ctx_of(dspmap* m) {
         else if (m->ro_kernel && heavy * 128 < m->k.ntiles) m->ro_kernel = false;
     }
     c.ro_inline = !m->ro_kernel;
+    c.resample_wg_tiles = m->resample_wg_tiles;
+    c.sweep_rev = (m->sweep_alt < 0 ? m->k.ntiles >= 4096 : m->sweep_alt != 0) && (m->frame_parity & 1u);
     return c;
 }
 
@@ -152,6 +159,8 @@ extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
     m->device = cfg->device;
     m->vel.configure(cfg->half_fov_h, cfg->half_fov_v, cfg->angle_resolution);
     if (const char* e = getenv("DSPMAP_PLACE_SPLIT_TILES")) { const long v = atol(e); if (v > 0) m->place_split_tiles = (int)std::min(v, 2000000000l); }
+    if (const char* e = getenv("DSPMAP_SWEEP_ALTERNATE")) m->sweep_alt = atoi(e) < 0 ? -1 : (atoi(e) != 0 ? 1 : 0);
+    if (const char* e = getenv("DSPMAP_RESAMPLE_WG_TILES")) { const long v = atol(e); if (v >= 0) m->resample_wg_tiles = (int)std::min(v, 2000000000l); }
     return m;
 }
 
@@ -164,7 +173,7 @@ static void free_dev(dspmap* m) {
     if (m->device >= 0) chk(hipSetDevice(m->device), "hipSetDevice");
     if (m->stream) chk(hipStreamSynchronize(m->stream), "hipStreamSynchronize");   // nothing of this handle may be in flight
     if (m->stream2) chk(hipStreamSynchronize(m->stream2), "hipStreamSynchronize(2)");
-    if (m->graph_exec) chk(hipGraphExecDestroy(m->graph_exec), "hipGraphExecDestroy");
+    for (hipGraphExec_t& g : m->graph_exec) if (g) { chk(hipGraphExecDestroy(g), "hipGraphExecDestroy"); g = nullptr; }
     if (m->graph) chk(hipGraphDestroy(m->graph), "hipGraphDestroy");
     DevState& s = m->s;
     dspmap_dist_free(m);
@@ -174,7 +183,7 @@ static void free_dev(dspmap* m) {
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, s.fov_rec, s.fov_slot, s.fov_key, s.fov_spos, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt, s.in_n, s.pmask, s.ta, s.dflag, s.dirty,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.ro_cnt, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
-                    m->k.part_predict, m->k.tile_fov, s.tile_live, s.fut_dirty, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf, s.birth_cvr};
+                    m->k.ro_stat, m->k.part_predict, m->k.tile_fov, s.tile_live, s.fut_dirty, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf, s.birth_cvr};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
     if (m->nbsnap_buf) chk(hipFree(m->nbsnap_buf), "hipFree");
     {
@@ -365,13 +374,16 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&k.mv_rec, ntiles * 64 * d.slots * 2));
     HIPCHK(m, dalloc(&k.in_rec, ntiles * 64 * d.slots * 2));
     HIPCHK(m, dalloc(&k.in_cnt, ntiles));
-    HIPCHK(m, dalloc(&s.in_n, ntiles));
-    HIPCHK(m, hipMemset(s.in_n, 0, sizeof(int) * ntiles));
+    HIPCHK(m, dalloc(&s.in_n, 2 * ntiles));
+    HIPCHK(m, hipMemset(s.in_n, 0xff, sizeof(int) * 2 * ntiles));   // (no prediction's stamp)
     HIPCHK(m, dalloc(&s.pmask, W)); HIPCHK(m, dalloc(&s.ta, W)); HIPCHK(m, dalloc(&s.dflag, (size_t)d.v_loc)); HIPCHK(m, dalloc(&s.dirty, (size_t)DSP_DIRTY_CAP));
     HIPCHK(m, hipMemset(s.pmask, 0, sizeof(u64) * W)); HIPCHK(m, hipMemset(s.ta, 0, sizeof(u64) * W)); HIPCHK(m, hipMemset(s.dflag, 0, sizeof(int) * (size_t)d.v_loc));
     k.ro_rec = k.mv_rec;   // k_predict's staging area is dead once k_predict has ended: k_resample -> k_rollout reuse it
     HIPCHK(m, dalloc(&k.ro_cnt, 2 * ntiles));   // [ntiles] counts, then [ntiles] the float bits of the tiles' moving weight
     HIPCHK(m, hipMemset(k.ro_cnt, 0, sizeof(int) * 2 * ntiles));
+    HIPCHK(m, dalloc(&k.ro_stat, 2 * ((ntiles + 7) / 8)));
+    HIPCHK(m, hipMemset(k.ro_stat, 0, sizeof(int) * 2 * ((ntiles + 7) / 8)));
+    kernels_init_device();
     HIPCHK(m, dalloc(&k.omask, W));
     HIPCHK(m, hipMemset(k.omask, 0, sizeof(u64) * W));
     HIPCHK(m, dalloc(&k.ck_items, (size_t)d.np * ((d.capp + 63) / 64 + 1)));
@@ -396,7 +408,7 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, hipMemset(s.mask, 0, sizeof(u64) * W)); HIPCHK(m, hipMemset(s.nbmask, 0, sizeof(u64) * W));
     if (k.expmask) HIPCHK(m, hipMemset(k.expmask, 0, sizeof(u64) * W));
     HIPCHK(m, hipMemset(s.res4, 0, sizeof(float4) * (size_t)d.v_loc));
-    HIPCHK(m, hipMemset(s.fut, 0, sizeof(float) * (size_t)d.v_loc * (d.T ? d.T : 1)));
+    HIPCHK(m, hipMemset(s.fut, 0, sizeof(u64) * (size_t)d.v_loc * (d.T ? d.T : 1)));
     HIPCHK(m, hipMemset(s.fs, 0, sizeof(FrameScalars)));
     HIPCHK(m, hipMemset(s.obs_cnt, 0, sizeof(int) * d.np));
     HIPCHK(m, hipMemset(s.obs_ck, 0, sizeof(long long) * d.np * DSP_OBS_CAP));
@@ -515,6 +527,8 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
         case DSPMAP_P_ROLLOUT_INLINE: m->ro_force = v < 0 ? -1 : (v != 0 ? 1 : 0); break;
         case DSPMAP_P_FAST_DIVISION: if (v == 0) { m->d.div_ok = 0; m->div_forced_off = true; m->graph_epoch++; } break;
         case DSPMAP_P_PLACE_SPLIT_TILES: m->place_split_tiles = v < 1 ? 1 : (v > 2e9 ? 2000000000 : (int)v); m->graph_epoch++; break;
+        case DSPMAP_P_RESAMPLE_WG_TILES: m->resample_wg_tiles = v < 0 ? 0 : (v > 2e9 ? 2000000000 : (int)v); m->graph_epoch++; break;
+        case DSPMAP_P_SWEEP_ALTERNATE: m->sweep_alt = v < 0 ? -1 : (v != 0 ? 1 : 0); break;
         case DSPMAP_P_OCCLUSION_MARGIN: m->fp.occl_margin = (float)v; break;
         case DSPMAP_P_PAIR_CULL_SIGMAS: if (!(v > 0)) return dspmap_fail(m, DSPMAP_E_ARG, "pair cull radius must be positive"); m->cull_sigmas = (float)v; refresh_fp(m); break;
         case DSPMAP_P_REGENERATE_TABLES:
@@ -545,6 +559,8 @@ extern "C" double dspmap_get_param(const dspmap_t* m, int key) {
         case DSPMAP_P_UPDATE_TIME: return m->update_time;
         case DSPMAP_P_UPDATE_COUNTER: return m->update_counter;
         case DSPMAP_P_PLACE_SPLIT_TILES: return m->place_split_tiles;
+        case DSPMAP_P_RESAMPLE_WG_TILES: return m->resample_wg_tiles;
+        case DSPMAP_P_SWEEP_ALTERNATE: return m->sweep_alt;
         case DSPMAP_P_SPARSE_SWEEP: return m->sparse_mode ? 1 : 0;
         case DSPMAP_P_ROLLOUT_INLINE: return m->ro_kernel ? 0 : 1;
         case DSPMAP_P_FAST_DIVISION: return m->d.div_ok;
@@ -725,7 +741,7 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
         dspmap_prof_mark(m, 6);
         launch_birth_late(c, birth_grid, false, !split);
         dspmap_prof_mark(m, 7);
-        launch_resample(c);
+        dspmap_resample(m, c);
         dspmap_prof_mark(m, 8);
         if (m->prof) m->prof_pending = true;
         return;
@@ -734,6 +750,7 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     // k_predict and k_place and leave the frame's critical path; split, cursors and insert follow the weight update
     const bool early_birth = !fork && birth_grid > 0;
     launch_predict_only(c, !fork, early_birth);
+    { static const int gap_us = getenv("DSPMAP_EXP_GAP_US") ? atoi(getenv("DSPMAP_EXP_GAP_US")) : 0; launch_spin(c, gap_us); }   // (experiment: counted in the predict stage)
     dspmap_prof_mark(m, 2);
     launch_claim(c, early_birth ? birth_grid : 0, 0, 0, 0, split ? 1 : -1);
     if (split) {
@@ -762,18 +779,21 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     if (early_birth) launch_birth_late(c, birth_grid, all_static);
     else launch_birth(c, birth_grid, true, all_static);
     dspmap_prof_mark(m, 7);
-    launch_resample(c);
+    dspmap_resample(m, c);
     dspmap_prof_mark(m, 8);
     if (m->prof) m->prof_pending = true;
 }
 
-static int upload_birth(dspmap* m, const dspmap_vpoint* pts, int n);
+int dspmap_upload_birth(dspmap* m, const dspmap_vpoint* pts, int n);
+static int upload_birth(dspmap* m, const dspmap_vpoint* pts, int n) { return dspmap_upload_birth(m, pts, n); }
 
 // The reference keeps ONE clusters_feature_vector_dynamic_last (a function static, :1401,1542).  Here the device estimator
 // (dspmap_velest.hip) and the host stage (velocity_estimator.cpp: clouds beyond the device estimator's capacity, or
 // DSPMAP_P_VELOCITY_ESTIMATOR = 1) each hold a copy: whenever a frame is about to run on the one that does not hold the
 // newer copy, the state is handed over first.
-static int ve_state_to_host(dspmap* m) {
+int dspmap_ve_state_to_host(dspmap* m);
+static int ve_state_to_host(dspmap* m) { return dspmap_ve_state_to_host(m); }
+int dspmap_ve_state_to_host(dspmap* m) {
     if (m->ve_last_at != 2) return DSPMAP_OK;
     HIPCHK(m, hipStreamSynchronize(m->stream));
     int n3[4] = {0, 0, 0, 0};
@@ -785,7 +805,9 @@ static int ve_state_to_host(dspmap* m) {
     m->ve_last_at = 1;
     return DSPMAP_OK;
 }
-static int ve_state_to_device(dspmap* m) {
+int dspmap_ve_state_to_device(dspmap* m);
+static int ve_state_to_device(dspmap* m) { return dspmap_ve_state_to_device(m); }
+int dspmap_ve_state_to_device(dspmap* m) {
     if (m->ve_last_at != 1) return DSPMAP_OK;
     const int cap = m->ve.cap / 5 + 8;
     std::vector<float> buf((size_t)cap * 5);
@@ -805,6 +827,7 @@ static int ve_state_to_device(dspmap* m) {
 static int frame_with_host_stages(dspmap* m, int np, const float* pts_dev, const float q[4], const float dp[3], float dt,
                                   hipEvent_t pts_ready) {
     dspmap_freeze_birth_statics(m);
+    m->frame_parity ^= 1u;
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
     // dsp_static.h has no velocity estimation: every in-FOV point is a zero-velocity birth source
@@ -843,7 +866,7 @@ static int frame_with_host_stages(dspmap* m, int np, const float* pts_dev, const
     }
     if (nb > 0) launch_birth(c, nb, true, !have_cloud);  // :314-316
     else launch_ck_finalize(c);
-    launch_resample(c);
+    dspmap_resample(m, c);
     if (m->vz_frames > 0) --m->vz_frames;
     if (m->nb_dirty) { m->nb_dirty = false; m->graph_epoch++; }
     HIPCHK(m, hipEventRecord(m->ev1, m->stream));
@@ -881,6 +904,7 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
         return frame_with_host_stages(m, n_points, points_dev, q, dp, dt, m->ev_fork);
     }
     if (est_dev) { rc = ve_state_to_device(m); if (rc != DSPMAP_OK) return rc; m->ve_last_at = 2; }
+    m->frame_parity ^= 1u;
     LaunchCtx c = dspmap_ctx_of(m);
     const bool has_vz = m->vz_frames > 0;
     if (!has_vz) c.s.vz0 = nullptr;
@@ -918,22 +942,24 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
     if (m->use_graph && !m->prof) {
         // the kernel arguments of a frame are constant (per-frame values live in s.fpar): capture once, replay
         const unsigned long long key = ((unsigned long long)m->graph_epoch << 8) | (has_vz ? 1u : 0u) | ((unsigned)mode << 1) | (c.sparse ? 8u : 0u) | (c.ro_inline ? 16u : 0u);
-        if (!m->graph_exec || m->graph_key != key) {
-            if (m->graph_exec) {   // (replays of the old executable graph may still be queued: let them finish before it goes)
+        const int gi = c.sweep_rev ? 1 : 0;   // (one executable graph per sweep direction: the direction is a kernel argument)
+        if (!m->graph_exec[gi] || m->graph_key[gi] != key) {
+            if (m->graph_exec[gi]) {   // (replays of the old executable graph may still be queued: let them finish before it goes)
                 HIPCHK(m, hipStreamSynchronize(m->stream));
-                (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr;
+                (void)hipGraphExecDestroy(m->graph_exec[gi]); m->graph_exec[gi] = nullptr;
             }
             if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
             HIPCHK(m, hipStreamBeginCapture(m->stream, hipStreamCaptureModeRelaxed));
             enqueue_frame(m, c, m->pt_cap, m->birth_cap, false, mode == 1, mode == 2);  // (fork=true measured slower: HIP replays multi-branch graphs with a much higher launch cost) grids sized for the capacity; kernels bound-check against fpar
             HIPCHK(m, hipStreamEndCapture(m->stream, &m->graph));
             if (const char* dot = getenv("DSPMAP_GRAPH_DOT")) (void)hipGraphDebugDotPrint(m->graph, dot, 0);   // diagnostics: the frame's nodes and edges
-            HIPCHK(m, hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
+            HIPCHK(m, hipGraphInstantiate(&m->graph_exec[gi], m->graph, nullptr, nullptr, 0));
             (void)hipGraphDestroy(m->graph);   // the executable graph keeps its own copy of the topology
             m->graph = nullptr;
-            m->graph_key = key;
+            m->graph_key[gi] = key;
         }
-        HIPCHK(m, hipGraphLaunch(m->graph_exec, m->stream));
+        m->last_resample_variant = resample_variant(c);   // (baked into the graph: c.ro_inline is part of its key)
+        HIPCHK(m, hipGraphLaunch(m->graph_exec[gi], m->stream));
         if (m->frame_ring) {
             if (m->ring_head % (DSPMAP_RING / 4) == DSPMAP_RING / 4 - 1) {
                 const unsigned q = (m->ring_head / (DSPMAP_RING / 4)) % 4;
@@ -1005,7 +1031,7 @@ int dspmap_stage_points(dspmap* m, int n, int stride, const float* pts) {
     return DSPMAP_OK;
 }
 
-static int upload_birth(dspmap* m, const dspmap_vpoint* pts, int n) {
+int dspmap_upload_birth(dspmap* m, const dspmap_vpoint* pts, int n) {
     int rc = dspmap_ensure_point_cap(m, n);
     if (rc != DSPMAP_OK) return rc;
     if (n > m->birth_pin_cap) {
@@ -1204,7 +1230,7 @@ extern "C" int dspmap_clear_state(dspmap_t* m) {
     HIPCHK(m, hipMemsetAsync(m->s.mask, 0, sizeof(u64) * W, m->stream));
     HIPCHK(m, hipMemsetAsync(m->s.nbmask, 0, sizeof(u64) * W, m->stream));
     HIPCHK(m, hipMemsetAsync(m->s.res4, 0, sizeof(float4) * (size_t)d.v_loc, m->stream));
-    HIPCHK(m, hipMemsetAsync(m->s.fut, 0, sizeof(float) * (size_t)d.v_loc * (d.T ? d.T : 1), m->stream));
+    HIPCHK(m, hipMemsetAsync(m->s.fut, 0, sizeof(u64) * (size_t)d.v_loc * (d.T ? d.T : 1), m->stream));
     HIPCHK(m, hipMemsetAsync(m->s.fut_stat, 0, sizeof(float) * (size_t)d.v_loc, m->stream));
     m->fut_clear_pending = false;
     HIPCHK(m, hipMemsetAsync(m->s.pyr_cnt, 0, sizeof(int) * d.np, m->stream));
@@ -1328,6 +1354,7 @@ extern "C" int dspmap_set_current_position(dspmap_t* m, float x, float y, float 
 }
 extern "C" int dspmap_stage_predict(dspmap_t* m, float dx, float dy, float dz, float dt) {
     READY(m);
+    m->frame_parity ^= 1u;
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
     for (int i = 0; i < 4; i++) m->hp.quat[i] = m->quat[i];
@@ -1379,7 +1406,7 @@ extern "C" int dspmap_stage_resample(dspmap_t* m) {
     dspmap_flush_future_clear(m);   // a pending clear must not wipe what this stage accumulates
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
-    launch_resample(c);
+    dspmap_resample(m, c);
     if (m->nb_dirty) { m->nb_dirty = false; m->graph_epoch++; }
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
@@ -1457,6 +1484,20 @@ extern "C" int dspmap_debug_tile_view(dspmap_t* m, int* out, int cap) {
     for (int i = 0; i < m->k.ntiles; ++i) out[i] = (out[i] >> 1) == m->hp.epoch ? (out[i] & 1) : -1;   // -1: not visited by the last k_predict (empty)
     return m->k.ntiles;
 }
+extern "C" int dspmap_debug_rollout_paths(dspmap_t* m, long long out[3]) {
+    READY(m);
+    if (!out) return DSPMAP_E_ARG;
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    out[0] = m->last_resample_variant; out[1] = 0; out[2] = 0;
+    const int ro = m->last_resample_variant >> 1;
+    if (ro == 1 || ro == 2) {   // k_rollout ran: its groups' counts
+        const size_t ng = ((size_t)m->k.ntiles + 7) / 8;
+        std::vector<int> st(2 * ng);
+        HIPCHK(m, hipMemcpy(st.data(), m->k.ro_stat, sizeof(int) * 2 * ng, hipMemcpyDeviceToHost));
+        for (size_t g = 0; g < ng; ++g) { out[1] += st[2 * g]; out[2] += st[2 * g + 1]; }
+    }
+    return DSPMAP_OK;
+}
 extern "C" int dspmap_get_pyramid_counts(dspmap_t* m, int* out) {
     READY(m);
     if (!out) return DSPMAP_E_ARG;
@@ -1521,16 +1562,17 @@ extern "C" int dspmap_save_checkpoint(dspmap_t* m, const char* path) {
     rc = dspmap_export_state(m, n, voxel.data(), slot.data(), rec.data(), &n);
     if (rc != DSPMAP_OK) return rc;
     const size_t V = (size_t)m->d.v_loc, T = (size_t)m->d.T;
-    std::vector<float> res(V * 4), fut(V * (T ? T : 1));
-    LaunchCtx c = dspmap_ctx_of(m);
-    launch_future_combine(c);   // fold the static-particle mass into the per-horizon accumulators
+    // the future accumulators as they are: fixed-point sums of the moving particles [T][V] + the static particles' mass [V]
+    std::vector<float> res(V * 4), fstat(V);
+    std::vector<u64> fut(V * (T ? T : 1));
     HIPCHK(m, hipMemcpyAsync(res.data(), m->s.res4, sizeof(float4) * V, hipMemcpyDeviceToHost, m->stream));
-    if (T) HIPCHK(m, hipMemcpyAsync(fut.data(), m->s.fut_out, sizeof(float) * V * T, hipMemcpyDeviceToHost, m->stream));
+    if (T) HIPCHK(m, hipMemcpyAsync(fut.data(), m->s.fut, sizeof(u64) * V * T, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipMemcpyAsync(fstat.data(), m->s.fut_stat, sizeof(float) * V, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     CkHeader h;
     memset(&h, 0, sizeof(h));
     memcpy(h.magic, "DSPMAPCK", 8);
-    h.version = 1;
+    h.version = 2;
     h.cfg = m->cfg; h.fp = m->fp;
     h.nb_frozen = m->nb_frozen; h.have_last = m->have_last; h.vz_frames = m->vz_frames;
     for (int i = 0; i < 3; i++) { h.last_p[i] = m->last_p[i]; h.cur_pos[i] = m->cur_pos[i]; }
@@ -1546,7 +1588,8 @@ extern "C" int dspmap_save_checkpoint(dspmap_t* m, const char* path) {
     ok = ok && (n == 0 || (fwrite(voxel.data(), sizeof(int), n, f) == (size_t)n && fwrite(slot.data(), sizeof(int), n, f) == (size_t)n &&
                            fwrite(rec.data(), sizeof(float) * 8, n, f) == (size_t)n));
     ok = ok && fwrite(res.data(), sizeof(float) * 4, V, f) == V;
-    ok = ok && (T == 0 || fwrite(fut.data(), sizeof(float) * T, V, f) == V);
+    ok = ok && (T == 0 || fwrite(fut.data(), sizeof(u64) * T, V, f) == V);
+    ok = ok && fwrite(fstat.data(), sizeof(float), V, f) == V;
     ok = (fclose(f) == 0) && ok;
     if (!ok) return dspmap_fail(m, DSPMAP_E_STATE, "short write to %s", path);
     return DSPMAP_OK;
@@ -1558,9 +1601,9 @@ extern "C" int dspmap_load_checkpoint(dspmap_t* m, const char* path) {
     FILE* f = fopen(path, "rb");
     if (!f) return dspmap_fail(m, DSPMAP_E_ARG, "cannot open %s", path);
     CkHeader h;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "DSPMAPCK", 8) != 0 || h.version != 1) {
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "DSPMAPCK", 8) != 0 || h.version != 2) {
         fclose(f);
-        return dspmap_fail(m, DSPMAP_E_ARG, "%s is not a version-1 dspmap checkpoint", path);
+        return dspmap_fail(m, DSPMAP_E_ARG, "%s is not a version-2 dspmap checkpoint", path);
     }
     const dspmap_config &a = h.cfg, &b = m->cfg;
     bool same = a.nx == b.nx && a.ny == b.ny && a.nz == b.nz && a.voxel_resolution == b.voxel_resolution &&
@@ -1578,11 +1621,13 @@ extern "C" int dspmap_load_checkpoint(dspmap_t* m, const char* path) {
     }
     const size_t V = (size_t)m->d.v_loc, T = (size_t)m->d.T;
     std::vector<int> voxel((size_t)n + 1), slot((size_t)n + 1);
-    std::vector<float> rec((size_t)n * 8 + 8), res(V * 4), fut(V * (T ? T : 1));
+    std::vector<float> rec((size_t)n * 8 + 8), res(V * 4), fstat(V);
+    std::vector<u64> fut(V * (T ? T : 1));
     bool ok = n == 0 || (fread(voxel.data(), sizeof(int), n, f) == (size_t)n && fread(slot.data(), sizeof(int), n, f) == (size_t)n &&
                          fread(rec.data(), sizeof(float) * 8, n, f) == (size_t)n);
     ok = ok && fread(res.data(), sizeof(float) * 4, V, f) == V;
-    ok = ok && (T == 0 || fread(fut.data(), sizeof(float) * T, V, f) == V);
+    ok = ok && (T == 0 || fread(fut.data(), sizeof(u64) * T, V, f) == V);
+    ok = ok && fread(fstat.data(), sizeof(float), V, f) == V;
     fclose(f);
     if (!ok) return dspmap_fail(m, DSPMAP_E_ARG, "%s is truncated", path);
     int rc = dspmap_clear_state(m);
@@ -1590,14 +1635,9 @@ extern "C" int dspmap_load_checkpoint(dspmap_t* m, const char* path) {
     rc = dspmap_import_state(m, n, voxel.data(), slot.data(), rec.data());
     if (rc != DSPMAP_OK) return rc;
     HIPCHK(m, hipMemcpyAsync(m->s.res4, res.data(), sizeof(float4) * V, hipMemcpyHostToDevice, m->stream));
-    if (T) {   // the file holds the caller's [V][T] layout (static mass folded in); the accumulators are horizon-major
-        std::vector<float> ft(V * T);
-        for (size_t v = 0; v < V; ++v)
-            for (size_t t = 0; t < T; ++t) ft[t * V + v] = fut[v * T + t];
-        HIPCHK(m, hipMemcpy(m->s.fut, ft.data(), sizeof(float) * V * T, hipMemcpyHostToDevice));
-        HIPCHK(m, hipMemsetAsync(m->s.fut_stat, 0, sizeof(float) * V, m->stream));
-        HIPCHK(m, hipMemsetAsync(m->s.fut_dirty, 1, sizeof(int) * (size_t)m->k.ntiles, m->stream));   // (any tile may hold mass now)
-    }
+    if (T) HIPCHK(m, hipMemcpy(m->s.fut, fut.data(), sizeof(u64) * V * T, hipMemcpyHostToDevice));
+    HIPCHK(m, hipMemcpy(m->s.fut_stat, fstat.data(), sizeof(float) * V, hipMemcpyHostToDevice));
+    HIPCHK(m, hipMemsetAsync(m->s.fut_dirty, 1, sizeof(int) * (size_t)m->k.ntiles, m->stream));   // (any tile may hold mass now)
     HIPCHK(m, hipStreamSynchronize(m->stream));
     {   // filter parameters and the frozen birth statics come from the checkpoint; the random tables are THIS handle's
         // (regenerated from its seed or injected by its caller), so their lengths stay, and the pair-cull radius is

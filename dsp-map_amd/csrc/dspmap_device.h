@@ -255,6 +255,18 @@ __device__ __forceinline__ f2v pair_gk2(f2v px, f2v py, f2v pz, f2v ox, f2v oy, 
 __device__ __forceinline__ double ck_snap(float a) { return __dsub_rn(__dadd_rn((double)a, 393216.0), 393216.0); }
 __device__ __forceinline__ float ck_from_fix(long long v) { return (float)((double)v * (1.0 / CK_FIX_SCALE)); }
 
+// Future-status accumulators (voxels_objects_number[v][4..], `+=` at :961): 64-bit fixed point in units of 2^-24 (6e-8 -- the
+// rounding of an fp32 accumulator that holds ~1; weights entering the rollout are >= 1e-3, :941).  Every moving particle adds
+// the SAME integer whichever path carries it (resampler's idle waves, k_rollout's LDS windows or its single atomics, any slab of a
+// sharded map), and integer sums are associative: the future status is reproducible bit for bit and independent of the variant
+// the handle picked.  A 32-bit LDS window cell holds up to 2^32 * 2^-24 = 256 units of weight.
+#define FUT_FIX_SCALE 16777216.0f
+#define FUT_FIX_INV 5.9604644775390625e-08
+#define FUT_WINDOW_MAX_W 250.0f
+__device__ __forceinline__ u64 fut_quantum(float w) { return (u64)__float2ull_rn(w * FUT_FIX_SCALE); }   // (NaN / negative -> 0)
+__device__ __forceinline__ void fut_add(u64* cell, u64 q) { __hip_atomic_fetch_add(cell, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float fut_value(u64 q) { return (float)((double)q * FUT_FIX_INV); }
+
 #define GU 16
 // obs_gather_wave: one wave per pyramid (k_obs_gather; in a whole frame the extra workgroups of k_predict).  Appends matching points in INPUT order
 // (stable, ballot + prefix popcount) to the pyramid's bin, keeps the first 99

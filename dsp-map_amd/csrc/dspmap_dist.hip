@@ -235,9 +235,47 @@ struct RdzvRecord {
 void rdzv_nonce(char out[120]) {
     const char* run = getenv("DSPMAP_RDZV_NONCE");
     if (!run) run = getenv("TORCHELASTIC_RUN_ID");
+    memset(out, 0, 120);   // the whole field is written to the file and compared: no stack residue behind the string
     snprintf(out, 120, "%s:%ld", run ? run : "-", (long)getppid());
 }
+// does a record read from the rendezvous file belong to this launch?  (magic + the nonce STRING: bytes behind its NUL do not count)
+bool rdzv_matches(const RdzvRecord& r, const char nonce[120]) {
+    return memcmp(r.magic, "DSPRDZV1", 8) == 0 && strnlen(r.nonce, sizeof(r.nonce)) < sizeof(r.nonce) && strncmp(r.nonce, nonce, sizeof(r.nonce)) == 0;
+}
 }  // namespace
+// test hook (no device, no RCCL): waits up to `timeout_ms` for this launch's record in `path` like a rank != 0 does and copies
+// the unique id out.  1 = found, 0 = not found.
+extern "C" int dspmap_debug_rdzv_wait(const char* path, int timeout_ms, char id_out[DSPMAP_UNIQUE_ID_BYTES]) {
+    char nonce[120];
+    rdzv_nonce(nonce);
+    for (int t = 0; t <= timeout_ms; t += 10) {
+        const int fd = open(path, O_RDONLY | O_NOFOLLOW);
+        if (fd >= 0) {
+            struct stat st;
+            RdzvRecord r2;
+            const bool got = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == getuid() &&
+                             read(fd, &r2, sizeof(r2)) == (ssize_t)sizeof(r2) && rdzv_matches(r2, nonce);
+            close(fd);
+            if (got) { if (id_out) memcpy(id_out, r2.id, DSPMAP_UNIQUE_ID_BYTES); return 1; }
+        }
+        usleep(10000);
+    }
+    return 0;
+}
+// ... and what rank 0 publishes (same record layout, same nonce rule); 1 = written
+extern "C" int dspmap_debug_rdzv_publish(const char* path, const char id[DSPMAP_UNIQUE_ID_BYTES]) {
+    RdzvRecord rec;
+    memset(&rec, 0, sizeof(rec));
+    memcpy(rec.magic, "DSPRDZV1", 8);
+    rdzv_nonce(rec.nonce);
+    memcpy(rec.id, id, DSPMAP_UNIQUE_ID_BYTES);
+    (void)unlink(path);
+    const int fd = open(path, O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+    if (fd < 0) return 0;
+    const bool ok = write(fd, &rec, sizeof(rec)) == (ssize_t)sizeof(rec);
+    close(fd);
+    return ok ? 1 : 0;
+}
 extern "C" int dspmap_mgpu_comm_init_from_env(dspmap_t* m) {
     if (!m) return DSPMAP_E_ARG;
     const char* wr = getenv("WORLD_SIZE"); const char* rk = getenv("RANK");
@@ -273,8 +311,7 @@ extern "C" int dspmap_mgpu_comm_init_from_env(dspmap_t* m) {
                 struct stat st;
                 RdzvRecord r2;
                 got = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == getuid() &&
-                      read(fd, &r2, sizeof(r2)) == (ssize_t)sizeof(r2) && memcmp(r2.magic, "DSPRDZV1", 8) == 0 &&
-                      memcmp(r2.nonce, nonce, sizeof(r2.nonce)) == 0;   // this launch's file, not a leftover
+                      read(fd, &r2, sizeof(r2)) == (ssize_t)sizeof(r2) && rdzv_matches(r2, nonce);   // this launch's file, not a leftover
                 if (got) rec = r2;
                 close(fd);
             }

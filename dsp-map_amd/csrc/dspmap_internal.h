@@ -97,9 +97,13 @@ struct dspmap {
     int sparse_force = -1;           // DSPMAP_P_SPARSE_SWEEP: -1 from the hint, 0 / 1 forced
     int place_split_tiles = 8192;    // maps with at least this many tiles place the arrivals of the tiles outside the field of view
                                      // on the side stream, beside the pair kernels (DSPMAP_P_PLACE_SPLIT_TILES)
+    int resample_wg_tiles = 8192;    // one-word maps with fewer tiles run the four-waves-per-tile resampler (DSPMAP_P_RESAMPLE_WG_TILES)
+    int last_resample_variant = 0;   // resample_variant() of the last frame / stage (dspmap_debug_rollout_paths)
     hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    unsigned long long graph_key = ~0ull;
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};   // the captured frame, one per sweep direction (LaunchCtx::sweep_rev is a kernel argument)
+    unsigned long long graph_key[2] = {~0ull, ~0ull};
+    int sweep_alt = -1;              // DSPMAP_P_SWEEP_ALTERNATE: -1 maps of >= 4096 tiles alternate the direction of their tile sweeps, 0 never, 1 always
+    unsigned frame_parity = 0;       // toggled by every prediction
     unsigned graph_epoch = 0;   // bumped whenever a baked-in kernel argument (pointer / parameter) changes
     // multi-GPU split-phase state
     float cull_sigmas = 9.f;           // DSPMAP_P_PAIR_CULL_SIGMAS
@@ -134,6 +138,7 @@ int dspmap_fail(dspmap* m, int code, const char* fmt, ...);
 void dspmap_prof_mark(dspmap* m, int i);
 void dspmap_prof_collect(dspmap* m);
 LaunchCtx dspmap_ctx_of(dspmap* m);
+void dspmap_resample(dspmap* m, const LaunchCtx& c);   // launch_resample + bookkeeping of the variant it ran
 int dspmap_gate_and_delta(dspmap* m, const float pos[3], double stamp, const float q[4], float dp[3], float* dt);
 void dspmap_freeze_birth_statics(dspmap* m);
 int dspmap_ensure_point_cap(dspmap* m, int n);
@@ -144,7 +149,10 @@ void dspmap_dist_free(dspmap* m);
 int dspmap_pts_slot_acquire(dspmap* m, int n);   // next pinned staging slot (waits for the copy that last used it) -> m->pts_pin
 int dspmap_pts_slot_release(dspmap* m);          // after queueing the copy that reads / writes m->pts_pin
 int dspmap_stage_points(dspmap* m, int n, int stride, const float* pts);   // host cloud -> m->pts_dev (pinned staging, async copy)
-int dspmap_begin_cloud(dspmap* m, int n_points, bool static_birth);   // bumps the frame epoch; returns the birth grid bound
+int dspmap_begin_cloud(dspmap* m, int n_points, bool static_birth);
+int dspmap_upload_birth(dspmap* m, const dspmap_vpoint* pts, int n);   // host cloud -> DevState::birth (pinned staging, async copy)
+int dspmap_ve_state_to_host(dspmap* m);     // clusters_feature_vector_dynamic_last (:1401) to the implementation that runs next
+int dspmap_ve_state_to_device(dspmap* m);   // bumps the frame epoch; returns the birth grid bound
 
 #define HIPCHK(m, call)                                                                            \
     do {                                                                                           \

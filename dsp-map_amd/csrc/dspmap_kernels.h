@@ -29,6 +29,7 @@ struct KernelScratch {
                         // flag-15 records / a second birth stage without resampling: addAParticle (:1184-1185) skips those slots
     float4* ro_rec;     // [ntiles][64*slots][2] the tile's MOVING old particles {px, py, vx, vy}, {w, local voxel} (k_resample -> k_rollout)
     int* ro_cnt;        // [2 * ntiles] per tile: records in ro_rec; then the float bits of their summed weight
+    int* ro_stat;       // [2 * ceil(ntiles / 8)] per group of k_rollout: contributions through its LDS windows / straight to the accumulators
     int* work_list;     // [v_loc] scratch: per-voxel prefix of the constructor-seeded particles' noise ranks (k_vz_count)
     int ntiles;         // tiles of 64 voxels; k_predict / k_place run one workgroup per tile
     int nblk_sweep;
@@ -44,6 +45,9 @@ struct LaunchCtx {
     VelEst ve;
     int n_cu = 256;      // compute units of the device (sizes launches that are meant to occupy only a share of it)
     bool ro_inline = true; // small maps (k_resample_wg): the tiles roll their moving particles out themselves, no k_rollout launch
+    int resample_wg_tiles = 8192;   // one-word maps with fewer tiles run k_resample_wg (dspmap::resample_wg_tiles, DSPMAP_P_RESAMPLE_WG_TILES)
+    bool sweep_rev = false;   // this frame's k_predict / k_resample walk the tiles from the last one down and k_place from the first one up
+                              // (the next frame the other way round): every tile sweep starts where its predecessor ended (Infinity Cache)
     bool sparse = false; // most tiles hold nothing (dspmap::sparse_mode): k_predict's variant that leaves such tiles first
 };
 
@@ -54,6 +58,7 @@ void launch_obs_bin(const LaunchCtx& c, int n_pts_grid);
 void launch_setup_and_bin(const LaunchCtx& c, int n_pts_grid, bool gather = true, const FrameParams* ring = nullptr, int ring_mask = 0);   // ring: the frame's parameter block is read from this pinned ring   // gather = false: launch_predict*(c, true) does it
 // mapPrediction (:627-701) incl. re-binning of movers (moveParticle :1206-1274)
 void launch_predict(const LaunchCtx& c, bool with_gather = false);
+void launch_spin(const LaunchCtx& c, int us);   // experiment aid: a one-wave kernel that waits `us` microseconds
 void launch_predict_only(const LaunchCtx& c, bool with_gather = false, bool with_rank = false);   // with_rank: k_birth_rank rides along
 void launch_scan_blocks(const LaunchCtx& c, int nblk);   // exclusive scan of s.blk_cnt[0..nblk), total -> fs->occupied_count
 void launch_claim(const LaunchCtx& c, int n_birth_grid = 0, int part = 0, int tile_lo = 0, int tile_hi = 0, int sel = -1);   // sel: -1 every tile of the part, 1 / 0 only the tiles with / without a view on the sensor's field of view (tile_fov)   // part: 0 all tiles, 1 [lo, hi), 2 the rest;   // > 0: k_birth_children rides along (after a launch with_rank)
@@ -86,6 +91,8 @@ void launch_birth_plan_insert(const LaunchCtx& c, int n_birth, bool in_frame, bo
 void launch_birth_materialize(const LaunchCtx& c, BirthSrc* out, int cap, int* n_out);   // the frame's synthesised birth cloud, for host readback
 // mapOccupancyCalculationAndResample (:924-1057)
 void launch_resample(const LaunchCtx& c);   // + the future rollout of the moving particles (k_rollout)
+int resample_variant(const LaunchCtx& c);   // bit 0: k_resample_wg; bits 1-2: rollout 0 inline, 1 k_rollout light, 2 k_rollout windows, 3 none
+void kernels_init_device();                 // function attributes of the current device (dynamic LDS of k_rollout)
 // readout (:385-438)
 void launch_occupied_compact(const LaunchCtx& c, float thr);
 void launch_clear_future(const LaunchCtx& c);

@@ -57,7 +57,7 @@ __global__ void k_reset(MapDims d, DevState s, int flags) {
     if (flags & RESET_PRED) {
         for (int i = gt; i < d.np; i += gn) s.pyr_cnt[i] = 0;
         if (gt == 0) {
-            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->n_pyr_removed = 0; s.fs->n_dirty = 0; s.fs->n_overflow_inexact = 0; s.fs->n_place_vf = 0; s.fs->n_place_pf = 0; s.fs->live_hint = s.fs->live_acc; s.hint_out[0] = s.fs->live_acc; s.fs->live_acc = 0; s.hint_out[1] = s.fs->mv_acc; s.fs->mv_acc = 0;
+            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->n_pyr_removed = 0; s.fs->n_dirty = 0; s.fs->n_overflow_inexact = 0; s.fs->n_place_vf = 0; s.fs->n_place_pf = 0; s.fs->pred_epoch = s.fs->pred_epoch + 1; s.fs->live_hint = s.fs->live_acc; s.hint_out[0] = s.fs->live_acc; s.fs->live_acc = 0; s.hint_out[1] = s.fs->mv_acc; s.fs->mv_acc = 0;
         }
     }
 }
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) k_obs_points(MapDims d, DevState s, const
         if (gt == 0) {
             s.fs->cur_pos[0] = cpx; s.fs->cur_pos[1] = cpy; s.fs->cur_pos[2] = cpz;
             s.fs->n_valid = 0; s.fs->n_obs = 0; s.fs->has_expected_override = 0;   // k_obs_gather accumulates the first two
-            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->n_pyr_removed = 0; s.fs->n_dirty = 0; s.fs->n_overflow_inexact = 0; s.fs->n_place_vf = 0; s.fs->n_place_pf = 0; s.fs->live_hint = s.fs->live_acc; s.hint_out[0] = s.fs->live_acc; s.fs->live_acc = 0; s.hint_out[1] = s.fs->mv_acc; s.fs->mv_acc = 0;
+            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->n_pyr_removed = 0; s.fs->n_dirty = 0; s.fs->n_overflow_inexact = 0; s.fs->n_place_vf = 0; s.fs->n_place_pf = 0; s.fs->pred_epoch = s.fs->pred_epoch + 1; s.fs->live_hint = s.fs->live_acc; s.hint_out[0] = s.fs->live_acc; s.fs->live_acc = 0; s.hint_out[1] = s.fs->mv_acc; s.fs->mv_acc = 0;
         }
     } else {
         for (int i = threadIdx.x; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
@@ -309,7 +309,10 @@ __device__ __forceinline__ void place_fix_wave(const MapDims& d, const DevState&
                                                const int* __restrict__ refs, const int lv, int* s_key, int* s_idx, int* s_s1, int* s_s2) {
     const int l = lane_id();
     const int tile = lv >> 6, cap = 64 * d.slots;
-    const int n = min(s.in_n[tile], cap);
+    // the tile's inbox, its arrival count and its pmask words are THIS prediction's only if k_place served the tile in it (a tile
+    // without arrivals keeps an earlier frame's: its voxels can still be dirty -- a stayer turned away by a full list -- and then
+    // there is nothing to re-slot)
+    const int n = s.in_n[2 * tile + 1] == s.fs->pred_epoch ? min(s.in_n[2 * tile], cap) : 0;
     const size_t base = (size_t)tile * cap;
     const int gD = lv + d.v_base;
     int m = 0;   // (wave-uniform)
@@ -1493,12 +1496,12 @@ __global__ void k_future_combine(MapDims d, DevState s) {
     const int lv = blockIdx.x * blockDim.x + threadIdx.x;
     if (lv >= d.v_loc) return;
     const float st = s.fut_stat[lv];
-    for (int t = 0; t < d.T; ++t) s.fut_out[(size_t)lv * d.T + t] = s.fut[(size_t)t * d.v_loc + lv] + st;
+    for (int t = 0; t < d.T; ++t) s.fut_out[(size_t)lv * d.T + t] = fut_value(s.fut[(size_t)t * d.v_loc + lv]) + st;
 }
 void launch_future_combine(const LaunchCtx& c) {
     hipLaunchKernelGGL(k_future_combine, dim3((c.d.v_loc + 255) / 256), dim3(256), 0, c.stream, c.d, c.s);
 }
 void launch_clear_future(const LaunchCtx& c) {
-    (void)hipMemsetAsync(c.s.fut, 0, sizeof(float) * (size_t)c.d.v_loc * c.d.T, c.stream);
+    (void)hipMemsetAsync(c.s.fut, 0, sizeof(u64) * (size_t)c.d.v_loc * c.d.T, c.stream);
     (void)hipMemsetAsync(c.s.fut_stat, 0, sizeof(float) * (size_t)c.d.v_loc, c.stream);
 }

@@ -1,6 +1,8 @@
 // dspmap_mgpu.hip -- split-phase frame for Z-slab sharding across GPUs (include/dspmap.h,
 // "multi-GPU split-phase frame").  One process per GPU; the collectives between the phases are
 // issued by the caller through torch.distributed / RCCL on buffers it owns and binds here.
+#include <vector>
+
 #include "dspmap_internal.h"
 
 extern "C" int dspmap_mgpu_bind(dspmap_t* m, long long* ck_dev, int* nstatic_dev, int nstatic_cap) {
@@ -33,19 +35,46 @@ extern "C" int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_
     READY(m);
     if (!m->mgpu_bound) return dspmap_fail(m, DSPMAP_E_STATE, "call dspmap_mgpu_bind first");
     if (n_points < 0 || (n_points > 0 && !points_dev) || !pos || !q) return dspmap_fail(m, DSPMAP_E_ARG, "bad arguments");
-    const int nb_own = birth_dev ? n_birth : n_points;
-    if (nb_own > m->mgpu_nstatic_cap || n_points > m->pt_cap) return dspmap_fail(m, DSPMAP_E_ARG, "more points than the bound capacity");
+    if (n_points > m->mgpu_nstatic_cap || n_points > m->pt_cap || (birth_dev && n_birth > m->mgpu_nstatic_cap))
+        return dspmap_fail(m, DSPMAP_E_ARG, "more points than the bound capacity");
     // birth cloud: the caller's (mode 0), every point in view a static source (1), or -- DSPMAP_P_VELOCITY_ESTIMATOR = 2 -- the
     // device velocity estimator's (2).  The estimator (velocityEstimationThread :1377-1544, forked and joined by every
     // update() :297,311) works on the frame's cloud, which every rank holds, and is deterministic: every rank runs it
     // redundantly and gets the same tagged cloud bit for bit, exactly like the rank / children of the birth stage.
-    const bool want_est = !birth_dev && m->use_vel_est != 0 && !m->cfg.static_model;
-    if (want_est && (m->use_vel_est != 2 || n_points > m->ve.cap))
-        return dspmap_fail(m, DSPMAP_E_ARG, "a sharded frame runs the velocity estimator on the device (DSPMAP_P_VELOCITY_ESTIMATOR = 2, "
-                           "clouds of at most %d points); got mode %d, %d points", m->ve.cap, m->use_vel_est, n_points);
+    bool want_est = !birth_dev && m->use_vel_est != 0 && !m->cfg.static_model;
+    const bool est_host = want_est && (m->use_vel_est != 2 || n_points > m->ve.cap);
     float dp[3], dt;
     if (!dspmap_gate_and_delta(m, pos, stamp, q, dp, &dt)) return DSPMAP_REJECTED;
+    if (est_host && n_points > 0) {
+        // DSPMAP_P_VELOCITY_ESTIMATOR = 1, or a cloud beyond the device estimator's capacity: every rank runs the HOST stage on the
+        // replicated cloud (deterministic: the same tagged cloud everywhere), like the unsharded map falls back to it
+        // (dspmap_api.hip: device_frame).  One D2H copy of the cloud and a host synchronisation in such a frame.
+        int rc = dspmap_pts_slot_acquire(m, n_points);
+        if (rc != DSPMAP_OK) return rc;
+        HIPCHK(m, hipMemcpyAsync(m->pts_pin, points_dev, sizeof(float) * 3 * (size_t)n_points, hipMemcpyDeviceToHost, m->stream));
+        rc = dspmap_pts_slot_release(m);
+        if (rc != DSPMAP_OK) return rc;
+        rc = dspmap_ve_state_to_host(m);   // (synchronises the stream: the copy has landed)
+        if (rc != DSPMAP_OK) return rc;
+        HIPCHK(m, hipStreamSynchronize(m->stream));
+        std::vector<float> view;
+        view.reserve((size_t)n_points * 3);
+        m->vel.rotate_and_filter(m->pts_pin, n_points, q, view);
+        m->vel.run(view, m->cur_pos, dt, m->voxel_filter_res, m->h_birth);
+        m->ve_last_at = 1;
+        rc = dspmap_upload_birth(m, m->h_birth.data(), (int)m->h_birth.size());
+        if (rc != DSPMAP_OK) return rc;
+        birth_dev = reinterpret_cast<const dspmap_vpoint*>(m->s.birth);
+        n_birth = (int)m->h_birth.size();
+        want_est = false;
+    } else if (est_host) {
+        want_est = false;   // (an empty cloud: nothing to estimate, the view is empty either way)
+    }
+    if (want_est) { const int rc = dspmap_ve_state_to_device(m); if (rc != DSPMAP_OK) return rc; }
+    const int nb_own = birth_dev ? n_birth : n_points;
+    if (nb_own > m->mgpu_nstatic_cap) return dspmap_fail(m, DSPMAP_E_ARG, "more birth sources than the bound capacity");
     dspmap_freeze_birth_statics(m);
+    m->frame_parity ^= 1u;
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
     const int mode = birth_dev ? 0 : (want_est ? 2 : 1);
@@ -201,7 +230,7 @@ extern "C" int dspmap_mgpu_finish(dspmap_t* m) {
     if (!m->mgpu_birth_early) launch_birth_early(c, m->last_n_birth, false);   // caller used the per-direction exports
     launch_birth_finish(c, m->last_n_birth, m->mgpu_all_static);
     m->mgpu_birth_early = false;
-    launch_resample(c);
+    dspmap_resample(m, c);
     if (m->nb_dirty) { m->nb_dirty = false; m->graph_epoch++; }
     HIPCHK(m, hipEventRecord(m->ev1, m->stream));
     m->ev_valid = true;

@@ -243,7 +243,13 @@ template <int MW, int NW, bool HASVZ, bool SPARSE>
 __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevState s, FilterParams fp, int has_vz, int* __restrict__ part,
                                                  float4* __restrict__ mv_rec, float4* __restrict__ in_rec, int* __restrict__ in_cnt,
                                                  u64* __restrict__ expmask, const int* __restrict__ vz_pre, const u64* __restrict__ vz_q,
-                                                 u64* __restrict__ omask, int extra, int* __restrict__ tile_fov) {
+                                                 u64* __restrict__ omask, int extra, int* __restrict__ tile_fov, int rev) {
+    // rev: the tiles are walked from the last one down (workgroup -> tile mapping only).  The tile sweeps of a frame alternate
+    // their direction -- k_predict, then k_place the other way, then k_resample, and the next frame's k_predict the other way
+    // again -- so that each starts on the tiles its predecessor touched last: a large map's live rows are several times the
+    // 256 MB Infinity Cache, and a sweep that starts where the last one ENDED finds its first ~fifth there instead of in HBM
+    // (132x132x60 saturated: placement -18 %, resampling -8 %, prediction -6 %; same results -- no stage depends on the order
+    // in which tiles are visited).
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
     __shared__ u64 s_keep[MW * 64], s_ex[MW * 64];
@@ -267,7 +273,8 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
     if (SPARSE) {
         const int nextra0 = ((extra & 1) ? (d.np + NW - 1) / NW : 0) + ((extra & 2) ? 1 : 0);
         if ((int)blockIdx.x >= nextra0) {
-            const int bx0 = (int)blockIdx.x - nextra0;
+            const int bq0 = (int)blockIdx.x - nextra0;
+            const int bx0 = rev ? (int)gridDim.x - nextra0 - 1 - bq0 : bq0;
             int t_live, f_dirty, f_clear;
             sload_i3(s.tile_live + bx0, s.fut_dirty + bx0, &s.fpar->clear_fut, t_live, f_dirty, f_clear);
             tflags = (t_live ? 1 : 0) | ((f_clear && f_dirty) ? 2 : 0);
@@ -298,7 +305,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
         }
         return;
     }
-    const int BX = (int)blockIdx.x - nextra;   // tile index
+    const int BX = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x - nextra;   // tile index
     const int lv = BX * 64 + l;   // all four waves of the block look at the same tile
     if (!SPARSE) tflags = (s.tile_live[BX] ? 1 : 0) | (s.fpar->clear_fut ? 2 : 0);   // (a dense map: nearly every tile's accumulators were added to -- not worth a look at fut_dirty)
     if (tflags & 2) {
@@ -307,7 +314,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
         // it since it was zeroed last (fut_dirty: set by whoever adds)
         if (tid == 0) s.fut_dirty[BX] = 0;
         const int v0 = BX * 64, nv = min(64, d.v_loc - v0);
-        for (int t = wave; t < d.T; t += NW) if (l < nv) s.fut[(size_t)t * d.v_loc + v0 + l] = 0.f;   // [T][V]: one row of 64 per wave and horizon
+        for (int t = wave; t < d.T; t += NW) if (l < nv) s.fut[(size_t)t * d.v_loc + v0 + l] = 0ull;   // [T][V]: one row of 64 per wave and horizon
         if (tid < nv) s.fut_stat[v0 + tid] = 0.f;
     }
     if (!(tflags & 1)) {   // (empty, but its accumulators had to be zeroed)
@@ -483,7 +490,11 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
                 int kind = view ? advance_one<true>(d, s_ph, s_pv, dt, odx, ody, zadd, vx, vy, px, py, pz, lv, pyr, gv)
                                 : advance_one<false>(d, s_ph, s_pv, dt, odx, ody, zadd, vx, vy, px, py, pz, lv, pyr, gv);
                 if (!act) kind = -1;
+#ifdef EXP_WRITE_DEAD
+                if (kind >= 1) bs_pos(rs_pos, l, srow, px, py, pz);
+#else
                 if (kind == 1 || kind == 3) bs_pos(rs_pos, l, srow, px, py, pz);   // (a mover's cell is dead: its record carries the position)
+#endif
                 const unsigned bit = 1u << (rw & 31);
                 const unsigned fr = (kind == 0 || kind == 2) ? bit : 0u, xp = kind == 3 ? bit : 0u;   // left the map :688 / changed voxel; left the slab
                 if (rw < 32) { kc_lo |= fr; ex_lo |= xp; } else { kc_hi |= fr; ex_hi |= xp; }
@@ -671,7 +682,9 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
             s_org[e * 64 + tid] = in ? (was_live ? org : 0ull) : ~0ull;
             s_new[e * 64 + tid] = 0ull;
             if (in) {   // what k_place_fix needs should a pyramid list turn arrivals of this tile away: both occupancies as used here
+#ifndef EXP_NO_PMASK
                 s.pmask[(size_t)lv * MW + e] = s_cur[e * 64 + tid];
+#endif
                 if (!was_live) const_cast<u64*>(omask)[(size_t)lv * MW + e] = 0ull;
             }
         }
@@ -792,7 +805,9 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
                     keep = false;
                 }
             }
+#ifndef EXP_NO_REF
             gbk[cap + i] = ref;   // the arrival's list entry, beside its inbox record (k_place_fix re-points it if the arrival is moved)
+#endif
             if (keep) atomicOr(&s_new[(nsl >> 6) * 64 + ln], 1ull << (nsl & 63));
         }
     }
@@ -809,18 +824,21 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
             if (s_new[e * 64 + tid]) s.mask[(size_t)lv * MW + e] = s_own[e * 64 + tid] | s_new[e * 64 + tid];
     }
     if (tid == 0) {
-        in_cnt[BX] = 0; s.in_n[BX] = n; s.tile_live[BX] = 1;   // ready for the next frame; the tile holds particles now
+        in_cnt[BX] = 0; s.in_n[2 * BX] = n; s.in_n[2 * BX + 1] = s.fs->pred_epoch; s.tile_live[BX] = 1;   // ready for the next frame; the tile holds particles now
         if (s_cnt[0]) atomicAdd(&s.fs->n_place_vf, s_cnt[0]);   // (rare events: the frame's counts, reset with the pyramid lists)
         if (s_cnt[1]) atomicAdd(&s.fs->n_place_pf, s_cnt[1]);
     }
 }
 
+#ifndef PLACE_LB
+#define PLACE_LB 7
+#endif
 template <int MW>
-__global__ void __launch_bounds__(256, 7) k_place(MapDims d, DevState s, const float4* __restrict__ in_rec,
+__global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, const float4* __restrict__ in_rec,
                                                int* __restrict__ in_cnt, int has_vz, int tab_n,
                                                const u64* __restrict__ omask, FilterParams fp, float4* __restrict__ child,
                                                int* __restrict__ vb_cnt, int* __restrict__ vb_idx, int nchild, int t0, int n0, int t1, int n1,
-                                               const int* __restrict__ tile_fov, int sel, float4* __restrict__ stage) {
+                                               const int* __restrict__ tile_fov, int sel, float4* __restrict__ stage, int rev) {
     // whole frame: workgroups behind the tiles generate the frame's newborn children (k_birth_children's job; needs the
     // birth cloud and the rank only, both done before this launch)
     // (the first `nchild` workgroups: they run beside the tiles, not after them).
@@ -832,7 +850,8 @@ __global__ void __launch_bounds__(256, 7) k_place(MapDims d, DevState s, const f
         return;
     }
     for (int bq = (int)blockIdx.x - nchild; bq < n0 + n1; bq += (int)gridDim.x - nchild) {
-        const int BX = bq < n0 ? t0 + bq : t1 + (bq - n0);   // tile index
+        const int bqr = rev ? n0 + n1 - 1 - bq : bq;           // (the launch's tiles from the last one down: see k_predict)
+        const int BX = bqr < n0 ? t0 + bqr : t1 + (bqr - n0);   // tile index
         if (has_vz && BX == 0 && sel != 0 && threadIdx.x == 0)   // k_predict drew 3 table values per ranked particle (:655-657)
             s.fs->v_cur = (int)(((long long)s.fs->v_cur + 3ll * (long long)s.fs->occupied_count) % tab_n);
         const int n_in = sload_i(in_cnt + BX);
@@ -865,16 +884,17 @@ __global__ void __launch_bounds__(256, 7) k_place(MapDims d, DevState s, const f
 // --------------------------------------------------------------------------
 template <int MW>
 __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __restrict__ part_live, int* __restrict__ vb_cnt,
-                                                  float4* __restrict__ ro_rec, int* __restrict__ ro_cnt) {
+                                                  float4* __restrict__ ro_rec, int* __restrict__ ro_cnt, int rev) {
     extern __shared__ float s_dyn[];
     const int l = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int cpmax = d.M;   // a voxel makes at most M copies
     float* s_w = s_dyn + (size_t)wave * (d.slots * 64 + (64 * cpmax + 1) / 2);
     unsigned short* s_cp = (unsigned short*)(s_w + d.slots * 64);
-    const int wave_g = blockIdx.x * (blockDim.x >> 6) + wave;
+    const int wq = blockIdx.x * (blockDim.x >> 6) + wave;
+    const int wave_g = rev ? ((d.v_loc + 63) >> 6) - 1 - wq : wq;   // (tiles from the last one down: see k_predict)
     const int lv = wave_g * 64 + l;
-    if (wave_g * 64 >= d.v_loc || !sload_i(s.tile_live + wave_g)) return;   // empty since its last visit: result, buckets and lists are already zero (one scalar round trip)
+    if (wave_g < 0 || wave_g * 64 >= d.v_loc || !sload_i(s.tile_live + wave_g)) return;   // empty since its last visit: result, buckets and lists are already zero (one scalar round trip)
     const bool inr = lv < d.v_loc;
     const int lvs = inr ? lv : 0;
     u64 m[MW], nb[MW];
@@ -1090,12 +1110,16 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
 }
 
 // --------------------------------------------------------------------------
-// One moving old particle's future status (:950-964), one float atomic per horizon: record {px, py, vx, vy}, {w, local voxel}.
+// One moving old particle's future status (:950-964), one integer atomic per horizon: record {px, py, vx, vy}, {w, local voxel}.
 // (k_rollout's path for tiles with few moving particles; k_resample_wg's waves 1-3 run it for their tile while wave 0 resamples.)
+// The accumulators are FIXED-POINT (fut_quantum, dspmap_device.h): every particle adds the same integer whichever path carries it
+// -- this one, k_rollout's LDS windows, a sharded or an unsharded map -- and integer sums do not depend on the order of the adds,
+// so the future status is reproducible bit for bit (the reference's own `+=` is a sequential loop, :961).
 __device__ __forceinline__ void rollout_direct(const MapDims& d, const DevState& s, const float4 a, const float4 b) {
     const int zc = d.ny * d.nx;
     const size_t V = (size_t)d.v_loc;
     const int lbase = ((__float_as_int(b.y) + d.v_base) / zc) * zc - d.v_base;   // voxel (x 0, y 0) of the particle's layer: it never changes (vz == 0)
+    const u64 q = fut_quantum(b.x);
     for (int t = 0; t < d.T; ++t) {
         const float pt = d.pred_t[t];
         const float fx = a.x + a.z * pt;      // :954-955
@@ -1105,7 +1129,7 @@ __device__ __forceinline__ void rollout_direct(const MapDims& d, const DevState&
         const int yi = (int)div_res(d, fy + d.half_y);
         const int dl = lbase + (int)__umul24((unsigned)yi, (unsigned)d.nx) + xi;
         if (dl < 0 || dl >= d.v_loc) continue;
-        unsafeAtomicAdd(&s.fut[(size_t)t * V + dl], b.x);
+        fut_add(&s.fut[(size_t)t * V + dl], q);
         s.fut_dirty[dl >> 6] = 1;
     }
 }
@@ -1420,26 +1444,30 @@ struct RolloutPlan {
     int halo[DSP_MAX_PRED];      // rows of the grid a horizon's window reaches beyond the group's voxels, either side
     int woff[DSP_MAX_PRED + 1];  // first cell of every horizon's window in the workgroup's LDS
 };
-// LIGHT: no LDS windows at all -- 256 threads, every contribution a float atomic.  A map with few moving particles (what the
+// LIGHT: no LDS windows at all -- 256 threads, every contribution a global atomic.  A map with few moving particles (what the
 // depth stream builds: newborns of matched clusters) holds no group that would use the windows, and the 120 kB of LDS they take
 // let ONE workgroup per CU start at a time: 10 890 groups at 264x264x80 cost 25 us although next to none has anything to do.
 // The handle launches this variant while last frame's count of tiles with hundreds of moving particles is low (c.ro_inline).
 template <int TPB, bool LIGHT>
 __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const float4* __restrict__ ro_rec, const int* __restrict__ ro_cnt, int ntiles,
-                                                    RolloutPlan pl) {
+                                                    RolloutPlan pl, int* __restrict__ ro_stat) {
     // One workgroup per group of RO_G consecutive tiles (512 voxels: a few rows of a layer).  EVERY particle is read once and
     // adds its weight to its future voxel at all T horizons (reading the particles once per horizon was what bound this kernel
     // with every particle moving: 10 x 0.5 GB at 132x132x60).  Horizon t has its own LDS window over the voxel-index range the
     // group's particles reach at a design speed -- halo[t] rows of the grid either side -- so that the footprints of the group's
     // tiles, which overlap almost completely, cost ONE global atomic per touched cell and horizon; faster particles fall outside
     // and take the single-atomic path.  Windows are flushed with coalesced atomics onto the horizon-major accumulators.
-    // The windows are FIXED-POINT (unsigned, 2^kexp per unit of weight): ds_add_f32 runs at a third of a lane per clock and CU
-    // on this chip, ds_add_u32 eight times faster (tools/micro/lds_atomic_bench.hip), and integer sums do not depend on the order of
-    // the adds.  No cell can receive more than the group's whole moving weight W (k_resample's per-tile sums), so the scale is the
-    // largest power of two with W * 2^kexp < 2^31: a resolution of W * 2^-31 per add, finer than a float accumulator's.
+    // The windows are FIXED-POINT like the accumulators they are flushed to (fut_quantum: 2^-24 per unit, the same integer per
+    // particle on every path): ds_add_f32 runs at a third of a lane per clock and CU on this chip, ds_add_u32 eight times faster
+    // (tools/micro/lds_atomic_bench.hip), and integer sums do not depend on the order of the adds.  A 32-bit cell can receive at
+    // most the group's whole moving weight W (k_resample's per-tile sums): a group with W >= FUT_WINDOW_MAX_W (256 units, never
+    // seen) takes the single-atomic path for every particle -- same result.
+    // ro_stat[2 * group + {0, 1}] = contributions this group sent through its windows / straight to the accumulators (diagnostics:
+    // which path ran; summed on request, no atomics here)
     extern __shared__ unsigned s_win[];
     __shared__ int s_cnt[RO_G + 1];
     __shared__ float s_wtot;
+    __shared__ int s_stat[2];
     const int G0 = (int)blockIdx.x * RO_G;
     const int ng = min(RO_G, ntiles - G0);
     const int tid = threadIdx.x;
@@ -1455,10 +1483,9 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
     }
     __syncthreads();
     const int total = s_cnt[RO_G];
-    if (total == 0) return;
-    int kexp = 0;
-    { int e; (void)frexpf(fmaxf(s_wtot, 1e-30f), &e); kexp = 31 - e; }   // W < 2^e
-    const float fscale = ldexpf(1.f, kexp), finv = ldexpf(1.f, -kexp);
+    if (total == 0) { if (tid < 2) ro_stat[blockIdx.x * 2 + tid] = 0; return; }
+    if (tid < 2) s_stat[tid] = 0;
+    int n_win = 0, n_dir = 0;
     const int T = d.T;
     const int zc = d.ny * d.nx;
     const int cap = 64 * d.slots;
@@ -1471,7 +1498,8 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
         const size_t o = ((size_t)(G0 + g) * cap + (it - s_cnt[g])) * 2;
         a = ro_rec[o]; b = ro_rec[o + 1];
     };
-    const bool dense = !LIGHT && total >= RO_DENSE;
+    // (a window cell is 32 bits wide and can receive at most the group's whole moving weight: windows only while that fits)
+    const bool dense = !LIGHT && total >= RO_DENSE && s_wtot < FUT_WINDOW_MAX_W;
     const int ncell = pl.woff[T];
     if (dense) for (int i = tid; i < ncell; i += TPB) s_win[i] = 0u;
     __syncthreads();
@@ -1487,7 +1515,7 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
         for (int u = 0; u < 3; ++u) {
             if (it0 + u * TPB >= total) continue;
             const int lbase = ((__float_as_int(b[u].y) + d.v_base) / zc) * zc - d.v_base;   // voxel (x 0, y 0) of the particle's layer: it never changes (vz == 0)
-            wq[u] = __float2uint_rn(b[u].x * fscale);
+            wq[u] = (unsigned)fut_quantum(b[u].x);   // (dense: below 2^32 because the group's sum is)
             for (int t = 0; t < T; ++t) {
                 const float pt = d.pred_t[t];
                 const float fx = a[u].x + a[u].z * pt;      // :954-955
@@ -1498,19 +1526,22 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
                 const int dl = lbase + (int)__umul24((unsigned)yi, (unsigned)d.nx) + xi;
                 if (dl < 0 || dl >= d.v_loc) continue;
                 const int off = dl - (G0 * 64 - pl.halo[t] * d.nx);
-                if (dense && off >= 0 && off < pl.woff[t + 1] - pl.woff[t]) atomicAdd(&s_win[pl.woff[t] + off], wq[u]);
-                else { unsafeAtomicAdd(&s.fut[(size_t)t * V + dl], b[u].x); s.fut_dirty[dl >> 6] = 1; }
+                if (dense && off >= 0 && off < pl.woff[t + 1] - pl.woff[t]) { atomicAdd(&s_win[pl.woff[t] + off], wq[u]); ++n_win; }
+                else { fut_add(&s.fut[(size_t)t * V + dl], fut_quantum(b[u].x)); s.fut_dirty[dl >> 6] = 1; ++n_dir; }
             }
         }
     }
-    if (!dense) return;
+    n_win = wave_sum_i(n_win); n_dir = wave_sum_i(n_dir);
+    if (lane_id() == 0) { if (n_win) atomicAdd(&s_stat[0], n_win); if (n_dir) atomicAdd(&s_stat[1], n_dir); }
     __syncthreads();
+    if (tid < 2) ro_stat[blockIdx.x * 2 + tid] = s_stat[tid];
+    if (!dense) return;
     for (int t = 0; t < T; ++t) {
         const int w0 = pl.woff[t], wn = pl.woff[t + 1] - w0;
         const int g0 = G0 * 64 - pl.halo[t] * d.nx;   // local voxel index of the window's first cell (cells outside the slab stay zero)
         for (int i = tid; i < wn; i += TPB) {
             const unsigned q = s_win[w0 + i];
-            if (q) { unsafeAtomicAdd(&s.fut[(size_t)t * V + g0 + i], (float)q * finv); s.fut_dirty[(g0 + i) >> 6] = 1; }
+            if (q) { fut_add(&s.fut[(size_t)t * V + g0 + i], (u64)q); s.fut_dirty[(g0 + i) >> 6] = 1; }
         }
     }
 }
@@ -1813,7 +1844,7 @@ void launch_sweep_probe(const LaunchCtx& c, int what, int rows, int rows_per_bat
 }
 
 // div_res (dspmap_device.h): comparison of the 3-instruction quotient with the IEEE division, bit for bit, over
-//   * EVERY float of one binade, a in [1, 2) -- 2^23 values.  All three operations (a * y, fma(-q0, res, a), fma(r, y, q0)) and
+//   * EVERY float of one binade [2^k, 2^(k+1)) with 2^k >= res (every quotient >= 1) -- 2^23 values.  All three operations (a * y, fma(-q0, res, a), fma(r, y, q0)) and
 //     the division itself commute with a scaling of `a` by a power of two as long as nothing leaves the normal range, so this
 //     proves every binade the map divides in (a >= res / 2; below that both quotients are < 1 and the voxel coordinate is 0);
 //   * every `stride`-th float of the whole range [0, amax] as a direct check of exactly that argument.
@@ -1836,8 +1867,16 @@ __global__ void __launch_bounds__(256) k_verify_div(float res, float rcp, unsign
 void launch_verify_div(hipStream_t stream, float res, float rcp_res, float amax, int* bad) {
     unsigned bits;
     memcpy(&bits, &amax, sizeof(bits));
-    hipLaunchKernelGGL(k_verify_div, dim3(2048), dim3(256), 0, stream, res, rcp_res, 0x3f800000u, 0x3fffffffu, 1u, bad);   // [1, 2)
-    hipLaunchKernelGGL(k_verify_div, dim3(2048), dim3(256), 0, stream, res, rcp_res, 0u, bits, 97u, bad);                 // the range, sampled
+    // the exhaustive binade: [2^k, 2^(k+1)) with 2^k >= res, so that EVERY quotient of the pass is >= 1 and is compared bit for
+    // bit (k_verify_div lets a pair of quotients below 1 pass: both give voxel coordinate 0) -- [1, 2) would prove nothing for a
+    // resolution above 1 m
+    int k = 0;
+    (void)frexpf(res, &k);                       // res = f * 2^k, f in [0.5, 1)  ->  2^k > res (or == 2 res' for a power of two)
+    const float lo = ldexpf(1.f, k);
+    unsigned lo_bits;
+    memcpy(&lo_bits, &lo, sizeof(lo_bits));
+    hipLaunchKernelGGL(k_verify_div, dim3(2048), dim3(256), 0, stream, res, rcp_res, lo_bits, lo_bits + 0x7fffffu, 1u, bad);   // one whole binade
+    hipLaunchKernelGGL(k_verify_div, dim3(2048), dim3(256), 0, stream, res, rcp_res, 0u, bits, 97u, bad);                       // the range, sampled
 }
 
 // PMC calibration: stream the field arrays with the sweeps' 4-byte-per-lane pattern
@@ -1902,6 +1941,14 @@ __global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScra
 // ==========================================================================
 // launchers
 // ==========================================================================
+// experiment aid (DSPMAP_EXP_GAP_US): one wave that waits, so that a stage's stores can drain before the next stage's clock starts
+__global__ void k_spin(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+void launch_spin(const LaunchCtx& c, int us) {   // wall_clock64 ticks at 100 MHz
+    if (us > 0) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c.stream, (long long)us * 100);
+}
 void launch_predict_only(const LaunchCtx& c, bool with_gather, bool with_rank) {
     const int extra = (with_gather ? 1 : 0) | (with_rank ? 2 : 0);
     const unsigned xb = (with_gather ? (c.d.np + 3) / 4 : 0) + (with_rank ? 1 : 0);
@@ -1913,7 +1960,7 @@ void launch_predict_only(const LaunchCtx& c, bool with_gather, bool with_rank) {
         launch_scan_blocks(c, nblk);   // blk_cnt -> exclusive, total -> fs->occupied_count
     }
 #define PRED_LAUNCH(MWV, VZ, SP) hipLaunchKernelGGL((k_predict<MWV, 4, VZ, SP>), dim3(k->ntiles + xb), dim3(256), 0, c.stream, c.d, c.s, c.fp, VZ ? 1 : 0, \
-                                                k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask, extra, k->tile_fov)
+                                                k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask, extra, k->tile_fov, c.sweep_rev ? 1 : 0)
 #define PRED_LAUNCH2(MWV, VZ) do { if (c.sparse) PRED_LAUNCH(MWV, VZ, true); else PRED_LAUNCH(MWV, VZ, false); } while (0)
     if (c.d.mw == 1) { if (c.s.vz0) PRED_LAUNCH2(1, true); else PRED_LAUNCH2(1, false); }
     else { if (c.s.vz0) PRED_LAUNCH2(2, true); else PRED_LAUNCH2(2, false); }
@@ -1933,12 +1980,23 @@ void launch_claim(const LaunchCtx& c, int n_birth_grid, int part, int tile_lo, i
     // and the wave slots, registers and LDS it leaves free are what the pair kernels run in
     unsigned grid = (unsigned)(n0 + n1) + xb;
     if (sel == 0) grid = std::min(grid, (unsigned)(PLACE_SIDE_WG * c.n_cu));
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec);
-    else hipLaunchKernelGGL(k_place<2>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec);
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec, c.sweep_rev ? 0 : 1);
+    else hipLaunchKernelGGL(k_place<2>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec, c.sweep_rev ? 0 : 1);
 }
 void launch_predict(const LaunchCtx& c, bool with_gather) {
     launch_predict_only(c, with_gather, false);
     launch_claim(c);
+}
+// which kernels the stage runs for this map and these hints: bit 0 = the four-waves-per-tile resampler; bits 1-2 = the rollout of
+// the moving particles: 0 inside the resampler (float-free integer atomics from its idle waves), 1 k_rollout LIGHT, 2 k_rollout with LDS
+// windows, 3 none (no prediction horizons)
+int resample_variant(const LaunchCtx& c) {
+    const bool wg = c.k.ntiles < c.resample_wg_tiles && c.d.mw == 1 && c.d.slots <= 4 * RWB;
+    int ro = c.d.T <= 0 ? 3 : (c.ro_inline ? (wg ? 0 : 1) : 2);
+    return (wg ? 1 : 0) | (ro << 1);
+}
+void kernels_init_device() {   // per device, once (dspmap_init_device)
+    (void)hipFuncSetAttribute((const void*)k_rollout<RO_TPB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RO_LDS_CELLS * 4);
 }
 void launch_resample(const LaunchCtx& c) {
     const KernelScratch* k = &c.k;
@@ -1946,20 +2004,20 @@ void launch_resample(const LaunchCtx& c) {
     const size_t lds = (size_t)nw * (c.d.slots * 64 + (64 * c.d.M + 1) / 2) * sizeof(float);
     const unsigned grid = (unsigned)((k->ntiles + nw - 1) / nw);
     // maps of the metric's size run the four-waves-per-tile variant: their frame is a chain of latencies and the longest tile is
-    // the kernel; large maps keep one wave per tile (more tiles in flight per CU)
-    static const int wg_tiles = getenv("DSPMAP_RESAMPLE_WG_TILES") ? atoi(getenv("DSPMAP_RESAMPLE_WG_TILES")) : 8192;
-    if (k->ntiles < wg_tiles && c.d.mw == 1 && c.d.slots <= 4 * RWB) {
+    // the kernel; large maps keep one wave per tile (more tiles in flight per CU).  The limit is the handle's
+    // (DSPMAP_P_RESAMPLE_WG_TILES), so either variant can be run on any one-word map.
+    const int var = resample_variant(c);
+    const int ro = var >> 1;
+    if (var & 1) {
         const size_t lds4 = (size_t)(c.d.slots * 64) * sizeof(float) + (size_t)c.d.slots * 64 + (size_t)64 * c.d.M * 2;
-        // ... and roll their moving particles out themselves (one float atomic per particle and horizon from the waves that wait for
+        // ... and roll their moving particles out themselves (one integer atomic per particle and horizon from the waves that wait for
         // the sequential walk anyway): no k_rollout launch
         // -- unless many tiles hold hundreds of moving particles (c.ro_inline, the handle's choice from last frame's count):
         // then k_rollout's LDS windows are worth their launch (66x66x40 saturated, every particle moving: 0.11 vs 0.27 ms)
-        const int inline_ro = c.ro_inline ? 1 : 0;
-        hipLaunchKernelGGL(k_resample_wg, dim3(k->ntiles), dim3(256), lds4, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, inline_ro);
-        if (inline_ro) return;
-    } else if (c.d.mw == 1) hipLaunchKernelGGL(k_resample<1>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt);
-    else hipLaunchKernelGGL(k_resample<2>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt);
-    if (c.d.T > 0) {
+        hipLaunchKernelGGL(k_resample_wg, dim3(k->ntiles), dim3(256), lds4, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, ro == 0 ? 1 : 0);
+    } else if (c.d.mw == 1) hipLaunchKernelGGL(k_resample<1>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, c.sweep_rev ? 1 : 0);
+    else hipLaunchKernelGGL(k_resample<2>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, c.sweep_rev ? 1 : 0);
+    if (ro == 1 || ro == 2) {
         // windows: the rows a particle reaches at a design speed (1.5 m/s, a brisk pedestrian), lowered until all T windows fit the LDS
         RolloutPlan pl;
         float vdes = 1.5f;
@@ -1979,12 +2037,10 @@ void launch_resample(const LaunchCtx& c) {
             for (int t = 0; t < c.d.T; ++t) { pl.halo[t] = 0; pl.woff[t] = tot; tot += RO_G * 64; }
             pl.woff[c.d.T] = tot;
         }
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_rollout<RO_TPB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RO_LDS_CELLS * 4); attr_set = true; }
-        if (c.ro_inline) hipLaunchKernelGGL((k_rollout<256, true>), dim3((k->ntiles + RO_G - 1) / RO_G), dim3(256), 0, c.stream, c.d, c.s, k->ro_rec, k->ro_cnt,
-                                            k->ntiles, pl);
+        if (ro == 1) hipLaunchKernelGGL((k_rollout<256, true>), dim3((k->ntiles + RO_G - 1) / RO_G), dim3(256), 0, c.stream, c.d, c.s, k->ro_rec, k->ro_cnt,
+                                        k->ntiles, pl, k->ro_stat);
         else hipLaunchKernelGGL((k_rollout<RO_TPB, false>), dim3((k->ntiles + RO_G - 1) / RO_G), dim3(RO_TPB), (size_t)pl.woff[c.d.T] * 4, c.stream, c.d, c.s, k->ro_rec, k->ro_cnt,
-                                k->ntiles, pl);
+                                k->ntiles, pl, k->ro_stat);
     }
 }
 __global__ void k_set_live_sample(DevState s, int v) { s.fs->live_acc = v; }

@@ -104,6 +104,8 @@ struct FrameScalars {
     int view_epoch, stale_n;
     int n_birth_ovf;    // entries of DevState::birth_ovf (reset by the birth rank, which precedes every generation of children)
     int est_n;          // length of the birth cloud the device velocity estimator wrote (kept when a view is empty, :1379)
+    int pred_epoch;     // bumped by whatever resets the pyramid lists for a prediction (k_reset / k_obs_points): k_place stamps the tiles it
+                        // served with it, k_place_fix only trusts a tile's inbox / pmask when the stamp is this prediction's
 };
 
 // Per-frame inputs, written by ONE small H2D copy per frame and read by the kernels from HBM, so that
@@ -137,8 +139,10 @@ struct DevState {
     float* w;     // [S]                   rewritten by the weight update and the resampler
     float* vz0;    // optional, only right after an import with vz != 0 (consumed by the next prediction)
     float4* res4;  // [v_loc] {mass, mean vx, mean vy, mean vz}
-    float* fut;    // [T][v_loc]  future mass scattered by moving particles, HORIZON-major: the rollout flushes whole rows of
-                   //             neighbouring voxels of one horizon (coalesced atomics)
+    u64* fut;      // [T][v_loc]  future mass scattered by moving particles, FIXED-POINT (units of 2^-24, fut_quantum in dspmap_device.h:
+                   //             integer atomics -- the sum does not depend on the order of the adds, on the rollout variant or on
+                   //             the sharding), HORIZON-major: the rollout flushes whole rows of neighbouring voxels of one horizon
+                   //             (coalesced atomics)
     float* fut_out; // [v_loc][T] the caller's layout (voxels_objects_number[v][4..], :118-120): fut + fut_stat, written by
                    //             k_future_combine on demand (readout is not part of update())
     float* fut_stat; // [v_loc]   future mass of static particles (identical for every horizon; folded in at readout)
@@ -192,7 +196,7 @@ struct DevState {
     u64* ta;            // [v_loc*mw] cells whose particle its pyramid's full list turned away this frame (all zero between frames)
     int* dflag;         // [v_loc] 1 = the voxel is in the dirty list
     int* dirty;         // [DSP_DIRTY_CAP] local voxels that lost a particle to a full pyramid list this frame
-    int* in_n;          // [tiles] arrivals the last placement served per tile
+    int* in_n;          // [2 * tiles] {arrivals the last placement served in the tile, FrameScalars::pred_epoch of that placement}
     int* fut_dirty;     // [tiles] 1 = something was added to the tile's future accumulators (fut, fut_stat) since they were zeroed
     int* tile_live;     // [tiles] 0 = the 64-voxel tile holds no particle (k_resample found it empty and nothing was placed, born or
                         // imported there since): the sweeps skip it without reading its occupancy words.  Conservative: nonzero

@@ -128,8 +128,16 @@ enum dspmap_param {
                                        one (same result either way; read: the variant of the last frame) */
     DSPMAP_P_ROLLOUT_INLINE = 19,   /* maps small enough for the four-waves-per-tile resampler: 1 = its tiles add their moving particles' future
                                        status themselves (one float atomic per particle and horizon; no k_rollout launch), 0 = k_rollout's LDS
-                                       windows, -1 (default) the handle decides from the number of tiles with hundreds of moving particles
-                                       (same result up to the order of float additions; read: the last frame's choice) */
+                                       windows, -1 (default) the handle decides from the number of tiles with hundreds of moving particles; larger
+                                       maps: 1 = k_rollout without windows, 0 = with them.  The future status is accumulated in fixed point, every
+                                       particle adds the same integer on every path: the SAME result bit for bit (read: the last frame's choice) */
+    DSPMAP_P_RESAMPLE_WG_TILES = 20,/* one-occupancy-word maps with FEWER 64-voxel tiles than this (default 8192) run the four-waves-per-tile variant of the
+                                       resampling stage, the others the one-wave-per-tile variant (same result slot for slot; a scheduling knob: 0 =
+                                       never, a huge value = whenever the map qualifies; the environment variable DSPMAP_RESAMPLE_WG_TILES presets it) */
+    DSPMAP_P_SWEEP_ALTERNATE = 21,  /* the three sweeps over the map's 64-voxel tiles (prediction, placement of the voxel-changing particles,
+                                       resampling) alternate their direction from one sweep to the next, so that each starts on the tiles its
+                                       predecessor touched last (they are still in the 256 MB Infinity Cache): -1 (default) maps of at least 4096
+                                       tiles, 0 never, 1 always.  Same result: no stage depends on the order in which the tiles are visited */
     DSPMAP_P_PAIR_CULL_SIGMAS = 13  /* mapUpdate evaluates a (particle, observation) pair only if their ranges differ by at most this many
                                        sigma_ob (default 9: the dropped terms are < 1e-19 and zero on the fixed-point Ck grid);
                                        a huge value evaluates every pair of the neighbourhood like the reference's loops */
@@ -233,6 +241,14 @@ int dspmap_debug_sweep_probe(dspmap_t* m, int what, int rows, int rows_per_batch
 /* diagnostics: out[t] = 1 if a particle inside 64-voxel tile t could lie in the field of view of the last frame
  * (the conservative box test behind DSPMAP_P_PLACE_SPLIT_TILES); returns the number of tiles or an error */
 int dspmap_debug_tile_view(dspmap_t* m, int* out, int cap);
+/* diagnostics: which kernels the last resampling stage ran and which path the future-status contributions took:
+ * out[0] = bit 0: four-waves-per-tile resampler; bits 1-2: rollout 0 inside the resampler, 1 k_rollout without LDS windows,
+ * 2 k_rollout with LDS windows, 3 none; out[1] / out[2] = contributions k_rollout sent through its windows / as single atomics */
+int dspmap_debug_rollout_paths(dspmap_t* m, long long out[3]);
+/* test hooks of dspmap_mgpu_comm_init_from_env's rendezvous file (no device, no RCCL): what rank 0 publishes / what a rank != 0
+ * waits for (this launch's nonce: DSPMAP_RDZV_NONCE or TORCHELASTIC_RUN_ID + the parent's pid).  1 = written / found, 0 = not */
+int dspmap_debug_rdzv_publish(const char* path, const char id[128]);
+int dspmap_debug_rdzv_wait(const char* path, int timeout_ms, char id_out[128]);
 
 /* ---- state access (the reference's equivalent is direct access to its
  * file-scope arrays, dsp_dynamic.h:116).  A record is 8 floats

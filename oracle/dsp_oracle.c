@@ -414,6 +414,30 @@ static int add_a_particle(dsp_oracle* o, float px, float py, float pz, float vx,
     return 0;
 }
 
+/* test helper (no counterpart in the reference): state injection -- every particle goes to the first free slot of its voxel
+ * (the addAParticle rule, :1184-1185) with the given flag; particles outside the map or into a full voxel are skipped.
+ * flags may be NULL (then `flag` for all).  Returns the number placed. */
+int dspo_inject(dsp_oracle* o, int n, const float* px, const float* py, const float* pz, const float* vx, const float* vy,
+                const float* vz, const float* w, const float* flags, float flag) {
+    int placed = 0;
+    for (int k = 0; k < n; k++) {
+        int idx;
+        if (!dspo_voxel_index(o, px[k], py[k], pz[k], &idx)) continue;
+        for (int i = 0; i < o->slots; i++) {
+            float* r = PART(o, idx, i);
+            if (r[0] < 0.1f) {
+                r[0] = flags ? flags[k] : flag;
+                r[1] = vx[k]; r[2] = vy[k]; r[3] = vz[k];
+                r[4] = px[k]; r[5] = py[k]; r[6] = pz[k];
+                r[7] = w[k];
+                ++placed;
+                break;
+            }
+        }
+    }
+    return placed;
+}
+
 /* addRandomParticles :594-624 */
 void dspo_add_random_particles(dsp_oracle* o, int n, float w) {
     for (int i = 0; i < n; i++) {

@@ -136,6 +136,9 @@ void dspo_voxel_center(const dsp_oracle* o, int idx, float* x, float* y, float* 
 const int* dspo_neighbor_table(const dsp_oracle* o);  /* [NP][10], :126-127,1128-1147 */
 float dspo_generate_random_float(dsp_oracle* o, float lo, float hi);              /* :1551-1553 */
 void dspo_add_random_particles(dsp_oracle* o, int n, float w);                    /* :594-624 */
+/* test helper: first-free-slot injection of n particles with a flag each (flags) or one for all (flag); returns the number placed */
+int dspo_inject(dsp_oracle* o, int n, const float* px, const float* py, const float* pz, const float* vx, const float* vy,
+                const float* vz, const float* w, const float* flags, float flag);
 
 /* ---- raw state (the reference's file-scope arrays) ---- */
 float* dspo_particles(dsp_oracle* o);       /* [V][SLOTS][9]  voxels_with_particle :116 */

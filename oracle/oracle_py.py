@@ -95,6 +95,7 @@ def _load(fast=False):
         "dspo_neighbor_table": (ip, [P]),
         "dspo_generate_random_float": (f, [P, f, f]),
         "dspo_add_random_particles": (None, [P, i, f]),
+        "dspo_inject": (i, [P, i, P, P, P, P, P, P, P, P, f]),
         "dspo_particles": (fp, [P]), "dspo_results": (fp, [P]), "dspo_pyramid_lists": (ip, [P]),
         "dspo_obs": (fp, [P]), "dspo_obs_count": (ip, [P]), "dspo_obs_max_length": (fp, [P]),
         "dspo_expected_newborn": (f, [P]), "dspo_set_expected_newborn": (None, [P, f]),
@@ -287,17 +288,8 @@ class Oracle:
 
     def inject(self, px, py, pz, vx, vy, vz, w, flag=1.0):
         """place particles into first free slots of their voxels (like addAParticle but with a flag)."""
-        p = self.particles
-        idx = C.c_int()
-        placed = 0
-        for k in range(len(px)):
-            if not self.L.dspo_voxel_index(self.h, float(px[k]), float(py[k]), float(pz[k]), C.byref(idx)):
-                continue
-            row = p[idx.value]
-            free = np.nonzero(row[:, 0] < 0.1)[0]
-            if free.size == 0:
-                continue
-            fl = flag[k] if np.ndim(flag) else flag
-            row[free[0], :8] = (fl, vx[k], vy[k], vz[k], px[k], py[k], pz[k], w[k])
-            placed += 1
-        return placed
+        arrs = [np.ascontiguousarray(a, np.float32) for a in (px, py, pz, vx, vy, vz, w)]
+        fl = np.ascontiguousarray(flag, np.float32) if np.ndim(flag) else None
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        return self.L.dspo_inject(self.h, len(arrs[0]), *[ptr(a) for a in arrs], ptr(fl) if fl is not None else None,
+                                  float(flag) if fl is None else 0.0)

@@ -137,3 +137,39 @@ def test_parameter_ids_of_the_binding_match_the_header(dsp):
         for v in (1, 0, -1):
             assert m.L.dspmap_set_param(m.h, key, float(v)) == 1
     m.close()
+
+
+def test_rendezvous_file_is_matched_by_its_nonce_string(dsp, tmp_path, monkeypatch):
+    """dspmap_mgpu_comm_init_from_env (the drop-in class's sharded start-up, -DDSPMAP_WORLD): a rank != 0 accepts exactly the record
+    whose nonce STRING is this launch's -- whatever follows the string's NUL in the 120-byte field (rank 0's stack residue before
+    the fix; zeros; anything) does not count; another launch's nonce, a wrong magic or a short file are refused"""
+    L = dsp.load_library()
+    monkeypatch.setenv("DSPMAP_RDZV_NONCE", "run-42")
+    path = str(tmp_path / "rdzv")
+    uid = bytes(range(128))
+    out = C.create_string_buffer(128)
+    # what rank 0 publishes is what the others wait for
+    assert L.dspmap_debug_rdzv_publish(path.encode(), uid) == 1
+    assert L.dspmap_debug_rdzv_wait(path.encode(), 50, out) == 1 and out.raw == uid
+    nonce = ("run-42:%d" % os.getppid()).encode()
+    assert open(path, "rb").read()[8:8 + len(nonce) + 1] == nonce + b"\0"
+    # a hand-made record: correct string, garbage behind its NUL
+    rec = b"DSPRDZV1" + nonce + b"\0" + b"\xa5" * (120 - len(nonce) - 1) + uid
+    open(path, "wb").write(rec)
+    out = C.create_string_buffer(128)
+    assert L.dspmap_debug_rdzv_wait(path.encode(), 50, out) == 1 and out.raw == uid
+    # ... zero-padded
+    open(path, "wb").write(b"DSPRDZV1" + nonce.ljust(120, b"\0") + uid)
+    assert L.dspmap_debug_rdzv_wait(path.encode(), 50, out) == 1
+    # refused: another launch's nonce (also one that merely starts like ours), wrong magic, truncated file, no file
+    for bad in (b"DSPRDZV1" + (nonce + b"7").ljust(120, b"\0") + uid,
+                b"DSPRDZV1" + b"run-41:1".ljust(120, b"\0") + uid,
+                b"DSPRDZV0" + nonce.ljust(120, b"\0") + uid,
+                (b"DSPRDZV1" + nonce.ljust(120, b"\0") + uid)[:200]):
+        open(path, "wb").write(bad)
+        assert L.dspmap_debug_rdzv_wait(path.encode(), 30, out) == 0
+    os.unlink(path)
+    assert L.dspmap_debug_rdzv_wait(path.encode(), 30, out) == 0
+    monkeypatch.setenv("DSPMAP_RDZV_NONCE", "run-43")                      # a later launch does not take the old file
+    open(path, "wb").write(b"DSPRDZV1" + nonce.ljust(120, b"\0") + uid)
+    assert L.dspmap_debug_rdzv_wait(path.encode(), 30, out) == 0
