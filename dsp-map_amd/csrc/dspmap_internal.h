@@ -102,7 +102,8 @@ struct dspmap {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};   // the captured frame, one per sweep direction (LaunchCtx::sweep_rev is a kernel argument)
     unsigned long long graph_key[2] = {~0ull, ~0ull};
-    int sweep_alt = -1;              // DSPMAP_P_SWEEP_ALTERNATE: -1 maps of >= 4096 tiles alternate the direction of their tile sweeps, 0 never, 1 always
+    int sweep_alt = 0;               // DSPMAP_P_SWEEP_ALTERNATE: 1 = all three tile sweeps flip their direction from frame to frame (0, the default: k_place
+                                     // always walks against k_predict / k_resample; -1: flip on maps of >= 4096 tiles)
     unsigned frame_parity = 0;       // toggled by every prediction
     unsigned graph_epoch = 0;   // bumped whenever a baked-in kernel argument (pointer / parameter) changes
     // multi-GPU split-phase state

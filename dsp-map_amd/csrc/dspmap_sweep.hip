@@ -244,12 +244,11 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
                                                  float4* __restrict__ mv_rec, float4* __restrict__ in_rec, int* __restrict__ in_cnt,
                                                  u64* __restrict__ expmask, const int* __restrict__ vz_pre, const u64* __restrict__ vz_q,
                                                  u64* __restrict__ omask, int extra, int* __restrict__ tile_fov, int rev) {
-    // rev: the tiles are walked from the last one down (workgroup -> tile mapping only).  The tile sweeps of a frame alternate
-    // their direction -- k_predict, then k_place the other way, then k_resample, and the next frame's k_predict the other way
-    // again -- so that each starts on the tiles its predecessor touched last: a large map's live rows are several times the
-    // 256 MB Infinity Cache, and a sweep that starts where the last one ENDED finds its first ~fifth there instead of in HBM
-    // (132x132x60 saturated: placement -18 %, resampling -8 %, prediction -6 %; same results -- no stage depends on the order
-    // in which tiles are visited).
+    // rev: the tiles are walked from the last one down (workgroup -> tile mapping only).  k_place always walks AGAINST the k_predict
+    // before it: a large map's live rows are several times the 256 MB Infinity Cache, and a sweep that starts where the last one
+    // ENDED finds its first tiles (rows, occupancy words, inbox records) there instead of in HBM -- 132x132x60 saturated:
+    // placement 0.186 -> 0.159 ms in three interleaved A/B rounds on one box.  DSPMAP_P_SWEEP_ALTERNATE = 1 flips all three
+    // sweeps from frame to frame on top of that (no further gain measured).  Same results: no stage depends on the tile order.
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
     __shared__ u64 s_keep[MW * 64], s_ex[MW * 64];
@@ -869,7 +868,9 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
 }
 
 #define RO_INLINE_MAX 384   // moving particles of a tile beyond which the tile counts as "heavy" for the choice inline rollout / k_rollout
-#define RBK 16  // rows per batch of the loads in k_resample
+#ifndef RBK
+#define RBK 8   // rows per batch of the loads in k_resample (two batches in flight)
+#endif
 #define CPB 8   // deferred copies per step
 
 // --------------------------------------------------------------------------
@@ -920,42 +921,47 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
     const size_t ro_base = (size_t)wave_g * 64 * d.slots;
     int n = 0, n_old = 0;
     float wsum = 0.f, vxs = 0.f, vys = 0.f, stat_w = 0.f;
+    // rows stream through registers in batches of RBK; the loads of the NEXT batch are issued before this one is consumed
+    // (two register sets of RBK rows each: the wave's memory round trip hides behind the sequential per-voxel sums)
+    struct RowBatch { int row[RBK]; V2 vv[RBK]; float wr[RBK]; };
 #pragma unroll
     for (int e = 0; e < MW; ++e) {
         u64 tor = wave_or_u64(m[e]);
-        while (tor) {
-            int row[RBK];
-            V2 vv[RBK];
-            float wr[RBK];
-            bool act[RBK];
+        const brsrc rs_vel = __builtin_amdgcn_make_buffer_rsrc((void*)(s.vel + 2 * ((size_t)wave_g * d.slots * 64)), 0, d.slots * 64 * 8, 0x00020000);
+        const brsrc rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(s.w + (size_t)wave_g * d.slots * 64), 0, d.slots * 64 * 4, 0x00020000);
+        auto issue = [&](RowBatch& B) {
 #pragma unroll
             for (int r = 0; r < RBK; ++r) {
-                row[r] = tor ? __ffsll((long long)tor) - 1 : -1;
+                B.row[r] = tor ? __ffsll((long long)tor) - 1 : -1;
                 if (tor) tor &= tor - 1ull;
-                act[r] = row[r] >= 0 && ((m[e] >> (row[r] & 63)) & 1ull);
-                // unconditional loads, see k_predict
-                const size_t idx = pidx(d, lvs, e * 64 + (row[r] < 0 ? 0 : row[r]));
-                wr[r] = s.w[idx];
-                vv[r] = ld_vel(s, idx);
+                // unconditional loads, see k_predict (the row enters as a wave-uniform scalar offset)
+                const int srow = (e * 64 + (B.row[r] < 0 ? 0 : B.row[r])) * 64;
+                B.wr[r] = bl_w(rs_w, l, srow);
+                B.vv[r] = bl_vel(rs_vel, l, srow);
             }
+        };
+        auto consume = [&](const RowBatch& B) {
+            bool act[RBK];
             float vx[RBK], vy[RBK];
             bool any_mv = false;
 #pragma unroll
             for (int r = 0; r < RBK; ++r) {
-                const bool old = act[r] && !((nb[e] >> row[r]) & 1ull);
-                vx[r] = old ? vv[r].x : 0.f; vy[r] = old ? vv[r].y : 0.f;
+                act[r] = B.row[r] >= 0 && ((m[e] >> (B.row[r] & 63)) & 1ull);
+                const bool old = act[r] && !((nb[e] >> (B.row[r] & 63)) & 1ull);
+                vx[r] = old ? B.vv[r].x : 0.f; vy[r] = old ? B.vv[r].y : 0.f;
                 any_mv |= vx[r] != 0.f || vy[r] != 0.f;
             }
             // the rollout (:950-964) needs the position of the MOVING old particles only: their (x, y) are requested for the
             // whole batch at once -- one extra memory round trip per batch that holds a moving particle instead of one per
             // moving particle inside the sequential loop below
             float mpx[RBK], mpy[RBK];
-            if (__ballot(any_mv)) {
+            const bool batch_mv = __ballot(any_mv) != 0ull;
+            if (batch_mv) {
 #pragma unroll
                 for (int r = 0; r < RBK; ++r) {
                     mpx[r] = 0.f; mpy[r] = 0.f;
                     if (vx[r] != 0.f || vy[r] != 0.f) {
-                        const float2 q = *reinterpret_cast<const float2*>(s.pos + 3 * pidx(d, lvs, e * 64 + row[r]));
+                        const float2 q = *reinterpret_cast<const float2*>(s.pos + 3 * pidx(d, lvs, e * 64 + B.row[r]));
                         mpx[r] = q.x; mpy[r] = q.y;
                     }
                 }
@@ -966,9 +972,9 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
 #pragma unroll
             for (int r = 0; r < RBK; ++r) {
                 if (!act[r]) continue;
-                const u64 bit = 1ull << row[r];
-                const float w = wr[r];
-                s_w[(e * 64 + row[r]) * 64 + l] = w;   // the resampling pass below reads the weights from LDS
+                const u64 bit = 1ull << B.row[r];
+                const float w = B.wr[r];
+                s_w[(e * 64 + B.row[r]) * 64 + l] = w;   // the resampling pass below reads the weights from LDS
                 if (w < 1e-3f) {                  // :941
                     m[e] &= ~bit;
                 } else {
@@ -984,19 +990,32 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
             }
             // the batch's moving old particles join the tile's rollout list (stable wave-level append, no atomics: one
             // wave owns the tile)
-            if (__ballot(any_mv)) {
+            if (batch_mv) {
 #pragma unroll
                 for (int r = 0; r < RBK; ++r) {
                     const u64 mb = __ballot(mv_now[r]);
                     if (mv_now[r]) {
                         const size_t o = (ro_base + nmv + (int)__popcll(mb & lanemask_lt())) * 2;
                         ro_rec[o] = make_float4(mpx[r], mpy[r], vx[r], vy[r]);
-                        ro_rec[o + 1] = make_float4(wr[r], __int_as_float(lv), 0.f, 0.f);
-                        mvw += wr[r];
+                        ro_rec[o + 1] = make_float4(B.wr[r], __int_as_float(lv), 0.f, 0.f);
+                        mvw += B.wr[r];
                     }
                     nmv += (int)__popcll(mb);
                 }
             }
+        };
+        if (!tor) continue;
+        RowBatch A, B;
+        issue(A);
+        for (;;) {   // (tor is wave-uniform: scalar control flow)
+            const bool more_b = tor != 0ull;
+            if (more_b) issue(B);
+            consume(A);
+            if (!more_b) break;
+            const bool more_a = tor != 0ull;
+            if (more_a) issue(A);
+            consume(B);
+            if (!more_a) break;
         }
     }
     if (nmv) mvw = wave_sum_f(mvw);
