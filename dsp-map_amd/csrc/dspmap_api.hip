@@ -73,7 +73,8 @@ LaunchCtx dspmap_ctx_of(dspmap* m) {
     }
     c.ro_inline = !m->ro_kernel;
     c.resample_wg_tiles = m->resample_wg_tiles;
-    c.sweep_rev = (m->sweep_alt < 0 ? m->k.ntiles >= 4096 : m->sweep_alt != 0) && (m->frame_parity & 1u);
+    c.sweep_rev = (m->sweep_alt < 0 ? m->k.ntiles >= 4096 : m->sweep_alt == 1) && (m->frame_parity & 1u);
+    c.resample_rev = m->sweep_alt == 2 ? true : c.sweep_rev;   // 2: k_predict up, k_place down, k_resample down -- and the next k_predict starts where it ended
     return c;
 }
 
@@ -159,7 +160,7 @@ extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
     m->device = cfg->device;
     m->vel.configure(cfg->half_fov_h, cfg->half_fov_v, cfg->angle_resolution);
     if (const char* e = getenv("DSPMAP_PLACE_SPLIT_TILES")) { const long v = atol(e); if (v > 0) m->place_split_tiles = (int)std::min(v, 2000000000l); }
-    if (const char* e = getenv("DSPMAP_SWEEP_ALTERNATE")) m->sweep_alt = atoi(e) < 0 ? -1 : (atoi(e) != 0 ? 1 : 0);
+    if (const char* e = getenv("DSPMAP_SWEEP_ALTERNATE")) m->sweep_alt = atoi(e) < 0 ? -1 : (atoi(e) >= 2 ? 2 : (atoi(e) != 0 ? 1 : 0));
     if (const char* e = getenv("DSPMAP_RESAMPLE_WG_TILES")) { const long v = atol(e); if (v >= 0) m->resample_wg_tiles = (int)std::min(v, 2000000000l); }
     return m;
 }
@@ -528,7 +529,7 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
         case DSPMAP_P_FAST_DIVISION: if (v == 0) { m->d.div_ok = 0; m->div_forced_off = true; m->graph_epoch++; } break;
         case DSPMAP_P_PLACE_SPLIT_TILES: m->place_split_tiles = v < 1 ? 1 : (v > 2e9 ? 2000000000 : (int)v); m->graph_epoch++; break;
         case DSPMAP_P_RESAMPLE_WG_TILES: m->resample_wg_tiles = v < 0 ? 0 : (v > 2e9 ? 2000000000 : (int)v); m->graph_epoch++; break;
-        case DSPMAP_P_SWEEP_ALTERNATE: m->sweep_alt = v < 0 ? -1 : (v != 0 ? 1 : 0); break;
+        case DSPMAP_P_SWEEP_ALTERNATE: m->sweep_alt = v < 0 ? -1 : (v >= 2 ? 2 : (v != 0 ? 1 : 0)); m->graph_epoch++; break;
         case DSPMAP_P_OCCLUSION_MARGIN: m->fp.occl_margin = (float)v; break;
         case DSPMAP_P_PAIR_CULL_SIGMAS: if (!(v > 0)) return dspmap_fail(m, DSPMAP_E_ARG, "pair cull radius must be positive"); m->cull_sigmas = (float)v; refresh_fp(m); break;
         case DSPMAP_P_REGENERATE_TABLES:
@@ -1225,6 +1226,7 @@ int dspmap_mark_nb_dirty(dspmap* m) {
 
 extern "C" int dspmap_clear_state(dspmap_t* m) {
     READY(m);
+    m->state_epoch++;
     const MapDims& d = m->d;
     const size_t W = (size_t)d.v_loc * d.mw;
     HIPCHK(m, hipMemsetAsync(m->s.mask, 0, sizeof(u64) * W, m->stream));
@@ -1242,6 +1244,7 @@ extern "C" int dspmap_clear_state(dspmap_t* m) {
 
 extern "C" int dspmap_import_state(dspmap_t* m, int n, const int* voxel, const int* slot, const float* rec8) {
     READY(m);
+    m->state_epoch++;
     if (n < 0 || (n > 0 && (!voxel || !rec8))) return DSPMAP_E_ARG;
     if (n == 0) return DSPMAP_OK;
     bool any_vz = false;
@@ -1296,6 +1299,7 @@ extern "C" int dspmap_export_state(dspmap_t* m, int cap, int* voxel, int* slot, 
 
 extern "C" int dspmap_add_random_particles(dspmap_t* m, int n, float weight) {
     READY(m);
+    m->state_epoch++;
     if (n < 0) return DSPMAP_E_ARG;
     int rc = ensure_vz(m);
     if (rc != DSPMAP_OK) return rc;
@@ -1314,6 +1318,7 @@ extern "C" int dspmap_add_random_particles(dspmap_t* m, int n, float weight) {
 
 extern "C" int dspmap_seed_uniform_moving(dspmap_t* m, int per_voxel, float weight, unsigned seed, float vmax) {
     READY(m);
+    m->state_epoch++;
     if (per_voxel < 0 || per_voxel > m->d.slots) return dspmap_fail(m, DSPMAP_E_ARG, "per_voxel must be in [0, %d]", m->d.slots);
     if (!(vmax >= 0.f)) return dspmap_fail(m, DSPMAP_E_ARG, "vmax must be >= 0");
     LaunchCtx c = dspmap_ctx_of(m);
@@ -1502,7 +1507,7 @@ extern "C" int dspmap_get_pyramid_counts(dspmap_t* m, int* out) {
     READY(m);
     if (!out) return DSPMAP_E_ARG;
     HIPCHK(m, hipStreamSynchronize(m->stream));
-    HIPCHK(m, hipMemcpy(out, m->s.pyr_cnt, sizeof(int) * m->d.np, hipMemcpyDeviceToHost));
+    HIPCHK(m, hipMemcpy(out, m->s.pyr_kept ? m->s.pyr_kept : m->s.pyr_cnt, sizeof(int) * m->d.np, hipMemcpyDeviceToHost));   // (a sharded map's global cut: what this rank keeps)
     for (int i = 0; i < m->d.np; i++) if (out[i] > m->d.capp) out[i] = m->d.capp;
     return DSPMAP_OK;
 }

@@ -267,6 +267,12 @@ __device__ __forceinline__ u64 fut_quantum(float w) { return (u64)__float2ull_rn
 __device__ __forceinline__ void fut_add(u64* cell, u64 q) { __hip_atomic_fetch_add(cell, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float fut_value(u64 q) { return (float)((double)q * FUT_FIX_INV); }
 
+// entries of pyramid b's range-sorted particle list (what the pair kernels read): the list as registered, cut to the reference's
+// capacity -- on a sharded map in a frame with a global cut, what THIS rank keeps of it
+__device__ __forceinline__ int pyr_len(const MapDims& d, const DevState& s, int b) {
+    return s.pyr_kept ? s.pyr_kept[b] : min(s.pyr_cnt[b], d.capp);
+}
+
 #define GU 16
 // obs_gather_wave: one wave per pyramid (k_obs_gather; in a whole frame the extra workgroups of k_predict).  Appends matching points in INPUT order
 // (stable, ballot + prefix popcount) to the pyramid's bin, keeps the first 99

@@ -84,7 +84,19 @@ struct dspmap_dist {
     int nb_hi = 0;                      // longest birth cloud so far (span of the n_static all-reduce)
     int min_slab = 1;                   // thinnest slab of the partition, in layers (number of forwarding rounds)
     long long overflow_frames = 0;
+    // the pyramid lists' GLOBAL capacity (:64-66,1256-1259): distributed radix select of every pyramid's CAPP-th smallest sweep key
+    int* hist = nullptr;                // [np][256] digit counts of one pass (summed over the ranks)
+    int2* sel = nullptr;                // [np] {digits chosen so far, entries still wanted}
+    int* kstar = nullptr;               // [np] the selected key (0x7fffffff: the list is not overfull)
+    int* kept = nullptr;                // [np] entries of this rank's list under the selected key
+    int exact_mode = 1;                 // DSPMAP_SHARDED_EXACT_LISTS: 0 never (a full list is cut per rank), 1 when a list may overflow (default), 2 every frame
+    int gcnt_max = 1 << 30;             // the longest list of an earlier frame over all ranks (nothing known yet: assume overfull)
+    unsigned state_epoch_seen = ~0u;    // dspmap::state_epoch at the last frame: particles written outside a frame -> nothing known
+    long long exact_frames = 0;         // frames that ran the selection
 };
+
+// one-process group: element-wise SUM (int64 / int32) / MAX (int32) over the members' buffers, written back to all of them
+struct PtrList { void* p[16]; int n; };
 
 #define NCCLCHK(m, call)                                                                                   \
     do {                                                                                                   \
@@ -101,6 +113,20 @@ __global__ void k_dist_headers(float* up, float* down, const int* cnt2, int* nst
         nstatic[slot] = max(cnt2[0], cnt2[1]);   // rides on the MAX all-reduce: next frames' message size
     }
 }
+// after the Ck all-reduce: the ranks' list lengths have been summed with it; their maximum goes to the slot behind the export
+// maximum (identical on every rank, read by the host a frame later: does the NEXT frame have to run the selection?); a list that
+// overflows globally in a frame that did not run it was cut per rank: counted
+__global__ void k_dist_gcnt(MapDims d, const long long* __restrict__ gcnt, int* __restrict__ out, int exact, FrameScalars* fs) {
+    int mx = 0;
+    for (int b = threadIdx.x; b < d.np; b += 64) mx = max(mx, (int)min(gcnt[b], (long long)(1 << 30)));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, WAVE));
+    if (threadIdx.x == 0) {
+        *out = mx;
+        if (!exact && mx > d.capp) atomicAdd(&fs->n_overflow_inexact, 1);
+    }
+}
+__global__ void k_group_sum_i32(PtrList l, int count);
 __global__ void k_dist_fwd_reset(float* fwd_up, float* fwd_down) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { reinterpret_cast<int*>(fwd_up)[0] = 0; reinterpret_cast<int*>(fwd_down)[0] = 0; }
 }
@@ -131,8 +157,13 @@ __global__ void __launch_bounds__(256) k_dist_import(MapDims d, const float* __r
     }
     wave_count_add(lost, gone);
 }
-// one-process group: element-wise SUM (int64) / MAX (int32) over the members' buffers, written back to all of them
-struct PtrList { void* p[16]; int n; };
+__global__ void k_group_sum_i32(PtrList l, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    int acc = 0;
+    for (int k = 0; k < l.n; ++k) acc += reinterpret_cast<int*>(l.p[k])[i];
+    for (int k = 0; k < l.n; ++k) reinterpret_cast<int*>(l.p[k])[i] = acc;
+}
 __global__ void k_group_sum_i64(PtrList l, int count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -166,6 +197,20 @@ static int dist_alloc(dspmap* m, int world, int rank) {
             HIPCHK(m, hipMemset(x->buf[dir][k], 0, sizeof(float) * 8));
         }
     HIPCHK(m, hipMalloc((void**)&x->cnt2, sizeof(int) * 2));
+    HIPCHK(m, hipMalloc((void**)&x->hist, sizeof(int) * 256 * (size_t)d.np));
+    HIPCHK(m, hipMalloc((void**)&x->sel, sizeof(int2) * (size_t)d.np));
+    HIPCHK(m, hipMalloc((void**)&x->kstar, sizeof(int) * (size_t)d.np));
+    HIPCHK(m, hipMalloc((void**)&x->kept, sizeof(int) * (size_t)d.np));
+    if (const char* e = getenv("DSPMAP_SHARDED_EXACT_LISTS")) x->exact_mode = std::max(0, std::min(2, atoi(e)));
+    {   // the ranks' list lengths ride on the Ck all-reduce: np more 64-bit slots behind the np * 100 sums
+        long long* ck = nullptr;
+        HIPCHK(m, hipMalloc((void**)&ck, sizeof(long long) * ((size_t)d.np * DSP_OBS_CAP + d.np)));
+        HIPCHK(m, hipMemset(ck, 0, sizeof(long long) * ((size_t)d.np * DSP_OBS_CAP + d.np)));
+        (void)hipFree(m->s.obs_ck);
+        m->s.obs_ck = ck;
+        m->s.pyr_gcnt = ck + (size_t)d.np * DSP_OBS_CAP;
+        m->graph_epoch++;
+    }
     HIPCHK(m, hipHostMalloc((void**)&x->gmax_pin, sizeof(int) * 2));
     x->gmax_pin[0] = 0;
     HIPCHK(m, hipEventCreateWithFlags(&x->gmax_ev, hipEventDisableTiming));
@@ -189,6 +234,11 @@ void dspmap_dist_free(dspmap* m) {
     if (x->comm && rccl()->ok) (void)rccl()->CommDestroy(x->comm);
     for (int dir = 0; dir < 2; ++dir) for (int k = 0; k < 3; ++k) if (x->buf[dir][k]) (void)hipFree(x->buf[dir][k]);
     if (x->cnt2) (void)hipFree(x->cnt2);
+    if (x->hist) (void)hipFree(x->hist);
+    if (x->sel) (void)hipFree(x->sel);
+    if (x->kstar) (void)hipFree(x->kstar);
+    if (x->kept) (void)hipFree(x->kept);
+    m->s.pyr_kept = nullptr; m->s.pyr_kstar = nullptr; m->s.pyr_gcnt = nullptr;
     if (x->gmax_pin) (void)hipHostFree(x->gmax_pin);
     if (x->gmax_ev) (void)hipEventDestroy(x->gmax_ev);
     delete x;
@@ -341,14 +391,24 @@ static int phase_begin(dspmap* m, int n_points, const float* points_dev, int n_b
         HIPCHK(m, hipEventSynchronize(x->gmax_ev));
         x->gmax_pending = false;
         const int g = x->gmax_pin[0];
+        x->gcnt_max = x->gmax_pin[1];
         if (g > x->xsend) ++x->overflow_frames;   // that frame's messages were too small: particles were lost
         x->xsend = (int)std::min<long long>(x->xcap, std::max<long long>(4096, (long long)g + g / 2 + 1024));
     }
-    {   // room for the cloud and for the extra slot of the n_static all-reduce
-        const int rcap = dspmap_ensure_point_cap(m, std::max(n_points, n_birth) + 2);
+    {   // room for the cloud and for the two extra slots of the n_static all-reduce
+        const int rcap = dspmap_ensure_point_cap(m, std::max(n_points, n_birth) + 3);
         if (rcap != DSPMAP_OK) return rcap;
-        m->mgpu_nstatic_cap = m->pt_cap - 1;
+        m->mgpu_nstatic_cap = m->pt_cap - 2;
     }
+    // Does this frame select the pyramid lists' cut over ALL ranks?  Yes whenever a list may be overfull: nothing is known
+    // yet (first frames, particles written outside a frame), or the longest list of the last frame whose count has arrived
+    // was at least half the capacity -- list lengths change by the few per cent of the particles that cross a pyramid
+    // boundary per frame, so a frame that skips the selection cannot overflow (if it does, n_overflow_inexact counts it).
+    // Every input of the decision is identical on every rank (the count is the all-reduced one): the ranks agree.
+    if (x->state_epoch_seen != m->state_epoch) { x->state_epoch_seen = m->state_epoch; x->gcnt_max = 1 << 30; }
+    m->mgpu_exact_lists = x->world > 1 && (x->exact_mode == 2 || (x->exact_mode == 1 && 2ll * x->gcnt_max >= m->d.capp));
+    m->s.pyr_kstar = m->mgpu_exact_lists ? x->kstar : nullptr;
+    m->s.pyr_kept = m->mgpu_exact_lists ? x->kept : nullptr;
     const int rc = dspmap_mgpu_begin(m, n_points, points_dev, n_birth, birth_dev, pos, stamp, q);
     if (rc != DSPMAP_OK) return rc;
     x->nb_hi = std::max(x->nb_hi, m->last_n_birth);
@@ -376,12 +436,18 @@ static void phase_import(dspmap* m, int dir_from /* 0: message came from below (
     hipLaunchKernelGGL(k_dist_import, dim3((x->xsend + 255) / 256), dim3(256), 0, m->stream, m->d, x->buf[dir_from][1], x->xsend,
                        c.k.in_rec, c.k.in_cnt, fwd, x->xsend, &m->s.fs->n_voxel_full_import);
 }
-static int phase_place_and_ck(dspmap* m) { return dspmap_mgpu_ck_partial(m); }
+static int phase_place(dspmap* m) { return dspmap_mgpu_place_phase(m); }
+static int phase_ck(dspmap* m) { return dspmap_mgpu_ck_phase(m); }
+// after the Ck all-reduce: the longest list over all ranks -> the slot behind the export maximum
+static void phase_gcnt(dspmap* m) {
+    dspmap_dist* x = m->dist;
+    hipLaunchKernelGGL(k_dist_gcnt, dim3(1), dim3(64), 0, m->stream, m->d, m->s.pyr_gcnt, m->s.nstatic + x->nb_hi + 1, m->mgpu_exact_lists ? 1 : 0, m->s.fs);
+}
 static int phase_weights(dspmap* m) { return dspmap_mgpu_weights_and_split(m); }
 static int phase_finish(dspmap* m) {
     dspmap_dist* x = m->dist;
     // the frame's largest export (all ranks) travels to the host behind the all-reduce; read at the start of a later frame
-    HIPCHK(m, hipMemcpyAsync(x->gmax_pin, m->s.nstatic + x->nb_hi, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipMemcpyAsync(x->gmax_pin, m->s.nstatic + x->nb_hi, 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipEventRecord(x->gmax_ev, m->stream));
     x->gmax_pending = true;
     return dspmap_mgpu_finish(m);
@@ -413,12 +479,26 @@ extern "C" int dspmap_mgpu_update(dspmap_t* m, int n_points, const float* points
         if (x->rank + 1 < x->world) phase_import(m, 1, rd + 1 == rounds);
         if (rd + 1 < rounds) { std::swap(x->buf[0][0], x->buf[0][2]); std::swap(x->buf[1][0], x->buf[1][2]); }   // forward what has to travel on
     }
-    rc = phase_place_and_ck(m);
+    rc = phase_place(m);
     if (rc != DSPMAP_OK) return rc;
-    NCCLCHK(m, r->AllReduce(m->s.obs_ck, m->s.obs_ck, (size_t)m->d.np * DSP_OBS_CAP, ncclInt64, ncclSum, x->comm, m->stream));
+    if (m->mgpu_exact_lists) {
+        // SAFE_PARTICLE_NUM_PYRAMID over all ranks: one small all-reduce per 8-bit digit of the selection
+        LaunchCtx c = dspmap_ctx_of(m);
+        for (int ps = 0; ps < pyr_select_passes(); ++ps) {
+            launch_pyr_hist(c, ps, x->sel, x->hist);
+            NCCLCHK(m, r->AllReduce(x->hist, x->hist, (size_t)m->d.np * 256, ncclInt32, ncclSum, x->comm, m->stream));
+            launch_pyr_pick(c, ps, x->hist, x->sel, x->kstar);
+        }
+        launch_pyr_kept(c, x->kstar, x->kept);
+        ++x->exact_frames;
+    }
+    rc = phase_ck(m);
+    if (rc != DSPMAP_OK) return rc;
+    NCCLCHK(m, r->AllReduce(m->s.obs_ck, m->s.obs_ck, (size_t)m->d.np * DSP_OBS_CAP + m->d.np, ncclInt64, ncclSum, x->comm, m->stream));
+    phase_gcnt(m);
     rc = phase_weights(m);
     if (rc != DSPMAP_OK) return rc;
-    NCCLCHK(m, r->AllReduce(m->s.nstatic, m->s.nstatic, (size_t)x->nb_hi + 1, ncclInt32, ncclMax, x->comm, m->stream));
+    NCCLCHK(m, r->AllReduce(m->s.nstatic, m->s.nstatic, (size_t)x->nb_hi + 2, ncclInt32, ncclMax, x->comm, m->stream));
     rc = phase_finish(m);
     if (rc != DSPMAP_OK) return rc;
     if (x->overflow_frames) {
@@ -472,11 +552,23 @@ extern "C" int dspmap_mgpu_group_update(dspmap_t** hs, int n, int n_points, cons
     }
     PtrList l;
     l.n = n;
-    for (int i = 0; i < n; ++i) { const int rc = phase_place_and_ck(hs[i]); if (rc != DSPMAP_OK) return rc; l.p[i] = hs[i]->s.obs_ck; }
-    const int n_ck = hs[0]->d.np * DSP_OBS_CAP;
+    for (int i = 0; i < n; ++i) { const int rc = phase_place(hs[i]); if (rc != DSPMAP_OK) return rc; }
+    if (hs[0]->mgpu_exact_lists) {
+        for (int i = 1; i < n; ++i) if (!hs[i]->mgpu_exact_lists) return dspmap_fail(hs[0], DSPMAP_E_STATE, "the slabs of a group disagree about the list selection");
+        const int n_h = hs[0]->d.np * 256;
+        for (int ps = 0; ps < pyr_select_passes(); ++ps) {
+            for (int i = 0; i < n; ++i) { LaunchCtx c = dspmap_ctx_of(hs[i]); launch_pyr_hist(c, ps, hs[i]->dist->sel, hs[i]->dist->hist); l.p[i] = hs[i]->dist->hist; }
+            hipLaunchKernelGGL(k_group_sum_i32, dim3((n_h + 255) / 256), dim3(256), 0, st, l, n_h);
+            for (int i = 0; i < n; ++i) { LaunchCtx c = dspmap_ctx_of(hs[i]); launch_pyr_pick(c, ps, hs[i]->dist->hist, hs[i]->dist->sel, hs[i]->dist->kstar); }
+        }
+        for (int i = 0; i < n; ++i) { LaunchCtx c = dspmap_ctx_of(hs[i]); launch_pyr_kept(c, hs[i]->dist->kstar, hs[i]->dist->kept); ++hs[i]->dist->exact_frames; }
+    }
+    for (int i = 0; i < n; ++i) { const int rc = phase_ck(hs[i]); if (rc != DSPMAP_OK) return rc; l.p[i] = hs[i]->s.obs_ck; }
+    const int n_ck = hs[0]->d.np * DSP_OBS_CAP + hs[0]->d.np;
     hipLaunchKernelGGL(k_group_sum_i64, dim3((n_ck + 255) / 256), dim3(256), 0, st, l, n_ck);
+    for (int i = 0; i < n; ++i) phase_gcnt(hs[i]);
     int span = 0;
-    for (int i = 0; i < n; ++i) { const int rc = phase_weights(hs[i]); if (rc != DSPMAP_OK) return rc; l.p[i] = hs[i]->s.nstatic; span = std::max(span, hs[i]->dist->nb_hi + 1); }
+    for (int i = 0; i < n; ++i) { const int rc = phase_weights(hs[i]); if (rc != DSPMAP_OK) return rc; l.p[i] = hs[i]->s.nstatic; span = std::max(span, hs[i]->dist->nb_hi + 2); }
     hipLaunchKernelGGL(k_group_max_i32, dim3((span + 255) / 256), dim3(256), 0, st, l, span);
     for (int i = 0; i < n; ++i) { const int rc = phase_finish(hs[i]); if (rc != DSPMAP_OK) return rc; }
     long long ov = 0;

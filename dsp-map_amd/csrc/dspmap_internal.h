@@ -102,8 +102,8 @@ struct dspmap {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};   // the captured frame, one per sweep direction (LaunchCtx::sweep_rev is a kernel argument)
     unsigned long long graph_key[2] = {~0ull, ~0ull};
-    int sweep_alt = 0;               // DSPMAP_P_SWEEP_ALTERNATE: 1 = all three tile sweeps flip their direction from frame to frame (0, the default: k_place
-                                     // always walks against k_predict / k_resample; -1: flip on maps of >= 4096 tiles)
+    int sweep_alt = 2;               // DSPMAP_P_SWEEP_ALTERNATE: 2 (default) k_predict up, k_place down, k_resample down; 0 k_resample up; 1 all three flip
+                                     // from frame to frame; -1 flip on maps of >= 4096 tiles
     unsigned frame_parity = 0;       // toggled by every prediction
     unsigned graph_epoch = 0;   // bumped whenever a baked-in kernel argument (pointer / parameter) changes
     // multi-GPU split-phase state
@@ -116,6 +116,9 @@ struct dspmap {
     bool mgpu_interior_done = false;   // dspmap_mgpu_place_interior placed the tiles [mgpu_tile_lo, mgpu_tile_hi)
     int mgpu_tile_lo = 0, mgpu_tile_hi = 0;
     bool mgpu_place_pending = false;   // k_predict ran, k_place waits for the imports
+    bool mgpu_exact_lists = false;     // this frame selects the pyramid lists' cut over all ranks (dspmap_dist.hip)
+    bool mgpu_split = false, mgpu_placed = false;   // between dspmap_mgpu_place_phase and dspmap_mgpu_ck_phase
+    unsigned state_epoch = 0;          // bumped whenever particles are written outside a frame (seed / import / clear / checkpoint)
     bool mgpu_side_pending = false;    // the placement of the tiles without a view runs on the side stream (joined before the birth split)
     int vz_frames_at_begin = 0;
     int mgpu_nstatic_cap = 0;
@@ -153,7 +156,9 @@ int dspmap_stage_points(dspmap* m, int n, int stride, const float* pts);   // ho
 int dspmap_begin_cloud(dspmap* m, int n_points, bool static_birth);
 int dspmap_upload_birth(dspmap* m, const dspmap_vpoint* pts, int n);   // host cloud -> DevState::birth (pinned staging, async copy)
 int dspmap_ve_state_to_host(dspmap* m);     // clusters_feature_vector_dynamic_last (:1401) to the implementation that runs next
-int dspmap_ve_state_to_device(dspmap* m);   // bumps the frame epoch; returns the birth grid bound
+int dspmap_ve_state_to_device(dspmap* m);
+int dspmap_mgpu_place_phase(dspmap* m);   // dspmap_mgpu_ck_partial in two halves: placement of the voxel-changing particles ...
+int dspmap_mgpu_ck_phase(dspmap* m);      // ... list preparation (with DevState::pyr_kstar, if set) + the Ck pass   // bumps the frame epoch; returns the birth grid bound
 
 #define HIPCHK(m, call)                                                                            \
     do {                                                                                           \

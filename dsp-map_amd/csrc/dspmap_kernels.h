@@ -48,6 +48,7 @@ struct LaunchCtx {
     int resample_wg_tiles = 8192;   // one-word maps with fewer tiles run k_resample_wg (dspmap::resample_wg_tiles, DSPMAP_P_RESAMPLE_WG_TILES)
     bool sweep_rev = false;   // this frame's k_predict / k_resample walk the tiles from the last one down and k_place from the first one up
                               // (the next frame the other way round): every tile sweep starts where its predecessor ended (Infinity Cache)
+    bool resample_rev = false;   // k_resample walks the tiles from the last one down (after a k_place that ended there)
     bool sparse = false; // most tiles hold nothing (dspmap::sparse_mode): k_predict's variant that leaves such tiles first
 };
 
@@ -76,6 +77,12 @@ int velocity_estimator_capacity();   // points per frame the device estimator ha
 int velocity_estimator_slices();
 // mapUpdate (:704-793)
 void launch_place_fix(const LaunchCtx& c);     // re-slots the arrivals of voxels in which a full pyramid list turned a particle away (after launch_pyr_prepare)
+// sharded maps: one pass (8 bits, most significant first) of the distributed selection of every pyramid's CAPP-th smallest sweep key;
+// the caller sums `hist` ([np][256]) over the ranks between the two launches
+void launch_pyr_hist(const LaunchCtx& c, int pass, const int2* sel, int* hist);
+void launch_pyr_pick(const LaunchCtx& c, int pass, const int* hist, int2* sel, int* kstar);
+int pyr_select_passes();
+void launch_pyr_kept(const LaunchCtx& c, const int* kstar, int* kept);   // after the last pass: this rank's kept entries per pyramid
 void launch_pyr_prepare(const LaunchCtx& c);   // range sort + full-list selection of the pyramid lists, work items (idempotent)
 void launch_ck_partial(const LaunchCtx& c, bool prepared = false);     // launch_pyr_prepare (unless already queued) + the Ck pass
 void launch_ck_finalize(const LaunchCtx& c);

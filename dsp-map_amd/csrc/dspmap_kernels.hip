@@ -156,6 +156,7 @@ __device__ __forceinline__ void pyr_sort_block(const MapDims& d, const DevState&
     __shared__ int s_scan[17];
     const int tid = threadIdx.x;
     const int P_all = min(s.pyr_cnt[b], d.capa);
+    if (tid == 0 && s.pyr_gcnt) s.pyr_gcnt[b] = P_all;   // (a sharded map: the ranks' list lengths are summed by the Ck all-reduce)
     if (P_all == 0) return;
     const float4* __restrict__ src = s.fov_rec + (size_t)b * d.capa;
     const int* __restrict__ src_slot = s.fov_slot + (size_t)b * d.capa;
@@ -165,7 +166,12 @@ __device__ __forceinline__ void pyr_sort_block(const MapDims& d, const DevState&
     // every entry carries its sweep key: the capp SMALLEST keys stay (radix select of the capp-th key, 4 x 8 bits),
     // the others lose their slot -- the same particles as in the reference, independent of the arrival order.
     int kstar = 0x7fffffff;
-    if (P_all > d.capp) {
+    if (s.pyr_kstar) {
+        // a sharded map: SAFE_PARTICLE_NUM_PYRAMID bounds the list over ALL ranks -- the threshold was selected over the union of
+        // the ranks' entries (k_pyr_hist / k_pyr_pick + an all-reduce per digit, dspmap_dist.hip); this rank may have to turn
+        // entries away although its own share is short of the capacity, and keeps fewer than CAPP of them
+        kstar = s.pyr_kstar[b];
+    } else if (P_all > d.capp) {
         // keys are below v_glob * slots: 13 bits per pass (8192 bins), highest digits first
         const unsigned kmax = (unsigned)d.v_glob * (unsigned)d.slots;
         const int nbits = 32 - __clz((int)max(kmax, 2u) - 1);
@@ -277,6 +283,95 @@ __global__ void __launch_bounds__(1024) k_pyr_prepare(MapDims d, DevState s, int
     if ((int)blockIdx.x == d.np) pyr_items_block(d, s, ck_items, wu_items, n_items, nb_tab);
     else pyr_sort_block(d, s, (int)blockIdx.x);
 }
+
+// --------------------------------------------------------------------------
+// Distributed selection of the CAPP-th smallest sweep key of every pyramid over the ranks of a sharded map (:1256-1259 with the
+// reference's GLOBAL capacity): radix select, 8 bits per pass, most significant digit first.  Per pass every rank counts its
+// entries (those that match the digits chosen so far) per pyramid and digit -- k_pyr_hist --, the [np][256] tables are summed
+// over the ranks (ncclAllReduce / the group driver's reduction kernel), and every rank picks the digit in which the cumulative
+// count reaches what is still wanted -- k_pyr_pick: the same table, hence the same choice, everywhere.  sel[b] = {digits so
+// far, entries still wanted among them; -1: the pyramid's list is not overfull}.  After the last pass kstar[b] is the key itself
+// (sweep keys are unique: one per particle).
+// --------------------------------------------------------------------------
+#define PSEL_PASSES 4   // keys are below 2^31
+__global__ void __launch_bounds__(256) k_pyr_hist(MapDims d, DevState s, int pass, const int2* __restrict__ sel, int* __restrict__ hist) {
+    __shared__ int s_h[256];
+    const int b = (int)blockIdx.x, tid = threadIdx.x;
+    s_h[tid] = 0;
+    __syncthreads();
+    const int2 st = pass > 0 ? sel[b] : make_int2(0, 0);
+    if (pass == 0 || st.y >= 0) {
+        const int shift = 24 - 8 * pass;
+        const int P_all = min(s.pyr_cnt[b], d.capa);
+        const int* __restrict__ key = s.fov_key + (size_t)b * d.capa;
+        for (int i = tid; i < P_all; i += 256) {
+            const unsigned k = (unsigned)key[i];
+            if (k == 0x7fffffffu) continue;   // (turned away by an earlier preparation of the same lists)
+            if (pass > 0 && (k >> (shift + 8)) != ((unsigned)st.x >> (shift + 8))) continue;
+            atomicAdd(&s_h[(k >> shift) & 255u], 1);
+        }
+    }
+    __syncthreads();
+    hist[b * 256 + tid] = s_h[tid];
+}
+__global__ void __launch_bounds__(64) k_pyr_pick(MapDims d, int pass, const int* __restrict__ hist, int2* __restrict__ sel, int* __restrict__ kstar) {
+    const int b = (int)blockIdx.x, l = threadIdx.x;
+    int2 st = pass > 0 ? sel[b] : make_int2(0, d.capp);
+    int c4[4], mine = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { c4[q] = hist[b * 256 + l * 4 + q]; mine += c4[q]; }
+    const int inc = wave_incl_scan_i(mine);
+    if (pass == 0) {
+        const int total = __shfl(inc, 63, WAVE);
+        if (total <= d.capp) st.y = -1;   // the list fits: nobody is turned away
+    }
+    if (st.y >= 0) {
+        int ex = inc - mine;
+        const bool here = ex < st.y && st.y <= inc;
+        int digit = 0, left = 0;
+        if (here) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (ex < st.y && st.y <= ex + c4[q]) { digit = l * 4 + q; left = st.y - ex; }
+                ex += c4[q];
+            }
+        }
+        const u64 who = __ballot(here);
+        const int src = __ffsll((long long)who) - 1;    // (exactly one lane: the counts are non-negative and their sum >= want)
+        digit = __shfl(digit, src, WAVE); left = __shfl(left, src, WAVE);
+        st.x |= digit << (24 - 8 * pass);
+        st.y = left;
+    }
+    if (l == 0) {
+        sel[b] = st;
+        if (pass == PSEL_PASSES - 1) kstar[b] = st.y >= 0 ? st.x : 0x7fffffff;
+    }
+}
+// ... and what this rank keeps of every list under the selected thresholds (the pair kernels' list lengths)
+__global__ void __launch_bounds__(256) k_pyr_kept(MapDims d, DevState s, const int* __restrict__ kstar, int* __restrict__ kept) {
+    __shared__ int s_n;
+    const int b = (int)blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const int P_all = min(s.pyr_cnt[b], d.capa), ks = kstar[b];
+    const int* __restrict__ key = s.fov_key + (size_t)b * d.capa;
+    int n = 0;
+    for (int i = tid; i < P_all; i += 256) { const int k = key[i]; n += (k <= ks && k != 0x7fffffff) ? 1 : 0; }
+    n = wave_sum_i(n);
+    if (lane_id() == 0 && n) atomicAdd(&s_n, n);
+    __syncthreads();
+    if (tid == 0) kept[b] = s_n;
+}
+void launch_pyr_kept(const LaunchCtx& c, const int* kstar, int* kept) {
+    hipLaunchKernelGGL(k_pyr_kept, dim3(c.d.np), dim3(256), 0, c.stream, c.d, c.s, kstar, kept);
+}
+void launch_pyr_hist(const LaunchCtx& c, int pass, const int2* sel, int* hist) {
+    hipLaunchKernelGGL(k_pyr_hist, dim3(c.d.np), dim3(256), 0, c.stream, c.d, c.s, pass, sel, hist);
+}
+void launch_pyr_pick(const LaunchCtx& c, int pass, const int* hist, int2* sel, int* kstar) {
+    hipLaunchKernelGGL(k_pyr_pick, dim3(c.d.np), dim3(64), 0, c.stream, c.d, pass, hist, sel, kstar);
+}
+int pyr_select_passes() { return PSEL_PASSES; }
 
 // --------------------------------------------------------------------------
 // k_place_fix: a particle that its pyramid's full list turns away gives its slot back AT ONCE (:1256-1259), so the arrivals
@@ -515,7 +610,7 @@ __device__ __forceinline__ void pyr_items_block(const MapDims& d, const DevState
     // chunk size of k_ck_partial's items: with few particles in the field of view the kernel is one round of workgroups
     // whose run time is the pair loop of ONE item, so the items are halved (twice as many workgroups, half the loop)
     int mine = 0;
-    for (int b = tid; b < d.np; b += (int)blockDim.x) mine += min(s.pyr_cnt[b], d.capp);
+    for (int b = tid; b < d.np; b += (int)blockDim.x) mine += pyr_len(d, s, b);
     int tot_fov;
     (void)block_excl_scan_1024(mine, s_tmp, &tot_fov);
     const int pch = tot_fov <= CK_SMALL_FOV ? CK_PCH / 2 : CK_PCH;
@@ -524,7 +619,7 @@ __device__ __forceinline__ void pyr_items_block(const MapDims& d, const DevState
         const int b = b0 + tid;
         int nck = 0, nwu = 0;
         if (b < d.np) {
-            const int P = min(s.pyr_cnt[b], d.capp);
+            const int P = pyr_len(d, s, b);
             // observations in the 3x3 neighbourhood: decides how many lanes share one particle in k_weight
             const int h0 = b / d.np_v, v0 = b % d.np_v;
             // ... and the neighbourhood table the items of this pyramid read instead of rebuilding it: valid
@@ -592,7 +687,7 @@ __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, Fi
         const int start = chunk * pch;
         float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tid < pch && start + tid < d.capp) r = s.fov_rec_s[(size_t)b * d.capp + start + tid];
-        const int P = min(s.pyr_cnt[b], d.capp);
+        const int P = pyr_len(d, s, b);
         if (it + GX < total) item_next = items[it + GX];
         const int npart = min(pch, P - start);
         __syncthreads();  // LDS reuse across items
@@ -705,7 +800,7 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
     for (int it = blockIdx.x; it < total; it += gridDim.x) {
         const int item = items[it];
         const int b = item >> 12, chunk = item & 0xfff;
-        const int P = min(s.pyr_cnt[b], d.capp);
+        const int P = pyr_len(d, s, b);
         __syncthreads();  // LDS reuse across items
         if (chunk == 0) {
             // final Ck of this pyramid's own observations + their sum of 1/Ck (:799-804)

@@ -178,24 +178,34 @@ extern "C" int dspmap_mgpu_import(dspmap_t* m, int n, const float* rec_dev) {
     return DSPMAP_OK;
 }
 
-extern "C" int dspmap_mgpu_ck_partial(dspmap_t* m) {
+// the phase in two halves, so that the C++ driver (dspmap_dist.hip) can select the pyramid lists' GLOBAL cut between them
+int dspmap_mgpu_place_phase(dspmap* m) {
     READY(m);
+    if (!m->mgpu_place_pending) return DSPMAP_OK;
     LaunchCtx c = dspmap_ctx_of(m);
-    if (m->mgpu_place_pending) {
+    if (m->vz_frames_at_begin <= 0) c.s.vz0 = nullptr;
+    // a large slab: only the arrivals of tiles that can see the field of view are registered in pyramids, so only their
+    // placement has to precede the weight update -- the others get their slots on the side stream, beside the pair kernels
+    // AND the Ck all-reduce that follows this phase (the same split as the unsharded frame, dspmap_api.hip: enqueue_frame)
+    m->mgpu_split = !m->mgpu_interior_done && c.k.ntiles >= m->place_split_tiles;
+    if (m->mgpu_interior_done) launch_claim(c, 0, 2, m->mgpu_tile_lo, m->mgpu_tile_hi);
+    else launch_claim(c, 0, 0, 0, 0, m->mgpu_split ? 1 : -1);
+    m->mgpu_interior_done = false;
+    m->mgpu_place_pending = false;
+    m->mgpu_placed = true;
+    HIPCHK(m, hipGetLastError());
+    return DSPMAP_OK;
+}
+int dspmap_mgpu_ck_phase(dspmap* m) {
+    READY(m);
+    LaunchCtx c = dspmap_ctx_of(m);   // (carries DevState::pyr_kstar when the driver selected a global cut for this frame)
+    if (m->mgpu_placed) {
+        m->mgpu_placed = false;
         if (m->vz_frames_at_begin <= 0) c.s.vz0 = nullptr;
-        // a large slab: only the arrivals of tiles that can see the field of view are registered in pyramids, so only their
-        // placement has to precede the weight update -- the others get their slots on the side stream, beside the pair kernels
-        // AND the Ck all-reduce that follows this phase (the same split as the unsharded frame, dspmap_api.hip: enqueue_frame)
-        const bool split = !m->mgpu_interior_done && c.k.ntiles >= m->place_split_tiles;
-        if (m->mgpu_interior_done) launch_claim(c, 0, 2, m->mgpu_tile_lo, m->mgpu_tile_hi);
-        else launch_claim(c, 0, 0, 0, 0, split ? 1 : -1);
-        m->mgpu_interior_done = false;
-        m->mgpu_place_pending = false;
-        if (split) {
+        if (m->mgpu_split) {
             launch_pyr_prepare(c);
             HIPCHK(m, hipEventRecord(m->ev_fork2, m->stream));
-            LaunchCtx cm = dspmap_ctx_of(m);
-            launch_ck_partial(cm, true);
+            launch_ck_partial(c, true);
             HIPCHK(m, hipStreamWaitEvent(m->stream2, m->ev_fork2, 0));
             LaunchCtx c2 = c;
             c2.stream = m->stream2;
@@ -205,11 +215,14 @@ extern "C" int dspmap_mgpu_ck_partial(dspmap_t* m) {
             HIPCHK(m, hipGetLastError());
             return DSPMAP_OK;
         }
-        c = dspmap_ctx_of(m);
     }
     launch_ck_partial(c);
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
+}
+extern "C" int dspmap_mgpu_ck_partial(dspmap_t* m) {
+    const int rc = dspmap_mgpu_place_phase(m);
+    return rc != DSPMAP_OK ? rc : dspmap_mgpu_ck_phase(m);
 }
 
 extern "C" int dspmap_mgpu_weights_and_split(dspmap_t* m) {

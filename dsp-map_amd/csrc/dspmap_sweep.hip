@@ -1942,7 +1942,7 @@ __global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScra
         s.fs->n_pyramid_full = out[2] + s.fs->n_place_pf + s.fs->n_pyr_removed; s.fs->n_moved = out[3];
         s.fs->n_voxel_full = s.fs->n_place_vf + s.fs->n_voxel_full_import; s.fs->n_live_out = out[6];
         int nf = 0;
-        for (int b = 0; b < d.np; ++b) nf += min(s.pyr_cnt[b], d.capp);
+        for (int b = 0; b < d.np; ++b) nf += pyr_len(d, s, b);
         s.fs->n_fov = nf;
     }
     for (int c = 0; c < 2; ++c) {
@@ -2034,8 +2034,8 @@ void launch_resample(const LaunchCtx& c) {
         // -- unless many tiles hold hundreds of moving particles (c.ro_inline, the handle's choice from last frame's count):
         // then k_rollout's LDS windows are worth their launch (66x66x40 saturated, every particle moving: 0.11 vs 0.27 ms)
         hipLaunchKernelGGL(k_resample_wg, dim3(k->ntiles), dim3(256), lds4, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, ro == 0 ? 1 : 0);
-    } else if (c.d.mw == 1) hipLaunchKernelGGL(k_resample<1>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, c.sweep_rev ? 1 : 0);
-    else hipLaunchKernelGGL(k_resample<2>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, c.sweep_rev ? 1 : 0);
+    } else if (c.d.mw == 1) hipLaunchKernelGGL(k_resample<1>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, c.resample_rev ? 1 : 0);
+    else hipLaunchKernelGGL(k_resample<2>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, c.resample_rev ? 1 : 0);
     if (ro == 1 || ro == 2) {
         // windows: the rows a particle reaches at a design speed (1.5 m/s, a brisk pedestrian), lowered until all T windows fit the LDS
         RolloutPlan pl;

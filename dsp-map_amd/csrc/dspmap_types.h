@@ -196,6 +196,12 @@ struct DevState {
     u64* ta;            // [v_loc*mw] cells whose particle its pyramid's full list turned away this frame (all zero between frames)
     int* dflag;         // [v_loc] 1 = the voxel is in the dirty list
     int* dirty;         // [DSP_DIRTY_CAP] local voxels that lost a particle to a full pyramid list this frame
+    // sharded maps: the pyramid-list capacity is the reference's GLOBAL one (:64-66,1256-1259)
+    const int* pyr_kstar; // [np] or nullptr: the CAPP-th smallest sweep key of every pyramid over ALL ranks (0x7fffffff: no cut), found by the
+                        // distributed radix select of dspmap_dist.hip; k_pyr_prepare cuts with it instead of selecting among the rank's own entries
+    const int* pyr_kept; // [np] or nullptr (set together with pyr_kstar): entries of this rank's list that the global cut keeps = the length of
+                        // the range-sorted list the pair kernels read (without a global cut: min(pyr_cnt, capp))
+    long long* pyr_gcnt; // [np] or nullptr: this rank's list lengths before the cut, summed over the ranks by the Ck all-reduce they ride on
     int* in_n;          // [2 * tiles] {arrivals the last placement served in the tile, FrameScalars::pred_epoch of that placement}
     int* fut_dirty;     // [tiles] 1 = something was added to the tile's future accumulators (fut, fut_stat) since they were zeroed
     int* tile_live;     // [tiles] 0 = the 64-voxel tile holds no particle (k_resample found it empty and nothing was placed, born or

@@ -134,12 +134,12 @@ enum dspmap_param {
     DSPMAP_P_RESAMPLE_WG_TILES = 20,/* one-occupancy-word maps with FEWER 64-voxel tiles than this (default 8192) run the four-waves-per-tile variant of the
                                        resampling stage, the others the one-wave-per-tile variant (same result slot for slot; a scheduling knob: 0 =
                                        never, a huge value = whenever the map qualifies; the environment variable DSPMAP_RESAMPLE_WG_TILES presets it) */
-    DSPMAP_P_SWEEP_ALTERNATE = 21,  /* the placement of the voxel-changing particles always walks the map's 64-voxel tiles AGAINST the prediction sweep
-                                       before it (it starts on the tiles that are still in the 256 MB Infinity Cache: -15 % at 132x132x60 saturated).
-                                       1 = in addition all three tile sweeps (prediction, placement, resampling) flip their direction from frame to
-                                       frame, so that the next frame's prediction starts where the resampling ended (measured: no further gain);
-                                       0 (default) = fixed directions; -1 = flip on maps of at least 4096 tiles.  Same result either way: no stage
-                                       depends on the order in which the tiles are visited */
+    DSPMAP_P_SWEEP_ALTERNATE = 21,  /* direction of the three sweeps over the map's 64-voxel tiles.  A large map's live rows are several times the 256 MB
+                                       Infinity Cache, so a sweep that starts where its predecessor ENDED finds its first tiles there instead of in HBM:
+                                       2 (default) = prediction upwards, placement of the voxel-changing particles downwards, resampling downwards (and
+                                       the next frame's prediction starts where it ended); 0 = resampling upwards; 1 = all three flip from frame to frame
+                                       (two captured graphs); -1 = 1 on maps of at least 4096 tiles.  132x132x60 saturated: placement -15 %, frame -3 %.
+                                       Same result in every mode: no stage depends on the order in which the tiles are visited */
     DSPMAP_P_PAIR_CULL_SIGMAS = 13  /* mapUpdate evaluates a (particle, observation) pair only if their ranges differ by at most this many
                                        sigma_ob (default 9: the dropped terms are < 1e-19 and zero on the fixed-point Ck grid);
                                        a huge value evaluates every pair of the neighbourhood like the reference's loops */

@@ -424,7 +424,6 @@ def test_sharded_future_status_with_every_particle_moving(dsp, world):
             assert fa.sum() > 100 and (fa > 0).mean() > 0.5
             assert np.array_equal(fa, fb), f
             assert np.array_equal(fut_s, fa), f
-    assert fulls[0].counters()["n_pyramid_full"] == 0
     got = np.concatenate([x.results() for x in grp.maps], 0)
     assert np.array_equal(got, fulls[0].results())
     parts = [x.export_state() for x in grp.maps]
@@ -446,7 +445,7 @@ def test_alternating_sweep_direction_changes_nothing(dsp):
     cfg = dict(nx=56, ny=88, nz=12, res=0.15, ppv=24)
     tables = common.tables(5)
     maps = []
-    for alt in (1, 0):
+    for alt in (1, 0, 2):
         m = dsp.DSPMap(dsp.make_config(**cfg)); m.set_tables(*tables)
         m.L.dspmap_init_device(m.h)
         m.set_param(dsp.capi.P_PLACE_SPLIT_TILES, 1)
@@ -470,12 +469,79 @@ def test_alternating_sweep_direction_changes_nothing(dsp):
         cs = [m.counters() for m in maps]
         for c in cs:
             c.pop("update_ms")
-        assert cs[0] == cs[1], (f, cs)
+        assert cs[0] == cs[1] == cs[2], (f, cs)
         futs = [m.getFutureStatus() for m in maps]
-        assert np.array_equal(futs[0], futs[1]) and futs[0].sum() > 0, f
+        assert np.array_equal(futs[0], futs[1]) and np.array_equal(futs[0], futs[2]) and futs[0].sum() > 0, f
     assert cs[0]["n_moved"] > 1000
-    for a, b in zip(maps[0].export_state(), maps[1].export_state()):
-        assert np.array_equal(a, b)
-    assert np.array_equal(maps[0].results(), maps[1].results())
+    for m in maps[1:]:
+        for a, b in zip(maps[0].export_state(), m.export_state()):
+            assert np.array_equal(a, b)
+        assert np.array_equal(maps[0].results(), m.results())
     for m in maps:
         m.close()
+
+
+def _sharded_overfull(dsp, world, exact):
+    """a saturated map whose sensor looks INTO it (identity attitude: dozens of pyramid lists are overfull in every frame, the cut
+    and the re-slotting run), every particle moving, the sensor advancing and climbing (particles change slab): slabs vs unsharded"""
+    import os
+    sharded = __import__("dsp-map_amd.sharded", fromlist=["CppGroup"])
+    # 12 m long: a pyramid reaches 6 m into the map and holds ~60 voxels -> 500 - 700 of the 10 particles per voxel, its list
+    # takes CAPP = 368 (and accepts CAPA = 800 before the cut, beyond which entries would be dropped in arrival order)
+    cfg = dict(nx=80, ny=40, nz=16, res=0.15, ppv=24)
+    tables = common.tables(9)
+    os.environ["DSPMAP_SHARDED_EXACT_LISTS"] = "1" if exact else "0"
+    try:
+        grp = sharded.CppGroup(dsp, cfg, world)
+        grp.create()
+    finally:
+        del os.environ["DSPMAP_SHARDED_EXACT_LISTS"]
+    full = dsp.DSPMap(dsp.make_config(**cfg))
+    for x in grp.maps + [full]:
+        x.set_tables(*tables)
+        x.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, 2)
+        x.seed_uniform(10, weight=0.01, seed=99, vmax=1.0)
+    pts = common.wall_cloud(3, n_side=40, dist=4.2, half_w=1.8, half_h=0.6)
+    d = torch.from_numpy(pts).cuda()
+    stats = []
+    same = True
+    for f in range(5):
+        pos = (0.03 * f, -0.02 * f, 0.025 * f)
+        assert grp.update(d, pos, f / 30.0, (1.0, 0.0, 0.0, 0.0)) == 1
+        assert full.update_device(d.data_ptr(), len(pts), pos, f / 30.0, (1.0, 0.0, 0.0, 0.0)) == 1
+        grp.sync()
+        c = full.counters()
+        stats.append((c["n_pyramid_full"], c["n_reslotted"], c["n_overflow_inexact"], c["n_moved"],
+                      sum(x.counters()["n_exported_up"] + x.counters()["n_exported_down"] for x in grp.maps)))
+        fut_s = np.concatenate([x.getFutureStatus() for x in grp.maps], 0)
+        same = same and np.array_equal(fut_s, full.getFutureStatus())
+        same = same and sum(x.counters()["n_pyramid_full"] for x in grp.maps) == c["n_pyramid_full"]
+    got = np.concatenate([x.results() for x in grp.maps], 0)
+    same = same and np.array_equal(got, full.results())
+    parts = [x.export_state() for x in grp.maps]
+    sv, ss, sr = (np.concatenate([p[k] for p in parts]) for k in range(3))
+    order = np.lexsort((ss, sv))
+    fv, fs_, fr = full.export_state()
+    same = same and len(sv) == len(fv) and np.array_equal(sv[order], fv) and np.array_equal(ss[order], fs_) and np.array_equal(sr[order], fr)
+    inexact = sum(x.counters()["n_overflow_inexact"] for x in grp.maps)
+    grp.close(); full.close()
+    return same, stats, inexact
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_map_with_overfull_pyramid_lists_is_the_unsharded_map(dsp, world):
+    """SAFE_PARTICLE_NUM_PYRAMID (:64-66) bounds a pyramid's list over the WHOLE map: when it is full, the particles that come later
+    in the reference's sweep are turned away (:1256-1259).  A sharded map selects the CAPP-th smallest sweep key over all ranks
+    (radix select, one small all-reduce per 8-bit digit) and every rank cuts with it: the sharded map is the unsharded one, bit
+    for bit, with dozens of overfull lists per frame -- 2 / 4 / 8 slabs.  With the selection switched off (a full list cut per
+    rank, the documented deviation of the earlier rounds) the same run differs, and the frames that overflowed are counted."""
+    same, stats, inexact = _sharded_overfull(dsp, world, exact=True)
+    assert all(s[0] > 200 for s in stats), stats                                         # every frame turned particles away
+    assert sum(s[1] for s in stats) > 20, stats                                          # arrivals were re-slotted
+    # (n_overflow_inexact of the unsharded map counts ITS residue against the reference -- arrivals that found their voxel full
+    # before the cut, a handful in the voxels the births fill up; the slabs treat those voxels alike)
+    assert same, (stats, inexact)
+    same0, stats0, inexact0 = _sharded_overfull(dsp, world, exact=False)
+    assert inexact0 > 0, (stats0, inexact0)                # the frames whose lists overflowed globally are counted
+    if world >= 4:                                          # (with two slabs nearly every pyramid lies in one of them)
+        assert not same0, stats0
