@@ -93,6 +93,7 @@ SIGNATURES = {
     "dspmap_get_counters": (_i, [_P, C.POINTER(Counters)]),
     "dspmap_set_profiling": (_i, [_P, _i]),
     "dspmap_get_stage_ms": (_i, [_P, _fp, _ip]),
+    "dspmap_get_event_overhead_ms": (_i, [_P, _fp]),
     "dspmap_debug_stream": (_i, [_P, _i, C.POINTER(C.c_longlong)]),
     "dspmap_debug_sweep_probe": (_i, [_P, _i, _i, _i, _i, _fp, C.POINTER(C.c_longlong)]),
     "dspmap_debug_tile_view": (_i, [_P, C.POINTER(C.c_int), _i]),
@@ -378,6 +379,12 @@ class DSPMap:
         n = C.c_int()
         self._chk(self.L.dspmap_get_stage_ms(self.h, out, C.byref(n)))
         return dict(zip(self.STAGES, list(out))), n.value
+
+    def event_overhead_ms(self):
+        """what an event bracket adds to the one kernel inside it (calibrated by set_profiling(True))"""
+        out = C.c_float()
+        self._chk(self.L.dspmap_get_event_overhead_ms(self.h, C.byref(out)))
+        return out.value
 
     # -- state
     def clear_state(self):

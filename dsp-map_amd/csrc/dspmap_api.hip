@@ -1520,6 +1520,28 @@ extern "C" int dspmap_set_profiling(dspmap_t* m, int on) {
     m->prof_pending = false;
     m->prof_frames = 0;
     for (int i = 0; i < DSPMAP_N_STAGES; i++) m->stage_ms[i] = 0.0;
+    if (on) {
+        // what an event bracket adds to the kernel inside it (the record's own cost on the queue + the launch gaps either side):
+        // a one-wave kernel that waits a KNOWN 20 us between two records, 24 times; the median excess is subtracted by callers
+        // that want kernel durations from the stage brackets (bench.py's roofline; rocprofv3's kernel durations agree)
+        LaunchCtx c = dspmap_ctx_of(m);
+        std::vector<float> ex;
+        for (int k = 0; k < 24; ++k) {
+            HIPCHK(m, hipEventRecord(m->pev[0], m->stream));
+            launch_spin(c, 20);
+            HIPCHK(m, hipEventRecord(m->pev[1], m->stream));
+            HIPCHK(m, hipEventSynchronize(m->pev[1]));
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, m->pev[0], m->pev[1]) == hipSuccess) ex.push_back(ms - 0.020f);
+        }
+        std::sort(ex.begin(), ex.end());
+        m->event_overhead_ms = ex.empty() ? 0.f : std::max(0.f, ex[ex.size() / 2]);
+    }
+    return DSPMAP_OK;
+}
+extern "C" int dspmap_get_event_overhead_ms(dspmap_t* m, float* out) {
+    if (!m || !out) return DSPMAP_E_ARG;
+    *out = m->event_overhead_ms;
     return DSPMAP_OK;
 }
 extern "C" int dspmap_get_stage_ms(dspmap_t* m, float out[DSPMAP_N_STAGES], int* n_frames) {

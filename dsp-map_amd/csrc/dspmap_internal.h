@@ -136,6 +136,7 @@ struct dspmap {
     double stage_ms[DSPMAP_N_STAGES] = {};
     int prof_frames = 0;
     bool prof_pending = false;
+    float event_overhead_ms = 0.f;   // calibrated by dspmap_set_profiling(1): what an event bracket adds to the one kernel inside it
 };
 
 int dspmap_fail(dspmap* m, int code, const char* fmt, ...);

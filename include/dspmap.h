@@ -230,6 +230,9 @@ int dspmap_get_counters(dspmap_t* m, dspmap_counters* out);
 #define DSPMAP_N_STAGES 8
 int dspmap_set_profiling(dspmap_t* m, int on);
 int dspmap_get_stage_ms(dspmap_t* m, float ms_sum_out[DSPMAP_N_STAGES], int* n_frames_out); /* sums since enabling; syncs */
+/* what one event bracket adds to the kernel inside it (record cost + launch gaps), calibrated when profiling is switched on with a
+ * kernel of known duration: stage time - this = the kernel's own duration for the stages that are one launch */
+int dspmap_get_event_overhead_ms(dspmap_t* m, float* ms_out);
 
 /* profiling aid: streams the six particle field arrays once with the sweeps' access pattern
  * (4 B per lane, 256 B per wave) -- mode 0 reads them (known byte count = 6*4*capacity), mode 1

@@ -36,7 +36,7 @@ done
 for W in B C_sat; do
   rm -rf /tmp/sq_$W
   rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d /tmp/sq_$W -- python $R/bench.py ${ARGS[$W]} > /tmp/sq_$W.log 2>&1
-  python $R/profiles/pmc_reduce.py $(find /tmp/sq_$W -name "*counter_collection.csv" | head -1) $R/gpurun_out/${TAG}_sq_$W.json > /dev/null
+  python $R/profiles/pmc_reduce.py $(find /tmp/sq_$W -name "*counter_collection.csv" | head -1) $R/gpurun_out/${TAG}_sq_$W.json $(find /tmp/sq_$W -name "*kernel_trace.csv" | head -1) > /dev/null
 done
 # the sources these figures belong to (bench.py prints the traffic only while the fingerprint still matches)
 (cd $R && python -c "import bench; print(bench.csrc_fingerprint())" > $R/gpurun_out/${TAG}_csrc_sha16.txt)

@@ -81,8 +81,10 @@ def main(tag):
           "`rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU "
           "SQ_INSTS_SALU --kernel-trace` on the bench commands of the PMC passes; averages per dispatch, summed over the device. "
           "SQ_WAVE_CYCLES / SQ_WAIT_ANY / SQ_ACTIVE_INST_* count in units of 4 cycles. `VALU issue` = 4 x SQ_ACTIVE_INST_VALU / "
-          "(SQ_BUSY_CYCLES / 32 shader engines x 1024 SIMDs): the share of all VALU issue slots of the chip the kernel used while it "
-          "ran; `waiting` = SQ_WAIT_ANY / SQ_WAVE_CYCLES: the share of its waves' lifetime spent in s_waitcnt / barriers.\n"]
+          "(kernel duration from the same run's kernel trace x 2.4 GHz x 1024 SIMDs): the share of all VALU issue slots of the chip "
+          "the kernel used while it ran -- at most 1 by construction (the earlier tables divided by SQ_BUSY_CYCLES / 32, which sums the "
+          "busy cycles of the shader engines that had work and under-counts the elapsed time of a kernel that leaves some of them idle: "
+          "shares above 1); `waiting` = SQ_WAIT_ANY / SQ_WAVE_CYCLES: the share of its waves' lifetime spent in s_waitcnt / barriers.\n"]
     for w in ("B", "C_sat"):
         try:
             js = json.load(open(os.path.join(g, "%s_sq_%s.json" % (tag, w))))
@@ -90,11 +92,12 @@ def main(tag):
             continue
         sq += ["\n## workload %s\n" % w, "| kernel | waves | VALU inst / wave | SALU inst / wave | VALU issue | waiting |", "|---|---|---|---|---|---|"]
         for k, v in sorted(js.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", {}).get("avg", 0)):
-            a = {c: v.get(c, {}).get("avg", 0.0) for c in ("SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU")}
+            a = {c: v.get(c, {}).get("avg", 0.0) for c in ("SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "duration_ns")}
             if a["SQ_WAVES"] <= 0 or a["SQ_BUSY_CYCLES"] <= 0:
                 continue
+            slots = a["duration_ns"] * 2.4 * 1024.0 if a["duration_ns"] > 0 else a["SQ_BUSY_CYCLES"] / 32.0 * 1024.0
             sq.append("| %s | %d | %.0f | %.0f | %.2f | %.2f |" % (base(k), a["SQ_WAVES"], a["SQ_INSTS_VALU"] / a["SQ_WAVES"], a["SQ_INSTS_SALU"] / a["SQ_WAVES"],
-                                                                4.0 * a["SQ_ACTIVE_INST_VALU"] / (a["SQ_BUSY_CYCLES"] / 32.0 * 1024.0),
+                                                                4.0 * a["SQ_ACTIVE_INST_VALU"] / slots,
                                                                 a["SQ_WAIT_ANY"] / max(a["SQ_WAVE_CYCLES"], 1.0)))
     open(os.path.join(HERE, tag + "_sq_issue.md"), "w").write("\n".join(sq) + "\n")
     open(os.path.join(HERE, tag + "_pmc_traffic.md"), "w").write("\n".join(md) + "\n")
