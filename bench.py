@@ -109,6 +109,9 @@ STAGE_KERNELS = {"predict": ("k_predict",), "claim": ("k_place",), "ck_partial":
                  "resample": ("k_resample", "k_resample_wg", "k_rollout")}
 
 
+KERNEL_US = {}   # profiles/pmc_traffic.json "kernel_us" (rocprofv3 --kernel-trace --stats averages), while its sources are this run's
+
+
 def roofline_block(stage_ms, cnt, V, T, mw, traffic_db, wl_name, peak=8000.0, traffic_meta=None, overhead_ms=0.0):
     """roofline of the dominant kernel + every kernel's fraction.  A kernel cannot beat the HBM peak on the bytes it has to
     move: a fraction above 1 means the accounting (or the timer) is wrong and is never printed.
@@ -139,6 +142,16 @@ def roofline_block(stage_ms, cnt, V, T, mw, traffic_db, wl_name, peak=8000.0, tr
             "kernel_ms": per[dom]["ms"], "algorithmic_bytes": per[dom]["bytes"], "per_kernel": per,
             "timer": "HIP events on the library's stream around each kernel launch, minus the calibrated bracket overhead of %.4f ms "
                      "(stage brackets as recorded: frame.stage_ms)" % overhead_ms}
+    rk = KERNEL_US.get(wl_name, {})
+    if rk:   # the committed rocprofv3 durations of the same command on the same sources: the figure the events must agree with
+        for k, v in per.items():
+            us = sum(rk.get(n, 0.0) for n in STAGE_KERNELS.get(k, ()))
+            if us > 0 and v.get("bytes"):
+                v["rocprof_kernel_us"] = round(us, 2)
+                v["frac_on_rocprof_duration"] = round(v["bytes"] / (us * 1e-6) / 1e9 / peak, 5)
+        if "rocprof_kernel_us" in per[dom]:
+            roof["rocprof_kernel_us"] = per[dom]["rocprof_kernel_us"]
+            roof["frac_on_rocprof_duration"] = per[dom]["frac_on_rocprof_duration"]
     if tdb:
         meta = traffic_meta or {}
         roof["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload "
@@ -346,6 +359,7 @@ def main():
         fp_now = csrc_fingerprint()
         if tj.get("csrc_sha16") == fp_now:
             traffic_db = tj["workloads"]
+            KERNEL_US.update(tj.get("kernel_us", {}))
             traffic_meta = {"commit": tj.get("commit"), "csrc_sha16": fp_now}
         else:
             traffic_meta = {"stale": "profiles/pmc_traffic.json was measured on other kernel sources (fingerprint %s, commit %s; this "

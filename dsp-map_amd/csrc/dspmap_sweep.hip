@@ -1227,11 +1227,16 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
             row[r] = tor ? __ffsll((long long)tor) - 1 : -1;
             if (tor) tor &= tor - 1ull;
             const int srow = (row[r] < 0 ? 0 : row[r]) * 64;
-            wr[r] = bl_w(rs_w, l, srow);
-            vv[r] = bl_vel(rs_vel, l, srow);
+            // only the voxel's LIVE cells are fetched: a lane whose cell is empty asks for an offset beyond the tile's descriptor --
+            // the buffer unit returns 0 for it without touching memory and without a branch (a predicated load would make the
+            // compiler wait before it issues the next row's).  A tile of the metric's map is 8 % full: its rows were 37 MB per launch
+            const bool cell = row[r] >= 0 && (((row[r] < 32 ? m_lo : m_hi) >> (row[r] & 31)) & 1u) != 0u;
+            const int ln = cell ? l : (1 << 24);
+            wr[r] = bl_w(rs_w, ln, srow);
+            vv[r] = bl_vel(rs_vel, ln, srow);
             // (x, y) of every cell too: only the moving particles need them (rollout), but asking afterwards would be a second
             // dependent round trip
-            const f2w q = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(rs_pos, l * 12, srow * 12, 0));
+            const f2w q = __builtin_bit_cast(f2w, __builtin_amdgcn_raw_buffer_load_b64(rs_pos, ln * 12, srow * 12, 0));
             pq[r] = make_float2(q.x, q.y);
         }
     }
@@ -1249,6 +1254,9 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
     const u64 sv_mine = ((u64)sv_hi << 32) | sv_lo;
     if (sv_mine) atomicOr(&s_surv[l], sv_mine);
     __syncthreads();
+#ifdef RESAMPLE_PROF2
+    const long long t_sa = __builtin_readcyclecounter();
+#endif
     const u64 surv = s_surv[l];   // the voxel's survivors, all rows
     const size_t ro_base = (size_t)BX * cells;
     u64 oldc_mine = 0ull;
@@ -1439,7 +1447,11 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
     }
 #ifdef RESAMPLE_PROF
     t_s4 = __builtin_readcyclecounter();
+#ifdef RESAMPLE_PROF2
+    if (tid == 0 && BX < 65536) { g_rprof[BX * 4] = t_sa - t_s0; g_rprof[BX * 4 + 1] = t_s1 - t_sa; g_rprof[BX * 4 + 2] = t_s3 - t_s2; g_rprof[BX * 4 + 3] = t_s4 - t_s3; }
+#else
     if (tid == 0 && BX < 65536) { g_rprof[BX * 4] = t_s1 - t_s0; g_rprof[BX * 4 + 1] = t_s2 - t_s1; g_rprof[BX * 4 + 2] = t_s3 - t_s2; g_rprof[BX * 4 + 3] = t_s4 - t_s3; }
+#endif
 #endif
 }
 

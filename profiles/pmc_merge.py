@@ -58,6 +58,23 @@ def main(tag):
                "| kernel | FETCH_SIZE KB | WRITE_SIZE KB | corrected HBM bytes / launch |", "|---|---|---|---|"]
         for k, v in out["workloads"][w].items():
             md.append("| %s | %.1f | %.1f | %s |" % (k, v["fetch_kb"], v["write_kb"], format(v["hbm_bytes"], ",")))
+    # rocprofv3's own kernel durations of the bench commands (--kernel-trace --stats): what bench.py's event-derived kernel
+    # durations must agree with; bench.py prints the dominant kernel's fraction on both
+    import csv
+    out["kernel_us"] = {}
+    for w in ("B", "C_sat", "E_sat"):
+        try:
+            rows = list(csv.DictReader(open(os.path.join(g, "%s_%s_kernel_stats.csv" % (tag, w)))))
+        except OSError:
+            continue
+        d = {}
+        for r in rows:
+            n = r["Name"].replace("void ", "").split("(")[0]
+            if n.startswith("k_"):
+                k = base(n)
+                a = d.setdefault(k, [0.0, 0])
+                a[0] += float(r["TotalDurationNs"]); a[1] += int(r["Calls"])
+        out["kernel_us"][w] = {k: round(a[0] / max(a[1], 1) / 1e3, 2) for k, a in d.items()}
     # the sources the passes ran on, and the commit that holds them
     try:
         out["csrc_sha16"] = open(os.path.join(g, tag + "_csrc_sha16.txt")).read().strip()

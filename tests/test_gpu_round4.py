@@ -545,3 +545,30 @@ def test_sharded_map_with_overfull_pyramid_lists_is_the_unsharded_map(dsp, world
     assert inexact0 > 0, (stats0, inexact0)                # the frames whose lists overflowed globally are counted
     if world >= 4:                                          # (with two slabs nearly every pyramid lies in one of them)
         assert not same0, stats0
+
+
+def test_sharded_frame_with_a_cloud_beyond_the_device_estimator(dsp):
+    """a cloud larger than the device estimator's capacity (6144 points) inside a SHARDED frame: every rank falls back to the host
+    stage on the replicated cloud (like the unsharded map does) instead of rejecting the frame, and the cluster state is handed
+    between the two implementations -- 4 slabs == the unsharded map over a stream whose third frame is padded to 7000 points"""
+    from tests.test_gpu_round2 import _cluster_scene
+    from tests.test_gpu_round3 import _group_vs_full
+    cfg = dict(nx=66, ny=66, nz=40, res=0.15, ppv=12)
+    rng = np.random.default_rng(0)
+    frames = []
+    for f in range(4):
+        t = f * 0.1
+        pts = _cluster_scene(t, f)
+        if f == 2:
+            pad = np.stack([rng.uniform(2.3, 3.4, 6400), rng.uniform(-1.6, 1.6, 6400), np.full(6400, -0.98)], 1).astype(np.float32)
+            pts = np.concatenate([pts, pad])
+            assert len(pts) > 6144
+        frames.append((pts, (0.0, 0.0, 1.0 + 0.04 * f), t, (1.0, 0.0, 0.0, 0.0)))
+    clouds, rec, holding = _group_vs_full(dsp, 4, cfg, frames)
+    for f, (a, b, c) in enumerate(clouds):
+        assert len(a) == len(b) == len(c) > 500, f
+        for k in ("x", "y", "z", "nx", "ny", "nz"):
+            assert np.array_equal(a[k], c[k]) and np.array_equal(b[k], c[k]), (f, k)
+    g = clouds[-1][2]
+    dyn = g["intensity"] > 0.01
+    assert np.isclose(g["ny"][dyn], 1.0, atol=0.02).sum() == 60      # cluster A keeps its 1 m/s through the switches
