@@ -890,8 +890,7 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
     const int l = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int cpmax = d.M;   // a voxel makes at most M copies
-    float* s_w = s_dyn + (size_t)wave * (d.slots * 64 + (64 * cpmax + 1) / 2);
-    unsigned short* s_cp = (unsigned short*)(s_w + d.slots * 64);
+    unsigned short* s_cp = (unsigned short*)(s_dyn + (size_t)wave * ((64 * cpmax + 1) / 2));
     const int wq = blockIdx.x * (blockDim.x >> 6) + wave;
     const int wave_g = rev ? ((d.v_loc + 63) >> 6) - 1 - wq : wq;   // (tiles from the last one down: see k_predict)
     const int lv = wave_g * 64 + l;
@@ -974,7 +973,6 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
                 if (!act[r]) continue;
                 const u64 bit = 1ull << B.row[r];
                 const float w = B.wr[r];
-                s_w[(e * 64 + B.row[r]) * 64 + l] = w;   // the resampling pass below reads the weights from LDS
                 if (w < 1e-3f) {                  // :941
                     m[e] &= ~bit;
                 } else {
@@ -1030,56 +1028,86 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
         if (stat_w != 0.f) s.fut_stat[lv] += stat_w;  // only this lane ever writes fut_stat[lv]
     }
     if (__ballot(inr && stat_w != 0.f) && l == 0) s.fut_dirty[wave_g] = 1;   // (k_predict zeroes the tile's accumulators on the next clear)
-    // ---- systematic resampling :986-1053 (weights from the LDS panel)
+    // ---- systematic resampling :986-1053.  The walk needs every weight a second time, in slot order: the rows are re-read (they
+    // left this CU's caches microseconds ago at worst to the Infinity Cache), wave-uniformly and a batch ahead of the walk, instead
+    // of being kept in an LDS panel of [slots][64] floats -- that panel (12 - 18 kB per one-wave workgroup) was what bounded the
+    // residency of this kernel at 10 / 6 tiles per CU; without it the registers do (16)
     int ncp = 0;
     float w_copy = 0.f;
     const bool resample = n >= 5;
-    if (resample) {
-        const int n_after = n > d.M ? d.M : n;                  // :992-997
-        const float w_after = __fdiv_rn(wsum, (float)n_after);  // :1000
+    {
+        const int n_after = n > d.M ? d.M : n;                                       // :992-997
+        const float w_after = resample ? __fdiv_rn(wsum, (float)n_after) : 0.f;      // :1000
         w_copy = w_after;
-        float acc_ori = 0.f, acc_new = w_after * 0.5f;          // :1005-1006
+        float acc_ori = 0.f, acc_new = w_after * 0.5f;                               // :1005-1006
         // survivors before ANY copy is placed: copies carry flag 0.6 and are not revisited (:1009), also those that
         // land in a later occupancy word than the one being walked
         u64 surv[MW];
 #pragma unroll
-        for (int e = 0; e < MW; ++e) surv[e] = m[e];
+        for (int e = 0; e < MW; ++e) surv[e] = resample ? m[e] : 0ull;
+        struct WBatch { int row[RBK]; float wr[RBK]; };
 #pragma unroll
         for (int e = 0; e < MW; ++e) {
-            u64 todo = surv[e];
-            while (todo) {
-                const int row = __ffsll((long long)todo) - 1;
-                todo &= todo - 1ull;
-                const u64 bit = 1ull << row;
-                acc_ori += s_w[(e * 64 + row) * 64 + l];        // :1011
-                if (acc_ori > acc_new) {
-                    float wn = w_after;                         // keep, new weight :1014
-                    acc_new += w_after;
-                    bool full = false;
-                    while (acc_ori > acc_new) {                 // copy heavy particles :1021
-                        int fslot = -1;
-                        if (!full) {
+            u64 tor = wave_or_u64(surv[e]);   // rows in which ANY voxel of the tile walks a particle (wave-uniform)
+            if (!tor) continue;
+            const brsrc rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(s.w + (size_t)wave_g * d.slots * 64), 0, d.slots * 64 * 4, 0x00020000);
+            auto issue = [&](WBatch& B) {
 #pragma unroll
-                            for (int e2 = 0; e2 < MW; ++e2) {
-                                const u64 fr = ~m[e2] & valid_bits(d, e2);
-                                if (fslot < 0 && fr) { fslot = e2 * 64 + (__ffsll((long long)fr) - 1); m[e2] |= fr & (~fr + 1ull); }
-                            }
-                        }
-                        if (fslot >= 0) {
-                            // the copy itself (5 loads + 6 stores) is deferred: only (source, destination)
-                            // is noted here so that no global access sits in this sequential loop
-                            if (ncp < cpmax) s_cp[l * cpmax + ncp] = (unsigned short)(((e * 64 + row) << 8) | fslot);
-                            ++ncp;
-                        } else {
-                            wn += w_after;                      // no free slot: fold the weight back :1037-1041
-                            full = true;
-                        }
-                        acc_new += w_after;
-                    }
-                    s.w[pidx(d, lvs, e * 64 + row)] = wn;
-                } else {
-                    m[e] &= ~bit;                               // remove :1046-1049
+                for (int r = 0; r < RBK; ++r) {
+                    B.row[r] = tor ? __ffsll((long long)tor) - 1 : -1;
+                    if (tor) tor &= tor - 1ull;
+                    B.wr[r] = bl_w(rs_w, l, (e * 64 + (B.row[r] < 0 ? 0 : B.row[r])) * 64);
                 }
+            };
+            auto consume = [&](const WBatch& B) {
+#pragma unroll
+                for (int r = 0; r < RBK; ++r) {
+                    if (B.row[r] < 0) continue;                     // (scalar)
+                    const int row = B.row[r];
+                    const u64 bit = 1ull << row;
+                    if (!(surv[e] & bit)) continue;                 // this voxel holds no survivor in the row
+                    acc_ori += B.wr[r];                             // :1011
+                    if (acc_ori > acc_new) {
+                        float wn = w_after;                         // keep, new weight :1014
+                        acc_new += w_after;
+                        bool full = false;
+                        while (acc_ori > acc_new) {                 // copy heavy particles :1021
+                            int fslot = -1;
+                            if (!full) {
+#pragma unroll
+                                for (int e2 = 0; e2 < MW; ++e2) {
+                                    const u64 fr = ~m[e2] & valid_bits(d, e2);
+                                    if (fslot < 0 && fr) { fslot = e2 * 64 + (__ffsll((long long)fr) - 1); m[e2] |= fr & (~fr + 1ull); }
+                                }
+                            }
+                            if (fslot >= 0) {
+                                // the copy itself (5 loads + 6 stores) is deferred: only (source, destination)
+                                // is noted here so that no global access sits in this sequential loop
+                                if (ncp < cpmax) s_cp[l * cpmax + ncp] = (unsigned short)(((e * 64 + row) << 8) | fslot);
+                                ++ncp;
+                            } else {
+                                wn += w_after;                      // no free slot: fold the weight back :1037-1041
+                                full = true;
+                            }
+                            acc_new += w_after;
+                        }
+                        s.w[pidx(d, lvs, e * 64 + row)] = wn;
+                    } else {
+                        m[e] &= ~bit;                               // remove :1046-1049
+                    }
+                }
+            };
+            WBatch A, B;
+            issue(A);
+            for (;;) {
+                const bool more_b = tor != 0ull;
+                if (more_b) issue(B);
+                consume(A);
+                if (!more_b) break;
+                const bool more_a = tor != 0ull;
+                if (more_a) issue(A);
+                consume(B);
+                if (!more_a) break;
             }
         }
     }
@@ -2032,7 +2060,7 @@ void kernels_init_device() {   // per device, once (dspmap_init_device)
 void launch_resample(const LaunchCtx& c) {
     const KernelScratch* k = &c.k;
     const int nw = 1;   // waves (= tiles) per workgroup; the LDS panel bounds the occupancy, small groups pack best
-    const size_t lds = (size_t)nw * (c.d.slots * 64 + (64 * c.d.M + 1) / 2) * sizeof(float);
+    const size_t lds = (size_t)nw * ((64 * c.d.M + 1) / 2) * sizeof(float);   // the copy notes; the weights are re-read (no LDS panel)
     const unsigned grid = (unsigned)((k->ntiles + nw - 1) / nw);
     // maps of the metric's size run the four-waves-per-tile variant: their frame is a chain of latencies and the longest tile is
     // the kernel; large maps keep one wave per tile (more tiles in flight per CU).  The limit is the handle's
