@@ -184,7 +184,7 @@ static void free_dev(dspmap* m) {
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, s.fov_rec, s.fov_slot, s.fov_key, s.fov_spos, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt, s.in_n, s.pmask, s.ta, s.dflag, s.dirty,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.ro_cnt, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
-                    m->k.ro_stat, m->k.part_predict, m->k.tile_fov, s.tile_live, s.fut_dirty, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf, s.birth_cvr};
+                    s.tile_moving, m->k.ro_stat, m->k.part_predict, m->k.tile_fov, s.tile_live, s.fut_dirty, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf, s.birth_cvr};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
     if (m->nbsnap_buf) chk(hipFree(m->nbsnap_buf), "hipFree");
     {
@@ -397,6 +397,8 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&k.part_predict, (size_t)k.ntiles * 4));
     HIPCHK(m, dalloc(&s.tile_live, (size_t)k.ntiles));
     HIPCHK(m, hipMemset(s.tile_live, 1, sizeof(int) * (size_t)k.ntiles));
+    HIPCHK(m, dalloc(&s.tile_moving, (size_t)k.ntiles));
+    HIPCHK(m, hipMemset(s.tile_moving, 1, sizeof(int) * (size_t)k.ntiles));
     HIPCHK(m, dalloc(&s.fut_dirty, (size_t)k.ntiles));
     HIPCHK(m, hipMemset(s.fut_dirty, 0, sizeof(int) * (size_t)k.ntiles));   // (the accumulators start zeroed)
     HIPCHK(m, dalloc(&k.tile_fov, (size_t)k.ntiles));

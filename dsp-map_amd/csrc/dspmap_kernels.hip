@@ -1327,6 +1327,7 @@ __global__ void __launch_bounds__(256) k_birth_insert(MapDims d, DevState s, Fil
                     const size_t idx = pidx(d, lv, sl);
                     st_pos(s, idx, ch.x, ch.y, ch.z);
                     st_vel(s, idx, vx, vy);
+                    if (vx != 0.f || vy != 0.f) s.tile_moving[lv >> 6] = 1;   // (a newborn of a matched cluster: the tile's velocity rows count again)
                     s.w[idx] = newborn_w;
                     atomicOr(&s.nbmask[(size_t)lv * d.mw + (sl >> 6)], 1ull << (sl & 63));  // flag 15
                     s.tile_live[lv >> 6] = 1;   // (the tile may have been empty: the sweeps must visit it again)

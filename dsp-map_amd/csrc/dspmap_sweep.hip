@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
     __shared__ u64 s_keep[MW * 64], s_ex[MW * 64];
     __shared__ int s_nmv, s_nst;
     __shared__ int s_cnt[4];
-    __shared__ int s_any, s_view;
+    __shared__ int s_any, s_view, s_mvany;
     // the first LSTG movers / stayers of the tile are noted in LDS (free: registers, not LDS, bound the
     // occupancy of this kernel), the rest in the tile's staging area in HBM
     __shared__ float4 s_mv[LSTG * 2], s_st[LSTG * 2];
@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
             if (inr) omask[(size_t)lv * MW + e] = mword[e] | nbword;   // occupancy before this prediction (k_place: arrivals from lower voxels)
         }
     }
-    if (tid == 0) { s_any = 0; s_nmv = 0; s_nst = 0; s_ncell = 0; }
+    if (tid == 0) { s_any = 0; s_nmv = 0; s_nst = 0; s_ncell = 0; s_mvany = 0; }
     if (tid < 4) s_cnt[tid] = 0;
     if (d.np <= HIST_NP) for (int b = tid; b < d.np; b += NW * 64) s_hist[b] = 0;
     // the rotated planes are requested together with the occupancy words (one round trip less for the tiles that have work)
@@ -365,6 +365,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
     __syncthreads();
     if (!s_any) {  // empty tile
         if (tid < 4) part[BX * 4 + tid] = 0;
+        if (tid == 0) s.tile_moving[BX] = 0;
         return;
     }
 #ifdef EXP_NO_DENSE
@@ -376,6 +377,14 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
     const size_t mv_base = (size_t)BX * cap;    // this tile's staging area (2 float4 per record)
     int c_live = 0, c_out = 0, c_pf = 0, c_mv = 0;   // c_live / c_out / c_mv: wave-uniform (sums of ballots), c_pf: per lane
     const bool view = s_view != 0;                    // can a particle of this tile lie in the field of view at all?
+    // every live particle of the tile has velocity (0, 0) -- k_predict's own finding of the last frame, plus whatever arrived or was
+    // born since -- : the velocity rows are not fetched (a third of what this sweep reads)
+#ifdef EXP_NO_STATIC_SKIP
+    const bool tmov = true;
+#else
+    const bool tmov = HASVZ || __builtin_amdgcn_readfirstlane(s.tile_moving[BX]) != 0;
+#endif
+    bool mv_seen = false;                             // a live particle with a velocity (this lane)
     const float zadd = dt * 0.f + odz;                // :667, the same for every particle
     // buffer descriptors of this tile's share of the three field arrays (the tile's cells are contiguous: [slot][64]): a
     // lane's byte offset is ONE register whatever the row, the row enters as a scalar offset
@@ -425,7 +434,8 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
             const int cell = act ? (int)s_cells[c] : l;   // (a valid cell of the tile for the idle lanes too)
             const int slot = cell >> 6, ln = cell & 63;
             const int coff = slot * 64 + ln;              // the cell inside the tile
-            V2 v2 = bl_vel(rs_vel, coff, 0);
+            V2 v2; v2.x = 0.f; v2.y = 0.f;
+            if (tmov) v2 = bl_vel(rs_vel, coff, 0);
             const P3 p3 = bl_pos(rs_pos, coff, 0);
             const float w = bl_w(rs_w, coff, 0);
             float px = p3.x, py = p3.y, pz = p3.z;
@@ -434,6 +444,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
                 if (act && (v2.x != 0.f || v2.y != 0.f)) st_vel(s, tcell + coff, 0.f, 0.f);
                 v2.x = 0.f; v2.y = 0.f;
             }
+            mv_seen |= act && (v2.x != 0.f || v2.y != 0.f);
             if (act) {
                 kind = view ? advance_one<true>(d, s_ph, s_pv, dt, odx, ody, zadd, v2.x, v2.y, px, py, pz, BX * 64 + ln, pyr, gv)
                             : advance_one<false>(d, s_ph, s_pv, dt, odx, ody, zadd, v2.x, v2.y, px, py, pz, BX * 64 + ln, pyr, gv);
@@ -466,7 +477,8 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
                 // unconditional loads (always a valid cell of this lane's voxel; dead cells share the row's cache lines): a
                 // predicated vector load makes the compiler wait for it before issuing the next row
                 const int srow = (e * 64 + (row[r] < 0 ? 0 : row[r])) * 64;   // cells before this row inside the tile (wave-uniform)
-                vv[r] = bl_vel(rs_vel, l, srow);
+                vv[r].x = 0.f; vv[r].y = 0.f;
+                if (tmov) vv[r] = bl_vel(rs_vel, l, srow);   // (wave-uniform: no predicated load)
                 pp[r] = bl_pos(rs_pos, l, srow);
                 w[r] = bl_w(rs_w, l, srow);
             }
@@ -485,6 +497,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
                 if (HASVZ) {
                     if (act) { float vxy[2] = {vx, vy}; vz_noise(d, s, fp, vz_pre, vz_q, MW, lvs, e, rw, tcell + srow + l, vxy); vx = vxy[0]; vy = vxy[1]; }
                 }
+                mv_seen |= act && (vx != 0.f || vy != 0.f);
                 int pyr = -1, gv = -1;
                 int kind = view ? advance_one<true>(d, s_ph, s_pv, dt, odx, ody, zadd, vx, vy, px, py, pz, lv, pyr, gv)
                                 : advance_one<false>(d, s_ph, s_pv, dt, odx, ody, zadd, vx, vy, px, py, pz, lv, pyr, gv);
@@ -510,6 +523,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
         if (ex) atomicOr(&s_ex[e * 64 + l], ex);
     }
     }
+    if (__ballot(mv_seen) && l == 0) s_mvany = 1;
     // workgroup-scope ordering is enough for the read-back below: the waves of a workgroup share the
     // CU's write-through L1 (an agent-scope fence would write back the XCD's whole L2)
     __syncthreads();
@@ -622,6 +636,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
         }
     }
     if (tid < 4) part[BX * 4 + tid] = s_cnt[tid];
+    if (tid == 0 && tmov) s.tile_moving[BX] = s_mvany;   // (a tile that was static stays so until somebody brings a velocity)
 }
 
 // --------------------------------------------------------------------------
@@ -782,6 +797,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
                 nidx = pidx(d, BX * 64 + ln, nsl);
                 st_pos(s, nidx, px, py, pz);
                 st_vel(s, nidx, avx, avy);
+                if (avx != 0.f || avy != 0.f) s.tile_moving[BX] = 1;   // (k_predict wrote the tile's flag before any arrival)
                 s.w[nidx] = w;
                 key[0] = pyramid_of(d, s_ph, s_pv, px, py, pz);
             } else {
@@ -894,7 +910,13 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
     const int wq = blockIdx.x * (blockDim.x >> 6) + wave;
     const int wave_g = rev ? ((d.v_loc + 63) >> 6) - 1 - wq : wq;   // (tiles from the last one down: see k_predict)
     const int lv = wave_g * 64 + l;
-    if (wave_g < 0 || wave_g * 64 >= d.v_loc || !sload_i(s.tile_live + wave_g)) return;   // empty since its last visit: result, buckets and lists are already zero (one scalar round trip)
+    if (wave_g < 0 || wave_g * 64 >= d.v_loc) return;
+    int t_live, t_mov, t_unused;
+    sload_i3(s.tile_live + wave_g, s.tile_moving + wave_g, s.tile_live + wave_g, t_live, t_mov, t_unused);   // (one scalar round trip)
+    if (!t_live) return;   // empty since its last visit: result, buckets and lists are already zero
+#ifdef EXP_NO_STATIC_SKIP
+    t_mov = 1;
+#endif
     const bool inr = lv < d.v_loc;
     const int lvs = inr ? lv : 0;
     u64 m[MW], nb[MW];
@@ -936,7 +958,8 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
                 // unconditional loads, see k_predict (the row enters as a wave-uniform scalar offset)
                 const int srow = (e * 64 + (B.row[r] < 0 ? 0 : B.row[r])) * 64;
                 B.wr[r] = bl_w(rs_w, l, srow);
-                B.vv[r] = bl_vel(rs_vel, l, srow);
+                B.vv[r].x = 0.f; B.vv[r].y = 0.f;
+                if (t_mov) B.vv[r] = bl_vel(rs_vel, l, srow);   // (a tile of static particles: its velocity rows are not fetched)
             }
         };
         auto consume = [&](const RowBatch& B) {
@@ -2105,6 +2128,7 @@ void launch_resample(const LaunchCtx& c) {
 __global__ void k_set_live_sample(DevState s, int v) { s.fs->live_acc = v; }
 static void mark_all_live(const LaunchCtx& c) {   // particles were written outside a frame: every tile may hold some
     (void)hipMemsetAsync(c.s.tile_live, 1, sizeof(int) * (size_t)c.k.ntiles, c.stream);
+    (void)hipMemsetAsync(c.s.tile_moving, 1, sizeof(int) * (size_t)c.k.ntiles, c.stream);   // (nothing known about the velocities)
     // ... and the next frame's estimate of the non-empty tiles (FrameScalars::live_hint) says so too
     hipLaunchKernelGGL(k_set_live_sample, dim3(1), dim3(1), 0, c.stream, c.s, (c.k.ntiles + 63) / 64);
 }

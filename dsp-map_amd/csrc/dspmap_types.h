@@ -204,6 +204,11 @@ struct DevState {
     long long* pyr_gcnt; // [np] or nullptr: this rank's list lengths before the cut, summed over the ranks by the Ck all-reduce they ride on
     int* in_n;          // [2 * tiles] {arrivals the last placement served in the tile, FrameScalars::pred_epoch of that placement}
     int* fut_dirty;     // [tiles] 1 = something was added to the tile's future accumulators (fut, fut_stat) since they were zeroed
+    int* tile_moving;   // [tiles] 0 = every LIVE particle of the tile has velocity (0, 0): rewritten by k_predict for every tile it visits (it reads
+                        // the velocities anyway), set by whoever puts a moving particle there afterwards (k_place: arrivals, k_birth_insert:
+                        // newborns of matched clusters; 1 everywhere after particles were written outside a frame).  The sweeps of such a tile
+                        // do not fetch its velocity rows (8 of the 24 / 12 bytes k_predict / k_resample read per cell): a map is mostly
+                        // static particles -- that is what the reference's static / dynamic split is about.  Conservative: 1 promises nothing.
     int* tile_live;     // [tiles] 0 = the 64-voxel tile holds no particle (k_resample found it empty and nothing was placed, born or
                         // imported there since): the sweeps skip it without reading its occupancy words.  Conservative: nonzero
                         // does not promise a particle.
