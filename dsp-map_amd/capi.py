@@ -98,6 +98,7 @@ SIGNATURES = {
     "dspmap_debug_sweep_probe": (_i, [_P, _i, _i, _i, _i, _fp, C.POINTER(C.c_longlong)]),
     "dspmap_debug_tile_view": (_i, [_P, C.POINTER(C.c_int), _i]),
     "dspmap_debug_rollout_paths": (_i, [_P, C.POINTER(C.c_longlong)]),
+    "dspmap_debug_tile_moving": (_i, [_P, C.POINTER(C.c_int), _i]),
     "dspmap_debug_rdzv_publish": (_i, [C.c_char_p, C.c_char_p]),
     "dspmap_debug_rdzv_wait": (_i, [C.c_char_p, _i, C.c_char_p]),
     "dspmap_clear_state": (_i, [_P]),
@@ -254,6 +255,16 @@ class DSPMap:
         out = (C.c_longlong * 3)()
         self._chk(self.L.dspmap_debug_rollout_paths(self.h, out))
         return int(out[0]), int(out[1]), int(out[2])
+
+    def tile_moving(self):
+        """per 64-voxel tile: 0 = all of its live particles are static (its velocity rows are not fetched by the sweeps)"""
+        import numpy as np
+        n = (self.V + 63) // 64
+        out = np.zeros(n, np.int32)
+        r = self.L.dspmap_debug_tile_moving(self.h, out.ctypes.data_as(C.POINTER(C.c_int)), n)
+        if r < 0:
+            self._chk(r)
+        return out[:r]
 
     # -- reference setters (dsp_dynamic.h:355-382)
     def setPredictionVariance(self, p_stddev, v_stddev):

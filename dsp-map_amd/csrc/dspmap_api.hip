@@ -1491,6 +1491,13 @@ extern "C" int dspmap_debug_tile_view(dspmap_t* m, int* out, int cap) {
     for (int i = 0; i < m->k.ntiles; ++i) out[i] = (out[i] >> 1) == m->hp.epoch ? (out[i] & 1) : -1;   // -1: not visited by the last k_predict (empty)
     return m->k.ntiles;
 }
+extern "C" int dspmap_debug_tile_moving(dspmap_t* m, int* out, int cap) {
+    READY(m);
+    if (!out || cap < m->k.ntiles) return DSPMAP_E_ARG;
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    HIPCHK(m, hipMemcpy(out, m->s.tile_moving, sizeof(int) * m->k.ntiles, hipMemcpyDeviceToHost));
+    return m->k.ntiles;
+}
 extern "C" int dspmap_debug_rollout_paths(dspmap_t* m, long long out[3]) {
     READY(m);
     if (!out) return DSPMAP_E_ARG;

@@ -246,6 +246,10 @@ int dspmap_debug_sweep_probe(dspmap_t* m, int what, int rows, int rows_per_batch
 /* diagnostics: out[t] = 1 if a particle inside 64-voxel tile t could lie in the field of view of the last frame
  * (the conservative box test behind DSPMAP_P_PLACE_SPLIT_TILES); returns the number of tiles or an error */
 int dspmap_debug_tile_view(dspmap_t* m, int* out, int cap);
+/* diagnostics: out[t] = the "somebody moves" flag of 64-voxel tile t: 0 = every live particle of the tile had velocity (0, 0)
+ * when k_predict last swept it and nothing with a velocity has arrived or been born there since -- the sweeps of such a tile do
+ * not fetch its velocity rows (k_predict).  Returns the number of tiles or an error */
+int dspmap_debug_tile_moving(dspmap_t* m, int* out, int cap);
 /* diagnostics: which kernels the last resampling stage ran and which path the future-status contributions took:
  * out[0] = bit 0: four-waves-per-tile resampler; bits 1-2: rollout 0 inside the resampler, 1 k_rollout without LDS windows,
  * 2 k_rollout with LDS windows, 3 none; out[1] / out[2] = contributions k_rollout sent through its windows / as single atomics */

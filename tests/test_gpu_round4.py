@@ -622,3 +622,69 @@ def test_full_size_config_e_stages_against_oracle(dsp, orc):
     vo, so, ro, rg = _slot_exact(o, m, cols=(1, 2, 4, 5, 6))
     assert np.allclose(ro[:, 7], rg[:, 7], rtol=1e-6)
     o.close(); m.close()
+
+
+def test_static_tiles_skip_their_velocity_rows_until_a_mover_arrives_or_is_born(dsp, orc):
+    """k_predict notes per tile whether any live particle has a velocity; a tile of static particles is swept without its
+    velocity rows (k_predict, k_resample).  The flag must come back the moment a mover ARRIVES (k_place) or is BORN
+    (k_birth_insert) there.  A map full of static particles, a blob of fast movers that crosses it tile by tile, six stage-level
+    frames against the oracle (every float of every slot after each prediction and each resampling); then whole frames with a
+    matched moving cluster (dynamic newborns into static tiles), compared like the fused-birth test."""
+    cfgkw = dict(nx=66, ny=66, nz=40, res=0.15, ppv=24)
+    o, m = make_pair(dsp, orc, seed=8, **cfgkw)
+    half = common.half_extent(o.cfg)
+    px, py, pz, vx, vy, w = common.random_particles(5, 150000, half, vmax=0.0, wlo=0.01, whi=0.08)
+    bx, by, bz, bvx, bvy, bw = common.random_particles(6, 6000, (0.5, 0.5, 0.8), vmax=0.0, wlo=0.01, whi=0.08)
+    bx -= 3.5; by += 2.0
+    bvx[:] = 3.1; bvy[:] = -1.7
+    cat = np.concatenate
+    n = common.inject_both(o, m, cat([px, bx]), cat([py, by]), cat([pz, bz]), cat([vx, bvx]), cat([vy, bvy]), cat([w, bw]))
+    assert m.tile_moving().all()                                  # (an imported state: nothing is known yet)
+    empty = np.zeros((0, 3), np.float32)
+    o.bin_points(empty); m.bin_points(empty)
+    seen_moving = np.zeros(len(m.tile_moving()), bool)
+    for f in range(6):
+        o.predict(0.0, 0.0, 0.0, 0.1); m.predict(0.0, 0.0, 0.0, 0.1)
+        vo, so, ro, rg = _slot_exact(o, m)
+        mv = m.tile_moving() != 0
+        # the flag is exactly "holds a particle with a velocity" wherever it is 0, and set wherever a mover sits
+        has_mover = np.zeros(len(mv), bool)
+        has_mover[np.unique(vo[(ro[:, 1] != 0) | (ro[:, 2] != 0)] >> 6)] = True
+        assert not (has_mover & ~mv).any(), f
+        assert (~mv).mean() > 0.8, (f, mv.mean())
+        seen_moving |= has_mover
+        o.occupancy_resample(); m.occupancy_resample()
+        _slot_exact(o, m, cols=(1, 2, 4, 5, 6))
+        assert np.array_equal(m.results()[:, 1:3], o.results[:, 1:3])      # mean velocities: the movers' voxels included
+        o.L.dspo_clear_future(o.h); m.clearOccupancyMapPrediction()
+    assert seen_moving.sum() > 3 * has_mover.sum() / 2                     # the blob visited tiles that had been static
+    # whole frames: dynamic newborns (a matched moving cluster) into tiles that are static by now
+    from tests.test_gpu_round2 import _cluster_scene
+    o.L.dspo_use_velocity_estimator(o.h, 1)
+    m.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, 2)
+    pos = (0.0, 0.0, 1.0)
+    for f in range(3):
+        t = 1.0 + f * 0.1
+        pts = _cluster_scene(t, f)
+        assert o.update(pts, pos, t, (1, 0, 0, 0)) == 1
+        assert m.update(pts, pos, t, (1, 0, 0, 0)) == 1
+        o.get_occupancy_with_future(0.2); m.getOccupancyMapWithFutureStatus(0.2)
+    vo, so, ro = o.export_sparse()
+    vg, sg, rg = gpu_state(m)
+    ko, kg = np.lexsort((so, vo)), np.lexsort((sg, vg))
+    co, cg = np.bincount(vo, minlength=o.V), np.bincount(vg, minlength=o.V)
+    assert (co == cg).mean() > 0.999 and abs(len(vo) - len(vg)) < 1e-3 * len(vo)
+    same = (co == cg)
+    mo, mg = same[vo[ko]], same[vg[kg]]
+    a = set(zip(vo[ko][mo].tolist(), so[ko][mo].tolist())); b = set(zip(vg[kg][mg].tolist(), sg[kg][mg].tolist()))
+    assert len(a ^ b) < 1e-3 * len(a), len(a ^ b)
+    if not (a ^ b):
+        newborn_movers = (np.abs(rg[kg][mg][:, 1]) + np.abs(rg[kg][mg][:, 2]) > 0.3) & (rg[kg][mg][:, 1] != np.float32(3.1))
+        assert newborn_movers.sum() > 100
+        frac = (ro[ko][mo][:, 1:7] == rg[kg][mg][:, 1:7]).all(axis=1).mean()
+        assert frac > 0.999, frac
+    mv = m.tile_moving() != 0
+    has_mover = np.zeros(len(mv), bool)
+    has_mover[np.unique(vg[(rg[:, 1] != 0) | (rg[:, 2] != 0)] >> 6)] = True
+    assert not (has_mover & ~mv).any()
+    o.close(); m.close()
