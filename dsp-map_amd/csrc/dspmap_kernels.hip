@@ -697,8 +697,18 @@ __global__ void __launch_bounds__(CK_TPB) k_ck_partial(MapDims d, DevState s, Fi
             float lo = tid < npart ? len : 3.0e38f, hi = tid < npart ? len : -3.0e38f;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, WAVE)); hi = fmaxf(hi, __shfl_xor(hi, o, WAVE)); }
-            if (tid == 0) { s_rng[0] = lo - fp.cull_r; s_rng[1] = hi + fp.cull_r; s_n = 0; }
             r.w = fp.p_det * r.w;  // P_detection * weight (pre-update weights), :732
+            // The radius beyond which this chunk's terms are EXACTLY zero: a term is snapped to the 2^-34 grid before it is added
+            // (ck_snap), so c3 * w * exp2(-K s) < 2^-35 adds nothing; ranges R apart mean a distance >= R, i.e.
+            // s >= (1000 R / sigma - sqrt(3))^2 for the truncated table indices (u in (1000 z - 1, 1000 z]).  With the chunk's
+            // largest weight: s > (log2(c3 w) + 35) / K  <=>  R > sigma * (sqrt(.) / 1000 + 0.0018); 0.01 sigma of margin covers
+            // the roundings of the two ranges.  Never wider than the handle's cull radius (which also bounds the +-9.9 clamp).
+            float wm = tid < npart ? r.w : 0.f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o, WAVE));
+            const float need = (__log2f(fp.pdf_c3 * wm) + 35.f) * (1.f / 7.213475204444817e-07f);
+            const float rad = fminf(fp.cull_r, fp.sigma_ob * (sqrtf(fmaxf(need, 0.f)) * 0.001f + 0.01f));
+            if (tid == 0) { s_rng[0] = lo - rad; s_rng[1] = hi + rad; s_n = 0; }
             s_p[tid] = r;
         }
         __syncthreads();

@@ -365,8 +365,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
     __syncthreads();
     if (!s_any) {  // empty tile
         if (tid < 4) part[BX * 4 + tid] = 0;
-        if (tid == 0) s.tile_moving[BX] = 0;
-        return;
+        return;   // (tile_moving keeps its value: 0 promises zeroed velocity cells, which only a sweep that read the rows can give)
     }
 #ifdef EXP_NO_DENSE
     const bool dense = false;
@@ -379,10 +378,11 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
     const bool view = s_view != 0;                    // can a particle of this tile lie in the field of view at all?
     // every live particle of the tile has velocity (0, 0) -- k_predict's own finding of the last frame, plus whatever arrived or was
     // born since -- : the velocity rows are not fetched (a third of what this sweep reads)
+    const int tflag = __builtin_amdgcn_readfirstlane(s.tile_moving[BX]);
 #ifdef EXP_NO_STATIC_SKIP
     const bool tmov = true;
 #else
-    const bool tmov = HASVZ || __builtin_amdgcn_readfirstlane(s.tile_moving[BX]) != 0;
+    const bool tmov = HASVZ || tflag != 0;
 #endif
     bool mv_seen = false;                             // a live particle with a velocity (this lane)
     const float zadd = dt * 0.f + odz;                // :667, the same for every particle
@@ -636,7 +636,16 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
         }
     }
     if (tid < 4) part[BX * 4 + tid] = s_cnt[tid];
-    if (tid == 0 && tmov) s.tile_moving[BX] = s_mvany;   // (a tile that was static stays so until somebody brings a velocity)
+    // (a tile that was static stays so until somebody brings a velocity.)  A tile that BECOMES static has its velocity cells zeroed,
+    // all of them: the flag promises that every cell of the tile -- live, dead, rows this sweep never loaded -- holds (0, 0), so
+    // that whoever puts a static particle there (k_place: two scattered stores per arrival instead of three) need not write one.
+    if (tmov && tflag != 0) {
+        if (!s_mvany) {
+            float4* const vz4 = reinterpret_cast<float4*>(s.vel + 2 * tcell);
+            for (int i = tid; i < tcells / 2; i += NW * 64) vz4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid == 0) s.tile_moving[BX] = s_mvany;
+    }
 }
 
 // --------------------------------------------------------------------------
@@ -672,6 +681,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
     __shared__ int s_cnt[2];
     const int tid = threadIdx.x;
     const bool was_live = s.tile_live[BX] != 0;   // an empty tile was skipped by k_predict: its omask words are stale (and zero in truth)
+    const bool t_moving = s.tile_moving[BX] != 0;   // as k_predict left it (this workgroup is the only one that raises it during the placement)
     const int cap = 64 * d.slots;
     const int n = min(n_all, cap);
     const bool in_lds = n <= PLACE_MAX;
@@ -796,8 +806,9 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
             if (nsl >= 0) {
                 nidx = pidx(d, BX * 64 + ln, nsl);
                 st_pos(s, nidx, px, py, pz);
-                st_vel(s, nidx, avx, avy);
-                if (avx != 0.f || avy != 0.f) s.tile_moving[BX] = 1;   // (k_predict wrote the tile's flag before any arrival)
+                // a static arrival in a tile of static particles finds (0, 0) in its cell already (tile_moving = 0 promises it)
+                if (avx != 0.f || avy != 0.f) { st_vel(s, nidx, avx, avy); s.tile_moving[BX] = 1; }   // (k_predict wrote the tile's flag before any arrival)
+                else if (t_moving) st_vel(s, nidx, 0.f, 0.f);
                 s.w[nidx] = w;
                 key[0] = pyramid_of(d, s_ph, s_pv, px, py, pz);
             } else {
@@ -1149,7 +1160,8 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
                 const size_t sidx = pidx(d, lvs, (int)(pr >> 8));
                 didx[j] = (unsigned)pidx(d, lvs, (int)(pr & 0xff));
                 cp[j] = ld_pos(s, sidx);
-                cv[j] = ld_vel(s, sidx);
+                cv[j].x = 0.f; cv[j].y = 0.f;
+                if (t_mov) cv[j] = ld_vel(s, sidx);   // (static tile: every velocity cell is (0, 0) already)
                 cvz[j] = s.vz0 ? s.vz0[sidx] : 0.f;
             }
         }
@@ -1157,7 +1169,7 @@ __global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __
         for (int j = 0; j < CPB; ++j) {
             if (k0 + j < ncp) {
                 st_pos(s, didx[j], cp[j].x, cp[j].y, cp[j].z);
-                st_vel(s, didx[j], cv[j].x, cv[j].y);
+                if (t_mov) st_vel(s, didx[j], cv[j].x, cv[j].y);
                 if (s.vz0) s.vz0[didx[j]] = cvz[j];
                 s.w[didx[j]] = w_copy;
             }

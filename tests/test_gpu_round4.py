@@ -626,26 +626,36 @@ def test_full_size_config_e_stages_against_oracle(dsp, orc):
 
 def test_static_tiles_skip_their_velocity_rows_until_a_mover_arrives_or_is_born(dsp, orc):
     """k_predict notes per tile whether any live particle has a velocity; a tile of static particles is swept without its
-    velocity rows (k_predict, k_resample).  The flag must come back the moment a mover ARRIVES (k_place) or is BORN
-    (k_birth_insert) there.  A map full of static particles, a blob of fast movers that crosses it tile by tile, six stage-level
-    frames against the oracle (every float of every slot after each prediction and each resampling); then whole frames with a
-    matched moving cluster (dynamic newborns into static tiles), compared like the fused-birth test."""
+    velocity rows (k_predict, k_resample), and a tile that BECOMES static has all its velocity cells zeroed, so that a static
+    arrival there is placed with two stores instead of three (k_place writes no velocity).  The flag must come back the moment
+    a mover ARRIVES (k_place) or is BORN (k_birth_insert) there.  A map full of static particles under ego-motion (static
+    particles change voxels and tiles every frame), TWO blobs of fast movers that cross it on the same track a few frames apart
+    (the second one makes the sweeps read the velocity cells the first one left behind and static arrivals took over), ten
+    stage-level frames against the oracle (every float of every slot after each prediction and each resampling); then whole
+    frames with a matched moving cluster (dynamic newborns into static tiles): no tile that holds a particle with a velocity may
+    carry a zero flag afterwards (a build whose k_birth_insert does not raise it fails here; one whose k_place does not, or whose
+    k_predict does not zero the cells of a tile that becomes static, fails in the stage-level part)."""
     cfgkw = dict(nx=66, ny=66, nz=40, res=0.15, ppv=24)
     o, m = make_pair(dsp, orc, seed=8, **cfgkw)
     half = common.half_extent(o.cfg)
     px, py, pz, vx, vy, w = common.random_particles(5, 150000, half, vmax=0.0, wlo=0.01, whi=0.08)
-    bx, by, bz, bvx, bvy, bw = common.random_particles(6, 6000, (0.5, 0.5, 0.8), vmax=0.0, wlo=0.01, whi=0.08)
-    bx -= 3.5; by += 2.0
-    bvx[:] = 3.1; bvy[:] = -1.7
+    bx, by, bz, bvx, bvy, bw = common.random_particles(6, 6000, (0.3, 0.5, 0.8), vmax=0.0, wlo=0.01, whi=0.08)
+    cx, cy, cz, cvx, cvy, cw = common.random_particles(7, 3000, (0.15, 0.5, 0.8), vmax=0.0, wlo=0.01, whi=0.08)
+    bx -= 2.9; by += 2.0; cx -= 4.65; cy += 2.0        # the second blob follows 1.3 m (four frames) behind the first
+    bvx[:] = 3.1; bvy[:] = -1.7; cvx[:] = 3.1; cvy[:] = -1.7
     cat = np.concatenate
-    n = common.inject_both(o, m, cat([px, bx]), cat([py, by]), cat([pz, bz]), cat([vx, bvx]), cat([vy, bvy]), cat([w, bw]))
+    n = common.inject_both(o, m, cat([px, bx, cx]), cat([py, by, cy]), cat([pz, bz, cz]), cat([vx, bvx, cvx]),
+                           cat([vy, bvy, cvy]), cat([w, bw, cw]))
     assert m.tile_moving().all()                                  # (an imported state: nothing is known yet)
     empty = np.zeros((0, 3), np.float32)
     o.bin_points(empty); m.bin_points(empty)
     seen_moving = np.zeros(len(m.tile_moving()), bool)
-    for f in range(6):
-        o.predict(0.0, 0.0, 0.0, 0.1); m.predict(0.0, 0.0, 0.0, 0.1)
+    n_static_movers = 0
+    for f in range(10):
+        ego = (-0.05, 0.03, 0.02, 0.1)
+        o.predict(*ego); m.predict(*ego)
         vo, so, ro, rg = _slot_exact(o, m)
+        n_static_movers += m.counters()["n_moved"]
         mv = m.tile_moving() != 0
         # the flag is exactly "holds a particle with a velocity" wherever it is 0, and set wherever a mover sits
         has_mover = np.zeros(len(mv), bool)
@@ -657,7 +667,8 @@ def test_static_tiles_skip_their_velocity_rows_until_a_mover_arrives_or_is_born(
         _slot_exact(o, m, cols=(1, 2, 4, 5, 6))
         assert np.array_equal(m.results()[:, 1:3], o.results[:, 1:3])      # mean velocities: the movers' voxels included
         o.L.dspo_clear_future(o.h); m.clearOccupancyMapPrediction()
-    assert seen_moving.sum() > 3 * has_mover.sum() / 2                     # the blob visited tiles that had been static
+    assert seen_moving.sum() > 3 * has_mover.sum() / 2                     # the blobs visited tiles that had been static
+    assert n_static_movers > 300000                                        # ... and static particles changed voxels all along
     # whole frames: dynamic newborns (a matched moving cluster) into tiles that are static by now
     from tests.test_gpu_round2 import _cluster_scene
     o.L.dspo_use_velocity_estimator(o.h, 1)
@@ -676,13 +687,19 @@ def test_static_tiles_skip_their_velocity_rows_until_a_mover_arrives_or_is_born(
     assert (co == cg).mean() > 0.999 and abs(len(vo) - len(vg)) < 1e-3 * len(vo)
     same = (co == cg)
     mo, mg = same[vo[ko]], same[vg[kg]]
-    a = set(zip(vo[ko][mo].tolist(), so[ko][mo].tolist())); b = set(zip(vg[kg][mg].tolist(), sg[kg][mg].tolist()))
-    assert len(a ^ b) < 1e-3 * len(a), len(a ^ b)
-    if not (a ^ b):
-        newborn_movers = (np.abs(rg[kg][mg][:, 1]) + np.abs(rg[kg][mg][:, 2]) > 0.3) & (rg[kg][mg][:, 1] != np.float32(3.1))
-        assert newborn_movers.sum() > 100
-        frac = (ro[ko][mo][:, 1:7] == rg[kg][mg][:, 1:7]).all(axis=1).mean()
-        assert frac > 0.999, frac
+    # (three resampled frames: equal-weight ties pick another survivor in a few voxels -- DESIGN: threshold ties; the cells both
+    # sides occupy must hold the same particle, velocity included)
+    key_o = vo[ko][mo].astype(np.int64) * 256 + so[ko][mo]; key_g = vg[kg][mg].astype(np.int64) * 256 + sg[kg][mg]
+    both, io, ig = np.intersect1d(key_o, key_g, return_indices=True)
+    assert len(both) > 0.995 * len(key_o), (len(both), len(key_o))
+    rbo, rbg = ro[ko][mo][io], rg[kg][mg][ig]
+    newborn_movers = (np.abs(rbg[:, 1]) + np.abs(rbg[:, 2]) > 0.3) & (rbg[:, 1] != np.float32(3.1))
+    assert newborn_movers.sum() > 100
+    # (the stream cursors may differ by a few draws by now -- a source point's static / dynamic split follows the voxel's mass, which
+    # carries Ck's 1e-6 -- and every later newborn of that frame then draws other table entries: the bulk must agree, and what this
+    # test is about is the flag below)
+    frac = (rbo[:, 1:7] == rbg[:, 1:7]).all(axis=1).mean()
+    assert frac > 0.99, frac
     mv = m.tile_moving() != 0
     has_mover = np.zeros(len(mv), bool)
     has_mover[np.unique(vg[(rg[:, 1] != 0) | (rg[:, 2] != 0)] >> 6)] = True
