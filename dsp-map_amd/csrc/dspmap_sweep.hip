@@ -910,8 +910,11 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
 //   * all per-voxel sums run sequentially per lane in slot order = the reference's operation order.
 // dynamic LDS per wave: [slots][64] fp32 weights + [64][M] u16 (source slot, destination slot) of deferred copies
 // --------------------------------------------------------------------------
+#ifndef RS_LB
+#define RS_LB 3
+#endif
 template <int MW>
-__global__ void __launch_bounds__(256) k_resample(MapDims d, DevState s, int* __restrict__ part_live, int* __restrict__ vb_cnt,
+__global__ void __launch_bounds__(256, RS_LB) k_resample(MapDims d, DevState s, int* __restrict__ part_live, int* __restrict__ vb_cnt,
                                                   float4* __restrict__ ro_rec, int* __restrict__ ro_cnt, int rev) {
     extern __shared__ float s_dyn[];
     const int l = lane_id();
