@@ -118,8 +118,9 @@ enum dspmap_param {
     DSPMAP_P_UPDATE_COUNTER = 15,   /* read-only: update_counter, the number of predictions run (:635) */
     DSPMAP_P_PLACE_SPLIT_TILES = 16,/* maps with at least this many 64-voxel tiles (default 8192) give the voxel-changing particles of the tiles
                                        that cannot see the sensor's field of view their slots on a side stream, beside the weight update
-                                       (same result; a scheduling knob: 1 = always, a huge value = never; the environment variable
-                                       DSPMAP_PLACE_SPLIT_TILES presets it at dspmap_create) */
+                                       (same result; a scheduling knob: 1 = always, a huge value = never; not while the handle sweeps the map
+                                       as a sparse one -- most tiles empty, DSPMAP_P_SPARSE_SWEEP -- unless the value is 1; the environment
+                                       variable DSPMAP_PLACE_SPLIT_TILES presets it at dspmap_create) */
     DSPMAP_P_FAST_DIVISION = 17,    /* read: 1 if (p + half) / VOXEL_RESOLUTION (:1062-1088) is computed as reciprocal + two FMAs -- only after a
                                        kernel has compared that quotient with the IEEE division, bit for bit, for this resolution
                                        (device initialisation); write 0: force the IEEE division (same results by construction) */
