@@ -875,6 +875,16 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
         birth_child_thread(d, s, fp, child, vb_cnt, vb_idx, (int)(blockIdx.x * 256 + threadIdx.x));
         return;
     }
+    {   // A workgroup whose ONLY tile received nothing leaves here, before the loop below is set up: the loop's invariants (hoisted in
+        // front of it by the compiler, ~100 vector instructions with the scalar registers it parks in lanes) were what a sparse map's
+        // placement spent its time on -- 87 120 workgroups, 12 k with arrivals: 0.76 of the chip's VALU issue slots, 77 us
+        const int bq = (int)blockIdx.x - nchild, stride = (int)gridDim.x - nchild;
+        if (bq < n0 + n1 && bq + stride >= n0 + n1) {
+            const int bqr = rev ? n0 + n1 - 1 - bq : bq;
+            const int BX = bqr < n0 ? t0 + bqr : t1 + (bqr - n0);
+            if (!(has_vz && BX == 0) && sload_i(in_cnt + BX) == 0) return;
+        }
+    }
     for (int bq = (int)blockIdx.x - nchild; bq < n0 + n1; bq += (int)gridDim.x - nchild) {
         const int bqr = rev ? n0 + n1 - 1 - bq : bq;           // (the launch's tiles from the last one down: see k_predict)
         const int BX = bqr < n0 ? t0 + bqr : t1 + (bqr - n0);   // tile index
