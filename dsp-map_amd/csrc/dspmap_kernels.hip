@@ -873,8 +873,8 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
             lo = fminf(fminf(s_mm[0], s_mm[2]), fminf(s_mm[4], s_mm[6])) - fp.cull_r;
             hi = fmaxf(fmaxf(s_mm[1], s_mm[3]), fmaxf(s_mm[5], s_mm[7])) + fp.cull_r;
             const int wave = tid >> 6, l = tid & 63;
-            u64 cmask = 0ull;   // lanes of my residue class (WU_TPB and 64 are multiples of spl: class of o == class of the lane)
-            for (int q = sub; q < 64; q += spl) cmask |= 1ull << q;
+            // lanes of my residue class (WU_TPB and 64 are multiples of spl: class of o == class of the lane); spl is 1, 2, 4 or 8
+            const u64 cmask = (spl == 1 ? ~0ull : spl == 2 ? 0x5555555555555555ull : spl == 4 ? 0x1111111111111111ull : 0x0101010101010101ull) << sub;
             int run = 0, round = 0;
             for (int base = 0; base < O; base += WU_TPB, ++round) {
                 const int o = base + tid;

@@ -905,9 +905,9 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
 }
 
 #define RO_INLINE_MAX 384   // moving particles of a tile beyond which the tile counts as "heavy" for the choice inline rollout / k_rollout
-#ifndef RBK
-#define RBK 8   // rows per batch of the loads in k_resample (two batches in flight)
-#endif
+// rows per batch of the loads in k_resample (two batches in flight) = its template parameter RBK_: 8 on sparse maps (the launch is as long as
+// its fullest tiles: fewer round trips per tile), 4 on dense ones (81 / 91 registers instead of 146 / 156: five waves per SIMD instead of
+// three -- 264x264x80 saturated 0.713 -> 0.623 ms, 132x132x60 0.104 -> 0.100; the realistic fills lose 4 % with 4 and 30 - 45 % with 12 / 16)
 #define CPB 8   // deferred copies per step
 
 // --------------------------------------------------------------------------
@@ -920,11 +920,8 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
 //   * all per-voxel sums run sequentially per lane in slot order = the reference's operation order.
 // dynamic LDS per wave: [slots][64] fp32 weights + [64][M] u16 (source slot, destination slot) of deferred copies
 // --------------------------------------------------------------------------
-#ifndef RS_LB
-#define RS_LB 3
-#endif
-template <int MW>
-__global__ void __launch_bounds__(256, RS_LB) k_resample(MapDims d, DevState s, int* __restrict__ part_live, int* __restrict__ vb_cnt,
+template <int MW, int RBK_>
+__global__ void __launch_bounds__(256, RBK_ >= 8 ? 3 : 5) k_resample(MapDims d, DevState s, int* __restrict__ part_live, int* __restrict__ vb_cnt,
                                                   float4* __restrict__ ro_rec, int* __restrict__ ro_cnt, int rev) {
     extern __shared__ float s_dyn[];
     const int l = lane_id();
@@ -966,9 +963,9 @@ __global__ void __launch_bounds__(256, RS_LB) k_resample(MapDims d, DevState s, 
     const size_t ro_base = (size_t)wave_g * 64 * d.slots;
     int n = 0, n_old = 0;
     float wsum = 0.f, vxs = 0.f, vys = 0.f, stat_w = 0.f;
-    // rows stream through registers in batches of RBK; the loads of the NEXT batch are issued before this one is consumed
-    // (two register sets of RBK rows each: the wave's memory round trip hides behind the sequential per-voxel sums)
-    struct RowBatch { int row[RBK]; V2 vv[RBK]; float wr[RBK]; };
+    // rows stream through registers in batches of RBK_; the loads of the NEXT batch are issued before this one is consumed
+    // (two register sets of RBK_ rows each: the wave's memory round trip hides behind the sequential per-voxel sums)
+    struct RowBatch { int row[RBK_]; V2 vv[RBK_]; float wr[RBK_]; };
 #pragma unroll
     for (int e = 0; e < MW; ++e) {
         u64 tor = wave_or_u64(m[e]);
@@ -976,7 +973,7 @@ __global__ void __launch_bounds__(256, RS_LB) k_resample(MapDims d, DevState s, 
         const brsrc rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(s.w + (size_t)wave_g * d.slots * 64), 0, d.slots * 64 * 4, 0x00020000);
         auto issue = [&](RowBatch& B) {
 #pragma unroll
-            for (int r = 0; r < RBK; ++r) {
+            for (int r = 0; r < RBK_; ++r) {
                 B.row[r] = tor ? __ffsll((long long)tor) - 1 : -1;
                 if (tor) tor &= tor - 1ull;
                 // unconditional loads, see k_predict (the row enters as a wave-uniform scalar offset)
@@ -987,11 +984,11 @@ __global__ void __launch_bounds__(256, RS_LB) k_resample(MapDims d, DevState s, 
             }
         };
         auto consume = [&](const RowBatch& B) {
-            bool act[RBK];
-            float vx[RBK], vy[RBK];
+            bool act[RBK_];
+            float vx[RBK_], vy[RBK_];
             bool any_mv = false;
 #pragma unroll
-            for (int r = 0; r < RBK; ++r) {
+            for (int r = 0; r < RBK_; ++r) {
                 act[r] = B.row[r] >= 0 && ((m[e] >> (B.row[r] & 63)) & 1ull);
                 const bool old = act[r] && !((nb[e] >> (B.row[r] & 63)) & 1ull);
                 vx[r] = old ? B.vv[r].x : 0.f; vy[r] = old ? B.vv[r].y : 0.f;
@@ -1000,11 +997,11 @@ __global__ void __launch_bounds__(256, RS_LB) k_resample(MapDims d, DevState s, 
             // the rollout (:950-964) needs the position of the MOVING old particles only: their (x, y) are requested for the
             // whole batch at once -- one extra memory round trip per batch that holds a moving particle instead of one per
             // moving particle inside the sequential loop below
-            float mpx[RBK], mpy[RBK];
+            float mpx[RBK_], mpy[RBK_];
             const bool batch_mv = __ballot(any_mv) != 0ull;
             if (batch_mv) {
 #pragma unroll
-                for (int r = 0; r < RBK; ++r) {
+                for (int r = 0; r < RBK_; ++r) {
                     mpx[r] = 0.f; mpy[r] = 0.f;
                     if (vx[r] != 0.f || vy[r] != 0.f) {
                         const float2 q = *reinterpret_cast<const float2*>(s.pos + 3 * pidx(d, lvs, e * 64 + B.row[r]));
@@ -1012,11 +1009,11 @@ __global__ void __launch_bounds__(256, RS_LB) k_resample(MapDims d, DevState s, 
                     }
                 }
             }
-            bool mv_now[RBK];
+            bool mv_now[RBK_];
 #pragma unroll
-            for (int r = 0; r < RBK; ++r) mv_now[r] = false;
+            for (int r = 0; r < RBK_; ++r) mv_now[r] = false;
 #pragma unroll
-            for (int r = 0; r < RBK; ++r) {
+            for (int r = 0; r < RBK_; ++r) {
                 if (!act[r]) continue;
                 const u64 bit = 1ull << B.row[r];
                 const float w = B.wr[r];
@@ -1037,7 +1034,7 @@ __global__ void __launch_bounds__(256, RS_LB) k_resample(MapDims d, DevState s, 
             // wave owns the tile)
             if (batch_mv) {
 #pragma unroll
-                for (int r = 0; r < RBK; ++r) {
+                for (int r = 0; r < RBK_; ++r) {
                     const u64 mb = __ballot(mv_now[r]);
                     if (mv_now[r]) {
                         const size_t o = (ro_base + nmv + (int)__popcll(mb & lanemask_lt())) * 2;
@@ -1092,7 +1089,7 @@ __global__ void __launch_bounds__(256, RS_LB) k_resample(MapDims d, DevState s, 
         u64 surv[MW];
 #pragma unroll
         for (int e = 0; e < MW; ++e) surv[e] = resample ? m[e] : 0ull;
-        struct WBatch { int row[RBK]; float wr[RBK]; };
+        struct WBatch { int row[RBK_]; float wr[RBK_]; };
 #pragma unroll
         for (int e = 0; e < MW; ++e) {
             u64 tor = wave_or_u64(surv[e]);   // rows in which ANY voxel of the tile walks a particle (wave-uniform)
@@ -1100,7 +1097,7 @@ __global__ void __launch_bounds__(256, RS_LB) k_resample(MapDims d, DevState s, 
             const brsrc rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(s.w + (size_t)wave_g * d.slots * 64), 0, d.slots * 64 * 4, 0x00020000);
             auto issue = [&](WBatch& B) {
 #pragma unroll
-                for (int r = 0; r < RBK; ++r) {
+                for (int r = 0; r < RBK_; ++r) {
                     B.row[r] = tor ? __ffsll((long long)tor) - 1 : -1;
                     if (tor) tor &= tor - 1ull;
                     B.wr[r] = bl_w(rs_w, l, (e * 64 + (B.row[r] < 0 ? 0 : B.row[r])) * 64);
@@ -1108,7 +1105,7 @@ __global__ void __launch_bounds__(256, RS_LB) k_resample(MapDims d, DevState s, 
             };
             auto consume = [&](const WBatch& B) {
 #pragma unroll
-                for (int r = 0; r < RBK; ++r) {
+                for (int r = 0; r < RBK_; ++r) {
                     if (B.row[r] < 0) continue;                     // (scalar)
                     const int row = B.row[r];
                     const u64 bit = 1ull << row;
@@ -2122,8 +2119,12 @@ void launch_resample(const LaunchCtx& c) {
         // -- unless many tiles hold hundreds of moving particles (c.ro_inline, the handle's choice from last frame's count):
         // then k_rollout's LDS windows are worth their launch (66x66x40 saturated, every particle moving: 0.11 vs 0.27 ms)
         hipLaunchKernelGGL(k_resample_wg, dim3(k->ntiles), dim3(256), lds4, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, ro == 0 ? 1 : 0);
-    } else if (c.d.mw == 1) hipLaunchKernelGGL(k_resample<1>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, c.resample_rev ? 1 : 0);
-    else hipLaunchKernelGGL(k_resample<2>, dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, c.resample_rev ? 1 : 0);
+    } else {
+#define RS_LAUNCH(MWV, RB) hipLaunchKernelGGL((k_resample<MWV, RB>), dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, c.resample_rev ? 1 : 0)
+        if (c.d.mw == 1) { if (c.sparse) RS_LAUNCH(1, 8); else RS_LAUNCH(1, 4); }
+        else { if (c.sparse) RS_LAUNCH(2, 8); else RS_LAUNCH(2, 4); }
+#undef RS_LAUNCH
+    }
     if (ro == 1 || ro == 2) {
         // windows: the rows a particle reaches at a design speed (1.5 m/s, a brisk pedestrian), lowered until all T windows fit the LDS
         RolloutPlan pl;
