@@ -756,7 +756,6 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     // k_predict and k_place and leave the frame's critical path; split, cursors and insert follow the weight update
     const bool early_birth = !fork && birth_grid > 0;
     launch_predict_only(c, !fork, early_birth);
-    { static const int gap_us = getenv("DSPMAP_EXP_GAP_US") ? atoi(getenv("DSPMAP_EXP_GAP_US")) : 0; launch_spin(c, gap_us); }   // (experiment: counted in the predict stage)
     dspmap_prof_mark(m, 2);
     launch_claim(c, early_birth ? birth_grid : 0, 0, 0, 0, split ? 1 : -1);
     if (split) {

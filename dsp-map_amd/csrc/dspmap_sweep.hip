@@ -356,22 +356,14 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
 #pragma unroll
         for (int e = 0; e < MW; ++e) { cl += (int)__popcll(live[e]); nrows += (int)__popcll(wave_or_u64(live[e])); }
         const int nlive = wave_sum_i(cl);
-#ifdef EXP_NO_DENSE
-        if (l == 0) s_any = 1;
-#else
         if (l == 0) s_any = (!HASVZ && nlive <= DENSE_MAX && nlive * 5 < nrows * 64 * 3) ? 2 : 1;
-#endif
     }
     __syncthreads();
     if (!s_any) {  // empty tile
         if (tid < 4) part[BX * 4 + tid] = 0;
         return;   // (tile_moving keeps its value: 0 promises zeroed velocity cells, which only a sweep that read the rows can give)
     }
-#ifdef EXP_NO_DENSE
-    const bool dense = false;
-#else
     const bool dense = s_any == 2;
-#endif
     const int cap = 64 * d.slots;                       // records per staging area / inbox
     const size_t mv_base = (size_t)BX * cap;    // this tile's staging area (2 float4 per record)
     int c_live = 0, c_out = 0, c_pf = 0, c_mv = 0;   // c_live / c_out / c_mv: wave-uniform (sums of ballots), c_pf: per lane
@@ -379,11 +371,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
     // every live particle of the tile has velocity (0, 0) -- k_predict's own finding of the last frame, plus whatever arrived or was
     // born since -- : the velocity rows are not fetched (a third of what this sweep reads)
     const int tflag = __builtin_amdgcn_readfirstlane(s.tile_moving[BX]);
-#ifdef EXP_NO_STATIC_SKIP
-    const bool tmov = true;
-#else
     const bool tmov = HASVZ || tflag != 0;
-#endif
     bool mv_seen = false;                             // a live particle with a velocity (this lane)
     const float zadd = dt * 0.f + odz;                // :667, the same for every particle
     // buffer descriptors of this tile's share of the three field arrays (the tile's cells are contiguous: [slot][64]): a
@@ -502,11 +490,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
                 int kind = view ? advance_one<true>(d, s_ph, s_pv, dt, odx, ody, zadd, vx, vy, px, py, pz, lv, pyr, gv)
                                 : advance_one<false>(d, s_ph, s_pv, dt, odx, ody, zadd, vx, vy, px, py, pz, lv, pyr, gv);
                 if (!act) kind = -1;
-#ifdef EXP_WRITE_DEAD
-                if (kind >= 1) bs_pos(rs_pos, l, srow, px, py, pz);
-#else
                 if (kind == 1 || kind == 3) bs_pos(rs_pos, l, srow, px, py, pz);   // (a mover's cell is dead: its record carries the position)
-#endif
                 const unsigned bit = 1u << (rw & 31);
                 const unsigned fr = (kind == 0 || kind == 2) ? bit : 0u, xp = kind == 3 ? bit : 0u;   // left the map :688 / changed voxel; left the slab
                 if (rw < 32) { kc_lo |= fr; ex_lo |= xp; } else { kc_hi |= fr; ex_hi |= xp; }
@@ -706,9 +690,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
             s_org[e * 64 + tid] = in ? (was_live ? org : 0ull) : ~0ull;
             s_new[e * 64 + tid] = 0ull;
             if (in) {   // what k_place_fix needs should a pyramid list turn arrivals of this tile away: both occupancies as used here
-#ifndef EXP_NO_PMASK
                 s.pmask[(size_t)lv * MW + e] = s_cur[e * 64 + tid];
-#endif
                 if (!was_live) const_cast<u64*>(omask)[(size_t)lv * MW + e] = 0ull;
             }
         }
@@ -831,9 +813,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
                     keep = false;
                 }
             }
-#ifndef EXP_NO_REF
             gbk[cap + i] = ref;   // the arrival's list entry, beside its inbox record (k_place_fix re-points it if the arrival is moved)
-#endif
             if (keep) atomicOr(&s_new[(nsl >> 6) * 64 + ln], 1ull << (nsl & 63));
         }
     }
@@ -935,9 +915,6 @@ __global__ void __launch_bounds__(256, RBK_ >= 8 ? 3 : 5) k_resample(MapDims d, 
     int t_live, t_mov, t_unused;
     sload_i3(s.tile_live + wave_g, s.tile_moving + wave_g, s.tile_live + wave_g, t_live, t_mov, t_unused);   // (one scalar round trip)
     if (!t_live) return;   // empty since its last visit: result, buckets and lists are already zero
-#ifdef EXP_NO_STATIC_SKIP
-    t_mov = 1;
-#endif
     const bool inr = lv < d.v_loc;
     const int lvs = inr ? lv : 0;
     u64 m[MW], nb[MW];
@@ -2045,7 +2022,7 @@ __global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScra
 // ==========================================================================
 // launchers
 // ==========================================================================
-// experiment aid (DSPMAP_EXP_GAP_US): one wave that waits, so that a stage's stores can drain before the next stage's clock starts
+// one wave that waits a given time: the known-duration kernel dspmap_set_profiling calibrates the cost of an event bracket with
 __global__ void k_spin(long long ticks) {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
