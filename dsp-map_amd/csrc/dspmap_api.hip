@@ -106,6 +106,7 @@ static void derive_dims(dspmap* m) {
     d.nn = c.pyramid_neighbor_n > 0 ? c.pyramid_neighbor_n : 1;
     d.nbins = (2 * d.nn + 1) * (2 * d.nn + 1);
     d.static_model = c.static_model ? 1 : 0;
+    d.tile_skip = 1;
     d.mw = (d.slots + 63) / 64;
     const int A = c.angle_resolution;
     d.np_h = c.half_fov_h * 2 / A;                                     // :58
@@ -532,6 +533,7 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
         case DSPMAP_P_PLACE_SPLIT_TILES: m->place_split_tiles = v < 1 ? 1 : (v > 2e9 ? 2000000000 : (int)v); m->graph_epoch++; break;
         case DSPMAP_P_RESAMPLE_WG_TILES: m->resample_wg_tiles = v < 0 ? 0 : (v > 2e9 ? 2000000000 : (int)v); m->graph_epoch++; break;
         case DSPMAP_P_SWEEP_ALTERNATE: m->sweep_alt = v < 0 ? -1 : (v >= 2 ? 2 : (v != 0 ? 1 : 0)); m->graph_epoch++; break;
+        case DSPMAP_P_STATIC_TILE_SKIP: m->d.tile_skip = v != 0 ? 1 : 0; m->graph_epoch++; break;
         case DSPMAP_P_OCCLUSION_MARGIN: m->fp.occl_margin = (float)v; break;
         case DSPMAP_P_PAIR_CULL_SIGMAS: if (!(v > 0)) return dspmap_fail(m, DSPMAP_E_ARG, "pair cull radius must be positive"); m->cull_sigmas = (float)v; refresh_fp(m); break;
         case DSPMAP_P_REGENERATE_TABLES:
@@ -564,6 +566,7 @@ extern "C" double dspmap_get_param(const dspmap_t* m, int key) {
         case DSPMAP_P_PLACE_SPLIT_TILES: return m->place_split_tiles;
         case DSPMAP_P_RESAMPLE_WG_TILES: return m->resample_wg_tiles;
         case DSPMAP_P_SWEEP_ALTERNATE: return m->sweep_alt;
+        case DSPMAP_P_STATIC_TILE_SKIP: return m->d.tile_skip;
         case DSPMAP_P_SPARSE_SWEEP: return m->sparse_mode ? 1 : 0;
         case DSPMAP_P_ROLLOUT_INLINE: return m->ro_kernel ? 0 : 1;
         case DSPMAP_P_FAST_DIVISION: return m->d.div_ok;

@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
     // every live particle of the tile has velocity (0, 0) -- k_predict's own finding of the last frame, plus whatever arrived or was
     // born since -- : the velocity rows are not fetched (a third of what this sweep reads)
     const int tflag = __builtin_amdgcn_readfirstlane(s.tile_moving[BX]);
-    const bool tmov = HASVZ || tflag != 0;
+    const bool tmov = HASVZ || tflag != 0 || !d.tile_skip;
     bool mv_seen = false;                             // a live particle with a velocity (this lane)
     const float zadd = dt * 0.f + odz;                // :667, the same for every particle
     // buffer descriptors of this tile's share of the three field arrays (the tile's cells are contiguous: [slot][64]): a
@@ -623,7 +623,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
     // (a tile that was static stays so until somebody brings a velocity.)  A tile that BECOMES static has its velocity cells zeroed,
     // all of them: the flag promises that every cell of the tile -- live, dead, rows this sweep never loaded -- holds (0, 0), so
     // that whoever puts a static particle there (k_place: two scattered stores per arrival instead of three) need not write one.
-    if (tmov && tflag != 0) {
+    if (tmov && tflag != 0 && d.tile_skip) {
         if (!s_mvany) {
             float4* const vz4 = reinterpret_cast<float4*>(s.vel + 2 * tcell);
             for (int i = tid; i < tcells / 2; i += NW * 64) vz4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -665,7 +665,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
     __shared__ int s_cnt[2];
     const int tid = threadIdx.x;
     const bool was_live = s.tile_live[BX] != 0;   // an empty tile was skipped by k_predict: its omask words are stale (and zero in truth)
-    const bool t_moving = s.tile_moving[BX] != 0;   // as k_predict left it (this workgroup is the only one that raises it during the placement)
+    const bool t_moving = s.tile_moving[BX] != 0 || !d.tile_skip;   // as k_predict left it (this workgroup is the only one that raises it during the placement)
     const int cap = 64 * d.slots;
     const int n = min(n_all, cap);
     const bool in_lds = n <= PLACE_MAX;
@@ -915,6 +915,7 @@ __global__ void __launch_bounds__(256, RBK_ >= 8 ? 3 : 5) k_resample(MapDims d, 
     int t_live, t_mov, t_unused;
     sload_i3(s.tile_live + wave_g, s.tile_moving + wave_g, s.tile_live + wave_g, t_live, t_mov, t_unused);   // (one scalar round trip)
     if (!t_live) return;   // empty since its last visit: result, buckets and lists are already zero
+    if (!d.tile_skip) t_mov = 1;
     const bool inr = lv < d.v_loc;
     const int lvs = inr ? lv : 0;
     u64 m[MW], nb[MW];

@@ -45,6 +45,7 @@ struct MapDims {
     int nn;                // pyramid neighbourhood radius: 1 = 3x3 (:1135-1136), 2 = 5x5 (dsp_dynamic_multiple_neighbors.h)
     int nbins;             // (2*nn+1)^2
     int static_model;      // dsp_static.h's motion model: velocities forced to 0 in prediction
+    int tile_skip;         // DSPMAP_P_STATIC_TILE_SKIP: tiles of static particles are swept without their velocity rows (DevState::tile_moving)
     float res;
     float rcp_res;         // RN(1 / res)
     int div_ok;            // 1: a / res may be computed as reciprocal + two FMAs (verified exhaustively on the device, dspmap_device.h: div_res)

@@ -141,6 +141,10 @@ enum dspmap_param {
                                        the next frame's prediction starts where it ended); 0 = resampling upwards; 1 = all three flip from frame to frame
                                        (two captured graphs); -1 = 1 on maps of at least 4096 tiles.  132x132x60 saturated: placement -15 %, frame -3 %.
                                        Same result in every mode: no stage depends on the order in which the tiles are visited */
+    DSPMAP_P_STATIC_TILE_SKIP = 22, /* 1 (default): a 64-voxel tile whose live particles all have velocity (0, 0) is swept without its velocity rows, keeps
+                                       its velocity cells zeroed, and a static particle that arrives there is placed without a velocity store (the
+                                       reference never gives a static particle a velocity, :653); 0 = every tile is treated as if something moved in it.
+                                       Same result either way, bit for bit (the diagnostic the differential GPU test switches) */
     DSPMAP_P_PAIR_CULL_SIGMAS = 13  /* mapUpdate evaluates a (particle, observation) pair only if their ranges differ by at most this many
                                        sigma_ob (default 9: the dropped terms are < 1e-19 and zero on the fixed-point Ck grid);
                                        a huge value evaluates every pair of the neighbourhood like the reference's loops */

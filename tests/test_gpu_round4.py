@@ -705,3 +705,42 @@ def test_static_tiles_skip_their_velocity_rows_until_a_mover_arrives_or_is_born(
     has_mover[np.unique(vg[(rg[:, 1] != 0) | (rg[:, 2] != 0)] >> 6)] = True
     assert not (has_mover & ~mv).any()
     o.close(); m.close()
+
+
+def test_static_tile_shortcuts_change_nothing_on_the_depth_stream(dsp):
+    """DSPMAP_P_STATIC_TILE_SKIP = 0 treats every tile as if something moved in it: all velocity rows are read, every arrival's
+    velocity is stored, no tile is ever zeroed.  240 frames of the metric's depth stream (moving pedestrians: matched clusters
+    bear dynamic newborns, their particles cross tiles of static ones, tiles turn static and moving again all the time) through
+    the captured frame with the shortcuts on and off, the SAME clouds for both: every slot, every float and the future status
+    equal every 40 frames -- and the shortcuts were taken (hundreds of tiles flagged static beside thousands of movers)."""
+    scene_mod = __import__("dsp-map_amd.scene", fromlist=["CorridorScene"])
+    cfg = dict(nx=66, ny=66, nz=40, res=0.15, ppv=24)
+    sc = scene_mod.CorridorScene(66 * 0.15, 66 * 0.15, 40 * 0.15, seed=1234, device="cuda")
+    frames = [sc.frame(f / 30.0) for f in range(240)]
+    torch.cuda.synchronize()
+    maps = []
+    for skip in (1, 0):
+        m = dsp.DSPMap(dsp.make_config(seed=1234, **cfg))
+        m.L.dspmap_init_device(m.h)
+        m.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, 2)
+        m.set_param(dsp.capi.P_STATIC_TILE_SKIP, skip)
+        assert m.get_param(dsp.capi.P_STATIC_TILE_SKIP) == skip
+        maps.append(m)
+    seen_static, seen_movers = 0, 0
+    for f, (pts, pos, quat) in enumerate(frames):
+        for m in maps:
+            assert m.update_device(pts.data_ptr(), pts.shape[0], pos, f / 30.0, quat) == 1
+        if f % 40 == 39:
+            a, b = maps[0].export_state(), maps[1].export_state()
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), f
+            assert np.array_equal(maps[0].getFutureStatus(), maps[1].getFutureStatus()), f
+            assert np.array_equal(maps[0].results(), maps[1].results()), f
+            seen_static = max(seen_static, int((maps[0].tile_moving() == 0).sum()))
+            seen_movers = max(seen_movers, int(((a[2][:, 1] != 0) | (a[2][:, 2] != 0)).sum()))
+            assert (maps[1].tile_moving() != 0).all()
+        for m in maps:
+            m.clearOccupancyMapPrediction()
+    assert seen_static > 200 and seen_movers > 1000, (seen_static, seen_movers)
+    for m in maps:
+        m.close()
