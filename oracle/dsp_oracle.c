@@ -945,6 +945,59 @@ static int cmp_cluster_desc(const void* a, const void* b) {
     return d ? d : ((const cluster_span*)a)->start - ((const cluster_span*)b)->start;
 }
 
+/* pcl::EuclideanClusterExtraction (see the note above): clusters of pts[n][3] under the squared tolerance tol2 whose size is
+ * within [min_sz, max_sz], largest first; order[] receives the members of the clusters one after the other (ascending index
+ * inside a cluster), spans[] (room for n / min_sz + 1) where each cluster sits in order[].  Returns the number of clusters. */
+static int euclidean_clusters(const float* ng, int n_ng, float tol2, int min_sz, int max_sz, int* order, cluster_span* spans) {
+    char* processed = (char*)calloc(n_ng > 0 ? n_ng : 1, 1);
+    int n_order = 0, n_spans = 0;
+    int* queue = (int*)malloc(sizeof(int) * (n_ng > 0 ? n_ng : 1));
+    dist_idx* nbrs = (dist_idx*)malloc(sizeof(dist_idx) * (n_ng > 0 ? n_ng : 1));
+    for (int i = 0; i < n_ng; i++) {
+        if (processed[i]) continue;
+        int qn = 0, qi = 0;
+        queue[qn++] = i; processed[i] = 1;
+        while (qi < qn) {
+            int c = queue[qi++];
+            int nn = 0;
+            for (int j = 0; j < n_ng; j++) {
+                float dx = ng[3 * j] - ng[3 * c], dy = ng[3 * j + 1] - ng[3 * c + 1], dz = ng[3 * j + 2] - ng[3 * c + 2];
+                float d2 = dx * dx + dy * dy + dz * dz;
+                if (d2 <= tol2) { nbrs[nn].d = d2; nbrs[nn].i = j; nn++; }
+            }
+            qsort(nbrs, nn, sizeof(dist_idx), cmp_dist);
+            for (int k = 0; k < nn; k++)
+                if (!processed[nbrs[k].i]) { processed[nbrs[k].i] = 1; queue[qn++] = nbrs[k].i; }
+        }
+        if (qn >= min_sz && qn <= max_sz) {
+            /* PCL's extractEuclideanClusters sorts (and uniques) the indices of every cluster before it returns them
+             * (pcl/segmentation/impl/extract_clusters.hpp: std::sort(r.indices.begin(), r.indices.end())), so the points
+             * of a cluster reach :1424-1429 and :1509-1519 in ascending index order, not in region-growing order */
+            qsort(queue, qn, sizeof(int), cmp_int_asc);
+            spans[n_spans].start = n_order; spans[n_spans].size = qn; n_spans++;
+            memcpy(order + n_order, queue, sizeof(int) * qn);
+            n_order += qn;
+        }
+    }
+    qsort(spans, n_spans, sizeof(cluster_span), cmp_cluster_desc);
+    free(processed); free(queue); free(nbrs);
+    return n_spans;
+}
+
+/* test hooks for the two third-party algorithms (tests/test_oracle_kat.py checks them against independent implementations:
+ * scipy's linear_sum_assignment, connected components of the radius graph) */
+void dspo_hungarian(const float* cost, int nr, int nc, int* assign) { hungarian(cost, nr, nc, assign); }
+int dspo_euclidean_clusters(const float* pts, int n, float tol, int min_sz, int max_sz, int* label) {
+    int* order = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+    cluster_span* spans = (cluster_span*)malloc(sizeof(cluster_span) * (n / (min_sz > 0 ? min_sz : 1) + 1));
+    const int ns = euclidean_clusters(pts, n, tol * tol, min_sz, max_sz, order, spans);
+    for (int i = 0; i < n; i++) label[i] = -1;
+    for (int c = 0; c < ns; c++)
+        for (int k = 0; k < spans[c].size; k++) label[order[spans[c].start + k]] = c;   /* c = rank by size, largest first */
+    free(order); free(spans);
+    return ns;
+}
+
 void dspo_velocity_estimation(dsp_oracle* o) {
     if (o->cloud_view_n == 0) return; /* :1379: early return WITHOUT clearing the previous output */
     o->birth_n = 0;                   /* :1381 */
@@ -963,38 +1016,9 @@ void dspo_velocity_estimation(dsp_oracle* o) {
     if (n_ng > 0) { /* :1406 */
         /* Euclidean clustering: tolerance 2*res_filter, size 5..10000 (:1411-1413) */
         float tol = 2 * o->voxel_filtered_resolution, tol2 = tol * tol;
-        char* processed = (char*)calloc(n_ng, 1);
-        int* order = (int*)malloc(sizeof(int) * n_ng); int n_order = 0; /* concatenated cluster indices */
-        cluster_span* spans = (cluster_span*)malloc(sizeof(cluster_span) * (n_ng / 5 + 1)); int n_spans = 0;
-        int* queue = (int*)malloc(sizeof(int) * n_ng);
-        dist_idx* nbrs = (dist_idx*)malloc(sizeof(dist_idx) * n_ng);
-        for (int i = 0; i < n_ng; i++) {
-            if (processed[i]) continue;
-            int qn = 0, qi = 0;
-            queue[qn++] = i; processed[i] = 1;
-            while (qi < qn) {
-                int c = queue[qi++];
-                int nn = 0;
-                for (int j = 0; j < n_ng; j++) {
-                    float dx = ng[3 * j] - ng[3 * c], dy = ng[3 * j + 1] - ng[3 * c + 1], dz = ng[3 * j + 2] - ng[3 * c + 2];
-                    float d2 = dx * dx + dy * dy + dz * dz;
-                    if (d2 <= tol2) { nbrs[nn].d = d2; nbrs[nn].i = j; nn++; }
-                }
-                qsort(nbrs, nn, sizeof(dist_idx), cmp_dist);
-                for (int k = 0; k < nn; k++)
-                    if (!processed[nbrs[k].i]) { processed[nbrs[k].i] = 1; queue[qn++] = nbrs[k].i; }
-            }
-            if (qn >= 5 && qn <= 10000) {
-                /* PCL's extractEuclideanClusters sorts (and uniques) the indices of every cluster before it returns them
-                 * (pcl/segmentation/impl/extract_clusters.hpp: std::sort(r.indices.begin(), r.indices.end())), so the points
-                 * of a cluster reach :1424-1429 and :1509-1519 in ascending index order, not in region-growing order */
-                qsort(queue, qn, sizeof(int), cmp_int_asc);
-                spans[n_spans].start = n_order; spans[n_spans].size = qn; n_spans++;
-                memcpy(order + n_order, queue, sizeof(int) * qn);
-                n_order += qn;
-            }
-        }
-        qsort(spans, n_spans, sizeof(cluster_span), cmp_cluster_desc);
+        int* order = (int*)malloc(sizeof(int) * n_ng); /* concatenated cluster indices */
+        cluster_span* spans = (cluster_span*)malloc(sizeof(cluster_span) * (n_ng / 5 + 1));
+        const int n_spans = euclidean_clusters(ng, n_ng, tol2, 5, 10000, order, spans);
         char* possibly_dynamic = (char*)calloc(n_spans + 1, 1);
         dyn = (cluster_feature*)calloc(n_spans + 1, sizeof(cluster_feature));
         for (int c = 0; c < n_spans; c++) { /* :1419-1447 */
@@ -1064,7 +1088,7 @@ void dspo_velocity_estimation(dsp_oracle* o) {
                 ++dseq;
             }
         }
-        free(processed); free(order); free(spans); free(queue); free(nbrs); free(possibly_dynamic);
+        free(order); free(spans); free(possibly_dynamic);
     }
     birth_reserve(o, o->birth_n + n_st);
     for (int i = 0; i < n_st; i++) { /* :1529-1540 */

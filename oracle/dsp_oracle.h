@@ -158,6 +158,13 @@ int dspo_count_live(const dsp_oracle* o);
 int dspo_preprocess_cloud(int n, const float* pts, int stride, float leaf, int swap_axes, float hx, float hy, float hz,
                           int max_points, float* out, int* n_leaves);
 
+/* ---- test hooks for the restated third-party algorithms of the velocity estimator (checked against independent
+ * implementations by tests/test_oracle_kat.py) ----
+ * munkres-cpp: minimum-cost assignment of an nr x nc matrix, assign[r] = column or -1 (:1474-1481 reads only which cells are assigned) */
+void dspo_hungarian(const float* cost, int nr, int nc, int* assign);
+/* pcl::EuclideanClusterExtraction (:1406-1417): label[i] = rank of point i's cluster by size (0 = largest) or -1; returns the cluster count */
+int dspo_euclidean_clusters(const float* pts, int n, float tol, int min_sz, int max_sz, int* label);
+
 #ifdef __cplusplus
 }
 #endif

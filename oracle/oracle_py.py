@@ -103,6 +103,8 @@ def _load(fast=False):
         "dspo_update_time": (f, [P]), "dspo_count_live": (i, [P]),
         "dspo_fill_gaussian_tables": (None, [P, P, i, f, f, C.c_uint]),
         "dspo_preprocess_cloud": (i, [i, P, i, f, i, f, f, f, i, P, ip]),
+        "dspo_hungarian": (None, [P, i, i, P]),
+        "dspo_euclidean_clusters": (i, [P, i, f, i, i, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -118,6 +120,23 @@ def lib(fast=False):
     if fast not in _LIBS:
         _LIBS[fast] = _load(fast)
     return _LIBS[fast]
+
+
+def hungarian(cost):
+    """the estimator's restated munkres-cpp (:1474-1481): assign[r] = column of row r or -1"""
+    cost = np.ascontiguousarray(cost, np.float32)
+    assign = np.empty(cost.shape[0], np.int32)
+    lib().dspo_hungarian(cost.ctypes.data_as(C.c_void_p), cost.shape[0], cost.shape[1], assign.ctypes.data_as(C.c_void_p))
+    return assign
+
+
+def euclidean_clusters(pts, tol, min_size=5, max_size=10000):
+    """the estimator's restated pcl::EuclideanClusterExtraction (:1406-1417): -> (labels (n,), cluster count); label = rank by size"""
+    pts = np.ascontiguousarray(pts, np.float32)
+    label = np.empty(pts.shape[0], np.int32)
+    n = lib().dspo_euclidean_clusters(pts.ctypes.data_as(C.c_void_p), pts.shape[0], float(tol), min_size, max_size,
+                                      label.ctypes.data_as(C.c_void_p))
+    return label, n
 
 
 def preprocess_cloud(pts, leaf, half, max_points=5000, swap_axes=True):

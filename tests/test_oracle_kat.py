@@ -319,3 +319,88 @@ def test_workload_statistics_match_the_reference_probe(orc):
     assert 0.05 < (s[:, 3] / s[:, 4]).mean() < 0.30           # copies: of the order of 15 % of the live set
     assert s[:, 5].max() == 24                                # fullest voxel after resampling = MAX_PARTICLE_NUM_VOXEL
     o.close()
+
+
+# ---- the third-party algorithms of the velocity estimator (absent from /root/reference: PCL, munkres-cpp, Eigen) ----
+# The oracle restates their PUBLISHED algorithms; these tests check the restatements against independent implementations
+# that ship with the image (scipy), which is as far as they can be pinned without the libraries themselves.
+
+def test_restated_munkres_is_a_minimum_cost_assignment(orc):
+    """saebyn/munkres-cpp as used at include/dsp_dynamic.h:1474-1481 (only WHICH cells are assigned is read): the restated
+    Hungarian algorithm assigns min(rows, cols) distinct cells at the minimum total cost -- the same total as
+    scipy.optimize.linear_sum_assignment on square, wide, tall and tie-ridden matrices."""
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(7)
+    shapes = [(1, 1), (1, 6), (6, 1), (4, 4), (3, 9), (9, 3), (17, 17), (12, 30), (30, 12), (64, 64)]
+    for nr, nc in shapes:
+        for kind in ("uniform", "ties", "distances"):
+            if kind == "uniform":
+                cost = rng.uniform(0, 10, (nr, nc)).astype(np.float32)
+            elif kind == "ties":
+                cost = rng.integers(0, 4, (nr, nc)).astype(np.float32)
+            else:   # what the estimator feeds it: centre distances of clusters, gated pairs at a large constant (:1459-1472)
+                a, b = rng.uniform(-5, 5, (nr, 3)), rng.uniform(-5, 5, (nc, 3))
+                cost = np.linalg.norm(a[:, None] - b[None], axis=2).astype(np.float32)
+                cost[cost > 6] = 1000.0
+            assign = orc.hungarian(cost)
+            rows = np.nonzero(assign >= 0)[0]
+            assert len(rows) == min(nr, nc), (nr, nc, kind)
+            assert len(set(assign[rows].tolist())) == len(rows)          # one row per column
+            assert (assign[rows] < nc).all()
+            r, c = linear_sum_assignment(cost.astype(np.float64))
+            want = cost.astype(np.float64)[r, c].sum()
+            got = cost.astype(np.float64)[rows, assign[rows]].sum()
+            assert abs(got - want) <= 1e-6 * max(1.0, abs(want)), (nr, nc, kind, got, want)
+
+
+def test_restated_euclidean_cluster_extraction_is_the_radius_graphs_components(orc):
+    """pcl::EuclideanClusterExtraction as used at :1406-1417 (tolerance, min 5, max 10000 points): the region growing of the
+    restatement yields exactly the connected components of the graph "distance <= tolerance" whose size is within the limits,
+    largest first -- checked against scipy.sparse.csgraph.connected_components on blobs, chains and scattered points."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    rng = np.random.default_rng(11)
+    for case in range(6):
+        blobs = [rng.normal(rng.uniform(-4, 4, 3), rng.uniform(0.05, 0.3), (int(rng.integers(3, 120)), 3)) for _ in range(8)]
+        chain = np.stack([np.linspace(-3, 3, 40), np.full(40, 5.0), np.zeros(40)], 1)    # neighbours 0.154 apart: one component at 0.2
+        lone = rng.uniform(-6, 6, (60, 3))
+        pts = np.concatenate(blobs + [chain, lone]).astype(np.float32)
+        pts = pts[rng.permutation(len(pts))]
+        tol = np.float32(0.2)
+        for lo, hi in ((5, 10000), (5, 60), (1, 10000)):
+            label, n = orc.euclidean_clusters(pts, tol, lo, hi)
+            d = pts[:, None, :] - pts[None, :, :]
+            d2 = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]          # fp32, as the radius search
+            i, j = np.nonzero(d2 <= tol * tol)
+            _, comp = connected_components(coo_matrix((np.ones(len(i)), (i, j)), shape=(len(pts),) * 2), directed=False)
+            sizes = np.bincount(comp)
+            keep = (sizes[comp] >= lo) & (sizes[comp] <= hi)
+            assert np.array_equal(label >= 0, keep), (case, lo, hi)
+            assert n == int(((sizes >= lo) & (sizes <= hi)).sum())
+            # same partition: a label maps to one component and back
+            pairs = set(zip(label[keep].tolist(), comp[keep].tolist()))
+            assert len(pairs) == n and len({a for a, _ in pairs}) == n and len({b for _, b in pairs}) == n
+            # largest first
+            got_sizes = [int((label == c).sum()) for c in range(n)]
+            assert got_sizes == sorted(got_sizes, reverse=True)
+
+
+def test_restated_quaternion_rotation_is_the_rotation(orc):
+    """rotateVectorByQuaternion :1303-1322 (Eigen's q * p * q^-1): equal to scipy's Rotation for unit quaternions (1e-5),
+    and the identity / the half turns are exact."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(3)
+    q = rng.normal(size=(200, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    v = rng.uniform(-10, 10, (200, 3)).astype(np.float32)
+    out = np.zeros(3, np.float32)
+    for k in range(200):
+        qw = q[k].astype(np.float32)     # (w, x, y, z)
+        orc.lib().dspo_rotate_vector(v[k].ctypes.data_as(C.c_void_p), qw.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        want = Rotation.from_quat([qw[1], qw[2], qw[3], qw[0]]).apply(v[k].astype(np.float64))
+        assert np.allclose(out, want, atol=2e-5 * max(1.0, np.abs(v[k]).max())), (k, out, want)
+    for qq, f in (((1, 0, 0, 0), lambda a: a), ((0, 0, 0, 1), lambda a: np.array([-a[0], -a[1], a[2]])),
+                  ((0, 1, 0, 0), lambda a: np.array([a[0], -a[1], -a[2]]))):
+        qw = np.array(qq, np.float32)
+        orc.lib().dspo_rotate_vector(v[0].ctypes.data_as(C.c_void_p), qw.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(out, f(v[0]).astype(np.float32))
