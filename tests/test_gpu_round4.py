@@ -744,3 +744,26 @@ def test_static_tile_shortcuts_change_nothing_on_the_depth_stream(dsp):
     assert seen_static > 200 and seen_movers > 1000, (seen_static, seen_movers)
     for m in maps:
         m.close()
+
+
+@pytest.mark.parametrize("name", ["C_132x132x12_24ppv", "E_80x80x12_res010_36ppv"])
+def test_resample_sparse_map_instantiation_against_oracle(dsp, orc, name):
+    """k_resample<MW, RBK>: maps the handle takes for sparse (most tiles empty: the realistic fills of C and E) run the one-wave
+    resampler with 8-row load batches, dense ones with 4-row batches -- two instantiations per occupancy-word count since round
+    4.  The stage tests above leave the choice at its default (dense: RBK = 4); here DSPMAP_P_SPARSE_SWEEP = 1 forces the
+    sparse launch (k_resample<1, 8> on config C's shape, k_resample<2, 8> on config E's) on the same scene, against the
+    oracle: mass, mean velocity, survivors, copies and their slots bit-exact -- and the future status is the same bits as the
+    dense launch's."""
+    cfgkw, n_part = CONFIGS[name]
+    futs = []
+    for sparse in (1, 0):
+        o, m = make_pair(dsp, orc, seed=5, **cfgkw)
+        want = _force(m, dsp, "wave+light")
+        m.set_param(dsp.capi.P_SPARSE_SWEEP, sparse)
+        _resample_scene(o, m, cfgkw, n_part)
+        o.occupancy_resample(); m.occupancy_resample()
+        assert m.rollout_paths()[0] == want
+        assert m.get_param(dsp.capi.P_SPARSE_SWEEP) == sparse     # the launch context the stage ran with
+        futs.append(_check_resample(o, m, 6))
+        o.close(); m.close()
+    assert np.array_equal(futs[0], futs[1])
