@@ -97,7 +97,7 @@ struct dspmap {
     int sparse_force = -1;           // DSPMAP_P_SPARSE_SWEEP: -1 from the hint, 0 / 1 forced
     int place_split_tiles = 8192;    // maps with at least this many tiles place the arrivals of the tiles outside the field of view
                                      // on the side stream, beside the pair kernels (DSPMAP_P_PLACE_SPLIT_TILES)
-    int resample_wg_tiles = 8192;    // one-word maps with fewer tiles run the four-waves-per-tile resampler (DSPMAP_P_RESAMPLE_WG_TILES)
+    int resample_wg_tiles = 8192;    // one-word maps with fewer tiles (and sparse ones of any size) run the four-waves-per-tile resampler (DSPMAP_P_RESAMPLE_WG_TILES)
     int last_resample_variant = 0;   // resample_variant() of the last frame / stage (dspmap_debug_rollout_paths)
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};   // the captured frame, one per sweep direction (LaunchCtx::sweep_rev is a kernel argument)

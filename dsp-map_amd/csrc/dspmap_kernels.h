@@ -45,7 +45,7 @@ struct LaunchCtx {
     VelEst ve;
     int n_cu = 256;      // compute units of the device (sizes launches that are meant to occupy only a share of it)
     bool ro_inline = true; // small maps (k_resample_wg): the tiles roll their moving particles out themselves, no k_rollout launch
-    int resample_wg_tiles = 8192;   // one-word maps with fewer tiles run k_resample_wg (dspmap::resample_wg_tiles, DSPMAP_P_RESAMPLE_WG_TILES)
+    int resample_wg_tiles = 8192;   // one-word maps with fewer tiles (and sparse ones of any size) run k_resample_wg (dspmap::resample_wg_tiles, DSPMAP_P_RESAMPLE_WG_TILES)
     bool sweep_rev = false;   // this frame's k_predict / k_resample walk the tiles from the last one down and k_place from the first one up
                               // (the next frame the other way round): every tile sweep starts where its predecessor ended (Infinity Cache)
     bool resample_rev = false;   // k_resample walks the tiles from the last one down (after a k_place that ended there)

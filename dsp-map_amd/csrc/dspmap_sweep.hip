@@ -892,13 +892,13 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
 
 // --------------------------------------------------------------------------
 // k_resample: mapOccupancyCalculationAndResample :924-1057.  One wave per tile, one lane per voxel.
-//   * the first pass (cull / mass :938-984) stores every WEIGHT it reads into the wave's LDS panel; the second pass
-//     (systematic resampling :986-1053) reads the weights from there, so it costs no memory round trip and the
-//     weights cross HBM once (4-byte LDS-DMA loads for the panel were slower than load + ds_write);
-//   * weights and velocities stream through registers in batches of RBK rows; positions are read only for moving
-//     particles (noted for k_rollout :950-964) and for copies;
+//   * the first pass (cull / mass :938-984) streams weights and velocities through registers in batches of RBK_ rows, the next
+//     batch requested before this one is consumed; the second pass (systematic resampling :986-1053) re-reads the weight rows
+//     wave-uniformly, a batch ahead (no LDS weight panel since round 4: 16 instead of 10 / 6 resident tiles per CU);
+//   * positions are read only for moving particles (noted for k_rollout :950-964) and for copies; the velocity rows of a tile
+//     whose particles are all static are not fetched (DevState::tile_moving);
 //   * all per-voxel sums run sequentially per lane in slot order = the reference's operation order.
-// dynamic LDS per wave: [slots][64] fp32 weights + [64][M] u16 (source slot, destination slot) of deferred copies
+// dynamic LDS per wave: [64][M] u16 (source slot, destination slot) of deferred copies
 // --------------------------------------------------------------------------
 template <int MW, int RBK_>
 __global__ void __launch_bounds__(256, RBK_ >= 8 ? 3 : 5) k_resample(MapDims d, DevState s, int* __restrict__ part_live, int* __restrict__ vb_cnt,
@@ -935,7 +935,6 @@ __global__ void __launch_bounds__(256, RBK_ >= 8 ? 3 : 5) k_resample(MapDims d, 
         if (l == 0 && wave_g * 64 < d.v_loc + 63) { part_live[wave_g] = 0; ro_cnt[wave_g] = 0; s.tile_live[wave_g] = 0; }
         return;
     }
-    // every live weight row of the tile -> LDS, all loads in flight together
     int nmv = 0;   // moving old particles of the tile noted for k_rollout so far (wave-uniform)
     float mvw = 0.f;   // ... and this lane's share of their weight (k_rollout scales its fixed-point windows with the total)
     const size_t ro_base = (size_t)wave_g * 64 * d.slots;
@@ -2073,7 +2072,10 @@ void launch_predict(const LaunchCtx& c, bool with_gather) {
 // the moving particles: 0 inside the resampler (float-free integer atomics from its idle waves), 1 k_rollout LIGHT, 2 k_rollout with LDS
 // windows, 3 none (no prediction horizons)
 int resample_variant(const LaunchCtx& c) {
-    const bool wg = c.k.ntiles < c.resample_wg_tiles && c.d.mw == 1 && c.d.slots <= 4 * RWB;
+    // four waves per tile: maps below the handle's tile limit -- and, whatever their size, maps the handle takes for sparse (most tiles
+    // empty: what is left is a few thousand tiles of a few hundred particles each, the metric's regime; 132x132x60 filled by the depth
+    // stream, alternating inside one process: frame 0.2226 -> 0.2065 ms).  A limit of 0 keeps every map on the one-wave variant.
+    const bool wg = (c.k.ntiles < c.resample_wg_tiles || (c.sparse && c.resample_wg_tiles > 0)) && c.d.mw == 1 && c.d.slots <= 4 * RWB;
     int ro = c.d.T <= 0 ? 3 : (c.ro_inline ? (wg ? 0 : 1) : 2);
     return (wg ? 1 : 0) | (ro << 1);
 }
@@ -2082,7 +2084,7 @@ void kernels_init_device() {   // per device, once (dspmap_init_device)
 }
 void launch_resample(const LaunchCtx& c) {
     const KernelScratch* k = &c.k;
-    const int nw = 1;   // waves (= tiles) per workgroup; the LDS panel bounds the occupancy, small groups pack best
+    const int nw = 1;   // waves (= tiles) per workgroup (2 / 4 measured in round 4: -3 % on the realistic 264x264x80 fill, +2 % at saturation)
     const size_t lds = (size_t)nw * ((64 * c.d.M + 1) / 2) * sizeof(float);   // the copy notes; the weights are re-read (no LDS panel)
     const unsigned grid = (unsigned)((k->ntiles + nw - 1) / nw);
     // maps of the metric's size run the four-waves-per-tile variant: their frame is a chain of latencies and the longest tile is

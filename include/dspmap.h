@@ -132,7 +132,8 @@ enum dspmap_param {
                                        windows, -1 (default) the handle decides from the number of tiles with hundreds of moving particles; larger
                                        maps: 1 = k_rollout without windows, 0 = with them.  The future status is accumulated in fixed point, every
                                        particle adds the same integer on every path: the SAME result bit for bit (read: the last frame's choice) */
-    DSPMAP_P_RESAMPLE_WG_TILES = 20,/* one-occupancy-word maps with FEWER 64-voxel tiles than this (default 8192) run the four-waves-per-tile variant of the
+    DSPMAP_P_RESAMPLE_WG_TILES = 20,/* one-occupancy-word maps with FEWER 64-voxel tiles than this (default 8192) -- and larger ones while the handle takes
+                                       them for sparse (most tiles empty, DSPMAP_P_SPARSE_SWEEP) -- run the four-waves-per-tile variant of the
                                        resampling stage, the others the one-wave-per-tile variant (same result slot for slot; a scheduling knob: 0 =
                                        never, a huge value = whenever the map qualifies; the environment variable DSPMAP_RESAMPLE_WG_TILES presets it) */
     DSPMAP_P_SWEEP_ALTERNATE = 21,  /* direction of the three sweeps over the map's 64-voxel tiles.  A large map's live rows are several times the 256 MB

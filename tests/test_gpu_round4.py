@@ -767,3 +767,25 @@ def test_resample_sparse_map_instantiation_against_oracle(dsp, orc, name):
         futs.append(_check_resample(o, m, 6))
         o.close(); m.close()
     assert np.array_equal(futs[0], futs[1])
+
+
+def test_sparse_large_one_word_map_takes_the_four_wave_resampler_by_itself(dsp, orc):
+    """The dispatch rule of the resampling stage: a one-word map runs k_resample_wg below DSPMAP_P_RESAMPLE_WG_TILES (8 192) tiles --
+    and, whatever its size, while the handle takes it for sparse (config C filled by the depth stream: 16 335 tiles of which a tenth
+    hold anything).  A map of 8 712 tiles with its particles in a corner, the limit left at its default: forced sparse it runs
+    k_resample_wg, forced dense k_resample<1, 4> -- both against the oracle, slot for slot, and the same future-status bits."""
+    cfgkw = dict(nx=132, ny=132, nz=32, res=0.15, ppv=24)
+    futs = []
+    for sparse in (1, 0):
+        o, m = make_pair(dsp, orc, seed=5, **cfgkw)
+        assert m.V // 64 >= 8192 and m.get_param(dsp.capi.P_RESAMPLE_WG_TILES) == 8192
+        m.set_param(dsp.capi.P_SPARSE_SWEEP, sparse)
+        m.set_param(dsp.capi.P_ROLLOUT_INLINE, 1)
+        _resample_scene(o, m, cfgkw, 300000)
+        o.occupancy_resample(); m.occupancy_resample()
+        var = m.rollout_paths()[0]
+        assert (var & 1) == sparse, (var, sparse)                       # four waves per tile iff sparse
+        assert (var >> 1) == (0 if sparse else 1)                       # rollout inside the resampler / k_rollout light
+        futs.append(_check_resample(o, m, 6))
+        o.close(); m.close()
+    assert np.array_equal(futs[0], futs[1])
