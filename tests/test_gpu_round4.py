@@ -793,3 +793,51 @@ def test_sparse_large_one_word_map_takes_the_four_wave_resampler_by_itself(dsp, 
         futs.append(_check_resample(o, m, 6))
         o.close(); m.close()
     assert np.array_equal(futs[0], futs[1])
+
+
+def test_resampler_variant_switching_mid_run_changes_nothing(dsp):
+    """A one-word map of 8 712 tiles filled by the depth stream from empty: the handle starts on the one-wave resampler (nothing
+    known about the map yet), finds the map sparse after a few frames and switches to k_resample_wg by itself -- in the middle
+    of the run, on live state.  The same clouds through a handle pinned to the one-wave variant and one pinned to the four-wave
+    variant: every slot, every float, every counter and the future status equal every 10 frames, and the first handle DID
+    switch."""
+    scene_mod = __import__("dsp-map_amd.scene", fromlist=["CorridorScene"])
+    cfg = dict(nx=132, ny=132, nz=32, res=0.15, ppv=24)
+    sc = scene_mod.CorridorScene(132 * 0.15, 132 * 0.15, 32 * 0.15, seed=1234, device="cuda")
+    frames = [sc.frame(f / 30.0) for f in range(60)]
+    torch.cuda.synchronize()
+    maps = []
+    for limit in (None, 0, 1 << 30):
+        m = dsp.DSPMap(dsp.make_config(seed=1234, **cfg))
+        m.L.dspmap_init_device(m.h)
+        m.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, 2)
+        if limit is not None:
+            m.set_param(dsp.capi.P_RESAMPLE_WG_TILES, limit)
+        maps.append(m)
+    assert maps[0].V // 64 >= 8192
+    seen = set()
+    for f, (pts, pos, quat) in enumerate(frames):
+        for m in maps:
+            assert m.update_device(pts.data_ptr(), pts.shape[0], pos, f / 30.0, quat) == 1
+        seen.add(maps[0].rollout_paths()[0] & 1)
+        assert maps[1].rollout_paths()[0] & 1 == 0 and maps[2].rollout_paths()[0] & 1 == 1
+        if f % 10 == 9:
+            ref = maps[0].export_state()
+            assert len(ref[0]) > 1000
+            futs = [m.getFutureStatus() for m in maps]      # (ONE read per map: like the reference's getter, a read clears, :397-400)
+            assert futs[0].sum() > 100
+            for m, fut in zip(maps[1:], futs[1:]):
+                for a, b in zip(ref, m.export_state()):
+                    assert np.array_equal(a, b), f
+                assert np.array_equal(futs[0], fut), f
+                assert np.array_equal(maps[0].results(), m.results()), f
+            cs = [m.counters() for m in maps]
+            for c in cs:
+                c.pop("update_ms")
+            assert cs[0] == cs[1] == cs[2], f
+        for m in maps:
+            m.clearOccupancyMapPrediction()
+    assert seen == {0, 1}, seen                     # one wave per tile at first, four once the handle knew the map to be sparse
+    assert maps[0].get_param(dsp.capi.P_SPARSE_SWEEP) == 1
+    for m in maps:
+        m.close()
