@@ -36,6 +36,9 @@ WORKLOADS = {
     "C_sat": dict(nx=132, ny=132, nz=60, res=0.15, ppv=24, sat=True),
     "E": dict(nx=264, ny=264, nz=80, res=0.10, ppv=36, sat=False),
     "E_sat": dict(nx=264, ny=264, nz=80, res=0.10, ppv=36, sat=True),
+    # E's grid with 24 particles per voxel (one occupancy word): the only way to run the four-wave resampler on 87 120 sparse tiles
+    # (tools/ab_param.py --workload E24 --param RESAMPLE_WG_TILES --a 0 --b 1000000000: what a two-word k_resample_wg could bring E)
+    "E24": dict(nx=264, ny=264, nz=80, res=0.10, ppv=24, sat=False),
     # one rank's share of E_sat on 8 GPUs (10 of the 80 layers) as a stand-alone map: driver-overhead studies
     "E8_sat": dict(nx=264, ny=264, nz=10, res=0.10, ppv=36, sat=True),
     # config D (the 10-horizon rollout on C's saturated grid), static / moving fill, as workloads of their own for profiling
