@@ -3,7 +3,9 @@ against the oracle -- both resamplers on one-word maps (k_resample_wg / k_resamp
 resampler / k_rollout without windows / k_rollout with LDS windows), at reduced size and at config C / D's FULL size
 (132x132x60 @ 24, T = 6 and 10, natively >= 8 192 tiles: split placement, k_weight<SKIP>, k_resample<1>), the SPARSE
 prediction sweep and the fused birth insertion of the captured frame; the future status is order-free (fixed point) and
-bit-identical across variants, runs and slab counts; k_place_fix with a held pose (stale inboxes)."""
+bit-identical across variants, runs and slab counts; k_place_fix with a held pose (stale inboxes); the static-tile shortcuts and
+the resampler's sparse-map dispatch (k_resample<MW, 8>, k_resample_wg on large sparse maps, the switch in the middle of a run)
+as differential tests on the depth stream."""
 import numpy as np
 import pytest
 import torch
