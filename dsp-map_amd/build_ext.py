@@ -20,12 +20,31 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
 
+STAMP = LIB + ".srchash"
+
+
+def source_hash():
+    """sha256 over every source / header of the library, this recipe and the flags in effect: what the .so was built FROM.
+    (Modification times say nothing in a tree that arrived by a `gpurun` push or a fresh checkout -- VERDICT r4 -- so the
+    decision to rebuild compares this hash with the one stored next to the .so when it was built.)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        fp = os.path.join(CSRC, f)
+        if os.path.exists(fp):
+            h.update(f.encode()); h.update(open(fp, "rb").read())
+    h.update(open(os.path.abspath(__file__), "rb").read())
+    h.update(" ".join(FLAGS).encode()); h.update(os.environ.get("DSPMAP_EXTRA_FLAGS", "").encode())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    files = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.exists(f) and os.path.getmtime(f) > t for f in files)
+    try:
+        return open(STAMP).read().strip() != source_hash()
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=False):
@@ -37,7 +56,11 @@ def build(force=False, verbose=False):
     cmd = [hipcc] + FLAGS + os.environ.get("DSPMAP_EXTRA_FLAGS", "").split() + ["-x", "hip"] + srcs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
+    if os.path.exists(STAMP):
+        os.remove(STAMP)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
     return LIB
 
 

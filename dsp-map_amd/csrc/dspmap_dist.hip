@@ -182,6 +182,10 @@ __global__ void k_group_max_i32(PtrList l, int count) {
 // ------------------------------------------------------------------------------------------------ set-up
 static int dist_alloc(dspmap* m, int world, int rank) {
     if (m->dist) return dspmap_fail(m, DSPMAP_E_STATE, "the handle already belongs to a communicator / group");
+    // dspmap_mgpu_bind hands the handle CALLER-owned Ck / n_static buffers; this driver replaces the Ck buffer with one of its own
+    // (np more slots): the two do not mix -- freeing the caller's buffer here would be a double free on the caller's side
+    if (m->mgpu_bound && !m->mgpu_self_bound)
+        return dspmap_fail(m, DSPMAP_E_STATE, "the handle is bound to caller-owned buffers (dspmap_mgpu_bind) and cannot join a communicator / group: use a handle of its own");
     const MapDims& d = m->d;
     if (world > 1 && d.z_lo == 0 && d.z_hi == d.nz) return dspmap_fail(m, DSPMAP_E_ARG, "a sharded map needs z_lo / z_hi in its configuration");
     dspmap_dist* x = new dspmap_dist();
@@ -206,6 +210,8 @@ static int dist_alloc(dspmap* m, int world, int rank) {
         long long* ck = nullptr;
         HIPCHK(m, hipMalloc((void**)&ck, sizeof(long long) * ((size_t)d.np * DSP_OBS_CAP + d.np)));
         HIPCHK(m, hipMemset(ck, 0, sizeof(long long) * ((size_t)d.np * DSP_OBS_CAP + d.np)));
+        HIPCHK(m, hipStreamSynchronize(m->stream));   // nothing queued may still write the buffer that goes
+        if (m->stream2) HIPCHK(m, hipStreamSynchronize(m->stream2));
         (void)hipFree(m->s.obs_ck);
         m->s.obs_ck = ck;
         m->s.pyr_gcnt = ck + (size_t)d.np * DSP_OBS_CAP;

@@ -11,6 +11,7 @@
 
 #define DSPMAP_PTS_RING 4  // pinned cloud staging buffers in rotation
 #define DSPMAP_RING 1024   // slots of the pinned frame-parameter ring (power of two)
+#define DSPMAP_CLOUD_RING 64   // slots of the pinned, device-mapped CLOUD ring of the host-pointer update() (divides DSPMAP_RING)
 struct dspmap {
     dspmap_config cfg;
     MapDims d;
@@ -58,6 +59,12 @@ struct dspmap {
     float* pts_ring[DSPMAP_PTS_RING] = {}; int pts_ring_cap[DSPMAP_PTS_RING] = {};
     hipEvent_t pts_ring_ev[DSPMAP_PTS_RING] = {}; bool pts_ring_busy[DSPMAP_PTS_RING] = {};
     unsigned pts_ring_pos = 0;
+    // host-pointer update() as ONE graph launch: the caller's cloud is copied into a slot of a pinned, device-MAPPED ring and the
+    // frame's first kernel (k_obs_points) reads the points over the bus -- no H2D copy node, no event record in front of the graph.
+    // Slot (ring_head % DSPMAP_CLOUD_RING); the frame that read it last has published its ring position in hint_host[2]
+    // (k_predict, i.e. after every workgroup of k_obs_points is done with the slot) before the host refills it.
+    float* cring_host = nullptr; const float* cring_dev = nullptr; int cring_cap = 0;   // cring_cap: points per slot
+    const float* host_cloud = nullptr; int host_cloud_stride = 0;                       // set by dspmap_update for the frame being queued
     BirthSrc* birth_pin = nullptr; int birth_pin_cap = 0;
     hipEvent_t birth_ev = nullptr; bool birth_ev_set = false;   // behind the last copy out of birth_pin
     // birth cloud supplied by the caller (estimator off) / produced by the estimator
@@ -77,6 +84,7 @@ struct dspmap {
     FrameParams hp = {};
     // HIP graph of the device-resident frame (dspmap_update_device)
     bool use_graph = true;
+    bool host_direct = true;         // DSPMAP_P_HOST_CLOUD_DIRECT: dspmap_update feeds the captured frame through the mapped cloud ring
     bool fut_clear_pending = false;   // clearOccupancyMapPrediction is lazy: done by the next frame's k_predict, or by the next reader
     hipStream_t stream2 = nullptr;   // fork/join branch inside the captured frame
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr;

@@ -291,8 +291,10 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
     // (extra & 1).  The birth rank -- one workgroup that needs nothing but the frame's birth cloud -- is the last one
     // (extra & 2).
     // They come FIRST in the grid so that they run beside the tiles instead of after them.
-    if (blockIdx.x == 0 && tid == 0 && s.fpar->from_ring && (unsigned)*s.ring_seq == s.fpar->ring_pos)
-        *s.ring_seq = (int)(s.fpar->ring_pos + 1u);   // k_obs_points is done with the ring slot
+    if (blockIdx.x == 0 && tid == 0 && s.fpar->from_ring && (unsigned)*s.ring_seq == s.fpar->ring_pos) {
+        *s.ring_seq = (int)(s.fpar->ring_pos + 1u);   // k_obs_points is done with the ring slot ...
+        s.hint_out[2] = (int)(s.fpar->ring_pos + 1u); // ... and with the cloud it read over the bus (dspmap_update refills that slot 64 frames on)
+    }
     const int ngather = (extra & 1) ? (d.np + NW - 1) / NW : 0, nextra = ngather + ((extra & 2) ? 1 : 0);
     if ((int)blockIdx.x < nextra) {
         const int x = (int)blockIdx.x;
@@ -329,13 +331,14 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
     const bool inr = lv < d.v_loc;
     const int lvs = inr ? lv : 0;
     u64 mword[MW], live[MW];
-    bool any = false;
+    bool any = false, nb_any = false;
 #pragma unroll
     for (int e = 0; e < MW; ++e) {
         mword[e] = 0ull; u64 nbword = 0ull;
         if (inr) { mword[e] = s.mask[(size_t)lv * MW + e]; nbword = s.nbmask[(size_t)lv * MW + e]; }
         live[e] = mword[e] & ~nbword;  // particles born/seeded this frame (flag 15) are not predicted (:649)
         any |= live[e] != 0ull;
+        nb_any |= nbword != 0ull;      // ... and their velocities are not looked at: the tile cannot be called static (below)
         if (wave == 0) {
             s_keep[e * 64 + l] = live[e]; s_ex[e * 64 + l] = 0ull;
             if (inr) omask[(size_t)lv * MW + e] = mword[e] | nbword;   // occupancy before this prediction (k_place: arrivals from lower voxels)
@@ -372,7 +375,11 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
     // born since -- : the velocity rows are not fetched (a third of what this sweep reads)
     const int tflag = __builtin_amdgcn_readfirstlane(s.tile_moving[BX]);
     const bool tmov = HASVZ || tflag != 0 || !d.tile_skip;
-    bool mv_seen = false;                             // a live particle with a velocity (this lane)
+    // a live particle with a velocity (this lane).  Particles that are not predicted this frame (flag 15: a constructor pre-fill on a
+    // non-empty map, imported newborn records, a stage-API birth without a resampling) keep whatever velocity they have and this
+    // sweep does not read it: a tile that holds one counts as moving -- its velocity cells are NOT zeroed (the reference never
+    // touches an unpredicted particle, :649)
+    bool mv_seen = nb_any;
     const float zadd = dt * 0.f + odz;                // :667, the same for every particle
     // buffer descriptors of this tile's share of the three field arrays (the tile's cells are contiguous: [slot][64]): a
     // lane's byte offset is ONE register whatever the row, the row enters as a scalar offset

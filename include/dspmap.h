@@ -146,6 +146,10 @@ enum dspmap_param {
                                        its velocity cells zeroed, and a static particle that arrives there is placed without a velocity store (the
                                        reference never gives a static particle a velocity, :653); 0 = every tile is treated as if something moved in it.
                                        Same result either way, bit for bit (the diagnostic the differential GPU test switches) */
+    DSPMAP_P_HOST_CLOUD_DIRECT = 23,/* 1 (default): dspmap_update (the host-pointer update() of the reference, :181) copies the caller's cloud into a
+                                       slot of a pinned, device-mapped ring and the captured frame's first kernel reads it over the bus: the frame is
+                                       ONE graph launch (needs DSPMAP_P_USE_GRAPH and the device velocity estimator); 0 = pinned staging + one H2D
+                                       copy + an event in front of the graph (rounds 1-4).  Same result either way */
     DSPMAP_P_PAIR_CULL_SIGMAS = 13  /* mapUpdate evaluates a (particle, observation) pair only if their ranges differ by at most this many
                                        sigma_ob (default 9: the dropped terms are < 1e-19 and zero on the fixed-point Ck grid);
                                        a huge value evaluates every pair of the neighbourhood like the reference's loops */

@@ -92,6 +92,21 @@ def main(tag):
         out["commit"] = None
         print("commit not recorded:", e)
     out["tag"] = tag
+    # issue-slot shares (SQ counters) per workload and kernel: bench.py's per-kernel ceiling table prices the VALU-bound kernels with them
+    out["sq"] = {}
+    for w in ("B", "C_sat"):
+        try:
+            js = json.load(open(os.path.join(g, "%s_sq_%s.json" % (tag, w))))
+        except OSError:
+            continue
+        d = {}
+        for k, v in js.items():
+            a = {c: v.get(c, {}).get("avg", 0.0) for c in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "duration_ns")}
+            if a["SQ_WAVES"] <= 0 or a["duration_ns"] <= 0:
+                continue
+            d[base(k)] = {"valu_issue": round(4.0 * a["SQ_ACTIVE_INST_VALU"] / (a["duration_ns"] * 2.4 * 1024.0), 4),
+                          "waiting": round(a["SQ_WAIT_ANY"] / max(a["SQ_WAVE_CYCLES"], 1.0), 4)}
+        out["sq"][w] = d
     json.dump(out, open(os.path.join(HERE, "pmc_traffic.json"), "w"), indent=1)
     # issue-slot picture (SQ counters)
     sq = ["# %s -- issue slots of the frame's kernels (SQ counters)\n" % tag,

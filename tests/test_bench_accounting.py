@@ -83,3 +83,31 @@ def test_traffic_is_withheld_when_the_kernel_sources_changed():
     r = b.roofline_block({"predict": 0.04, "claim": 0.017, "ck_partial": 0.026, "weight": 0.018, "resample": 0.045},
                          B_RUN, V, T, 1, {}, "B", traffic_meta=stale)
     assert r["traffic"] is None and "other kernel sources" in r["traffic_source"] and "traffic_frame" not in r
+
+
+def test_ceiling_table_prices_every_kernel_with_its_own_ruler():
+    """bench.py: saturated_132x132x60.ceilings: sweeps at the measured skeleton rate on their PMC bytes, k_place at the
+    scattered-store rate, pair kernels at VALU issue 1.0, latency chains at >= one dependent launch; the frame at its ceilings is
+    faster than the frame measured, and no kernel beats its own ceiling."""
+    b = _bench()
+    tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    kus = {"k_predict": 247.5, "k_place": 94.8, "k_resample": 97.9, "k_ck_partial": 62.3, "k_weight": 53.1, "k_pyr_prepare": 36.8,
+           "k_birth_insert": 15.7, "k_obs_points": 7.2, "k_spin": 21.0}
+    pmc = {"k_predict": {"hbm_bytes": 966481836}, "k_resample": {"hbm_bytes": 358908746}, "k_pyr_prepare": {"hbm_bytes": 42801419},
+           "k_birth_insert": {"hbm_bytes": 12578555}, "k_obs_points": {"hbm_bytes": 613662}}
+    sq = {"k_ck_partial": {"valu_issue": 0.50}, "k_weight": {"valu_issue": 0.61}}
+    V, T = 132 * 132 * 60, 6
+    ct = b.ceiling_table(C_SAT, b.b_alg(C_SAT, V, T), 0.6584, kus, pmc, sq, 5.3)
+    pk = ct["per_kernel"]
+    assert "k_spin" not in pk and set(kus) - {"k_spin"} == set(pk)
+    assert abs(pk["k_predict"]["ceiling_us"] - 966481836 / 5.3e12 * 1e6) < 0.1
+    assert abs(pk["k_weight"]["ceiling_us"] - 53.1 * 0.61) < 0.1 and "VALU" in pk["k_weight"]["ruler"]
+    assert "scattered stores" in pk["k_place"]["ruler"] and 60 < pk["k_place"]["ceiling_us"] < 90
+    assert pk["k_obs_points"]["ceiling_us"] == 5.0                      # a latency chain never prices below one dependent launch
+    assert all(v["achieved_over_ceiling"] >= 1.0 for v in pk.values())
+    assert ct["sum_of_ceilings_us"] < ct["sum_of_kernels_us"] <= 0.6584e3
+    assert ct["frac_of_8TBps_now"] < ct["frac_of_8TBps_if_every_kernel_sat_on_its_ceiling"] < 1.0
+    json.dumps(ct)
+    # without PMC / SQ data (a run on kernel sources nobody profiled yet) the table still comes out, on algorithmic bytes
+    ct2 = b.ceiling_table(C_SAT, b.b_alg(C_SAT, V, T), 0.6584, kus, {}, {}, 5.3)
+    assert "algorithmic" in ct2["per_kernel"]["k_predict"]["ruler"] and ct2["per_kernel"]["k_weight"]["achieved_over_ceiling"] == 1.0

@@ -173,3 +173,33 @@ def test_rendezvous_file_is_matched_by_its_nonce_string(dsp, tmp_path, monkeypat
     monkeypatch.setenv("DSPMAP_RDZV_NONCE", "run-43")                      # a later launch does not take the old file
     open(path, "wb").write(b"DSPRDZV1" + nonce.ljust(120, b"\0") + uid)
     assert L.dspmap_debug_rdzv_wait(path.encode(), 30, out) == 0
+
+
+def test_rebuild_decision_follows_the_source_hash_not_the_clock(dsp, tmp_path, monkeypatch):
+    """build_ext.needs_build() compares a sha256 of the sources / headers / flags with the one stored next to the .so when it was
+    built: a tree that arrives by a `gpurun` push (fresh mtimes everywhere) is not rebuilt needlessly and -- the dangerous
+    direction -- a .so that is NEWER than edited sources is not trusted."""
+    import build_ext
+    assert os.path.exists(build_ext.LIB) and os.path.exists(build_ext.STAMP)
+    assert open(build_ext.STAMP).read().strip() == build_ext.source_hash() and not build_ext.needs_build()
+    os.utime(os.path.join(build_ext.CSRC, build_ext.SOURCES[0]))          # a newer clock on a source changes nothing
+    assert not build_ext.needs_build()
+    monkeypatch.setattr(build_ext, "FLAGS", build_ext.FLAGS + ["-DX=1"])   # other flags = another library
+    assert build_ext.needs_build()
+    monkeypatch.undo()
+    monkeypatch.setattr(build_ext, "STAMP", str(tmp_path / "missing"))     # no record of what the .so was built from
+    assert build_ext.needs_build()
+
+
+def test_reference_caller_type_checks_against_the_drop_in_header():
+    """tools/check_reference_caller.sh: g++ -fsyntax-only on the reference's own src/map_sim_example.cpp, in place, against
+    include/dsp_dynamic.h (declaration-only ROS / PCL / Eigen stubs in a temp dir).  Only where the reference tree exists (the build
+    container); the GPU box has none."""
+    import shutil
+    import subprocess
+    import pytest
+    if not os.path.exists("/root/reference/src/map_sim_example.cpp") or not shutil.which("g++"):
+        pytest.skip("no reference tree here")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "check_reference_caller.sh")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "OK: the reference's caller type-checks" in r.stdout
