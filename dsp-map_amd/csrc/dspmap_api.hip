@@ -186,7 +186,7 @@ static void free_dev(dspmap* m) {
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, s.fov_rec, s.fov_slot, s.fov_key, s.fov_spos, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt, s.in_n, s.pmask, s.ta, s.dflag, s.dirty,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.ro_cnt, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
-                    s.tile_moving, m->k.ro_stat, m->k.part_predict, m->k.tile_fov, s.tile_live, s.fut_dirty, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf, s.birth_cvr};
+                    s.tile_moving, m->k.ro_stat, m->k.part_predict, m->k.tile_fov, m->k.view_list, s.tile_live, s.fut_dirty, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf, s.birth_cvr};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
     if (m->nbsnap_buf) chk(hipFree(m->nbsnap_buf), "hipFree");
     {
@@ -410,6 +410,7 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, hipMemset(s.tile_moving, 1, sizeof(int) * (size_t)k.ntiles));
     HIPCHK(m, dalloc(&s.fut_dirty, (size_t)k.ntiles));
     HIPCHK(m, hipMemset(s.fut_dirty, 0, sizeof(int) * (size_t)k.ntiles));   // (the accumulators start zeroed)
+    HIPCHK(m, dalloc(&k.view_list, (size_t)k.ntiles));
     HIPCHK(m, dalloc(&k.tile_fov, (size_t)k.ntiles));
     HIPCHK(m, hipMemset(k.tile_fov, 0xff, sizeof(int) * (size_t)k.ntiles));   // no frame's tag
     HIPCHK(m, dalloc(&k.part_resample, (size_t)k.nblk_sweep * 4));
@@ -713,6 +714,7 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     // more than the overlap gives: 264x264x80 filled by the depth stream 0.445 -> 0.434 ms, 132x132x60 0.232 -> 0.228; saturated
     // maps keep the split: 0.659 against 0.667 ms and 4.61 against 4.80 ms, interleaved runs on one box)
     const bool split = !fork && !m->prof && (!c.sparse || m->place_split_tiles <= 1) && c.k.ntiles >= m->place_split_tiles;   // (1 = always, as documented)
+    c.place_split = split;
     dspmap_prof_mark(m, 0);
     if (!fork) {
         launch_setup_and_bin(c, pts_grid, false, m->frame_ring ? m->ring_dev : nullptr, DSPMAP_RING - 1);   // the gather rides on k_predict's launch

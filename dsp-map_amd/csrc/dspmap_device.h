@@ -20,6 +20,10 @@ __device__ __forceinline__ void sload_i3(const int* p0, const int* p1, const int
     asm volatile("s_load_dword %0, %3, 0x0\n\ts_load_dword %1, %4, 0x0\n\ts_load_dword %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
                  : "=&s"(v0), "=&s"(v1), "=&s"(v2) : "s"(p0), "s"(p1), "s"(p2));
 }
+__device__ __forceinline__ void sload_i4(const int* p0, const int* p1, const int* p2, const int* p3, int& v0, int& v1, int& v2, int& v3) {   // four at once
+    asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\ts_load_dword %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3) : "s"(p0), "s"(p1), "s"(p2), "s"(p3));
+}
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
 // ---- wavefront scan / reduction on the DPP network (no LDS traffic).

@@ -14,6 +14,9 @@ struct KernelScratch {
     int* part_predict;  // [ntiles*4]
     int* tile_fov;      // [ntiles] 1 = a particle inside this tile may lie in the field of view (k_predict, conservative box test):
                         // the placement of the other tiles registers nothing in a pyramid and may run beside the pair kernels
+    int* view_list;     // [ntiles] the tiles with a view on the field of view this frame, in no particular order (FrameScalars::n_view_tiles of them):
+                        // written by extra workgroups of k_predict when the frame splits its placement, walked by the placement that precedes
+                        // the pair kernels INSTEAD of all the tiles
     int* part_resample; // [ntiles rounded up to 4] live particles per tile after resampling
     int* vb_cnt;        // [v_loc] children per destination voxel this frame (birth ordering)
     int* vb_idx;        // [v_loc*128] their birth indices
@@ -49,6 +52,8 @@ struct LaunchCtx {
     bool sweep_rev = false;   // this frame's k_predict / k_resample walk the tiles from the last one down and k_place from the first one up
                               // (the next frame the other way round): every tile sweep starts where its predecessor ended (Infinity Cache)
     bool resample_rev = false;   // k_resample walks the tiles from the last one down (after a k_place that ended there)
+    bool place_split = false; // this frame places the arrivals of the tiles with a view first (launch_claim sel = 1) and the others beside the pair
+                              // kernels (sel = 0): k_predict leaves the list of the tiles with a view (KernelScratch::view_list)
     bool sparse = false; // most tiles hold nothing (dspmap::sparse_mode): k_predict's variant that leaves such tiles first
 };
 

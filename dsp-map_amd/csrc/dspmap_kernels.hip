@@ -57,7 +57,7 @@ __global__ void k_reset(MapDims d, DevState s, int flags) {
     if (flags & RESET_PRED) {
         for (int i = gt; i < d.np; i += gn) s.pyr_cnt[i] = 0;
         if (gt == 0) {
-            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->n_pyr_removed = 0; s.fs->n_dirty = 0; s.fs->n_overflow_inexact = 0; s.fs->n_place_vf = 0; s.fs->n_place_pf = 0; s.fs->pred_epoch = s.fs->pred_epoch + 1; s.fs->live_hint = s.fs->live_acc; s.hint_out[0] = s.fs->live_acc; s.fs->live_acc = 0; s.hint_out[1] = s.fs->mv_acc; s.fs->mv_acc = 0;
+            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->n_pyr_removed = 0; s.fs->n_dirty = 0; s.fs->n_overflow_inexact = 0; s.fs->n_place_vf = 0; s.fs->n_place_pf = 0; s.fs->n_view_tiles = 0; s.fs->pred_epoch = s.fs->pred_epoch + 1; s.fs->live_hint = s.fs->live_acc; s.hint_out[0] = s.fs->live_acc; s.fs->live_acc = 0; s.hint_out[1] = s.fs->mv_acc; s.fs->mv_acc = 0;
         }
     }
 }
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) k_obs_points(MapDims d, DevState s, const
         if (gt == 0) {
             s.fs->cur_pos[0] = cpx; s.fs->cur_pos[1] = cpy; s.fs->cur_pos[2] = cpz;
             s.fs->n_valid = 0; s.fs->n_obs = 0; s.fs->has_expected_override = 0;   // k_obs_gather accumulates the first two
-            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->n_pyr_removed = 0; s.fs->n_dirty = 0; s.fs->n_overflow_inexact = 0; s.fs->n_place_vf = 0; s.fs->n_place_pf = 0; s.fs->pred_epoch = s.fs->pred_epoch + 1; s.fs->live_hint = s.fs->live_acc; s.hint_out[0] = s.fs->live_acc; s.fs->live_acc = 0; s.hint_out[1] = s.fs->mv_acc; s.fs->mv_acc = 0;
+            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->n_pyr_removed = 0; s.fs->n_dirty = 0; s.fs->n_overflow_inexact = 0; s.fs->n_place_vf = 0; s.fs->n_place_pf = 0; s.fs->n_view_tiles = 0; s.fs->pred_epoch = s.fs->pred_epoch + 1; s.fs->live_hint = s.fs->live_acc; s.hint_out[0] = s.fs->live_acc; s.fs->live_acc = 0; s.hint_out[1] = s.fs->mv_acc; s.fs->mv_acc = 0;
         }
     } else {
         for (int i = threadIdx.x; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];

@@ -243,7 +243,7 @@ template <int MW, int NW, bool HASVZ, bool SPARSE>
 __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevState s, FilterParams fp, int has_vz, int* __restrict__ part,
                                                  float4* __restrict__ mv_rec, float4* __restrict__ in_rec, int* __restrict__ in_cnt,
                                                  u64* __restrict__ expmask, const int* __restrict__ vz_pre, const u64* __restrict__ vz_q,
-                                                 u64* __restrict__ omask, int extra, int* __restrict__ tile_fov, int rev) {
+                                                 u64* __restrict__ omask, int extra, int* __restrict__ tile_fov, int rev, int* __restrict__ view_list) {
     // rev: the tiles are walked from the last one down (workgroup -> tile mapping only).  k_place always walks AGAINST the k_predict
     // before it: a large map's live rows are several times the 256 MB Infinity Cache, and a sweep that starts where the last one
     // ENDED finds its first tiles (rows, occupancy words, inbox records) there instead of in HBM -- 132x132x60 saturated:
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
     // +2-3 % at 132x132x60 saturated.)
     int tflags = -1;   // bit 0: the tile holds particles, bit 1: its future accumulators are to be zeroed; -1: not looked at yet
     if (SPARSE) {
-        const int nextra0 = ((extra & 1) ? (d.np + NW - 1) / NW : 0) + ((extra & 2) ? 1 : 0);
+        const int nextra0 = ((extra & 1) ? (d.np + NW - 1) / NW : 0) + ((extra & 2) ? 1 : 0) + ((extra & 4) ? (((d.v_loc + 63) >> 6) + 64 * NW - 1) / (64 * NW) : 0);
         if ((int)blockIdx.x >= nextra0) {
             const int bq0 = (int)blockIdx.x - nextra0;
             const int bx0 = rev ? (int)gridDim.x - nextra0 - 1 - bq0 : bq0;
@@ -295,20 +295,43 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
         *s.ring_seq = (int)(s.fpar->ring_pos + 1u);   // k_obs_points is done with the ring slot ...
         s.hint_out[2] = (int)(s.fpar->ring_pos + 1u); // ... and with the cloud it read over the bus (dspmap_update refills that slot 64 frames on)
     }
-    const int ngather = (extra & 1) ? (d.np + NW - 1) / NW : 0, nextra = ngather + ((extra & 2) ? 1 : 0);
+    // (extra & 4) a frame that splits its placement: further workgroups list the tiles whose box can intersect the field of view --
+    // every tile of the map, 64 per wave, one atomic per wave --, so that the placement that precedes the pair kernels walks THOSE
+    // (a few per cent of a large map's tiles) instead of launching a workgroup per tile that finds out it has nothing to do: on the
+    // saturated 132x132x60 map that launch took 65 us for 5 % of the arrivals (round 5).  The test needs the frame's planes only.
+    const int ntl = (d.v_loc + 63) >> 6;
+    const int ngather = (extra & 1) ? (d.np + NW - 1) / NW : 0, nrank = (extra & 2) ? 1 : 0;
+    const int nviewb = (extra & 4) ? (ntl + 64 * NW - 1) / (64 * NW) : 0, nextra = ngather + nrank + nviewb;
     if ((int)blockIdx.x < nextra) {
         const int x = (int)blockIdx.x;
         if (x < ngather) {
             const int b = x * NW + wave;
             if (b < d.np) obs_gather_wave(d, s, b);
-        } else {
+        } else if (x < ngather + nrank) {
             birth_rank_block(d, s, fp);
+        } else {
+            const int t0 = ((x - ngather - nrank) * NW + wave) * 64;   // this wave's 64 tiles
+            const int ep = s.fpar->epoch;
+            u64 bits = 0ull;
+            for (int i = 0; i < 64 && t0 + i < ntl; ++i)
+                if (tile_view_test(d, s, t0 + i, l)) bits |= 1ull << i;   // (wave-uniform result)
+            if (t0 + l < ntl) tile_fov[t0 + l] = (ep << 1) | (int)((bits >> l) & 1ull);   // every tile gets this frame's tag, visited by the sweep or not
+            const int nv = (int)__popcll(bits);
+            int base = 0;
+            if (nv && l == 0) base = atomicAdd(&s.fs->n_view_tiles, nv);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if ((bits >> l) & 1ull) view_list[base + (int)__popcll(bits & lanemask_lt())] = t0 + l;
         }
         return;
     }
     const int BX = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x - nextra;   // tile index
     const int lv = BX * 64 + l;   // all four waves of the block look at the same tile
-    if (!SPARSE) tflags = (s.tile_live[BX] ? 1 : 0) | (s.fpar->clear_fut ? 2 : 0);   // (a dense map: nearly every tile's accumulators were added to -- not worth a look at fut_dirty)
+    int tflag_early = 1;   // (!SPARSE) the tile's tile_moving flag, fetched with its other flags
+    if (!SPARSE) {   // (a dense map: nearly every tile's accumulators were added to -- not worth a look at fut_dirty)
+        int t_live, f_clear;
+        sload_i3(s.tile_live + BX, s.tile_moving + BX, &s.fpar->clear_fut, t_live, tflag_early, f_clear);   // one scalar round trip
+        tflags = (t_live ? 1 : 0) | (f_clear ? 2 : 0);
+    }
     if (tflags & 2) {
         // clearOccupancyMapPrediction (:431-438) was requested since the last frame: this tile's share of the
         // future accumulators is zeroed here instead of by two extra memset launches per frame -- if anything was added to
@@ -326,7 +349,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
         // the tile's view on the field of view, tagged with the frame: a tile that was skipped here and receives arrivals is
         // tested by k_place itself
         const int v = tile_view_test(d, s, BX, l);
-        if (l == 0) { tile_fov[BX] = (s.fpar->epoch << 1) | v; s_view = v; }
+        if (l == 0) { if (!(extra & 4)) tile_fov[BX] = (s.fpar->epoch << 1) | v; s_view = v; }   // (extra & 4: the listing waves tag every tile)
     }
     const bool inr = lv < d.v_loc;
     const int lvs = inr ? lv : 0;
@@ -373,7 +396,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
     const bool view = s_view != 0;                    // can a particle of this tile lie in the field of view at all?
     // every live particle of the tile has velocity (0, 0) -- k_predict's own finding of the last frame, plus whatever arrived or was
     // born since -- : the velocity rows are not fetched (a third of what this sweep reads)
-    const int tflag = __builtin_amdgcn_readfirstlane(s.tile_moving[BX]);
+    const int tflag = SPARSE ? __builtin_amdgcn_readfirstlane(s.tile_moving[BX]) : tflag_early;   // (nobody writes a tile's flag between k_resample and this sweep)
     const bool tmov = HASVZ || tflag != 0 || !d.tile_skip;
     // a live particle with a velocity (this lane).  Particles that are not predicted this frame (flag 15: a constructor pre-fill on a
     // non-empty map, imported newborn records, a stage-API birth without a resampling) keep whatever velocity they have and this
@@ -663,7 +686,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
 template <int MW>
 __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, const float4* __restrict__ in_rec, int* __restrict__ in_cnt,
                                            const u64* __restrict__ omask,
-                                           float4* __restrict__ stage, const int BX, const int n_all) {   // n_all = in_cnt[BX] > 0
+                                           float4* __restrict__ stage, const int BX, const int n_all, const bool was_live, const bool t_moving_in) {   // n_all = in_cnt[BX] > 0
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
     __shared__ u64 s_cur[MW * 64], s_org[MW * 64], s_new[MW * 64], s_own[MW * 64];
@@ -671,8 +694,8 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
     __shared__ int s_bk[PLACE_MAX];              // source keys of the arrivals, bucketed by destination lane
     __shared__ int s_cnt[2];
     const int tid = threadIdx.x;
-    const bool was_live = s.tile_live[BX] != 0;   // an empty tile was skipped by k_predict: its omask words are stale (and zero in truth)
-    const bool t_moving = s.tile_moving[BX] != 0 || !d.tile_skip;   // as k_predict left it (this workgroup is the only one that raises it during the placement)
+    // was_live: an empty tile was skipped by k_predict: its omask words are stale (and zero in truth)
+    const bool t_moving = t_moving_in || !d.tile_skip;   // tile_moving as k_predict left it (this workgroup is the only one that raises it during the placement)
     const int cap = 64 * d.slots;
     const int n = min(n_all, cap);
     const bool in_lds = n <= PLACE_MAX;
@@ -851,7 +874,8 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
                                                int* __restrict__ in_cnt, int has_vz, int tab_n,
                                                const u64* __restrict__ omask, FilterParams fp, float4* __restrict__ child,
                                                int* __restrict__ vb_cnt, int* __restrict__ vb_idx, int nchild, int t0, int n0, int t1, int n1,
-                                               const int* __restrict__ tile_fov, int sel, float4* __restrict__ stage, int rev) {
+                                               const int* __restrict__ tile_fov, int sel, float4* __restrict__ stage, int rev,
+                                               const int* __restrict__ view_list) {
     // whole frame: workgroups behind the tiles generate the frame's newborn children (k_birth_children's job; needs the
     // birth cloud and the rank only, both done before this launch)
     // (the first `nchild` workgroups: they run beside the tiles, not after them).
@@ -862,31 +886,56 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
         birth_child_thread(d, s, fp, child, vb_cnt, vb_idx, (int)(blockIdx.x * 256 + threadIdx.x));
         return;
     }
-    {   // A workgroup whose ONLY tile received nothing leaves here, before the loop below is set up: the loop's invariants (hoisted in
-        // front of it by the compiler, ~100 vector instructions with the scalar registers it parks in lanes) were what a sparse map's
-        // placement spent its time on -- 87 120 workgroups, 12 k with arrivals: 0.76 of the chip's VALU issue slots, 77 us
-        const int bq = (int)blockIdx.x - nchild, stride = (int)gridDim.x - nchild;
-        if (bq < n0 + n1 && bq + stride >= n0 + n1) {
-            const int bqr = rev ? n0 + n1 - 1 - bq : bq;
-            const int BX = bqr < n0 ? t0 + bqr : t1 + (bqr - n0);
-            if (!(has_vz && BX == 0) && sload_i(in_cnt + BX) == 0) return;
+    // Everything a workgroup needs to know about a tile before it decides to work on it -- arrivals, the tile's view tag, its live
+    // and moving flags -- comes in ONE scalar round trip (round 5; there were three dependent ones, paid by every tile of both
+    // launches of a split placement: on a saturated map nearly every tile has arrivals, so the 85 % of the tiles that belong to the
+    // OTHER launch cost the launch that skips them most of its time -- 65 us for the tiles with a view, 89 us for the 768 strided
+    // workgroups of the side launch, profiles/r04_i_C_sat_timeline.md).
+    const int nt = n0 + n1, bq0 = (int)blockIdx.x - nchild, stride = (int)gridDim.x - nchild;
+    if (sel == 1 && view_list) {
+        // the tiles with a view, from k_predict's list (a frame that splits its placement): a few per cent of a large map's tiles, so the
+        // launch is a few hundred workgroups that all have work instead of one per tile
+        if (has_vz && bq0 == 0 && threadIdx.x == 0)   // k_predict drew 3 table values per ranked particle (:655-657)
+            s.fs->v_cur = (int)(((long long)s.fs->v_cur + 3ll * (long long)s.fs->occupied_count) % tab_n);
+        const int nv = sload_i(&s.fs->n_view_tiles);
+        for (int p = bq0; p < nv; p += stride) {
+            const int BX = sload_i(view_list + p);
+            int n_in, tf, t_live, t_mov;
+            sload_i4(in_cnt + BX, tile_fov + BX, s.tile_live + BX, s.tile_moving + BX, n_in, tf, t_live, t_mov);
+            if (n_in == 0) continue;
+            place_tile<MW>(d, s, in_rec, in_cnt, omask, stage, BX, n_in, t_live != 0, t_mov != 0);
+            __syncthreads();
+        }
+        return;
+    }
+    if (bq0 >= nt) return;
+    const int epoch = sel >= 0 ? sload_i(&s.fpar->epoch) : 0;
+    int n_in, tf, t_live, t_mov;
+    {   // the first tile's flags; a workgroup whose ONLY tile has nothing for it leaves HERE, before the loop below is set up: the
+        // invariants the compiler hoists in front of it (~100 vector instructions with the scalar registers it parks in lanes) were
+        // what a sparse map's placement spent its time on -- 87 120 workgroups, 12 k with arrivals
+        const int bqr = rev ? nt - 1 - bq0 : bq0;
+        const int BX = bqr < n0 ? t0 + bqr : t1 + (bqr - n0);
+        sload_i4(in_cnt + BX, tile_fov + BX, s.tile_live + BX, s.tile_moving + BX, n_in, tf, t_live, t_mov);
+        if (bq0 + stride >= nt && !(has_vz && BX == 0)) {
+            if (n_in == 0) return;
+            if (sel >= 0 && (tf >> 1) == epoch && ((tf & 1) != 0) != (sel != 0)) return;
         }
     }
-    for (int bq = (int)blockIdx.x - nchild; bq < n0 + n1; bq += (int)gridDim.x - nchild) {
-        const int bqr = rev ? n0 + n1 - 1 - bq : bq;           // (the launch's tiles from the last one down: see k_predict)
+    for (int bq = bq0; bq < nt; bq += stride) {
+        const int bqr = rev ? nt - 1 - bq : bq;                 // (the launch's tiles from the last one down: see k_predict)
         const int BX = bqr < n0 ? t0 + bqr : t1 + (bqr - n0);   // tile index
         if (has_vz && BX == 0 && sel != 0 && threadIdx.x == 0)   // k_predict drew 3 table values per ranked particle (:655-657)
             s.fs->v_cur = (int)(((long long)s.fs->v_cur + 3ll * (long long)s.fs->occupied_count) % tab_n);
-        const int n_in = sload_i(in_cnt + BX);
+        if (bq != bq0) sload_i4(in_cnt + BX, tile_fov + BX, s.tile_live + BX, s.tile_moving + BX, n_in, tf, t_live, t_mov);
         if (n_in == 0) continue;   // (no arrivals -- or the tile's owner is done with them)
         if (sel >= 0) {   // a split placement: the other launch owns the tiles of the other kind
-            const int tf = tile_fov[BX];
             int fv = tf & 1;
             // k_predict skipped the tile (empty) and particles arrive in it: its view is tested here, by both launches alike
-            if ((tf >> 1) != s.fpar->epoch) fv = tile_view_test(d, s, BX, lane_id());
+            if ((tf >> 1) != epoch) fv = tile_view_test(d, s, BX, lane_id());
             if ((fv != 0) != (sel != 0)) continue;
         }
-        place_tile<MW>(d, s, in_rec, in_cnt, omask, stage, BX, n_in);   // (the owner's view of in_cnt is stable: only the owner resets it)
+        place_tile<MW>(d, s, in_rec, in_cnt, omask, stage, BX, n_in, t_live != 0, t_mov != 0);   // (the owner's view of in_cnt is stable: only the owner resets it)
         __syncthreads();   // the tile's LDS tables are re-used by the next one
     }
 }
@@ -2038,8 +2087,8 @@ void launch_spin(const LaunchCtx& c, int us) {   // wall_clock64 ticks at 100 MH
     if (us > 0) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c.stream, (long long)us * 100);
 }
 void launch_predict_only(const LaunchCtx& c, bool with_gather, bool with_rank) {
-    const int extra = (with_gather ? 1 : 0) | (with_rank ? 2 : 0);
-    const unsigned xb = (with_gather ? (c.d.np + 3) / 4 : 0) + (with_rank ? 1 : 0);
+    const int extra = (with_gather ? 1 : 0) | (with_rank ? 2 : 0) | (c.place_split ? 4 : 0);   // 4: list the tiles with a view for the split placement
+    const unsigned xb = (with_gather ? (c.d.np + 3) / 4 : 0) + (with_rank ? 1 : 0) + (c.place_split ? (c.k.ntiles + 255) / 256 : 0);
     const KernelScratch* k = &c.k;
     if (c.s.vz0) {   // constructor-seeded particles take their velocity noise in the reference's sweep order
         const int nblk = (c.d.v_loc + 255) / 256;
@@ -2048,7 +2097,7 @@ void launch_predict_only(const LaunchCtx& c, bool with_gather, bool with_rank) {
         launch_scan_blocks(c, nblk);   // blk_cnt -> exclusive, total -> fs->occupied_count
     }
 #define PRED_LAUNCH(MWV, VZ, SP) hipLaunchKernelGGL((k_predict<MWV, 4, VZ, SP>), dim3(k->ntiles + xb), dim3(256), 0, c.stream, c.d, c.s, c.fp, VZ ? 1 : 0, \
-                                                k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask, extra, k->tile_fov, c.sweep_rev ? 1 : 0)
+                                                k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask, extra, k->tile_fov, c.sweep_rev ? 1 : 0, k->view_list)
 #define PRED_LAUNCH2(MWV, VZ) do { if (c.sparse) PRED_LAUNCH(MWV, VZ, true); else PRED_LAUNCH(MWV, VZ, false); } while (0)
     if (c.d.mw == 1) { if (c.s.vz0) PRED_LAUNCH2(1, true); else PRED_LAUNCH2(1, false); }
     else { if (c.s.vz0) PRED_LAUNCH2(2, true); else PRED_LAUNCH2(2, false); }
@@ -2068,8 +2117,10 @@ void launch_claim(const LaunchCtx& c, int n_birth_grid, int part, int tile_lo, i
     // and the wave slots, registers and LDS it leaves free are what the pair kernels run in
     unsigned grid = (unsigned)(n0 + n1) + xb;
     if (sel == 0) grid = std::min(grid, (unsigned)(PLACE_SIDE_WG * c.n_cu));
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec, c.sweep_rev ? 0 : 1);
-    else hipLaunchKernelGGL(k_place<2>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec, c.sweep_rev ? 0 : 1);
+    const int* vlist = (sel == 1 && c.place_split && part == 0) ? k->view_list : nullptr;   // (k_predict listed the tiles with a view)
+    if (vlist) grid = std::min((unsigned)(n0 + n1), (unsigned)(PLACE_LB * c.n_cu)) + xb;    // one round of workgroups walks the list
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec, c.sweep_rev ? 0 : 1, vlist);
+    else hipLaunchKernelGGL(k_place<2>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec, c.sweep_rev ? 0 : 1, vlist);
 }
 void launch_predict(const LaunchCtx& c, bool with_gather) {
     launch_predict_only(c, with_gather, false);

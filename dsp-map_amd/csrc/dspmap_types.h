@@ -105,6 +105,8 @@ struct FrameScalars {
     int view_epoch, stale_n;
     int n_birth_ovf;    // entries of DevState::birth_ovf (reset by the birth rank, which precedes every generation of children)
     int est_n;          // length of the birth cloud the device velocity estimator wrote (kept when a view is empty, :1379)
+    int n_view_tiles;   // entries of KernelScratch::view_list: the tiles whose box can intersect the field of view this frame (k_predict's extra
+                        // workgroups of a split placement; reset with the pyramid lists)
     int pred_epoch;     // bumped by whatever resets the pyramid lists for a prediction (k_reset / k_obs_points): k_place stamps the tiles it
                         // served with it, k_place_fix only trusts a tile's inbox / pmask when the stamp is this prediction's
 };
