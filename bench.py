@@ -235,6 +235,40 @@ def ceiling_table(cnt, b_alg_bytes, frame_ms, kernel_us, pmc, sq, skeleton_TBps,
     return out
 
 
+XGMI_COLLECTIVE_US = 30.0   # assumed latency of one small collective over xGMI (20 - 40 us); never measured here
+
+
+def balanced_ranges(layer_cost, world):
+    """contiguous z ranges with (nearly) equal summed cost: cut the prefix sum of the per-layer costs into `world` equal parts, every
+    slab at least one layer"""
+    nz = len(layer_cost)
+    tot = float(sum(layer_cost))
+    cuts, acc, z = [0], 0.0, 0
+    for r in range(1, world):
+        target = tot * r / world
+        while z < nz - (world - r) and (acc + layer_cost[z] <= target or z < cuts[-1] + 1):
+            acc += layer_cost[z]; z += 1
+        # the cut closer to the target
+        if z < nz - (world - r) and z > cuts[-1] + 0 and abs(acc + layer_cost[z] - target) < abs(acc - target):
+            acc += layer_cost[z]; z += 1
+        cuts.append(z)
+    cuts.append(nz)
+    return [(cuts[i], cuts[i + 1]) for i in range(world)]
+
+
+SEGMENTS = ((0,), (1, 2, 4), (5,), (6,))   # phases between two collectives: begin | exchange .. Ck | weights + split | births + resampling
+
+
+def critical_path(tab, n, select_ran):
+    """tab[slab][phase] mean ms (slab n = the group's stand-ins for the collectives).  Every collective is a barrier (the neighbour
+    exchange only between neighbours: treated as one): between two of them a rank runs its phases back to back, so the frame's critical
+    path is the sum over those SEGMENTS of the slowest slab's segment -- + a rank's share of the list selection (measured for all slabs
+    together) in the frames that run it."""
+    per_seg = [max(sum(tab[i][ph] for ph in seg) for i in range(n)) for seg in SEGMENTS]
+    sel = tab[n][3] / n if select_ran else 0.0
+    return sum(per_seg) + sel, per_seg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,6 +279,8 @@ def main():
     ap.add_argument("--estimator", type=int, default=2, help="velocity estimator of the realistic workloads: 0 static tags, 1 host stage, 2 device (default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the saturated extra measurements")
+    ap.add_argument("--only", default="", help="comma list: run only these extra blocks of the default line (saturated, realistic, rollout, variants, "
+                                              "host, node, preprocess, origin, projection); the contract measurement always runs")
     args = ap.parse_args()
 
     import numpy as np
@@ -405,6 +441,11 @@ def main():
         cnt_all["message_records"] = rk.map.L.dspmap_mgpu_message_records(rk.map.h)
         return rk.map, frames, dt, cnt_all, None
 
+    only = set(x for x in args.only.split(",") if x)
+
+    def want(name):
+        return rank == 0 and not sharded_run and not args.no_extra and wl_name == "B" and (not only or name in only)
+
     # ------------------------------------------------------------------ main measurement
     if not sharded_run:
         m, frames, dt, cnt, stage = measure(wl, args.steps, args.warmup, args.prefill, estimator=args.estimator if not wl["sat"] else 0)
@@ -470,7 +511,7 @@ def main():
     }
 
     # ------------------------------------------------------------------ saturated large map (C_sat): the roofline case
-    if rank == 0 and not sharded_run and not args.no_extra and wl_name == "B":
+    if want("saturated"):
         try:
             del frames
             m.close()
@@ -511,7 +552,7 @@ def main():
             result["saturated_132x132x60"] = {"error": repr(e)}
 
     # ------------------------------------------------------------------ C and E with a REALISTIC fill
-    if rank == 0 and not sharded_run and not args.no_extra and wl_name == "B":
+    if want("realistic"):
         try:
             out = {"what": "the large grids filled by the depth stream itself (empty start, particles only near surfaces) instead "
                            "of the saturated fill: what a deployed map looks like; device velocity estimator in the frame"}
@@ -528,7 +569,7 @@ def main():
             result["realistic_fill"] = {"error": repr(e)}
 
     # ------------------------------------------------------------------ config D: the future-status rollout, T = 10
-    if rank == 0 and not sharded_run and not args.no_extra and wl_name == "B":
+    if want("rollout"):
         try:
             out = {}
             for tag, vmax in (("static_fill", 0.0), ("moving_fill", 1.0)):
@@ -562,7 +603,7 @@ def main():
             result["rollout_D_132x132x60_T10"] = {"error": repr(e)}
 
     # ------------------------------------------------------------------ the metric's workload with the other birth-tag sources
-    if rank == 0 and not sharded_run and not args.no_extra and wl_name == "B":
+    if want("variants"):
         try:
             var = {}
             for tag, est, nst in (("static_tags", 0, 150), ("host_estimator", 1, 150), ("device_estimator_300_steps", 2, 300)):
@@ -582,7 +623,7 @@ def main():
             result["birth_tag_variants"] = {"error": repr(e)}
 
     # ------------------------------------------------------------------ the boundary's own call: update(float* host, ...)
-    if rank == 0 and not sharded_run and not args.no_extra and wl_name == "B":
+    if want("host"):
         try:
             mh = make_map(wl)
             if args.estimator:
@@ -621,7 +662,7 @@ def main():
             result["host_update_66x66x40"] = {"error": repr(e)}
 
     # ------------------------------------------------------------------ the reference node's loop: update() + the getter
-    if rank == 0 and not sharded_run and not args.no_extra and wl_name == "B":
+    if want("node"):
         try:
             mn = make_map(wl)
             if args.estimator:
@@ -657,7 +698,7 @@ def main():
             result["node_loop_66x66x40"] = {"error": repr(e)}
 
     # ------------------------------------------------------------------ next row: the caller's pre-processing on the device
-    if rank == 0 and not sharded_run and not args.no_extra and wl_name == "B":
+    if want("preprocess"):
         try:
             mp = make_map(wl)
             sc = scene_mod.CorridorScene(wl["nx"] * wl["res"], wl["ny"] * wl["res"], wl["nz"] * wl["res"], seed=1234, device=dev)
@@ -682,7 +723,7 @@ def main():
             result["preprocess_640x480"] = {"error": repr(e)}
 
     # ------------------------------------------------------------------ strong-scaling origin: config E on ONE GPU, unsharded
-    if rank == 0 and not args.no_extra and (wl_name == "B" or sharded_run) and os.environ.get("DSPMAP_BENCH_ORIGIN", "1") == "1":
+    if rank == 0 and not args.no_extra and (wl_name == "B" or sharded_run) and os.environ.get("DSPMAP_BENCH_ORIGIN", "1") == "1" and (sharded_run or want("origin")):
         try:
             if sharded_run:
                 m.close()
@@ -708,6 +749,110 @@ def main():
                             "line (workload B, 66x66x40)"}
         except Exception as e:
             result["single_gpu_264x264x80"] = {"error": repr(e)}
+
+    # ------------------------------------------------------------------ projected multi-GPU critical path (N > 1 is unmeasured)
+    if want("projection") and os.environ.get("DSPMAP_BENCH_PROJECTION", "1") == "1":
+        try:
+            sharded = __import__("dsp-map_amd.sharded", fromlist=["CppGroup"])
+            we = WORKLOADS["E_sat"]
+            NW = 8
+            ckw = dict(nx=we["nx"], ny=we["ny"], nz=we["nz"], res=we["res"], ppv=we["ppv"], seed=1234)
+            fre = gen_frames(we, 3 + 6, seed=1234)
+
+            def group_run(ranges):
+                g = sharded.CppGroup(D, ckw, NW, device_index=local_rank, ranges=ranges)
+                for mm in g.maps:
+                    mm.seed_uniform(we["ppv"], 0.01, 99)
+                g.create()
+
+                def run(fr, tolerant=False):
+                    for pts, pos, quat, t in fr:
+                        try:
+                            assert g.update(pts, pos, t, quat) == 1
+                        except RuntimeError as e:   # the first frames size the exchange messages (an undersized one is reported once, then raised)
+                            if not (tolerant and "exchange message" in str(e)):
+                                raise
+                        for mm in g.maps:
+                            mm.clearOccupancyMapPrediction()
+                run(fre[:3], tolerant=True)
+                g.sync()
+                g.set_profiling(True)
+                run(fre[3:])
+                g.sync()
+                tab, nf = g.phase_ms()
+                sel = any(mm.L.dspmap_mgpu_message_records(mm.h) < 0 for mm in g.maps) or tab[NW][3] > 0
+                cnts = [mm.counters() for mm in g.maps]
+                g.close()
+                return tab, sel, cnts
+
+            eq = sharded.slab_ranges(we["nz"], NW)
+            tab_eq, sel_eq, cnt_eq = group_run(eq)
+            crit_eq, per_eq = critical_path(tab_eq, NW, sel_eq)
+            # slab boundaries by measured work: every layer of a slab is charged the slab's time per layer, the prefix sum is cut in equal parts
+            layer_cost = []
+            for (z0, z1), row in zip(eq, tab_eq[:NW]):
+                layer_cost += [sum(row) / (z1 - z0)] * (z1 - z0)
+            bal = balanced_ranges(layer_cost, NW)
+            tab_b, sel_b, cnt_b = (tab_eq, sel_eq, cnt_eq) if bal == eq else group_run(bal)
+            crit_b, per_b = critical_path(tab_b, NW, sel_b)
+            ranges, tab, crit, per, selr, cnts = (bal, tab_b, crit_b, per_b, sel_b, cnt_b) if crit_b < crit_eq else (eq, tab_eq, crit_eq, per_eq, sel_eq, cnt_eq)
+            # what the RCCL calls themselves cost a rank (launch + protocol, no wire): the C++ driver with a world-1 communicator against the
+            # same driver inside a one-slab group (device copies / reduction kernels), on one rank's share of the map
+            w8 = WORKLOADS["E8_sat"]
+            ckw8 = dict(nx=w8["nx"], ny=w8["ny"], nz=w8["nz"], res=w8["res"], ppv=w8["ppv"], seed=1234)
+            fr8 = gen_frames(w8, 4 + 12, seed=1234)
+
+            def timed(update, sync, seed_maps):
+                for mm in seed_maps:
+                    mm.seed_uniform(w8["ppv"], 0.01, 99)
+                for pts, pos, quat, t in fr8[:4]:
+                    try:
+                        assert update(pts, pos, t, quat) == 1
+                    except Exception as e:   # (message sizing, see above)
+                        if "exchange message" not in str(e):
+                            raise
+                    for mm in seed_maps:
+                        mm.clearOccupancyMapPrediction()
+                sync()
+                t0 = time.perf_counter()
+                for pts, pos, quat, t in fr8[4:]:
+                    assert update(pts, pos, t, quat) == 1
+                    for mm in seed_maps:
+                        mm.clearOccupancyMapPrediction()
+                sync()
+                return (time.perf_counter() - t0) / 12 * 1e3
+            g1 = sharded.CppGroup(D, ckw8, 1, device_index=local_rank)
+            ms_group1 = timed(g1.update, g1.sync, g1.maps)
+            g1.close()
+            r1 = sharded.CppShardedRank(D, ckw8, 1, 0, local_rank)
+            ms_rccl1 = timed(r1.update, r1.sync, [r1.map])
+            r1.map.close()
+            n_coll = 3 + (4 if selr else 0)   # the send/recv group, the Ck all-reduce, the n_static all-reduce (+ 4 digit all-reduces in frames that select)
+            rccl_over = max(ms_rccl1 - ms_group1, 0.0)
+            proj = crit + rccl_over + n_coll * XGMI_COLLECTIVE_US * 1e-3
+            one = result.get("single_gpu_264x264x80", {}).get("ms_per_step")
+            result["projected_8gpu_264x264x80"] = {
+                "what": "a PROJECTION, not a measurement (no multi-GPU box in this environment; N > 1 has never run on hardware): the 8 "
+                        "slabs of E_sat through the C++ frame driver inside ONE process (dspmap_mgpu_group_update), HIP events around every "
+                        "phase of every slab; inside the group a slab has the GPU to itself for the length of its phase, as its own GPU "
+                        "would.  projected_ms = sum over phases of the slowest slab + the RCCL calls' own cost at world 1 + %d collectives "
+                        "x %.0f us ASSUMED xGMI latency" % (n_coll, XGMI_COLLECTIVE_US),
+                "phases": list(sharded.CppGroup.GROUP_PHASES),
+                "slab_ranges": [list(r) for r in ranges], "equal_height_ranges": [list(r) for r in eq],
+                "phase_ms_per_slab": [[round(x, 4) for x in row] for row in tab[:NW]],
+                "group_stand_ins_ms": [round(x, 4) for x in tab[NW]],
+                "segments": [list(x) for x in SEGMENTS], "slowest_slab_per_segment_ms": [round(x, 4) for x in per],
+                "critical_path_ms": round(crit, 4), "critical_path_equal_height_ms": round(crit_eq, 4),
+                "mean_slab_ms": round(sum(sum(r) for r in tab[:NW]) / NW, 4),
+                "rccl_calls_world1_ms": round(rccl_over, 4), "world1_driver_ms": round(ms_rccl1, 4), "one_slab_group_ms": round(ms_group1, 4),
+                "assumed_xgmi_ms": round(n_coll * XGMI_COLLECTIVE_US * 1e-3, 4), "list_selection_ran": bool(selr),
+                "projected_ms": round(proj, 4), "projected_frames_per_s": round(1e3 / proj, 1),
+                "one_gpu_ms": one, "projected_speedup": round(one / proj, 2) if one else None,
+                "projected_efficiency_8": round(one / proj / NW, 3) if one else None,
+                "in_view_particles_per_slab": [int(c["n_fov"]) for c in cnts]}
+            del fre, fr8
+        except Exception as e:
+            result["projected_8gpu_264x264x80"] = {"error": repr(e)}
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)
     if rank == 0 and not sharded_run and not args.no_cpu:

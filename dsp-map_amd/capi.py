@@ -138,6 +138,8 @@ SIGNATURES = {
     "dspmap_mgpu_message_records": (_i, [_P]),
     "dspmap_mgpu_group_create": (_i, [_P, _i]),
     "dspmap_mgpu_group_update": (_i, [_P, _i, _i, _P, _i, _P, _P, _d, _P]),
+    "dspmap_mgpu_group_set_profiling": (_i, [_P, _i, _i]),
+    "dspmap_mgpu_group_get_phase_ms": (_i, [_P, _i, _fp, _ip]),
 }
 
 _LIB = None

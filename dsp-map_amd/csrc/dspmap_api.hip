@@ -900,6 +900,29 @@ static int frame_with_host_stages(dspmap* m, int np, const float* pts_dev, const
 }
 
 
+// The frame's parameter block through the pinned ring instead of a pageable H2D copy (which makes the host wait for the stream to
+// drain: every kernel of the frame is then launched into an empty queue).  For frames that are NOT replayed as a graph (the sharded
+// frame of dspmap_mgpu_begin): fills the ring slot and returns the ring to pass to launch_setup_and_bin; dspmap_ring_pushed() after
+// the frame's first launches were queued.  Falls back to the copy when the ring does not exist.
+const FrameParams* dspmap_ring_push(dspmap* m) {
+    if (!m->ring_host) return nullptr;
+    const unsigned q = (m->ring_head / (DSPMAP_RING / 4)) % 4;
+    if (m->ring_head % (DSPMAP_RING / 4) == 0 && m->ring_ev_set[q]) (void)hipEventSynchronize(m->ring_ev[q]);
+    m->hp.clear_fut = m->fut_clear_pending ? 1 : 0;
+    m->fut_clear_pending = false;
+    m->hp.from_ring = 1;
+    m->hp.ring_pos = m->ring_head;
+    m->ring_host[m->ring_head % DSPMAP_RING] = m->hp;
+    return m->ring_dev;
+}
+void dspmap_ring_pushed(dspmap* m) {
+    if (m->ring_head % (DSPMAP_RING / 4) == DSPMAP_RING / 4 - 1) {
+        const unsigned q = (m->ring_head / (DSPMAP_RING / 4)) % 4;
+        if (hipEventRecord(m->ring_ev[q], m->stream) == hipSuccess) m->ring_ev_set[q] = true;
+    }
+    ++m->ring_head;
+}
+
 // One device-resident frame after the gate (dspmap_update_device; dspmap_update with the device estimator).
 static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_birth, const dspmap_vpoint* birth_dev,
                         const float dp[3], float dt, const float q[4]) {

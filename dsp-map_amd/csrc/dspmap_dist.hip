@@ -77,6 +77,8 @@ struct dspmap_dist {
     float* buf[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // [dir 0 up / 1 down][send, recv, forward]: (1 + xcap) records of 8 floats
     int xcap = 0;                       // records the exchange buffers hold
     int xsend = 0;                      // records this frame's messages carry (the same on every rank)
+    double xratio = 0.75;               // exports of a frame / (cells of one layer x |dz| / res): what fraction of "a layer's slots times the vertical
+                                        // step in voxels" really crossed a face in earlier frames (0.75: nothing known -- more than a saturated map's 0.5)
     int* cnt2 = nullptr;                // device: export counts {up, down}
     int* gmax_pin = nullptr;            // pinned: the largest export of a frame over all ranks
     hipEvent_t gmax_ev = nullptr;
@@ -93,6 +95,15 @@ struct dspmap_dist {
     int gcnt_max = 1 << 30;             // the longest list of an earlier frame over all ranks (nothing known yet: assume overfull)
     unsigned state_epoch_seen = ~0u;    // dspmap::state_epoch at the last frame: particles written outside a frame -> nothing known
     long long exact_frames = 0;         // frames that ran the selection
+    // one-process group: per-slab, per-phase device time (dspmap_mgpu_group_set_profiling; kept on the group's first handle).  Every
+    // slab of the group runs alone on the GPU for the length of its phase, which is what its own GPU would spend on it in a
+    // one-process-per-GPU run: sum over the phases of the slowest slab = the frame's critical path without the transport.
+    bool gprof = false;
+    std::vector<hipEvent_t> gev;        // [slab][phase][start, end]
+    std::vector<char> gev_set;          // recorded in the pending frame
+    int gprof_spin_us = 400;            // per slab: see dspmap_mgpu_group_update
+    std::vector<double> gms;            // [slab][phase] summed ms
+    int gprof_n = 0, gprof_frames = 0, gprof_pending = 0;
 };
 
 // one-process group: element-wise SUM (int64 / int32) / MAX (int32) over the members' buffers, written back to all of them
@@ -106,11 +117,12 @@ struct PtrList { void* p[16]; int n; };
     } while (0)
 
 // ------------------------------------------------------------------------------------------------ small kernels
-__global__ void k_dist_headers(float* up, float* down, const int* cnt2, int* nstatic, int slot) {
+__global__ void k_dist_headers(float* up, float* down, int* cnt2, int* nstatic, int slot) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         reinterpret_cast<int*>(up)[0] = cnt2[0];
         reinterpret_cast<int*>(down)[0] = cnt2[1];
         nstatic[slot] = max(cnt2[0], cnt2[1]);   // rides on the MAX all-reduce: next frames' message size
+        cnt2[0] = 0; cnt2[1] = 0;                // ready for the next frame's export (no memset node per frame)
     }
 }
 // after the Ck all-reduce: the ranks' list lengths have been summed with it; their maximum goes to the slot behind the export
@@ -201,6 +213,7 @@ static int dist_alloc(dspmap* m, int world, int rank) {
             HIPCHK(m, hipMemset(x->buf[dir][k], 0, sizeof(float) * 8));
         }
     HIPCHK(m, hipMalloc((void**)&x->cnt2, sizeof(int) * 2));
+    HIPCHK(m, hipMemset(x->cnt2, 0, sizeof(int) * 2));   // (k_dist_headers leaves it zeroed for the next frame)
     HIPCHK(m, hipMalloc((void**)&x->hist, sizeof(int) * 256 * (size_t)d.np));
     HIPCHK(m, hipMalloc((void**)&x->sel, sizeof(int2) * (size_t)d.np));
     HIPCHK(m, hipMalloc((void**)&x->kstar, sizeof(int) * (size_t)d.np));
@@ -247,6 +260,7 @@ void dspmap_dist_free(dspmap* m) {
     m->s.pyr_kept = nullptr; m->s.pyr_kstar = nullptr; m->s.pyr_gcnt = nullptr;
     if (x->gmax_pin) (void)hipHostFree(x->gmax_pin);
     if (x->gmax_ev) (void)hipEventDestroy(x->gmax_ev);
+    for (hipEvent_t e : x->gev) if (e) (void)hipEventDestroy(e);
     delete x;
     m->dist = nullptr;
 }
@@ -273,6 +287,19 @@ extern "C" int dspmap_mgpu_comm_init(dspmap_t* m, int world, int rank, const cha
     ncclUniqueId id;
     memcpy(&id, id_bytes, sizeof(id));
     NCCLCHK(m, r->CommInitRank(&m->dist->comm, world, id, rank));
+    {   // the thinnest slab over all ranks (slabs need not be equally high: a partition balanced by predicted work): the number of
+        // forwarding rounds of a frame follows from it and must be the same everywhere -- one 4-byte all-reduce(MIN), once
+        int* dmin = nullptr;
+        const int mine = m->d.z_hi - m->d.z_lo;
+        HIPCHK(m, hipMalloc((void**)&dmin, sizeof(int)));
+        HIPCHK(m, hipMemcpyAsync(dmin, &mine, sizeof(int), hipMemcpyHostToDevice, m->stream));
+        NCCLCHK(m, r->AllReduce(dmin, dmin, 1, ncclInt32, ncclMin, m->dist->comm, m->stream));
+        int got = mine;
+        HIPCHK(m, hipMemcpyAsync(&got, dmin, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(m, hipStreamSynchronize(m->stream));
+        (void)hipFree(dmin);
+        m->dist->min_slab = std::max(1, got);
+    }
     return DSPMAP_OK;
 }
 
@@ -399,7 +426,13 @@ static int phase_begin(dspmap* m, int n_points, const float* points_dev, int n_b
         const int g = x->gmax_pin[0];
         x->gcnt_max = x->gmax_pin[1];
         if (g > x->xsend) ++x->overflow_frames;   // that frame's messages were too small: particles were lost
-        x->xsend = (int)std::min<long long>(x->xcap, std::max<long long>(4096, (long long)g + g / 2 + 1024));
+        // what crossed a face per unit of vertical step (m->hp still holds THAT frame's step): vz == 0, so a frame's exports follow its
+        // own |dz| -- the size of the NEXT message is derived from the next frame's step below, not from this count (round 5: a message
+        // sized from the last frame's exports alone shrank to its floor after a frame without vertical motion and lost the particles of
+        // the next frame that had one)
+        const double steps = std::fabs((double)m->hp.od[2]) / m->d.res;
+        const double layer_cells = (double)m->d.nx * m->d.ny * m->d.slots;
+        if (steps * layer_cells >= 1.0) x->xratio = std::max((double)g / (steps * layer_cells), 0.9 * x->xratio);
     }
     {   // room for the cloud and for the two extra slots of the n_static all-reduce
         const int rcap = dspmap_ensure_point_cap(m, std::max(n_points, n_birth) + 3);
@@ -417,9 +450,15 @@ static int phase_begin(dspmap* m, int n_points, const float* points_dev, int n_b
     m->s.pyr_kept = m->mgpu_exact_lists ? x->kept : nullptr;
     const int rc = dspmap_mgpu_begin(m, n_points, points_dev, n_birth, birth_dev, pos, stamp, q);
     if (rc != DSPMAP_OK) return rc;
+    {   // this frame's message size, from ITS vertical step (the same pose, ratio and arithmetic on every rank): 1.5 x the expected
+        // exports + 2048 records; particles that still carry a vz (constructor pre-fill, first prediction) are not bounded by the step
+        const double steps = std::fabs((double)m->hp.od[2]) / m->d.res;
+        const double layer_cells = (double)m->d.nx * m->d.ny * m->d.slots;
+        const double want = m->vz_frames_at_begin > 0 ? (double)x->xcap : 1.5 * x->xratio * steps * layer_cells + 2048.0;
+        x->xsend = (int)std::min<double>((double)x->xcap, std::max<double>(4096.0, std::ceil(want)));
+    }
     x->nb_hi = std::max(x->nb_hi, m->last_n_birth);
     LaunchCtx c = dspmap_ctx_of(m);
-    HIPCHK(m, hipMemsetAsync(x->cnt2, 0, 2 * sizeof(int), m->stream));
     launch_export_slab(c, 0, x->buf[0][0] + 8, x->xsend, x->cnt2, x->buf[1][0] + 8);   // both faces in one pass
     hipLaunchKernelGGL(k_dist_headers, dim3(1), dim3(64), 0, m->stream, x->buf[0][0], x->buf[1][0], x->cnt2, m->s.nstatic, x->nb_hi);
     launch_birth_early(c, m->last_n_birth, false);   // newborn children: they only need the birth cloud (the rank rode on k_predict)
@@ -517,6 +556,47 @@ extern "C" int dspmap_mgpu_update(dspmap_t* m, int n_points, const float* points
 }
 
 // ------------------------------------------------------------------------------------------------ one-process group
+static void group_prof_collect(dspmap_dist* g) {
+    if (!g->gprof_pending || g->gev.empty()) return;
+    const int n = g->gprof_n;
+    for (int i = 0; i <= n; ++i)
+        for (int ph = 0; ph < DSPMAP_GROUP_PHASES; ++ph) {
+            float ms = 0.f;
+            const size_t e = ((size_t)i * DSPMAP_GROUP_PHASES + ph) * 2;
+            if (!g->gev_set[e] || !g->gev_set[e + 1]) continue;
+            (void)hipEventSynchronize(g->gev[e + 1]);
+            if (hipEventElapsedTime(&ms, g->gev[e], g->gev[e + 1]) == hipSuccess && ms > 0.f) g->gms[(size_t)i * DSPMAP_GROUP_PHASES + ph] += ms;
+        }
+    ++g->gprof_frames;
+    g->gprof_pending = 0;
+}
+extern "C" int dspmap_mgpu_group_set_profiling(dspmap_t** hs, int n, int on) {
+    if (!hs || n < 1 || n > 16 || !hs[0] || !hs[0]->dist) return DSPMAP_E_ARG;
+    dspmap* m = hs[0];
+    dspmap_dist* g = m->dist;
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (on && (g->gev.empty() || g->gprof_n != n)) {
+        for (hipEvent_t e : g->gev) (void)hipEventDestroy(e);
+        g->gev.assign((size_t)(n + 1) * DSPMAP_GROUP_PHASES * 2, nullptr);
+        for (hipEvent_t& e : g->gev) HIPCHK(m, hipEventCreate(&e));
+        g->gprof_n = n;
+    }
+    g->gev_set.assign(g->gev.size(), 0);
+    g->gprof_spin_us = 600 * n;
+    g->gms.assign((size_t)(n + 1) * DSPMAP_GROUP_PHASES, 0.0);
+    g->gprof_frames = 0; g->gprof_pending = 0;
+    g->gprof = on != 0;
+    return DSPMAP_OK;
+}
+extern "C" int dspmap_mgpu_group_get_phase_ms(dspmap_t** hs, int n, float* out, int* n_frames) {
+    if (!hs || n < 1 || n > 16 || !hs[0] || !hs[0]->dist || !out) return DSPMAP_E_ARG;
+    dspmap_dist* g = hs[0]->dist;
+    if (g->gprof_n != n || g->gms.empty()) return dspmap_fail(hs[0], DSPMAP_E_STATE, "group profiling is not enabled for %d slabs", n);
+    group_prof_collect(g);
+    for (size_t i = 0; i < g->gms.size(); ++i) out[i] = (float)g->gms[i];
+    if (n_frames) *n_frames = g->gprof_frames;
+    return DSPMAP_OK;
+}
 extern "C" int dspmap_mgpu_group_create(dspmap_t** hs, int n) {
     if (!hs || n < 1 || n > 16) return DSPMAP_E_ARG;
     for (int i = 0; i < n; ++i) {
@@ -526,6 +606,11 @@ extern "C" int dspmap_mgpu_group_create(dspmap_t** hs, int n) {
         int rc = dist_alloc(m, n, i);
         if (rc != DSPMAP_OK) return rc;
     }
+    // slabs need not be equally high (a partition balanced by predicted work, bench.py: projected_8gpu): the number of forwarding
+    // rounds follows from the THINNEST one
+    int thin = 1 << 30;
+    for (int i = 0; i < n; ++i) thin = std::min(thin, hs[i]->d.z_hi - hs[i]->d.z_lo);
+    for (int i = 0; i < n; ++i) hs[i]->dist->min_slab = std::max(1, thin);
     return DSPMAP_OK;
 }
 extern "C" int dspmap_mgpu_group_update(dspmap_t** hs, int n, int n_points, const float* points_dev, int n_birth,
@@ -533,9 +618,27 @@ extern "C" int dspmap_mgpu_group_update(dspmap_t** hs, int n, int n_points, cons
     if (!hs || n < 1 || n > 16) return DSPMAP_E_ARG;
     for (int i = 0; i < n; ++i) if (!hs[i] || !hs[i]->dist || hs[i]->dist->comm) return DSPMAP_E_STATE;
     hipStream_t st = hs[0]->stream;
+    dspmap_dist* g0 = hs[0]->dist;
+    const bool prof = g0->gprof && g0->gprof_n == n;
+    if (prof && g0->gprof_pending) group_prof_collect(g0);
+    auto mark = [&](int slab, int phase, int end) {   // (slab n = the group's stand-ins for the collectives)
+        if (!prof) return;
+        const size_t e = ((size_t)slab * DSPMAP_GROUP_PHASES + phase) * 2 + end;
+        (void)hipEventRecord(g0->gev[e], st);
+        g0->gev_set[e] = 1;   // (phases a frame skips are not read)
+    };
+    if (prof) {
+        std::fill(g0->gev_set.begin(), g0->gev_set.end(), 0);
+        // the intervals between two events must hold device work only: a one-wave kernel keeps the stream busy while the host queues
+        // the whole frame (8 slabs x 7 phases from ONE thread take longer to queue than to run; a rank of a real run queues one slab)
+        LaunchCtx c0 = dspmap_ctx_of(hs[0]);
+        launch_spin(c0, g0->gprof_spin_us);
+    }
     int accepted = 0;
     for (int i = 0; i < n; ++i) {
+        mark(i, 0, 0);
         const int rc = phase_begin(hs[i], n_points, points_dev, n_birth, birth_dev, pos, stamp, q);
+        mark(i, 0, 1);
         if (rc < 0) return rc;
         accepted += rc == DSPMAP_OK ? 1 : 0;
     }
@@ -546,20 +649,25 @@ extern "C" int dspmap_mgpu_group_update(dspmap_t** hs, int n, int n_points, cons
     for (int rd = 0; rd < rounds; ++rd) {
         for (int i = 0; i < n; ++i)
             if (rd + 1 < rounds) hipLaunchKernelGGL(k_dist_fwd_reset, dim3(1), dim3(64), 0, st, hs[i]->dist->buf[0][2], hs[i]->dist->buf[1][2]);
+        if (rd == 0) mark(n, 1, 0);
         for (int i = 0; i < n; ++i) {   // the "send / recv" pairs
             if (i + 1 < n) (void)hipMemcpyAsync(hs[i + 1]->dist->buf[0][1], hs[i]->dist->buf[0][0], bytes, hipMemcpyDeviceToDevice, st);
             if (i > 0) (void)hipMemcpyAsync(hs[i - 1]->dist->buf[1][1], hs[i]->dist->buf[1][0], bytes, hipMemcpyDeviceToDevice, st);
         }
+        if (rd == 0) mark(n, 1, 1);
         for (int i = 0; i < n; ++i) {
+            if (rd == 0) mark(i, 1, 0);
             if (i > 0) phase_import(hs[i], 0, rd + 1 == rounds);
             if (i + 1 < n) phase_import(hs[i], 1, rd + 1 == rounds);
+            if (rd == 0) mark(i, 1, 1);
             if (rd + 1 < rounds) { std::swap(hs[i]->dist->buf[0][0], hs[i]->dist->buf[0][2]); std::swap(hs[i]->dist->buf[1][0], hs[i]->dist->buf[1][2]); }
         }
     }
     PtrList l;
     l.n = n;
-    for (int i = 0; i < n; ++i) { const int rc = phase_place(hs[i]); if (rc != DSPMAP_OK) return rc; }
+    for (int i = 0; i < n; ++i) { mark(i, 2, 0); const int rc = phase_place(hs[i]); mark(i, 2, 1); if (rc != DSPMAP_OK) return rc; }
     if (hs[0]->mgpu_exact_lists) {
+        mark(n, 3, 0);
         for (int i = 1; i < n; ++i) if (!hs[i]->mgpu_exact_lists) return dspmap_fail(hs[0], DSPMAP_E_STATE, "the slabs of a group disagree about the list selection");
         const int n_h = hs[0]->d.np * 256;
         for (int ps = 0; ps < pyr_select_passes(); ++ps) {
@@ -568,15 +676,21 @@ extern "C" int dspmap_mgpu_group_update(dspmap_t** hs, int n, int n_points, cons
             for (int i = 0; i < n; ++i) { LaunchCtx c = dspmap_ctx_of(hs[i]); launch_pyr_pick(c, ps, hs[i]->dist->hist, hs[i]->dist->sel, hs[i]->dist->kstar); }
         }
         for (int i = 0; i < n; ++i) { LaunchCtx c = dspmap_ctx_of(hs[i]); launch_pyr_kept(c, hs[i]->dist->kstar, hs[i]->dist->kept); ++hs[i]->dist->exact_frames; }
+        mark(n, 3, 1);   // (the whole selection, all slabs: 4 x (histogram, sum, pick) -- per rank a 1 / n share of the kernels + 4 all-reduces)
     }
-    for (int i = 0; i < n; ++i) { const int rc = phase_ck(hs[i]); if (rc != DSPMAP_OK) return rc; l.p[i] = hs[i]->s.obs_ck; }
+    for (int i = 0; i < n; ++i) { mark(i, 4, 0); const int rc = phase_ck(hs[i]); mark(i, 4, 1); if (rc != DSPMAP_OK) return rc; l.p[i] = hs[i]->s.obs_ck; }
     const int n_ck = hs[0]->d.np * DSP_OBS_CAP + hs[0]->d.np;
+    mark(n, 4, 0);
     hipLaunchKernelGGL(k_group_sum_i64, dim3((n_ck + 255) / 256), dim3(256), 0, st, l, n_ck);
     for (int i = 0; i < n; ++i) phase_gcnt(hs[i]);
+    mark(n, 4, 1);
     int span = 0;
-    for (int i = 0; i < n; ++i) { const int rc = phase_weights(hs[i]); if (rc != DSPMAP_OK) return rc; l.p[i] = hs[i]->s.nstatic; span = std::max(span, hs[i]->dist->nb_hi + 2); }
+    for (int i = 0; i < n; ++i) { mark(i, 5, 0); const int rc = phase_weights(hs[i]); mark(i, 5, 1); if (rc != DSPMAP_OK) return rc; l.p[i] = hs[i]->s.nstatic; span = std::max(span, hs[i]->dist->nb_hi + 2); }
+    mark(n, 5, 0);
     hipLaunchKernelGGL(k_group_max_i32, dim3((span + 255) / 256), dim3(256), 0, st, l, span);
-    for (int i = 0; i < n; ++i) { const int rc = phase_finish(hs[i]); if (rc != DSPMAP_OK) return rc; }
+    mark(n, 5, 1);
+    for (int i = 0; i < n; ++i) { mark(i, 6, 0); const int rc = phase_finish(hs[i]); mark(i, 6, 1); if (rc != DSPMAP_OK) return rc; }
+    if (prof) g0->gprof_pending = 1;
     long long ov = 0;
     for (int i = 0; i < n; ++i) { ov += hs[i]->dist->overflow_frames; hs[i]->dist->overflow_frames = 0; }
     if (ov) return dspmap_fail(hs[0], DSPMAP_E_STATE, "an earlier frame exported more particles across a slab face than the exchange message held");

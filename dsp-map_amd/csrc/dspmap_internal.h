@@ -159,6 +159,8 @@ int dspmap_push_frame_params(dspmap* m);
 void dspmap_flush_future_clear(dspmap* m);   // m->hp -> device
 int dspmap_mark_nb_dirty(dspmap* m);
 void dspmap_dist_free(dspmap* m);
+const FrameParams* dspmap_ring_push(dspmap* m);   // the frame's parameter block into the pinned ring (direct launches); nullptr: no ring
+void dspmap_ring_pushed(dspmap* m);               // after the launches that read the slot were queued
 int dspmap_pts_slot_acquire(dspmap* m, int n);   // next pinned staging slot (waits for the copy that last used it) -> m->pts_pin
 int dspmap_pts_slot_release(dspmap* m);          // after queueing the copy that reads / writes m->pts_pin
 int dspmap_stage_points(dspmap* m, int n, int stride, const float* pts);   // host cloud -> m->pts_dev (pinned staging, async copy)

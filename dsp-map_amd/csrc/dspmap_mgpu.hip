@@ -89,13 +89,16 @@ extern "C" int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_
     const int nb = static_birth ? nb_grid : nb_own;   // grid bound of the birth launches
     m->hp.pts = points_dev;
     m->hp.birth = static_birth ? m->s.birth : m->mgpu_birth;
-    int rcp = dspmap_push_frame_params(m);
-    if (rcp != DSPMAP_OK) return rcp;
+    // the parameter block travels through the pinned ring (the frame's first kernel fetches it over the bus): a pageable H2D copy
+    // makes the host wait for the stream to drain, and every kernel of the frame is then launched into an empty queue
+    const FrameParams* ring = dspmap_ring_push(m);
+    if (!ring) { int rcp = dspmap_push_frame_params(m); if (rcp != DSPMAP_OK) return rcp; }
     dspmap_prof_collect(m);
     HIPCHK(m, hipEventRecord(m->ev0, m->stream));
-    launch_setup_and_bin(c, n_points, false);
+    launch_setup_and_bin(c, n_points, false, ring, DSPMAP_RING - 1);
     // + gather + (static tags) the birth rank; k_place follows the exchange: imported movers take part in the sweep-order placement
     launch_predict_only(c, true, nb > 0 && mode != 2);
+    if (ring) dspmap_ring_pushed(m);
     if (mode == 2 && nb > 0) { launch_velocity_estimator(c, true); m->ve_last_at = 2; }   // ... with the estimator the rank rides on k_ve_clusters
     m->mgpu_all_static = mode == 1;
     m->mgpu_place_pending = true;

@@ -358,9 +358,11 @@ class CppGroup:
     """several slabs in ONE process driven by the same C++ frame driver (dspmap_mgpu_group_update): device-to-device
     copies and small reduction kernels stand in for the collectives"""
 
-    def __init__(self, dsp, cfg_kwargs, world, device_index=0, example_params=True):
+    def __init__(self, dsp, cfg_kwargs, world, device_index=0, example_params=True, ranges=None):
         self.maps = []
-        for (z_lo, z_hi) in slab_ranges(cfg_kwargs["nz"], world):
+        self.ranges = list(ranges) if ranges is not None else slab_ranges(cfg_kwargs["nz"], world)   # (ranges: slabs of unequal height)
+        assert len(self.ranges) == world and self.ranges[0][0] == 0 and self.ranges[-1][1] == cfg_kwargs["nz"]
+        for (z_lo, z_hi) in self.ranges:
             cfg = dsp.make_config(z_lo=z_lo, z_hi=z_hi, device=device_index, **cfg_kwargs)
             m = dsp.DSPMap(cfg, example_params=example_params)
             m._chk(m.L.dspmap_init_device(m.h))
@@ -386,6 +388,27 @@ class CppGroup:
         if rc < 0:
             raise RuntimeError(self.L.dspmap_last_error(self.maps[0].h).decode())
         return rc
+
+    GROUP_PHASES = ("begin", "exchange+import", "place", "select", "prepare+ck", "weights+split", "births+resample")
+
+    def set_profiling(self, on):
+        if not self.created:
+            self.create()
+        rc = self.L.dspmap_mgpu_group_set_profiling(C.cast(self.handles, C.c_void_p), len(self.maps), 1 if on else 0)
+        if rc < 0:
+            raise RuntimeError(self.L.dspmap_last_error(self.maps[0].h).decode())
+
+    def phase_ms(self):
+        """([slab or 'collectives'][phase] mean ms per frame, frames): HIP events around every phase of every slab"""
+        n = len(self.maps)
+        out = (C.c_float * ((n + 1) * len(self.GROUP_PHASES)))()
+        nf = C.c_int()
+        rc = self.L.dspmap_mgpu_group_get_phase_ms(C.cast(self.handles, C.c_void_p), n, out, C.byref(nf))
+        if rc < 0:
+            raise RuntimeError(self.L.dspmap_last_error(self.maps[0].h).decode())
+        k = len(self.GROUP_PHASES)
+        f = max(nf.value, 1)
+        return [[out[i * k + p] / f for p in range(k)] for i in range(n + 1)], nf.value
 
     def sync(self):
         for m in self.maps:

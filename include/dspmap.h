@@ -388,6 +388,17 @@ int dspmap_mgpu_group_update(dspmap_t** handles, int n, int n_points, const floa
                              const dspmap_vpoint* birth_dev, const float sensor_pos[3], double time_stamp_second,
                              const float quat_wxyz[4]);
 
+/* per-slab, per-phase device time of the group's frames (HIP events around every phase of every slab; slab index n = the group's
+ * stand-ins for the collectives).  Inside the group every slab has the GPU to itself for the length of its phase -- what its own
+ * GPU would spend on it in a one-process-per-GPU run -- so  sum over phases of max over slabs  is the frame's critical path on n GPUs
+ * without the transport: the figure bench.py reports as projected_8gpu (a projection; N > 1 has not run on hardware).
+ * phases: 0 begin (binning, prediction, estimator, export), 1 exchange + import, 2 placement, 3 list selection (only frames that
+ * run it; group level), 4 list preparation + Ck, 5 weights + split, 6 births + resampling + rollout.
+ * out: [n + 1][DSPMAP_GROUP_PHASES] summed ms since enabling */
+#define DSPMAP_GROUP_PHASES 7
+int dspmap_mgpu_group_set_profiling(dspmap_t** handles, int n, int on);
+int dspmap_mgpu_group_get_phase_ms(dspmap_t** handles, int n, float* ms_sum_out, int* n_frames_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,3 +111,21 @@ def test_ceiling_table_prices_every_kernel_with_its_own_ruler():
     # without PMC / SQ data (a run on kernel sources nobody profiled yet) the table still comes out, on algorithmic bytes
     ct2 = b.ceiling_table(C_SAT, b.b_alg(C_SAT, V, T), 0.6584, kus, {}, {}, 5.3)
     assert "algorithmic" in ct2["per_kernel"]["k_predict"]["ruler"] and ct2["per_kernel"]["k_weight"]["achieved_over_ceiling"] == 1.0
+
+
+def test_projection_helpers_balance_slabs_and_sum_the_slowest_slab_per_phase():
+    """bench.py: projected_8gpu: slab boundaries from per-layer costs (contiguous, every slab at least one layer,
+    equal costs -> equal heights) and the critical path = sum over phases of the slowest slab + a rank's share of the list selection"""
+    b = _bench()
+    assert b.balanced_ranges([1.0] * 80, 8) == [(10 * i, 10 * i + 10) for i in range(8)]
+    cost = [1.0] * 30 + [2.0] * 20 + [1.0] * 30
+    r = b.balanced_ranges(cost, 8)
+    assert r[0][0] == 0 and r[-1][1] == 80 and all(a[1] == c[0] for a, c in zip(r, r[1:])) and all(z1 > z0 for z0, z1 in r)
+    sums = [sum(cost[z0:z1]) for z0, z1 in r]
+    assert max(sums) - min(sums) <= 2.0 and max(sums) < max(sum(cost[10 * i:10 * i + 10]) for i in range(8))
+    assert b.balanced_ranges([1, 1, 1, 1, 1, 1, 1, 100], 8) == [(i, i + 1) for i in range(8)]
+    tab = [[1.0, 0.1, 0.5, 0.0, 0.3, 0.2, 1.0], [1.2, 0.1, 0.4, 0.0, 0.6, 0.2, 0.9], [0.0, 0.05, 0.0, 0.8, 0.02, 0.01, 0.0]]
+    crit, per = b.critical_path(tab, 2, True)
+    # segments between collectives: begin | exchange + place + Ck | weights | finish
+    assert [round(x, 6) for x in per] == [1.2, 1.1, 0.2, 1.0] and abs(crit - (sum(per) + 0.4)) < 1e-9
+    assert abs(b.critical_path(tab, 2, False)[0] - sum(per)) < 1e-9

@@ -229,3 +229,88 @@ def test_host_pointer_update_through_the_mapped_cloud_ring_is_the_device_residen
             m.clearOccupancyMapPrediction()
     for m in maps:
         m.close()
+
+
+def test_sharded_map_resting_then_stepping_vertically_with_unequal_slabs(dsp):
+    """The exchange messages of the C++ frame driver have a fixed size every rank must know without asking.  Until round 4 it was
+    derived from the PREVIOUS frame's exports: after a frame without vertical motion it fell to its floor (4096 records) and the
+    next frame with a vertical step lost what did not fit (reported one frame later) -- a saturated map of config E's size overflowed
+    in its third frame.  Now the size follows THIS frame's vertical step (vz == 0: only the sensor's dz moves particles across
+    layers) times the crossings per unit step seen so far.  A saturated map, 4 slabs of UNEQUAL height (3 / 9 / 5 / 7 layers: what a
+    partition balanced by work looks like; the thinnest slab sets the number of forwarding rounds), the sensor resting, stepping
+    0.05 m up, resting, stepping 0.3 m down (two layers: more than the message floor holds, fewer than the thinnest slab): no frame
+    reports an overflow and the sharded map IS the unsharded one, slot for slot; per-slab phase times come out of the group's
+    profiling (every phase of every slab measured)."""
+    sharded = __import__("dsp-map_amd.sharded", fromlist=["CppGroup"])
+    cfg = dict(nx=40, ny=40, nz=24, res=0.15, ppv=12)
+    ranges = [(0, 3), (3, 12), (12, 17), (17, 24)]
+    tables = common.tables(3)
+    grp = sharded.CppGroup(dsp, cfg, 4, ranges=ranges)
+    full = dsp.DSPMap(dsp.make_config(**cfg))
+    for m in grp.maps + [full]:
+        m.set_tables(*tables)
+        m.L.dspmap_init_device(m.h)
+        m.seed_uniform(12, 0.01, 99)
+    grp.create()
+    grp.set_profiling(True)
+    pts = common.wall_cloud(5, n_side=40, dist=2.2, half_w=1.8, half_h=0.9)
+    d = torch.from_numpy(pts).cuda()
+    z = [0.0, 0.0, 0.05, 0.05, 0.05, -0.25, -0.25, -0.20]
+    sizes, moved = [], 0
+    for f, dz in enumerate(z):
+        pos = (0.01 * f, 0.0, 1.0 + dz)
+        assert grp.update(d, pos, f / 30.0, (1.0, 0.0, 0.0, 0.0)) == 1          # (an overflow of an earlier frame would raise here)
+        assert full.update_device(d.data_ptr(), len(pts), pos, f / 30.0, (1.0, 0.0, 0.0, 0.0)) == 1
+        grp.sync()
+        sizes.append(grp.maps[0].L.dspmap_mgpu_message_records(grp.maps[0].h))
+        moved += sum(m.counters()["n_moved"] for m in grp.maps)
+        for m in grp.maps + [full]:
+            m.clearOccupancyMapPrediction()
+    assert sizes[0] == sizes[1] == sizes[3] == 4096 and sizes[5] > 20000 and sizes[5] > sizes[2] > 4096, sizes   # the size follows the step
+    got = np.concatenate([m.results() for m in grp.maps], 0)
+    assert np.array_equal(got, full.results())
+    parts = [m.export_state() for m in grp.maps]
+    sv, ss, sr = (np.concatenate([p[k] for p in parts]) for k in range(3))
+    order = np.lexsort((ss, sv))
+    fv, fs_, fr = full.export_state()
+    assert len(fv) > 200000 and moved > 100000
+    assert np.array_equal(sv[order], fv) and np.array_equal(ss[order], fs_) and np.array_equal(sr[order], fr)
+    assert np.array_equal(np.concatenate([m.getFutureStatus() for m in grp.maps], 0), full.getFutureStatus())
+    tab, nf = grp.phase_ms()
+    assert nf == len(z) and len(tab) == 5 and len(tab[0]) == len(grp.GROUP_PHASES)
+    for i in range(4):
+        assert tab[i][0] > 0 and tab[i][2] > 0 and tab[i][4] > 0 and tab[i][6] > 0, tab[i]      # begin, placement, Ck, births + resampling
+    assert sum(tab[1]) > sum(tab[0])                                                             # 9 layers cost more than 3
+    grp.close(); full.close()
+
+
+def test_identical_maps_have_identical_future_status_every_frame(dsp):
+    """Three maps, the same clouds, the same calls: everything they report must be the same bits -- the future status included, which
+    the prediction sweep zeroes per tile (only where something was added since the last zeroing: fut_dirty) when a
+    clearOccupancyMapPrediction is pending.  Round 5 found a race there: every wave of a tile's workgroup read the flag for itself and
+    wave 0 reset it, so a late wave skipped its horizons and a cell kept last frame's mass (2 x the value, horizons 1, 2, 3, 5 only)."""
+    scene_mod = __import__("dsp-map_amd.scene", fromlist=["CorridorScene"])
+    cfg = dict(nx=66, ny=66, nz=40, res=0.15, ppv=24)
+    sc = scene_mod.CorridorScene(66 * 0.15, 66 * 0.15, 40 * 0.15, seed=1234, device="cuda")
+    frames = [sc.frame(f / 30.0) for f in range(80)]
+    torch.cuda.synchronize()
+    maps = []
+    for k in range(3):
+        m = dsp.DSPMap(dsp.make_config(seed=1234, **cfg))
+        m.L.dspmap_init_device(m.h)
+        m.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, 2)
+        maps.append(m)
+    maps[2].set_param(dsp.capi.P_SPARSE_SWEEP, 1)            # the sparse variant of the sweep looks at the same flag
+    total = 0.0
+    for f, (pts, pos, quat) in enumerate(frames):
+        for m in maps:
+            assert m.update_device(pts.data_ptr(), pts.shape[0], pos, f / 30.0, quat) == 1
+        if f % 2 == 1:
+            fs = [m.getFutureStatus() for m in maps]
+            assert np.array_equal(fs[0], fs[1]) and np.array_equal(fs[0], fs[2]), f
+            total += float(fs[0].sum())
+        for m in maps:
+            m.clearOccupancyMapPrediction()
+    assert total > 100.0
+    for m in maps:
+        m.close()
