@@ -582,7 +582,7 @@ extern "C" int dspmap_mgpu_group_set_profiling(dspmap_t** hs, int n, int on) {
         g->gprof_n = n;
     }
     g->gev_set.assign(g->gev.size(), 0);
-    g->gprof_spin_us = 600 * n;
+    g->gprof_spin_us = 2000 * n;
     g->gms.assign((size_t)(n + 1) * DSPMAP_GROUP_PHASES, 0.0);
     g->gprof_frames = 0; g->gprof_pending = 0;
     g->gprof = on != 0;

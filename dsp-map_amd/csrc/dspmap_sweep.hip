@@ -1882,46 +1882,64 @@ __global__ void __launch_bounds__(256) k_export_slab(MapDims d, DevState s, u64*
     const int l = lane_id();
     const int lv = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + l;
     const bool inr = lv < d.v_loc;
+    // Two passes per wave (round 5).  One aggregated atomic per slot ROW -- what this kernel did -- is a chain of up to 2 M dependent
+    // same-address atomics per wave, and every wave of a boundary layer hammers the same two counters: 250 - 280 us per slab of the
+    // saturated 264x264x80 map (as long as the slab's whole prediction sweep), against 6 us when nothing leaves.  Pass 1 classifies the
+    // wave's leavers (up / down) and counts them; ONE atomic per wave and direction reserves their records; pass 2 writes them.
+    u64 exw[MW], dnw[MW], minew[MW];
+    int cu = 0, cd = 0;
 #pragma unroll
     for (int e = 0; e < MW; ++e) {
-        const u64 ex = inr ? expmask[(size_t)lv * MW + e] : 0ull;
-        u64 tor = wave_or_u64(ex);
-        u64 done = 0ull;
+        exw[e] = inr ? expmask[(size_t)lv * MW + e] : 0ull;
+        dnw[e] = 0ull; minew[e] = 0ull;
+        u64 bits = exw[e];
+        while (bits) {   // (per lane: a voxel exports a handful of particles)
+            const int sb = __ffsll((long long)bits) - 1;
+            bits &= bits - 1ull;
+            const P3 p3 = ld_pos(s, pidx(d, lv, e * 64 + sb));
+            int gv;
+            voxel_of(d, p3.x, p3.y, p3.z, gv);
+            const int nlv = gv - d.v_base;
+            const bool down = nlv < 0;
+            const bool mine = dir > 0 ? nlv >= d.v_loc : (dir < 0 ? down : (down || nlv >= d.v_loc));
+            if (mine) { minew[e] |= 1ull << sb; if (down && dir == 0) { dnw[e] |= 1ull << sb; ++cd; } else ++cu; }
+        }
+    }
+    if (!__ballot(cu | cd)) return;
+    const int tu = wave_sum_i(cu), td = wave_sum_i(cd);
+    int base_u = 0, base_d = 0;
+    if (l == 0) {
+        if (tu) base_u = atomicAdd(count, tu);                 // (dir != 0: everything counts as "up" = count[0] / rec_out)
+        if (td) base_d = atomicAdd(count + 1, td);
+    }
+    base_u = __builtin_amdgcn_readfirstlane(base_u); base_d = __builtin_amdgcn_readfirstlane(base_d);
+    int run_u = 0, run_d = 0;   // (wave-uniform)
+#pragma unroll
+    for (int e = 0; e < MW; ++e) {
+        u64 tor = wave_or_u64(minew[e]);
         while (tor) {
             const int sb = __ffsll((long long)tor) - 1;
             tor &= tor - 1ull;
-            bool mine = false, down = false;
-            float px = 0, py = 0, pz = 0, vx = 0, vy = 0, w = 0;
-            int gv = 0;
-            if (ex & (1ull << sb)) {
-                const size_t idx = pidx(d, lv, e * 64 + sb);
-                const P3 p3 = ld_pos(s, idx);
-                const V2 v2 = ld_vel(s, idx);
-                px = p3.x; py = p3.y; pz = p3.z;
-                vx = v2.x; vy = v2.y; w = s.w[idx];
-                voxel_of(d, px, py, pz, gv);
-                const int nlv = gv - d.v_base;
-                down = nlv < 0;
-                mine = dir > 0 ? nlv >= d.v_loc : (dir < 0 ? down : (down || nlv >= d.v_loc));
-            }
-            int pos;
-            if (dir != 0) pos = wave_agg_inc1(count, mine);
-            else {
-                const int pu = wave_agg_inc1(count, mine && !down), pd = wave_agg_inc1(count + 1, mine && down);
-                pos = down ? pd : pu;
-            }
+            const bool mine = (minew[e] >> sb) & 1ull, down = (dnw[e] >> sb) & 1ull;
+            const u64 bu = __ballot(mine && !down), bd = __ballot(mine && down);
             if (mine) {
+                const int pos = down ? base_d + run_d + (int)__popcll(bd & lanemask_lt()) : base_u + run_u + (int)__popcll(bu & lanemask_lt());
                 if (pos < cap) {
-                    float* r = (dir == 0 && down ? rec_out2 : rec_out) + 8 * (size_t)pos;
-                    r[0] = __int_as_float(gv); r[1] = vx; r[2] = vy; r[3] = px; r[4] = py; r[5] = pz; r[6] = w;
+                    const size_t idx = pidx(d, lv, e * 64 + sb);
+                    const P3 p3 = ld_pos(s, idx);
+                    const V2 v2 = ld_vel(s, idx);
+                    int gv;
+                    voxel_of(d, p3.x, p3.y, p3.z, gv);
+                    float* r = (down ? rec_out2 : rec_out) + 8 * (size_t)pos;
+                    r[0] = __int_as_float(gv); r[1] = v2.x; r[2] = v2.y; r[3] = p3.x; r[4] = p3.y; r[5] = p3.z; r[6] = s.w[idx];
                     r[7] = __int_as_float((lv + d.v_base) * d.slots + e * 64 + sb);   // source key: k_place's service order
                 }
-                done |= 1ull << sb;
             }
+            run_u += (int)__popcll(bu); run_d += (int)__popcll(bd);
         }
-        if (done) {
-            atomicAnd(&s.mask[(size_t)lv * MW + e], ~done);
-            expmask[(size_t)lv * MW + e] = ex & ~done;
+        if (minew[e]) {
+            atomicAnd(&s.mask[(size_t)lv * MW + e], ~minew[e]);
+            expmask[(size_t)lv * MW + e] = exw[e] & ~minew[e];
         }
     }
 }
