@@ -163,6 +163,7 @@ extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
     m->vel.configure(cfg->half_fov_h, cfg->half_fov_v, cfg->angle_resolution);
     if (const char* e = getenv("DSPMAP_PLACE_SPLIT_TILES")) { const long v = atol(e); if (v > 0) m->place_split_tiles = (int)std::min(v, 2000000000l); }
     if (const char* e = getenv("DSPMAP_SWEEP_ALTERNATE")) m->sweep_alt = atoi(e) < 0 ? -1 : (atoi(e) >= 2 ? 2 : (atoi(e) != 0 ? 1 : 0));
+    if (const char* e = getenv("DSPMAP_EARLY_REGISTER")) m->early_reg = atoi(e) < 0 ? -1 : (atoi(e) != 0 ? 1 : 0);
     if (const char* e = getenv("DSPMAP_RESAMPLE_WG_TILES")) { const long v = atol(e); if (v >= 0) m->resample_wg_tiles = (int)std::min(v, 2000000000l); }
     return m;
 }
@@ -186,7 +187,7 @@ static void free_dev(dspmap* m) {
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, s.fov_rec, s.fov_slot, s.fov_key, s.fov_spos, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt, s.in_n, s.pmask, s.ta, s.dflag, s.dirty,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.ro_cnt, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
-                    s.tile_moving, m->k.ro_stat, m->k.part_predict, m->k.tile_fov, m->k.view_list, s.tile_live, s.fut_dirty, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf, s.birth_cvr};
+                    s.tile_moving, m->k.ro_stat, m->k.part_predict, m->k.tile_fov, m->k.view_list, m->k.in_ref, m->k.in_slot, m->k.fov_w_s, m->k.ta_list, s.tile_live, s.fut_dirty, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf, s.birth_cvr};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
     if (m->nbsnap_buf) chk(hipFree(m->nbsnap_buf), "hipFree");
     {
@@ -411,6 +412,12 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&s.fut_dirty, (size_t)k.ntiles));
     HIPCHK(m, hipMemset(s.fut_dirty, 0, sizeof(int) * (size_t)k.ntiles));   // (the accumulators start zeroed)
     HIPCHK(m, dalloc(&k.view_list, (size_t)k.ntiles));
+    {   // early registration (dense large maps; small ones only when a test forces it)
+        HIPCHK(m, dalloc(&k.in_ref, ntiles * 64 * d.slots));
+        HIPCHK(m, dalloc(&k.in_slot, ntiles * 64 * d.slots));
+        HIPCHK(m, dalloc(&k.fov_w_s, (size_t)d.np * d.capp));
+        HIPCHK(m, dalloc(&k.ta_list, (size_t)d.np * (d.capa - d.capp)));
+    }
     HIPCHK(m, dalloc(&k.tile_fov, (size_t)k.ntiles));
     HIPCHK(m, hipMemset(k.tile_fov, 0xff, sizeof(int) * (size_t)k.ntiles));   // no frame's tag
     HIPCHK(m, dalloc(&k.part_resample, (size_t)k.nblk_sweep * 4));
@@ -537,6 +544,7 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
             m->use_vel_est = (int)v; break;
         case DSPMAP_P_USE_GRAPH: m->use_graph = v != 0; break;
         case DSPMAP_P_HOST_CLOUD_DIRECT: m->host_direct = v != 0; break;
+        case DSPMAP_P_EARLY_REGISTER: m->early_reg = v < 0 ? -1 : (v != 0 ? 1 : 0); m->graph_epoch++; break;
         case DSPMAP_P_SPARSE_SWEEP: m->sparse_force = v < 0 ? -1 : (v != 0 ? 1 : 0); break;
         case DSPMAP_P_ROLLOUT_INLINE: m->ro_force = v < 0 ? -1 : (v != 0 ? 1 : 0); break;
         case DSPMAP_P_FAST_DIVISION: if (v == 0) { m->d.div_ok = 0; m->div_forced_off = true; m->graph_epoch++; } break;
@@ -581,6 +589,7 @@ extern "C" double dspmap_get_param(const dspmap_t* m, int key) {
         case DSPMAP_P_ROLLOUT_INLINE: return m->ro_kernel ? 0 : 1;
         case DSPMAP_P_FAST_DIVISION: return m->d.div_ok;
         case DSPMAP_P_HOST_CLOUD_DIRECT: return m->host_direct ? 1 : 0;
+        case DSPMAP_P_EARLY_REGISTER: return m->early_reg;
         case DSPMAP_P_USE_GRAPH: return m->use_graph ? 1 : 0;
         default: return 0;
     }
@@ -713,8 +722,21 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     // (per-stage timing keeps the frame on one stream; so does a sparse map -- most tiles empty: two passes over all the tiles cost
     // more than the overlap gives: 264x264x80 filled by the depth stream 0.445 -> 0.434 ms, 132x132x60 0.232 -> 0.228; saturated
     // maps keep the split: 0.659 against 0.667 ms and 4.61 against 4.80 ms, interleaved runs on one box)
-    const bool split = !fork && !m->prof && (!c.sparse || m->place_split_tiles <= 1) && c.k.ntiles >= m->place_split_tiles;   // (1 = always, as documented)
+    const bool split0 = !fork && !m->prof && (!c.sparse || m->place_split_tiles <= 1) && c.k.ntiles >= m->place_split_tiles;   // (1 = always, as documented)
+    // EARLY REGISTRATION (round 5; DSPMAP_P_EARLY_REGISTER): k_predict registers the voxel-changing particles in their pyramids itself, the
+    // WHOLE placement runs on the side stream beside list preparation, Ck pass and weight update (which leaves its results with the
+    // list entries), and k_post / k_place_fix tie the two together behind the join.  Replaces the split placement where that applied.
+    // MEASURED (round 5, profiles/r05_*): bit-identical (tests/test_gpu_round5.py::test_early_registration_changes_nothing, incl. revoked
+    // arrivals and overfull lists) and NOT faster -- 132x132x60 saturated 0.686 against 0.657 ms, 264x264x80 4.42 / 4.40: the placement
+    // is bound by DRAM row activations, and the list preparation -- a chain of dependent round trips -- stretches from 13 to 137 us
+    // while it runs beside it; started behind the list preparation instead, the whole placement (138 us at the side stream's
+    // footprint) outlasts the pair kernels it hides behind (73 - 95 us), and k_post / k_place_fix / the second weight launch add
+    // ~20 us of dependent launches.  Hence OFF unless asked for (-1 = off).
+    const bool early = !fork && !m->prof && m->early_reg == 1;
+    (void)split0;
+    const bool split = split0 && !early;
     c.place_split = split;
+    c.early_reg = early;
     dspmap_prof_mark(m, 0);
     if (!fork) {
         launch_setup_and_bin(c, pts_grid, false, m->frame_ring ? m->ring_dev : nullptr, DSPMAP_RING - 1);   // the gather rides on k_predict's launch
@@ -743,9 +765,25 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
         // the children (the rank ran inside k_ve_clusters): on the side branch when it goes on with the placement of the tiles without
         // a view (large maps); otherwise the branch -- the longer one at the metric's size -- ends here and the waves of the split
         // generate them (launch_birth_late)
-        if (split) launch_birth_early(c2, birth_grid, false);
+        if (split || early) launch_birth_early(c2, birth_grid, false);
         (void)hipEventRecord(m->ev_join, m->stream2);
         dspmap_prof_mark(m, 2);
+        if (early) {
+            (void)hipEventRecord(m->ev_fork2, m->stream);                 // the prediction has ended: lists and inboxes are complete
+            launch_pyr_prepare(c);
+            (void)hipStreamWaitEvent(m->stream2, m->ev_fork2, 0);         // (behind the estimator's kernels)
+            launch_claim(c2, 0, 0, 0, 0, -1);
+            (void)hipEventRecord(m->ev_join, m->stream2);
+            launch_ck_partial(c, true, false);
+            launch_weight_update(c);
+            (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
+            launch_weight_update(c, true);
+            launch_post(c);
+            launch_place_fix(c);
+            launch_birth_late(c, birth_grid, false, false);
+            dspmap_resample(m, c);
+            return;
+        }
         launch_claim(c, 0, 0, 0, 0, split ? 1 : -1);
         if (split) launch_pyr_prepare(c);
         dspmap_prof_mark(m, 3);
@@ -773,6 +811,26 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     const bool early_birth = !fork && birth_grid > 0;
     launch_predict_only(c, !fork, early_birth);
     dspmap_prof_mark(m, 2);
+    if (early) {
+        (void)hipEventRecord(m->ev_fork2, m->stream);
+        launch_pyr_prepare(c);                                            // (queued before the side branch's kernel: the branch whose node comes first stays on the parent's queue)
+        (void)hipStreamWaitEvent(m->stream2, m->ev_fork2, 0);
+        LaunchCtx c2 = c;
+        c2.stream = m->stream2;
+        launch_claim(c2, early_birth ? birth_grid : 0, 0, 0, 0, -1);      // every tile; the newborn children ride along as before
+        (void)hipEventRecord(m->ev_join, m->stream2);
+        launch_ck_partial(c, true, false);
+        launch_weight_update(c);
+        (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
+        launch_weight_update(c, true);
+        launch_post(c);
+        launch_place_fix(c);
+        if (birth_grid <= 0) launch_ck_finalize(c);
+        if (early_birth) launch_birth_late(c, birth_grid, all_static);
+        else launch_birth(c, birth_grid, true, all_static);
+        dspmap_resample(m, c);
+        return;
+    }
     launch_claim(c, early_birth ? birth_grid : 0, 0, 0, 0, split ? 1 : -1);
     if (split) {
         // Only the arrivals of tiles that can see the field of view are registered in pyramids, so only their placement

@@ -84,6 +84,7 @@ struct dspmap {
     FrameParams hp = {};
     // HIP graph of the device-resident frame (dspmap_update_device)
     bool use_graph = true;
+    int early_reg = -1;              // DSPMAP_P_EARLY_REGISTER: -1 the frame decides (dense maps that would split their placement), 0 never, 1 always
     bool host_direct = true;         // DSPMAP_P_HOST_CLOUD_DIRECT: dspmap_update feeds the captured frame through the mapped cloud ring
     bool fut_clear_pending = false;   // clearOccupancyMapPrediction is lazy: done by the next frame's k_predict, or by the next reader
     hipStream_t stream2 = nullptr;   // fork/join branch inside the captured frame

@@ -17,6 +17,14 @@ struct KernelScratch {
     int* view_list;     // [ntiles] the tiles with a view on the field of view this frame, in no particular order (FrameScalars::n_view_tiles of them):
                         // written by extra workgroups of k_predict when the frame splits its placement, walked by the placement that precedes
                         // the pair kernels INSTEAD of all the tiles
+    // EARLY REGISTRATION (LaunchCtx::early_reg; dense large maps, captured frame): k_predict registers the particles that change voxel in
+    // their pyramids itself (their new position is known there), so that the list preparation and the Ck pass no longer wait for the
+    // placement -- which runs beside them on the side stream -- and the weight update leaves its results with the list entries:
+    int* in_ref;        // [ntiles * 64 * slots] per inbox record: its entry in the pyramid lists (pyramid * capa + position), -1 not in view,
+                        // -3 its pyramid's list was beyond CAPA (the particle vanishes, :1256-1259)
+    int* in_slot;       // [ntiles * 64 * slots] per inbox record: the cell k_place gave it (pidx), -1 none (voxel full)
+    float* fov_w_s;     // [np * capp] the weight update's result per range-sorted list entry (< 0: not re-weighted), scattered to the cells by k_post
+    int* ta_list;       // [np * (capa - capp)] list entries (pyramid * capa + position) k_pyr_prepare turned away (FrameScalars::n_ta)
     int* part_resample; // [ntiles rounded up to 4] live particles per tile after resampling
     int* vb_cnt;        // [v_loc] children per destination voxel this frame (birth ordering)
     int* vb_idx;        // [v_loc*128] their birth indices
@@ -52,6 +60,7 @@ struct LaunchCtx {
     bool sweep_rev = false;   // this frame's k_predict / k_resample walk the tiles from the last one down and k_place from the first one up
                               // (the next frame the other way round): every tile sweep starts where its predecessor ended (Infinity Cache)
     bool resample_rev = false;   // k_resample walks the tiles from the last one down (after a k_place that ended there)
+    bool early_reg = false;   // this frame: early registration (see KernelScratch::in_ref)
     bool place_split = false; // this frame places the arrivals of the tiles with a view first (launch_claim sel = 1) and the others beside the pair
                               // kernels (sel = 0): k_predict leaves the list of the tiles with a view (KernelScratch::view_list)
     bool sparse = false; // most tiles hold nothing (dspmap::sparse_mode): k_predict's variant that leaves such tiles first
@@ -81,6 +90,7 @@ void launch_velocity_estimator(const LaunchCtx& c, bool with_rank);   // with_ra
 int velocity_estimator_capacity();   // points per frame the device estimator handles
 int velocity_estimator_slices();
 // mapUpdate (:704-793)
+void launch_post(const LaunchCtx& c);          // early registration, after the placement and the weight update have both ended: weights -> cells, turned-away entries -> occupancy / dirty voxels
 void launch_place_fix(const LaunchCtx& c);     // re-slots the arrivals of voxels in which a full pyramid list turned a particle away (after launch_pyr_prepare)
 // sharded maps: one pass (8 bits, most significant first) of the distributed selection of every pyramid's CAPP-th smallest sweep key;
 // the caller sums `hist` ([np][256]) over the ranks between the two launches
@@ -89,9 +99,9 @@ void launch_pyr_pick(const LaunchCtx& c, int pass, const int* hist, int2* sel, i
 int pyr_select_passes();
 void launch_pyr_kept(const LaunchCtx& c, const int* kstar, int* kept);   // after the last pass: this rank's kept entries per pyramid
 void launch_pyr_prepare(const LaunchCtx& c);   // range sort + full-list selection of the pyramid lists, work items (idempotent)
-void launch_ck_partial(const LaunchCtx& c, bool prepared = false);     // launch_pyr_prepare (unless already queued) + the Ck pass
+void launch_ck_partial(const LaunchCtx& c, bool prepared = false, bool with_fix = true);   // with_fix: the first workgroups run k_place_fix's pass     // launch_pyr_prepare (unless already queued) + the Ck pass
 void launch_ck_finalize(const LaunchCtx& c);
-void launch_weight_update(const LaunchCtx& c);
+void launch_weight_update(const LaunchCtx& c, bool redo = false);   // redo (early registration): only if the placement revoked a registered arrival
 // mapAddNewBornParticlesByObservation (:796-921)
 void launch_birth(const LaunchCtx& c, int n_birth, bool in_frame, bool all_static);  // in_frame: between k_weight and k_resample of a whole frame
 void launch_birth_split(const LaunchCtx& c, int n_birth);

@@ -243,7 +243,8 @@ template <int MW, int NW, bool HASVZ, bool SPARSE>
 __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevState s, FilterParams fp, int has_vz, int* __restrict__ part,
                                                  float4* __restrict__ mv_rec, float4* __restrict__ in_rec, int* __restrict__ in_cnt,
                                                  u64* __restrict__ expmask, const int* __restrict__ vz_pre, const u64* __restrict__ vz_q,
-                                                 u64* __restrict__ omask, int extra, int* __restrict__ tile_fov, int rev, int* __restrict__ view_list) {
+                                                 u64* __restrict__ omask, int extra, int* __restrict__ tile_fov, int rev, int* __restrict__ view_list,
+                                                 int* __restrict__ in_ref) {
     // rev: the tiles are walked from the last one down (workgroup -> tile mapping only).  k_place always walks AGAINST the k_predict
     // before it: a large map's live rows are several times the 256 MB Infinity Cache, and a sweep that starts where the last one
     // ENDED finds its first tiles (rows, occupancy words, inbox records) there instead of in HBM -- 132x132x60 saturated:
@@ -621,6 +622,12 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
         }
     }
     // ---- tail 2: route the movers to the inbox of their destination tile
+    // (extra & 8, EARLY REGISTRATION: a mover whose new position lies in the field of view is registered in its pyramid HERE -- :1233-1259
+    // needs its position, weight and sweep key, all known now; only its slot is not, and the list entry points at the inbox record
+    // instead (k_place leaves the slot in KernelScratch::in_slot).  mapUpdate's list preparation and Ck pass then do not wait for the
+    // placement.  The reference registers a mover only if its voxel had room (:1227-1229 returns first): k_place revokes the entry
+    // of an arrival it finds no slot for.)
+    const bool early = (extra & 8) != 0;
     for (int i0 = 0; i0 < nmv; i0 += NW * 64 * TB) {
         int key[TB], pos[TB];
 #pragma unroll
@@ -630,14 +637,36 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
             if (i < nmv) key[j] = (__float_as_int(i < LSTG ? s_mv[i * 2].x : mv_rec[(mv_base + i) * 2].x) - d.v_base) >> 6;
         }
         batch_append<TB>(in_cnt, key, pos);
+        float4 ra[TB], rb[TB];
+        int pk[TB], pp2[TB];
 #pragma unroll
         for (int j = 0; j < TB; ++j) {
+            pk[j] = -1;
             // beyond the inbox: more arrivals than the tile has slots; k_place counts them as dropped
             if (key[j] < 0 || pos[j] >= cap) continue;
-            float4 a, b;
-            mv_get(i0 + j * NW * 64 + tid, a, b);
+            mv_get(i0 + j * NW * 64 + tid, ra[j], rb[j]);
             const size_t o = ((size_t)key[j] * cap + pos[j]) * 2;
-            in_rec[o] = a; in_rec[o + 1] = b;
+            in_rec[o] = ra[j]; in_rec[o + 1] = rb[j];
+            if (early) pk[j] = pyramid_of(d, s_ph, s_pv, ra[j].w, rb[j].x, rb[j].y);
+        }
+        if (early) {
+            batch_append<TB>(s.pyr_cnt, pk, pp2);
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                if (key[j] < 0 || pos[j] >= cap) continue;
+                const size_t ib = (size_t)key[j] * cap + pos[j];
+                int ref = -1;
+                if (pk[j] >= 0) {
+                    if (pp2[j] < d.capa) {
+                        const size_t o = (size_t)pk[j] * d.capa + pp2[j];
+                        s.fov_rec[o] = make_float4(ra[j].w, rb[j].x, rb[j].y, rb[j].z);
+                        s.fov_slot[o] = -2 - (int)ib;                 // "the cell k_place gives inbox record ib"
+                        s.fov_key[o] = __float_as_int(rb[j].w);      // a mover is registered when the sweep reaches its SOURCE cell
+                        ref = (int)o;
+                    } else ref = -3;                                  // the list is beyond CAPA: the particle vanishes (-2, :1256-1259); k_place counts it
+                }
+                in_ref[ib] = ref;
+            }
         }
     }
     // per-block statistics (reduced lazily by the host; no global atomics here)
@@ -690,12 +719,36 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
 #ifndef PLACE_SIDE_WG
 #define PLACE_SIDE_WG 3   // workgroups per CU of the side-stream placement
 #endif
+// EARLY REGISTRATION: an arrival that k_predict registered in pyramid b and that finds its voxel full is lost BEFORE the reference
+// would have registered it (:1227-1229 precede :1233): its terms are taken out of Ck again -- the same integers k_ck_partial adds
+// for its list entry (every term snapped to the 2^-34 grid; integer sums commute, so it does not matter which of the two comes
+// first) --, the weight update runs again once the placement has ended (launch_weight_update(redo)), and k_post skips the entry.
+// One thread, a few hundred pairs; rare (a voxel must be full).
+__device__ __forceinline__ void ck_revoke(const MapDims& d, const DevState& s, const FilterParams& fp, int b, float px, float py, float pz, float w) {
+    const int h0 = b / d.np_v, v0 = b % d.np_v;
+    const float pw = fp.p_det * w;
+    for (int i = -d.nn; i <= d.nn; ++i)
+        for (int j = -d.nn; j <= d.nn; ++j) {
+            const int h = h0 + i, v = v0 + j;
+            if (h < 0 || h >= d.np_h || v < 0 || v >= d.np_v) continue;
+            const int bin = h * d.np_v + v, n = s.obs_cnt[bin];
+            for (int k = 0; k < n; ++k) {
+                const float4 z = s.obs[bin * DSP_OBS_CAP + k];
+                const double t = ck_snap(pw * pair_gk(px, py, pz, z.x, z.y, z.z, fp.sigma_ob, fp.inv_sigma_ob, fp.pdf_c3));
+                const long long q = __double2ll_rn(t * CK_FIX_SCALE);
+                if (q) atomicAdd(reinterpret_cast<unsigned long long*>(&s.obs_ck[bin * DSP_OBS_CAP + k]), (unsigned long long)(-q));
+            }
+        }
+    atomicAdd(&s.fs->n_revoked, 1);
+    if (s.pyr_cnt[b] > d.capp) atomicAdd(&s.fs->n_overflow_inexact, 1);   // (it also took part in the cut of an overfull list)
+}
 #define PLACE_MAX 1024   // arrivals of one tile whose bucketed keys fit the LDS table; a tile that receives more (up to its
                          // capacity of 64 * slots records) keeps them in its own staging area of k_predict, which is dead by now
 template <int MW>
 __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, const float4* __restrict__ in_rec, int* __restrict__ in_cnt,
                                            const u64* __restrict__ omask,
-                                           float4* __restrict__ stage, const int BX, const int n_all, const bool was_live, const bool t_moving_in) {   // n_all = in_cnt[BX] > 0
+                                           float4* __restrict__ stage, const int BX, const int n_all, const bool was_live, const bool t_moving_in,
+                                           const FilterParams& fp, const int* __restrict__ in_ref, int* __restrict__ in_slot) {   // n_all = in_cnt[BX] > 0; in_ref: early registration
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
     __shared__ u64 s_cur[MW * 64], s_org[MW * 64], s_new[MW * 64], s_own[MW * 64];
@@ -763,7 +816,8 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
     for (int i0 = 0; i0 < n; i0 += 256) {
         const int i = i0 + tid;
         int key[1] = {-1}, pos[1];
-        int ln = 0, nsl = -1, skey = 0;
+        int ln = 0, nsl = -1, skey = 0, ref_in = -1;
+        const bool early = in_ref != nullptr;
         size_t nidx = 0;
         float px = 0, py = 0, pz = 0, w = 0, avx = 0, avy = 0;
         if (i < n) {
@@ -771,6 +825,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
             const float4 b = i == tid ? b0 : in_rec[(base + i) * 2 + 1];
             px = a.w; py = b.x; pz = b.y; w = b.z; avx = a.y; avy = a.z;
             skey = __float_as_int(b.w);
+            if (early) ref_in = in_ref[base + i];
             ln = (__float_as_int(a.x) - d.v_base) & 63;
             // position of this arrival in the reference's service order of its destination voxel, in closed form:
             // the nF arrivals from lower voxel indices take, in key order, the first free slots of the occupancy
@@ -831,16 +886,21 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
                 if (avx != 0.f || avy != 0.f) { st_vel(s, nidx, avx, avy); s.tile_moving[BX] = 1; }   // (k_predict wrote the tile's flag before any arrival)
                 else if (t_moving) st_vel(s, nidx, 0.f, 0.f);
                 s.w[nidx] = w;
-                key[0] = pyramid_of(d, s_ph, s_pv, px, py, pz);
+                if (!early) key[0] = pyramid_of(d, s_ph, s_pv, px, py, pz);
             } else {
                 ++c_vf;
+                if (early && ref_in >= 0) ck_revoke(d, s, fp, ref_in / d.capa, px, py, pz, w);
             }
+            if (early) in_slot[base + i] = nsl >= 0 ? (int)nidx : -1;
         }
-        batch_append<1>(s.pyr_cnt, key, pos);
+        if (!early) batch_append<1>(s.pyr_cnt, key, pos);
         if (nsl >= 0) {
             bool keep = true;
             int ref = -1;
-            if (key[0] >= 0) {
+            if (early) {
+                if (ref_in == -3) { ++c_pf; keep = false; }   // its pyramid's list was beyond CAPA when k_predict registered it: it vanishes (:1256-1259)
+                else ref = ref_in;
+            } else if (key[0] >= 0) {
                 if (pos[0] < d.capa) {
                     const size_t o = (size_t)key[0] * d.capa + pos[0];
                     s.fov_rec[o] = make_float4(px, py, pz, w);
@@ -884,7 +944,7 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
                                                const u64* __restrict__ omask, FilterParams fp, float4* __restrict__ child,
                                                int* __restrict__ vb_cnt, int* __restrict__ vb_idx, int nchild, int t0, int n0, int t1, int n1,
                                                const int* __restrict__ tile_fov, int sel, float4* __restrict__ stage, int rev,
-                                               const int* __restrict__ view_list) {
+                                               const int* __restrict__ view_list, const int* __restrict__ in_ref, int* __restrict__ in_slot) {
     // whole frame: workgroups behind the tiles generate the frame's newborn children (k_birth_children's job; needs the
     // birth cloud and the rank only, both done before this launch)
     // (the first `nchild` workgroups: they run beside the tiles, not after them).
@@ -912,7 +972,7 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
             int n_in, tf, t_live, t_mov;
             sload_i4(in_cnt + BX, tile_fov + BX, s.tile_live + BX, s.tile_moving + BX, n_in, tf, t_live, t_mov);
             if (n_in == 0) continue;
-            place_tile<MW>(d, s, in_rec, in_cnt, omask, stage, BX, n_in, t_live != 0, t_mov != 0);
+            place_tile<MW>(d, s, in_rec, in_cnt, omask, stage, BX, n_in, t_live != 0, t_mov != 0, fp, in_ref, in_slot);
             __syncthreads();
         }
         return;
@@ -944,7 +1004,7 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
             if ((tf >> 1) != epoch) fv = tile_view_test(d, s, BX, lane_id());
             if ((fv != 0) != (sel != 0)) continue;
         }
-        place_tile<MW>(d, s, in_rec, in_cnt, omask, stage, BX, n_in, t_live != 0, t_mov != 0);   // (the owner's view of in_cnt is stable: only the owner resets it)
+        place_tile<MW>(d, s, in_rec, in_cnt, omask, stage, BX, n_in, t_live != 0, t_mov != 0, fp, in_ref, in_slot);   // (the owner's view of in_cnt is stable: only the owner resets it)
         __syncthreads();   // the tile's LDS tables are re-used by the next one
     }
 }
@@ -2114,7 +2174,7 @@ void launch_spin(const LaunchCtx& c, int us) {   // wall_clock64 ticks at 100 MH
     if (us > 0) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c.stream, (long long)us * 100);
 }
 void launch_predict_only(const LaunchCtx& c, bool with_gather, bool with_rank) {
-    const int extra = (with_gather ? 1 : 0) | (with_rank ? 2 : 0) | (c.place_split ? 4 : 0);   // 4: list the tiles with a view for the split placement
+    const int extra = (with_gather ? 1 : 0) | (with_rank ? 2 : 0) | (c.place_split ? 4 : 0) | (c.early_reg ? 8 : 0);   // 4: list the tiles with a view for the split placement; 8: register the movers in their pyramids
     const unsigned xb = (with_gather ? (c.d.np + 3) / 4 : 0) + (with_rank ? 1 : 0) + (c.place_split ? (c.k.ntiles + 255) / 256 : 0);
     const KernelScratch* k = &c.k;
     if (c.s.vz0) {   // constructor-seeded particles take their velocity noise in the reference's sweep order
@@ -2124,7 +2184,7 @@ void launch_predict_only(const LaunchCtx& c, bool with_gather, bool with_rank) {
         launch_scan_blocks(c, nblk);   // blk_cnt -> exclusive, total -> fs->occupied_count
     }
 #define PRED_LAUNCH(MWV, VZ, SP) hipLaunchKernelGGL((k_predict<MWV, 4, VZ, SP>), dim3(k->ntiles + xb), dim3(256), 0, c.stream, c.d, c.s, c.fp, VZ ? 1 : 0, \
-                                                k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask, extra, k->tile_fov, c.sweep_rev ? 1 : 0, k->view_list)
+                                                k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask, extra, k->tile_fov, c.sweep_rev ? 1 : 0, k->view_list, k->in_ref)
 #define PRED_LAUNCH2(MWV, VZ) do { if (c.sparse) PRED_LAUNCH(MWV, VZ, true); else PRED_LAUNCH(MWV, VZ, false); } while (0)
     if (c.d.mw == 1) { if (c.s.vz0) PRED_LAUNCH2(1, true); else PRED_LAUNCH2(1, false); }
     else { if (c.s.vz0) PRED_LAUNCH2(2, true); else PRED_LAUNCH2(2, false); }
@@ -2145,9 +2205,11 @@ void launch_claim(const LaunchCtx& c, int n_birth_grid, int part, int tile_lo, i
     unsigned grid = (unsigned)(n0 + n1) + xb;
     if (sel == 0) grid = std::min(grid, (unsigned)(PLACE_SIDE_WG * c.n_cu));
     const int* vlist = (sel == 1 && c.place_split && part == 0) ? k->view_list : nullptr;   // (k_predict listed the tiles with a view)
+    const int* iref = c.early_reg ? k->in_ref : nullptr;                                    // (k_predict registered the movers in their pyramids)
+    if (c.early_reg) grid = std::min((unsigned)(n0 + n1), (unsigned)(PLACE_SIDE_WG * c.n_cu)) + xb;   // the whole placement runs beside the pair kernels
     if (vlist) grid = std::min((unsigned)(n0 + n1), (unsigned)(PLACE_LB * c.n_cu)) + xb;    // one round of workgroups walks the list
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec, c.sweep_rev ? 0 : 1, vlist);
-    else hipLaunchKernelGGL(k_place<2>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec, c.sweep_rev ? 0 : 1, vlist);
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec, c.sweep_rev ? 0 : 1, vlist, iref, k->in_slot);
+    else hipLaunchKernelGGL(k_place<2>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec, c.sweep_rev ? 0 : 1, vlist, iref, k->in_slot);
 }
 void launch_predict(const LaunchCtx& c, bool with_gather) {
     launch_predict_only(c, with_gather, false);

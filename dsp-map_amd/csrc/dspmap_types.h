@@ -105,6 +105,9 @@ struct FrameScalars {
     int view_epoch, stale_n;
     int n_birth_ovf;    // entries of DevState::birth_ovf (reset by the birth rank, which precedes every generation of children)
     int est_n;          // length of the birth cloud the device velocity estimator wrote (kept when a view is empty, :1379)
+    int n_ta;           // entries of KernelScratch::ta_list (early registration: the list entries k_pyr_prepare turned away this frame)
+    int n_revoked;      // early registration: arrivals that k_predict registered in a pyramid and that then found their voxel full (k_place takes
+                        // their terms out of Ck again and the weight update is repeated, launch_weight_update(redo))
     int n_view_tiles;   // entries of KernelScratch::view_list: the tiles whose box can intersect the field of view this frame (k_predict's extra
                         // workgroups of a split placement; reset with the pyramid lists)
     int pred_epoch;     // bumped by whatever resets the pyramid lists for a prediction (k_reset / k_obs_points): k_place stamps the tiles it

@@ -150,6 +150,12 @@ enum dspmap_param {
                                        slot of a pinned, device-mapped ring and the captured frame's first kernel reads it over the bus: the frame is
                                        ONE graph launch (needs DSPMAP_P_USE_GRAPH and the device velocity estimator); 0 = pinned staging + one H2D
                                        copy + an event in front of the graph (rounds 1-4).  Same result either way */
+    DSPMAP_P_EARLY_REGISTER = 24,   /* whole frames (dspmap_update / dspmap_update_device): the prediction sweep itself registers the particles that change
+                                       voxel in their pyramids (:1233-1259 -- their new position is known there), so that mapUpdate's list preparation
+                                       and Ck pass run BESIDE the placement of those particles (:1209-1230) instead of after it, and the weights reach
+                                       the cells once both have ended.  1 = on; 0 / -1 (default) = off: the same result slot for slot (tested), but measured
+                                       slower on the saturated maps it was built for (the placement is bound by DRAM row activations and the list
+                                       preparation stretches 10 x beside it; DESIGN.md / LOG.md round 5).  DSPMAP_EARLY_REGISTER sets new handles' default */
     DSPMAP_P_PAIR_CULL_SIGMAS = 13  /* mapUpdate evaluates a (particle, observation) pair only if their ranges differ by at most this many
                                        sigma_ob (default 9: the dropped terms are < 1e-19 and zero on the fixed-point Ck grid);
                                        a huge value evaluates every pair of the neighbourhood like the reference's loops */
