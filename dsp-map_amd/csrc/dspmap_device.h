@@ -20,6 +20,9 @@ __device__ __forceinline__ void sload_i3(const int* p0, const int* p1, const int
     asm volatile("s_load_dword %0, %3, 0x0\n\ts_load_dword %1, %4, 0x0\n\ts_load_dword %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
                  : "=&s"(v0), "=&s"(v1), "=&s"(v2) : "s"(p0), "s"(p1), "s"(p2));
 }
+__device__ __forceinline__ void sload_i2(const int* p0, const int* p1, int& v0, int& v1) {   // two at once: one round trip
+    asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v0), "=&s"(v1) : "s"(p0), "s"(p1));
+}
 __device__ __forceinline__ void sload_i4(const int* p0, const int* p1, const int* p2, const int* p3, int& v0, int& v1, int& v2, int& v3) {   // four at once
     asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\ts_load_dword %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
                  : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3) : "s"(p0), "s"(p1), "s"(p2), "s"(p3));

@@ -755,7 +755,8 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
     __shared__ int s_lcnt[64], s_loff[65];
     __shared__ int s_bk[PLACE_MAX];              // source keys of the arrivals, bucketed by destination lane
     __shared__ int s_cnt[2];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, NT = (int)blockDim.x;   // (64 threads per workgroup on sparse maps: a tile receives a handful of arrivals and
+                                                         // what bounds the launch is how many tiles' latency chains run at once, launch_claim)
     // was_live: an empty tile was skipped by k_predict: its omask words are stale (and zero in truth)
     const bool t_moving = t_moving_in || !d.tile_skip;   // tile_moving as k_predict left it (this workgroup is the only one that raises it during the placement)
     const int cap = 64 * d.slots;
@@ -791,7 +792,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
     int c_vf = tid == 0 ? n_all - n : 0, c_pf = 0;
     __syncthreads();
     // bucket the arrivals' source keys by destination lane: counts, offsets, then every key into its lane's run
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += NT) {
         const int gv = __float_as_int(i == tid ? a0.x : in_rec[(base + i) * 2].x);
         atomicAdd(&s_lcnt[(gv - d.v_base) & 63], 1);
     }
@@ -804,7 +805,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
         s_lcnt[tid] = 0;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += NT) {
         const int gv = __float_as_int(i == tid ? a0.x : in_rec[(base + i) * 2].x);
         const int key = __float_as_int(i == tid ? b0.w : in_rec[(base + i) * 2 + 1].w);
         const int ln = (gv - d.v_base) & 63;
@@ -813,7 +814,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
         else __hip_atomic_store(&gbk[o], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += 256) {
+    for (int i0 = 0; i0 < n; i0 += NT) {
         const int i = i0 + tid;
         int key[1] = {-1}, pos[1];
         int ln = 0, nsl = -1, skey = 0, ref_in = -1;
@@ -955,11 +956,10 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
         birth_child_thread(d, s, fp, child, vb_cnt, vb_idx, (int)(blockIdx.x * 256 + threadIdx.x));
         return;
     }
-    // Everything a workgroup needs to know about a tile before it decides to work on it -- arrivals, the tile's view tag, its live
-    // and moving flags -- comes in ONE scalar round trip (round 5; there were three dependent ones, paid by every tile of both
-    // launches of a split placement: on a saturated map nearly every tile has arrivals, so the 85 % of the tiles that belong to the
-    // OTHER launch cost the launch that skips them most of its time -- 65 us for the tiles with a view, 89 us for the 768 strided
-    // workgroups of the side launch, profiles/r04_i_C_sat_timeline.md).
+    // What a workgroup needs to know to decide whether a tile is its business -- arrivals, and in a split placement the tile's view
+    // tag -- comes in ONE scalar round trip; the tile's live / moving flags follow in a second one for the tiles it works on (round 5;
+    // there were three dependent ones before the decision.  Fetching all four words at once costs the EMPTY tiles of a sparse map --
+    // 75 of 87 k workgroups at 264x264x80 -- three more cache lines each: 48 -> 87 us for that launch).
     const int nt = n0 + n1, bq0 = (int)blockIdx.x - nchild, stride = (int)gridDim.x - nchild;
     if (sel == 1 && view_list) {
         // the tiles with a view, from k_predict's list (a frame that splits its placement): a few per cent of a large map's tiles, so the
@@ -979,13 +979,13 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
     }
     if (bq0 >= nt) return;
     const int epoch = sel >= 0 ? sload_i(&s.fpar->epoch) : 0;
-    int n_in, tf, t_live, t_mov;
-    {   // the first tile's flags; a workgroup whose ONLY tile has nothing for it leaves HERE, before the loop below is set up: the
+    int n_in, tf = 0;
+    {   // the first tile's words; a workgroup whose ONLY tile has nothing for it leaves HERE, before the loop below is set up: the
         // invariants the compiler hoists in front of it (~100 vector instructions with the scalar registers it parks in lanes) were
         // what a sparse map's placement spent its time on -- 87 120 workgroups, 12 k with arrivals
         const int bqr = rev ? nt - 1 - bq0 : bq0;
         const int BX = bqr < n0 ? t0 + bqr : t1 + (bqr - n0);
-        sload_i4(in_cnt + BX, tile_fov + BX, s.tile_live + BX, s.tile_moving + BX, n_in, tf, t_live, t_mov);
+        if (sel >= 0) sload_i2(in_cnt + BX, tile_fov + BX, n_in, tf); else n_in = sload_i(in_cnt + BX);
         if (bq0 + stride >= nt && !(has_vz && BX == 0)) {
             if (n_in == 0) return;
             if (sel >= 0 && (tf >> 1) == epoch && ((tf & 1) != 0) != (sel != 0)) return;
@@ -996,7 +996,7 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
         const int BX = bqr < n0 ? t0 + bqr : t1 + (bqr - n0);   // tile index
         if (has_vz && BX == 0 && sel != 0 && threadIdx.x == 0)   // k_predict drew 3 table values per ranked particle (:655-657)
             s.fs->v_cur = (int)(((long long)s.fs->v_cur + 3ll * (long long)s.fs->occupied_count) % tab_n);
-        if (bq != bq0) sload_i4(in_cnt + BX, tile_fov + BX, s.tile_live + BX, s.tile_moving + BX, n_in, tf, t_live, t_mov);
+        if (bq != bq0) { if (sel >= 0) sload_i2(in_cnt + BX, tile_fov + BX, n_in, tf); else n_in = sload_i(in_cnt + BX); }
         if (n_in == 0) continue;   // (no arrivals -- or the tile's owner is done with them)
         if (sel >= 0) {   // a split placement: the other launch owns the tiles of the other kind
             int fv = tf & 1;
@@ -1004,6 +1004,8 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
             if ((tf >> 1) != epoch) fv = tile_view_test(d, s, BX, lane_id());
             if ((fv != 0) != (sel != 0)) continue;
         }
+        int t_live, t_mov;
+        sload_i2(s.tile_live + BX, s.tile_moving + BX, t_live, t_mov);
         place_tile<MW>(d, s, in_rec, in_cnt, omask, stage, BX, n_in, t_live != 0, t_mov != 0, fp, in_ref, in_slot);   // (the owner's view of in_cnt is stable: only the owner resets it)
         __syncthreads();   // the tile's LDS tables are re-used by the next one
     }
@@ -2208,8 +2210,14 @@ void launch_claim(const LaunchCtx& c, int n_birth_grid, int part, int tile_lo, i
     const int* iref = c.early_reg ? k->in_ref : nullptr;                                    // (k_predict registered the movers in their pyramids)
     if (c.early_reg) grid = std::min((unsigned)(n0 + n1), (unsigned)(PLACE_SIDE_WG * c.n_cu)) + xb;   // the whole placement runs beside the pair kernels
     if (vlist) grid = std::min((unsigned)(n0 + n1), (unsigned)(PLACE_LB * c.n_cu)) + xb;    // one round of workgroups walks the list
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec, c.sweep_rev ? 0 : 1, vlist, iref, k->in_slot);
-    else hipLaunchKernelGGL(k_place<2>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec, c.sweep_rev ? 0 : 1, vlist, iref, k->in_slot);
+    // a large sparse map: a tile receives a handful of arrivals and the launch is as long as (tiles with arrivals / resident workgroups) x
+    // one tile's chain of round trips: two-wave workgroups there (264x264x80 filled by the depth stream: frame 0.435 -> 0.420 ms, two
+    // alternating pairs of runs; one wave: no better; 132x132x60: +2 % with either, so only from 32 768 tiles on; the children riding
+    // along need 256 threads)
+    static const int sparse_threads = getenv("DSPMAP_PLACE_THREADS_SPARSE") ? atoi(getenv("DSPMAP_PLACE_THREADS_SPARSE")) : 128;
+    const unsigned nthr = (c.sparse && xb == 0 && !c.early_reg && c.k.ntiles >= 32768) ? (unsigned)sparse_threads : 256u;
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(grid), dim3(nthr), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec, c.sweep_rev ? 0 : 1, vlist, iref, k->in_slot);
+    else hipLaunchKernelGGL(k_place<2>, dim3(grid), dim3(nthr), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec, c.sweep_rev ? 0 : 1, vlist, iref, k->in_slot);
 }
 void launch_predict(const LaunchCtx& c, bool with_gather) {
     launch_predict_only(c, with_gather, false);
