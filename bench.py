@@ -636,8 +636,9 @@ def main():
             def host_frames(fr):
                 for pts, pos, quat, t in fr:
                     # dspmap_update: what DSPMap::update(int, int, float*, ...) forwards to (src/map_sim_example.cpp:345-347):
-                    # the caller's HOST cloud is staged through a pinned ring, one H2D copy of <= 60 kB, then the same captured
-                    # frame as dspmap_update_device; returns after enqueue like the reference returns after its own work
+                    # the caller's HOST cloud is copied into a slot of a pinned, device-mapped ring during the call and the captured
+                    # frame's first kernel reads it over the bus (no copy node, no event: one graph launch per frame, round 5);
+                    # returns after enqueue like the reference returns after its own work
                     assert mh.L.dspmap_update(mh.h, pts.shape[0], 3, pts.ctypes.data_as(C.c_void_p), pos[0], pos[1], pos[2], t,
                                               quat[0], quat[1], quat[2], quat[3]) == 1
                     mh.clearOccupancyMapPrediction()
@@ -652,8 +653,10 @@ def main():
             result["host_update_66x66x40"] = {
                 "what": "the drop-in boundary's own call, PCIe-inclusive: dspmap_update(float* HOST cloud, pose) -- what DSPMap::update "
                         "(include/dsp_dynamic.h, reference :181) forwards to and src/map_sim_example.cpp:345-347 calls -- %d frames of "
-                        "workload B, cloud staged through pinned memory + one H2D copy per frame, estimator on the device; never the "
-                        "contract line's value (that one has the cloud resident in HBM)" % len(host[30:]),
+                        "workload B, cloud copied into a pinned device-mapped ring and read over the bus by the frame's first kernel, "
+                        "estimator on the device; never the contract line's value (the contract defines that one with the cloud "
+                        "resident in HBM)" % len(host[30:]),
+                "ratio_to_device_resident": round((1.0 / dth) / fps, 4),
                 "frames_per_s": round(1.0 / dth, 1), "ms_per_frame": round(dth * 1e3, 4),
                 "h2d_bytes_per_frame": int(host[-1][0].nbytes)}
             mh.close()
