@@ -24,6 +24,7 @@
 #include "dspmap_device.h"
 
 #include <dlfcn.h>
+#include <sched.h>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <sys/types.h>
@@ -80,9 +81,15 @@ struct dspmap_dist {
     double xratio = 0.75;               // exports of a frame / (cells of one layer x |dz| / res): what fraction of "a layer's slots times the vertical
                                         // step in voxels" really crossed a face in earlier frames (0.75: nothing known -- more than a saturated map's 0.5)
     int* cnt2 = nullptr;                // device: export counts {up, down}
-    int* gmax_pin = nullptr;            // pinned: the largest export of a frame over all ranks
-    hipEvent_t gmax_ev = nullptr;
-    bool gmax_pending = false;
+    // what a frame learns for later ones -- its largest export over all ranks, the longest pyramid list -- reaches the host through
+    // pinned, device-MAPPED memory: the frame's last small kernel writes {export max, list max, frame + 1} into slot (frame % 4); frame k
+    // uses frame k - 2's values (every rank the same frame's: the decisions derived from them must agree) and normally finds them
+    // there without waiting -- no D2H copy node, no event, no host synchronisation per frame (round 5)
+    volatile int* pub = nullptr;        // host view [4][4]
+    int* pub_dev = nullptr;             // device view
+    unsigned frame_no = 0;              // frames begun
+    int xsend_hist[4] = {0, 0, 0, 0};   // message size of the last frames
+    float dz_hist[4] = {0.f, 0.f, 0.f, 0.f};   // |vertical step| of the last frames
     int nb_hi = 0;                      // longest birth cloud so far (span of the n_static all-reduce)
     int min_slab = 1;                   // thinnest slab of the partition, in layers (number of forwarding rounds)
     long long overflow_frames = 0;
@@ -136,6 +143,13 @@ __global__ void k_dist_gcnt(MapDims d, const long long* __restrict__ gcnt, int* 
     if (threadIdx.x == 0) {
         *out = mx;
         if (!exact && mx > d.capp) atomicAdd(&fs->n_overflow_inexact, 1);
+    }
+}
+__global__ void k_dist_publish(const int* __restrict__ two, int* __restrict__ slot, int seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        slot[0] = two[0]; slot[1] = two[1];
+        __threadfence_system();
+        slot[2] = seq;
     }
 }
 __global__ void k_group_sum_i32(PtrList l, int count);
@@ -230,9 +244,14 @@ static int dist_alloc(dspmap* m, int world, int rank) {
         m->s.pyr_gcnt = ck + (size_t)d.np * DSP_OBS_CAP;
         m->graph_epoch++;
     }
-    HIPCHK(m, hipHostMalloc((void**)&x->gmax_pin, sizeof(int) * 2));
-    x->gmax_pin[0] = 0;
-    HIPCHK(m, hipEventCreateWithFlags(&x->gmax_ev, hipEventDisableTiming));
+    {
+        int* pub_h = nullptr;
+        HIPCHK(m, hipHostMalloc((void**)&pub_h, sizeof(int) * 16, hipHostMallocMapped));
+        memset(pub_h, 0, sizeof(int) * 16);
+        void* dp = nullptr;
+        HIPCHK(m, hipHostGetDevicePointer(&dp, pub_h, 0));
+        x->pub = pub_h; x->pub_dev = (int*)dp;
+    }
     // thinnest slab of an even partition of nz over `world` ranks (dsp-map_amd/sharded.py: slab_ranges)
     x->min_slab = std::max(1, d.nz / std::max(1, world));
     if (!m->k.expmask) {
@@ -258,8 +277,7 @@ void dspmap_dist_free(dspmap* m) {
     if (x->kstar) (void)hipFree(x->kstar);
     if (x->kept) (void)hipFree(x->kept);
     m->s.pyr_kept = nullptr; m->s.pyr_kstar = nullptr; m->s.pyr_gcnt = nullptr;
-    if (x->gmax_pin) (void)hipHostFree(x->gmax_pin);
-    if (x->gmax_ev) (void)hipEventDestroy(x->gmax_ev);
+    if (x->pub) (void)hipHostFree((void*)x->pub);
     for (hipEvent_t e : x->gev) if (e) (void)hipEventDestroy(e);
     delete x;
     m->dist = nullptr;
@@ -420,17 +438,20 @@ static int phase_begin(dspmap* m, int n_points, const float* points_dev, int n_b
                        const float pos[3], double stamp, const float q[4]) {
     dspmap_dist* x = m->dist;
     // the size of this frame's messages: from the largest export two frames ago at the latest (its copy has landed)
-    if (x->gmax_pending) {
-        HIPCHK(m, hipEventSynchronize(x->gmax_ev));
-        x->gmax_pending = false;
-        const int g = x->gmax_pin[0];
-        x->gcnt_max = x->gmax_pin[1];
-        if (g > x->xsend) ++x->overflow_frames;   // that frame's messages were too small: particles were lost
-        // what crossed a face per unit of vertical step (m->hp still holds THAT frame's step): vz == 0, so a frame's exports follow its
-        // own |dz| -- the size of the NEXT message is derived from the next frame's step below, not from this count (round 5: a message
-        // sized from the last frame's exports alone shrank to its floor after a frame without vertical motion and lost the particles of
-        // the next frame that had one)
-        const double steps = std::fabs((double)m->hp.od[2]) / m->d.res;
+    if (x->frame_no >= 2) {
+        const unsigned f = x->frame_no - 2;
+        volatile int* sl = x->pub + 4 * (f & 3u);
+        for (long spin = 0; (unsigned)sl[2] != f + 1u; ++spin) {   // (frame k - 2 has normally ended long ago)
+            if (spin > 4000) { HIPCHK(m, hipStreamSynchronize(m->stream)); if ((unsigned)sl[2] != f + 1u) return dspmap_fail(m, DSPMAP_E_STATE, "frame %u never published its export count", f); break; }
+            sched_yield();
+        }
+        const int g = sl[0];
+        x->gcnt_max = sl[1];
+        if (g > x->xsend_hist[f & 3u]) ++x->overflow_frames;   // that frame's messages were too small: particles were lost
+        // what crossed a face per unit of vertical step in THAT frame: vz == 0, so a frame's exports follow its own |dz| -- the size of
+        // this frame's message is derived from ITS step below, not from that count (round 5: a message sized from the last frame's exports
+        // alone shrank to its floor after a frame without vertical motion and lost the particles of the next frame that had one)
+        const double steps = (double)x->dz_hist[f & 3u] / m->d.res;
         const double layer_cells = (double)m->d.nx * m->d.ny * m->d.slots;
         if (steps * layer_cells >= 1.0) x->xratio = std::max((double)g / (steps * layer_cells), 0.9 * x->xratio);
     }
@@ -456,6 +477,8 @@ static int phase_begin(dspmap* m, int n_points, const float* points_dev, int n_b
         const double layer_cells = (double)m->d.nx * m->d.ny * m->d.slots;
         const double want = m->vz_frames_at_begin > 0 ? (double)x->xcap : 1.5 * x->xratio * steps * layer_cells + 2048.0;
         x->xsend = (int)std::min<double>((double)x->xcap, std::max<double>(4096.0, std::ceil(want)));
+        x->xsend_hist[x->frame_no & 3u] = x->xsend;
+        x->dz_hist[x->frame_no & 3u] = std::fabs(m->hp.od[2]);
     }
     x->nb_hi = std::max(x->nb_hi, m->last_n_birth);
     LaunchCtx c = dspmap_ctx_of(m);
@@ -492,9 +515,8 @@ static int phase_weights(dspmap* m) { return dspmap_mgpu_weights_and_split(m); }
 static int phase_finish(dspmap* m) {
     dspmap_dist* x = m->dist;
     // the frame's largest export (all ranks) travels to the host behind the all-reduce; read at the start of a later frame
-    HIPCHK(m, hipMemcpyAsync(x->gmax_pin, m->s.nstatic + x->nb_hi, 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(m, hipEventRecord(x->gmax_ev, m->stream));
-    x->gmax_pending = true;
+    hipLaunchKernelGGL(k_dist_publish, dim3(1), dim3(64), 0, m->stream, m->s.nstatic + x->nb_hi, x->pub_dev + 4 * (x->frame_no & 3u), (int)(x->frame_no + 1u));
+    ++x->frame_no;
     return dspmap_mgpu_finish(m);
 }
 
