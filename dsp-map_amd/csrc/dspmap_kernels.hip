@@ -149,13 +149,27 @@ __device__ __forceinline__ int range_bucket(const MapDims& d, const float4& r) {
     return min(PS_NBK - 1, (int)(len * d.rng_inv_bw));
 }
 __device__ __forceinline__ int block_excl_scan_1024(int v, int* s_tmp, int* total);
+#ifndef PSU
+#define PSU 4   // list entries per thread and step in k_pyr_prepare's passes
+#endif
+#ifdef PYR_PROF
+__device__ long long g_pprof[8 * 1024];
+extern "C" int dspmap_debug_pyr_prof(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pprof), sizeof(long long) * (size_t)n); }
+#define PSTAMP(k) do { if (threadIdx.x == 0 && b < 1024) g_pprof[b * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define PSTAMP(k) do { } while (0)
+#endif
 __device__ __forceinline__ void pyr_sort_block(const MapDims& d, const DevState& s, int b, int* __restrict__ ta_list) {   // ta_list: early registration
     __shared__ int s_hist[PS_NBK], s_base[PS_NBK];
     __shared__ int s_sel[8192];
     __shared__ int s_pick[2];
     __shared__ int s_scan[17];
     const int tid = threadIdx.x;
+    PSTAMP(0);
     const int P_all = min(s.pyr_cnt[b], d.capa);
+#ifdef PYR_PROF
+    if (tid == 0 && b < 1024) g_pprof[b * 8 + 7] = P_all;
+#endif
     if (tid == 0 && s.pyr_gcnt) s.pyr_gcnt[b] = P_all;   // (a sharded map: the ranks' list lengths are summed by the Ck all-reduce)
     if (P_all == 0) return;
     const float4* __restrict__ src = s.fov_rec + (size_t)b * d.capa;
@@ -182,11 +196,16 @@ __device__ __forceinline__ void pyr_sort_block(const MapDims& d, const DevState&
             const int shift = ps * 13;
             for (int q = tid; q < 8192; q += 1024) s_sel[q] = 0;
             __syncthreads();
-            for (int i0 = 0; i0 < P_all; i0 += 1024) {
-                const int i = i0 + tid;
+            for (int i00 = 0; i00 < P_all; i00 += 1024 * PSU) {
+                unsigned k_u[PSU];
+#pragma unroll
+                for (int u = 0; u < PSU; ++u) k_u[u] = (unsigned)src_key[min(i00 + u * 1024 + tid, P_all - 1)];   // (the step's loads together)
+#pragma unroll
+                for (int u = 0; u < PSU; ++u) {
+                const int i = i00 + u * 1024 + tid;
                 int bin = -1;
                 if (i < P_all) {
-                    const unsigned k = (unsigned)src_key[i];
+                    const unsigned k = k_u[u];
                     if (ps == npass - 1 || (k >> (shift + 13)) == (prefix >> (shift + 13))) bin = (int)((k >> shift) & 8191u);
                 }
                 // the keys of a pyramid share their high bits: one LDS atomic per distinct bin of a wavefront, not one per lane
@@ -197,6 +216,7 @@ __device__ __forceinline__ void pyr_sort_block(const MapDims& d, const DevState&
                     const u64 grp = __ballot(bin == bk);
                     if (lane_id() == leader) atomicAdd(&s_sel[bk], (int)__popcll(grp));
                     todo &= ~grp;
+                }
                 }
             }
             __syncthreads();
@@ -221,12 +241,27 @@ __device__ __forceinline__ void pyr_sort_block(const MapDims& d, const DevState&
         }
         kstar = (int)prefix;
     }
+    PSTAMP(1);
     if (tid < PS_NBK) s_hist[tid] = 0;
     __syncthreads();
     int removed = 0;
-    for (int i = tid; i < P_all; i += 1024) {
-        const int key_i = src_key[i];
-        const float4 r_i = src[i];   // (requested together with the key: one memory round trip per step)
+    // (PSU entries per thread and step, their loads issued together: a step is one memory round trip, ~1.5 us, and a list of config E
+    // has 55 k entries -- 54 steps per pass at one entry per thread: 75 + 80 us for the two passes of the longest lists, round 5)
+    for (int i0 = tid; i0 < P_all; i0 += 1024 * PSU) {
+        int key_u[PSU];
+        float4 r_u[PSU];
+#pragma unroll
+        for (int u = 0; u < PSU; ++u) {   // unconditional loads (clamped index): a predicated load would be waited for before the next is issued
+            const int ic = min(i0 + u * 1024, P_all - 1);
+            key_u[u] = src_key[ic];
+            r_u[u] = src[ic];
+        }
+#pragma unroll
+        for (int u = 0; u < PSU; ++u) {
+        const int i = i0 + u * 1024;
+        if (i >= P_all) continue;
+        const int key_i = key_u[u];
+        const float4 r_i = r_u[u];
         if (key_i <= kstar) atomicAdd(&s_hist[range_bucket(d, r_i)], 1);
         else if (key_i != 0x7fffffff) {
             // turned away: the particle vanishes (-2): its cell -> (voxel, slot) -> occupancy bit.  The entry is marked so
@@ -252,9 +287,11 @@ __device__ __forceinline__ void pyr_sort_block(const MapDims& d, const DevState&
             }
             ++removed;
         }
+        }
     }
     if (__ballot(removed != 0)) { removed = wave_sum_i(removed); if (lane_id() == 0 && removed) atomicAdd(&s.fs->n_pyr_removed, removed); }
     __syncthreads();
+    PSTAMP(2);
     if (tid < PS_NBK) {   // exclusive scan over the 128 buckets: two waves
         const int c = s_hist[tid];
         const int inc = wave_incl_scan_i(c);
@@ -269,17 +306,49 @@ __device__ __forceinline__ void pyr_sort_block(const MapDims& d, const DevState&
         s_hist[tid] = 0;
     }
     __syncthreads();
-    for (int i = tid; i < P_all; i += 1024) {
-        const int key_i = src_key[i];
-        const float4 r = src[i];
-        const int sl_i = src_slot[i];
-        if (key_i > kstar) continue;
-        const int k = range_bucket(d, r);
-        const int pos = s_base[k] + atomicAdd(&s_hist[k], 1);
-        s.fov_rec_s[(size_t)b * d.capp + pos] = r;
-        s.fov_slot_s[(size_t)b * d.capp + pos] = sl_i;
-        s.fov_spos[(size_t)b * d.capa + i] = pos;   // (k_place_fix re-points the entries of particles it moves)
+    {
+        // software-pipelined: the NEXT step's loads are issued before this step's (scattered) stores -- loads and stores share one
+        // in-order counter on this part, so a step that waits for its loads also waits for every store issued before them
+        int key_u[PSU], sl_u[PSU], key_n[PSU], sl_n[PSU];
+        float4 r_u[PSU], r_n[PSU];
+        auto fetch = [&](int i0, int (&kk)[PSU], int (&ss)[PSU], float4 (&rr)[PSU]) {
+#pragma unroll
+            for (int u = 0; u < PSU; ++u) {
+                const int ic = min(i0 + u * 1024, P_all - 1);
+                kk[u] = src_key[ic]; rr[u] = src[ic]; ss[u] = src_slot[ic];
+            }
+        };
+        fetch(tid, key_u, sl_u, r_u);
+        for (int i0 = tid; i0 < P_all; i0 += 1024 * PSU) {
+            const bool more = i0 + 1024 * PSU < P_all;
+            if (more) fetch(i0 + 1024 * PSU, key_n, sl_n, r_n);
+#pragma unroll
+            for (int u = 0; u < PSU; ++u) {
+                const int i = i0 + u * 1024;
+                if (i >= P_all || key_u[u] > kstar) continue;
+                const float4 r = r_u[u];
+                const int k = range_bucket(d, r);
+                const int pos = s_base[k] + atomicAdd(&s_hist[k], 1);
+                s.fov_rec_s[(size_t)b * d.capp + pos] = r;
+                s.fov_slot_s[(size_t)b * d.capp + pos] = sl_u[u];
+                // where the entry went: k_place_fix re-points the entries of the ARRIVALS it moves -- only theirs is noted (a stayer's sweep
+                // key is its own cell; an arrival carries its source's): one scattered store less for nine entries in ten
+                const int c = sl_u[u];
+                bool arrival = c < 0;   // (early registration: the cell is not known yet -- an arrival by construction)
+                if (!arrival) {
+                    const int tile = c / (64 * d.slots), rem = c - tile * 64 * d.slots;
+                    arrival = key_u[u] != (tile * 64 + (rem & 63) + d.v_base) * d.slots + (rem >> 6);
+                }
+                if (arrival) s.fov_spos[(size_t)b * d.capa + i] = pos;
+            }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < PSU; ++u) { key_u[u] = key_n[u]; sl_u[u] = sl_n[u]; r_u[u] = r_n[u]; }
+            }
+        }
     }
+    __syncthreads();
+    PSTAMP(3);
 }
 __device__ __forceinline__ void pyr_items_block(const MapDims& d, const DevState& s, int* __restrict__ ck_items, int* __restrict__ wu_items,
                                                 int* __restrict__ n_items, int* __restrict__ nb_tab);
