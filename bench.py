@@ -763,7 +763,7 @@ def main():
             fre = gen_frames(we, 3 + 6, seed=1234)
 
             def group_run(ranges):
-                g = sharded.CppGroup(D, ckw, NW, device_index=local_rank, ranges=ranges)
+                g = sharded.CppGroup(D, ckw, len(ranges), device_index=local_rank, ranges=ranges)
                 for mm in g.maps:
                     mm.seed_uniform(we["ppv"], 0.01, 99)
                 g.create()
@@ -783,7 +783,7 @@ def main():
                 run(fre[3:])
                 g.sync()
                 tab, nf = g.phase_ms()
-                sel = any(mm.L.dspmap_mgpu_message_records(mm.h) < 0 for mm in g.maps) or tab[NW][3] > 0
+                sel = tab[len(ranges)][3] > 0
                 cnts = [mm.counters() for mm in g.maps]
                 g.close()
                 return tab, sel, cnts
@@ -799,6 +799,23 @@ def main():
             tab_b, sel_b, cnt_b = (tab_eq, sel_eq, cnt_eq) if bal == eq else group_run(bal)
             crit_b, per_b = critical_path(tab_b, NW, sel_b)
             ranges, tab, crit, per, selr, cnts = (bal, tab_b, crit_b, per_b, sel_b, cnt_b) if crit_b < crit_eq else (eq, tab_eq, crit_eq, per_eq, sel_eq, cnt_eq)
+            # What a BLOCK-CYCLIC assignment would do to the critical path: 16 blocks of nz / 16 layers, rank r owning blocks r and r + 8 (a
+            # lower and an upper one -- the field of view looks at the lower half, so every rank gets a share of the in-view work).  Not
+            # built as a driver (a rank would hold two slabs and exchange with both neighbours for each); the 16 blocks run through the
+            # group driver and a rank is charged the SUM of its two blocks in every segment.
+            cyc = None
+            try:
+                if we["nz"] % 16 == 0:
+                    r16 = sharded.slab_ranges(we["nz"], 16)
+                    tab16, sel16, _ = group_run(r16)
+                    per_rank = [[tab16[r][ph] + tab16[r + 8][ph] for ph in range(len(tab16[0]))] for r in range(8)] + [tab16[16]]
+                    crit16, per16 = critical_path(per_rank, 8, sel16)
+                    cyc = {"critical_path_ms": round(crit16, 4), "slowest_rank_per_segment_ms": [round(x, 4) for x in per16],
+                           "mean_rank_ms": round(sum(sum(r) for r in per_rank[:8]) / 8, 4),
+                           "what": "16 blocks of %d layers through the group driver, rank r = blocks r and r + 8, a rank's segment = the sum of its two "
+                                   "blocks' (an emulation: no such driver exists)" % (we["nz"] // 16)}
+            except Exception as e:
+                cyc = {"error": repr(e)}
             # what the RCCL calls themselves cost a rank (launch + protocol, no wire): the C++ driver with a world-1 communicator against the
             # same driver inside a one-slab group (device copies / reduction kernels), on one rank's share of the map
             w8 = WORKLOADS["E8_sat"]
@@ -852,7 +869,8 @@ def main():
                 "projected_ms": round(proj, 4), "projected_frames_per_s": round(1e3 / proj, 1),
                 "one_gpu_ms": one, "projected_speedup": round(one / proj, 2) if one else None,
                 "projected_efficiency_8": round(one / proj / NW, 3) if one else None,
-                "in_view_particles_per_slab": [int(c["n_fov"]) for c in cnts]}
+                "in_view_particles_per_slab": [int(c["n_fov"]) for c in cnts],
+                "block_cyclic_emulation": cyc}
             del fre, fr8
         except Exception as e:
             result["projected_8gpu_264x264x80"] = {"error": repr(e)}
