@@ -315,6 +315,19 @@ int dspmap_ensure_point_cap(dspmap* m, int n) {
     return DSPMAP_OK;
 }
 
+// the scratch of DSPMAP_P_EARLY_REGISTER (two ints per particle slot + the lists' weight / turned-away arrays): only for handles that ask for it
+static int ensure_early_buffers(dspmap* m) {
+    KernelScratch& k = m->k;
+    if (k.in_ref) return DSPMAP_OK;
+    const MapDims& d = m->d;
+    const size_t cells = (size_t)k.ntiles * 64 * d.slots;
+    HIPCHK(m, dalloc(&k.in_ref, cells));
+    HIPCHK(m, dalloc(&k.in_slot, cells));
+    HIPCHK(m, dalloc(&k.fov_w_s, (size_t)d.np * d.capp));
+    HIPCHK(m, dalloc(&k.ta_list, (size_t)d.np * (d.capa - d.capp)));
+    return DSPMAP_OK;
+}
+
 extern "C" int dspmap_init_device(dspmap_t* m) {
     if (!m) return DSPMAP_E_ARG;
     if (m->device_ready) return DSPMAP_OK;
@@ -412,12 +425,7 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&s.fut_dirty, (size_t)k.ntiles));
     HIPCHK(m, hipMemset(s.fut_dirty, 0, sizeof(int) * (size_t)k.ntiles));   // (the accumulators start zeroed)
     HIPCHK(m, dalloc(&k.view_list, (size_t)k.ntiles));
-    {   // early registration (dense large maps; small ones only when a test forces it)
-        HIPCHK(m, dalloc(&k.in_ref, ntiles * 64 * d.slots));
-        HIPCHK(m, dalloc(&k.in_slot, ntiles * 64 * d.slots));
-        HIPCHK(m, dalloc(&k.fov_w_s, (size_t)d.np * d.capp));
-        HIPCHK(m, dalloc(&k.ta_list, (size_t)d.np * (d.capa - d.capp)));
-    }
+    if (m->early_reg == 1) { const int rce = ensure_early_buffers(m); if (rce != DSPMAP_OK) return rce; }   // (off by default: 8 bytes per slot)
     HIPCHK(m, dalloc(&k.tile_fov, (size_t)k.ntiles));
     HIPCHK(m, hipMemset(k.tile_fov, 0xff, sizeof(int) * (size_t)k.ntiles));   // no frame's tag
     HIPCHK(m, dalloc(&k.part_resample, (size_t)k.nblk_sweep * 4));
@@ -544,7 +552,10 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
             m->use_vel_est = (int)v; break;
         case DSPMAP_P_USE_GRAPH: m->use_graph = v != 0; break;
         case DSPMAP_P_HOST_CLOUD_DIRECT: m->host_direct = v != 0; break;
-        case DSPMAP_P_EARLY_REGISTER: m->early_reg = v < 0 ? -1 : (v != 0 ? 1 : 0); m->graph_epoch++; break;
+        case DSPMAP_P_EARLY_REGISTER:
+            m->early_reg = v < 0 ? -1 : (v != 0 ? 1 : 0); m->graph_epoch++;
+            if (m->early_reg == 1 && m->device_ready) { HIPCHK(m, hipStreamSynchronize(m->stream)); return ensure_early_buffers(m); }
+            break;
         case DSPMAP_P_SPARSE_SWEEP: m->sparse_force = v < 0 ? -1 : (v != 0 ? 1 : 0); break;
         case DSPMAP_P_ROLLOUT_INLINE: m->ro_force = v < 0 ? -1 : (v != 0 ? 1 : 0); break;
         case DSPMAP_P_FAST_DIVISION: if (v == 0) { m->d.div_ok = 0; m->div_forced_off = true; m->graph_epoch++; } break;
@@ -732,7 +743,7 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     // while it runs beside it; started behind the list preparation instead, the whole placement (138 us at the side stream's
     // footprint) outlasts the pair kernels it hides behind (73 - 95 us), and k_post / k_place_fix / the second weight launch add
     // ~20 us of dependent launches.  Hence OFF unless asked for (-1 = off).
-    const bool early = !fork && !m->prof && m->early_reg == 1;
+    const bool early = !fork && !m->prof && m->early_reg == 1 && m->k.in_ref != nullptr;
     (void)split0;
     const bool split = split0 && !early;
     c.place_split = split;
