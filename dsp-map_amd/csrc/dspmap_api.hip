@@ -163,6 +163,8 @@ extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
     m->vel.configure(cfg->half_fov_h, cfg->half_fov_v, cfg->angle_resolution);
     if (const char* e = getenv("DSPMAP_PLACE_SPLIT_TILES")) { const long v = atol(e); if (v > 0) m->place_split_tiles = (int)std::min(v, 2000000000l); }
     if (const char* e = getenv("DSPMAP_SWEEP_ALTERNATE")) m->sweep_alt = atoi(e) < 0 ? -1 : (atoi(e) >= 2 ? 2 : (atoi(e) != 0 ? 1 : 0));
+    if (const char* e = getenv("DSPMAP_ESTIMATOR_QUEUE")) m->est_queue = atoi(e) != 0;
+    if (const char* e = getenv("DSPMAP_XQ_TEST_DELAY_US")) m->xq_test_delay_us = std::max(0, std::min(atoi(e), 100000));
     if (const char* e = getenv("DSPMAP_EARLY_REGISTER")) m->early_reg = atoi(e) < 0 ? -1 : (atoi(e) != 0 ? 1 : 0);
     if (const char* e = getenv("DSPMAP_RESAMPLE_WG_TILES")) { const long v = atol(e); if (v >= 0) m->resample_wg_tiles = (int)std::min(v, 2000000000l); }
     return m;
@@ -191,7 +193,8 @@ static void free_dev(dspmap* m) {
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
     if (m->nbsnap_buf) chk(hipFree(m->nbsnap_buf), "hipFree");
     {
-        void* vp[] = {m->ve.ng_view, m->ve.edges, m->ve.ecnt, m->ve.w, m->ve.root, m->ve.rank, m->ve.by_rank, m->ve.dyn_list, m->ve.cl, m->ve.last, m->ve.n};
+        void* vp[] = {m->ve.ng_view, m->ve.edges, m->ve.ecnt, m->ve.w, m->ve.root, m->ve.rank, m->ve.by_rank, m->ve.dyn_list, m->ve.cl, m->ve.last, m->ve.n,
+                      m->ve.v_rot, m->ve.v_pyr, m->ve.v_fpar};
         for (void* q : vp) if (q) chk(hipFree(q), "hipFree");
     }
     if (m->pp_box) chk(hipFree(m->pp_box), "hipFree");
@@ -213,6 +216,7 @@ static void free_dev(dspmap* m) {
     if (m->ring_host) { chk(hipHostFree(m->ring_host), "hipHostFree"); m->ring_host = nullptr; }
     if (m->hint_host) { chk(hipHostFree((void*)m->hint_host), "hipHostFree"); m->hint_host = nullptr; }
     if (m->s.ring_seq) { chk(hipFree(m->s.ring_seq), "hipFree"); m->s.ring_seq = nullptr; }
+    if (m->xq_dev) { chk(hipFree(m->xq_dev), "hipFree"); m->xq_dev = nullptr; }
     for (hipEvent_t e : m->pev) if (e) chk(hipEventDestroy(e), "hipEventDestroy(prof)");
     if (m->stream2) chk(hipStreamDestroy(m->stream2), "hipStreamDestroy(2)");
     if (m->ev0) chk(hipEventDestroy(m->ev0), "hipEventDestroy");
@@ -355,6 +359,8 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     { void* dp = nullptr; HIPCHK(m, hipHostGetDevicePointer(&dp, (void*)m->hint_host, 0)); m->s.hint_out = (int*)dp; }
     HIPCHK(m, hipMalloc((void**)&m->s.ring_seq, sizeof(int)));
     HIPCHK(m, hipMemset(m->s.ring_seq, 0, sizeof(int)));
+    HIPCHK(m, hipMalloc((void**)&m->xq_dev, (XQ_LIST + DSPMAP_XQ_LIST) * sizeof(int)));
+    HIPCHK(m, hipMemset(m->xq_dev, 0, (XQ_LIST + DSPMAP_XQ_LIST) * sizeof(int)));
     m->ring_head = 0;
     { int dev = 0, cu = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) m->n_cu = cu; }
     HIPCHK(m, hipEventCreate(&m->ev0));
@@ -468,6 +474,7 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
         HIPCHK(m, dalloc(&ve.dyn_list, nc)); HIPCHK(m, dalloc(&ve.cl, nc)); HIPCHK(m, dalloc(&ve.last, nc * 5));
         HIPCHK(m, dalloc(&ve.n, (size_t)4));
         HIPCHK(m, hipMemset(ve.n, 0, sizeof(int) * 4));
+        HIPCHK(m, dalloc(&ve.v_rot, (size_t)ve.cap)); HIPCHK(m, dalloc(&ve.v_pyr, (size_t)ve.cap)); HIPCHK(m, dalloc(&ve.v_fpar, (size_t)1));
     }
     {   // may a / res be computed as reciprocal + two FMAs?  Compared with the IEEE quotient on the device (k_verify_div), once
         // per resolution and process
@@ -552,6 +559,7 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
             m->use_vel_est = (int)v; break;
         case DSPMAP_P_USE_GRAPH: m->use_graph = v != 0; break;
         case DSPMAP_P_HOST_CLOUD_DIRECT: m->host_direct = v != 0; break;
+        case DSPMAP_P_ESTIMATOR_QUEUE: m->est_queue = v != 0; break;   // (part of the captured frame's key)
         case DSPMAP_P_EARLY_REGISTER:
             m->early_reg = v < 0 ? -1 : (v != 0 ? 1 : 0); m->graph_epoch++;
             if (m->early_reg == 1 && m->device_ready) { HIPCHK(m, hipStreamSynchronize(m->stream)); return ensure_early_buffers(m); }
@@ -600,6 +608,7 @@ extern "C" double dspmap_get_param(const dspmap_t* m, int key) {
         case DSPMAP_P_ROLLOUT_INLINE: return m->ro_kernel ? 0 : 1;
         case DSPMAP_P_FAST_DIVISION: return m->d.div_ok;
         case DSPMAP_P_HOST_CLOUD_DIRECT: return m->host_direct ? 1 : 0;
+        case DSPMAP_P_ESTIMATOR_QUEUE: return m->est_queue ? 1 : 0;
         case DSPMAP_P_EARLY_REGISTER: return m->early_reg;
         case DSPMAP_P_USE_GRAPH: return m->use_graph ? 1 : 0;
         default: return 0;
@@ -725,6 +734,12 @@ int dspmap_gate_and_delta(dspmap* m, const float pos[3], double stamp, const flo
     return 1;
 }
 
+// does this frame place the arrivals of the tiles with a view first and the others beside the pair kernels / register the movers in k_predict?
+static bool frame_splits_placement(const dspmap* m, const LaunchCtx& c, bool fork) {
+    return !fork && !m->prof && (!c.sparse || m->place_split_tiles <= 1) && c.k.ntiles >= m->place_split_tiles;   // (1 = always, as documented)
+}
+static bool frame_registers_early(const dspmap* m, bool fork) { return !fork && !m->prof && m->early_reg == 1 && m->k.in_ref != nullptr; }
+
 // enqueue one whole device-resident frame (setup .. resample); every per-frame value is read from s.fpar.
 // When `fork` is set (graph capture) the observation binning runs on a second stream concurrently with
 // prediction + re-binning: the two only share the rotated planes written by k_reset and meet again at
@@ -733,7 +748,7 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     // (per-stage timing keeps the frame on one stream; so does a sparse map -- most tiles empty: two passes over all the tiles cost
     // more than the overlap gives: 264x264x80 filled by the depth stream 0.445 -> 0.434 ms, 132x132x60 0.232 -> 0.228; saturated
     // maps keep the split: 0.659 against 0.667 ms and 4.61 against 4.80 ms, interleaved runs on one box)
-    const bool split0 = !fork && !m->prof && (!c.sparse || m->place_split_tiles <= 1) && c.k.ntiles >= m->place_split_tiles;   // (1 = always, as documented)
+    const bool split0 = frame_splits_placement(m, c, fork);
     // EARLY REGISTRATION (round 5; DSPMAP_P_EARLY_REGISTER): k_predict registers the voxel-changing particles in their pyramids itself, the
     // WHOLE placement runs on the side stream beside list preparation, Ck pass and weight update (which leaves its results with the
     // list entries), and k_post / k_place_fix tie the two together behind the join.  Replaces the split placement where that applied.
@@ -743,7 +758,7 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     // while it runs beside it; started behind the list preparation instead, the whole placement (138 us at the side stream's
     // footprint) outlasts the pair kernels it hides behind (73 - 95 us), and k_post / k_place_fix / the second weight launch add
     // ~20 us of dependent launches.  Hence OFF unless asked for (-1 = off).
-    const bool early = !fork && !m->prof && m->early_reg == 1 && m->k.in_ref != nullptr;
+    const bool early = frame_registers_early(m, fork);
     (void)split0;
     const bool split = split0 && !early;
     c.place_split = split;
@@ -767,17 +782,22 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
         // k_ve_components -> k_ve_clusters (+ the birth rank) -> the newborn children, and joins before the birth stage.
         // (The main chain's next kernel is queued BEFORE the side branch's: the branch whose node comes first after the
         // fork stays on the parent's hardware queue, the other one pays the cross-queue hand-over.)
-        (void)hipEventRecord(m->ev_fork, m->stream);
+        // DSPMAP_P_ESTIMATOR_QUEUE (c.s.xq set; never with a split placement / early registration): no branch at all in this graph -- the caller
+        // has queued the estimator's kernels on the other stream itself, k_predict and the split kernel below meet them through DevState::xq
+        const bool xq = c.s.xq != nullptr;
+        if (!xq) (void)hipEventRecord(m->ev_fork, m->stream);
         launch_predict_only(c, true, false);
-        (void)hipStreamWaitEvent(m->stream2, m->ev_fork, 0);
         LaunchCtx c2 = c;
         c2.stream = m->stream2;
-        launch_velocity_estimator(c2, true);
-        // the children (the rank ran inside k_ve_clusters): on the side branch when it goes on with the placement of the tiles without
-        // a view (large maps); otherwise the branch -- the longer one at the metric's size -- ends here and the waves of the split
-        // generate them (launch_birth_late)
-        if (split || early) launch_birth_early(c2, birth_grid, false);
-        (void)hipEventRecord(m->ev_join, m->stream2);
+        if (!xq) {
+            (void)hipStreamWaitEvent(m->stream2, m->ev_fork, 0);
+            launch_velocity_estimator(c2, true);
+            // the children (the rank ran inside k_ve_clusters): on the side branch when it goes on with the placement of the tiles without
+            // a view (large maps); otherwise the branch -- the longer one at the metric's size -- ends here and the waves of the split
+            // generate them (launch_birth_late)
+            if (split || early) launch_birth_early(c2, birth_grid, false);
+            (void)hipEventRecord(m->ev_join, m->stream2);
+        }
         dspmap_prof_mark(m, 2);
         if (early) {
             (void)hipEventRecord(m->ev_fork2, m->stream);                 // the prediction has ended: lists and inboxes are complete
@@ -808,7 +828,7 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
         dspmap_prof_mark(m, 4);
         launch_weight_update(c);
         dspmap_prof_mark(m, 5);
-        (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
+        if (!xq) (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
         dspmap_prof_mark(m, 6);
         launch_birth_late(c, birth_grid, false, !split);
         dspmap_prof_mark(m, 7);
@@ -1016,11 +1036,13 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
         if (rc != DSPMAP_OK) return rc;
         return frame_with_host_stages(m, n_points, points_dev, q, dp, dt, m->ev_fork);
     }
-    if (est_dev) { rc = ve_state_to_device(m); if (rc != DSPMAP_OK) return rc; m->ve_last_at = 2; }
+    if (est_dev) { if (m->ve_last_at != 2) m->xq_break = true; rc = ve_state_to_device(m); if (rc != DSPMAP_OK) return rc; m->ve_last_at = 2; }
     m->frame_parity ^= 1u;
     LaunchCtx c = dspmap_ctx_of(m);
     const bool has_vz = m->vz_frames > 0;
     if (!has_vz) c.s.vz0 = nullptr;
+    if (m->hint_host && m->hint_host[3] != 0)
+        return dspmap_fail(m, DSPMAP_E_DEVICE, "estimator queue: a cross-queue wait gave up at ring position %d (DSPMAP_P_ESTIMATOR_QUEUE)", m->hint_host[3] - 1);
     // birth cloud: the caller's (0), synthesised from the view (1: every point in view a static source), or the device
     // velocity estimator's (2)
     const int mode = birth_dev ? 0 : (est_dev ? 2 : 1);
@@ -1034,6 +1056,10 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
     // no copy node between two graph launches.  Slot k of the ring is reused DSPMAP_RING frames later; an event per
     // quarter of the ring makes sure the frames that read it have ended (the host never runs that far ahead in practice).
     m->frame_ring = m->use_graph && !m->prof && m->ring_host != nullptr;
+    // the estimator on a queue of its own (DSPMAP_P_ESTIMATOR_QUEUE): replayed frames with the device estimator whose graph would otherwise fork
+    // for it alone -- a split placement / early registration keeps its side branch, and the estimator on it
+    const bool xq = m->est_queue && m->xq_dev && mode == 2 && m->frame_ring && (m->birth_cap + 15) / 16 + 1 <= DSPMAP_XQ_LIST && !frame_splits_placement(m, c, false) && !frame_registers_early(m, false);
+    if (xq) c.s.xq = m->xq_dev;
     if (m->frame_ring) {
         const unsigned q = (m->ring_head / (DSPMAP_RING / 4)) % 4;
         if (m->ring_head % (DSPMAP_RING / 4) == 0 && m->ring_ev_set[q]) HIPCHK(m, hipEventSynchronize(m->ring_ev[q]));
@@ -1053,7 +1079,7 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
                 m->cring_dev = (const float*)dp2;
             }
             if (m->ring_head >= DSPMAP_CLOUD_RING) {   // the frame that read this slot last must be past its first kernel
-                const unsigned need = m->ring_head - DSPMAP_CLOUD_RING + 1u;
+                const unsigned need = m->ring_head - DSPMAP_CLOUD_RING + 2u;   // (+ 1: the estimator on its own queue reads the slot as well, and is only known to be done with it when the FOLLOWING frame's prediction starts)
                 const volatile int* seen = m->hint_host + 2;
                 for (long spin = 0; (int)((unsigned)*seen - need) < 0; ++spin) {
                     if (spin > 2000) { HIPCHK(m, hipStreamSynchronize(m->stream)); break; }   // (a queue more than 64 frames deep: wait for it)
@@ -1082,7 +1108,7 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
     if (timed) HIPCHK(m, hipEventRecord(m->ev0, m->stream));
     if (m->use_graph && !m->prof) {
         // the kernel arguments of a frame are constant (per-frame values live in s.fpar): capture once, replay
-        const unsigned long long key = ((unsigned long long)m->graph_epoch << 8) | (has_vz ? 1u : 0u) | ((unsigned)mode << 1) | (c.sparse ? 8u : 0u) | (c.ro_inline ? 16u : 0u);
+        const unsigned long long key = ((unsigned long long)m->graph_epoch << 8) | (has_vz ? 1u : 0u) | ((unsigned)mode << 1) | (c.sparse ? 8u : 0u) | (c.ro_inline ? 16u : 0u) | (xq ? 32u : 0u);
         const int gi = c.sweep_rev ? 1 : 0;   // (one executable graph per sweep direction: the direction is a kernel argument)
         if (!m->graph_exec[gi] || m->graph_key[gi] != key) {
             if (m->graph_exec[gi]) {   // (replays of the old executable graph may still be queued: let them finish before it goes)
@@ -1100,6 +1126,30 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
             m->graph_key[gi] = key;
         }
         m->last_resample_variant = resample_variant(c);   // (baked into the graph: c.ro_inline is part of its key)
+        if (xq) {
+            // this frame's estimator on its own queue, queued BEFORE the frame itself.  It waits for nothing of THIS frame (k_ve_view makes its
+            // own picture of the view from the ring slot) -- only for the previous frame's birth stage, which hands over the rand() cursor and
+            // the birth buffers: through the word that frame's resampling kernel publishes when that frame was the handle's previous call
+            // (nothing else can have touched the estimator's state in between), through an event on the handle's stream otherwise (after
+            // another entry point -- a pre-processed cloud, an import, new cursors, a frame of another kind --, or on a stream the caller
+            // owns and may have queued the cloud's producer on).  The frame's first birth kernel waits for k_ve_clusters' word.  Every wait
+            // is for work queued EARLIER, whatever hardware queues the two streams share: nothing to deadlock on.
+            LaunchCtx c2 = c;
+            c2.stream = m->stream2;
+            if (getenv("DSPMAP_XQ_TEST_BREAK")) m->xq_break = true;
+            const bool chained = m->own_stream && !m->xq_break && m->xq_chain_api + 1 == m->api_seq;
+            m->xq_break = false;
+            if (!chained) {
+                HIPCHK(m, hipEventRecord(m->ev_fork, m->stream));
+                HIPCHK(m, hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
+            }
+            const int seq = (int)(m->hp.ring_pos + 1u);
+            if (m->xq_test_delay_us > 0 && m->xq_frames % 3 == 1) launch_spin(c2, m->xq_test_delay_us);
+            launch_velocity_estimator_xq(c2, true, m->ring_dev + (m->ring_head % DSPMAP_RING), m->xq_dev, m->s.hint_out + 3, chained ? m->xq_last_seq : 0, seq);
+            m->xq_last_seq = seq;
+            m->xq_chain_api = m->api_seq;
+            ++m->xq_frames;
+        }
         HIPCHK(m, hipGraphLaunch(m->graph_exec[gi], m->stream));
         if (m->frame_ring) {
             if (m->ring_head % (DSPMAP_RING / 4) == DSPMAP_RING / 4 - 1) {
@@ -1216,6 +1266,7 @@ extern "C" int dspmap_update(dspmap_t* m, int n, int stride, const float* pts, f
     }
     int rc = dspmap_stage_points(m, np, stride, pts);
     if (rc != DSPMAP_OK) return rc;
+    m->xq_break = true;   // (the cloud reaches pts_dev through a copy on the handle's stream)
     if (dev_frame)
         return device_frame(m, np, m->pts_dev, 0, nullptr, dp, dt, q);   // velocity estimator on the device: no host stage in the frame
     return frame_with_host_stages(m, np, m->pts_dev, q, dp, dt, nullptr);
@@ -1291,11 +1342,13 @@ extern "C" int dspmap_get_occupancy_with_future(dspmap_t* m, float thr, float* x
 extern "C" int dspmap_get_future(dspmap_t* m, float* fut) { return readout(m, 0.f, nullptr, 0, nullptr, fut, false); }
 extern "C" int dspmap_clear_future(dspmap_t* m) {
     READY(m);
+    BENIGN(m);
     m->fut_clear_pending = true;   // :431-438, carried out by the next frame's k_predict or before the next read
     return DSPMAP_OK;
 }
 extern "C" int dspmap_get_results(dspmap_t* m, float* out) {
     READY(m);
+    BENIGN(m);
     HIPCHK(m, hipMemcpyAsync(out, m->s.res4, sizeof(float4) * (size_t)m->d.v_loc, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     return DSPMAP_OK;
@@ -1646,6 +1699,17 @@ extern "C" int dspmap_debug_tile_moving(dspmap_t* m, int* out, int cap) {
     HIPCHK(m, hipStreamSynchronize(m->stream));
     HIPCHK(m, hipMemcpy(out, m->s.tile_moving, sizeof(int) * m->k.ntiles, hipMemcpyDeviceToHost));
     return m->k.ntiles;
+}
+extern "C" int dspmap_debug_estimator_queue(dspmap_t* m, long long out[6]) {
+    READY(m);
+    BENIGN(m);
+    if (!out) return DSPMAP_E_ARG;
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    HIPCHK(m, hipStreamSynchronize(m->stream2));
+    int w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (m->xq_dev) HIPCHK(m, hipMemcpy(w, m->xq_dev, sizeof(w), hipMemcpyDeviceToHost));
+    out[0] = m->xq_frames; out[1] = w[0]; out[2] = w[1]; out[3] = m->hint_host ? m->hint_host[3] : 0; out[4] = w[6]; out[5] = w[7];
+    return DSPMAP_OK;
 }
 extern "C" int dspmap_debug_rollout_paths(dspmap_t* m, long long out[3]) {
     READY(m);

@@ -79,10 +79,14 @@ __device__ __forceinline__ BirthSrc birth_at(const BirthView& v, int i) {
 }
 // is source point i a birth source, and in which voxel (:818-820, :827 / :847).  dsp_static.h:797-825 has no voxel
 // lookup for the source: a point outside the map still draws and may place children inside it (gv = 0 then: unused).
-__device__ __forceinline__ bool birth_src_voxel(const MapDims& d, const DevState& s, const BirthSrc& src, float& cx, float& cy, float& cz, int& gv) {
-    cx = src.x - s.fs->cur_pos[0];  // :818-820
-    cy = src.y - s.fs->cur_pos[1];
-    cz = src.z - s.fs->cur_pos[2];
+// cp: the frame's sensor position where FrameScalars::cur_pos may still be the previous frame's (the estimator on a queue of its own runs its
+// rank before the frame's first kernel has copied it there); nullptr = FrameScalars::cur_pos
+__device__ __forceinline__ bool birth_src_voxel(const MapDims& d, const DevState& s, const BirthSrc& src, float& cx, float& cy, float& cz, int& gv,
+                                                const float* cp = nullptr) {
+    if (!cp) cp = s.fs->cur_pos;
+    cx = src.x - cp[0];  // :818-820
+    cy = src.y - cp[1];
+    cz = src.z - cp[2];
     if (!(src.intensity > -1.5f)) return false;
     if (voxel_of(d, cx, cy, cz, gv)) return true;  // :827 / :847
     gv = 0;
@@ -93,8 +97,9 @@ __device__ __forceinline__ bool birth_src_voxel(const MapDims& d, const DevState
 // ones -> first position-table cursor of the point (3 draws per child, always consumed, :871-873).  Validity comes
 // straight from the source point, so the rank needs nothing but the frame's birth cloud: in a whole frame it rides on
 // k_predict's launch.  Also clears the points' "child inside the map" words for k_birth_children.
-__device__ __forceinline__ void birth_rank_block(const MapDims& d, const DevState& s, const FilterParams& fp) {
+__device__ __forceinline__ void birth_rank_block(const MapDims& d, const DevState& s, const FilterParams& fp, bool fpar_pos = false) {
     const BirthView bv = birth_view(s);
+    const float* cp = fpar_pos ? s.fpar->cur_pos : nullptr;
     const int n_birth = bv.n;
     __shared__ int s_tmp[BK * 16 + 1];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -108,7 +113,7 @@ __device__ __forceinline__ void birth_rank_block(const MapDims& d, const DevStat
         for (int j = 0; j < BK; ++j) {   // coalesced index, all loads in flight together
             const int i = base + j * nt + tid;
             float cx, cy, cz; int gv;
-            ok[j] = i < n_birth && birth_src_voxel(d, s, birth_at(bv, i), cx, cy, cz, gv);
+            ok[j] = i < n_birth && birth_src_voxel(d, s, birth_at(bv, i), cx, cy, cz, gv, cp);
             v[j] = ok[j] ? 1 : 0;
             if (i < n_birth) s.plan_inside[i] = 0u;
         }

@@ -385,3 +385,24 @@ __device__ __forceinline__ int claim_slot(u64* mask, int lv, const MapDims& d) {
     }
     return -1;
 }
+
+// ---- cross-queue hand-over words (DevState::xq; DSPMAP_P_ESTIMATOR_QUEUE).  The estimator's kernels run on a hardware queue of their own and
+// meet the captured frame through sequence numbers in HBM: a publisher stores "ring position + 1" with an agent-scope atomic (after a
+// release fence where data it wrote inside the SAME kernel has to be visible); a waiter -- ONE lane of a workgroup, before the workgroup
+// reads anything the other queue wrote -- polls until the word has reached its frame's number.  In the usual case the word is there at
+// the first look and the kernel boundary in front of the waiter has already made the data visible; after a real wait an acquire fence
+// drops what the caches may hold.  A wait is bounded (200 ms of the 100 MHz wall clock): the pairing of the two queues is the host's job
+// and a missing partner must not hang the device -- the give-up is noted in host-mapped memory and the next call fails on it.
+__device__ __forceinline__ void xq_publish(int* word, int seq) {
+    __hip_atomic_store(word, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xq_wait(int* word, int want, int* gave_up) {
+    if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
+            if (wall_clock64() - t0 > 20000000ll) { *gave_up = want; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+}

@@ -11,6 +11,7 @@
 
 #define DSPMAP_PTS_RING 4  // pinned cloud staging buffers in rotation
 #define DSPMAP_RING 1024   // slots of the pinned frame-parameter ring (power of two)
+#define DSPMAP_XQ_LIST 65536   // workgroups of the first birth kernel the estimator queue's deferral list holds (DevState::xq; 16 birth sources each)
 #define DSPMAP_CLOUD_RING 64   // slots of the pinned, device-mapped CLOUD ring of the host-pointer update() (divides DSPMAP_RING)
 struct dspmap {
     dspmap_config cfg;
@@ -85,6 +86,17 @@ struct dspmap {
     // HIP graph of the device-resident frame (dspmap_update_device)
     bool use_graph = true;
     int early_reg = -1;              // DSPMAP_P_EARLY_REGISTER: -1 the frame decides (dense maps that would split their placement), 0 never, 1 always
+    bool est_queue = true;           // DSPMAP_P_ESTIMATOR_QUEUE: the device estimator's kernels on a queue of their own, tied to the captured frame through xq_dev
+    unsigned long long api_seq = 0;  // entry points called on this handle (READY; the harmless ones take themselves off again: BENIGN)
+    unsigned long long xq_chain_api = ~0ull;   // api_seq of the last frame whose estimator ran on its own queue: when the next such frame is the very
+                                     // next call, its estimator waits for that frame's "birth stage has ended" word (xq_last_seq) instead of an event
+    int xq_last_seq = 0;
+    bool xq_break = false;           // this call has queued work on the handle's stream that the frame's estimator depends on (a staged cloud, the
+                                     // estimator's state handed over from the host): its kernels are ordered behind the stream with an event
+    int xq_test_delay_us = 0;        // DSPMAP_XQ_TEST_DELAY_US (test hook): every third frame's estimator is held back this long, so that the
+                                     // frame's first birth kernel finds its word missing and takes the deferral path
+    long long xq_frames = 0;         // frames whose estimator ran that way (dspmap_debug_estimator_queue)
+    int* xq_dev = nullptr;           // DevState::xq of the frames that use it (m->s.xq stays null: stages and sharded frames never wait on it)
     bool host_direct = true;         // DSPMAP_P_HOST_CLOUD_DIRECT: dspmap_update feeds the captured frame through the mapped cloud ring
     bool fut_clear_pending = false;   // clearOccupancyMapPrediction is lazy: done by the next frame's k_predict, or by the next reader
     hipStream_t stream2 = nullptr;   // fork/join branch inside the captured frame
@@ -179,9 +191,11 @@ int dspmap_mgpu_ck_phase(dspmap* m);      // ... list preparation (with DevState
             return dspmap_fail((m), DSPMAP_E_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+#define BENIGN(m) (--(m)->api_seq)   /* (after READY) this entry point queues nothing that the velocity estimator's kernels read or write */
 #define READY(m)                                       \
     do {                                               \
         if (!(m)) return DSPMAP_E_ARG;                 \
+        ++(m)->api_seq;                                \
         if (!(m)->device_ready) {                      \
             int rc_ = dspmap_init_device(m);           \
             if (rc_ != DSPMAP_OK) return rc_;          \

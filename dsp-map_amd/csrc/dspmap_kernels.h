@@ -87,6 +87,10 @@ void launch_export_slab(const LaunchCtx& c, int dir, float* rec_out, int cap, in
 void launch_import_movers(const LaunchCtx& c, int n, const float* rec);  // folds the per-block partial counters into FrameScalars
 // velocityEstimationThread (:1377-1544) on the device: view -> birth cloud in DevState::birth, FrameScalars::est_n
 void launch_velocity_estimator(const LaunchCtx& c, bool with_rank);   // with_rank: + the birth stage's rank in the same workgroup
+// ... on a queue of its own (c.stream = that queue; DevState::xq): k_ve_view (waits for "the previous frame's birth stage has ended" unless want
+// == 0, then rotates and bins the view from the frame's ring slot), the two kernels on that picture, and the word the frame's first birth kernel
+// waits for (= xq_seq)
+void launch_velocity_estimator_xq(const LaunchCtx& c, bool with_rank, const FrameParams* slot, int* xq, int* gave_up, int want, int xq_seq);
 int velocity_estimator_capacity();   // points per frame the device estimator handles
 int velocity_estimator_slices();
 // mapUpdate (:704-793)

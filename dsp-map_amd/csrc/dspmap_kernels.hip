@@ -1639,18 +1639,17 @@ __global__ void __launch_bounds__(1024) k_birth_split_cksum(MapDims d, DevState 
 // CHILDREN (frame with the device estimator on a map without the split placement): the point's wave also generates its newborn
 // children first (k_birth_children's job; the "inside the map" bits are a ballot) -- the estimator's branch of the frame, the
 // longer one at the metric's size, ends with k_ve_clusters instead of a third kernel
+// one workgroup's share (16 source points, or -- the last workgroup -- the 1/Ck reduction and the cursor copies); bx = the workgroup's index
 template <bool CHILDREN>
-__global__ void __launch_bounds__(1024) k_birth_split_cksum_cvr(MapDims d, DevState s, FilterParams fp, int wg_off, float4* __restrict__ child,
-                                                                int* __restrict__ vb_cnt, int* __restrict__ vb_idx) {
-    __shared__ int2 s_c[1024 / WAVE];
-    if (blockIdx.x == gridDim.x - 1) {
-        __shared__ float s_red[512];
+__device__ __forceinline__ void birth_split_cvr_block(const MapDims& d, const DevState& s, const FilterParams& fp, int wg_off, float4* __restrict__ child,
+                                                      int* __restrict__ vb_cnt, int* __restrict__ vb_idx, int bx, int2* s_c, float* s_red) {
+    if (bx == (int)gridDim.x - 1) {
         ck_sum_block(d, s, fp, s_red);
         if (threadIdx.x == 0) { s.fs->v_cur_in = s.fs->v_cur; s.fs->r_cur_in = s.fs->r_cur; }
         return;
     }
     const int wave = (int)threadIdx.x / WAVE;
-    const int i = (int)(blockIdx.x * (1024 / WAVE)) + wave;
+    const int i = bx * (1024 / WAVE) + wave;
     int2 c;
     if (CHILDREN) birth_point_wave(d, s, fp, i, child, vb_cnt, vb_idx, &c);
     else birth_split_wave(d, s, fp, i, &c);
@@ -1659,8 +1658,74 @@ __global__ void __launch_bounds__(1024) k_birth_split_cksum_cvr(MapDims d, DevSt
     if (threadIdx.x == 0) {
         int2 t = make_int2(0, 0);
         for (int w = 0; w < 1024 / WAVE; ++w) { t.x += s_c[w].x; t.y += s_c[w].y; }
-        s.birth_cvr[wg_off + blockIdx.x] = t;
+        s.birth_cvr[wg_off + bx] = t;
     }
+}
+// DSPMAP_P_ESTIMATOR_QUEUE (s.xq set): the estimator ran on a queue of its own; its birth cloud, rank and cursors are complete once xq[1] has
+// reached this frame's number.  Normally that was tens of microseconds ago and every workgroup goes ahead at its first look.  When it is
+// NOT there yet, the machine must not fill up with waiting workgroups (the estimator's own kernels need room to be scheduled -- several
+// maps on one GPU did deadlock that way): only workgroup 0 waits; every other workgroup that finds the word missing notes its index in a
+// list and leaves, and workgroup 0 does the listed shares itself once the word has arrived and every workgroup has decided.  The shares
+// are independent of who runs them (a point's children land in per-voxel buckets that the insertion ranks), so the result is the same.
+// Control words behind the two hand-over words, zeroed by this frame's k_predict: xq[5] listed workgroups, XQ_NDEC counters of the
+// workgroups that have decided (spread over as many 256-byte blocks: 385 atomics on ONE address serialise in memory, 17 us on the
+// metric's frame), then the list.
+template <bool CHILDREN>
+__global__ void __launch_bounds__(1024) k_birth_split_cksum_cvr(MapDims d, DevState s, FilterParams fp, int wg_off, float4* __restrict__ child,
+                                                                int* __restrict__ vb_cnt, int* __restrict__ vb_idx) {
+    __shared__ int2 s_c[1024 / WAVE];
+    __shared__ float s_red[512];
+    __shared__ int s_flag;
+    if (s.xq) {
+        const int want = (int)(s.fpar->ring_pos + 1u);
+        if (threadIdx.x == 0) s_flag = __hip_atomic_load(s.xq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want >= 0 ? 1 : 0;
+        __syncthreads();
+        const bool ready = s_flag != 0;
+        if (blockIdx.x != 0) {
+            if (threadIdx.x == 0) {
+                // (relaxed atomics at agent scope are performed in memory, in this lane's program order: the list entry is there before the
+                // count says so -- a release would write the XCD's L2 back in every one of the kernel's workgroups, 25 us on the metric's frame)
+                if (!ready) {
+                    const int k = __hip_atomic_fetch_add(s.xq + 5, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(s.xq + XQ_LIST + k, (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (acknowledged by memory before the count below is sent)
+                }
+                __hip_atomic_fetch_add(s.xq + XQ_DEC + ((int)blockIdx.x & (XQ_NDEC - 1)) * 64, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (!ready) return;
+        } else {
+            // workgroup 0: waits if it has to, does its own share, and then -- ALWAYS: another workgroup may have looked before the word
+            // arrived although this one looked after -- makes sure every workgroup has decided and does the listed shares
+            __syncthreads();
+            if (threadIdx.x == 0 && !ready) xq_wait(s.xq + 1, want, s.hint_out + 3);
+            __syncthreads();
+            birth_split_cvr_block<CHILDREN>(d, s, fp, wg_off, child, vb_cnt, vb_idx, 0, s_c, s_red);
+            __syncthreads();
+            if (threadIdx.x < XQ_NDEC) {   // (one wave, the counters' loads in flight together)
+                const long long t0 = wall_clock64();
+                for (;;) {
+                    int dec = __hip_atomic_load(s.xq + XQ_DEC + (int)threadIdx.x * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int o = 32; o > 0; o >>= 1) dec += __shfl_xor(dec, o, WAVE);
+                    if (dec >= (int)gridDim.x - 1) break;
+                    if (wall_clock64() - t0 > 20000000ll) { if (threadIdx.x == 0) s.hint_out[3] = want; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                if (threadIdx.x == 0) {
+                    s_flag = __hip_atomic_load(s.xq + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!ready || s_flag) { s.xq[6] += 1; s.xq[7] += s_flag; }   // diagnostics (dspmap_debug_estimator_queue): frames in which somebody had to wait, shares done for others
+                }
+            }
+            __syncthreads();
+            const int n_listed = s_flag;
+            for (int k = 0; k < n_listed; ++k) {
+                __syncthreads();
+                const int bx = __hip_atomic_load(s.xq + XQ_LIST + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                birth_split_cvr_block<CHILDREN>(d, s, fp, wg_off, child, vb_cnt, vb_idx, bx, s_c, s_red);
+            }
+            return;
+        }
+    }
+    birth_split_cvr_block<CHILDREN>(d, s, fp, wg_off, child, vb_cnt, vb_idx, (int)blockIdx.x, s_c, s_red);
 }
 // split-phase (multi-GPU) frame: rank + children as soon as the prediction is queued (they only need the birth cloud; the
 // driver's host synchronisation for the neighbour exchange leaves the GPU idle right there), cursors + insert at the end

@@ -296,6 +296,11 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
         *s.ring_seq = (int)(s.fpar->ring_pos + 1u);   // k_obs_points is done with the ring slot ...
         s.hint_out[2] = (int)(s.fpar->ring_pos + 1u); // ... and with the cloud it read over the bus (dspmap_update refills that slot 64 frames on)
     }
+    // (DSPMAP_P_ESTIMATOR_QUEUE) the control words of this frame's first birth kernel: nobody has decided, nobody is listed
+    if (blockIdx.x == 0 && tid < XQ_NDEC && s.xq) {
+        __hip_atomic_store(s.xq + XQ_DEC + tid * 64, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(s.xq + 5, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // (extra & 4) a frame that splits its placement: further workgroups list the tiles whose box can intersect the field of view --
     // every tile of the map, 64 per wave, one atomic per wave --, so that the placement that precedes the pair kernels walks THOSE
     // (a few per cent of a large map's tiles) instead of launching a workgroup per tile that finds out it has nothing to do: on the
@@ -1031,6 +1036,9 @@ template <int MW, int RBK_>
 __global__ void __launch_bounds__(256, RBK_ >= 8 ? 3 : 5) k_resample(MapDims d, DevState s, int* __restrict__ part_live, int* __restrict__ vb_cnt,
                                                   float4* __restrict__ ro_rec, int* __restrict__ ro_cnt, int rev) {
     extern __shared__ float s_dyn[];
+    // (DSPMAP_P_ESTIMATOR_QUEUE) the frame's birth stage ended where this launch began: the next frame's estimator may have the rand() cursor
+    // and the birth buffers
+    if (blockIdx.x == 0 && threadIdx.x == 0 && s.xq && s.fpar->from_ring) xq_publish(s.xq, (int)(s.fpar->ring_pos + 1u));
     const int l = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int cpmax = d.M;   // a voxel makes at most M copies
@@ -1356,6 +1364,9 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
     __shared__ float s_wcp[64];
     __shared__ int s_nmv;
     __shared__ float s_mvw[4];   // weight of the moving old particles each wave noted
+    // (DSPMAP_P_ESTIMATOR_QUEUE) the frame's birth stage ended where this launch began: the next frame's estimator may have the rand() cursor
+    // and the birth buffers
+    if (blockIdx.x == 0 && threadIdx.x == 0 && s.xq && s.fpar->from_ring) xq_publish(s.xq, (int)(s.fpar->ring_pos + 1u));
     const int l = lane_id();
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

@@ -197,6 +197,16 @@ struct DevState {
     int* hint_out;      // host-mapped words for the caller's thread: [0] FrameScalars::live_hint (which k_predict variant to launch),
                         // [1] last frame's tiles with many moving particles (inline rollout or k_rollout)
     int* ring_seq;      // read position of the pinned parameter ring (frames replayed as a captured graph)
+#define XQ_NDEC 64       // DevState::xq: counters of the first birth kernel's workgroups that have decided, one per 256-byte block from XQ_DEC on
+#define XQ_DEC 64
+#define XQ_LIST (XQ_DEC + XQ_NDEC * 64)   // ... and the list of the workgroups that left their share to workgroup 0
+    int* xq;            // nullptr, or (DSPMAP_P_ESTIMATOR_QUEUE: the velocity estimator's kernels run on a queue of their own, tied to the
+                        // captured frame by nothing but these words in HBM, agent-scope atomics) [0] = ring position + 1 of the last frame
+                        // whose BIRTH STAGE has ended (published by the resampling kernel that follows it), polled by k_ve_view in front of
+                        // the NEXT frame's estimator kernels (the rand() cursor and the birth buffers are theirs from then on);
+                        // [1] = ring position + 1 of the last frame whose birth cloud the estimator has finished (k_ve_clusters, after a
+                        // release fence), polled by the frame's first birth kernel; hint_out[3] notes a poll that gave up.
+                        // Every wait is for work that was SUBMITTED EARLIER, so no mapping of streams to hardware queues can deadlock.
     // re-slotting after a full pyramid list has turned particles away (k_place_fix, dspmap_kernels.hip)
     u64* pmask;         // [v_loc*mw] occupancy after the prediction, before any arrival was placed (tiles with arrivals; k_place)
     u64* ta;            // [v_loc*mw] cells whose particle its pyramid's full list turned away this frame (all zero between frames)
@@ -239,6 +249,11 @@ struct VelEst {
     VeCluster* cl;    // [cap/5+8]
     float* last;      // [(cap/5+8) * 5] clusters_feature_vector_dynamic_last :1401: cx, cy, cz, point_num (int bits), intensity
     int* n;           // [4] view points, non-ground points, kept clusters of the last frame
+    // DSPMAP_P_ESTIMATOR_QUEUE: the estimator's own picture of the frame (it may run before the frame's first kernel has): the view rotated
+    // and binned by k_ve_view, and a copy of the frame's parameter block, taken from the pinned ring
+    float4* v_rot;    // [cap]
+    int* v_pyr;       // [cap]
+    FrameParams* v_fpar;
     int cap;          // view points the estimator handles (one workgroup holds them in LDS)
 };
 

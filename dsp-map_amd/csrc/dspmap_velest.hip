@@ -627,20 +627,79 @@ __device__ __forceinline__ void ve_clusters_block(const DevState& s, const VelEs
 
 // with_rank: the birth stage's rank (k_birth_rank's workgroup job: it needs nothing but the finished birth cloud) follows in
 // the same workgroup, so that the estimator's branch of the frame hands over a cloud whose table cursors are assigned
-__global__ void __launch_bounds__(VE_NT) k_ve_clusters(MapDims d, DevState s, VelEst ve, FilterParams fp, int with_rank) {
+__global__ void __launch_bounds__(VE_NT) k_ve_clusters(MapDims d, DevState s, VelEst ve, FilterParams fp, int with_rank, int* xq, int xq_seq) {
     ve_clusters_block(s, ve, fp);
     if (with_rank) {
         // (the cloud was written by THIS workgroup: its stores have to be complete, not written back across the chip --
         // an agent-scope fence flushes the XCD's L2 on this part and costs microseconds on the frame's longer branch)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __syncthreads();
-        birth_rank_block(d, s, fp);
+        birth_rank_block(d, s, fp, xq != nullptr);
+    }
+    if (xq) {
+        // a queue of its own (DSPMAP_P_ESTIMATOR_QUEUE): the frame's first birth kernel, on the other queue, waits for this word.  Everything
+        // this workgroup wrote (the birth cloud, the clusters, the table cursors) has to be in memory first: every wave waits for its own
+        // stores, the barrier collects the waves, the fence writes this XCD's L2 back -- once per frame, on the branch with the slack
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            xq_publish(xq + 1, xq_seq);
+        }
+    }
+}
+
+// k_ve_view (DSPMAP_P_ESTIMATOR_QUEUE): the estimator's kernels run on a queue of their own and may start before the frame's first kernel
+// has -- the estimator makes its own picture of the frame.  Every workgroup first waits (one lane) until the PREVIOUS frame's birth stage
+// has ended (xq[0]; `want` = 0: the host has ordered this launch behind the handle's stream with an event instead): from then on the
+// rand() cursor, the birth cloud and the rank's arrays belong to this frame's estimator.  Then the frame's parameter block is taken from
+// its slot of the pinned ring (workgroup 0 keeps a copy in HBM for the two kernels that follow: `s` of those has fpar = that copy and
+// pt_rot / pt_pyr = the arrays written here), the field of view's boundary planes are rotated (:226-232) and the points rotated and
+// binned (:244-263) exactly as k_obs_points does it -- the same device functions, the same bits.
+__global__ void __launch_bounds__(256) k_ve_view(MapDims d, DevState s, VelEst ve, const FrameParams* __restrict__ slot, int* xq, int* gave_up, int want) {
+    __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
+    __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
+    if (threadIdx.x == 0) xq_wait(xq, want, gave_up);
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(FrameParams) / 4)
+        reinterpret_cast<int*>(ve.v_fpar)[threadIdx.x] = reinterpret_cast<const int*>(slot)[threadIdx.x];
+    const int n_pts = min(slot->n_pts, VE_CAP);
+    const float* __restrict__ pts = slot->pts;
+    const float q[4] = {slot->quat[0], slot->quat[1], slot->quat[2], slot->quat[3]};
+    const int nh = d.np_h + 1, nv = d.np_v + 1;
+    for (int i = threadIdx.x; i < nh + nv; i += blockDim.x) {
+        float o[3];
+        if (i < nh) {
+            rotate_by_quat(s.planes_h0[3 * i], s.planes_h0[3 * i + 1], s.planes_h0[3 * i + 2], q, o);
+            s_ph[3 * i] = o[0]; s_ph[3 * i + 1] = o[1]; s_ph[3 * i + 2] = o[2];
+        } else {
+            const int j = i - nh;
+            rotate_by_quat(s.planes_v0[3 * j], s.planes_v0[3 * j + 1], s.planes_v0[3 * j + 2], q, o);
+            s_pv[3 * j] = o[0]; s_pv[3 * j + 1] = o[1]; s_pv[3 * j + 2] = o[2];
+        }
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pts) {
+        float r[3];
+        rotate_by_quat(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], q, r);
+        const int pyr = pyramid_of(d, s_ph, s_pv, r[0], r[1], r[2]);
+        const float len = sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        ve.v_rot[i] = make_float4(r[0], r[1], r[2], len);
+        ve.v_pyr[i] = pyr;
     }
 }
 
 void launch_velocity_estimator(const LaunchCtx& c, bool with_rank) {
     hipLaunchKernelGGL(k_ve_components, dim3(VE_NB), dim3(VE_NT), 0, c.stream, c.s, c.ve);
-    hipLaunchKernelGGL(k_ve_clusters, dim3(1), dim3(VE_NT), 0, c.stream, c.d, c.s, c.ve, c.fp, with_rank ? 1 : 0);
+    hipLaunchKernelGGL(k_ve_clusters, dim3(1), dim3(VE_NT), 0, c.stream, c.d, c.s, c.ve, c.fp, with_rank ? 1 : 0, (int*)nullptr, 0);
+}
+void launch_velocity_estimator_xq(const LaunchCtx& c, bool with_rank, const FrameParams* slot, int* xq, int* gave_up, int want, int xq_seq) {
+    hipLaunchKernelGGL(k_ve_view, dim3((VE_CAP + 255) / 256), dim3(256), 0, c.stream, c.d, c.s, c.ve, slot, xq, gave_up, want);
+    DevState s2 = c.s;   // the estimator's own picture of the frame
+    s2.fpar = c.ve.v_fpar; s2.pt_rot = c.ve.v_rot; s2.pt_pyr = c.ve.v_pyr;
+    hipLaunchKernelGGL(k_ve_components, dim3(VE_NB), dim3(VE_NT), 0, c.stream, s2, c.ve);
+    hipLaunchKernelGGL(k_ve_clusters, dim3(1), dim3(VE_NT), 0, c.stream, c.d, s2, c.ve, c.fp, with_rank ? 1 : 0, xq, xq_seq);
 }
 int velocity_estimator_capacity() { return VE_CAP; }
 int velocity_estimator_slices() { return VE_NB; }

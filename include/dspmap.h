@@ -156,6 +156,12 @@ enum dspmap_param {
                                        the cells once both have ended.  1 = on; 0 / -1 (default) = off: the same result slot for slot (tested), but measured
                                        slower on the saturated maps it was built for (the placement is bound by DRAM row activations and the list
                                        preparation stretches 10 x beside it; DESIGN.md / LOG.md round 5).  DSPMAP_EARLY_REGISTER sets new handles' default */
+    DSPMAP_P_ESTIMATOR_QUEUE = 25,  /* captured frames with the device velocity estimator (DSPMAP_P_VELOCITY_ESTIMATOR = 2) on maps that do not split their
+                                       placement: 1 (default) = the estimator's kernels are launched on a hardware queue of their own and meet the
+                                       frame through two words in device memory (the prediction's first workgroup says "the binned view is complete",
+                                       the frame's first birth kernel waits for "the birth cloud is complete") -- the reference's helper thread
+                                       (:297,311) without a fork / join inside the graph, which costs ~8 us of a 147-us frame on this runtime
+                                       (tools/micro/fork_join.hip); 0 = a forked branch of the captured graph (rounds 2-5).  Same result either way */
     DSPMAP_P_PAIR_CULL_SIGMAS = 13  /* mapUpdate evaluates a (particle, observation) pair only if their ranges differ by at most this many
                                        sigma_ob (default 9: the dropped terms are < 1e-19 and zero on the fixed-point Ck grid);
                                        a huge value evaluates every pair of the neighbourhood like the reference's loops */
@@ -270,6 +276,11 @@ int dspmap_debug_tile_moving(dspmap_t* m, int* out, int cap);
  * out[0] = bit 0: four-waves-per-tile resampler; bits 1-2: rollout 0 inside the resampler, 1 k_rollout without LDS windows,
  * 2 k_rollout with LDS windows, 3 none; out[1] / out[2] = contributions k_rollout sent through its windows / as single atomics */
 int dspmap_debug_rollout_paths(dspmap_t* m, long long out[3]);
+/* diagnostics of DSPMAP_P_ESTIMATOR_QUEUE: out[0] = frames of this handle whose velocity estimator ran on a queue of its own, out[1] / out[2] = the
+ * two hand-over words (ring position + 1 of the last frame whose prediction has started / whose birth cloud the estimator has finished),
+ * out[3] = nonzero if a cross-queue wait ever gave up, out[4] = frames whose first birth kernel found the birth cloud unfinished (its workgroup 0
+ * waited, the other workgroups left their shares to it), out[5] = shares it did for them */
+int dspmap_debug_estimator_queue(dspmap_t* m, long long out[6]);
 /* test hooks of dspmap_mgpu_comm_init_from_env's rendezvous file (no device, no RCCL): what rank 0 publishes / what a rank != 0
  * waits for (this launch's nonce: DSPMAP_RDZV_NONCE or TORCHELASTIC_RUN_ID + the parent's pid).  1 = written / found, 0 = not */
 int dspmap_debug_rdzv_publish(const char* path, const char id[128]);

@@ -433,3 +433,70 @@ def test_early_registration_changes_nothing(dsp, case):
         assert maps[0].slots == 72 and tot["n_pyramid_full"] > 1000 and tot["n_reslotted"] > 0, tot
     for m in maps:
         m.close()
+
+
+@pytest.mark.parametrize("delay_us", [0, 400])
+def test_estimator_on_a_queue_of_its_own_changes_nothing(dsp, delay_us, monkeypatch):
+    """DSPMAP_P_ESTIMATOR_QUEUE (round 5): the reference forks velocityEstimationThread before the prediction and joins it before the
+    birth stage (:297,311).  As a forked branch of the captured graph that costs ~8 us of the metric's 147-us frame on this runtime
+    (tools/micro/fork_join.hip); with the switch on (the default) the estimator's kernels are launched on a stream of their own and
+    meet the frame through two words in device memory (the resampling kernel: "the birth stage has ended, the NEXT frame's estimator
+    may have the rand() cursor and the birth buffers"; the frame's first birth kernel waits for "the birth cloud is complete") -- every
+    wait is for work queued earlier, so no mapping of streams to hardware queues can deadlock (four maps = nine streams on four
+    hardware queues here).  220 frames of the depth stream on four maps -- two with the switch on, one with it off, one that flips it
+    every 40 frames (a frame of either kind behind a frame of the other) and runs every 7th frame through the host-pointer update():
+    every slot, every float, results and future status equal at 8 checkpoints; the on-queue path is verified to have run (and the
+    off map never to have used it), both hand-over words stand at the last frame's ring position + 1, no wait gave up.
+    delay_us = 400 (test hook DSPMAP_XQ_TEST_DELAY_US): every third frame's estimator is held back 0.4 ms, longer than the frame: the
+    first birth kernel finds the cloud unfinished, only its workgroup 0 waits, the others leave their shares to it (the path that
+    keeps the machine free for the estimator's own kernels) -- verified to have run, same result."""
+    if delay_us:
+        monkeypatch.setenv("DSPMAP_XQ_TEST_DELAY_US", str(delay_us))
+    scene_mod = __import__("dsp-map_amd.scene", fromlist=["CorridorScene"])
+    cfg = dict(nx=66, ny=66, nz=40, res=0.15, ppv=24)
+    sc = scene_mod.CorridorScene(66 * 0.15, 66 * 0.15, 40 * 0.15, seed=77, device="cuda")
+    frames = [sc.frame(f / 30.0) for f in range(220)]
+    torch.cuda.synchronize()
+    maps = []
+    for k in range(4):
+        m = dsp.DSPMap(dsp.make_config(seed=4321, **cfg))
+        m.L.dspmap_init_device(m.h)
+        m.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, 2)
+        maps.append(m)
+    on, off, flip, on2 = maps
+    assert on.get_param(dsp.capi.P_ESTIMATOR_QUEUE) == 1          # the default
+    off.set_param(dsp.capi.P_ESTIMATOR_QUEUE, 0)
+    import ctypes as C
+    for f, (pts, pos, quat) in enumerate(frames):
+        n = pts.shape[0]
+        if f % 40 == 0:
+            flip.set_param(dsp.capi.P_ESTIMATOR_QUEUE, (f // 40) % 2)
+        for m in (on, off, on2):
+            assert m.update_device(pts.data_ptr(), n, pos, f / 30.0, quat) == 1
+        if f % 7 == 3:
+            host = np.ascontiguousarray(pts.cpu().numpy())
+            assert flip.L.dspmap_update(flip.h, n, 3, host.ctypes.data_as(C.c_void_p), pos[0], pos[1], pos[2], f / 30.0,
+                                        quat[0], quat[1], quat[2], quat[3]) == 1
+            host[:] = -1e9
+        else:
+            assert flip.update_device(pts.data_ptr(), n, pos, f / 30.0, quat) == 1
+        if f % 31 == 30 or f == 219:
+            a, ra, fa = on.export_state(), on.results(), on.getFutureStatus()   # (the getter clears the accumulators: once per map)
+            assert len(a[0]) > 50000 and fa.max() > 0
+            for other in (off, flip, on2):
+                b = other.export_state()
+                for x, y in zip(a, b):
+                    assert np.array_equal(x, y), f
+                assert np.array_equal(ra, other.results()), f
+                assert np.array_equal(fa, other.getFutureStatus()), f
+        for m in maps:
+            m.clearOccupancyMapPrediction()
+    q_on, q_off, q_flip = on.estimator_queue(), off.estimator_queue(), flip.estimator_queue()
+    print("estimator queue diagnostics (on / off / flip):", q_on, q_off, q_flip)
+    assert q_on[0] == 220 and q_on[1] == 220 and q_on[2] == 220 and q_on[3] == 0, q_on
+    assert q_off[0] == 0 and q_off[2] == 0 and q_off[3] == 0 and q_off[4] == 0, q_off
+    assert q_flip[0] == 100 and q_flip[3] == 0, q_flip            # frames 40-79, 120-159, 200-219 ran with the switch on
+    if delay_us:
+        assert q_on[4] >= 15 and q_on[5] >= 15 * 100, q_on        # a good part of the held-back frames waited (the four maps share the GPU: some delays are absorbed)
+    for m in maps:
+        m.close()
