@@ -104,7 +104,7 @@ def kernel_alg_bytes(stage, c, V, T, mw=1):
 
 
 FRAME_KERNELS = ("k_obs_points", "k_predict", "k_place", "k_pyr_prepare", "k_ck_partial", "k_weight", "k_birth_split_cksum", "k_birth_split_cksum_cvr",
-                 "k_birth_cursors", "k_birth_insert", "k_resample", "k_resample_wg", "k_rollout", "k_ve_components", "k_ve_clusters",
+                 "k_birth_cursors", "k_birth_insert", "k_resample", "k_resample_wg", "k_rollout", "k_ve_view", "k_ve_components", "k_ve_clusters",
                  "k_birth_children")
 # the kernels behind each timed stage (the resampling stage runs the one-wave-per-tile kernel on large maps, the four-waves-per-tile
 # one on small ones, and the rollout of the moving particles behind either)
