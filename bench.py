@@ -622,6 +622,33 @@ def main():
         except Exception as e:
             result["birth_tag_variants"] = {"error": repr(e)}
 
+    # ------------------------------------------------------------------ the same frame as plain launches (DSPMAP_P_USE_GRAPH = 2)
+    if want("plain"):
+        try:
+            mp = make_map(wl)
+            if args.estimator:
+                mp.set_param(D.capi.P_VELOCITY_ESTIMATOR, args.estimator)
+            mp.set_param(D.capi.P_USE_GRAPH, 2)
+            frp = gen_frames(wl, args.prefill + 330, seed=1234)
+            run_frames(mp, frp[:args.prefill + 30])
+            mp.sync()
+            quiet_host()
+            t0 = time.perf_counter()
+            run_frames(mp, frp[args.prefill + 30:])
+            t_issue = time.perf_counter() - t0
+            mp.sync()
+            dtp = (time.perf_counter() - t0) / 300
+            gc.enable()
+            result["plain_launches_66x66x40"] = {
+                "what": "NOT the contract line's configuration: the metric's workload with the frame queued as plain launches instead of a graph "
+                        "replay (DSPMAP_P_USE_GRAPH = 2: same kernels, parameter block through the same pinned ring, estimator on its own "
+                        "stream) -- no graph boundary between two frames (8.7 us on this runtime), but twelve launches of host work per frame: "
+                        "the device goes faster, the host-pointer update() becomes host-bound, hence not the default (include/dspmap.h)",
+                "frames_per_s": round(1.0 / dtp, 1), "ms_per_frame": round(dtp * 1e3, 4), "host_enqueue_ms_per_frame": round(t_issue / 300 * 1e3, 4)}
+            mp.close()
+        except Exception as e:
+            result["plain_launches_66x66x40"] = {"error": repr(e)}
+
     # ------------------------------------------------------------------ the boundary's own call: update(float* host, ...)
     if want("host"):
         try:

@@ -163,6 +163,7 @@ extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
     m->vel.configure(cfg->half_fov_h, cfg->half_fov_v, cfg->angle_resolution);
     if (const char* e = getenv("DSPMAP_PLACE_SPLIT_TILES")) { const long v = atol(e); if (v > 0) m->place_split_tiles = (int)std::min(v, 2000000000l); }
     if (const char* e = getenv("DSPMAP_SWEEP_ALTERNATE")) m->sweep_alt = atoi(e) < 0 ? -1 : (atoi(e) >= 2 ? 2 : (atoi(e) != 0 ? 1 : 0));
+    if (const char* e = getenv("DSPMAP_USE_GRAPH")) { m->use_graph = atoi(e) == 1; m->direct_ring = atoi(e) == 2; }
     if (const char* e = getenv("DSPMAP_ESTIMATOR_QUEUE")) m->est_queue = atoi(e) != 0;
     if (const char* e = getenv("DSPMAP_XQ_TEST_DELAY_US")) m->xq_test_delay_us = std::max(0, std::min(atoi(e), 100000));
     if (const char* e = getenv("DSPMAP_EARLY_REGISTER")) m->early_reg = atoi(e) < 0 ? -1 : (atoi(e) != 0 ? 1 : 0);
@@ -557,7 +558,7 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
         case DSPMAP_P_VELOCITY_ESTIMATOR:
             if (v != 0 && v != 1 && v != 2) return dspmap_fail(m, DSPMAP_E_ARG, "velocity estimator: 0 off, 1 host stage, 2 device");
             m->use_vel_est = (int)v; break;
-        case DSPMAP_P_USE_GRAPH: m->use_graph = v != 0; break;
+        case DSPMAP_P_USE_GRAPH: m->use_graph = v == 1; m->direct_ring = v == 2; break;
         case DSPMAP_P_HOST_CLOUD_DIRECT: m->host_direct = v != 0; break;
         case DSPMAP_P_ESTIMATOR_QUEUE: m->est_queue = v != 0; break;   // (part of the captured frame's key)
         case DSPMAP_P_EARLY_REGISTER:
@@ -610,7 +611,7 @@ extern "C" double dspmap_get_param(const dspmap_t* m, int key) {
         case DSPMAP_P_HOST_CLOUD_DIRECT: return m->host_direct ? 1 : 0;
         case DSPMAP_P_ESTIMATOR_QUEUE: return m->est_queue ? 1 : 0;
         case DSPMAP_P_EARLY_REGISTER: return m->early_reg;
-        case DSPMAP_P_USE_GRAPH: return m->use_graph ? 1 : 0;
+        case DSPMAP_P_USE_GRAPH: return m->use_graph ? 1 : (m->direct_ring ? 2 : 0);
         default: return 0;
     }
 }
@@ -1055,7 +1056,7 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
     // A replayed frame reads its parameter block from a pinned ring (its first kernel fetches the slot over the bus):
     // no copy node between two graph launches.  Slot k of the ring is reused DSPMAP_RING frames later; an event per
     // quarter of the ring makes sure the frames that read it have ended (the host never runs that far ahead in practice).
-    m->frame_ring = m->use_graph && !m->prof && m->ring_host != nullptr;
+    m->frame_ring = (m->use_graph || m->direct_ring) && !m->prof && m->ring_host != nullptr;
     // the estimator on a queue of its own (DSPMAP_P_ESTIMATOR_QUEUE): replayed frames with the device estimator whose graph would otherwise fork
     // for it alone -- a split placement / early registration keeps its side branch, and the estimator on it
     const bool xq = m->est_queue && m->xq_dev && mode == 2 && m->frame_ring && (m->birth_cap + 15) / 16 + 1 <= DSPMAP_XQ_LIST && !frame_splits_placement(m, c, false) && !frame_registers_early(m, false);
@@ -1104,29 +1105,10 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
     // update_ms (dspmap_get_counters): an event record between two graph launches costs ~5 us of device time each (measured:
     // 0.162 -> 0.150 ms per frame at the metric's workload without them), so a replayed frame carries the pair only every
     // 32nd time; direct launches (profiling, DSPMAP_P_USE_GRAPH = 0) are timed every frame
-    const bool timed = !(m->use_graph && !m->prof) || (m->frame_no++ % 32u) == 0;
+    const bool timed = !((m->use_graph || m->direct_ring) && !m->prof) || (m->frame_no++ % 32u) == 0;
     if (timed) HIPCHK(m, hipEventRecord(m->ev0, m->stream));
-    if (m->use_graph && !m->prof) {
-        // the kernel arguments of a frame are constant (per-frame values live in s.fpar): capture once, replay
-        const unsigned long long key = ((unsigned long long)m->graph_epoch << 8) | (has_vz ? 1u : 0u) | ((unsigned)mode << 1) | (c.sparse ? 8u : 0u) | (c.ro_inline ? 16u : 0u) | (xq ? 32u : 0u);
-        const int gi = c.sweep_rev ? 1 : 0;   // (one executable graph per sweep direction: the direction is a kernel argument)
-        if (!m->graph_exec[gi] || m->graph_key[gi] != key) {
-            if (m->graph_exec[gi]) {   // (replays of the old executable graph may still be queued: let them finish before it goes)
-                HIPCHK(m, hipStreamSynchronize(m->stream));
-                (void)hipGraphExecDestroy(m->graph_exec[gi]); m->graph_exec[gi] = nullptr;
-            }
-            if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
-            HIPCHK(m, hipStreamBeginCapture(m->stream, hipStreamCaptureModeRelaxed));
-            enqueue_frame(m, c, m->pt_cap, m->birth_cap, false, mode == 1, mode == 2);  // (fork=true measured slower: HIP replays multi-branch graphs with a much higher launch cost) grids sized for the capacity; kernels bound-check against fpar
-            HIPCHK(m, hipStreamEndCapture(m->stream, &m->graph));
-            if (const char* dot = getenv("DSPMAP_GRAPH_DOT")) (void)hipGraphDebugDotPrint(m->graph, dot, 0);   // diagnostics: the frame's nodes and edges
-            HIPCHK(m, hipGraphInstantiate(&m->graph_exec[gi], m->graph, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(m->graph);   // the executable graph keeps its own copy of the topology
-            m->graph = nullptr;
-            m->graph_key[gi] = key;
-        }
-        m->last_resample_variant = resample_variant(c);   // (baked into the graph: c.ro_inline is part of its key)
-        if (xq) {
+    auto queue_estimator = [&]() -> int {
+        if (!xq) return DSPMAP_OK;
             // this frame's estimator on its own queue, queued BEFORE the frame itself.  It waits for nothing of THIS frame (k_ve_view makes its
             // own picture of the view from the ring slot) -- only for the previous frame's birth stage, which hands over the rand() cursor and
             // the birth buffers: through the word that frame's resampling kernel publishes when that frame was the handle's previous call
@@ -1149,7 +1131,30 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
             m->xq_last_seq = seq;
             m->xq_chain_api = m->api_seq;
             ++m->xq_frames;
+            return DSPMAP_OK;
+    };
+    if (m->use_graph && !m->prof) {
+        // the kernel arguments of a frame are constant (per-frame values live in s.fpar): capture once, replay
+        const unsigned long long key = ((unsigned long long)m->graph_epoch << 8) | (has_vz ? 1u : 0u) | ((unsigned)mode << 1) | (c.sparse ? 8u : 0u) | (c.ro_inline ? 16u : 0u) | (xq ? 32u : 0u);
+        const int gi = c.sweep_rev ? 1 : 0;   // (one executable graph per sweep direction: the direction is a kernel argument)
+        if (!m->graph_exec[gi] || m->graph_key[gi] != key) {
+            if (m->graph_exec[gi]) {   // (replays of the old executable graph may still be queued: let them finish before it goes)
+                HIPCHK(m, hipStreamSynchronize(m->stream));
+                (void)hipGraphExecDestroy(m->graph_exec[gi]); m->graph_exec[gi] = nullptr;
+            }
+            if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+            HIPCHK(m, hipStreamBeginCapture(m->stream, hipStreamCaptureModeRelaxed));
+            enqueue_frame(m, c, m->pt_cap, m->birth_cap, false, mode == 1, mode == 2);  // (fork=true measured slower: HIP replays multi-branch graphs with a much higher launch cost) grids sized for the capacity; kernels bound-check against fpar
+            HIPCHK(m, hipStreamEndCapture(m->stream, &m->graph));
+            if (const char* dot = getenv("DSPMAP_GRAPH_DOT")) (void)hipGraphDebugDotPrint(m->graph, dot, 0);   // diagnostics: the frame's nodes and edges
+            HIPCHK(m, hipGraphInstantiate(&m->graph_exec[gi], m->graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(m->graph);   // the executable graph keeps its own copy of the topology
+            m->graph = nullptr;
+            m->graph_key[gi] = key;
         }
+        m->last_resample_variant = resample_variant(c);   // (baked into the graph: c.ro_inline is part of its key)
+        rc = queue_estimator();
+        if (rc != DSPMAP_OK) return rc;
         HIPCHK(m, hipGraphLaunch(m->graph_exec[gi], m->stream));
         if (m->frame_ring) {
             if (m->ring_head % (DSPMAP_RING / 4) == DSPMAP_RING / 4 - 1) {
@@ -1160,7 +1165,16 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
             ++m->ring_head;
         }
     } else {
+        if (m->frame_ring) { rc = queue_estimator(); if (rc != DSPMAP_OK) return rc; }
         enqueue_frame(m, c, n_points, nb_grid, false, mode == 1, mode == 2);
+        if (m->frame_ring) {
+            if (m->ring_head % (DSPMAP_RING / 4) == DSPMAP_RING / 4 - 1) {
+                const unsigned q = (m->ring_head / (DSPMAP_RING / 4)) % 4;
+                HIPCHK(m, hipEventRecord(m->ring_ev[q], m->stream));
+                m->ring_ev_set[q] = true;
+            }
+            ++m->ring_head;
+        }
     }
     if (m->vz_frames > 0) --m->vz_frames;
     if (m->nb_dirty) { m->nb_dirty = false; m->graph_epoch++; }
@@ -1254,7 +1268,7 @@ extern "C" int dspmap_update(dspmap_t* m, int n, int stride, const float* pts, f
     if (!dspmap_gate_and_delta(m, pos, stamp, q, dp, &dt)) return DSPMAP_REJECTED;
     const int np = n > 0 ? n : 0;
     const bool dev_frame = m->use_vel_est == 2 && !m->cfg.static_model && !m->h_birth_valid && np <= m->ve.cap;
-    if (dev_frame && m->use_graph && !m->prof && m->ring_host && m->host_direct) {
+    if (dev_frame && (m->use_graph || m->direct_ring) && !m->prof && m->ring_host && m->host_direct) {
         // velocity estimator on the device + captured frame: the cloud rides in the pinned cloud ring (device_frame), the frame is one
         // graph launch -- no copy node, no event in front of it (round 4: 5 837 against 6 913 frames/s with the cloud resident in HBM)
         int rc0 = dspmap_ensure_point_cap(m, np);

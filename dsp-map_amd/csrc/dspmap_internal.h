@@ -85,6 +85,7 @@ struct dspmap {
     FrameParams hp = {};
     // HIP graph of the device-resident frame (dspmap_update_device)
     bool use_graph = true;
+    bool direct_ring = false;        // DSPMAP_P_USE_GRAPH = 2: plain launches, the frame's parameter block through the pinned ring like a replayed frame's
     int early_reg = -1;              // DSPMAP_P_EARLY_REGISTER: -1 the frame decides (dense maps that would split their placement), 0 never, 1 always
     bool est_queue = true;           // DSPMAP_P_ESTIMATOR_QUEUE: the device estimator's kernels on a queue of their own, tied to the captured frame through xq_dev
     unsigned long long api_seq = 0;  // entry points called on this handle (READY; the harmless ones take themselves off again: BENIGN)

@@ -112,7 +112,11 @@ enum dspmap_param {
                                        with the kernels (velocity_estimator.cpp); 0 = births use the caller's cloud, or tag every
                                        point in view as a static source */
     DSPMAP_P_REGENERATE_TABLES = 10,/* 1 = setPredictionVariance regenerates the Gaussian tables (:359) */
-    DSPMAP_P_USE_GRAPH = 11,        /* 1 (default) = dspmap_update_device replays the frame as a captured HIP graph */
+    DSPMAP_P_USE_GRAPH = 11,        /* 1 (default) = dspmap_update / dspmap_update_device replay the frame as a captured HIP graph (one launch, ~18 us of host time per
+                                       frame); 2 = the same kernels as plain launches, parameter block through the same pinned ring: no graph boundary between two
+                                       frames (it costs 8.7 us on this runtime: 66x66x40 0.151 -> 0.144 ms, -4.4 .. -5.9 % in-process; larger maps +-1 %) but ~100 us of
+                                       host time per frame for its twelve launches (the host-pointer update() becomes host-bound: 4 800 frames/s), which is why it
+                                       is not the default; 0 = plain launches with a copied parameter block (rounds 1-2; what stage profiling uses).  Same result */
     DSPMAP_P_OCCLUSION_MARGIN = 12, /* obstacle_thickness_for_occlusion :70 (0.3 m); the reference's two other headers use VOXEL_RESOLUTION */
     DSPMAP_P_UPDATE_TIME = 14,      /* read-only: update_time, the sum of the accepted frames' delt_t (:634) */
     DSPMAP_P_UPDATE_COUNTER = 15,   /* read-only: update_counter, the number of predictions run (:635) */

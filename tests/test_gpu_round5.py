@@ -443,8 +443,9 @@ def test_estimator_on_a_queue_of_its_own_changes_nothing(dsp, delay_us, monkeypa
     meet the frame through two words in device memory (the resampling kernel: "the birth stage has ended, the NEXT frame's estimator
     may have the rand() cursor and the birth buffers"; the frame's first birth kernel waits for "the birth cloud is complete") -- every
     wait is for work queued earlier, so no mapping of streams to hardware queues can deadlock (four maps = nine streams on four
-    hardware queues here).  220 frames of the depth stream on five maps -- two with the switch on, one with it off, one that flips it
+    hardware queues here).  220 frames of the depth stream on six maps -- two with the switch on, one with it off, one that flips it
     every 40 frames (a frame of either kind behind a frame of the other) and runs every 7th frame through the host-pointer update():
+    a sixth that runs the frame as plain launches instead of a graph replay (DSPMAP_P_USE_GRAPH = 2),
     and a fifth on a stream the CALLER owns, whose cloud is produced by a copy queued on that stream behind 0.1 ms of other work
     and not waited for (the estimator's stream is ordered behind the caller's with an event then):
     every slot, every float, results and future status equal at 8 checkpoints; the on-queue path is verified to have run (and the
@@ -460,12 +461,14 @@ def test_estimator_on_a_queue_of_its_own_changes_nothing(dsp, delay_us, monkeypa
     frames = [sc.frame(f / 30.0) for f in range(220)]
     torch.cuda.synchronize()
     maps = []
-    for k in range(5):
+    for k in range(6):
         m = dsp.DSPMap(dsp.make_config(seed=4321, **cfg))
         m.L.dspmap_init_device(m.h)
         m.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, 2)
         maps.append(m)
-    on, off, flip, on2, caller = maps
+    on, off, flip, on2, caller, plain = maps
+    plain.set_param(dsp.capi.P_USE_GRAPH, 2)          # the same kernels as plain launches (parameter ring, estimator on its own stream): no graph
+    assert plain.get_param(dsp.capi.P_USE_GRAPH) == 2
     st = torch.cuda.Stream()
     caller._chk(caller.L.dspmap_set_stream(caller.h, st.cuda_stream))   # a stream the caller owns: the cloud's producer is queued on it
     keep = []
@@ -476,7 +479,7 @@ def test_estimator_on_a_queue_of_its_own_changes_nothing(dsp, delay_us, monkeypa
         n = pts.shape[0]
         if f % 40 == 0:
             flip.set_param(dsp.capi.P_ESTIMATOR_QUEUE, (f // 40) % 2)
-        for m in (on, off, on2):
+        for m in (on, off, on2, plain):
             assert m.update_device(pts.data_ptr(), n, pos, f / 30.0, quat) == 1
         with torch.cuda.stream(st):
             torch.cuda._sleep(200000)                 # ~0.1 ms of the caller's own work in front of the producer ...
@@ -493,7 +496,7 @@ def test_estimator_on_a_queue_of_its_own_changes_nothing(dsp, delay_us, monkeypa
         if f % 31 == 30 or f == 219:
             a, ra, fa = on.export_state(), on.results(), on.getFutureStatus()   # (the getter clears the accumulators: once per map)
             assert len(a[0]) > 50000 and fa.max() > 0
-            for other in (off, flip, on2, caller):
+            for other in (off, flip, on2, caller, plain):
                 b = other.export_state()
                 for x, y in zip(a, b):
                     assert np.array_equal(x, y), f

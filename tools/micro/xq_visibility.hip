@@ -43,6 +43,12 @@ __global__ void k_c(const int* x, int n, int* flag, int val, int* stale, int* la
     if (bad) atomicAdd(stale, bad);
 }
 
+// Second question (same queue): kernel K1's workgroup 0 stores a word with a plain store; K2, the next kernel of the same queue, reads it with
+// plain loads from every XCD -- after K2 of the PREVIOUS round has cached the word's line in every L2.  Stale reads would mean that
+// a kernel boundary inside one queue does not invalidate the L2s.
+__global__ void k_w1(int* w, int val) { if (blockIdx.x == 0 && threadIdx.x == 0) w[3] = val; }
+__global__ void k_r2(const int* w, int val, int* stale) { if (threadIdx.x == 0 && w[3] != val) atomicAdd(stale, 1); }
+
 int main() {
     const int n = 256 * 1024;   // 1 MB
     int *x, *flag, *stale, *late, *sink;
@@ -80,6 +86,32 @@ int main() {
         printf("variant %d (%s%s%s): %d trials, stale words seen by C %d (of %lld read), workgroups of C that had to wait %d\n", variant,
                graph ? "graph {A, C}" : "plain launches", with_release ? "" : ", NO release in B", fence_always ? ", C fences always" : "", trials, hs,
                (long long)trials * n, hl);
+    }
+    {
+        int* w; CHK(hipMalloc(&w, 256)); CHK(hipMemset(w, 0, 256)); CHK(hipMemset(stale, 0, 4));
+        for (int mode = 0; mode < 2; ++mode) {   // 0 plain launches, 1 one graph {K1, K2} per round
+            CHK(hipMemset(stale, 0, 4)); CHK(hipDeviceSynchronize());
+            const int rounds = 2000;
+            for (int t = 1; t <= rounds; ++t) {
+                if (mode == 0) {
+                    hipLaunchKernelGGL(k_w1, dim3(64), dim3(64), 0, s1, w, t);
+                    hipLaunchKernelGGL(k_r2, dim3(1024), dim3(64), 0, s1, w, t, stale);
+                } else {
+                    hipGraph_t g; hipGraphExec_t ge;
+                    CHK(hipStreamBeginCapture(s1, hipStreamCaptureModeRelaxed));
+                    hipLaunchKernelGGL(k_w1, dim3(64), dim3(64), 0, s1, w, t);
+                    hipLaunchKernelGGL(k_r2, dim3(1024), dim3(64), 0, s1, w, t, stale);
+                    CHK(hipStreamEndCapture(s1, &g));
+                    CHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+                    CHK(hipGraphLaunch(ge, s1));
+                    CHK(hipStreamSynchronize(s1));
+                    hipGraphExecDestroy(ge); hipGraphDestroy(g);
+                }
+            }
+            CHK(hipStreamSynchronize(s1));
+            int hs = 0; CHK(hipMemcpy(&hs, stale, 4, hipMemcpyDeviceToHost));
+            printf("same queue, %s: %d rounds x 1024 workgroups, stale reads of the word the previous kernel stored: %d\n", mode ? "graph {K1, K2}" : "plain launches", rounds, hs);
+        }
     }
     return 0;
 }
