@@ -180,6 +180,7 @@ static void free_dev(dspmap* m) {
     if (m->device >= 0) chk(hipSetDevice(m->device), "hipSetDevice");
     if (m->stream) chk(hipStreamSynchronize(m->stream), "hipStreamSynchronize");   // nothing of this handle may be in flight
     if (m->stream2) chk(hipStreamSynchronize(m->stream2), "hipStreamSynchronize(2)");
+    if (m->stream3) chk(hipStreamSynchronize(m->stream3), "hipStreamSynchronize(3)");
     for (hipGraphExec_t& g : m->graph_exec) if (g) { chk(hipGraphExecDestroy(g), "hipGraphExecDestroy"); g = nullptr; }
     if (m->graph) chk(hipGraphDestroy(m->graph), "hipGraphDestroy");
     DevState& s = m->s;
@@ -220,6 +221,7 @@ static void free_dev(dspmap* m) {
     if (m->xq_dev) { chk(hipFree(m->xq_dev), "hipFree"); m->xq_dev = nullptr; }
     for (hipEvent_t e : m->pev) if (e) chk(hipEventDestroy(e), "hipEventDestroy(prof)");
     if (m->stream2) chk(hipStreamDestroy(m->stream2), "hipStreamDestroy(2)");
+    if (m->stream3) chk(hipStreamDestroy(m->stream3), "hipStreamDestroy(3)");
     if (m->ev0) chk(hipEventDestroy(m->ev0), "hipEventDestroy");
     if (m->ev1) chk(hipEventDestroy(m->ev1), "hipEventDestroy");
     if (m->own_stream && m->stream) chk(hipStreamDestroy(m->stream), "hipStreamDestroy");
@@ -345,6 +347,16 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     else HIPCHK(m, hipGetDevice(&m->device));
     if (!m->stream) { HIPCHK(m, hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
     HIPCHK(m, hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
+    {
+        // the estimator's own stream (DSPMAP_P_ESTIMATOR_QUEUE) gets the HIGHEST priority the device offers: the runtime keeps a pool of hardware
+        // queues per priority and maps more streams than queues onto shared ones (GPU_MAX_HW_QUEUES = 4) -- at normal priority a process that
+        // holds a few other streams could find this stream and the handle's main stream on ONE hardware queue: still correct (every cross-stream
+        // wait is for earlier work), but the estimator then runs after the frame instead of beside it (66x66x40: 0.148 -> 0.214 ms, seen in
+        // bench.py).  A stream of its own rather than stream2: that one is forked into during graph capture (mixed priorities inside a capture crashed)
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
+        HIPCHK(m, hipStreamCreateWithPriority(&m->stream3, hipStreamNonBlocking, greatest));
+    }
     HIPCHK(m, hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     HIPCHK(m, hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     HIPCHK(m, hipEventCreateWithFlags(&m->ev_fork2, hipEventDisableTiming));
@@ -1117,13 +1129,13 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
             // owns and may have queued the cloud's producer on).  The frame's first birth kernel waits for k_ve_clusters' word.  Every wait
             // is for work queued EARLIER, whatever hardware queues the two streams share: nothing to deadlock on.
             LaunchCtx c2 = c;
-            c2.stream = m->stream2;
+            c2.stream = m->stream3;
             if (getenv("DSPMAP_XQ_TEST_BREAK")) m->xq_break = true;
             const bool chained = m->own_stream && !m->xq_break && m->xq_chain_api + 1 == m->api_seq;
             m->xq_break = false;
             if (!chained) {
                 HIPCHK(m, hipEventRecord(m->ev_fork, m->stream));
-                HIPCHK(m, hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
+                HIPCHK(m, hipStreamWaitEvent(m->stream3, m->ev_fork, 0));
             }
             const int seq = (int)(m->hp.ring_pos + 1u);
             if (m->xq_test_delay_us > 0 && m->xq_frames % 3 == 1) launch_spin(c2, m->xq_test_delay_us);
@@ -1719,7 +1731,7 @@ extern "C" int dspmap_debug_estimator_queue(dspmap_t* m, long long out[6]) {
     BENIGN(m);
     if (!out) return DSPMAP_E_ARG;
     HIPCHK(m, hipStreamSynchronize(m->stream));
-    HIPCHK(m, hipStreamSynchronize(m->stream2));
+    HIPCHK(m, hipStreamSynchronize(m->stream3));
     int w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (m->xq_dev) HIPCHK(m, hipMemcpy(w, m->xq_dev, sizeof(w), hipMemcpyDeviceToHost));
     out[0] = m->xq_frames; out[1] = w[0]; out[2] = w[1]; out[3] = m->hint_host ? m->hint_host[3] : 0; out[4] = w[6]; out[5] = w[7];
