@@ -347,16 +347,6 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     else HIPCHK(m, hipGetDevice(&m->device));
     if (!m->stream) { HIPCHK(m, hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
     HIPCHK(m, hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
-    {
-        // the estimator's own stream (DSPMAP_P_ESTIMATOR_QUEUE) gets the HIGHEST priority the device offers: the runtime keeps a pool of hardware
-        // queues per priority and maps more streams than queues onto shared ones (GPU_MAX_HW_QUEUES = 4) -- at normal priority a process that
-        // holds a few other streams could find this stream and the handle's main stream on ONE hardware queue: still correct (every cross-stream
-        // wait is for earlier work), but the estimator then runs after the frame instead of beside it (66x66x40: 0.148 -> 0.214 ms, seen in
-        // bench.py).  A stream of its own rather than stream2: that one is forked into during graph capture (mixed priorities inside a capture crashed)
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
-        HIPCHK(m, hipStreamCreateWithPriority(&m->stream3, hipStreamNonBlocking, greatest));
-    }
     HIPCHK(m, hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     HIPCHK(m, hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     HIPCHK(m, hipEventCreateWithFlags(&m->ev_fork2, hipEventDisableTiming));
@@ -1025,6 +1015,39 @@ void dspmap_ring_pushed(dspmap* m) {
     ++m->ring_head;
 }
 
+// The estimator's own stream (DSPMAP_P_ESTIMATOR_QUEUE), created at the first frame that uses it.  The runtime maps more streams than it has
+// hardware queues (GPU_MAX_HW_QUEUES = 4) onto shared ones; if this stream and the handle's main stream land on ONE hardware queue everything
+// stays correct (every cross-stream wait is for earlier work) but the estimator runs after the frame instead of beside it (66x66x40: 0.148 ->
+// 0.214 ms, seen in bench.py with five streams alive).  So the pairing is TESTED: the main stream is kept busy for 2 ms, a one-microsecond kernel
+// goes to the candidate -- if it ends while the main stream is still busy the two do not share a queue; otherwise the candidate is kept aside
+// (so that the next one lands elsewhere) and another is tried.  (A high stream priority -- its own pool of hardware queues -- was the first fix:
+// with such a stream alive, graph replays WITH a forked branch ran 0.15 ms longer, 132x132x60 saturated + device estimator 0.58 -> 0.73 ms, and
+// forking into a prioritised stream during capture crashed the runtime.)
+static int ensure_estimator_stream(dspmap* m, const LaunchCtx& c) {
+    if (m->stream3 && m->stream3_for == m->stream) return DSPMAP_OK;
+    if (m->stream3) { HIPCHK(m, hipStreamSynchronize(m->stream3)); (void)hipStreamDestroy(m->stream3); m->stream3 = nullptr; }
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    hipStream_t aside[6]; int n_aside = 0;
+    hipStream_t good = nullptr;
+    for (int attempt = 0; attempt < 6 && !good; ++attempt) {
+        hipStream_t cand = nullptr;
+        HIPCHK(m, hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+        LaunchCtx cm = c; cm.stream = m->stream;
+        LaunchCtx cs = c; cs.stream = cand;
+        launch_spin(cm, 2000);
+        launch_spin(cs, 1);
+        HIPCHK(m, hipStreamSynchronize(cand));
+        const bool apart = hipStreamQuery(m->stream) == hipErrorNotReady;
+        (void)hipGetLastError();
+        HIPCHK(m, hipStreamSynchronize(m->stream));
+        if (apart) good = cand; else aside[n_aside++] = cand;
+    }
+    if (!good) good = aside[--n_aside];   // (every candidate shared the main stream's queue: slower, still correct)
+    for (int i = 0; i < n_aside; ++i) (void)hipStreamDestroy(aside[i]);
+    m->stream3 = good; m->stream3_for = m->stream;
+    return DSPMAP_OK;
+}
+
 // One device-resident frame after the gate (dspmap_update_device; dspmap_update with the device estimator).
 static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_birth, const dspmap_vpoint* birth_dev,
                         const float dp[3], float dt, const float q[4]) {
@@ -1128,6 +1151,7 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
             // another entry point -- a pre-processed cloud, an import, new cursors, a frame of another kind --, or on a stream the caller
             // owns and may have queued the cloud's producer on).  The frame's first birth kernel waits for k_ve_clusters' word.  Every wait
             // is for work queued EARLIER, whatever hardware queues the two streams share: nothing to deadlock on.
+            { const int rs = ensure_estimator_stream(m, c); if (rs != DSPMAP_OK) return rs; }
             LaunchCtx c2 = c;
             c2.stream = m->stream3;
             if (getenv("DSPMAP_XQ_TEST_BREAK")) m->xq_break = true;
@@ -1731,7 +1755,7 @@ extern "C" int dspmap_debug_estimator_queue(dspmap_t* m, long long out[6]) {
     BENIGN(m);
     if (!out) return DSPMAP_E_ARG;
     HIPCHK(m, hipStreamSynchronize(m->stream));
-    HIPCHK(m, hipStreamSynchronize(m->stream3));
+    if (m->stream3) HIPCHK(m, hipStreamSynchronize(m->stream3));
     int w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (m->xq_dev) HIPCHK(m, hipMemcpy(w, m->xq_dev, sizeof(w), hipMemcpyDeviceToHost));
     out[0] = m->xq_frames; out[1] = w[0]; out[2] = w[1]; out[3] = m->hint_host ? m->hint_host[3] : 0; out[4] = w[6]; out[5] = w[7];

@@ -101,7 +101,9 @@ struct dspmap {
     bool host_direct = true;         // DSPMAP_P_HOST_CLOUD_DIRECT: dspmap_update feeds the captured frame through the mapped cloud ring
     bool fut_clear_pending = false;   // clearOccupancyMapPrediction is lazy: done by the next frame's k_predict, or by the next reader
     hipStream_t stream2 = nullptr;   // fork/join branch inside the captured frame
-    hipStream_t stream3 = nullptr;   // the estimator's own stream (DSPMAP_P_ESTIMATOR_QUEUE), highest priority: plain launches only, never captured
+    hipStream_t stream3 = nullptr;   // the estimator's own stream (DSPMAP_P_ESTIMATOR_QUEUE): created at first use, tested not to share the main stream's
+                                     // hardware queue (ensure_estimator_stream); plain launches only, never captured
+    hipStream_t stream3_for = nullptr;   // the main stream it was paired with (dspmap_set_stream may change that one)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr;
     int n_cu = 256;
     // pinned parameter ring of the captured frames: slot (ring_head % DSPMAP_RING) is written by the host, read by the

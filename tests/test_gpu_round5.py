@@ -435,7 +435,7 @@ def test_early_registration_changes_nothing(dsp, case):
         m.close()
 
 
-@pytest.mark.parametrize("delay_us", [0, 400])
+@pytest.mark.parametrize("delay_us", [0, 2000])
 def test_estimator_on_a_queue_of_its_own_changes_nothing(dsp, delay_us, monkeypatch):
     """DSPMAP_P_ESTIMATOR_QUEUE (round 5): the reference forks velocityEstimationThread before the prediction and joins it before the
     birth stage (:297,311).  As a forked branch of the captured graph that costs ~8 us of the metric's 147-us frame on this runtime
@@ -450,7 +450,7 @@ def test_estimator_on_a_queue_of_its_own_changes_nothing(dsp, delay_us, monkeypa
     and not waited for (the estimator's stream is ordered behind the caller's with an event then):
     every slot, every float, results and future status equal at 8 checkpoints; the on-queue path is verified to have run (and the
     off map never to have used it), both hand-over words stand at the last frame's ring position + 1, no wait gave up.
-    delay_us = 400 (test hook DSPMAP_XQ_TEST_DELAY_US): every third frame's estimator is held back 0.4 ms, longer than the frame: the
+    delay_us = 2000 (test hook DSPMAP_XQ_TEST_DELAY_US): every third frame's estimator is held back 2 ms, longer than a round of the six maps' frames: the
     first birth kernel finds the cloud unfinished, only its workgroup 0 waits, the others leave their shares to it (the path that
     keeps the machine free for the estimator's own kernels) -- verified to have run, same result."""
     if delay_us:
@@ -510,6 +510,6 @@ def test_estimator_on_a_queue_of_its_own_changes_nothing(dsp, delay_us, monkeypa
     assert q_off[0] == 0 and q_off[2] == 0 and q_off[3] == 0 and q_off[4] == 0, q_off
     assert q_flip[0] == 100 and q_flip[3] == 0, q_flip            # frames 40-79, 120-159, 200-219 ran with the switch on
     if delay_us:
-        assert q_on[4] >= 15 and q_on[5] >= 15 * 100, q_on        # a good part of the held-back frames waited (the four maps share the GPU: some delays are absorbed)
+        assert q_on[4] >= 20 and q_on[5] >= 20 * 100, q_on        # the held-back frames (73 of 220) waited, unless a neighbour's frames absorbed the delay
     for m in maps:
         m.close()
