@@ -1,6 +1,9 @@
 """GPU parity tests added in round 5 (run with `-m gpu`): unpredicted (flag 15) particles with a velocity inside tiles of static
 particles keep it (k_predict's static-tile shortcut); the host-pointer update() that reads the caller's cloud from
-the pinned ring is the device-resident update(); checkpoint format 1 is still read."""
+the pinned ring is the device-resident update(); checkpoint format 1 is still read; the trajectory envelope of the two oracle
+builds; sharded maps resting / stepping vertically with unequal slabs; identical maps keep identical future status; early
+registration changes nothing; the velocity estimator on a stream of its own (DSPMAP_P_ESTIMATOR_QUEUE: six maps -- switch on / off /
+flipping, a caller-owned stream, plain launches instead of a graph replay, the estimator held back) changes nothing."""
 import numpy as np
 import pytest
 import torch
