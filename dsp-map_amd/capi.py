@@ -20,7 +20,7 @@ OK, REJECTED = 1, 0
 P_POSITION_STDDEV, P_VELOCITY_STDDEV, P_OBSERVATION_STDDEV, P_NEWBORN_WEIGHT, P_NEWBORN_NUMBER, \
     P_VOXEL_FILTER_RES, P_KAPPA, P_DETECTION, P_VELOCITY_ESTIMATOR, P_REGENERATE_TABLES, P_USE_GRAPH, P_OCCLUSION_MARGIN, \
     P_PAIR_CULL_SIGMAS, P_UPDATE_TIME, P_UPDATE_COUNTER, P_PLACE_SPLIT_TILES, P_FAST_DIVISION, P_SPARSE_SWEEP, P_ROLLOUT_INLINE, \
-    P_RESAMPLE_WG_TILES, P_SWEEP_ALTERNATE, P_STATIC_TILE_SKIP, P_HOST_CLOUD_DIRECT, P_EARLY_REGISTER, P_ESTIMATOR_QUEUE = range(1, 26)
+    P_RESAMPLE_WG_TILES, P_SWEEP_ALTERNATE, P_STATIC_TILE_SKIP, P_HOST_CLOUD_DIRECT, _P_REMOVED_24, P_ESTIMATOR_QUEUE, P_FRAME_BRANCHES = range(1, 27)
 
 
 class Config(C.Structure):
@@ -99,6 +99,7 @@ SIGNATURES = {
     "dspmap_debug_tile_view": (_i, [_P, C.POINTER(C.c_int), _i]),
     "dspmap_debug_rollout_paths": (_i, [_P, C.POINTER(C.c_longlong)]),
     "dspmap_debug_estimator_queue": (_i, [_P, C.POINTER(C.c_longlong)]),
+    "dspmap_debug_frame_branches": (_i, [_P, C.POINTER(C.c_longlong)]),
     "dspmap_debug_tile_moving": (_i, [_P, C.POINTER(C.c_int), _i]),
     "dspmap_debug_rdzv_publish": (_i, [C.c_char_p, C.c_char_p]),
     "dspmap_debug_rdzv_wait": (_i, [C.c_char_p, _i, C.c_char_p]),
@@ -264,6 +265,12 @@ class DSPMap:
         had to wait for the birth cloud, shares its workgroup 0 did for the others) -- DSPMAP_P_ESTIMATOR_QUEUE"""
         out = (C.c_longlong * 6)()
         self._chk(self.L.dspmap_debug_estimator_queue(self.h, out))
+        return tuple(int(v) for v in out)
+
+    def frame_branches(self):
+        """(frames run as two branches, tiles of class Q, tiles of class P, tiles of the map, largest speed ever given in mm/s) -- DSPMAP_P_FRAME_BRANCHES"""
+        out = (C.c_longlong * 5)()
+        self._chk(self.L.dspmap_debug_frame_branches(self.h, out))
         return tuple(int(v) for v in out)
 
     def tile_moving(self):

@@ -166,7 +166,7 @@ extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
     if (const char* e = getenv("DSPMAP_USE_GRAPH")) { m->use_graph = atoi(e) == 1; m->direct_ring = atoi(e) == 2; }
     if (const char* e = getenv("DSPMAP_ESTIMATOR_QUEUE")) m->est_queue = atoi(e) != 0;
     if (const char* e = getenv("DSPMAP_XQ_TEST_DELAY_US")) m->xq_test_delay_us = std::max(0, std::min(atoi(e), 100000));
-    if (const char* e = getenv("DSPMAP_EARLY_REGISTER")) m->early_reg = atoi(e) < 0 ? -1 : (atoi(e) != 0 ? 1 : 0);
+    if (const char* e = getenv("DSPMAP_FRAME_BRANCHES")) m->frame_branches = atoi(e) < 0 ? -1 : (atoi(e) != 0 ? 1 : 0);
     if (const char* e = getenv("DSPMAP_RESAMPLE_WG_TILES")) { const long v = atol(e); if (v >= 0) m->resample_wg_tiles = (int)std::min(v, 2000000000l); }
     return m;
 }
@@ -180,6 +180,7 @@ static void free_dev(dspmap* m) {
     if (m->device >= 0) chk(hipSetDevice(m->device), "hipSetDevice");
     if (m->stream) chk(hipStreamSynchronize(m->stream), "hipStreamSynchronize");   // nothing of this handle may be in flight
     if (m->stream2) chk(hipStreamSynchronize(m->stream2), "hipStreamSynchronize(2)");
+    if (m->stream4) chk(hipStreamSynchronize(m->stream4), "hipStreamSynchronize(4)");
     if (m->stream3) chk(hipStreamSynchronize(m->stream3), "hipStreamSynchronize(3)");
     for (hipGraphExec_t& g : m->graph_exec) if (g) { chk(hipGraphExecDestroy(g), "hipGraphExecDestroy"); g = nullptr; }
     if (m->graph) chk(hipGraphDestroy(m->graph), "hipGraphDestroy");
@@ -191,7 +192,7 @@ static void free_dev(dspmap* m) {
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, s.fov_rec, s.fov_slot, s.fov_key, s.fov_spos, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt, s.in_n, s.pmask, s.ta, s.dflag, s.dirty,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.ro_cnt, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
-                    s.tile_moving, m->k.ro_stat, m->k.part_predict, m->k.tile_fov, m->k.view_list, m->k.in_ref, m->k.in_slot, m->k.fov_w_s, m->k.ta_list, s.tile_live, s.fut_dirty, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf, s.birth_cvr};
+                    s.tile_moving, m->k.ro_stat, m->k.part_predict, m->k.tile_fov, m->k.view_list, m->k.tile_cls, s.tile_live, s.fut_dirty, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf, s.birth_cvr};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
     if (m->nbsnap_buf) chk(hipFree(m->nbsnap_buf), "hipFree");
     {
@@ -221,6 +222,8 @@ static void free_dev(dspmap* m) {
     if (m->xq_dev) { chk(hipFree(m->xq_dev), "hipFree"); m->xq_dev = nullptr; }
     for (hipEvent_t e : m->pev) if (e) chk(hipEventDestroy(e), "hipEventDestroy(prof)");
     if (m->stream2) chk(hipStreamDestroy(m->stream2), "hipStreamDestroy(2)");
+    if (m->stream4) chk(hipStreamDestroy(m->stream4), "hipStreamDestroy(4)");
+    for (hipEvent_t e : m->ev_br) if (e) chk(hipEventDestroy(e), "hipEventDestroy");
     if (m->stream3) chk(hipStreamDestroy(m->stream3), "hipStreamDestroy(3)");
     if (m->ev0) chk(hipEventDestroy(m->ev0), "hipEventDestroy");
     if (m->ev1) chk(hipEventDestroy(m->ev1), "hipEventDestroy");
@@ -274,6 +277,9 @@ static int upload_tables(dspmap* m) {
     HIPCHK(m, hipMemcpy(s.p_tab, m->h_ptab.data(), sizeof(float) * n, hipMemcpyHostToDevice));
     HIPCHK(m, hipMemcpy(s.v_tab, m->h_vtab.data(), sizeof(float) * n, hipMemcpyHostToDevice));
     m->fp.tab_n = (int)n;
+    float pm = 0.f;   // how far from its observation a newborn can land (:871-873): FrameParams::birth_reach, k_tile_class
+    for (size_t i = 0; i < n; ++i) { const float a = fabsf(m->h_ptab[i]); if (a > pm || a != a) pm = a != a ? INFINITY : a; }
+    m->ptab_max = pm;
     return DSPMAP_OK;
 }
 static int upload_rtab(dspmap* m) {
@@ -322,19 +328,6 @@ int dspmap_ensure_point_cap(dspmap* m, int n) {
     return DSPMAP_OK;
 }
 
-// the scratch of DSPMAP_P_EARLY_REGISTER (two ints per particle slot + the lists' weight / turned-away arrays): only for handles that ask for it
-static int ensure_early_buffers(dspmap* m) {
-    KernelScratch& k = m->k;
-    if (k.in_ref) return DSPMAP_OK;
-    const MapDims& d = m->d;
-    const size_t cells = (size_t)k.ntiles * 64 * d.slots;
-    HIPCHK(m, dalloc(&k.in_ref, cells));
-    HIPCHK(m, dalloc(&k.in_slot, cells));
-    HIPCHK(m, dalloc(&k.fov_w_s, (size_t)d.np * d.capp));
-    HIPCHK(m, dalloc(&k.ta_list, (size_t)d.np * (d.capa - d.capp)));
-    return DSPMAP_OK;
-}
-
 extern "C" int dspmap_init_device(dspmap_t* m) {
     if (!m) return DSPMAP_E_ARG;
     if (m->device_ready) return DSPMAP_OK;
@@ -347,6 +340,8 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     else HIPCHK(m, hipGetDevice(&m->device));
     if (!m->stream) { HIPCHK(m, hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
     HIPCHK(m, hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
+    HIPCHK(m, hipStreamCreateWithFlags(&m->stream4, hipStreamNonBlocking));
+    for (hipEvent_t& e : m->ev_br) HIPCHK(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(m, hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     HIPCHK(m, hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     HIPCHK(m, hipEventCreateWithFlags(&m->ev_fork2, hipEventDisableTiming));
@@ -434,7 +429,8 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&s.fut_dirty, (size_t)k.ntiles));
     HIPCHK(m, hipMemset(s.fut_dirty, 0, sizeof(int) * (size_t)k.ntiles));   // (the accumulators start zeroed)
     HIPCHK(m, dalloc(&k.view_list, (size_t)k.ntiles));
-    if (m->early_reg == 1) { const int rce = ensure_early_buffers(m); if (rce != DSPMAP_OK) return rce; }   // (off by default: 8 bytes per slot)
+    HIPCHK(m, dalloc(&k.tile_cls, (size_t)k.ntiles));
+    HIPCHK(m, hipMemset(k.tile_cls, 0, sizeof(int) * (size_t)k.ntiles));
     HIPCHK(m, dalloc(&k.tile_fov, (size_t)k.ntiles));
     HIPCHK(m, hipMemset(k.tile_fov, 0xff, sizeof(int) * (size_t)k.ntiles));   // no frame's tag
     HIPCHK(m, dalloc(&k.part_resample, (size_t)k.nblk_sweep * 4));
@@ -563,10 +559,7 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
         case DSPMAP_P_USE_GRAPH: m->use_graph = v == 1; m->direct_ring = v == 2; break;
         case DSPMAP_P_HOST_CLOUD_DIRECT: m->host_direct = v != 0; break;
         case DSPMAP_P_ESTIMATOR_QUEUE: m->est_queue = v != 0; break;   // (part of the captured frame's key)
-        case DSPMAP_P_EARLY_REGISTER:
-            m->early_reg = v < 0 ? -1 : (v != 0 ? 1 : 0); m->graph_epoch++;
-            if (m->early_reg == 1 && m->device_ready) { HIPCHK(m, hipStreamSynchronize(m->stream)); return ensure_early_buffers(m); }
-            break;
+        case DSPMAP_P_FRAME_BRANCHES: m->frame_branches = v < 0 ? -1 : (v != 0 ? 1 : 0); m->graph_epoch++; break;
         case DSPMAP_P_SPARSE_SWEEP: m->sparse_force = v < 0 ? -1 : (v != 0 ? 1 : 0); break;
         case DSPMAP_P_ROLLOUT_INLINE: m->ro_force = v < 0 ? -1 : (v != 0 ? 1 : 0); break;
         case DSPMAP_P_FAST_DIVISION: if (v == 0) { m->d.div_ok = 0; m->div_forced_off = true; m->graph_epoch++; } break;
@@ -612,7 +605,7 @@ extern "C" double dspmap_get_param(const dspmap_t* m, int key) {
         case DSPMAP_P_FAST_DIVISION: return m->d.div_ok;
         case DSPMAP_P_HOST_CLOUD_DIRECT: return m->host_direct ? 1 : 0;
         case DSPMAP_P_ESTIMATOR_QUEUE: return m->est_queue ? 1 : 0;
-        case DSPMAP_P_EARLY_REGISTER: return m->early_reg;
+        case DSPMAP_P_FRAME_BRANCHES: return m->frame_branches;
         case DSPMAP_P_USE_GRAPH: return m->use_graph ? 1 : (m->direct_ring ? 2 : 0);
         default: return 0;
     }
@@ -710,6 +703,7 @@ static void fill_pose(dspmap* m, const float dp[3], float dt) {
     for (int i = 0; i < 3; i++) { m->hp.cur_pos[i] = m->cur_pos[i]; m->hp.od[i] = -dp[i]; }  // particles move opposite to the sensor (:300)
     m->hp.dt = dt;
     m->hp.res_filter = m->voxel_filter_res;
+    m->hp.birth_reach = m->ptab_max;
 }
 
 // C0 gate + deltas, update() :187-218.  returns 1 (accepted) / 0 (rejected)
@@ -741,7 +735,17 @@ int dspmap_gate_and_delta(dspmap* m, const float pos[3], double stamp, const flo
 static bool frame_splits_placement(const dspmap* m, const LaunchCtx& c, bool fork) {
     return !fork && !m->prof && (!c.sparse || m->place_split_tiles <= 1) && c.k.ntiles >= m->place_split_tiles;   // (1 = always, as documented)
 }
-static bool frame_registers_early(const dspmap* m, bool fork) { return !fork && !m->prof && m->early_reg == 1 && m->k.in_ref != nullptr; }
+
+// does this frame run as two branches (DSPMAP_P_FRAME_BRANCHES; KernelScratch::tile_cls)?  The same maps that split their placement -- dense and
+// large: the branches cost a classification launch and two passes of workgroups over the tiles --, unless forced; never a frame whose
+// prediction changes velocities (vz0: constructor-seeded particles draw their noise there, after the classes were sized), a profiled
+// frame (one stream), or a map that runs the four-waves-per-tile resampler (no class filter there: small maps)
+static bool frame_runs_two_branches(const dspmap* m, const LaunchCtx& c, bool fork) {
+    if (fork || m->prof || m->frame_branches == 0 || c.s.vz0 || !c.k.tile_cls) return false;
+    if (resample_variant(c) & 1) return false;
+    if ((size_t)c.d.ny * (size_t)(c.d.z_hi - c.d.z_lo) > (size_t)480 * 1024) return false;   // (k_tile_class's two row bitmaps must fit the LDS)
+    return m->frame_branches == 1 || frame_splits_placement(m, c, fork);
+}
 
 // enqueue one whole device-resident frame (setup .. resample); every per-frame value is read from s.fpar.
 // When `fork` is set (graph capture) the observation binning runs on a second stream concurrently with
@@ -751,21 +755,63 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     // (per-stage timing keeps the frame on one stream; so does a sparse map -- most tiles empty: two passes over all the tiles cost
     // more than the overlap gives: 264x264x80 filled by the depth stream 0.445 -> 0.434 ms, 132x132x60 0.232 -> 0.228; saturated
     // maps keep the split: 0.659 against 0.667 ms and 4.61 against 4.80 ms, interleaved runs on one box)
+    if (frame_runs_two_branches(m, c, fork)) {
+        // TWO BRANCHES (round 6).  The reference's frame is four sweeps over every voxel (:300-322); here most of a large map is only moved
+        // and resampled -- bandwidth-bound sweeps -- while pyramid lists, Ck, weights and births (a chain of latency- and VALU-bound
+        // kernels) concern the part the sensor sees.  k_tile_class cuts the tiles into that part, grown by the reach of a newborn (Q) and
+        // again by the frame's largest displacement (P); then
+        //   main:  predict(P) -> place(Q) -> lists -> Ck -> weights -> births -> resample(Q) -+-> rollout
+        //   side:  predict(not P) -> [predict(P) done] -> place(not Q) -> resample(not Q) ----+
+        // run beside each other.  Same kernels, same per-tile work, same result slot for slot (tests/test_gpu_round6.py).
+        c.place_split = false;
+        c.branches = true;
+        launch_setup_and_bin(c, pts_grid, false, m->frame_ring ? m->ring_dev : nullptr, DSPMAP_RING - 1);
+        launch_tile_class(c);
+        (void)hipEventRecord(m->ev_br[0], m->stream);
+        (void)hipStreamWaitEvent(m->stream4, m->ev_br[0], 0);
+        LaunchCtx cb = c;
+        cb.stream = m->stream4;
+        const bool with_est = est && birth_grid > 0;
+        const bool early_birth = !with_est && birth_grid > 0;
+        launch_predict_only(c, true, early_birth, TILE_P);
+        (void)hipEventRecord(m->ev_br[1], m->stream);                 // predict(P) has ended: every arrival of a Q tile is in its inbox
+        launch_predict_only(cb, false, false, -TILE_P);
+        (void)hipEventRecord(m->ev_br[2], m->stream4);                // predict(not P) has ended: every tile's pending clear is done
+        (void)hipStreamWaitEvent(m->stream4, m->ev_br[1], 0);
+        launch_claim(cb, 0, 0, 0, 0, -1, -TILE_Q);
+        launch_resample(cb, -TILE_Q, false);
+        (void)hipEventRecord(m->ev_br[3], m->stream4);
+        if (with_est) {   // the estimator's branch (the reference's helper thread, :297,311): a third one, from the binning to the birth stage
+            (void)hipStreamWaitEvent(m->stream2, m->ev_br[0], 0);
+            LaunchCtx c2 = c;
+            c2.stream = m->stream2;
+            launch_velocity_estimator(c2, true);
+            launch_birth_early(c2, birth_grid, false);
+            (void)hipEventRecord(m->ev_join, m->stream2);
+        }
+        launch_claim(c, early_birth ? birth_grid : 0, 0, 0, 0, -1, TILE_Q);
+        launch_pyr_prepare(c);
+        launch_ck_partial(c, true);
+        launch_weight_update(c);
+        if (with_est) {
+            (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
+            launch_birth_late(c, birth_grid, false, false);
+        } else {
+            if (birth_grid <= 0) launch_ck_finalize(c);
+            if (early_birth) launch_birth_late(c, birth_grid, all_static);
+            else launch_birth(c, birth_grid, true, all_static);
+        }
+        (void)hipStreamWaitEvent(m->stream, m->ev_br[2], 0);          // (the rollout of the Q tiles adds to accumulators anywhere: after every clear)
+        launch_resample(c, TILE_Q, false);
+        (void)hipStreamWaitEvent(m->stream, m->ev_br[3], 0);
+        launch_rollout(c);
+        m->last_resample_variant = resample_variant(c);
+        m->branch_pending = true;
+        return;
+    }
     const bool split0 = frame_splits_placement(m, c, fork);
-    // EARLY REGISTRATION (round 5; DSPMAP_P_EARLY_REGISTER): k_predict registers the voxel-changing particles in their pyramids itself, the
-    // WHOLE placement runs on the side stream beside list preparation, Ck pass and weight update (which leaves its results with the
-    // list entries), and k_post / k_place_fix tie the two together behind the join.  Replaces the split placement where that applied.
-    // MEASURED (round 5, profiles/r05_*): bit-identical (tests/test_gpu_round5.py::test_early_registration_changes_nothing, incl. revoked
-    // arrivals and overfull lists) and NOT faster -- 132x132x60 saturated 0.686 against 0.657 ms, 264x264x80 4.42 / 4.40: the placement
-    // is bound by DRAM row activations, and the list preparation -- a chain of dependent round trips -- stretches from 13 to 137 us
-    // while it runs beside it; started behind the list preparation instead, the whole placement (138 us at the side stream's
-    // footprint) outlasts the pair kernels it hides behind (73 - 95 us), and k_post / k_place_fix / the second weight launch add
-    // ~20 us of dependent launches.  Hence OFF unless asked for (-1 = off).
-    const bool early = frame_registers_early(m, fork);
-    (void)split0;
-    const bool split = split0 && !early;
+    const bool split = split0;
     c.place_split = split;
-    c.early_reg = early;
     dspmap_prof_mark(m, 0);
     if (!fork) {
         launch_setup_and_bin(c, pts_grid, false, m->frame_ring ? m->ring_dev : nullptr, DSPMAP_RING - 1);   // the gather rides on k_predict's launch
@@ -798,26 +844,10 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
             // the children (the rank ran inside k_ve_clusters): on the side branch when it goes on with the placement of the tiles without
             // a view (large maps); otherwise the branch -- the longer one at the metric's size -- ends here and the waves of the split
             // generate them (launch_birth_late)
-            if (split || early) launch_birth_early(c2, birth_grid, false);
+            if (split) launch_birth_early(c2, birth_grid, false);
             (void)hipEventRecord(m->ev_join, m->stream2);
         }
         dspmap_prof_mark(m, 2);
-        if (early) {
-            (void)hipEventRecord(m->ev_fork2, m->stream);                 // the prediction has ended: lists and inboxes are complete
-            launch_pyr_prepare(c);
-            (void)hipStreamWaitEvent(m->stream2, m->ev_fork2, 0);         // (behind the estimator's kernels)
-            launch_claim(c2, 0, 0, 0, 0, -1);
-            (void)hipEventRecord(m->ev_join, m->stream2);
-            launch_ck_partial(c, true, false);
-            launch_weight_update(c);
-            (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
-            launch_weight_update(c, true);
-            launch_post(c);
-            launch_place_fix(c);
-            launch_birth_late(c, birth_grid, false, false);
-            dspmap_resample(m, c);
-            return;
-        }
         launch_claim(c, 0, 0, 0, 0, split ? 1 : -1);
         if (split) launch_pyr_prepare(c);
         dspmap_prof_mark(m, 3);
@@ -845,26 +875,6 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     const bool early_birth = !fork && birth_grid > 0;
     launch_predict_only(c, !fork, early_birth);
     dspmap_prof_mark(m, 2);
-    if (early) {
-        (void)hipEventRecord(m->ev_fork2, m->stream);
-        launch_pyr_prepare(c);                                            // (queued before the side branch's kernel: the branch whose node comes first stays on the parent's queue)
-        (void)hipStreamWaitEvent(m->stream2, m->ev_fork2, 0);
-        LaunchCtx c2 = c;
-        c2.stream = m->stream2;
-        launch_claim(c2, early_birth ? birth_grid : 0, 0, 0, 0, -1);      // every tile; the newborn children ride along as before
-        (void)hipEventRecord(m->ev_join, m->stream2);
-        launch_ck_partial(c, true, false);
-        launch_weight_update(c);
-        (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
-        launch_weight_update(c, true);
-        launch_post(c);
-        launch_place_fix(c);
-        if (birth_grid <= 0) launch_ck_finalize(c);
-        if (early_birth) launch_birth_late(c, birth_grid, all_static);
-        else launch_birth(c, birth_grid, true, all_static);
-        dspmap_resample(m, c);
-        return;
-    }
     launch_claim(c, early_birth ? birth_grid : 0, 0, 0, 0, split ? 1 : -1);
     if (split) {
         // Only the arrivals of tiles that can see the field of view are registered in pyramids, so only their placement
@@ -1094,7 +1104,7 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
     m->frame_ring = (m->use_graph || m->direct_ring) && !m->prof && m->ring_host != nullptr;
     // the estimator on a queue of its own (DSPMAP_P_ESTIMATOR_QUEUE): replayed frames with the device estimator whose graph would otherwise fork
     // for it alone -- a split placement / early registration keeps its side branch, and the estimator on it
-    const bool xq = m->est_queue && m->xq_dev && mode == 2 && m->frame_ring && (m->birth_cap + 15) / 16 + 1 <= DSPMAP_XQ_LIST && !frame_splits_placement(m, c, false) && !frame_registers_early(m, false);
+    const bool xq = m->est_queue && m->xq_dev && mode == 2 && m->frame_ring && (m->birth_cap + 15) / 16 + 1 <= DSPMAP_XQ_LIST && !frame_splits_placement(m, c, false) && !frame_runs_two_branches(m, c, false);
     if (xq) c.s.xq = m->xq_dev;
     if (m->frame_ring) {
         const unsigned q = (m->ring_head / (DSPMAP_RING / 4)) % 4;
@@ -1189,6 +1199,7 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
             m->graph_key[gi] = key;
         }
         m->last_resample_variant = resample_variant(c);   // (baked into the graph: c.ro_inline is part of its key)
+        if (frame_runs_two_branches(m, c, false)) ++m->branch_frames;
         rc = queue_estimator();
         if (rc != DSPMAP_OK) return rc;
         HIPCHK(m, hipGraphLaunch(m->graph_exec[gi], m->stream));
@@ -1202,7 +1213,9 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
         }
     } else {
         if (m->frame_ring) { rc = queue_estimator(); if (rc != DSPMAP_OK) return rc; }
+        m->branch_pending = false;
         enqueue_frame(m, c, n_points, nb_grid, false, mode == 1, mode == 2);
+        if (m->branch_pending) ++m->branch_frames;
         if (m->frame_ring) {
             if (m->ring_head % (DSPMAP_RING / 4) == DSPMAP_RING / 4 - 1) {
                 const unsigned q = (m->ring_head / (DSPMAP_RING / 4)) % 4;
@@ -1490,6 +1503,7 @@ extern "C" int dspmap_clear_state(dspmap_t* m) {
     HIPCHK(m, hipMemsetAsync(m->s.fut_stat, 0, sizeof(float) * (size_t)d.v_loc, m->stream));
     m->fut_clear_pending = false;
     HIPCHK(m, hipMemsetAsync(m->s.pyr_cnt, 0, sizeof(int) * d.np, m->stream));
+    HIPCHK(m, hipMemsetAsync(&m->s.fs->vmax_bits, 0, sizeof(int), m->stream));   // (no particle, no speed)
     HIPCHK(m, hipStreamSynchronize(m->stream));
     m->have_last = false;
     if (m->nb_dirty) { m->nb_dirty = false; m->graph_epoch++; }
@@ -1773,6 +1787,21 @@ extern "C" int dspmap_debug_rollout_paths(dspmap_t* m, long long out[3]) {
         HIPCHK(m, hipMemcpy(st.data(), m->k.ro_stat, sizeof(int) * 2 * ng, hipMemcpyDeviceToHost));
         for (size_t g = 0; g < ng; ++g) { out[1] += st[2 * g]; out[2] += st[2 * g + 1]; }
     }
+    return DSPMAP_OK;
+}
+extern "C" int dspmap_debug_frame_branches(dspmap_t* m, long long out[5]) {
+    READY(m);
+    BENIGN(m);
+    if (!out) return DSPMAP_E_ARG;
+    HIPCHK(m, hipStreamSynchronize(m->stream));
+    out[0] = m->branch_frames; out[1] = 0; out[2] = 0; out[3] = m->k.ntiles; out[4] = 0;
+    std::vector<int> cls((size_t)m->k.ntiles);
+    HIPCHK(m, hipMemcpy(cls.data(), m->k.tile_cls, sizeof(int) * cls.size(), hipMemcpyDeviceToHost));
+    for (int c : cls) { out[1] += (c & TILE_Q) ? 1 : 0; out[2] += (c & TILE_P) ? 1 : 0; }
+    int vb = 0;
+    HIPCHK(m, hipMemcpy(&vb, &m->s.fs->vmax_bits, sizeof(int), hipMemcpyDeviceToHost));
+    float vf; memcpy(&vf, &vb, sizeof(float));
+    out[4] = (long long)(vf * 1000.f);
     return DSPMAP_OK;
 }
 extern "C" int dspmap_get_pyramid_counts(dspmap_t* m, int* out) {

@@ -20,6 +20,10 @@ __device__ __forceinline__ void sload_i3(const int* p0, const int* p1, const int
     asm volatile("s_load_dword %0, %3, 0x0\n\ts_load_dword %1, %4, 0x0\n\ts_load_dword %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
                  : "=&s"(v0), "=&s"(v1), "=&s"(v2) : "s"(p0), "s"(p1), "s"(p2));
 }
+__device__ __forceinline__ void sload_i5(const int* p0, const int* p1, const int* p2, const int* p3, const int* p4, int& v0, int& v1, int& v2, int& v3, int& v4) {
+    asm volatile("s_load_dword %0, %5, 0x0\n\ts_load_dword %1, %6, 0x0\n\ts_load_dword %2, %7, 0x0\n\ts_load_dword %3, %8, 0x0\n\ts_load_dword %4, %9, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(v0), "=&s"(v1), "=&s"(v2), "=&s"(v3), "=&s"(v4) : "s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(p4));
+}
 __device__ __forceinline__ void sload_i2(const int* p0, const int* p1, int& v0, int& v1) {   // two at once: one round trip
     asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v0), "=&s"(v1) : "s"(p0), "s"(p1));
 }
@@ -338,6 +342,14 @@ __device__ __forceinline__ void st_pos(const DevState& s, size_t idx, float x, f
 __device__ __forceinline__ void st_vel(const DevState& s, size_t idx, float x, float y) {
     V2 v; v.x = x; v.y = y;
     reinterpret_cast<V2*>(s.vel)[idx] = v;
+}
+
+// Whoever gives a particle a velocity the map has not seen before notes its size (FrameScalars::vmax_bits; non-negative floats order like
+// their bit patterns).  `cur` = the word as the caller read it earlier (any stale value is fine: the maximum only grows); the atomic is
+// issued only by a lane that exceeds what memory holds NOW, i.e. a handful of times in a map's life.
+__device__ __forceinline__ void note_speed(const DevState& s, float vx, float vy) {
+    const int b = __float_as_int(fmaxf(fabsf(vx), fabsf(vy)));   // (a NaN component is ignored by fmaxf; inf makes every tile a halo tile: still correct)
+    if (b > 0 && b > __hip_atomic_load(&s.fs->vmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&s.fs->vmax_bits, b);
 }
 
 // The same records through a buffer descriptor of one tile's cells: the lane's byte offset is a single register whatever

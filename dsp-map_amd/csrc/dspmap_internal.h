@@ -86,7 +86,6 @@ struct dspmap {
     // HIP graph of the device-resident frame (dspmap_update_device)
     bool use_graph = true;
     bool direct_ring = false;        // DSPMAP_P_USE_GRAPH = 2: plain launches, the frame's parameter block through the pinned ring like a replayed frame's
-    int early_reg = -1;              // DSPMAP_P_EARLY_REGISTER: -1 the frame decides (dense maps that would split their placement), 0 never, 1 always
     bool est_queue = true;           // DSPMAP_P_ESTIMATOR_QUEUE: the device estimator's kernels on a queue of their own, tied to the captured frame through xq_dev
     unsigned long long api_seq = 0;  // entry points called on this handle (READY; the harmless ones take themselves off again: BENIGN)
     unsigned long long xq_chain_api = ~0ull;   // api_seq of the last frame whose estimator ran on its own queue: when the next such frame is the very
@@ -101,6 +100,12 @@ struct dspmap {
     bool host_direct = true;         // DSPMAP_P_HOST_CLOUD_DIRECT: dspmap_update feeds the captured frame through the mapped cloud ring
     bool fut_clear_pending = false;   // clearOccupancyMapPrediction is lazy: done by the next frame's k_predict, or by the next reader
     hipStream_t stream2 = nullptr;   // fork/join branch inside the captured frame
+    hipStream_t stream4 = nullptr;   // the bulk branch of a two-branch frame (DSPMAP_P_FRAME_BRANCHES)
+    hipEvent_t ev_br[4] = {nullptr, nullptr, nullptr, nullptr};   // its fork, "predict(P) ended", "predict(not P) ended", its join
+    int frame_branches = -1;         // DSPMAP_P_FRAME_BRANCHES: -1 the maps that would split their placement, 0 never, 1 whenever possible
+    long long branch_frames = 0;     // frames that ran as two branches (dspmap_debug_frame_branches)
+    bool branch_pending = false;
+    float ptab_max = 0.f;            // largest |value| of the position table (FrameParams::birth_reach)
     hipStream_t stream3 = nullptr;   // the estimator's own stream (DSPMAP_P_ESTIMATOR_QUEUE): created at first use, tested not to share the main stream's
                                      // hardware queue (ensure_estimator_stream); plain launches only, never captured
     hipStream_t stream3_for = nullptr;   // the main stream it was paired with (dspmap_set_stream may change that one)

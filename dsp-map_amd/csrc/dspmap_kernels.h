@@ -17,14 +17,11 @@ struct KernelScratch {
     int* view_list;     // [ntiles] the tiles with a view on the field of view this frame, in no particular order (FrameScalars::n_view_tiles of them):
                         // written by extra workgroups of k_predict when the frame splits its placement, walked by the placement that precedes
                         // the pair kernels INSTEAD of all the tiles
-    // EARLY REGISTRATION (LaunchCtx::early_reg; dense large maps, captured frame): k_predict registers the particles that change voxel in
-    // their pyramids itself (their new position is known there), so that the list preparation and the Ck pass no longer wait for the
-    // placement -- which runs beside them on the side stream -- and the weight update leaves its results with the list entries:
-    int* in_ref;        // [ntiles * 64 * slots] per inbox record: its entry in the pyramid lists (pyramid * capa + position), -1 not in view,
-                        // -3 its pyramid's list was beyond CAPA (the particle vanishes, :1256-1259)
-    int* in_slot;       // [ntiles * 64 * slots] per inbox record: the cell k_place gave it (pidx), -1 none (voxel full)
-    float* fov_w_s;     // [np * capp] the weight update's result per range-sorted list entry (< 0: not re-weighted), scattered to the cells by k_post
-    int* ta_list;       // [np * (capa - capp)] list entries (pyramid * capa + position) k_pyr_prepare turned away (FrameScalars::n_ta)
+    int* tile_cls;      // [ntiles] the TWO-BRANCH frame's tile classes, written by k_tile_class right after the binning (LaunchCtx::branches):
+                        // bit 0 (Q) = a newborn of this frame can land in the tile (its rows, grown by the position table's reach, touch the field
+                        // of view) -- and every tile in which a particle can be registered in a pyramid; bit 1 (P) = a particle of the tile can
+                        // reach a Q tile this frame (Q's rows dilated by the frame's largest displacement).  The in-view chain predicts P,
+                        // places and resamples Q; the bulk branch predicts / places / resamples the complements beside it
     int* part_resample; // [ntiles rounded up to 4] live particles per tile after resampling
     int* vb_cnt;        // [v_loc] children per destination voxel this frame (birth ordering)
     int* vb_idx;        // [v_loc*128] their birth indices
@@ -60,9 +57,9 @@ struct LaunchCtx {
     bool sweep_rev = false;   // this frame's k_predict / k_resample walk the tiles from the last one down and k_place from the first one up
                               // (the next frame the other way round): every tile sweep starts where its predecessor ended (Infinity Cache)
     bool resample_rev = false;   // k_resample walks the tiles from the last one down (after a k_place that ended there)
-    bool early_reg = false;   // this frame: early registration (see KernelScratch::in_ref)
     bool place_split = false; // this frame places the arrivals of the tiles with a view first (launch_claim sel = 1) and the others beside the pair
                               // kernels (sel = 0): k_predict leaves the list of the tiles with a view (KernelScratch::view_list)
+    bool branches = false;   // this frame runs as two branches (DSPMAP_P_FRAME_BRANCHES; see KernelScratch::tile_cls)
     bool sparse = false; // most tiles hold nothing (dspmap::sparse_mode): k_predict's variant that leaves such tiles first
 };
 
@@ -74,9 +71,13 @@ void launch_setup_and_bin(const LaunchCtx& c, int n_pts_grid, bool gather = true
 // mapPrediction (:627-701) incl. re-binning of movers (moveParticle :1206-1274)
 void launch_predict(const LaunchCtx& c, bool with_gather = false);
 void launch_spin(const LaunchCtx& c, int us);   // experiment aid: a one-wave kernel that waits `us` microseconds
-void launch_predict_only(const LaunchCtx& c, bool with_gather = false, bool with_rank = false);   // with_rank: k_birth_rank rides along
+void launch_predict_only(const LaunchCtx& c, bool with_gather = false, bool with_rank = false, int cls = 0);   // with_rank: k_birth_rank rides along
+   // cls (two-branch frame): 0 every tile; +m only the tiles whose class has a bit of m, -m only those that have none (KernelScratch::tile_cls)
+void launch_tile_class(const LaunchCtx& c);   // after the binning (needs the rotated planes and the frame's parameter block)
+#define TILE_Q 1
+#define TILE_P 2
 void launch_scan_blocks(const LaunchCtx& c, int nblk);   // exclusive scan of s.blk_cnt[0..nblk), total -> fs->occupied_count
-void launch_claim(const LaunchCtx& c, int n_birth_grid = 0, int part = 0, int tile_lo = 0, int tile_hi = 0, int sel = -1);   // sel: -1 every tile of the part, 1 / 0 only the tiles with / without a view on the sensor's field of view (tile_fov)   // part: 0 all tiles, 1 [lo, hi), 2 the rest;   // > 0: k_birth_children rides along (after a launch with_rank)
+void launch_claim(const LaunchCtx& c, int n_birth_grid = 0, int part = 0, int tile_lo = 0, int tile_hi = 0, int sel = -1, int cls = 0);   // sel: -1 every tile of the part, 1 / 0 only the tiles with / without a view on the sensor's field of view (tile_fov)   // part: 0 all tiles, 1 [lo, hi), 2 the rest;   // > 0: k_birth_children rides along (after a launch with_rank)
 void launch_reduce_counters(const LaunchCtx& c);
 void launch_calib(const LaunchCtx& c, int mode, size_t n);
 void launch_sweep_probe(const LaunchCtx& c, int what, int rows, int rows_per_batch);
@@ -94,7 +95,6 @@ void launch_velocity_estimator_xq(const LaunchCtx& c, bool with_rank, const Fram
 int velocity_estimator_capacity();   // points per frame the device estimator handles
 int velocity_estimator_slices();
 // mapUpdate (:704-793)
-void launch_post(const LaunchCtx& c);          // early registration, after the placement and the weight update have both ended: weights -> cells, turned-away entries -> occupancy / dirty voxels
 void launch_place_fix(const LaunchCtx& c);     // re-slots the arrivals of voxels in which a full pyramid list turned a particle away (after launch_pyr_prepare)
 // sharded maps: one pass (8 bits, most significant first) of the distributed selection of every pyramid's CAPP-th smallest sweep key;
 // the caller sums `hist` ([np][256]) over the ranks between the two launches
@@ -105,7 +105,7 @@ void launch_pyr_kept(const LaunchCtx& c, const int* kstar, int* kept);   // afte
 void launch_pyr_prepare(const LaunchCtx& c);   // range sort + full-list selection of the pyramid lists, work items (idempotent)
 void launch_ck_partial(const LaunchCtx& c, bool prepared = false, bool with_fix = true);   // with_fix: the first workgroups run k_place_fix's pass     // launch_pyr_prepare (unless already queued) + the Ck pass
 void launch_ck_finalize(const LaunchCtx& c);
-void launch_weight_update(const LaunchCtx& c, bool redo = false);   // redo (early registration): only if the placement revoked a registered arrival
+void launch_weight_update(const LaunchCtx& c);
 // mapAddNewBornParticlesByObservation (:796-921)
 void launch_birth(const LaunchCtx& c, int n_birth, bool in_frame, bool all_static);  // in_frame: between k_weight and k_resample of a whole frame
 void launch_birth_split(const LaunchCtx& c, int n_birth);
@@ -116,7 +116,8 @@ void launch_birth_late(const LaunchCtx& c, int n_birth, bool all_static, bool wi
 void launch_birth_plan_insert(const LaunchCtx& c, int n_birth, bool in_frame, bool all_static);
 void launch_birth_materialize(const LaunchCtx& c, BirthSrc* out, int cap, int* n_out);   // the frame's synthesised birth cloud, for host readback
 // mapOccupancyCalculationAndResample (:924-1057)
-void launch_resample(const LaunchCtx& c);   // + the future rollout of the moving particles (k_rollout)
+void launch_resample(const LaunchCtx& c, int cls = 0, bool with_rollout = true);   // + the future rollout of the moving particles (k_rollout)
+void launch_rollout(const LaunchCtx& c);    // the rollout alone (a two-branch frame: once, behind both branches' resampling)
 int resample_variant(const LaunchCtx& c);   // bit 0: k_resample_wg; bits 1-2: rollout 0 inline, 1 k_rollout light, 2 k_rollout windows, 3 none
 void kernels_init_device();                 // function attributes of the current device (dynamic LDS of k_rollout)
 // readout (:385-438)

@@ -57,7 +57,7 @@ __global__ void k_reset(MapDims d, DevState s, int flags) {
     if (flags & RESET_PRED) {
         for (int i = gt; i < d.np; i += gn) s.pyr_cnt[i] = 0;
         if (gt == 0) {
-            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->n_pyr_removed = 0; s.fs->n_dirty = 0; s.fs->n_overflow_inexact = 0; s.fs->n_place_vf = 0; s.fs->n_place_pf = 0; s.fs->n_view_tiles = 0; s.fs->n_ta = 0; s.fs->n_revoked = 0; s.fs->pred_epoch = s.fs->pred_epoch + 1; s.fs->live_hint = s.fs->live_acc; s.hint_out[0] = s.fs->live_acc; s.fs->live_acc = 0; s.hint_out[1] = s.fs->mv_acc; s.fs->mv_acc = 0;
+            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->n_pyr_removed = 0; s.fs->n_dirty = 0; s.fs->n_overflow_inexact = 0; s.fs->n_place_vf = 0; s.fs->n_place_pf = 0; s.fs->n_view_tiles = 0; s.fs->pred_epoch = s.fs->pred_epoch + 1; s.fs->live_hint = s.fs->live_acc; s.hint_out[0] = s.fs->live_acc; s.fs->live_acc = 0; s.hint_out[1] = s.fs->mv_acc; s.fs->mv_acc = 0;
         }
     }
 }
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) k_obs_points(MapDims d, DevState s, const
         if (gt == 0) {
             s.fs->cur_pos[0] = cpx; s.fs->cur_pos[1] = cpy; s.fs->cur_pos[2] = cpz;
             s.fs->n_valid = 0; s.fs->n_obs = 0; s.fs->has_expected_override = 0;   // k_obs_gather accumulates the first two
-            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->n_pyr_removed = 0; s.fs->n_dirty = 0; s.fs->n_overflow_inexact = 0; s.fs->n_place_vf = 0; s.fs->n_place_pf = 0; s.fs->n_view_tiles = 0; s.fs->n_ta = 0; s.fs->n_revoked = 0; s.fs->pred_epoch = s.fs->pred_epoch + 1; s.fs->live_hint = s.fs->live_acc; s.hint_out[0] = s.fs->live_acc; s.fs->live_acc = 0; s.hint_out[1] = s.fs->mv_acc; s.fs->mv_acc = 0;
+            s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->n_pyr_removed = 0; s.fs->n_dirty = 0; s.fs->n_overflow_inexact = 0; s.fs->n_place_vf = 0; s.fs->n_place_pf = 0; s.fs->n_view_tiles = 0; s.fs->pred_epoch = s.fs->pred_epoch + 1; s.fs->live_hint = s.fs->live_acc; s.hint_out[0] = s.fs->live_acc; s.fs->live_acc = 0; s.hint_out[1] = s.fs->mv_acc; s.fs->mv_acc = 0;
         }
     } else {
         for (int i = threadIdx.x; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
@@ -159,7 +159,7 @@ extern "C" int dspmap_debug_pyr_prof(long long* out, int n) { return (int)hipMem
 #else
 #define PSTAMP(k) do { } while (0)
 #endif
-__device__ __forceinline__ void pyr_sort_block(const MapDims& d, const DevState& s, int b, int* __restrict__ ta_list) {   // ta_list: early registration
+__device__ __forceinline__ void pyr_sort_block(const MapDims& d, const DevState& s, int b) {
     __shared__ int s_hist[PS_NBK], s_base[PS_NBK];
     __shared__ int s_sel[8192];
     __shared__ int s_pick[2];
@@ -268,13 +268,6 @@ __device__ __forceinline__ void pyr_sort_block(const MapDims& d, const DevState&
             // that a second preparation of the same lists (stage API: after the prediction and again before the update)
             // changes nothing.
             src_key[i] = 0x7fffffff;
-            if (ta_list) {
-                // EARLY REGISTRATION: the placement runs beside this kernel -- it reads the occupancy words, and an arrival's cell is not
-                // even known yet: the entry is only NOTED; k_post clears the bit and marks the voxel once both have ended
-                ta_list[atomicAdd(&s.fs->n_ta, 1)] = b * d.capa + i;
-                ++removed;
-                continue;
-            }
             const int c = src_slot[i];
             const int tile = c / (64 * d.slots), rem = c - tile * 64 * d.slots, slot = rem >> 6, lv = tile * 64 + (rem & 63);
             atomicAnd(&s.mask[(size_t)lv * d.mw + (slot >> 6)], ~(1ull << (slot & 63)));
@@ -334,12 +327,8 @@ __device__ __forceinline__ void pyr_sort_block(const MapDims& d, const DevState&
                 // where the entry went: k_place_fix re-points the entries of the ARRIVALS it moves -- only theirs is noted (a stayer's sweep
                 // key is its own cell; an arrival carries its source's): one scattered store less for nine entries in ten
                 const int c = sl_u[u];
-                bool arrival = c < 0;   // (early registration: the cell is not known yet -- an arrival by construction)
-                if (!arrival) {
-                    const int tile = c / (64 * d.slots), rem = c - tile * 64 * d.slots;
-                    arrival = key_u[u] != (tile * 64 + (rem & 63) + d.v_base) * d.slots + (rem >> 6);
-                }
-                if (arrival) s.fov_spos[(size_t)b * d.capa + i] = pos;
+                const int tile = c / (64 * d.slots), rem = c - tile * 64 * d.slots;
+                if (key_u[u] != (tile * 64 + (rem & 63) + d.v_base) * d.slots + (rem >> 6)) s.fov_spos[(size_t)b * d.capa + i] = pos;
             }
             if (more) {
 #pragma unroll
@@ -355,9 +344,9 @@ __device__ __forceinline__ void pyr_items_block(const MapDims& d, const DevState
 // k_pyr_prepare: what the pair kernels need once per frame, in one launch: workgroups 0 .. np-1 order the pyramid lists,
 // the last workgroup expands the work-item lists and neighbourhood tables (the two are independent of each other).
 __global__ void __launch_bounds__(1024) k_pyr_prepare(MapDims d, DevState s, int* __restrict__ ck_items, int* __restrict__ wu_items,
-                                                      int* __restrict__ n_items, int* __restrict__ nb_tab, int* __restrict__ ta_list) {
+                                                      int* __restrict__ n_items, int* __restrict__ nb_tab) {
     if ((int)blockIdx.x == d.np) pyr_items_block(d, s, ck_items, wu_items, n_items, nb_tab);
-    else pyr_sort_block(d, s, (int)blockIdx.x, ta_list);
+    else pyr_sort_block(d, s, (int)blockIdx.x);
 }
 
 // --------------------------------------------------------------------------
@@ -872,12 +861,7 @@ __global__ void __launch_bounds__(512) k_ck_sum(MapDims d, DevState s, FilterPar
 // masked to zero.  Both variants add exactly the same terms.
 template <bool SKIP>
 __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, FilterParams fp, const int* __restrict__ items,
-                                                   const int* __restrict__ n_items, const int* __restrict__ nb_tab,
-                                                   float* __restrict__ fov_w_s, int redo) {
-    // fov_w_s (EARLY REGISTRATION): the new weight stays with the list entry -- the placement that knows an arrival's cell runs beside
-    // this kernel; k_post scatters the weights once both have ended.  redo: the second launch of such a frame, behind the placement:
-    // it repeats the update only if the placement took a registered arrival's terms out of Ck again (ck_revoke: a full voxel)
-    if (redo && s.fs->n_revoked == 0) return;
+                                                   const int* __restrict__ n_items, const int* __restrict__ nb_tab) {
     extern __shared__ float4 s_o[];   // [nbins * DSP_OBS_CAP]: the neighbourhood's observations {x, y, z, P_d/Ck} ...
     float* s_len = reinterpret_cast<float*>(s_o + (size_t)d.nbins * DSP_OBS_CAP);   // ... and their ranges
     __shared__ int s_bin[DSP_MAX_NBINS];
@@ -1016,8 +1000,7 @@ __global__ void __launch_bounds__(WU_TPB) k_weight(MapDims d, DevState s, Filter
         if (spl >= 2) sum += __shfl_xor(sum, 1, WAVE);
         if (spl >= 4) sum += __shfl_xor(sum, 2, WAVE);
         if (spl >= 8) sum += __shfl_xor(sum, 4, WAVE);
-        if (fov_w_s) { if (valid && sub == 0) fov_w_s[ri] = occluded ? -1.f : p.w * ((1.f - fp.p_det) + sum); }
-        else if (valid && !occluded && sub == 0) s.w[s.fov_slot_s[ri]] = p.w * ((1.f - fp.p_det) + sum);  // :786
+        if (valid && !occluded && sub == 0) s.w[s.fov_slot_s[ri]] = p.w * ((1.f - fp.p_det) + sum);  // :786
     }
 }
 
@@ -1419,6 +1402,7 @@ __global__ void __launch_bounds__(256) k_birth_insert(MapDims d, DevState s, Fil
                     const size_t idx = pidx(d, lv, sl);
                     st_pos(s, idx, ch.x, ch.y, ch.z);
                     st_vel(s, idx, vx, vy);
+                    note_speed(s, vx, vy);
                     if (vx != 0.f || vy != 0.f) s.tile_moving[lv >> 6] = 1;   // (a newborn of a matched cluster: the tile's velocity rows count again)
                     s.w[idx] = newborn_w;
                     atomicOr(&s.nbmask[(size_t)lv * d.mw + (sl >> 6)], 1ull << (sl & 63));  // flag 15
@@ -1528,60 +1512,21 @@ void launch_place_fix(const LaunchCtx& c) {   // stage API: after launch_pyr_pre
     hipLaunchKernelGGL(k_place_fix, dim3(PF_WG), dim3(256), PF_LDS_BYTES, c.stream, c.d, c.s, c.k.in_rec, c.k.omask, reinterpret_cast<const int*>(c.k.mv_rec));
 }
 void launch_pyr_prepare(const LaunchCtx& c) {
-    hipLaunchKernelGGL(k_pyr_prepare, dim3(c.d.np + 1), dim3(1024), 0, c.stream, c.d, c.s, c.k.ck_items, c.k.wu_items, c.k.n_items, c.k.nb_tab, c.early_reg ? c.k.ta_list : nullptr);
+    hipLaunchKernelGGL(k_pyr_prepare, dim3(c.d.np + 1), dim3(1024), 0, c.stream, c.d, c.s, c.k.ck_items, c.k.wu_items, c.k.n_items, c.k.nb_tab);
 }
 void launch_ck_partial(const LaunchCtx& c, bool prepared, bool with_fix) {
-    if (!prepared) hipLaunchKernelGGL(k_pyr_prepare, dim3(c.d.np + 1), dim3(1024), 0, c.stream, c.d, c.s, c.k.ck_items, c.k.wu_items, c.k.n_items, c.k.nb_tab, c.early_reg ? c.k.ta_list : nullptr);
+    if (!prepared) hipLaunchKernelGGL(k_pyr_prepare, dim3(c.d.np + 1), dim3(1024), 0, c.stream, c.d, c.s, c.k.ck_items, c.k.wu_items, c.k.n_items, c.k.nb_tab);
     hipLaunchKernelGGL(k_ck_partial, dim3(4096 + PF_WG), dim3(CK_TPB), (sizeof(float4) + sizeof(int)) * (size_t)c.d.nbins * DSP_OBS_CAP, c.stream, c.d, c.s, c.fp, c.k.ck_items, c.k.n_items, c.k.nb_tab,
                        c.k.in_rec, c.k.omask, reinterpret_cast<const int*>(c.k.mv_rec), with_fix ? 1 : 0);
 }
 void launch_ck_finalize(const LaunchCtx& c) {  // after launch_weight_update: reduces the per-pyramid 1/Ck sums
     hipLaunchKernelGGL(k_ck_sum, dim3(1), dim3(512), 0, c.stream, c.d, c.s, c.fp);
 }
-void launch_weight_update(const LaunchCtx& c, bool redo) {  // after launch_ck_partial (which also builds the item lists)
+void launch_weight_update(const LaunchCtx& c) {  // after launch_ck_partial (which also builds the item lists)
     const bool skip = weight_culls(c);
     const size_t lds = (sizeof(float4) + sizeof(float)) * (size_t)c.d.nbins * DSP_OBS_CAP;
-    float* wout = c.early_reg ? c.k.fov_w_s : nullptr;
-    if (skip) hipLaunchKernelGGL(k_weight<true>, dim3(4096), dim3(WU_TPB), lds, c.stream, c.d, c.s, c.fp, c.k.wu_items, c.k.n_items, c.k.nb_tab, wout, redo ? 1 : 0);
-    else hipLaunchKernelGGL(k_weight<false>, dim3(4096), dim3(WU_TPB), lds, c.stream, c.d, c.s, c.fp, c.k.wu_items, c.k.n_items, c.k.nb_tab, wout, redo ? 1 : 0);
-}
-
-// EARLY REGISTRATION, after the placement (side stream) and the weight update have both ended:
-//   workgroups [0, np * ceil(capp / 1024)): the new weights leave the range-sorted lists for their cells -- an arrival's cell is where
-//     k_place put it (KernelScratch::in_slot; none: the arrival found its voxel full and its entry was revoked);
-//   the others: the entries k_pyr_prepare turned away (:1256-1259) lose their occupancy bit, their voxel is noted for k_place_fix
-//     (what k_pyr_prepare does itself when the placement precedes it).
-__global__ void __launch_bounds__(1024) k_post(MapDims d, DevState s, const float* __restrict__ fov_w_s, const int* __restrict__ in_slot,
-                                               const int* __restrict__ ta_list, int nwb) {
-    const int per = (d.capp + 1023) / 1024;
-    if ((int)blockIdx.x < nwb) {
-        const int b = (int)blockIdx.x / per, i = ((int)blockIdx.x % per) * 1024 + (int)threadIdx.x;
-        if (i >= pyr_len(d, s, b)) return;
-        const size_t ri = (size_t)b * d.capp + i;
-        const float w = fov_w_s[ri];
-        if (!(w >= 0.f)) return;                       // occluded: not re-weighted (:761-765)
-        int c = s.fov_slot_s[ri];
-        if (c < -1) c = in_slot[-2 - c];
-        if (c >= 0) s.w[c] = w;                        // :786
-        return;
-    }
-    const int nta = s.fs->n_ta;
-    for (int t = ((int)blockIdx.x - nwb) * 1024 + (int)threadIdx.x; t < nta; t += ((int)gridDim.x - nwb) * 1024) {
-        int c = s.fov_slot[ta_list[t]];
-        if (c < -1) c = in_slot[-2 - c];
-        if (c < 0) continue;                           // (an arrival that found its voxel full: it holds no cell)
-        const int tile = c / (64 * d.slots), rem = c - tile * 64 * d.slots, slot = rem >> 6, lv = tile * 64 + (rem & 63);
-        atomicAnd(&s.mask[(size_t)lv * d.mw + (slot >> 6)], ~(1ull << (slot & 63)));
-        atomicOr(&s.ta[(size_t)lv * d.mw + (slot >> 6)], 1ull << (slot & 63));
-        if (atomicExch(&s.dflag[lv], 1) == 0) {
-            const int q = atomicAdd(&s.fs->n_dirty, 1);
-            if (q < DSP_DIRTY_CAP) s.dirty[q] = lv; else atomicAdd(&s.fs->n_overflow_inexact, 1);
-        }
-    }
-}
-void launch_post(const LaunchCtx& c) {
-    const int nwb = c.d.np * ((c.d.capp + 1023) / 1024);
-    hipLaunchKernelGGL(k_post, dim3(nwb + 16), dim3(1024), 0, c.stream, c.d, c.s, c.k.fov_w_s, c.k.in_slot, c.k.ta_list, nwb);
+    if (skip) hipLaunchKernelGGL(k_weight<true>, dim3(4096), dim3(WU_TPB), lds, c.stream, c.d, c.s, c.fp, c.k.wu_items, c.k.n_items, c.k.nb_tab);
+    else hipLaunchKernelGGL(k_weight<false>, dim3(4096), dim3(WU_TPB), lds, c.stream, c.d, c.s, c.fp, c.k.wu_items, c.k.n_items, c.k.nb_tab);
 }
 
 // n_birth_grid sizes the launches (>= the frame's n_birth, which the kernels read from FrameParams)

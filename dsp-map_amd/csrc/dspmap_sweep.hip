@@ -196,6 +196,7 @@ __device__ __forceinline__ void vz_noise(const MapDims& d, const DevState& s, co
         vxy[0] += s.v_tab[c];
         vxy[1] += s.v_tab[(c + 1) % fp.tab_n];
         st_vel(s, idx, vxy[0], vxy[1]);
+        note_speed(s, vxy[0], vxy[1]);
     }
     s.vz0[idx] = 0.f;
 }
@@ -233,6 +234,100 @@ __device__ __forceinline__ int tile_view_test(const MapDims& d, const DevState& 
     auto box_in = [&](int sh) { return ((b0 >> sh) & 0xffull) && ((b1 >> sh) & 0xffull) && ((b2 >> sh) & 0xffull) && ((b3 >> sh) & 0xffull); };
     return (box_in(0) || box_in(8)) ? 1 : 0;
 }
+// Two-branch frame: is tile BX this launch's business?  cls > 0: the tiles whose class has a bit of cls; < 0: those that have none of -cls.
+__device__ __forceinline__ bool cls_mine(int tc, int cls) { return cls > 0 ? (tc & cls) != 0 : (tc & -cls) == 0; }
+
+// --------------------------------------------------------------------------
+// k_tile_class: the tile classes of a TWO-BRANCH frame (KernelScratch::tile_cls), one workgroup, right after the binning.
+// The frame (reference :300-322: prediction -> update -> births -> resampling, each a sweep over ALL voxels) touches most of a large
+// map only to move it and to resample it; weights, births and pyramid lists live in the part the sensor sees.  The two parts run as
+// two branches; what ties them together is (a) a particle that changes voxel ACROSS the border and (b) a newborn landing beyond it.
+// Both have a bounded reach, and the classes are the border grown by those reaches:
+//   rows   the map is cut in x-rows (one (y, z) each, the whole x extent): a row is IN VIEW if its box, grown by the reach of a
+//          newborn (the position table's largest value, FrameParams::birth_reach), passes the four boundary planes of the field of
+//          view (the same corner argument as tile_view_test: a plane's dot product is monotone in every coordinate, so its
+//          extreme over a box sits at the corner the normal's signs select);
+//   Q      a tile that touches a row in view: every observation lies in the wedge, so every newborn lands in a Q tile, and every
+//          tile with a view (tile_view_test) is one;
+//   P      a tile that touches a row within the frame's largest displacement -- |od| + dt * (largest speed the map has seen,
+//          FrameScalars::vmax_bits), in rows and layers -- of a row of a Q tile: nothing outside P can send a particle into Q.
+// So: predict(P) -> place(Q) sees every arrival of Q; place(not Q) waits for both predictions; births stay inside Q.
+// Conservative on purpose (rows, not boxes: the classes are a few per cent larger than they must be), exact never matters.
+// dynamic LDS: two bitmaps of one bit per row.
+// --------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_tile_class(MapDims d, DevState s, int* __restrict__ tile_cls) {
+    extern __shared__ unsigned s_bm[];
+    const int tid = threadIdx.x;
+    const int nlay = d.z_hi - d.z_lo;
+    const int nrows = d.ny * nlay;
+    const int nw = (nrows + 31) >> 5;
+    unsigned* const bm0 = s_bm;
+    unsigned* const bm1 = s_bm + nw;
+    const int ntl = (d.v_loc + 63) >> 6;
+    for (int i = tid; i < 2 * nw; i += 1024) s_bm[i] = 0u;
+    const float* __restrict__ gph = s.planes_h;
+    const float* __restrict__ gpv = s.planes_v;
+    const float n0[3] = {gph[0], gph[1], gph[2]}, n1[3] = {gph[3 * d.np_h], gph[3 * d.np_h + 1], gph[3 * d.np_h + 2]};
+    const float n2[3] = {gpv[0], gpv[1], gpv[2]}, n3[3] = {gpv[3 * d.np_v], gpv[3 * d.np_v + 1], gpv[3 * d.np_v + 2]};
+    const float reach = s.fpar->birth_reach;
+    const float mg = d.res * 0.01f + (reach > 0.f ? reach * 1.0001f : 0.f);   // (res * 0.01: tile_view_test's own margin -- a row's box contains the boxes of its tiles)
+    const float vmax = __int_as_float(s.fs->vmax_bits);
+    const float dt = fabsf(s.fpar->dt);
+    const float my = (fabsf(s.fpar->od[1]) + dt * vmax) * 1.0001f, mz = fabsf(s.fpar->od[2]) * 1.0001f;
+    // rows / layers a particle can cross: floor(m / res) + 1 (it may sit right at the face), none if it cannot move that way at all
+    const int ky = my > 0.f ? (my < d.res * (float)d.ny ? (int)(my / d.res) + 1 : d.ny) : 0;
+    const int kz = mz > 0.f ? (mz < d.res * (float)d.nz ? (int)(mz / d.res) + 1 : d.nz) : 0;
+    __syncthreads();
+    // the extreme of dot3 over a box: the corner the normal's signs select (dot3 itself, so the value IS the extreme of the corner values)
+    auto ext = [&](const float* n, bool mx, float x0, float x1, float y0, float y1, float z0, float z1) {
+        const float cx = ((n[0] >= 0.f) == mx) ? x1 : x0, cy = ((n[1] >= 0.f) == mx) ? y1 : y0, cz = ((n[2] >= 0.f) == mx) ? z1 : z0;
+        return dot3(cx, cy, cz, n);
+    };
+    for (int r = tid; r < nrows; r += 1024) {
+        const int y = r % d.ny, z = d.z_lo + r / d.ny;
+        const float x0 = 0.f * d.res - d.half_x - mg, x1 = (float)d.nx * d.res - d.half_x + mg;
+        const float y0 = (float)y * d.res - d.half_y - mg, y1 = (float)(y + 1) * d.res - d.half_y + mg;
+        const float z0 = (float)z * d.res - d.half_z - mg, z1 = (float)(z + 1) * d.res - d.half_z + mg;
+        const bool in = ext(n0, true, x0, x1, y0, y1, z0, z1) >= 0.f && ext(n1, false, x0, x1, y0, y1, z0, z1) <= 0.f &&
+                        ext(n2, false, x0, x1, y0, y1, z0, z1) <= 0.f && ext(n3, true, x0, x1, y0, y1, z0, z1) >= 0.f;
+        if (in) atomicOr(&bm0[r >> 5], 1u << (r & 31));
+    }
+    __syncthreads();
+    auto any_row = [&](const unsigned* bm, int r0, int r1) {
+        for (int r = r0; r <= r1; ++r) if ((bm[r >> 5] >> (r & 31)) & 1u) return true;
+        return false;
+    };
+    for (int t = tid; t < ntl; t += 1024) {
+        const int r0 = (t * 64) / d.nx, r1 = min(t * 64 + 63, d.v_loc - 1) / d.nx;
+        const bool q = any_row(bm0, r0, r1);
+        tile_cls[t] = q ? TILE_Q : 0;
+        if (q) for (int r = r0; r <= r1; ++r) atomicOr(&bm1[r >> 5], 1u << (r & 31));   // the rows of the Q tiles
+    }
+    __syncthreads();
+    for (int i = tid; i < nw; i += 1024) bm0[i] = 0u;
+    __syncthreads();
+    for (int r = tid; r < nrows; r += 1024) {   // does a row within (ky, kz) of this one belong to a Q tile?
+        const int y = r % d.ny, zl = r / d.ny;
+        bool near = false;
+        for (int dz = -kz; dz <= kz && !near; ++dz) {
+            const int z2 = zl + dz;
+            if (z2 < 0 || z2 >= nlay) continue;
+            const int ya = max(0, y - ky), yb = min(d.ny - 1, y + ky);
+            for (int y2 = ya; y2 <= yb; ++y2) { const int r2 = z2 * d.ny + y2; if ((bm1[r2 >> 5] >> (r2 & 31)) & 1u) { near = true; break; } }
+        }
+        if (near) atomicOr(&bm0[r >> 5], 1u << (r & 31));
+    }
+    __syncthreads();
+    for (int t = tid; t < ntl; t += 1024) {
+        const int r0 = (t * 64) / d.nx, r1 = min(t * 64 + 63, d.v_loc - 1) / d.nx;
+        if (any_row(bm0, r0, r1)) tile_cls[t] |= TILE_P;   // (only this thread writes tile_cls[t])
+    }
+}
+void launch_tile_class(const LaunchCtx& c) {
+    const int nrows = c.d.ny * (c.d.z_hi - c.d.z_lo);
+    hipLaunchKernelGGL(k_tile_class, dim3(1), dim3(1024), (size_t)2 * ((nrows + 31) / 32) * sizeof(unsigned), c.stream, c.d, c.s, c.k.tile_cls);
+}
+
 // eight workgroups per CU: the sweep is a chain of phases (occupancy words, rows, tails) and only the workgroups that are in
 // their row phase keep the memory system busy -- residency, not per-wave batch depth, is what moved this kernel (measured:
 // 5 -> 7 -> 8 resident workgroups 0.274 -> 0.239 -> 0.224 ms at 132x132x60 saturated; 2 / 3 / 4 / 6 rows per batch all alike)
@@ -244,7 +339,8 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
                                                  float4* __restrict__ mv_rec, float4* __restrict__ in_rec, int* __restrict__ in_cnt,
                                                  u64* __restrict__ expmask, const int* __restrict__ vz_pre, const u64* __restrict__ vz_q,
                                                  u64* __restrict__ omask, int extra, int* __restrict__ tile_fov, int rev, int* __restrict__ view_list,
-                                                 int* __restrict__ in_ref) {
+                                                 const int* __restrict__ tcls, int cls) {
+    // tcls / cls (two-branch frame): this launch sweeps only the tiles cls_mine() selects; the riders (extra) go with the in-view branch
     // rev: the tiles are walked from the last one down (workgroup -> tile mapping only).  k_place always walks AGAINST the k_predict
     // before it: a large map's live rows are several times the 256 MB Infinity Cache, and a sweep that starts where the last one
     // ENDED finds its first tiles (rows, occupancy words, inbox records) there instead of in HBM -- 132x132x60 saturated:
@@ -337,10 +433,11 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
         // (round 5: fut_dirty is looked at here too -- it arrives in the same scalar round trip.  Zeroing EVERY tile's accumulators on
         // every pending clear was 8.4 of the 14.1 MB this kernel wrote per launch at the metric's size, 3.46 x its algorithmic bytes,
         // VERDICT r4 -- most tiles of a map never see a moving particle)
-        int t_live, f_clear, f_dirty;
-        sload_i4(s.tile_live + BX, s.tile_moving + BX, &s.fpar->clear_fut, s.fut_dirty + BX, t_live, tflag_early, f_clear, f_dirty);   // one scalar round trip
+        int t_live, f_clear, f_dirty, tc;
+        sload_i5(s.tile_live + BX, s.tile_moving + BX, &s.fpar->clear_fut, s.fut_dirty + BX, tcls ? tcls + BX : s.tile_live + BX, t_live, tflag_early, f_clear, f_dirty, tc);   // one scalar round trip
+        if (tcls && !cls_mine(tc, cls)) return;   // the other branch's tile
         tflags = (t_live ? 1 : 0) | ((f_clear && f_dirty) ? 2 : 0);
-    }
+    } else if (tcls && !cls_mine(sload_i(tcls + BX), cls)) return;
     if (tflags & 2) {
         // clearOccupancyMapPrediction (:431-438) was requested since the last frame: this tile's share of the
         // future accumulators is zeroed here instead of by two extra memset launches per frame -- if anything was added to
@@ -627,12 +724,6 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
         }
     }
     // ---- tail 2: route the movers to the inbox of their destination tile
-    // (extra & 8, EARLY REGISTRATION: a mover whose new position lies in the field of view is registered in its pyramid HERE -- :1233-1259
-    // needs its position, weight and sweep key, all known now; only its slot is not, and the list entry points at the inbox record
-    // instead (k_place leaves the slot in KernelScratch::in_slot).  mapUpdate's list preparation and Ck pass then do not wait for the
-    // placement.  The reference registers a mover only if its voxel had room (:1227-1229 returns first): k_place revokes the entry
-    // of an arrival it finds no slot for.)
-    const bool early = (extra & 8) != 0;
     for (int i0 = 0; i0 < nmv; i0 += NW * 64 * TB) {
         int key[TB], pos[TB];
 #pragma unroll
@@ -642,36 +733,14 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
             if (i < nmv) key[j] = (__float_as_int(i < LSTG ? s_mv[i * 2].x : mv_rec[(mv_base + i) * 2].x) - d.v_base) >> 6;
         }
         batch_append<TB>(in_cnt, key, pos);
-        float4 ra[TB], rb[TB];
-        int pk[TB], pp2[TB];
 #pragma unroll
         for (int j = 0; j < TB; ++j) {
-            pk[j] = -1;
             // beyond the inbox: more arrivals than the tile has slots; k_place counts them as dropped
             if (key[j] < 0 || pos[j] >= cap) continue;
-            mv_get(i0 + j * NW * 64 + tid, ra[j], rb[j]);
+            float4 ra, rb;
+            mv_get(i0 + j * NW * 64 + tid, ra, rb);
             const size_t o = ((size_t)key[j] * cap + pos[j]) * 2;
-            in_rec[o] = ra[j]; in_rec[o + 1] = rb[j];
-            if (early) pk[j] = pyramid_of(d, s_ph, s_pv, ra[j].w, rb[j].x, rb[j].y);
-        }
-        if (early) {
-            batch_append<TB>(s.pyr_cnt, pk, pp2);
-#pragma unroll
-            for (int j = 0; j < TB; ++j) {
-                if (key[j] < 0 || pos[j] >= cap) continue;
-                const size_t ib = (size_t)key[j] * cap + pos[j];
-                int ref = -1;
-                if (pk[j] >= 0) {
-                    if (pp2[j] < d.capa) {
-                        const size_t o = (size_t)pk[j] * d.capa + pp2[j];
-                        s.fov_rec[o] = make_float4(ra[j].w, rb[j].x, rb[j].y, rb[j].z);
-                        s.fov_slot[o] = -2 - (int)ib;                 // "the cell k_place gives inbox record ib"
-                        s.fov_key[o] = __float_as_int(rb[j].w);      // a mover is registered when the sweep reaches its SOURCE cell
-                        ref = (int)o;
-                    } else ref = -3;                                  // the list is beyond CAPA: the particle vanishes (-2, :1256-1259); k_place counts it
-                }
-                in_ref[ib] = ref;
-            }
+            in_rec[o] = ra; in_rec[o + 1] = rb;
         }
     }
     // per-block statistics (reduced lazily by the host; no global atomics here)
@@ -724,36 +793,13 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
 #ifndef PLACE_SIDE_WG
 #define PLACE_SIDE_WG 3   // workgroups per CU of the side-stream placement
 #endif
-// EARLY REGISTRATION: an arrival that k_predict registered in pyramid b and that finds its voxel full is lost BEFORE the reference
-// would have registered it (:1227-1229 precede :1233): its terms are taken out of Ck again -- the same integers k_ck_partial adds
-// for its list entry (every term snapped to the 2^-34 grid; integer sums commute, so it does not matter which of the two comes
-// first) --, the weight update runs again once the placement has ended (launch_weight_update(redo)), and k_post skips the entry.
-// One thread, a few hundred pairs; rare (a voxel must be full).
-__device__ __forceinline__ void ck_revoke(const MapDims& d, const DevState& s, const FilterParams& fp, int b, float px, float py, float pz, float w) {
-    const int h0 = b / d.np_v, v0 = b % d.np_v;
-    const float pw = fp.p_det * w;
-    for (int i = -d.nn; i <= d.nn; ++i)
-        for (int j = -d.nn; j <= d.nn; ++j) {
-            const int h = h0 + i, v = v0 + j;
-            if (h < 0 || h >= d.np_h || v < 0 || v >= d.np_v) continue;
-            const int bin = h * d.np_v + v, n = s.obs_cnt[bin];
-            for (int k = 0; k < n; ++k) {
-                const float4 z = s.obs[bin * DSP_OBS_CAP + k];
-                const double t = ck_snap(pw * pair_gk(px, py, pz, z.x, z.y, z.z, fp.sigma_ob, fp.inv_sigma_ob, fp.pdf_c3));
-                const long long q = __double2ll_rn(t * CK_FIX_SCALE);
-                if (q) atomicAdd(reinterpret_cast<unsigned long long*>(&s.obs_ck[bin * DSP_OBS_CAP + k]), (unsigned long long)(-q));
-            }
-        }
-    atomicAdd(&s.fs->n_revoked, 1);
-    if (s.pyr_cnt[b] > d.capp) atomicAdd(&s.fs->n_overflow_inexact, 1);   // (it also took part in the cut of an overfull list)
-}
 #define PLACE_MAX 1024   // arrivals of one tile whose bucketed keys fit the LDS table; a tile that receives more (up to its
                          // capacity of 64 * slots records) keeps them in its own staging area of k_predict, which is dead by now
 template <int MW>
 __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, const float4* __restrict__ in_rec, int* __restrict__ in_cnt,
                                            const u64* __restrict__ omask,
                                            float4* __restrict__ stage, const int BX, const int n_all, const bool was_live, const bool t_moving_in,
-                                           const FilterParams& fp, const int* __restrict__ in_ref, int* __restrict__ in_slot) {   // n_all = in_cnt[BX] > 0; in_ref: early registration
+                                           const FilterParams& fp) {   // n_all = in_cnt[BX] > 0
     __shared__ float s_ph[DSP_MAX_PLANES_H * 3];
     __shared__ float s_pv[DSP_MAX_PLANES_V * 3];
     __shared__ u64 s_cur[MW * 64], s_org[MW * 64], s_new[MW * 64], s_own[MW * 64];
@@ -822,8 +868,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
     for (int i0 = 0; i0 < n; i0 += NT) {
         const int i = i0 + tid;
         int key[1] = {-1}, pos[1];
-        int ln = 0, nsl = -1, skey = 0, ref_in = -1;
-        const bool early = in_ref != nullptr;
+        int ln = 0, nsl = -1, skey = 0;
         size_t nidx = 0;
         float px = 0, py = 0, pz = 0, w = 0, avx = 0, avy = 0;
         if (i < n) {
@@ -831,7 +876,6 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
             const float4 b = i == tid ? b0 : in_rec[(base + i) * 2 + 1];
             px = a.w; py = b.x; pz = b.y; w = b.z; avx = a.y; avy = a.z;
             skey = __float_as_int(b.w);
-            if (early) ref_in = in_ref[base + i];
             ln = (__float_as_int(a.x) - d.v_base) & 63;
             // position of this arrival in the reference's service order of its destination voxel, in closed form:
             // the nF arrivals from lower voxel indices take, in key order, the first free slots of the occupancy
@@ -889,24 +933,19 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
                 nidx = pidx(d, BX * 64 + ln, nsl);
                 st_pos(s, nidx, px, py, pz);
                 // a static arrival in a tile of static particles finds (0, 0) in its cell already (tile_moving = 0 promises it)
-                if (avx != 0.f || avy != 0.f) { st_vel(s, nidx, avx, avy); s.tile_moving[BX] = 1; }   // (k_predict wrote the tile's flag before any arrival)
+                if (avx != 0.f || avy != 0.f) { st_vel(s, nidx, avx, avy); s.tile_moving[BX] = 1; if (d.v_loc != d.v_glob) note_speed(s, avx, avy); }   // (a slab: the arrival may come from another rank's map)   // (k_predict wrote the tile's flag before any arrival)
                 else if (t_moving) st_vel(s, nidx, 0.f, 0.f);
                 s.w[nidx] = w;
-                if (!early) key[0] = pyramid_of(d, s_ph, s_pv, px, py, pz);
+                key[0] = pyramid_of(d, s_ph, s_pv, px, py, pz);
             } else {
                 ++c_vf;
-                if (early && ref_in >= 0) ck_revoke(d, s, fp, ref_in / d.capa, px, py, pz, w);
             }
-            if (early) in_slot[base + i] = nsl >= 0 ? (int)nidx : -1;
         }
-        if (!early) batch_append<1>(s.pyr_cnt, key, pos);
+        batch_append<1>(s.pyr_cnt, key, pos);
         if (nsl >= 0) {
             bool keep = true;
             int ref = -1;
-            if (early) {
-                if (ref_in == -3) { ++c_pf; keep = false; }   // its pyramid's list was beyond CAPA when k_predict registered it: it vanishes (:1256-1259)
-                else ref = ref_in;
-            } else if (key[0] >= 0) {
+            if (key[0] >= 0) {
                 if (pos[0] < d.capa) {
                     const size_t o = (size_t)key[0] * d.capa + pos[0];
                     s.fov_rec[o] = make_float4(px, py, pz, w);
@@ -950,7 +989,8 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
                                                const u64* __restrict__ omask, FilterParams fp, float4* __restrict__ child,
                                                int* __restrict__ vb_cnt, int* __restrict__ vb_idx, int nchild, int t0, int n0, int t1, int n1,
                                                const int* __restrict__ tile_fov, int sel, float4* __restrict__ stage, int rev,
-                                               const int* __restrict__ view_list, const int* __restrict__ in_ref, int* __restrict__ in_slot) {
+                                               const int* __restrict__ view_list, const int* __restrict__ tcls, int cls) {
+    // tcls / cls (two-branch frame): only the tiles cls_mine() selects
     // whole frame: workgroups behind the tiles generate the frame's newborn children (k_birth_children's job; needs the
     // birth cloud and the rank only, both done before this launch)
     // (the first `nchild` workgroups: they run beside the tiles, not after them).
@@ -977,7 +1017,7 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
             int n_in, tf, t_live, t_mov;
             sload_i4(in_cnt + BX, tile_fov + BX, s.tile_live + BX, s.tile_moving + BX, n_in, tf, t_live, t_mov);
             if (n_in == 0) continue;
-            place_tile<MW>(d, s, in_rec, in_cnt, omask, stage, BX, n_in, t_live != 0, t_mov != 0, fp, in_ref, in_slot);
+            place_tile<MW>(d, s, in_rec, in_cnt, omask, stage, BX, n_in, t_live != 0, t_mov != 0, fp);
             __syncthreads();
         }
         return;
@@ -990,9 +1030,10 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
         // what a sparse map's placement spent its time on -- 87 120 workgroups, 12 k with arrivals
         const int bqr = rev ? nt - 1 - bq0 : bq0;
         const int BX = bqr < n0 ? t0 + bqr : t1 + (bqr - n0);
-        if (sel >= 0) sload_i2(in_cnt + BX, tile_fov + BX, n_in, tf); else n_in = sload_i(in_cnt + BX);
+        if (sel >= 0) sload_i2(in_cnt + BX, tile_fov + BX, n_in, tf); else if (tcls) sload_i2(in_cnt + BX, tcls + BX, n_in, tf); else n_in = sload_i(in_cnt + BX);
         if (bq0 + stride >= nt && !(has_vz && BX == 0)) {
             if (n_in == 0) return;
+            if (tcls && !cls_mine(tf, cls)) return;
             if (sel >= 0 && (tf >> 1) == epoch && ((tf & 1) != 0) != (sel != 0)) return;
         }
     }
@@ -1001,8 +1042,9 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
         const int BX = bqr < n0 ? t0 + bqr : t1 + (bqr - n0);   // tile index
         if (has_vz && BX == 0 && sel != 0 && threadIdx.x == 0)   // k_predict drew 3 table values per ranked particle (:655-657)
             s.fs->v_cur = (int)(((long long)s.fs->v_cur + 3ll * (long long)s.fs->occupied_count) % tab_n);
-        if (bq != bq0) { if (sel >= 0) sload_i2(in_cnt + BX, tile_fov + BX, n_in, tf); else n_in = sload_i(in_cnt + BX); }
+        if (bq != bq0) { if (sel >= 0) sload_i2(in_cnt + BX, tile_fov + BX, n_in, tf); else if (tcls) sload_i2(in_cnt + BX, tcls + BX, n_in, tf); else n_in = sload_i(in_cnt + BX); }
         if (n_in == 0) continue;   // (no arrivals -- or the tile's owner is done with them)
+        if (tcls && !cls_mine(tf, cls)) continue;   // (sel < 0 with tcls: tf holds the tile's class)
         if (sel >= 0) {   // a split placement: the other launch owns the tiles of the other kind
             int fv = tf & 1;
             // k_predict skipped the tile (empty) and particles arrive in it: its view is tested here, by both launches alike
@@ -1011,7 +1053,7 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
         }
         int t_live, t_mov;
         sload_i2(s.tile_live + BX, s.tile_moving + BX, t_live, t_mov);
-        place_tile<MW>(d, s, in_rec, in_cnt, omask, stage, BX, n_in, t_live != 0, t_mov != 0, fp, in_ref, in_slot);   // (the owner's view of in_cnt is stable: only the owner resets it)
+        place_tile<MW>(d, s, in_rec, in_cnt, omask, stage, BX, n_in, t_live != 0, t_mov != 0, fp);   // (the owner's view of in_cnt is stable: only the owner resets it)
         __syncthreads();   // the tile's LDS tables are re-used by the next one
     }
 }
@@ -1034,7 +1076,7 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
 // --------------------------------------------------------------------------
 template <int MW, int RBK_>
 __global__ void __launch_bounds__(256, RBK_ >= 8 ? 3 : 5) k_resample(MapDims d, DevState s, int* __restrict__ part_live, int* __restrict__ vb_cnt,
-                                                  float4* __restrict__ ro_rec, int* __restrict__ ro_cnt, int rev) {
+                                                  float4* __restrict__ ro_rec, int* __restrict__ ro_cnt, int rev, const int* __restrict__ tcls, int cls) {
     extern __shared__ float s_dyn[];
     // (DSPMAP_P_ESTIMATOR_QUEUE) the frame's birth stage ended where this launch began: the next frame's estimator may have the rand() cursor
     // and the birth buffers
@@ -1047,8 +1089,9 @@ __global__ void __launch_bounds__(256, RBK_ >= 8 ? 3 : 5) k_resample(MapDims d, 
     const int wave_g = rev ? ((d.v_loc + 63) >> 6) - 1 - wq : wq;   // (tiles from the last one down: see k_predict)
     const int lv = wave_g * 64 + l;
     if (wave_g < 0 || wave_g * 64 >= d.v_loc) return;
-    int t_live, t_mov, t_unused;
-    sload_i3(s.tile_live + wave_g, s.tile_moving + wave_g, s.tile_live + wave_g, t_live, t_mov, t_unused);   // (one scalar round trip)
+    int t_live, t_mov, tc;
+    sload_i3(s.tile_live + wave_g, s.tile_moving + wave_g, tcls ? tcls + wave_g : s.tile_live + wave_g, t_live, t_mov, tc);   // (one scalar round trip)
+    if (tcls && !cls_mine(tc, cls)) return;   // (two-branch frame) the other branch's tile
     if (!t_live) return;   // empty since its last visit: result, buckets and lists are already zero
     if (!d.tile_skip) t_mov = 1;
     const bool inr = lv < d.v_loc;
@@ -1804,6 +1847,7 @@ __global__ void k_seed_uniform(MapDims d, DevState s, int per_voxel, float weigh
         vy = vmax * (2.f * (float)(h4 >> 8) * (1.f / 16777216.f) - 1.f);
     }
     st_vel(s, idx, vx, vy); s.w[idx] = weight;
+    note_speed(s, vx, vy);
 }
 
 // import sparse records {flag,vx,vy,vz,px,py,pz,w} at (global voxel, slot); slot < 0 = first free
@@ -1828,6 +1872,7 @@ __global__ void k_import(MapDims d, DevState s, int n, const int* __restrict__ v
     const float* r = rec + 8 * (size_t)i;
     const size_t idx = pidx(d, lv, sl);
     st_vel(s, idx, r[1], r[2]);
+    note_speed(s, r[1], r[2]);
     if (s.vz0) s.vz0[idx] = r[3];
     st_pos(s, idx, r[4], r[5], r[6]); s.w[idx] = r[7];
     if (r[0] > 10.f) atomicOr(&s.nbmask[(size_t)lv * d.mw + (sl >> 6)], 1ull << (sl & 63));
@@ -1924,6 +1969,7 @@ __global__ void k_add_random_place(MapDims d, DevState s, FilterParams fp, int n
     if (sl < 0) return;      // voxel full :1198-1200
     const size_t idx = pidx(d, r.lv, sl);
     st_pos(s, idx, r.px, r.py, r.pz); st_vel(s, idx, r.vx, r.vy); s.w[idx] = weight;
+    note_speed(s, r.vx, r.vy);
     if (s.vz0) s.vz0[idx] = r.vz;
     slot_of[i] = (r.lv << 7) | sl;
 }
@@ -2186,8 +2232,8 @@ __global__ void k_spin(long long ticks) {
 void launch_spin(const LaunchCtx& c, int us) {   // wall_clock64 ticks at 100 MHz
     if (us > 0) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c.stream, (long long)us * 100);
 }
-void launch_predict_only(const LaunchCtx& c, bool with_gather, bool with_rank) {
-    const int extra = (with_gather ? 1 : 0) | (with_rank ? 2 : 0) | (c.place_split ? 4 : 0) | (c.early_reg ? 8 : 0);   // 4: list the tiles with a view for the split placement; 8: register the movers in their pyramids
+void launch_predict_only(const LaunchCtx& c, bool with_gather, bool with_rank, int cls) {
+    const int extra = (with_gather ? 1 : 0) | (with_rank ? 2 : 0) | (c.place_split ? 4 : 0);   // 4: list the tiles with a view for the split placement
     const unsigned xb = (with_gather ? (c.d.np + 3) / 4 : 0) + (with_rank ? 1 : 0) + (c.place_split ? (c.k.ntiles + 255) / 256 : 0);
     const KernelScratch* k = &c.k;
     if (c.s.vz0) {   // constructor-seeded particles take their velocity noise in the reference's sweep order
@@ -2197,14 +2243,14 @@ void launch_predict_only(const LaunchCtx& c, bool with_gather, bool with_rank) {
         launch_scan_blocks(c, nblk);   // blk_cnt -> exclusive, total -> fs->occupied_count
     }
 #define PRED_LAUNCH(MWV, VZ, SP) hipLaunchKernelGGL((k_predict<MWV, 4, VZ, SP>), dim3(k->ntiles + xb), dim3(256), 0, c.stream, c.d, c.s, c.fp, VZ ? 1 : 0, \
-                                                k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask, extra, k->tile_fov, c.sweep_rev ? 1 : 0, k->view_list, k->in_ref)
+                                                k->part_predict, k->mv_rec, k->in_rec, k->in_cnt, k->expmask, k->work_list, k->vz_q, k->omask, extra, k->tile_fov, c.sweep_rev ? 1 : 0, k->view_list, cls ? k->tile_cls : nullptr, cls)
 #define PRED_LAUNCH2(MWV, VZ) do { if (c.sparse) PRED_LAUNCH(MWV, VZ, true); else PRED_LAUNCH(MWV, VZ, false); } while (0)
     if (c.d.mw == 1) { if (c.s.vz0) PRED_LAUNCH2(1, true); else PRED_LAUNCH2(1, false); }
     else { if (c.s.vz0) PRED_LAUNCH2(2, true); else PRED_LAUNCH2(2, false); }
 #undef PRED_LAUNCH2
 #undef PRED_LAUNCH
 }
-void launch_claim(const LaunchCtx& c, int n_birth_grid, int part, int tile_lo, int tile_hi, int sel) {   // n_birth_grid > 0: the children of that many source points ride along
+void launch_claim(const LaunchCtx& c, int n_birth_grid, int part, int tile_lo, int tile_hi, int sel, int cls) {   // n_birth_grid > 0: the children of that many source points ride along
     const unsigned xb = n_birth_grid > 0 ? (unsigned)(((long long)n_birth_grid * c.fp.nb_num + 255) / 256) : 0u;
     const int nt = c.k.ntiles;
     int t0 = 0, n0 = nt, t1 = nt, n1 = 0;                       // part 0: every tile
@@ -2218,17 +2264,15 @@ void launch_claim(const LaunchCtx& c, int n_birth_grid, int part, int tile_lo, i
     unsigned grid = (unsigned)(n0 + n1) + xb;
     if (sel == 0) grid = std::min(grid, (unsigned)(PLACE_SIDE_WG * c.n_cu));
     const int* vlist = (sel == 1 && c.place_split && part == 0) ? k->view_list : nullptr;   // (k_predict listed the tiles with a view)
-    const int* iref = c.early_reg ? k->in_ref : nullptr;                                    // (k_predict registered the movers in their pyramids)
-    if (c.early_reg) grid = std::min((unsigned)(n0 + n1), (unsigned)(PLACE_SIDE_WG * c.n_cu)) + xb;   // the whole placement runs beside the pair kernels
     if (vlist) grid = std::min((unsigned)(n0 + n1), (unsigned)(PLACE_LB * c.n_cu)) + xb;    // one round of workgroups walks the list
     // a large sparse map: a tile receives a handful of arrivals and the launch is as long as (tiles with arrivals / resident workgroups) x
     // one tile's chain of round trips: two-wave workgroups there (264x264x80 filled by the depth stream: frame 0.435 -> 0.420 ms, two
     // alternating pairs of runs; one wave: no better; 132x132x60: +2 % with either, so only from 32 768 tiles on; the children riding
     // along need 256 threads)
     static const int sparse_threads = getenv("DSPMAP_PLACE_THREADS_SPARSE") ? atoi(getenv("DSPMAP_PLACE_THREADS_SPARSE")) : 128;
-    const unsigned nthr = (c.sparse && xb == 0 && !c.early_reg && c.k.ntiles >= 32768) ? (unsigned)sparse_threads : 256u;
-    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(grid), dim3(nthr), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec, c.sweep_rev ? 0 : 1, vlist, iref, k->in_slot);
-    else hipLaunchKernelGGL(k_place<2>, dim3(grid), dim3(nthr), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec, c.sweep_rev ? 0 : 1, vlist, iref, k->in_slot);
+    const unsigned nthr = (c.sparse && xb == 0 && c.k.ntiles >= 32768) ? (unsigned)sparse_threads : 256u;
+    if (c.d.mw == 1) hipLaunchKernelGGL(k_place<1>, dim3(grid), dim3(nthr), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec, c.sweep_rev ? 0 : 1, vlist, cls ? k->tile_cls : nullptr, cls);
+    else hipLaunchKernelGGL(k_place<2>, dim3(grid), dim3(nthr), 0, c.stream, c.d, c.s, k->in_rec, k->in_cnt, c.s.vz0 ? 1 : 0, c.fp.tab_n, k->omask, c.fp, k->child, k->vb_cnt, k->vb_idx, (int)xb, t0, n0, t1, n1, k->tile_fov, sel, k->mv_rec, c.sweep_rev ? 0 : 1, vlist, cls ? k->tile_cls : nullptr, cls);
 }
 void launch_predict(const LaunchCtx& c, bool with_gather) {
     launch_predict_only(c, with_gather, false);
@@ -2248,7 +2292,7 @@ int resample_variant(const LaunchCtx& c) {
 void kernels_init_device() {   // per device, once (dspmap_init_device)
     (void)hipFuncSetAttribute((const void*)k_rollout<RO_TPB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RO_LDS_CELLS * 4);
 }
-void launch_resample(const LaunchCtx& c) {
+void launch_resample(const LaunchCtx& c, int cls, bool with_rollout) {
     const KernelScratch* k = &c.k;
     const int nw = 1;   // waves (= tiles) per workgroup (2 / 4 measured in round 4: -3 % on the realistic 264x264x80 fill, +2 % at saturation)
     const size_t lds = (size_t)nw * ((64 * c.d.M + 1) / 2) * sizeof(float);   // the copy notes; the weights are re-read (no LDS panel)
@@ -2266,11 +2310,16 @@ void launch_resample(const LaunchCtx& c) {
         // then k_rollout's LDS windows are worth their launch (66x66x40 saturated, every particle moving: 0.11 vs 0.27 ms)
         hipLaunchKernelGGL(k_resample_wg, dim3(k->ntiles), dim3(256), lds4, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, ro == 0 ? 1 : 0);
     } else {
-#define RS_LAUNCH(MWV, RB) hipLaunchKernelGGL((k_resample<MWV, RB>), dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, c.resample_rev ? 1 : 0)
+#define RS_LAUNCH(MWV, RB) hipLaunchKernelGGL((k_resample<MWV, RB>), dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, c.resample_rev ? 1 : 0, cls ? k->tile_cls : nullptr, cls)
         if (c.d.mw == 1) { if (c.sparse) RS_LAUNCH(1, 8); else RS_LAUNCH(1, 4); }
         else { if (c.sparse) RS_LAUNCH(2, 8); else RS_LAUNCH(2, 4); }
 #undef RS_LAUNCH
     }
+    if (with_rollout) launch_rollout(c);
+}
+void launch_rollout(const LaunchCtx& c) {
+    const KernelScratch* k = &c.k;
+    const int ro = resample_variant(c) >> 1;
     if (ro == 1 || ro == 2) {
         // windows: the rows a particle reaches at a design speed (1.5 m/s, a brisk pedestrian), lowered until all T windows fit the LDS
         RolloutPlan pl;

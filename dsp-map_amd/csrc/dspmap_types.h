@@ -105,11 +105,11 @@ struct FrameScalars {
     int view_epoch, stale_n;
     int n_birth_ovf;    // entries of DevState::birth_ovf (reset by the birth rank, which precedes every generation of children)
     int est_n;          // length of the birth cloud the device velocity estimator wrote (kept when a view is empty, :1379)
-    int n_ta;           // entries of KernelScratch::ta_list (early registration: the list entries k_pyr_prepare turned away this frame)
-    int n_revoked;      // early registration: arrivals that k_predict registered in a pyramid and that then found their voxel full (k_place takes
-                        // their terms out of Ck again and the weight update is repeated, launch_weight_update(redo))
     int n_view_tiles;   // entries of KernelScratch::view_list: the tiles whose box can intersect the field of view this frame (k_predict's extra
                         // workgroups of a split placement; reset with the pyramid lists)
+    int vmax_bits;      // float bits of the largest |vx|, |vy| any particle of the map was ever given (births, imports, seeds, first-prediction
+                        // noise; note_speed in dspmap_device.h; reset with the state): bounds how far a prediction can carry a particle --
+                        // k_tile_class sizes the halo of the two-branch frame with it.  Monotone, conservative, never a result
     int pred_epoch;     // bumped by whatever resets the pyramid lists for a prediction (k_reset / k_obs_points): k_place stamps the tiles it
                         // served with it, k_place_fix only trusts a tile's inbox / pmask when the stamp is this prediction's
 };
@@ -131,6 +131,8 @@ struct FrameParams {
     int from_ring;      // 1: this block came through the pinned parameter ring
     unsigned ring_pos;  // its position in the ring: k_predict moves the ring's read position from ring_pos to ring_pos + 1 (once,
                         // whatever else replays a stale block afterwards)
+    float birth_reach;  // the largest |value| of the position table (:871-873 adds three of them to a source point): how far from its
+                        // observation a newborn can land (k_tile_class)
     const float* pts;   // n_pts x 3, sensor frame
     struct BirthSrc* birth;
 };

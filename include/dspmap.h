@@ -154,18 +154,21 @@ enum dspmap_param {
                                        slot of a pinned, device-mapped ring and the captured frame's first kernel reads it over the bus: the frame is
                                        ONE graph launch (needs DSPMAP_P_USE_GRAPH and the device velocity estimator); 0 = pinned staging + one H2D
                                        copy + an event in front of the graph (rounds 1-4).  Same result either way */
-    DSPMAP_P_EARLY_REGISTER = 24,   /* whole frames (dspmap_update / dspmap_update_device): the prediction sweep itself registers the particles that change
-                                       voxel in their pyramids (:1233-1259 -- their new position is known there), so that mapUpdate's list preparation
-                                       and Ck pass run BESIDE the placement of those particles (:1209-1230) instead of after it, and the weights reach
-                                       the cells once both have ended.  1 = on; 0 / -1 (default) = off: the same result slot for slot (tested), but measured
-                                       slower on the saturated maps it was built for (the placement is bound by DRAM row activations and the list
-                                       preparation stretches 10 x beside it; DESIGN.md / LOG.md round 5).  DSPMAP_EARLY_REGISTER sets new handles' default */
+    /* 24: early registration of the voxel-changing particles by the prediction sweep (round 5) -- measured slower on the maps it was
+       built for and removed in round 6 (LOG.md); the value is not reused */
     DSPMAP_P_ESTIMATOR_QUEUE = 25,  /* captured frames with the device velocity estimator (DSPMAP_P_VELOCITY_ESTIMATOR = 2) on maps that do not split their
                                        placement: 1 (default) = the estimator's kernels are launched on a hardware queue of their own and meet the
                                        frame through two words in device memory (the prediction's first workgroup says "the binned view is complete",
                                        the frame's first birth kernel waits for "the birth cloud is complete") -- the reference's helper thread
                                        (:297,311) without a fork / join inside the graph, which costs ~8 us of a 147-us frame on this runtime
                                        (tools/micro/fork_join.hip); 0 = a forked branch of the captured graph (rounds 2-5).  Same result either way */
+    DSPMAP_P_FRAME_BRANCHES = 26,   /* whole frames of dense large maps run as TWO BRANCHES (round 6): the part of the map the sensor can see this frame -- grown by
+                                       the reach of a newborn (:871-873) and by the frame's largest displacement (:665-667) -- goes through prediction,
+                                       placement, mapUpdate, births and resampling on the main stream, the rest of the map (most of it: prediction,
+                                       placement, resampling only -- the bandwidth-bound sweeps) beside it on a forked branch.  -1 (default) = the maps that
+                                       would split their placement (DSPMAP_P_PLACE_SPLIT_TILES), 0 = never (the serial frame of rounds 1-5), 1 = whenever
+                                       the frame allows it (any size; what the differential tests force).  Same result slot for slot.  The environment
+                                       variable DSPMAP_FRAME_BRANCHES presets it */
     DSPMAP_P_PAIR_CULL_SIGMAS = 13  /* mapUpdate evaluates a (particle, observation) pair only if their ranges differ by at most this many
                                        sigma_ob (default 9: the dropped terms are < 1e-19 and zero on the fixed-point Ck grid);
                                        a huge value evaluates every pair of the neighbourhood like the reference's loops */
@@ -285,6 +288,10 @@ int dspmap_debug_rollout_paths(dspmap_t* m, long long out[3]);
  * out[3] = nonzero if a cross-queue wait ever gave up, out[4] = frames whose first birth kernel found the birth cloud unfinished (its workgroup 0
  * waited, the other workgroups left their shares to it), out[5] = shares it did for them */
 int dspmap_debug_estimator_queue(dspmap_t* m, long long out[6]);
+/* diagnostics of DSPMAP_P_FRAME_BRANCHES: out[0] = frames of this handle that ran as two branches, out[1] / out[2] = tiles of class Q (a newborn of
+ * the last such frame could land there) / P (a particle could reach a Q tile), out[3] = tiles of the map, out[4] = the largest speed any particle
+ * of the map was ever given, mm/s (what sizes P) */
+int dspmap_debug_frame_branches(dspmap_t* m, long long out[5]);
 /* test hooks of dspmap_mgpu_comm_init_from_env's rendezvous file (no device, no RCCL): what rank 0 publishes / what a rank != 0
  * waits for (this launch's nonce: DSPMAP_RDZV_NONCE or TORCHELASTIC_RUN_ID + the parent's pid).  1 = written / found, 0 = not */
 int dspmap_debug_rdzv_publish(const char* path, const char id[128]);

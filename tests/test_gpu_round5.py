@@ -1,8 +1,7 @@
 """GPU parity tests added in round 5 (run with `-m gpu`): unpredicted (flag 15) particles with a velocity inside tiles of static
 particles keep it (k_predict's static-tile shortcut); the host-pointer update() that reads the caller's cloud from
 the pinned ring is the device-resident update(); checkpoint format 1 is still read; the trajectory envelope of the two oracle
-builds; sharded maps resting / stepping vertically with unequal slabs; identical maps keep identical future status; early
-registration changes nothing; the velocity estimator on a stream of its own (DSPMAP_P_ESTIMATOR_QUEUE: six maps -- switch on / off /
+builds; sharded maps resting / stepping vertically with unequal slabs; identical maps keep identical future status; the velocity estimator on a stream of its own (DSPMAP_P_ESTIMATOR_QUEUE: six maps -- switch on / off /
 flipping, a caller-owned stream, plain launches instead of a graph replay, the estimator held back) changes nothing."""
 import numpy as np
 import pytest
@@ -329,113 +328,6 @@ def _equal_maps(a, b, f):
     for k in ("n_live_in", "n_moved", "n_out_of_map", "n_voxel_full", "n_pyramid_full", "n_born", "n_live_out", "n_reslotted"):
         assert ca[k] == cb[k], (f, k, ca[k], cb[k])
     return sa, ca
-
-
-@pytest.mark.parametrize("case", ["saturated_step", "nearly_full_voxels", "depth_stream_estimator", "two_words_overfull_lists"])
-def test_early_registration_changes_nothing(dsp, case):
-    """DSPMAP_P_EARLY_REGISTER (round 5): in whole frames of dense large maps the prediction sweep registers the voxel-changing
-    particles in their pyramids itself (:1233-1259 -- position, weight and sweep key are known there), the placement (:1209-1230) runs on
-    the side stream BESIDE list preparation, Ck pass and weight update, the new weights stay with the list entries until k_post hands
-    them to the cells, the entries a full list turns away are noted and lose their bit behind the join (k_post, then k_place_fix), and an
-    arrival that finds its voxel full after it was registered is revoked (its terms leave Ck again, the weight update is repeated).
-    Forced on for maps small enough to test, against the same map with the placement in front of the pair kernels, frame by frame:
-    every slot, every float, results, future status and counters equal --
-      saturated_step      every particle changes voxel every frame (24 arrivals per voxel, in and out of view), lists beyond CAPP
-      nearly_full_voxels  voxels with 44 of 48 slots taken receive 10 arrivals each: hundreds of arrivals IN VIEW find their voxel full and are revoked
-                          (the sensor looks straight up: short pyramids, no list overflows -- lists beyond CAPA = 2 CAPP + 64 drop entries
-                          in arrival order, the one documented place where two runs of ANY mode differ)
-      depth_stream_estimator  the metric's stream with the estimator's branch on the same side stream
-      two_words_overfull_lists  72 slots (two occupancy words), every list beyond CAPP: turned-away arrivals hand their slots back."""
-    scene_mod = __import__("dsp-map_amd.scene", fromlist=["CorridorScene"])
-    UP = (0.70710678, 0.0, -0.70710678, 0.0)
-    quat = (1.0, 0.0, 0.0, 0.0)
-    if case == "two_words_overfull_lists":
-        cfg = dict(nx=48, ny=48, nz=16, res=0.10, ppv=36)
-    elif case == "nearly_full_voxels":
-        cfg = dict(nx=64, ny=48, nz=12, res=0.15, ppv=24)
-        quat = UP
-    else:
-        cfg = dict(nx=66, ny=66, nz=40, res=0.15, ppv=24)
-    maps = []
-    for early in (1, 0):
-        m = dsp.DSPMap(dsp.make_config(seed=1234, **cfg))
-        m.L.dspmap_init_device(m.h)
-        m.set_param(dsp.capi.P_EARLY_REGISTER, early)
-        assert m.get_param(dsp.capi.P_EARLY_REGISTER) == early
-        if case == "depth_stream_estimator":
-            m.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, 2)
-        maps.append(m)
-    res = cfg["res"]
-    if case == "depth_stream_estimator":
-        sc = scene_mod.CorridorScene(66 * 0.15, 66 * 0.15, 40 * 0.15, seed=1234, device="cuda")
-        frames = [sc.frame(f / 30.0) for f in range(90)]
-        every = 15
-    else:
-        per = {"saturated_step": 24, "nearly_full_voxels": 44, "two_words_overfull_lists": 24}[case]
-        for m in maps:
-            if case != "nearly_full_voxels":   # (that case starts empty: its state is written after the first frame)
-                m.seed_uniform(per, 0.01, 99)
-        if case == "nearly_full_voxels":
-            yy, zz = np.meshgrid(np.linspace(-0.5, 0.5, 41), np.linspace(-0.3, 0.3, 25))
-            pts = np.stack([np.full(yy.size, 0.45) + 0.02 * np.sin(7 * yy.ravel()), yy.ravel(), zz.ravel()], 1).astype(np.float32)   # a patch above the sensor
-            pts = torch.from_numpy(pts).cuda()
-        else:
-            small = cfg["nx"] != 66
-            pts = torch.from_numpy(common.wall_cloud(5, n_side=50, dist=1.6 if small else 2.4, half_w=1.2 if small else 2.0,
-                                                     half_h=0.5 if small else 1.0)).cuda()
-        # the sensor advances a whole voxel per frame along x (and a third of one along z): every particle changes voxel
-        frames = [(pts, (res * f, 0.0, 0.34 * res * f), quat) for f in range(6)]
-        if case == "nearly_full_voxels":
-            frames = [(pts, (0.0, 0.0, 0.0), quat) for f in range(4)]   # the sensor rests; the state below arrives after the first frame
-        every = 1
-    torch.cuda.synchronize()
-    tot = dict(n_voxel_full=0, n_pyramid_full=0, n_moved=0, n_reslotted=0, n_fov=0)
-    for f, (pts, pos, q) in enumerate(frames):
-        if case == "nearly_full_voxels" and f == 1:
-            # (a voxel ends every frame with at most M = 24 particles, :992-997, and a map's first frame has dt = 0: nearly full voxels
-            # that receive arrivals only exist if the state is written between two frames)  A block of voxels above the sensor (in view,
-            # it looks straight up) holds 36 static particles each and 10 that move into the next voxel in x within this frame's dt:
-            # they come from a LOWER voxel index, the destination's own particles -- its 10 leavers too -- still hold their slots
-            # (:1214-1215): 2 fit, 8 find the voxel full -- after k_predict has registered all 10 in their pyramid
-            rng = np.random.default_rng(3)
-            nx, ny, nz = cfg["nx"], cfg["ny"], cfg["nz"]
-            hx, hy, hz = (np.float32(res) * np.float32(n) * np.float32(0.5) for n in (nx, ny, nz))
-            xs, ys, zs = np.meshgrid(np.arange(nx // 2 - 6, nx // 2 + 6), np.arange(ny // 2 - 6, ny // 2 + 6), np.arange(nz // 2 + 2, nz // 2 + 5), indexing="ij")
-            vox = (zs * ny * nx + ys * nx + xs).ravel()
-            def cloud(vx_idx, n_per, vel):
-                v = np.repeat(vx_idx, n_per)
-                zi, yi, xi = v // (ny * nx), (v // nx) % ny, v % nx
-                u = rng.uniform(0.2, 0.8, (len(v), 3))
-                px = (xi + u[:, 0]) * res - hx; py = (yi + u[:, 1]) * res - hy; pz = (zi + u[:, 2]) * res - hz
-                rec = np.zeros((len(v), 8), np.float32)
-                rec[:, 0] = 1.0; rec[:, 1] = vel; rec[:, 4] = px; rec[:, 5] = py; rec[:, 6] = pz; rec[:, 7] = 0.02
-                return v.astype(np.int32), rec
-            dt = 1.0 / 30.0
-            v1, r1 = cloud(vox, 36, 0.0)
-            v2, r2 = cloud(vox, 10, np.float32(res / dt))            # a voxel per frame towards +x: into the block's next voxel
-            vv, rr = np.concatenate([v1, v2]), np.concatenate([r1, r2])
-            sl = np.concatenate([np.tile(np.arange(36), len(vox)), np.tile(np.arange(36, 46), len(vox))]).astype(np.int32)   # explicit slots: the same state in both maps
-            for m in maps:
-                m.import_state(vv, rr, sl)
-        for m in maps:
-            npts = 0 if (case == "nearly_full_voxels" and f == 0) else pts.shape[0]   # (that case: no births before its state is written)
-            assert m.update_device(pts.data_ptr(), npts, pos, f / 30.0, q) == 1
-        if f % every == every - 1:
-            sa, ca = _equal_maps(maps[0], maps[1], f)
-            for k in tot:
-                tot[k] += ca[k]
-        for m in maps:
-            m.clearOccupancyMapPrediction()
-    print(case, tot)
-    assert tot["n_moved"] > 2000, tot
-    if case == "saturated_step":
-        assert tot["n_moved"] > 5 * 4000000 * 0.5 and tot["n_pyramid_full"] > 1000, tot
-    if case == "nearly_full_voxels":
-        assert tot["n_voxel_full"] > 200 and tot["n_pyramid_full"] == 0 and tot["n_fov"] > 1000, tot
-    if case == "two_words_overfull_lists":
-        assert maps[0].slots == 72 and tot["n_pyramid_full"] > 1000 and tot["n_reslotted"] > 0, tot
-    for m in maps:
-        m.close()
 
 
 @pytest.mark.parametrize("delay_us", [0, 2000])
