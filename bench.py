@@ -758,14 +758,20 @@ def main():
             if sharded_run:
                 m.close()
             we = WORKLOADS["E_sat"]
-            me, fre, dte, ce, ste = measure(we, 12, 2, 3, profile=False, solo=True)
+            # the origin of an N-rank run times THE SAME FRAMES FROM THE SAME STATE as the ranks did (same prefill, warmup and steps as
+            # measure_sharded: the saturated fill erodes from frame to frame, and round 5's origin -- 12 frames after 5 against `steps`
+            # frames after 5 + warmup -- showed a "speedup" of 1.305 at world 1); the stand-alone block of the N = 1 line keeps
+            # its short run
+            o_steps, o_warm, o_pre = (args.steps, args.warmup, 5) if sharded_run else (12, 2, 3)
+            me, fre, dte, ce, ste = measure(we, o_steps, o_warm, o_pre, profile=False, solo=True)
             be = b_alg(ce, me.V_local, me.T)
-            mse = dte / 12 * 1e3
+            mse = dte / o_steps * 1e3
             result["single_gpu_264x264x80"] = {
                 "workload": "E_sat unsharded on one GPU (the N = 1 point of the Z-slab strong-scaling series that "
                             "bench.py --gpus N > 1 reports)",
-                "frames_per_s": round(12 / dte, 2), "ms_per_step": round(mse, 4), "b_alg_bytes": int(be),
-                "frac_of_8TBps": round(be / (mse * 1e-3) / 1e9 / peak, 5)}
+                "frames_per_s": round(o_steps / dte, 2), "ms_per_step": round(mse, 4), "b_alg_bytes": int(be),
+                "frac_of_8TBps": round(be / (mse * 1e-3) / 1e9 / peak, 5),
+                "frames": {"prefill": o_pre, "warmup": o_warm, "steps": o_steps}, "n_live_in": int(ce["n_live_in"])}
             me.close()
             del fre
             if sharded_run and wl_name == "E_sat":
@@ -773,8 +779,10 @@ def main():
                 # point is the unsharded map measured above in this same run -- NOT the default N = 1 bench line, which
                 # runs the metric's own 66x66x40 workload.
                 result["strong_scaling_264x264x80"] = {
-                    "n_gpus": world, "frames_per_s": round(fps, 2), "one_gpu_frames_per_s": round(12 / dte, 2),
-                    "speedup_vs_one_gpu": round(fps / (12 / dte), 3),
+                    "n_gpus": world, "frames_per_s": round(fps, 2), "one_gpu_frames_per_s": round(o_steps / dte, 2),
+                    "speedup_vs_one_gpu": round(fps / (o_steps / dte), 3),
+                    "n_live_in": {"sharded_all_ranks": int(cnt["n_live_in"]), "one_gpu": int(ce["n_live_in"])},
+                    "same_frames": "both runs: 5 prefill + %d warmup frames untimed, then %d timed frames of the same stream from the same saturated fill" % (args.warmup, args.steps),
                     "note": "compare value with one_gpu_frames_per_s (same workload, same box), not with the N = 1 bench "
                             "line (workload B, 66x66x40)"}
         except Exception as e:

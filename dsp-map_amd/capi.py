@@ -20,7 +20,7 @@ OK, REJECTED = 1, 0
 P_POSITION_STDDEV, P_VELOCITY_STDDEV, P_OBSERVATION_STDDEV, P_NEWBORN_WEIGHT, P_NEWBORN_NUMBER, \
     P_VOXEL_FILTER_RES, P_KAPPA, P_DETECTION, P_VELOCITY_ESTIMATOR, P_REGENERATE_TABLES, P_USE_GRAPH, P_OCCLUSION_MARGIN, \
     P_PAIR_CULL_SIGMAS, P_UPDATE_TIME, P_UPDATE_COUNTER, P_PLACE_SPLIT_TILES, P_FAST_DIVISION, P_SPARSE_SWEEP, P_ROLLOUT_INLINE, \
-    P_RESAMPLE_WG_TILES, P_SWEEP_ALTERNATE, P_STATIC_TILE_SKIP, P_HOST_CLOUD_DIRECT, _P_REMOVED_24, P_ESTIMATOR_QUEUE, P_FRAME_BRANCHES = range(1, 27)
+    P_RESAMPLE_WG_TILES, P_SWEEP_ALTERNATE, P_STATIC_TILE_SKIP, P_HOST_CLOUD_DIRECT, _P_REMOVED_24, P_ESTIMATOR_QUEUE, P_FRAME_BRANCHES, P_TILING = range(1, 28)
 
 
 class Config(C.Structure):
@@ -100,6 +100,8 @@ SIGNATURES = {
     "dspmap_debug_rollout_paths": (_i, [_P, C.POINTER(C.c_longlong)]),
     "dspmap_debug_estimator_queue": (_i, [_P, C.POINTER(C.c_longlong)]),
     "dspmap_debug_frame_branches": (_i, [_P, C.POINTER(C.c_longlong)]),
+    "dspmap_debug_tile_count": (_i, [_P]),
+    "dspmap_debug_tile_of_voxels": (_i, [_P, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dspmap_debug_tile_moving": (_i, [_P, C.POINTER(C.c_int), _i]),
     "dspmap_debug_rdzv_publish": (_i, [C.c_char_p, C.c_char_p]),
     "dspmap_debug_rdzv_wait": (_i, [C.c_char_p, _i, C.c_char_p]),
@@ -273,10 +275,21 @@ class DSPMap:
         self._chk(self.L.dspmap_debug_frame_branches(self.h, out))
         return tuple(int(v) for v in out)
 
+    def tile_count(self):
+        return self.L.dspmap_debug_tile_count(self.h)
+
+    def tile_of(self, voxels):
+        """the 64-voxel tile each of the given GLOBAL voxel indices lives in (runs of 64 indices or 4x4x4 cubes: DSPMAP_P_TILING)"""
+        import numpy as np
+        v = np.ascontiguousarray(voxels, np.int32)
+        out = np.zeros(v.size, np.int32)
+        self._chk(self.L.dspmap_debug_tile_of_voxels(self.h, v.size, v.ctypes.data_as(C.POINTER(C.c_int)), out.ctypes.data_as(C.POINTER(C.c_int))))
+        return out
+
     def tile_moving(self):
         """per 64-voxel tile: 0 = all of its live particles are static (its velocity rows are not fetched by the sweeps)"""
         import numpy as np
-        n = (self.V + 63) // 64
+        n = self.tile_count()
         out = np.zeros(n, np.int32)
         r = self.L.dspmap_debug_tile_moving(self.h, out.ctypes.data_as(C.POINTER(C.c_int)), n)
         if r < 0:
@@ -384,7 +397,7 @@ class DSPMap:
         return ok, idx.value
 
     def debug_tile_fov(self):
-        n = (self.V_local + 63) // 64
+        n = self.tile_count()
         out = np.zeros(n, np.int32)
         got = self.L.dspmap_debug_tile_view(self.h, out.ctypes.data_as(C.POINTER(C.c_int)), n)
         if got < 0:

@@ -99,8 +99,16 @@ static void derive_dims(dspmap* m) {
     d.nx = c.nx; d.ny = c.ny; d.nz = c.nz;
     d.z_lo = c.z_lo; d.z_hi = c.z_hi;
     if (d.z_lo == 0 && d.z_hi == 0) d.z_hi = c.nz;
-    d.v_loc = c.nx * c.ny * (d.z_hi - d.z_lo);
+    d.v_true = c.nx * c.ny * (d.z_hi - d.z_lo);
     d.v_base = d.z_lo * c.nx * c.ny;
+    // storage order (MapDims::tiling): cubes of 4 x 4 x 4 voxels on unsharded maps large enough for the two-branch frame (the maps that split
+    // their placement), runs of 64 voxel indices otherwise -- DSPMAP_P_TILING / DSPMAP_TILING force either (before the device is initialised)
+    const bool whole = d.z_lo == 0 && d.z_hi == c.nz;
+    const long long needle_tiles = ((long long)d.v_true + 63) / 64;
+    d.tiling = m->tiling_req >= 0 ? (m->tiling_req != 0 ? 1 : 0) : ((whole && needle_tiles >= m->place_split_tiles && m->place_split_tiles > 1) ? 1 : 0);
+    d.ncx = (c.nx + 3) / 4; d.ncy = (c.ny + 3) / 4; d.ncz = (d.z_hi - d.z_lo + 3) / 4;
+    if (d.tiling && (double)d.ncx * d.ncy * d.ncz * 64.0 * ((c.safe_particle_factor > 0 ? c.safe_particle_factor : 2) * c.max_particle_num_voxel) >= 2147483648.0) d.tiling = 0;   // (cell indices are 31-bit, padding included)
+    d.v_loc = d.tiling ? d.ncx * d.ncy * d.ncz * 64 : d.v_true;
     d.v_glob = c.nx * c.ny * c.nz;                                     // :62
     d.M = c.max_particle_num_voxel;
     d.slots = (c.safe_particle_factor > 0 ? c.safe_particle_factor : 2) * d.M;   // :65 (x2); dsp_static.h:63 uses x5
@@ -124,6 +132,14 @@ static void derive_dims(dspmap* m) {
     d.half_z = (d.res * (float)c.nz) * 0.5f;
     for (int i = 0; i < d.T; ++i) d.pred_t[i] = c.prediction_future_time[i];
     d.rng_inv_bw = (float)PS_NBK / sqrtf(d.half_x * d.half_x + d.half_y * d.half_y + d.half_z * d.half_z);
+}
+
+int dspmap_need_index_order(dspmap* m) {
+    if (!m->d.tiling) return DSPMAP_OK;
+    if (m->device_ready) return dspmap_fail(m, DSPMAP_E_STATE, "the sharded frame needs index-order storage: set DSPMAP_P_TILING = 0 before the handle's first use");
+    m->tiling_req = 0;
+    derive_dims(m);
+    return DSPMAP_OK;
 }
 
 static void refresh_fp(dspmap* m) {
@@ -166,8 +182,10 @@ extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
     if (const char* e = getenv("DSPMAP_USE_GRAPH")) { m->use_graph = atoi(e) == 1; m->direct_ring = atoi(e) == 2; }
     if (const char* e = getenv("DSPMAP_ESTIMATOR_QUEUE")) m->est_queue = atoi(e) != 0;
     if (const char* e = getenv("DSPMAP_XQ_TEST_DELAY_US")) m->xq_test_delay_us = std::max(0, std::min(atoi(e), 100000));
+    if (const char* e = getenv("DSPMAP_TILING")) m->tiling_req = atoi(e) < 0 ? -1 : (atoi(e) != 0 ? 1 : 0);
     if (const char* e = getenv("DSPMAP_FRAME_BRANCHES")) m->frame_branches = atoi(e) < 0 ? -1 : (atoi(e) != 0 ? 1 : 0);
     if (const char* e = getenv("DSPMAP_RESAMPLE_WG_TILES")) { const long v = atol(e); if (v >= 0) m->resample_wg_tiles = (int)std::min(v, 2000000000l); }
+    derive_dims(m);   // (the storage order follows DSPMAP_TILING / DSPMAP_PLACE_SPLIT_TILES)
     return m;
 }
 
@@ -194,6 +212,7 @@ static void free_dev(dspmap* m) {
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.ro_cnt, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
                     s.tile_moving, m->k.ro_stat, m->k.part_predict, m->k.tile_fov, m->k.view_list, m->k.tile_cls, s.tile_live, s.fut_dirty, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf, s.birth_cvr};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
+    if (m->res_true) chk(hipFree(m->res_true), "hipFree");
     if (m->nbsnap_buf) chk(hipFree(m->nbsnap_buf), "hipFree");
     {
         void* vp[] = {m->ve.ng_view, m->ve.edges, m->ve.ecnt, m->ve.w, m->ve.root, m->ve.rank, m->ve.by_rank, m->ve.dyn_list, m->ve.cl, m->ve.last, m->ve.n,
@@ -239,6 +258,15 @@ extern "C" void dspmap_destroy(dspmap_t* m) {
 }
 
 extern "C" const char* dspmap_last_error(const dspmap_t* m) { return m ? m->err.c_str() : "null handle"; }
+
+// the slab's voxel t in the reference's index order -> storage (lv_of_true of dspmap_device.h on the host): checkpoints hold the
+// result grid and the accumulators in the reference's order, whatever order the map that wrote them stored them in
+static inline size_t host_lv_of_true(const MapDims& d, size_t t) {
+    if (!d.tiling) return t;
+    const size_t zc = (size_t)d.ny * d.nx;
+    const size_t zl = t / zc, rest = t - zl * zc, y = rest / d.nx, x = rest - y * d.nx;
+    return ((((zl >> 2) * d.ncy + (y >> 2)) * d.ncx + (x >> 2)) << 6) | ((zl & 3) << 4) | ((y & 3) << 2) | (x & 3);
+}
 
 template <typename T>
 static hipError_t dalloc(T** p, size_t n) {
@@ -340,7 +368,6 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     else HIPCHK(m, hipGetDevice(&m->device));
     if (!m->stream) { HIPCHK(m, hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
     HIPCHK(m, hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
-    HIPCHK(m, hipStreamCreateWithFlags(&m->stream4, hipStreamNonBlocking));
     for (hipEvent_t& e : m->ev_br) HIPCHK(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(m, hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     HIPCHK(m, hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
@@ -560,10 +587,18 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
         case DSPMAP_P_HOST_CLOUD_DIRECT: m->host_direct = v != 0; break;
         case DSPMAP_P_ESTIMATOR_QUEUE: m->est_queue = v != 0; break;   // (part of the captured frame's key)
         case DSPMAP_P_FRAME_BRANCHES: m->frame_branches = v < 0 ? -1 : (v != 0 ? 1 : 0); m->graph_epoch++; break;
+        case DSPMAP_P_TILING:
+            if (m->device_ready) return dspmap_fail(m, DSPMAP_E_STATE, "DSPMAP_P_TILING must be set before the device state is allocated");
+            m->tiling_req = v < 0 ? -1 : (v != 0 ? 1 : 0);
+            derive_dims(m);
+            break;
         case DSPMAP_P_SPARSE_SWEEP: m->sparse_force = v < 0 ? -1 : (v != 0 ? 1 : 0); break;
         case DSPMAP_P_ROLLOUT_INLINE: m->ro_force = v < 0 ? -1 : (v != 0 ? 1 : 0); break;
         case DSPMAP_P_FAST_DIVISION: if (v == 0) { m->d.div_ok = 0; m->div_forced_off = true; m->graph_epoch++; } break;
-        case DSPMAP_P_PLACE_SPLIT_TILES: m->place_split_tiles = v < 1 ? 1 : (v > 2e9 ? 2000000000 : (int)v); m->graph_epoch++; break;
+        case DSPMAP_P_PLACE_SPLIT_TILES:
+            m->place_split_tiles = v < 1 ? 1 : (v > 2e9 ? 2000000000 : (int)v); m->graph_epoch++;
+            if (!m->device_ready) derive_dims(m);   // (the storage order the handle picks by itself follows this limit)
+            break;
         case DSPMAP_P_RESAMPLE_WG_TILES: m->resample_wg_tiles = v < 0 ? 0 : (v > 2e9 ? 2000000000 : (int)v); m->graph_epoch++; break;
         case DSPMAP_P_SWEEP_ALTERNATE: m->sweep_alt = v < 0 ? -1 : (v >= 2 ? 2 : (v != 0 ? 1 : 0)); m->graph_epoch++; break;
         case DSPMAP_P_STATIC_TILE_SKIP: m->d.tile_skip = v != 0 ? 1 : 0; m->graph_epoch++; break;
@@ -606,6 +641,7 @@ extern "C" double dspmap_get_param(const dspmap_t* m, int key) {
         case DSPMAP_P_HOST_CLOUD_DIRECT: return m->host_direct ? 1 : 0;
         case DSPMAP_P_ESTIMATOR_QUEUE: return m->est_queue ? 1 : 0;
         case DSPMAP_P_FRAME_BRANCHES: return m->frame_branches;
+        case DSPMAP_P_TILING: return m->d.tiling;
         case DSPMAP_P_USE_GRAPH: return m->use_graph ? 1 : (m->direct_ring ? 2 : 0);
         default: return 0;
     }
@@ -739,11 +775,12 @@ static bool frame_splits_placement(const dspmap* m, const LaunchCtx& c, bool for
 // does this frame run as two branches (DSPMAP_P_FRAME_BRANCHES; KernelScratch::tile_cls)?  The same maps that split their placement -- dense and
 // large: the branches cost a classification launch and two passes of workgroups over the tiles --, unless forced; never a frame whose
 // prediction changes velocities (vz0: constructor-seeded particles draw their noise there, after the classes were sized), a profiled
-// frame (one stream), or a map that runs the four-waves-per-tile resampler (no class filter there: small maps)
+// frame (one stream), a map that runs the four-waves-per-tile resampler (no class filter there: small maps), or index-order storage
+// (MapDims::tiling == 0: a run of 64 voxel indices that points away from the sensor is cut by the field of view almost wherever it
+// lies -- 58 % of the 132x132x60 map's runs have a view: there is nothing to leave to a second branch)
 static bool frame_runs_two_branches(const dspmap* m, const LaunchCtx& c, bool fork) {
-    if (fork || m->prof || m->frame_branches == 0 || c.s.vz0 || !c.k.tile_cls) return false;
+    if (fork || m->prof || m->frame_branches == 0 || c.s.vz0 || !c.k.tile_cls || !c.d.tiling) return false;   // (cube storage: k_tile_class)
     if (resample_variant(c) & 1) return false;
-    if ((size_t)c.d.ny * (size_t)(c.d.z_hi - c.d.z_lo) > (size_t)480 * 1024) return false;   // (k_tile_class's two row bitmaps must fit the LDS)
     return m->frame_branches == 1 || frame_splits_placement(m, c, fork);
 }
 
@@ -765,6 +802,15 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
         // run beside each other.  Same kernels, same per-tile work, same result slot for slot (tests/test_gpu_round6.py).
         c.place_split = false;
         c.branches = true;
+        if (!m->stream4) {
+            // the bulk branch's stream, created at the first frame that needs it, with the LOWEST priority the device offers: its sweeps would
+            // otherwise keep every CU's wave slots and LDS filled and the in-view chain's kernels -- the frame's critical path -- would wait
+            // for them (list preparation 13 -> 73 us, weights 40 -> 71 us beside them, profiles/r06_b_C_sat_timeline.md)
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            static const bool flat = getenv("DSPMAP_BULK_PRIORITY_FLAT") != nullptr;
+            if (flat || hipStreamCreateWithPriority(&m->stream4, hipStreamNonBlocking, lo) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamCreateWithFlags(&m->stream4, hipStreamNonBlocking); }
+        }
         launch_setup_and_bin(c, pts_grid, false, m->frame_ring ? m->ring_dev : nullptr, DSPMAP_RING - 1);
         launch_tile_class(c);
         (void)hipEventRecord(m->ev_br[0], m->stream);
@@ -1179,7 +1225,12 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
             ++m->xq_frames;
             return DSPMAP_OK;
     };
-    if (m->use_graph && !m->prof) {
+    // A two-branch frame is queued as PLAIN launches on the handle's two streams, parameter block through the same pinned ring: replayed as
+    // one captured graph its branches did not overlap (the runtime put the bulk branch's prediction behind the in-view chain's birth
+    // kernels on one of its internal streams, profiles/r06_*_timeline*), and at this size (0.4 - 5 ms per frame) the ~0.1 ms of host time its
+    // fifteen launches take is hidden behind the device
+    const bool two = frame_runs_two_branches(m, c, false);
+    if (m->use_graph && !m->prof && !two) {
         // the kernel arguments of a frame are constant (per-frame values live in s.fpar): capture once, replay
         const unsigned long long key = ((unsigned long long)m->graph_epoch << 8) | (has_vz ? 1u : 0u) | ((unsigned)mode << 1) | (c.sparse ? 8u : 0u) | (c.ro_inline ? 16u : 0u) | (xq ? 32u : 0u);
         const int gi = c.sweep_rev ? 1 : 0;   // (one executable graph per sweep direction: the direction is a kernel argument)
@@ -1199,7 +1250,6 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
             m->graph_key[gi] = key;
         }
         m->last_resample_variant = resample_variant(c);   // (baked into the graph: c.ro_inline is part of its key)
-        if (frame_runs_two_branches(m, c, false)) ++m->branch_frames;
         rc = queue_estimator();
         if (rc != DSPMAP_OK) return rc;
         HIPCHK(m, hipGraphLaunch(m->graph_exec[gi], m->stream));
@@ -1389,7 +1439,7 @@ static int readout(dspmap* m, float thr, float* xyz, int cap, int* n_out, float*
     if (fut_out && d.T > 0) {
         dspmap_flush_future_clear(m);
         launch_future_combine(c);
-        HIPCHK(m, hipMemcpyAsync(fut_out, m->s.fut_out, sizeof(float) * (size_t)d.v_loc * d.T, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(m, hipMemcpyAsync(fut_out, m->s.fut_out, sizeof(float) * (size_t)d.v_true * d.T, hipMemcpyDeviceToHost, m->stream));
     }
     m->fut_clear_pending = true;  // :397-400, :420-424
     HIPCHK(m, hipStreamSynchronize(m->stream));
@@ -1412,11 +1462,23 @@ extern "C" int dspmap_clear_future(dspmap_t* m) {
 extern "C" int dspmap_get_results(dspmap_t* m, float* out) {
     READY(m);
     BENIGN(m);
-    HIPCHK(m, hipMemcpyAsync(out, m->s.res4, sizeof(float4) * (size_t)m->d.v_loc, hipMemcpyDeviceToHost, m->stream));
+    const float4* src = m->s.res4;
+    if (m->d.tiling) {   // cube storage: the caller's array is in the reference's voxel order
+        if (!m->res_true) HIPCHK(m, dalloc(&m->res_true, (size_t)m->d.v_true));
+        launch_results_true(dspmap_ctx_of(m), m->res_true);
+        src = m->res_true;
+    }
+    HIPCHK(m, hipMemcpyAsync(out, src, sizeof(float4) * (size_t)m->d.v_true, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
     return DSPMAP_OK;
 }
-extern "C" const float* dspmap_results_device(dspmap_t* m) { return (m && m->device_ready) ? (const float*)m->s.res4 : nullptr; }
+extern "C" const float* dspmap_results_device(dspmap_t* m) {
+    if (!m || !m->device_ready) return nullptr;
+    if (!m->d.tiling) return (const float*)m->s.res4;
+    if (!m->res_true && dalloc(&m->res_true, (size_t)m->d.v_true) != hipSuccess) return nullptr;
+    launch_results_true(dspmap_ctx_of(m), m->res_true);   // (stream-ordered like the future view below)
+    return (const float*)m->res_true;
+}
 extern "C" const float* dspmap_future_device(dspmap_t* m) {
     if (!m || !m->device_ready) return nullptr;
     dspmap_flush_future_clear(m);
@@ -1442,7 +1504,7 @@ extern "C" int dspmap_point_voxel_index(const dspmap_t* m, float px, float py, f
 }
 
 extern "C" int dspmap_voxel_num(const dspmap_t* m) { return m ? m->d.v_glob : 0; }
-extern "C" int dspmap_local_voxel_num(const dspmap_t* m) { return m ? m->d.v_loc : 0; }
+extern "C" int dspmap_local_voxel_num(const dspmap_t* m) { return m ? m->d.v_true : 0; }
 extern "C" int dspmap_local_voxel_base(const dspmap_t* m) { return m ? m->d.v_base : 0; }
 extern "C" int dspmap_slots_per_voxel(const dspmap_t* m) { return m ? m->d.slots : 0; }
 extern "C" int dspmap_pyramid_num(const dspmap_t* m) { return m ? m->d.np : 0; }
@@ -1757,6 +1819,21 @@ extern "C" int dspmap_debug_tile_view(dspmap_t* m, int* out, int cap) {
     for (int i = 0; i < m->k.ntiles; ++i) out[i] = (out[i] >> 1) == m->hp.epoch ? (out[i] & 1) : -1;   // -1: not visited by the last k_predict (empty)
     return m->k.ntiles;
 }
+extern "C" int dspmap_debug_tile_count(dspmap_t* m) {
+    READY(m);
+    BENIGN(m);
+    return m->k.ntiles;
+}
+extern "C" int dspmap_debug_tile_of_voxels(dspmap_t* m, int n, const int* voxel_global, int* tile_out) {
+    READY(m);
+    BENIGN(m);
+    if (n < 0 || (n > 0 && (!voxel_global || !tile_out))) return DSPMAP_E_ARG;
+    for (int i = 0; i < n; ++i) {
+        const long long t = (long long)voxel_global[i] - m->d.v_base;
+        tile_out[i] = (t >= 0 && t < m->d.v_true) ? (int)(host_lv_of_true(m->d, (size_t)t) >> 6) : -1;
+    }
+    return DSPMAP_OK;
+}
 extern "C" int dspmap_debug_tile_moving(dspmap_t* m, int* out, int cap) {
     READY(m);
     if (!out || cap < m->k.ntiles) return DSPMAP_E_ARG;
@@ -1889,14 +1966,25 @@ extern "C" int dspmap_save_checkpoint(dspmap_t* m, const char* path) {
     std::vector<float> rec((size_t)n * 8 + 8);
     rc = dspmap_export_state(m, n, voxel.data(), slot.data(), rec.data(), &n);
     if (rc != DSPMAP_OK) return rc;
-    const size_t V = (size_t)m->d.v_loc, T = (size_t)m->d.T;
+    const size_t V = (size_t)m->d.v_true, Vs = (size_t)m->d.v_loc, T = (size_t)m->d.T;
     // the future accumulators as they are: fixed-point sums of the moving particles [T][V] + the static particles' mass [V]
-    std::vector<float> res(V * 4), fstat(V);
-    std::vector<u64> fut(V * (T ? T : 1));
-    HIPCHK(m, hipMemcpyAsync(res.data(), m->s.res4, sizeof(float4) * V, hipMemcpyDeviceToHost, m->stream));
-    if (T) HIPCHK(m, hipMemcpyAsync(fut.data(), m->s.fut, sizeof(u64) * V * T, hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(m, hipMemcpyAsync(fstat.data(), m->s.fut_stat, sizeof(float) * V, hipMemcpyDeviceToHost, m->stream));
+    std::vector<float> res(Vs * 4), fstat(Vs);
+    std::vector<u64> fut(Vs * (T ? T : 1));
+    HIPCHK(m, hipMemcpyAsync(res.data(), m->s.res4, sizeof(float4) * Vs, hipMemcpyDeviceToHost, m->stream));
+    if (T) HIPCHK(m, hipMemcpyAsync(fut.data(), m->s.fut, sizeof(u64) * Vs * T, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(m, hipMemcpyAsync(fstat.data(), m->s.fut_stat, sizeof(float) * Vs, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (m->d.tiling) {   // cube storage -> the reference's voxel order
+        std::vector<float> res2(V * 4), fstat2(V);
+        std::vector<u64> fut2(V * (T ? T : 1));
+        for (size_t t = 0; t < V; ++t) {
+            const size_t lv = host_lv_of_true(m->d, t);
+            for (int q = 0; q < 4; ++q) res2[t * 4 + q] = res[lv * 4 + q];
+            fstat2[t] = fstat[lv];
+            for (size_t hh = 0; hh < T; ++hh) fut2[hh * V + t] = fut[hh * Vs + lv];
+        }
+        res.swap(res2); fstat.swap(fstat2); fut.swap(fut2);
+    }
     CkHeader h;
     memset(&h, 0, sizeof(h));
     memcpy(h.magic, "DSPMAPCK", 8);
@@ -1939,17 +2027,17 @@ extern "C" int dspmap_load_checkpoint(dspmap_t* m, const char* path) {
     bool same = a.nx == b.nx && a.ny == b.ny && a.nz == b.nz && a.voxel_resolution == b.voxel_resolution &&
                 a.angle_resolution == b.angle_resolution && a.max_particle_num_voxel == b.max_particle_num_voxel &&
                 a.half_fov_h == b.half_fov_h && a.half_fov_v == b.half_fov_v && a.prediction_times == b.prediction_times &&
-                a.z_lo == b.z_lo && a.z_hi == b.z_hi && h.v_loc == (long long)m->d.v_loc;
+                a.z_lo == b.z_lo && a.z_hi == b.z_hi && h.v_loc == (long long)m->d.v_true;
     for (int k = 0; same && k < a.prediction_times; k++) same = a.prediction_future_time[k] == b.prediction_future_time[k];
     same = same && a.pyramid_neighbor_n == b.pyramid_neighbor_n && a.safe_particle_factor == b.safe_particle_factor &&
            a.static_model == b.static_model;
     if (!same) { fclose(f); return dspmap_fail(m, DSPMAP_E_ARG, "checkpoint was written by a map with a different configuration"); }
     const int n = h.n_particles;
-    if (n < 0 || (long long)n > (long long)m->d.v_loc * m->d.slots) {
+    if (n < 0 || (long long)n > (long long)m->d.v_true * m->d.slots) {
         fclose(f);
-        return dspmap_fail(m, DSPMAP_E_ARG, "%s: particle count %d outside [0, %lld]", path, n, (long long)m->d.v_loc * m->d.slots);
+        return dspmap_fail(m, DSPMAP_E_ARG, "%s: particle count %d outside [0, %lld]", path, n, (long long)m->d.v_true * m->d.slots);
     }
-    const size_t V = (size_t)m->d.v_loc, T = (size_t)m->d.T;
+    const size_t V = (size_t)m->d.v_true, Vs = (size_t)m->d.v_loc, T = (size_t)m->d.T;
     std::vector<int> voxel((size_t)n + 1), slot((size_t)n + 1);
     std::vector<float> rec((size_t)n * 8 + 8), res(V * 4), fstat(V);
     std::vector<u64> fut(V * (T ? T : 1));
@@ -1972,14 +2060,25 @@ extern "C" int dspmap_load_checkpoint(dspmap_t* m, const char* path) {
     }
     fclose(f);
     if (!ok) return dspmap_fail(m, DSPMAP_E_ARG, "%s is truncated", path);
+    if (m->d.tiling) {   // the reference's voxel order -> cube storage (padding voxels: zero)
+        std::vector<float> res2(Vs * 4, 0.f), fstat2(Vs, 0.f);
+        std::vector<u64> fut2(Vs * (T ? T : 1), 0ull);
+        for (size_t t = 0; t < V; ++t) {
+            const size_t lv = host_lv_of_true(m->d, t);
+            for (int q = 0; q < 4; ++q) res2[lv * 4 + q] = res[t * 4 + q];
+            fstat2[lv] = fstat[t];
+            for (size_t hh = 0; hh < T; ++hh) fut2[hh * Vs + lv] = fut[hh * V + t];
+        }
+        res.swap(res2); fstat.swap(fstat2); fut.swap(fut2);
+    }
     int rc = dspmap_clear_state(m);
     if (rc != DSPMAP_OK) return rc;
     rc = dspmap_import_state(m, n, voxel.data(), slot.data(), rec.data());
     if (rc != DSPMAP_OK) return rc;
-    HIPCHK(m, hipMemcpyAsync(m->s.res4, res.data(), sizeof(float4) * V, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(m, hipMemcpyAsync(m->s.res4, res.data(), sizeof(float4) * Vs, hipMemcpyHostToDevice, m->stream));
     // (on the handle's stream, behind clear_state's memsets of the same buffers and the import)
-    if (T) HIPCHK(m, hipMemcpyAsync(m->s.fut, fut.data(), sizeof(u64) * V * T, hipMemcpyHostToDevice, m->stream));
-    HIPCHK(m, hipMemcpyAsync(m->s.fut_stat, fstat.data(), sizeof(float) * V, hipMemcpyHostToDevice, m->stream));
+    if (T) HIPCHK(m, hipMemcpyAsync(m->s.fut, fut.data(), sizeof(u64) * Vs * T, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(m, hipMemcpyAsync(m->s.fut_stat, fstat.data(), sizeof(float) * Vs, hipMemcpyHostToDevice, m->stream));
     HIPCHK(m, hipMemsetAsync(m->s.fut_dirty, 1, sizeof(int) * (size_t)m->k.ntiles, m->stream));   // (any tile may hold mass now)
     HIPCHK(m, hipStreamSynchronize(m->stream));
     {   // filter parameters and the frozen birth statics come from the checkpoint; the random tables are THIS handle's

@@ -146,10 +146,9 @@ __device__ __forceinline__ void birth_child_thread(const MapDims& d, const DevSt
     const float z = cz + s.p_tab[(c + 2) % fp.tab_n];
     int gv = 0;
     int lv = -1;
-    if (voxel_of(d, x, y, z, gv)) {                          // :875
+    if (voxel_of_lv(d, x, y, z, gv, lv)) {                   // :875
         if (inside_out) *inside_out = true; else atomicOr(&s.plan_inside[i], 1u << k);
-        lv = gv - d.v_base;
-        if (lv >= 0 && lv < d.v_loc) {                       // children landing in another slab are inserted by their owner
+        if (lv >= 0) {                                       // children landing in another slab are inserted by their owner
             const int pos = atomicAdd(&vb_cnt[lv], 1);
             if (pos < BIRTH_BUCKET_CAP) vb_idx[(size_t)lv * BIRTH_BUCKET_CAP + pos] = t;
             else s.birth_ovf[atomicAdd(&s.fs->n_birth_ovf, 1)] = t;   // bucket full: WHICH children land in it depends on the arrival

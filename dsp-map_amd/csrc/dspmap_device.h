@@ -195,6 +195,62 @@ __device__ __forceinline__ bool voxel_of(const MapDims& d, float px, float py, f
     return (unsigned)gidx < (unsigned)d.v_glob;
 }
 
+// ---- storage order of the voxels (MapDims::tiling): the device arrays are indexed with lv; the reference's voxel index (:1081) is kept for
+// everything that ORDERS (sweep keys) or leaves the library (results, state records).
+__device__ __forceinline__ int lv_of_xyz(const MapDims& d, int x, int y, int zl) {   // zl = z - z_lo, inside the slab
+    if (!d.tiling) return (int)(__umul24((unsigned)zl, (unsigned)(d.ny * d.nx)) + __umul24((unsigned)y, (unsigned)d.nx) + (unsigned)x);
+    return ((((zl >> 2) * d.ncy + (y >> 2)) * d.ncx + (x >> 2)) << 6) | ((zl & 3) << 4) | ((y & 3) << 2) | (x & 3);
+}
+// the slab's voxel t in index order (t = global index - v_base) -> storage
+__device__ __forceinline__ int lv_of_true(const MapDims& d, int t) {
+    if (!d.tiling) return t;
+    const int zc = d.ny * d.nx;
+    const int zl = t / zc, rest = t - zl * zc, y = rest / d.nx, x = rest - y * d.nx;
+    return lv_of_xyz(d, x, y, zl);
+}
+// the reference's GLOBAL voxel index -> storage; -1 outside this rank's slab
+__device__ __forceinline__ int lv_of_g(const MapDims& d, int gv) {
+    const int t = gv - d.v_base;
+    return (t >= 0 && t < d.v_true) ? lv_of_true(d, t) : -1;
+}
+// storage -> the reference's GLOBAL voxel index; -1 for a padding voxel of a cube that sticks out of the map
+__device__ __forceinline__ int g_of_lv(const MapDims& d, int lv) {
+    if (!d.tiling) return lv + d.v_base;
+    const int c = lv >> 6;
+    const int cx = c % d.ncx, r = c / d.ncx, cy = r % d.ncy, cz = r / d.ncy;
+    const int x = cx * 4 + (lv & 3), y = cy * 4 + ((lv >> 2) & 3), zl = cz * 4 + ((lv >> 4) & 3);
+    if (x >= d.nx || y >= d.ny || zl >= d.z_hi - d.z_lo) return -1;
+    return ((d.z_lo + zl) * d.ny + y) * d.nx + x;
+}
+// the same for the sweeps, one tile at a time: global index of (tile, lane) = tile_gbase(tile) + lane_goff(lane); the base is wave-uniform
+// (integer divisions on the scalar unit, once per tile), the lane's offset depends on the lane only.  (Padding lanes get an index of no
+// meaning: no particle ever lives there.)
+__device__ __forceinline__ int tile_gbase(const MapDims& d, int BX) {
+    if (!d.tiling) return d.v_base + BX * 64;
+    const int cx = BX % d.ncx, r = BX / d.ncx, cy = r % d.ncy, cz = r / d.ncy;
+    return ((d.z_lo + cz * 4) * d.ny + cy * 4) * d.nx + cx * 4;
+}
+__device__ __forceinline__ int lane_goff(const MapDims& d, int lane) {
+    return d.tiling ? (((lane >> 4) & 3) * d.ny + ((lane >> 2) & 3)) * d.nx + (lane & 3) : lane;
+}
+// the box of a tile's voxels in voxel units: [x0, x1] x [y0, y1] x [z0, z1] (global z), cube tiling only
+__device__ __forceinline__ void cube_box(const MapDims& d, int BX, int& x0, int& y0, int& z0) {
+    const int cx = BX % d.ncx, r = BX / d.ncx, cy = r % d.ncy, cz = r / d.ncy;
+    x0 = cx * 4; y0 = cy * 4; z0 = d.z_lo + cz * 4;
+}
+// getParticleVoxelsIndex (:1076-1088) with the storage index as well: lv = -1 when the voxel lies in another rank's slab
+__device__ __forceinline__ bool voxel_of_lv(const MapDims& d, float px, float py, float pz, int& gidx, int& lv) {
+    if (fabsf(px) >= d.half_x || fabsf(py) >= d.half_y || fabsf(pz) >= d.half_z) return false;
+    const int x = (int)div_res(d, px + d.half_x);
+    const int y = (int)div_res(d, py + d.half_y);
+    const int z = (int)div_res(d, pz + d.half_z);
+    gidx = (int)(__umul24((unsigned)z, (unsigned)(d.ny * d.nx)) + __umul24((unsigned)y, (unsigned)d.nx) + (unsigned)x);
+    if (!((unsigned)gidx < (unsigned)d.v_glob)) return false;
+    const int zl = z - d.z_lo;
+    lv = (unsigned)zl < (unsigned)(d.z_hi - d.z_lo) ? lv_of_xyz(d, x, y, zl) : -1;
+    return true;
+}
+
 // ---- queryNormalPDF :1294-1301 reproduced arithmetically.  The reference's
 // LUT (calculateNormalPDFBuffer :1288-1292) holds c*exp(-t^2/2) at
 // t = (i-10000)*0.001 with c = 1/sqrt(pi); the index truncates

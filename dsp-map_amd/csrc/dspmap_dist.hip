@@ -296,6 +296,7 @@ extern "C" int dspmap_mgpu_get_unique_id(char out[DSPMAP_UNIQUE_ID_BYTES]) {
 }
 
 extern "C" int dspmap_mgpu_comm_init(dspmap_t* m, int world, int rank, const char id_bytes[DSPMAP_UNIQUE_ID_BYTES]) {
+    INDEX_ORDER(m);
     READY(m);
     if (world < 1 || rank < 0 || rank >= world || !id_bytes) return dspmap_fail(m, DSPMAP_E_ARG, "bad communicator arguments");
     RcclApi* r = rccl();
@@ -522,6 +523,7 @@ static int phase_finish(dspmap* m) {
 
 extern "C" int dspmap_mgpu_update(dspmap_t* m, int n_points, const float* points_dev, int n_birth,
                                   const dspmap_vpoint* birth_dev, const float pos[3], double stamp, const float q[4]) {
+    INDEX_ORDER(m);
     READY(m);
     dspmap_dist* x = m->dist;
     if (!x || !x->comm) return dspmap_fail(m, DSPMAP_E_STATE, "call dspmap_mgpu_comm_init first");
@@ -623,6 +625,7 @@ extern "C" int dspmap_mgpu_group_create(dspmap_t** hs, int n) {
     if (!hs || n < 1 || n > 16) return DSPMAP_E_ARG;
     for (int i = 0; i < n; ++i) {
         dspmap* m = hs[i];
+        INDEX_ORDER(m);
         READY(m);
         if (i > 0) { int rc = dspmap_set_stream(m, (void*)hs[0]->stream); if (rc != DSPMAP_OK) return rc; }   // one stream orders the group
         int rc = dist_alloc(m, n, i);
@@ -723,6 +726,7 @@ extern "C" int dspmap_mgpu_message_records(const dspmap_t* m) { return (m && m->
 // the host-buffer twin of dspmap_mgpu_update (what the drop-in class DSPMap calls when it is built with -DDSPMAP_WORLD)
 extern "C" int dspmap_mgpu_update_host(dspmap_t* m, int n, int stride, const float* pts, float sx, float sy, float sz, double stamp,
                                        float qw, float qx, float qy, float qz) {
+    INDEX_ORDER(m);
     READY(m);
     if (n > 0 && (!pts || stride < 3)) return dspmap_fail(m, DSPMAP_E_ARG, "bad point cloud arguments");
     const int np = n > 0 ? n : 0;

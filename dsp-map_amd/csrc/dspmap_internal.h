@@ -79,6 +79,7 @@ struct dspmap {
     bool nb_dirty = false;           // newborn bits may be set outside a frame (pre-fill, import of flag-15 records, a birth stage
                                      // that no resampling followed): the next birth stage snapshots them (KernelScratch::nbsnap)
     u64* nbsnap_buf = nullptr;
+    float4* res_true = nullptr;      // cube storage: voxels_objects_number[v][0..3] in the reference's voxel order, filled on demand (dspmap_get_results / dspmap_results_device)
     int last_n_points = 0;
     VelocityEstimator vel;
     // per-frame parameter block (host copy; pushed to s.fpar with one H2D copy per frame)
@@ -102,7 +103,8 @@ struct dspmap {
     hipStream_t stream2 = nullptr;   // fork/join branch inside the captured frame
     hipStream_t stream4 = nullptr;   // the bulk branch of a two-branch frame (DSPMAP_P_FRAME_BRANCHES)
     hipEvent_t ev_br[4] = {nullptr, nullptr, nullptr, nullptr};   // its fork, "predict(P) ended", "predict(not P) ended", its join
-    int frame_branches = -1;         // DSPMAP_P_FRAME_BRANCHES: -1 the maps that would split their placement, 0 never, 1 whenever possible
+    int tiling_req = -1;             // DSPMAP_P_TILING: -1 by size (derive_dims), 0 runs of 64 voxel indices, 1 cubes of 4 x 4 x 4
+    int frame_branches = 0;          // DSPMAP_P_FRAME_BRANCHES: 0 never (default: measured slower), -1 the maps that would split their placement (cube storage), 1 whenever possible
     long long branch_frames = 0;     // frames that ran as two branches (dspmap_debug_frame_branches)
     bool branch_pending = false;
     float ptab_max = 0.f;            // largest |value| of the position table (FrameParams::birth_reach)
@@ -200,6 +202,10 @@ int dspmap_mgpu_ck_phase(dspmap* m);      // ... list preparation (with DevState
             return dspmap_fail((m), DSPMAP_E_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// entry points of the sharded frame (Z-slabs): their kernels take the slab's voxels in index order (layers are contiguous runs of it).  A whole-map
+// handle that would pick the cube storage switches back while its device state does not exist yet; afterwards the call fails
+int dspmap_need_index_order(dspmap* m);
+#define INDEX_ORDER(m) do { if ((m) && (m)->d.tiling) { const int rc_io_ = dspmap_need_index_order(m); if (rc_io_ != DSPMAP_OK) return rc_io_; } } while (0)
 #define BENIGN(m) (--(m)->api_seq)   /* (after READY) this entry point queues nothing that the velocity estimator's kernels read or write */
 #define READY(m)                                       \
     do {                                               \

@@ -124,6 +124,7 @@ void kernels_init_device();                 // function attributes of the curren
 void launch_occupied_compact(const LaunchCtx& c, float thr);
 void launch_clear_future(const LaunchCtx& c);
 void launch_future_combine(const LaunchCtx& c);  // fold the static-particle future mass into the [V][T] grid
+void launch_results_true(const LaunchCtx& c, float4* out);   // res4 (storage order) -> the reference's voxel order
 // state helpers
 void launch_seed_uniform(const LaunchCtx& c, int per_voxel, float weight, unsigned seed, float vmax);
 void launch_import(const LaunchCtx& c, int n, const int* voxel_dev, const int* slot_dev, const float* rec8_dev, int* n_failed_dev);

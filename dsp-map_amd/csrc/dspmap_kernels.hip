@@ -328,7 +328,7 @@ __device__ __forceinline__ void pyr_sort_block(const MapDims& d, const DevState&
                 // key is its own cell; an arrival carries its source's): one scattered store less for nine entries in ten
                 const int c = sl_u[u];
                 const int tile = c / (64 * d.slots), rem = c - tile * 64 * d.slots;
-                if (key_u[u] != (tile * 64 + (rem & 63) + d.v_base) * d.slots + (rem >> 6)) s.fov_spos[(size_t)b * d.capa + i] = pos;
+                if (key_u[u] != g_of_lv(d, tile * 64 + (rem & 63)) * d.slots + (rem >> 6)) s.fov_spos[(size_t)b * d.capa + i] = pos;
             }
             if (more) {
 #pragma unroll
@@ -474,7 +474,7 @@ __device__ __forceinline__ void place_fix_wave(const MapDims& d, const DevState&
     // there is nothing to re-slot)
     const int n = s.in_n[2 * tile + 1] == s.fs->pred_epoch ? min(s.in_n[2 * tile], cap) : 0;
     const size_t base = (size_t)tile * cap;
-    const int gD = lv + d.v_base;
+    const int gD = g_of_lv(d, lv);   // the reference's index of the voxel: sweep keys
     int m = 0;   // (wave-uniform)
     // lanes hand data to each other through LDS below: the wave runs in lockstep, but the COMPILER must not move a lane's
     // load above another lane's store -- a wavefront-scope fence between the steps
@@ -485,7 +485,7 @@ __device__ __forceinline__ void place_fix_wave(const MapDims& d, const DevState&
         bool mine = false;
         int key = 0;
         if (i < n) {
-            mine = __float_as_int(in_rec[(base + i) * 2].x) == gD;
+            mine = __float_as_int(in_rec[(base + i) * 2].x) == lv;   // (.x: the destination's storage index)
             key = __float_as_int(in_rec[(base + i) * 2 + 1].w);
         }
         const u64 g = __ballot(mine);
@@ -1026,8 +1026,8 @@ __device__ __forceinline__ void birth_split_wave(const MapDims& d, const DevStat
     int n_static = 0;
     if (ok) {
         pl.gvox = gv;
-        const int lv = gv - d.v_base;
-        if (lv >= 0 && lv < d.v_loc) {
+        const int lv = lv_of_g(d, gv);
+        if (lv >= 0) {
             float ws = 0.f, wsd = 0.f, wd = 0.f;
             for (int e = 0; e < d.mw; ++e) {
                 const int sl = e * 64 + l;
@@ -1090,8 +1090,8 @@ __device__ __forceinline__ void birth_point_wave(const MapDims& d, const DevStat
         return;
     }
     pl.gvox = gv;
-    const int lvs = gv - d.v_base;
-    const bool own = lvs >= 0 && lvs < d.v_loc;   // (else: the source voxel belongs to another slab; that rank supplies n_static)
+    const int lvs = lv_of_g(d, gv);
+    const bool own = lvs >= 0;   // (else: the source voxel belongs to another slab; that rank supplies n_static)
     const int lvq = own ? lvs : 0;
     // stage 2
     const int c = (int)(((long long)pb + 3 * min(l, nb - 1)) % fp.tab_n);
@@ -1116,10 +1116,9 @@ __device__ __forceinline__ void birth_point_wave(const MapDims& d, const DevStat
         const int t = i * nb + l;
         const float x = pl.cx + t0, y = pl.cy + t1, z = pl.cz + t2;
         int gvc = 0, lvc = -1;
-        if (voxel_of(d, x, y, z, gvc)) {
+        if (voxel_of_lv(d, x, y, z, gvc, lvc)) {
             in = true;
-            lvc = gvc - d.v_base;
-            if (lvc >= 0 && lvc < d.v_loc) {                     // children landing in another slab are inserted by their owner
+            if (lvc >= 0) {                                      // children landing in another slab are inserted by their owner
                 const int pos = atomicAdd(&vb_cnt[lvc], 1);
                 if (pos < BIRTH_BUCKET_CAP) vb_idx[(size_t)lvc * BIRTH_BUCKET_CAP + pos] = t;
                 else s.birth_ovf[atomicAdd(&s.fs->n_birth_ovf, 1)] = t;
@@ -1432,8 +1431,8 @@ __global__ void __launch_bounds__(256) k_birth_insert(MapDims d, DevState s, Fil
 // --------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_occ_count(MapDims d, DevState s, float thr) {
     __shared__ int s_c[4];
-    const int lv = blockIdx.x * 256 + threadIdx.x;
-    const bool occ = lv < d.v_loc && s.res4[lv].x > thr;
+    const int tv = blockIdx.x * 256 + threadIdx.x;   // the slab's voxels in the reference's index order, whatever the storage order
+    const bool occ = tv < d.v_true && s.res4[lv_of_true(d, tv)].x > thr;
     const u64 b = __ballot(occ);
     if (lane_id() == 0) s_c[threadIdx.x >> 6] = (int)__popcll(b);
     __syncthreads();
@@ -1458,8 +1457,8 @@ __global__ void __launch_bounds__(1024) k_occ_scan(DevState s, int nblk) {
 }
 __global__ void __launch_bounds__(256) k_occ_emit(MapDims d, DevState s, float thr, int cap) {
     __shared__ int s_c[4];
-    const int lv = blockIdx.x * 256 + threadIdx.x;
-    const bool occ = lv < d.v_loc && s.res4[lv].x > thr;
+    const int tv = blockIdx.x * 256 + threadIdx.x;
+    const bool occ = tv < d.v_true && s.res4[lv_of_true(d, tv)].x > thr;
     const u64 b = __ballot(occ);
     const int w = threadIdx.x >> 6;
     if (lane_id() == 0) s_c[w] = (int)__popcll(b);
@@ -1470,7 +1469,7 @@ __global__ void __launch_bounds__(256) k_occ_emit(MapDims d, DevState s, float t
         const int pos = off + (int)__popcll(b & lanemask_lt());
         if (pos < cap) {
             // getVoxelPositionFromIndex :1090-1107 on the GLOBAL index
-            const int index = lv + d.v_base;
+            const int index = tv + d.v_base;
             const int zc = d.ny * d.nx;
             const int zi = index / zc;
             const int rest = index - zi * zc;
@@ -1722,21 +1721,31 @@ void launch_scan_blocks(const LaunchCtx& c, int nblk) {
     hipLaunchKernelGGL(k_occ_scan, dim3(1), dim3(1024), 0, c.stream, c.s, nblk);
 }
 void launch_occupied_compact(const LaunchCtx& c, float thr) {
-    const int nblk = (c.d.v_loc + 255) / 256;
+    const int nblk = (c.d.v_true + 255) / 256;
     hipLaunchKernelGGL(k_occ_count, dim3(nblk), dim3(256), 0, c.stream, c.d, c.s, thr);
     hipLaunchKernelGGL(k_occ_scan, dim3(1), dim3(1024), 0, c.stream, c.s, nblk);
-    hipLaunchKernelGGL(k_occ_emit, dim3(nblk), dim3(256), 0, c.stream, c.d, c.s, thr, c.d.v_loc);
+    hipLaunchKernelGGL(k_occ_emit, dim3(nblk), dim3(256), 0, c.stream, c.d, c.s, thr, c.d.v_true);
 }
 // fut_out[v][t] = fut[t][v] + fut_stat[v]: the caller's [V][T] layout from the horizon-major accumulators and the
 // static-particle mass (the same for every horizon).  Pure function of the accumulators: callable any number of times.
+// (fut_out and res_out are in the reference's voxel order, the accumulators in storage order)
 __global__ void k_future_combine(MapDims d, DevState s) {
-    const int lv = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lv >= d.v_loc) return;
+    const int tv = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tv >= d.v_true) return;
+    const int lv = lv_of_true(d, tv);
     const float st = s.fut_stat[lv];
-    for (int t = 0; t < d.T; ++t) s.fut_out[(size_t)lv * d.T + t] = fut_value(s.fut[(size_t)t * d.v_loc + lv]) + st;
+    for (int t = 0; t < d.T; ++t) s.fut_out[(size_t)tv * d.T + t] = fut_value(s.fut[(size_t)t * d.v_loc + lv]) + st;
 }
 void launch_future_combine(const LaunchCtx& c) {
-    hipLaunchKernelGGL(k_future_combine, dim3((c.d.v_loc + 255) / 256), dim3(256), 0, c.stream, c.d, c.s);
+    hipLaunchKernelGGL(k_future_combine, dim3((c.d.v_true + 255) / 256), dim3(256), 0, c.stream, c.d, c.s);
+}
+// voxels_objects_number[v][0..3] (:118-120) in the reference's voxel order (cube storage only: otherwise res4 IS in that order)
+__global__ void k_results_true(MapDims d, DevState s, float4* __restrict__ out) {
+    const int tv = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tv < d.v_true) out[tv] = s.res4[lv_of_true(d, tv)];
+}
+void launch_results_true(const LaunchCtx& c, float4* out) {
+    hipLaunchKernelGGL(k_results_true, dim3((c.d.v_true + 255) / 256), dim3(256), 0, c.stream, c.d, c.s, out);
 }
 void launch_clear_future(const LaunchCtx& c) {
     (void)hipMemsetAsync(c.s.fut, 0, sizeof(u64) * (size_t)c.d.v_loc * c.d.T, c.stream);

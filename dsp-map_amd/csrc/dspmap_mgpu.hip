@@ -6,6 +6,7 @@
 #include "dspmap_internal.h"
 
 extern "C" int dspmap_mgpu_bind(dspmap_t* m, long long* ck_dev, int* nstatic_dev, int nstatic_cap) {
+    INDEX_ORDER(m);
     READY(m);
     if (!ck_dev || !nstatic_dev || nstatic_cap <= 0) return dspmap_fail(m, DSPMAP_E_ARG, "bad buffers");
     HIPCHK(m, hipStreamSynchronize(m->stream));
@@ -32,6 +33,7 @@ extern "C" int dspmap_mgpu_bind(dspmap_t* m, long long* ck_dev, int* nstatic_dev
 
 extern "C" int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_dev, int n_birth,
                                  const dspmap_vpoint* birth_dev, const float pos[3], double stamp, const float q[4]) {
+    INDEX_ORDER(m);
     READY(m);
     if (!m->mgpu_bound) return dspmap_fail(m, DSPMAP_E_STATE, "call dspmap_mgpu_bind first");
     if (n_points < 0 || (n_points > 0 && !points_dev) || !pos || !q) return dspmap_fail(m, DSPMAP_E_ARG, "bad arguments");

@@ -134,9 +134,11 @@ __device__ __forceinline__ u64 rows_of_wave(u64 tor, int wave) {
 template <int MW>
 __global__ void __launch_bounds__(256) k_vz_count(MapDims d, DevState s, int* __restrict__ vz_pre, u64* __restrict__ vz_q) {
     __shared__ int s_w[4];
-    const int lv = blockIdx.x * 256 + threadIdx.x;
+    const int tv = blockIdx.x * 256 + threadIdx.x;   // the slab's voxels in the reference's SWEEP order (= index order), whatever the storage order
+    const bool in = tv < d.v_true;
+    const int lv = in ? lv_of_true(d, tv) : 0;
     int q = 0;
-    if (lv < d.v_loc) {
+    if (in) {
 #pragma unroll
         for (int e = 0; e < MW; ++e) {
             u64 live = s.mask[(size_t)lv * MW + e] & ~s.nbmask[(size_t)lv * MW + e];
@@ -156,13 +158,13 @@ __global__ void __launch_bounds__(256) k_vz_count(MapDims d, DevState s, int* __
     __syncthreads();
     int off = 0;
     for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) off += s_w[k];
-    if (lv < d.v_loc) vz_pre[lv] = off + inc - q;
+    if (in) vz_pre[lv] = off + inc - q;
     if (threadIdx.x == 255) s.blk_cnt[blockIdx.x] = off + inc;
 }
 
 // one particle of mapPrediction: advance (:665-667, vz forced to 0 :662), classify.
 // returns 0 = left the map (:688), 1 = stays in its voxel (pyr = its pyramid or -1), 2 = changed voxel (gv = the
-// new global voxel), 3 = left this rank's slab (multi-GPU).  zadd = dt * 0.f + odz (:667, the same for every particle).
+// new voxel's STORAGE index inside the slab), 3 = left this rank's slab (multi-GPU).  zadd = dt * 0.f + odz (:667, the same for every particle).
 // VIEW = false: no particle of the tile can lie in the field of view (the tile's box test), a stayer needs no pyramid.
 template <bool VIEW>
 __device__ __forceinline__ int advance_one(const MapDims& d, const float* s_ph, const float* s_pv, float dt, float odx, float ody,
@@ -171,10 +173,11 @@ __device__ __forceinline__ int advance_one(const MapDims& d, const float* s_ph, 
     py += dt * vy + ody;   // :666
     pz += zadd;            // :667
     pyr = -1;
-    if (!voxel_of(d, px, py, pz, gv)) return 0;
-    const int nlv = gv - d.v_base;
+    int gtrue, nlv;
+    if (!voxel_of_lv(d, px, py, pz, gtrue, nlv)) return 0;
+    gv = nlv;
     if (nlv == lvp) { if (VIEW) pyr = pyramid_of(d, s_ph, s_pv, px, py, pz); return 1; }
-    if ((unsigned)nlv >= (unsigned)d.v_loc) return 3;
+    if (nlv < 0) return 3;
     return 2;
 }
 
@@ -186,7 +189,7 @@ __device__ __forceinline__ void vz_noise(const MapDims& d, const DevState& s, co
     if (!(fabs((double)(vxy[0] * vxy[1] * vz)) < 1e-6)) {
         // rank in the reference's sweep order: qualifying particles of earlier voxels (k_vz_count + k_occ_scan) + those in
         // lower slots of this voxel
-        int rank = s.blk_cnt[lv >> 8] + vz_pre[lv];
+        int rank = s.blk_cnt[(g_of_lv(d, lv) - d.v_base) >> 8] + vz_pre[lv];
         for (int e2 = 0; e2 <= e; ++e2) {
             u64 qm = vz_q[(size_t)lv * mw + e2];
             if (e2 == e) qm &= (1ull << row) - 1ull;
@@ -209,18 +212,24 @@ __device__ __forceinline__ void vz_noise(const MapDims& d, const DevState& s, co
 __device__ __forceinline__ int tile_view_test(const MapDims& d, const DevState& s, const int BX, const int l) {
     const float* __restrict__ gph = s.planes_h;   // (rotated by k_obs_points; uniform addresses: scalar loads)
     const float* __restrict__ gpv = s.planes_v;
+    int x0, x1, y0, y1, z0, z1;
+    bool two = false;
+    if (d.tiling) {   // a cube of 4 x 4 x 4 voxels: one box
+        cube_box(d, BX, x0, y0, z0);
+        x1 = x0 + 3; y1 = y0 + 3; z1 = z0 + 3;
+    } else {
     const int g0 = d.v_base + BX * 64, g1 = d.v_base + min(BX * 64 + 63, d.v_loc - 1);
     const int zc = d.nx * d.ny;
     const int r0 = g0 / d.nx, r1 = g1 / d.nx;          // first and last x-row the tile touches
     const int bx = (l >> 3) & 1;
-    int x0 = g0 % d.nx, x1 = g1 % d.nx, y0 = (g0 % zc) / d.nx, y1 = (g1 % zc) / d.nx, z0 = g0 / zc, z1 = g1 / zc;
-    bool two = false;
+    x0 = g0 % d.nx; x1 = g1 % d.nx; y0 = (g0 % zc) / d.nx; y1 = (g1 % zc) / d.nx; z0 = g0 / zc; z1 = g1 / zc;
     if (r1 - r0 == 1) {
         two = true;
         if (bx == 0) { x1 = d.nx - 1; y1 = y0; z1 = z0; } else { x0 = 0; y0 = y1; z0 = z1; }
     } else if (r1 - r0 > 1) {                          // nx < 64: whole rows (layers)
         x0 = 0; x1 = d.nx - 1;
         if (z0 != z1) { y0 = 0; y1 = d.ny - 1; }
+    }
     }
     const float mg = d.res * 0.01f;   // a particle of voxel x has (int)((p + half) / res) == x: p may sit a rounding below the face
     const float cx = (l & 1) ? (float)(x1 + 1) * d.res - d.half_x + mg : (float)x0 * d.res - d.half_x - mg;
@@ -238,94 +247,65 @@ __device__ __forceinline__ int tile_view_test(const MapDims& d, const DevState& 
 __device__ __forceinline__ bool cls_mine(int tc, int cls) { return cls > 0 ? (tc & cls) != 0 : (tc & -cls) == 0; }
 
 // --------------------------------------------------------------------------
-// k_tile_class: the tile classes of a TWO-BRANCH frame (KernelScratch::tile_cls), one workgroup, right after the binning.
+// k_tile_class: the tile classes of a TWO-BRANCH frame (KernelScratch::tile_cls), one thread per tile, right after the binning.
+// Cube storage only (MapDims::tiling == 1: a tile is a box of 4 x 4 x 4 voxels).
 // The frame (reference :300-322: prediction -> update -> births -> resampling, each a sweep over ALL voxels) touches most of a large
 // map only to move it and to resample it; weights, births and pyramid lists live in the part the sensor sees.  The two parts run as
 // two branches; what ties them together is (a) a particle that changes voxel ACROSS the border and (b) a newborn landing beyond it.
 // Both have a bounded reach, and the classes are the border grown by those reaches:
-//   rows   the map is cut in x-rows (one (y, z) each, the whole x extent): a row is IN VIEW if its box, grown by the reach of a
-//          newborn (the position table's largest value, FrameParams::birth_reach), passes the four boundary planes of the field of
-//          view (the same corner argument as tile_view_test: a plane's dot product is monotone in every coordinate, so its
-//          extreme over a box sits at the corner the normal's signs select);
-//   Q      a tile that touches a row in view: every observation lies in the wedge, so every newborn lands in a Q tile, and every
-//          tile with a view (tile_view_test) is one;
-//   P      a tile that touches a row within the frame's largest displacement -- |od| + dt * (largest speed the map has seen,
-//          FrameScalars::vmax_bits), in rows and layers -- of a row of a Q tile: nothing outside P can send a particle into Q.
+//   Q   the tile's box, grown by the reach of a newborn (the position table's largest value, FrameParams::birth_reach), passes the
+//       four boundary planes of the field of view (the corner argument of tile_view_test: a plane's dot product is monotone in every
+//       coordinate, so its extreme over a box sits at the corner the normal's signs select).  Every observation lies in the wedge,
+//       so every newborn lands in a Q tile, and every tile with a view (tile_view_test: the same box, not grown) is one;
+//   P   a Q tile lies within the frame's largest displacement -- |od| + dt * (the largest speed the map has ever seen,
+//       FrameScalars::vmax_bits), in voxels per axis, rounded up to cubes -- of the tile: nothing outside P can send a particle into Q.
 // So: predict(P) -> place(Q) sees every arrival of Q; place(not Q) waits for both predictions; births stay inside Q.
-// Conservative on purpose (rows, not boxes: the classes are a few per cent larger than they must be), exact never matters.
-// dynamic LDS: two bitmaps of one bit per row.
+// Conservative on purpose, exact never matters.
 // --------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_tile_class(MapDims d, DevState s, int* __restrict__ tile_cls) {
-    extern __shared__ unsigned s_bm[];
-    const int tid = threadIdx.x;
-    const int nlay = d.z_hi - d.z_lo;
-    const int nrows = d.ny * nlay;
-    const int nw = (nrows + 31) >> 5;
-    unsigned* const bm0 = s_bm;
-    unsigned* const bm1 = s_bm + nw;
+__global__ void __launch_bounds__(256) k_tile_class(MapDims d, DevState s, int* __restrict__ tile_cls) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
     const int ntl = (d.v_loc + 63) >> 6;
-    for (int i = tid; i < 2 * nw; i += 1024) s_bm[i] = 0u;
+    if (t >= ntl) return;
     const float* __restrict__ gph = s.planes_h;
     const float* __restrict__ gpv = s.planes_v;
     const float n0[3] = {gph[0], gph[1], gph[2]}, n1[3] = {gph[3 * d.np_h], gph[3 * d.np_h + 1], gph[3 * d.np_h + 2]};
     const float n2[3] = {gpv[0], gpv[1], gpv[2]}, n3[3] = {gpv[3 * d.np_v], gpv[3 * d.np_v + 1], gpv[3 * d.np_v + 2]};
     const float reach = s.fpar->birth_reach;
-    const float mg = d.res * 0.01f + (reach > 0.f ? reach * 1.0001f : 0.f);   // (res * 0.01: tile_view_test's own margin -- a row's box contains the boxes of its tiles)
+    const float mg = d.res * 0.01f + (reach > 0.f ? reach * 1.0001f : 0.f);   // (res * 0.01: tile_view_test's own margin)
     const float vmax = __int_as_float(s.fs->vmax_bits);
     const float dt = fabsf(s.fpar->dt);
-    const float my = (fabsf(s.fpar->od[1]) + dt * vmax) * 1.0001f, mz = fabsf(s.fpar->od[2]) * 1.0001f;
-    // rows / layers a particle can cross: floor(m / res) + 1 (it may sit right at the face), none if it cannot move that way at all
-    const int ky = my > 0.f ? (my < d.res * (float)d.ny ? (int)(my / d.res) + 1 : d.ny) : 0;
-    const int kz = mz > 0.f ? (mz < d.res * (float)d.nz ? (int)(mz / d.res) + 1 : d.nz) : 0;
-    __syncthreads();
-    // the extreme of dot3 over a box: the corner the normal's signs select (dot3 itself, so the value IS the extreme of the corner values)
-    auto ext = [&](const float* n, bool mx, float x0, float x1, float y0, float y1, float z0, float z1) {
-        const float cx = ((n[0] >= 0.f) == mx) ? x1 : x0, cy = ((n[1] >= 0.f) == mx) ? y1 : y0, cz = ((n[2] >= 0.f) == mx) ? z1 : z0;
+    const float mx = (fabsf(s.fpar->od[0]) + dt * vmax) * 1.0001f, my = (fabsf(s.fpar->od[1]) + dt * vmax) * 1.0001f, mz = fabsf(s.fpar->od[2]) * 1.0001f;
+    // voxels a particle can cross along an axis: floor(m / res) + 1 (it may sit right at the face), none if it cannot move that way at
+    // all; in cubes: rounded up
+    auto cubes = [&](float m, int n) { const int k = m > 0.f ? (m < d.res * (float)n ? (int)(m / d.res) + 1 : n) : 0; return (k + 3) >> 2; };
+    const int rcx = cubes(mx, d.nx), rcy = cubes(my, d.ny), rcz = cubes(mz, d.nz);
+    // does the box of voxels [x0, x1) x [y0, y1) x [z0, z1) (global z), grown by g, pass the four planes?
+    auto ext = [&](const float* n, bool mxm, float ax, float bx, float ay, float by, float az, float bz) {
+        const float cx = ((n[0] >= 0.f) == mxm) ? bx : ax, cy = ((n[1] >= 0.f) == mxm) ? by : ay, cz = ((n[2] >= 0.f) == mxm) ? bz : az;
         return dot3(cx, cy, cz, n);
     };
-    for (int r = tid; r < nrows; r += 1024) {
-        const int y = r % d.ny, z = d.z_lo + r / d.ny;
-        const float x0 = 0.f * d.res - d.half_x - mg, x1 = (float)d.nx * d.res - d.half_x + mg;
-        const float y0 = (float)y * d.res - d.half_y - mg, y1 = (float)(y + 1) * d.res - d.half_y + mg;
-        const float z0 = (float)z * d.res - d.half_z - mg, z1 = (float)(z + 1) * d.res - d.half_z + mg;
-        const bool in = ext(n0, true, x0, x1, y0, y1, z0, z1) >= 0.f && ext(n1, false, x0, x1, y0, y1, z0, z1) <= 0.f &&
-                        ext(n2, false, x0, x1, y0, y1, z0, z1) <= 0.f && ext(n3, true, x0, x1, y0, y1, z0, z1) >= 0.f;
-        if (in) atomicOr(&bm0[r >> 5], 1u << (r & 31));
-    }
-    __syncthreads();
-    auto any_row = [&](const unsigned* bm, int r0, int r1) {
-        for (int r = r0; r <= r1; ++r) if ((bm[r >> 5] >> (r & 31)) & 1u) return true;
-        return false;
+    auto box_in = [&](int x0, int x1, int y0, int y1, int z0, int z1, float g) {
+        const float ax = (float)x0 * d.res - d.half_x - g, bx = (float)x1 * d.res - d.half_x + g;
+        const float ay = (float)y0 * d.res - d.half_y - g, by = (float)y1 * d.res - d.half_y + g;
+        const float az = (float)z0 * d.res - d.half_z - g, bz = (float)z1 * d.res - d.half_z + g;
+        return ext(n0, true, ax, bx, ay, by, az, bz) >= 0.f && ext(n1, false, ax, bx, ay, by, az, bz) <= 0.f &&
+               ext(n2, false, ax, bx, ay, by, az, bz) <= 0.f && ext(n3, true, ax, bx, ay, by, az, bz) >= 0.f;
     };
-    for (int t = tid; t < ntl; t += 1024) {
-        const int r0 = (t * 64) / d.nx, r1 = min(t * 64 + 63, d.v_loc - 1) / d.nx;
-        const bool q = any_row(bm0, r0, r1);
-        tile_cls[t] = q ? TILE_Q : 0;
-        if (q) for (int r = r0; r <= r1; ++r) atomicOr(&bm1[r >> 5], 1u << (r & 31));   // the rows of the Q tiles
+    const int cx = t % d.ncx, r = t / d.ncx, cy = r % d.ncy, cz = r / d.ncy;
+    auto q_of = [&](int ux, int uy, int uz) { return box_in(ux * 4, ux * 4 + 4, uy * 4, uy * 4 + 4, d.z_lo + uz * 4, d.z_lo + uz * 4 + 4, mg); };
+    const bool q = q_of(cx, cy, cz);
+    bool p = q;
+    // (one test rules most tiles out: the box of every cube within reach, grown like theirs)
+    if (!p && box_in((cx - rcx) * 4, (cx + rcx) * 4 + 4, (cy - rcy) * 4, (cy + rcy) * 4 + 4, d.z_lo + (cz - rcz) * 4, d.z_lo + (cz + rcz) * 4 + 4, mg)) {
+        for (int uz = max(0, cz - rcz); uz <= min(d.ncz - 1, cz + rcz) && !p; ++uz)
+            for (int uy = max(0, cy - rcy); uy <= min(d.ncy - 1, cy + rcy) && !p; ++uy)
+                for (int ux = max(0, cx - rcx); ux <= min(d.ncx - 1, cx + rcx); ++ux)
+                    if (q_of(ux, uy, uz)) { p = true; break; }
     }
-    __syncthreads();
-    for (int i = tid; i < nw; i += 1024) bm0[i] = 0u;
-    __syncthreads();
-    for (int r = tid; r < nrows; r += 1024) {   // does a row within (ky, kz) of this one belong to a Q tile?
-        const int y = r % d.ny, zl = r / d.ny;
-        bool near = false;
-        for (int dz = -kz; dz <= kz && !near; ++dz) {
-            const int z2 = zl + dz;
-            if (z2 < 0 || z2 >= nlay) continue;
-            const int ya = max(0, y - ky), yb = min(d.ny - 1, y + ky);
-            for (int y2 = ya; y2 <= yb; ++y2) { const int r2 = z2 * d.ny + y2; if ((bm1[r2 >> 5] >> (r2 & 31)) & 1u) { near = true; break; } }
-        }
-        if (near) atomicOr(&bm0[r >> 5], 1u << (r & 31));
-    }
-    __syncthreads();
-    for (int t = tid; t < ntl; t += 1024) {
-        const int r0 = (t * 64) / d.nx, r1 = min(t * 64 + 63, d.v_loc - 1) / d.nx;
-        if (any_row(bm0, r0, r1)) tile_cls[t] |= TILE_P;   // (only this thread writes tile_cls[t])
-    }
+    tile_cls[t] = (q ? TILE_Q : 0) | (p ? TILE_P : 0);
 }
 void launch_tile_class(const LaunchCtx& c) {
-    const int nrows = c.d.ny * (c.d.z_hi - c.d.z_lo);
-    hipLaunchKernelGGL(k_tile_class, dim3(1), dim3(1024), (size_t)2 * ((nrows + 31) / 32) * sizeof(unsigned), c.stream, c.d, c.s, c.k.tile_cls);
+    hipLaunchKernelGGL(k_tile_class, dim3((c.k.ntiles + 255) / 256), dim3(256), 0, c.stream, c.d, c.s, c.k.tile_cls);
 }
 
 // eight workgroups per CU: the sweep is a chain of phases (occupancy words, rows, tails) and only the workgroups that are in
@@ -465,6 +445,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
     }
     const bool inr = lv < d.v_loc;
     const int lvs = inr ? lv : 0;
+    const int tgb = __builtin_amdgcn_readfirstlane(tile_gbase(d, BX));   // the reference's voxel index of (tile, lane) = tgb + lane_goff(lane): sweep keys
     u64 mword[MW], live[MW];
     bool any = false, nb_any = false;
 #pragma unroll
@@ -538,7 +519,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
         if (km >= 0) {
             const float4 a = make_float4(__int_as_float(gv), vx, vy, px);
             // .w: source key = sweep position (global voxel, slot) of the particle: k_place serves arrivals in this order
-            const float4 b = make_float4(py, pz, w, __int_as_float((BX * 64 + (cell & 63) + d.v_base) * d.slots + (cell >> 6)));
+            const float4 b = make_float4(py, pz, w, __int_as_float((tgb + lane_goff(d, cell & 63)) * d.slots + (cell >> 6)));
             if (km < LSTG) { s_mv[km * 2] = a; s_mv[km * 2 + 1] = b; }
             else { const size_t o = (mv_base + km) * 2; mv_rec[o] = a; mv_rec[o + 1] = b; }
         }
@@ -688,7 +669,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
                 const size_t o = (size_t)pyr * d.capa + pos;
                 s.fov_rec[o] = make_float4(a.z, a.w, b.x, b.y);
                 s.fov_slot[o] = (int)(((size_t)BX * d.slots + (sl >> 6)) * 64 + (sl & 63));
-                s.fov_key[o] = (BX * 64 + (sl & 63) + d.v_base) * d.slots + (sl >> 6);   // a stayer's sweep key is its own cell
+                s.fov_key[o] = (tgb + lane_goff(d, sl & 63)) * d.slots + (sl >> 6);   // a stayer's sweep key is its own cell
             } else {
                 // pyramid list full: the particle vanishes (-2, :1256-1259)
                 atomicAnd(&s_keep[((sl >> 12) & 1) * 64 + (sl & 63)], ~(1ull << ((sl >> 6) & 63)));
@@ -715,7 +696,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
                 const size_t o = (size_t)key[j] * d.capa + pos[j];
                 s.fov_rec[o] = make_float4(a.z, a.w, b.x, b.y);
                 s.fov_slot[o] = (int)(((size_t)BX * d.slots + (sl >> 6)) * 64 + (sl & 63));
-                s.fov_key[o] = (BX * 64 + (sl & 63) + d.v_base) * d.slots + (sl >> 6);
+                s.fov_key[o] = (tgb + lane_goff(d, sl & 63)) * d.slots + (sl >> 6);
             } else {
                 // pyramid list full: the particle vanishes (-2, :1256-1259)
                 atomicAnd(&s_keep[((sl >> 12) & 1) * 64 + (sl & 63)], ~(1ull << ((sl >> 6) & 63)));
@@ -730,7 +711,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
         for (int j = 0; j < TB; ++j) {
             const int i = i0 + j * NW * 64 + tid;
             key[j] = -1;
-            if (i < nmv) key[j] = (__float_as_int(i < LSTG ? s_mv[i * 2].x : mv_rec[(mv_base + i) * 2].x) - d.v_base) >> 6;
+            if (i < nmv) key[j] = __float_as_int(i < LSTG ? s_mv[i * 2].x : mv_rec[(mv_base + i) * 2].x) >> 6;   // (.x: the new voxel's storage index)
         }
         batch_append<TB>(in_cnt, key, pos);
 #pragma unroll
@@ -844,8 +825,8 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
     __syncthreads();
     // bucket the arrivals' source keys by destination lane: counts, offsets, then every key into its lane's run
     for (int i = tid; i < n; i += NT) {
-        const int gv = __float_as_int(i == tid ? a0.x : in_rec[(base + i) * 2].x);
-        atomicAdd(&s_lcnt[(gv - d.v_base) & 63], 1);
+        const int gv = __float_as_int(i == tid ? a0.x : in_rec[(base + i) * 2].x);   // (the destination voxel's storage index)
+        atomicAdd(&s_lcnt[gv & 63], 1);
     }
     __syncthreads();
     if (tid < 64) {
@@ -859,7 +840,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
     for (int i = tid; i < n; i += NT) {
         const int gv = __float_as_int(i == tid ? a0.x : in_rec[(base + i) * 2].x);
         const int key = __float_as_int(i == tid ? b0.w : in_rec[(base + i) * 2 + 1].w);
-        const int ln = (gv - d.v_base) & 63;
+        const int ln = gv & 63;
         const int o = s_loff[ln] + atomicAdd(&s_lcnt[ln], 1);
         if (in_lds) s_bk[o] = key;
         else __hip_atomic_store(&gbk[o], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -876,13 +857,13 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
             const float4 b = i == tid ? b0 : in_rec[(base + i) * 2 + 1];
             px = a.w; py = b.x; pz = b.y; w = b.z; avx = a.y; avy = a.z;
             skey = __float_as_int(b.w);
-            ln = (__float_as_int(a.x) - d.v_base) & 63;
+            ln = __float_as_int(a.x) & 63;
             // position of this arrival in the reference's service order of its destination voxel, in closed form:
             // the nF arrivals from lower voxel indices take, in key order, the first free slots of the occupancy
             // BEFORE the prediction; the others then take the first free slots of the occupancy AFTER it that are
             // still left
             const int o0 = s_loff[ln], mm = s_loff[ln + 1] - o0;
-            const long long dkey = (long long)(BX * 64 + ln + d.v_base) * d.slots;   // key of (D, slot 0)
+            const long long dkey = (long long)(tile_gbase(d, BX) + lane_goff(d, ln)) * d.slots;   // key of (D, slot 0)
             int r = 0, nF = 0;
             if (in_lds) {
                 for (int x = 0; x < mm; ++x) {
@@ -933,7 +914,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
                 nidx = pidx(d, BX * 64 + ln, nsl);
                 st_pos(s, nidx, px, py, pz);
                 // a static arrival in a tile of static particles finds (0, 0) in its cell already (tile_moving = 0 promises it)
-                if (avx != 0.f || avy != 0.f) { st_vel(s, nidx, avx, avy); s.tile_moving[BX] = 1; if (d.v_loc != d.v_glob) note_speed(s, avx, avy); }   // (a slab: the arrival may come from another rank's map)   // (k_predict wrote the tile's flag before any arrival)
+                if (avx != 0.f || avy != 0.f) { st_vel(s, nidx, avx, avy); s.tile_moving[BX] = 1; if (d.v_true != d.v_glob) note_speed(s, avx, avy); }   // (a slab: the arrival may come from another rank's map)   // (k_predict wrote the tile's flag before any arrival)
                 else if (t_moving) st_vel(s, nidx, 0.f, 0.f);
                 s.w[nidx] = w;
                 key[0] = pyramid_of(d, s_ph, s_pv, px, py, pz);
@@ -1362,10 +1343,13 @@ __global__ void __launch_bounds__(256, RBK_ >= 8 ? 3 : 5) k_resample(MapDims d, 
 // The accumulators are FIXED-POINT (fut_quantum, dspmap_device.h): every particle adds the same integer whichever path carries it
 // -- this one, k_rollout's LDS windows, a sharded or an unsharded map -- and integer sums do not depend on the order of the adds,
 // so the future status is reproducible bit for bit (the reference's own `+=` is a sequential loop, :961).
+// the layer (relative to the slab) of storage voxel lv: a particle never leaves it within a frame's horizons (vz == 0)
+__device__ __forceinline__ int layer_of_lv(const MapDims& d, int lv) {
+    return d.tiling ? ((lv >> 6) / (d.ncx * d.ncy)) * 4 + ((lv >> 4) & 3) : lv / (d.ny * d.nx);
+}
 __device__ __forceinline__ void rollout_direct(const MapDims& d, const DevState& s, const float4 a, const float4 b) {
-    const int zc = d.ny * d.nx;
     const size_t V = (size_t)d.v_loc;
-    const int lbase = ((__float_as_int(b.y) + d.v_base) / zc) * zc - d.v_base;   // voxel (x 0, y 0) of the particle's layer: it never changes (vz == 0)
+    const int zl = layer_of_lv(d, __float_as_int(b.y));
     const u64 q = fut_quantum(b.x);
     for (int t = 0; t < d.T; ++t) {
         const float pt = d.pred_t[t];
@@ -1374,7 +1358,7 @@ __device__ __forceinline__ void rollout_direct(const MapDims& d, const DevState&
         if (fabsf(fx) >= d.half_x || fabsf(fy) >= d.half_y) continue;
         const int xi = (int)div_res(d, fx + d.half_x);
         const int yi = (int)div_res(d, fy + d.half_y);
-        const int dl = lbase + (int)__umul24((unsigned)yi, (unsigned)d.nx) + xi;
+        const int dl = lv_of_xyz(d, xi, yi, zl);
         if (dl < 0 || dl >= d.v_loc) continue;
         fut_add(&s.fut[(size_t)t * V + dl], q);
         s.fut_dirty[dl >> 6] = 1;
@@ -1749,7 +1733,6 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
     if (tid < 2) s_stat[tid] = 0;
     int n_win = 0, n_dir = 0;
     const int T = d.T;
-    const int zc = d.ny * d.nx;
     const int cap = 64 * d.slots;
     const size_t V = (size_t)d.v_loc;
     // particle `it` of the group -> its record
@@ -1761,7 +1744,7 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
         a = ro_rec[o]; b = ro_rec[o + 1];
     };
     // (a window cell is 32 bits wide and can receive at most the group's whole moving weight: windows only while that fits)
-    const bool dense = !LIGHT && total >= RO_DENSE && s_wtot < FUT_WINDOW_MAX_W;
+    const bool dense = !LIGHT && !d.tiling && total >= RO_DENSE && s_wtot < FUT_WINDOW_MAX_W;   // (the windows are runs of voxel indices: index-order storage only)
     const int ncell = pl.woff[T];
     if (dense) for (int i = tid; i < ncell; i += TPB) s_win[i] = 0u;
     __syncthreads();
@@ -1776,7 +1759,7 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             if (it0 + u * TPB >= total) continue;
-            const int lbase = ((__float_as_int(b[u].y) + d.v_base) / zc) * zc - d.v_base;   // voxel (x 0, y 0) of the particle's layer: it never changes (vz == 0)
+            const int zl = layer_of_lv(d, __float_as_int(b[u].y));   // the particle's layer: it never changes (vz == 0)
             wq[u] = (unsigned)fut_quantum(b[u].x);   // (dense: below 2^32 because the group's sum is)
             for (int t = 0; t < T; ++t) {
                 const float pt = d.pred_t[t];
@@ -1785,7 +1768,7 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
                 if (fabsf(fx) >= d.half_x || fabsf(fy) >= d.half_y) continue;
                 const int xi = (int)div_res(d, fx + d.half_x);
                 const int yi = (int)div_res(d, fy + d.half_y);
-                const int dl = lbase + (int)__umul24((unsigned)yi, (unsigned)d.nx) + xi;
+                const int dl = lv_of_xyz(d, xi, yi, zl);
                 if (dl < 0 || dl >= d.v_loc) continue;
                 const int off = dl - (G0 * 64 - pl.halo[t] * d.nx);
                 if (dense && off >= 0 && off < pl.woff[t + 1] - pl.woff[t]) { atomicAdd(&s_win[pl.woff[t] + off], wq[u]); ++n_win; }
@@ -1822,15 +1805,15 @@ __global__ void k_seed_uniform(MapDims d, DevState s, int per_voxel, float weigh
     const size_t total = (size_t)d.v_loc * d.slots;
     if (t >= total) return;
     const int lv = (int)(t / d.slots), sl = (int)(t - (size_t)lv * d.slots);
+    const int index = g_of_lv(d, lv);   // the reference's voxel index: the fill is the same whatever the storage order (-1: a padding voxel)
     if (sl == 0) {
         for (int e = 0; e < d.mw; ++e) {
-            const int nbits = max(0, min(64, per_voxel - e * 64));
+            const int nbits = index < 0 ? 0 : max(0, min(64, per_voxel - e * 64));
             s.mask[(size_t)lv * d.mw + e] = nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
             s.nbmask[(size_t)lv * d.mw + e] = 0ull;
         }
     }
-    if (sl >= per_voxel) return;
-    const int index = lv + d.v_base;
+    if (sl >= per_voxel || index < 0) return;
     const int zc = d.ny * d.nx;
     const int zi = index / zc, rest = index - zi * zc, yi = rest / d.nx, xi = rest - yi * d.nx;
     const unsigned h0 = hash_u32(seed ^ hash_u32((unsigned)index * 73u + (unsigned)sl));
@@ -1855,8 +1838,9 @@ __global__ void k_import(MapDims d, DevState s, int n, const int* __restrict__ v
                          const float* __restrict__ rec, int* __restrict__ n_failed) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int lv = voxel[i] - d.v_base;
-    bool ok = lv >= 0 && lv < d.v_loc;
+    const int tv = voxel[i] - d.v_base;
+    bool ok = tv >= 0 && tv < d.v_true;
+    const int lv = ok ? lv_of_true(d, tv) : 0;
     int sl = -1;
     if (ok) {
         sl = slot ? slot[i] : -1;
@@ -1892,7 +1876,7 @@ __global__ void k_export(MapDims d, DevState s, int* __restrict__ voxel, int* __
     if (live && pos < cap) {
         const bool nbf = (s.nbmask[(size_t)lv * d.mw + (sl >> 6)] >> (sl & 63)) & 1ull;
         const size_t idx = pidx(d, lv, sl);
-        voxel[pos] = lv + d.v_base;
+        voxel[pos] = g_of_lv(d, lv);
         slot[pos] = sl;
         float* r = rec + 8 * (size_t)pos;
         r[0] = nbf ? 15.f : 1.f;
@@ -1926,10 +1910,8 @@ __device__ __forceinline__ SeedDraw seed_draw(const MapDims& d, const DevState& 
     r.vz = rand_float_t(s, fp, c + 5, -1.f, 1.f);
     int gv;
     r.lv = -1;
-    if (voxel_of(d, r.px, r.py, r.pz, gv)) {
-        const int lv = gv - d.v_base;
-        if (lv >= 0 && lv < d.v_loc) r.lv = lv;
-    }
+    int lv;
+    if (voxel_of_lv(d, r.px, r.py, r.pz, gv, lv)) r.lv = lv;   // (-1: another rank's slab)
     return r;
 }
 __global__ void k_add_random_bucket(MapDims d, DevState s, FilterParams fp, int n, int* __restrict__ vb_cnt, int* __restrict__ vb_idx) {
@@ -2018,9 +2000,9 @@ __global__ void __launch_bounds__(256) k_export_slab(MapDims d, DevState s, u64*
             const P3 p3 = ld_pos(s, pidx(d, lv, e * 64 + sb));
             int gv;
             voxel_of(d, p3.x, p3.y, p3.z, gv);
-            const int nlv = gv - d.v_base;
+            const int nlv = gv - d.v_base;   // (slabs keep index-order storage: MapDims::tiling == 0)
             const bool down = nlv < 0;
-            const bool mine = dir > 0 ? nlv >= d.v_loc : (dir < 0 ? down : (down || nlv >= d.v_loc));
+            const bool mine = dir > 0 ? nlv >= d.v_true : (dir < 0 ? down : (down || nlv >= d.v_true));
             if (mine) { minew[e] |= 1ull << sb; if (down && dir == 0) { dnw[e] |= 1ull << sb; ++cd; } else ++cu; }
         }
     }
@@ -2051,7 +2033,7 @@ __global__ void __launch_bounds__(256) k_export_slab(MapDims d, DevState s, u64*
                     voxel_of(d, p3.x, p3.y, p3.z, gv);
                     float* r = (down ? rec_out2 : rec_out) + 8 * (size_t)pos;
                     r[0] = __int_as_float(gv); r[1] = v2.x; r[2] = v2.y; r[3] = p3.x; r[4] = p3.y; r[5] = p3.z; r[6] = s.w[idx];
-                    r[7] = __int_as_float((lv + d.v_base) * d.slots + e * 64 + sb);   // source key: k_place's service order
+                    r[7] = __int_as_float(g_of_lv(d, lv) * d.slots + e * 64 + sb);   // source key: k_place's service order
                 }
             }
             run_u += (int)__popcll(bu); run_d += (int)__popcll(bd);
@@ -2072,13 +2054,14 @@ __global__ void __launch_bounds__(256) k_import_movers(MapDims d, int n, const f
     bool lost = false;
     if (i < n) {
         const float* r = rec + 8 * (size_t)i;
-        const int nlv = __float_as_int(r[0]) - d.v_base;
-        if (nlv >= 0 && nlv < d.v_loc) {
+        const int tv = __float_as_int(r[0]) - d.v_base;
+        if (tv >= 0 && tv < d.v_true) {
+            const int nlv = lv_of_true(d, tv);
             const int tile = nlv >> 6, cap = 64 * d.slots;
             const int pos = atomicAdd(&in_cnt[tile], 1);   // beyond cap: k_place counts it as "voxel full"
             if (pos < cap) {
                 const size_t o = ((size_t)tile * cap + pos) * 2;
-                in_rec[o] = make_float4(r[0], r[1], r[2], r[3]);
+                in_rec[o] = make_float4(__int_as_float(nlv), r[1], r[2], r[3]);   // (.x: the destination's STORAGE index, like k_predict's own records)
                 in_rec[o + 1] = make_float4(r[4], r[5], r[6], r[7]);
             }
         } else lost = true;       // not a neighbouring slab's voxel (jump larger than a slab)
@@ -2237,7 +2220,7 @@ void launch_predict_only(const LaunchCtx& c, bool with_gather, bool with_rank, i
     const unsigned xb = (with_gather ? (c.d.np + 3) / 4 : 0) + (with_rank ? 1 : 0) + (c.place_split ? (c.k.ntiles + 255) / 256 : 0);
     const KernelScratch* k = &c.k;
     if (c.s.vz0) {   // constructor-seeded particles take their velocity noise in the reference's sweep order
-        const int nblk = (c.d.v_loc + 255) / 256;
+        const int nblk = (c.d.v_true + 255) / 256;
         if (c.d.mw == 1) hipLaunchKernelGGL(k_vz_count<1>, dim3(nblk), dim3(256), 0, c.stream, c.d, c.s, k->work_list, k->vz_q);
         else hipLaunchKernelGGL(k_vz_count<2>, dim3(nblk), dim3(256), 0, c.stream, c.d, c.s, k->work_list, k->vz_q);
         launch_scan_blocks(c, nblk);   // blk_cnt -> exclusive, total -> fs->occupied_count
@@ -2265,6 +2248,8 @@ void launch_claim(const LaunchCtx& c, int n_birth_grid, int part, int tile_lo, i
     if (sel == 0) grid = std::min(grid, (unsigned)(PLACE_SIDE_WG * c.n_cu));
     const int* vlist = (sel == 1 && c.place_split && part == 0) ? k->view_list : nullptr;   // (k_predict listed the tiles with a view)
     if (vlist) grid = std::min((unsigned)(n0 + n1), (unsigned)(PLACE_LB * c.n_cu)) + xb;    // one round of workgroups walks the list
+    if (cls) grid = std::min((unsigned)(n0 + n1), (unsigned)(PLACE_LB * c.n_cu)) + xb;      // (two-branch frame) one round of workgroups walks the tiles: a workgroup
+                                                                                            // that only finds out that its tile is the other branch's costs ~5 ns
     // a large sparse map: a tile receives a handful of arrivals and the launch is as long as (tiles with arrivals / resident workgroups) x
     // one tile's chain of round trips: two-wave workgroups there (264x264x80 filled by the depth stream: frame 0.435 -> 0.420 ms, two
     // alternating pairs of runs; one wave: no better; 132x132x60: +2 % with either, so only from 32 768 tiles on; the children riding
@@ -2286,7 +2271,7 @@ int resample_variant(const LaunchCtx& c) {
     // empty: what is left is a few thousand tiles of a few hundred particles each, the metric's regime; 132x132x60 filled by the depth
     // stream, alternating inside one process: frame 0.2226 -> 0.2065 ms).  A limit of 0 keeps every map on the one-wave variant.
     const bool wg = (c.k.ntiles < c.resample_wg_tiles || (c.sparse && c.resample_wg_tiles > 0)) && c.d.mw == 1 && c.d.slots <= 4 * RWB;
-    int ro = c.d.T <= 0 ? 3 : (c.ro_inline ? (wg ? 0 : 1) : 2);
+    int ro = c.d.T <= 0 ? 3 : (c.ro_inline ? (wg ? 0 : 1) : (c.d.tiling ? 1 : 2));   // (k_rollout's LDS windows are runs of voxel indices: index-order storage only)
     return (wg ? 1 : 0) | (ro << 1);
 }
 void kernels_init_device() {   // per device, once (dspmap_init_device)

@@ -32,7 +32,16 @@ typedef unsigned long long u64;
 struct MapDims {
     int nx, ny, nz;        // global grid
     int z_lo, z_hi;        // owned slab [z_lo, z_hi)
-    int v_loc;             // local voxel count = nx*ny*(z_hi-z_lo)
+    int v_loc;             // voxels of the STORAGE order the device arrays are indexed with (mask[lv], res4[lv], cells of tile lv >> 6): the
+                           // slab's nx*ny*(z_hi-z_lo) voxels in index order (tiling 0), or its 4x4x4 cubes, 64 voxels each, padding included (tiling 1)
+    int v_true;            // the slab's voxels: nx*ny*(z_hi-z_lo) (what the caller's arrays hold, :118-120)
+    int tiling;            // which 64 voxels share a tile (one wave, one lane per voxel): 0 = 64 consecutive voxel indices -- a run
+                           // along x --, 1 = a cube of 4 x 4 x 4 voxels: storage index = cube * 64 + (z & 3) * 16 + (y & 3) * 4 + (x & 3), cubes x-fastest.
+                           // A needle that points away from the sensor is cut by the field of view almost wherever it lies (58 % of the tiles of the
+                           // 132x132x60 map have a view, against 19 % of its cubes): cubes are what lets the two-branch frame leave most tiles alone.
+                           // Sweep keys, the caller's indices and every result array keep the reference's voxel index (:1081): lv_of_* / g_of_lv in
+                           // dspmap_device.h translate
+    int ncx, ncy, ncz;     // cubes per axis (tiling 1): ceil(nx / 4), ceil(ny / 4), ceil((z_hi - z_lo) / 4)
     int v_base;            // global index of local voxel 0 = z_lo*nx*ny
     int v_glob;            // nx*ny*nz
     int slots;             // SAFE_PARTICLE_NUM_VOXEL = 2*M  :65

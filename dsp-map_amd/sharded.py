@@ -331,6 +331,7 @@ class CppShardedRank:
         cfg = dsp.make_config(z_lo=z_lo if world > 1 else 0, z_hi=z_hi if world > 1 else 0, device=device_index, **cfg_kwargs)
         self.map = dsp.DSPMap(cfg, example_params=example_params)
         m = self.map
+        m.set_param(dsp.capi.P_TILING, 0)   # (the sharded frame's kernels take the slab in index order; a one-rank "slab" is the whole map)
         m._chk(m.L.dspmap_init_device(m.h))
         idb = (C.c_char * 128)()
         if rank == 0:
@@ -365,6 +366,7 @@ class CppGroup:
         for (z_lo, z_hi) in self.ranges:
             cfg = dsp.make_config(z_lo=z_lo, z_hi=z_hi, device=device_index, **cfg_kwargs)
             m = dsp.DSPMap(cfg, example_params=example_params)
+            m.set_param(dsp.capi.P_TILING, 0)   # (index-order storage: see CppShardedRank)
             m._chk(m.L.dspmap_init_device(m.h))
             self.maps.append(m)
         self.L = self.maps[0].L

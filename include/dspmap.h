@@ -169,6 +169,12 @@ enum dspmap_param {
                                        would split their placement (DSPMAP_P_PLACE_SPLIT_TILES), 0 = never (the serial frame of rounds 1-5), 1 = whenever
                                        the frame allows it (any size; what the differential tests force).  Same result slot for slot.  The environment
                                        variable DSPMAP_FRAME_BRANCHES presets it */
+    DSPMAP_P_TILING = 27,           /* which 64 voxels share a tile of the particle store (one wave, one lane per voxel): 0 = 64 consecutive voxel indices (a run along
+                                       x; rounds 1-5), 1 = a cube of 4 x 4 x 4 voxels, -1 (default) = cubes on unsharded maps large enough for the two-branch
+                                       frame, runs otherwise.  A run that points away from the sensor is cut by the field of view almost wherever it lies (58 %
+                                       of the 132x132x60 map's runs have a view, 19 % of its cubes).  Settable only before the handle's first use (read: the
+                                       order in use); sharded handles (Z-slabs) keep index order.  Results, state records and sweep order are the reference's
+                                       whatever the storage: the same result slot for slot.  The environment variable DSPMAP_TILING presets it */
     DSPMAP_P_PAIR_CULL_SIGMAS = 13  /* mapUpdate evaluates a (particle, observation) pair only if their ranges differ by at most this many
                                        sigma_ob (default 9: the dropped terms are < 1e-19 and zero on the fixed-point Ck grid);
                                        a huge value evaluates every pair of the neighbourhood like the reference's loops */
@@ -275,6 +281,10 @@ int dspmap_debug_sweep_probe(dspmap_t* m, int what, int rows, int rows_per_batch
 /* diagnostics: out[t] = 1 if a particle inside 64-voxel tile t could lie in the field of view of the last frame
  * (the conservative box test behind DSPMAP_P_PLACE_SPLIT_TILES); returns the number of tiles or an error */
 int dspmap_debug_tile_view(dspmap_t* m, int* out, int cap);
+/* diagnostics: the number of 64-voxel tiles of this handle's storage, and the tile each of n voxels (GLOBAL indices of the reference, :1081) lives
+ * in (-1: not in this handle's slab).  A tile is a run of 64 voxel indices or a cube of 4 x 4 x 4 voxels (DSPMAP_P_TILING) */
+int dspmap_debug_tile_count(dspmap_t* m);
+int dspmap_debug_tile_of_voxels(dspmap_t* m, int n, const int* voxel_global_host, int* tile_out_host);
 /* diagnostics: out[t] = the "somebody moves" flag of 64-voxel tile t: 0 = every live particle of the tile had velocity (0, 0)
  * when k_predict last swept it and nothing with a velocity has arrived or been born there since -- the sweeps of such a tile do
  * not fetch its velocity rows (k_predict).  Returns the number of tiles or an error */

@@ -404,8 +404,8 @@ def test_sparse_sweep_variant_changes_nothing(dsp, quat):
                 m.clearOccupancyMapPrediction()
     assert moved > 2000
     assert maps[0].get_param(dsp.capi.P_SPARSE_SWEEP) == 1 and maps[1].get_param(dsp.capi.P_SPARSE_SWEEP) == 0
-    live_tiles = (maps[0].export_state()[0] // 64)
-    assert len(np.unique(live_tiles)) < 0.5 * (cfg["nx"] * cfg["ny"] * cfg["nz"] // 64)    # the map IS mostly empty tiles
+    live_tiles = maps[0].tile_of(maps[0].export_state()[0])
+    assert len(np.unique(live_tiles)) < 0.5 * maps[0].tile_count()    # the map IS mostly empty tiles
     ref = maps[0].export_state()
     for m in maps[1:]:
         for a, b in zip(ref, m.export_state()):

@@ -269,7 +269,7 @@ def test_sparse_prediction_sweep_against_oracle(dsp, orc, name):
     vo, so, ro, rg = _slot_exact(o, m)
     c = m.counters()
     assert c["n_moved"] > 0.3 * c["n_live_in"] and c["n_live_in"] > 0.8 * n
-    assert len(np.unique(vo >> 6)) < 0.6 * (m.V // 64)                             # the map IS mostly empty tiles
+    assert len(np.unique(m.tile_of(vo))) < 0.6 * m.tile_count()                    # the map IS mostly empty tiles
     assert c["n_fov"] == int((o.pyramid_lists[:, :, 0] & 1).sum())
     o.close(); m.close()
 
@@ -665,7 +665,7 @@ def test_static_tiles_skip_their_velocity_rows_until_a_mover_arrives_or_is_born(
         mv = m.tile_moving() != 0
         # the flag is exactly "holds a particle with a velocity" wherever it is 0, and set wherever a mover sits
         has_mover = np.zeros(len(mv), bool)
-        has_mover[np.unique(vo[(ro[:, 1] != 0) | (ro[:, 2] != 0)] >> 6)] = True
+        has_mover[np.unique(m.tile_of(vo[(ro[:, 1] != 0) | (ro[:, 2] != 0)]))] = True
         assert not (has_mover & ~mv).any(), f
         assert (~mv).mean() > 0.8, (f, mv.mean())
         seen_moving |= has_mover
@@ -708,7 +708,7 @@ def test_static_tiles_skip_their_velocity_rows_until_a_mover_arrives_or_is_born(
     assert frac > 0.99, frac
     mv = m.tile_moving() != 0
     has_mover = np.zeros(len(mv), bool)
-    has_mover[np.unique(vg[(rg[:, 1] != 0) | (rg[:, 2] != 0)] >> 6)] = True
+    has_mover[np.unique(m.tile_of(vg[(rg[:, 1] != 0) | (rg[:, 2] != 0)]))] = True
     assert not (has_mover & ~mv).any()
     o.close(); m.close()
 

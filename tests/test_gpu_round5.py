@@ -45,7 +45,7 @@ def test_unpredicted_newborns_with_a_velocity_keep_it_in_a_tile_of_static_partic
             assert (ro[movers, 0] == 15.0).all()          # nobody has predicted them yet: flag and velocity as imported
         mv = m.tile_moving() != 0
         has_mover = np.zeros(len(mv), bool)
-        has_mover[np.unique(vo[movers] >> 6)] = True
+        has_mover[np.unique(m.tile_of(vo[movers]))] = True
         assert not (has_mover & ~mv).any(), f             # no tile that holds a velocity carries the "all static" flag
         o.occupancy_resample(); m.occupancy_resample()
         _slot_exact(o, m, cols=(1, 2, 4, 5, 6))

@@ -1,26 +1,44 @@
-"""GPU parity tests added in round 6 (run with `-m gpu`): the TWO-BRANCH frame (DSPMAP_P_FRAME_BRANCHES: the part of the map the sensor
-can see runs prediction -> placement -> mapUpdate -> births -> resampling on the main stream, the rest of the map prediction ->
-placement -> resampling beside it on a forked branch) changes nothing -- small maps that force it against the serial frame, every
-slot and every float, and the 132x132x60 map at its full size."""
+"""GPU parity tests added in round 6 (run with `-m gpu`): CUBE STORAGE (DSPMAP_P_TILING: a tile of the particle store is a cube of
+4 x 4 x 4 voxels instead of a run of 64 voxel indices) and the TWO-BRANCH frame on top of it (DSPMAP_P_FRAME_BRANCHES: the part of the
+map the sensor can see runs prediction -> placement -> mapUpdate -> births -> resampling on the main stream, the rest of the map
+prediction -> placement -> resampling beside it on a second stream) change nothing -- small maps that force them against the
+index-order serial frame of rounds 1-5, every slot and every float, and the 132x132x60 map at its full size."""
 import numpy as np
 import pytest
 import torch
 
 from tests import common
-from tests.test_gpu_round5 import _equal_maps
+
+
+def _snapshot(m):
+    """everything a map reports after a frame, read ONCE (reading the future status clears it, :420-424)"""
+    c = m.counters()
+    return (m.export_state(), m.results(), m.getFutureStatus(),
+            {k: c[k] for k in ("n_live_in", "n_moved", "n_out_of_map", "n_voxel_full", "n_pyramid_full", "n_born", "n_live_out", "n_reslotted", "n_fov")}, c)
+
+
+def _same(a, b, what):
+    for x, y in zip(a[0], b[0]):
+        assert np.array_equal(x, y), what              # every particle: voxel, slot, the eight floats of its record
+    assert np.array_equal(a[1], b[1]), what            # voxels_objects_number[v][0..3]
+    assert np.array_equal(a[2], b[2]), what            # the future status
+    assert a[3] == b[3], (what, a[3], b[3])
 
 pytestmark = pytest.mark.gpu
 
 UP = (0.70710678, 0.0, -0.70710678, 0.0)
 
 
-def _pair(dsp, cfg, estimator=0, extra=None):
-    """two maps of one configuration: [0] forced to run its frames as two branches, [1] the serial frame; both on the one-wave-per-tile
-    resampler (the four-waves-per-tile variant of small maps has no class filter: a map that runs it keeps the serial frame)"""
+def _trio(dsp, cfg, estimator=0, extra=None):
+    """three maps of one configuration: [0] cube storage, frames forced to run as two branches; [1] cube storage, the serial frame;
+    [2] index-order storage (rounds 1-5), the serial frame.  All on the one-wave-per-tile resampler (the four-waves-per-tile variant
+    of small maps has no class filter: a map that runs it keeps the serial frame)"""
     maps = []
-    for br in (1, 0):
+    for tiling, br in ((1, 1), (1, 0), (0, 0)):
         m = dsp.DSPMap(dsp.make_config(seed=1234, **cfg))
+        m.set_param(dsp.capi.P_TILING, tiling)            # (before the device state exists)
         m.L.dspmap_init_device(m.h)
+        assert m.get_param(dsp.capi.P_TILING) == tiling
         m.set_param(dsp.capi.P_RESAMPLE_WG_TILES, 0)
         m.set_param(dsp.capi.P_FRAME_BRANCHES, br)
         assert m.get_param(dsp.capi.P_FRAME_BRANCHES) == br
@@ -34,8 +52,10 @@ def _pair(dsp, cfg, estimator=0, extra=None):
 
 @pytest.mark.parametrize("case", ["saturated_step", "nearly_full_voxels", "depth_stream_estimator", "two_words_overfull_lists",
                                   "moving_fill_turning", "depth_stream_static_tags", "sparse_sweep_variant"])
-def test_two_branch_frame_changes_nothing(dsp, case):
-    """DSPMAP_P_FRAME_BRANCHES (round 6).  The reference's frame is four sweeps over every voxel (:300-322).  Here k_tile_class cuts the
+def test_cube_storage_and_two_branch_frame_change_nothing(dsp, case):
+    """DSPMAP_P_TILING + DSPMAP_P_FRAME_BRANCHES (round 6).  Storage: the device arrays are indexed tile by tile; with cubes for tiles the
+    voxel -> (tile, lane) map changes, the reference's voxel index (:1081) stays what orders sweeps (source keys) and what every result
+    and state record carries.  Frame:  The reference's frame is four sweeps over every voxel (:300-322).  Here k_tile_class cuts the
     tiles of a dense large map into Q -- a newborn of this frame can land there (:871-873: the observation's voxel row, grown by the
     position table's largest value, touches the field of view), which includes every tile in which a particle can be registered in a
     pyramid -- and P -- a particle of the tile can reach a Q tile this frame (:665-667: |od| + dt * the largest speed the map has ever
@@ -63,7 +83,7 @@ def test_two_branch_frame_changes_nothing(dsp, case):
         cfg = dict(nx=66, ny=66, nz=40, res=0.15, ppv=24)
     if case == "sparse_sweep_variant":
         extra[dsp.capi.P_SPARSE_SWEEP] = 1
-    maps = _pair(dsp, cfg, estimator=2 if case == "depth_stream_estimator" else 0, extra=extra)
+    maps = _trio(dsp, cfg, estimator=2 if case == "depth_stream_estimator" else 0, extra=extra)
     res = cfg["res"]
     if case in ("depth_stream_estimator", "depth_stream_static_tags", "sparse_sweep_variant"):
         sc = scene_mod.CorridorScene(66 * 0.15, 66 * 0.15, 40 * 0.15, seed=1234, device="cuda")
@@ -128,14 +148,18 @@ def test_two_branch_frame_changes_nothing(dsp, case):
             npts = 0 if (case == "nearly_full_voxels" and f == 0) else pts.shape[0]   # (that case: no births before its state is written)
             assert m.update_device(pts.data_ptr(), npts, pos, f / 30.0, q) == 1
         if f % every == every - 1:
-            sa, ca = _equal_maps(maps[0], maps[1], f)
+            snaps = [_snapshot(m) for m in maps]
+            _same(snaps[1], snaps[2], (f, "cube storage against index-order storage"))
+            _same(snaps[0], snaps[2], (f, "... and the two-branch frame on top of it"))
+            ca = snaps[0][4]
             for k in tot:
                 tot[k] += ca[k]
-        for m in maps:
-            m.clearOccupancyMapPrediction()
+        if f % every != every - 1:
+            for m in maps:
+                m.clearOccupancyMapPrediction()
     br = [m.frame_branches() for m in maps]
     print(case, tot, "branches", br)
-    assert br[0][0] == len(frames) and br[1][0] == 0, br          # every frame of map 0 ran as two branches, none of map 1
+    assert br[0][0] == len(frames) and br[1][0] == 0 and br[2][0] == 0, br   # every frame of map 0 ran as two branches, none of the others
     assert 0 < br[0][1] <= br[0][2] <= br[0][3], br                # Q inside P inside the map
     assert tot["n_moved"] > 2000 and tot["n_born"] > 100, tot
     if case == "saturated_step":
@@ -158,17 +182,19 @@ def test_two_branch_frame_changes_nothing(dsp, case):
 
 def test_two_branch_frame_changes_nothing_at_config_c_full_size(dsp):
     """the same at the size the branches are built for: 132x132x60 @ 0.15 m, every voxel seeded with 24 particles (the benchmark's
-    C_sat), the depth stream's clouds and poses; map 0 runs what the handle chooses by itself (two branches), map 1 the serial
-    frame.  Results, future status and counters every frame, every slot and float of the ~17 M particles after the last one."""
+    C_sat), the depth stream's clouds and poses; map 0 runs what the handle chooses by itself (cube storage, two branches), map 1
+    index-order storage and the serial frame.  Results, future status and counters every frame, every slot and float of the ~17 M particles after the last one."""
     scene_mod = __import__("dsp-map_amd.scene", fromlist=["CorridorScene"])
     cfg = dict(nx=132, ny=132, nz=60, res=0.15, ppv=24)
     maps = []
-    for br in (-1, 0):
+    for tiling, br in ((-1, -1), (0, 0)):
         m = dsp.DSPMap(dsp.make_config(seed=1234, **cfg))
+        m.set_param(dsp.capi.P_TILING, tiling)
         m.L.dspmap_init_device(m.h)
         m.set_param(dsp.capi.P_FRAME_BRANCHES, br)
         m.seed_uniform(24, 0.01, 99)
         maps.append(m)
+    assert maps[0].get_param(dsp.capi.P_TILING) == 1 and maps[1].get_param(dsp.capi.P_TILING) == 0
     sc = scene_mod.CorridorScene(132 * 0.15, 132 * 0.15, 60 * 0.15, seed=1234, device="cuda")
     frames = [sc.frame(f / 30.0) for f in range(5)]
     torch.cuda.synchronize()
