@@ -375,6 +375,7 @@ def main():
         dt = time.perf_counter() - t0
         gc.enable()
         measure.host_issue_ms = t_issue / steps * 1e3
+        measure.est_path = m.estimator_path()   # (of the TIMED frames: the stage-profiled ones below keep the frame on one stream)
         cnt = m.counters()
         stage = None
         if profile:
@@ -501,7 +502,11 @@ def main():
                                                                                if args.estimator == 2 else "as a host stage (velocity_estimator.cpp)")),
                    "parallelism": "1 GPU" if not sharded_run else "%d Z-slabs (one per GPU), C++ driver: ncclSend/ncclRecv neighbour "
                                                                 "exchange + 2 small ncclAllReduce per frame on the library's stream" % world,
-                   "n_points": int(frames[-1][0].shape[0])},
+                   "n_points": int(frames[-1][0].shape[0]),
+                   # where the device estimator of the timed frames ran: own_stream (DSPMAP_P_ESTIMATOR_QUEUE), forked_shared_queue (the
+                   # fallback: no stream apart from the main stream's hardware queue in this process), forked
+                   "estimator_path": getattr(measure, "est_path", None) if (not sharded_run and not wl["sat"] and args.estimator == 2) else None,
+                   "storage": ("cubes of 4x4x4 voxels" if m.get_param(D.capi.P_TILING) == 1 else "runs of 64 voxel indices") if not sharded_run else "runs of 64 voxel indices"},
         "roofline": roof,
         "host_enqueue_ms_per_step": round(getattr(measure, "host_issue_ms", 0.0), 5),
         "frame": {"b_alg_bytes": int(balg), "b_alg_GBps": round(balg / (ms * 1e-3) / 1e9, 3),
@@ -532,6 +537,12 @@ def main():
                 "frames_per_s": round(40 / dt2, 2), "ms_per_step": round(ms2, 4),
                 "b_alg_bytes": int(b2), "b_alg_GBps": round(b2 / (ms2 * 1e-3) / 1e9, 2),
                 "frac_of_8TBps": round(b2 / (ms2 * 1e-3) / 1e9 / peak, 5),
+                # how saturated "saturated" is when the timed frames end: live particles over V x M (the fill erodes from frame to frame: 24 per
+                # voxel are seeded, pyramid lists and the resampler's n_after = M cap take their share); every figure of this block depends on it
+                "fill_n_live_over_VM": round(c2["n_live_in"] / float(V2 * w2["ppv"]), 4),
+                "frames": {"prefill": 3, "warmup": 5, "steps": 40},
+                "storage": "cubes of 4x4x4 voxels" if m2.get_param(D.capi.P_TILING) == 1 else "runs of 64 voxel indices",
+                "frame": "two branches" if m2.frame_branches()[0] > 0 else "serial",
                 "roofline": roofline_block(st2, c2, V2, T2, 1, traffic_db, "C_sat", peak, traffic_meta, getattr(measure, "event_overhead_ms", 0.0)),
                 "stage_ms": {k: round(v, 5) for k, v in st2.items()},
                 "counters": {k: c2[k] for k in COUNTER_KEYS}}
@@ -548,6 +559,16 @@ def main():
             result["saturated_132x132x60"]["ceilings"] = ct
             m2.close()
             del fr2
+            # the same map FRESHLY seeded: the first timed frame sees all 24 particles per voxel (SURVEY 8(d)'s 25.09 M), no untimed frame before it
+            m3, fr3, dt3, c3, _ = measure(w2, 8, 0, 0, profile=False)
+            b3 = b_alg(c3, m3.V_local, m3.T)
+            result["saturated_132x132x60"]["freshly_seeded"] = {
+                "what": "8 timed frames straight after the seeding (prefill 0, warmup 0: the first frame also pays the frame's first-use set-up)",
+                "ms_per_step": round(dt3 / 8 * 1e3, 4), "n_live_in_last_frame": int(c3["n_live_in"]),
+                "fill_n_live_over_VM": round(c3["n_live_in"] / float(m3.V_local * w2["ppv"]), 4),
+                "frac_of_8TBps_on_last_frames_b_alg": round(b3 / (dt3 / 8) / 1e9 / peak, 5)}
+            m3.close()
+            del fr3
         except Exception as e:  # the extra line must never break the contract line
             result["saturated_132x132x60"] = {"error": repr(e)}
 
@@ -685,7 +706,9 @@ def main():
                         "resident in HBM)" % len(host[30:]),
                 "ratio_to_device_resident": round((1.0 / dth) / fps, 4),
                 "frames_per_s": round(1.0 / dth, 1), "ms_per_frame": round(dth * 1e3, 4),
-                "h2d_bytes_per_frame": int(host[-1][0].nbytes)}
+                "h2d_bytes_per_frame": int(host[-1][0].nbytes), "estimator_path": mh.estimator_path()}
+            # the boundary's own call beside `value` in the line's first level (the contract keeps `value` for inputs resident in HBM)
+            result["value_host_pointer_update"] = round(1.0 / dth, 1)
             mh.close()
             del frh, host
         except Exception as e:

@@ -100,6 +100,7 @@ SIGNATURES = {
     "dspmap_debug_rollout_paths": (_i, [_P, C.POINTER(C.c_longlong)]),
     "dspmap_debug_estimator_queue": (_i, [_P, C.POINTER(C.c_longlong)]),
     "dspmap_debug_frame_branches": (_i, [_P, C.POINTER(C.c_longlong)]),
+    "dspmap_debug_estimator_path": (_i, [_P]),
     "dspmap_debug_tile_count": (_i, [_P]),
     "dspmap_debug_tile_of_voxels": (_i, [_P, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dspmap_debug_tile_moving": (_i, [_P, C.POINTER(C.c_int), _i]),
@@ -274,6 +275,10 @@ class DSPMap:
         out = (C.c_longlong * 5)()
         self._chk(self.L.dspmap_debug_frame_branches(self.h, out))
         return tuple(int(v) for v in out)
+
+    def estimator_path(self):
+        """where the last device-estimator frame ran the estimator: 'own_stream', 'forked_shared_queue' (the fallback), 'forked', or None"""
+        return {0: None, 1: "own_stream", 2: "forked_shared_queue", 3: "forked"}.get(self.L.dspmap_debug_estimator_path(self.h))
 
     def tile_count(self):
         return self.L.dspmap_debug_tile_count(self.h)

@@ -182,6 +182,8 @@ extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
     if (const char* e = getenv("DSPMAP_USE_GRAPH")) { m->use_graph = atoi(e) == 1; m->direct_ring = atoi(e) == 2; }
     if (const char* e = getenv("DSPMAP_ESTIMATOR_QUEUE")) m->est_queue = atoi(e) != 0;
     if (const char* e = getenv("DSPMAP_XQ_TEST_DELAY_US")) m->xq_test_delay_us = std::max(0, std::min(atoi(e), 100000));
+    m->xq_test_break = getenv("DSPMAP_XQ_TEST_BREAK") != nullptr;   // (test hooks are read HERE, once: never in a frame)
+    if (const char* e = getenv("DSPMAP_XQ_FORCE")) m->xq_force = !strcmp(e, "shared") ? 1 : (!strcmp(e, "apart") ? 2 : 0);
     if (const char* e = getenv("DSPMAP_TILING")) m->tiling_req = atoi(e) < 0 ? -1 : (atoi(e) != 0 ? 1 : 0);
     if (const char* e = getenv("DSPMAP_FRAME_BRANCHES")) m->frame_branches = atoi(e) < 0 ? -1 : (atoi(e) != 0 ? 1 : 0);
     if (const char* e = getenv("DSPMAP_RESAMPLE_WG_TILES")) { const long v = atol(e); if (v >= 0) m->resample_wg_tiles = (int)std::min(v, 2000000000l); }
@@ -349,7 +351,7 @@ int dspmap_ensure_point_cap(dspmap* m, int n) {
     HIPCHK(m, dalloc(&m->k.part_birth, ((size_t)cap * 32 + 255) / 256 * 2));
     HIPCHK(m, hipMemset(m->k.part_birth, 0, sizeof(int) * (((size_t)cap * 32 + 255) / 256 * 2)));
     m->pt_cap = cap; m->birth_cap = cap;
-    if (m->cring_host && m->cring_cap < cap) {   // (the stream is idle: synchronised above) the cloud ring follows the capacity
+    if (m->cring_host && m->cring_cap < std::min(cap, m->ve.cap)) {   // (the stream is idle: synchronised above) the cloud ring follows the capacity, up to what the device estimator takes
         (void)hipHostFree(m->cring_host);
         m->cring_host = nullptr; m->cring_dev = nullptr; m->cring_cap = 0;
     }
@@ -436,8 +438,9 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     k.ro_rec = k.mv_rec;   // k_predict's staging area is dead once k_predict has ended: k_resample -> k_rollout reuse it
     HIPCHK(m, dalloc(&k.ro_cnt, 2 * ntiles));   // [ntiles] counts, then [ntiles] the float bits of the tiles' moving weight
     HIPCHK(m, hipMemset(k.ro_cnt, 0, sizeof(int) * 2 * ntiles));
-    HIPCHK(m, dalloc(&k.ro_stat, 2 * ((ntiles + 7) / 8)));
-    HIPCHK(m, hipMemset(k.ro_stat, 0, sizeof(int) * 2 * ((ntiles + 7) / 8)));
+    const size_t n_ro_wg = (size_t)rollout_groups(d, (int)ntiles) * (d.tiling ? 4 : 1);   // workgroups of k_rollout
+    HIPCHK(m, dalloc(&k.ro_stat, 2 * n_ro_wg));
+    HIPCHK(m, hipMemset(k.ro_stat, 0, sizeof(int) * 2 * n_ro_wg));
     kernels_init_device();
     HIPCHK(m, dalloc(&k.omask, W));
     HIPCHK(m, hipMemset(k.omask, 0, sizeof(u64) * W));
@@ -585,7 +588,11 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
             m->use_vel_est = (int)v; break;
         case DSPMAP_P_USE_GRAPH: m->use_graph = v == 1; m->direct_ring = v == 2; break;
         case DSPMAP_P_HOST_CLOUD_DIRECT: m->host_direct = v != 0; break;
-        case DSPMAP_P_ESTIMATOR_QUEUE: m->est_queue = v != 0; break;   // (part of the captured frame's key)
+        case DSPMAP_P_ESTIMATOR_QUEUE:   // (part of the captured frame's key)
+            m->est_queue = v != 0;
+            m->xq_failed = false;        // (setting the switch, either way, forgets an earlier give-up)
+            if (m->hint_host) m->hint_host[3] = 0;
+            break;
         case DSPMAP_P_FRAME_BRANCHES: m->frame_branches = v < 0 ? -1 : (v != 0 ? 1 : 0); m->graph_epoch++; break;
         case DSPMAP_P_TILING:
             if (m->device_ready) return dspmap_fail(m, DSPMAP_E_STATE, "DSPMAP_P_TILING must be set before the device state is allocated");
@@ -740,6 +747,22 @@ static void fill_pose(dspmap* m, const float dp[3], float dt) {
     m->hp.dt = dt;
     m->hp.res_filter = m->voxel_filter_res;
     m->hp.birth_reach = m->ptab_max;
+}
+
+// A cross-queue wait of an earlier frame gave up (DSPMAP_P_ESTIMATOR_QUEUE; bounded at 200 ms: a contended GPU, a debugger): that frame ran
+// WITHOUT its birth stage (k_birth_insert returns when it finds the give-up word: no partial birth cloud is consumed).  Checked by every frame
+// entry point BEFORE anything of the handle is touched: the call that finds the note fails once, with the state as the failed frame left
+// it, and the handle goes on with the estimator as a forked branch of the graph (xq_failed) -- until the state is cleared or restored or
+// the switch is set again.
+int dspmap_check_estimator_queue(dspmap* m) {
+    if (!m->hint_host || m->hint_host[3] == 0) return DSPMAP_OK;
+    const int at = m->hint_host[3] - 1;
+    (void)hipStreamSynchronize(m->stream);
+    if (m->stream3) (void)hipStreamSynchronize(m->stream3);
+    m->hint_host[3] = 0;
+    m->xq_failed = true;
+    m->graph_epoch++;
+    return dspmap_fail(m, DSPMAP_E_DEVICE, "estimator queue: a cross-queue wait gave up at ring position %d; that frame ran without its birth stage, the handle continues with the estimator inside the captured frame (DSPMAP_P_ESTIMATOR_QUEUE)", at);
 }
 
 // C0 gate + deltas, update() :187-218.  returns 1 (accepted) / 0 (rejected)
@@ -1079,13 +1102,19 @@ void dspmap_ring_pushed(dspmap* m) {
 // (so that the next one lands elsewhere) and another is tried.  (A high stream priority -- its own pool of hardware queues -- was the first fix:
 // with such a stream alive, graph replays WITH a forked branch ran 0.15 ms longer, 132x132x60 saturated + device estimator 0.58 -> 0.73 ms, and
 // forking into a prioritised stream during capture crashed the runtime.)
+// When NO candidate is apart from the main stream's hardware queue (seen in processes that had created hundreds of streams), the handle does
+// not take a shared one (0.214 instead of 0.151 ms per frame at the metric's size): m->xq_shared is set and its frames keep the estimator as
+// a forked branch of the captured graph (device_frame).  Test hooks (DSPMAP_XQ_FORCE, read at dspmap_create): "shared" = every candidate counts
+// as sharing the queue (the fallback is what runs), "apart" = a handle that finds no candidate apart fails loudly instead of falling back.
 static int ensure_estimator_stream(dspmap* m, const LaunchCtx& c) {
+    if (m->xq_shared && m->stream3_for == m->stream) return DSPMAP_OK;   // (tested before, for this main stream: nothing apart)
     if (m->stream3 && m->stream3_for == m->stream) return DSPMAP_OK;
+    m->xq_shared = false;
     if (m->stream3) { HIPCHK(m, hipStreamSynchronize(m->stream3)); (void)hipStreamDestroy(m->stream3); m->stream3 = nullptr; }
     HIPCHK(m, hipStreamSynchronize(m->stream));
-    hipStream_t aside[6]; int n_aside = 0;
     hipStream_t good = nullptr;
-    for (int attempt = 0; attempt < 6 && !good; ++attempt) {
+    hipStream_t aside[16]; int n_aside = 0;
+    for (int attempt = 0; attempt < (m->xq_force == 2 ? 16 : 6) && !good; ++attempt) {
         hipStream_t cand = nullptr;
         HIPCHK(m, hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
         LaunchCtx cm = c; cm.stream = m->stream;
@@ -1093,14 +1122,17 @@ static int ensure_estimator_stream(dspmap* m, const LaunchCtx& c) {
         launch_spin(cm, 2000);
         launch_spin(cs, 1);
         HIPCHK(m, hipStreamSynchronize(cand));
-        const bool apart = hipStreamQuery(m->stream) == hipErrorNotReady;
+        const bool apart = hipStreamQuery(m->stream) == hipErrorNotReady && m->xq_force != 1;
         (void)hipGetLastError();
         HIPCHK(m, hipStreamSynchronize(m->stream));
         if (apart) good = cand; else aside[n_aside++] = cand;
     }
-    if (!good) good = aside[--n_aside];   // (every candidate shared the main stream's queue: slower, still correct)
     for (int i = 0; i < n_aside; ++i) (void)hipStreamDestroy(aside[i]);
     m->stream3 = good; m->stream3_for = m->stream;
+    if (!good) {   // every candidate shared the main stream's hardware queue: the estimator stays a forked branch of the graph
+        m->xq_shared = true;
+        if (m->xq_force == 2) return dspmap_fail(m, DSPMAP_E_DEVICE, "estimator queue: no stream apart from the main stream's hardware queue (DSPMAP_XQ_FORCE=apart)");
+    }
     return DSPMAP_OK;
 }
 
@@ -1133,8 +1165,6 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
     LaunchCtx c = dspmap_ctx_of(m);
     const bool has_vz = m->vz_frames > 0;
     if (!has_vz) c.s.vz0 = nullptr;
-    if (m->hint_host && m->hint_host[3] != 0)
-        return dspmap_fail(m, DSPMAP_E_DEVICE, "estimator queue: a cross-queue wait gave up at ring position %d (DSPMAP_P_ESTIMATOR_QUEUE)", m->hint_host[3] - 1);
     // birth cloud: the caller's (0), synthesised from the view (1: every point in view a static source), or the device
     // velocity estimator's (2)
     const int mode = birth_dev ? 0 : (est_dev ? 2 : 1);
@@ -1150,8 +1180,14 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
     m->frame_ring = (m->use_graph || m->direct_ring) && !m->prof && m->ring_host != nullptr;
     // the estimator on a queue of its own (DSPMAP_P_ESTIMATOR_QUEUE): replayed frames with the device estimator whose graph would otherwise fork
     // for it alone -- a split placement / early registration keeps its side branch, and the estimator on it
-    const bool xq = m->est_queue && m->xq_dev && mode == 2 && m->frame_ring && (m->birth_cap + 15) / 16 + 1 <= DSPMAP_XQ_LIST && !frame_splits_placement(m, c, false) && !frame_runs_two_branches(m, c, false);
+    bool xq = m->est_queue && !m->xq_failed && m->xq_dev && mode == 2 && m->frame_ring && (m->birth_cap + 15) / 16 + 1 <= DSPMAP_XQ_LIST && !frame_splits_placement(m, c, false) && !frame_runs_two_branches(m, c, false);
+    if (xq) {   // ... and only on a stream that does not share the main stream's hardware queue (tested once per main stream)
+        const int rs = ensure_estimator_stream(m, c);
+        if (rs != DSPMAP_OK) return rs;
+        if (m->xq_shared) xq = false;
+    }
     if (xq) c.s.xq = m->xq_dev;
+    if (mode == 2) m->est_path = xq ? 1 : ((m->est_queue && m->xq_shared) ? 2 : 3);
     if (m->frame_ring) {
         const unsigned q = (m->ring_head / (DSPMAP_RING / 4)) % 4;
         if (m->ring_head % (DSPMAP_RING / 4) == 0 && m->ring_ev_set[q]) HIPCHK(m, hipEventSynchronize(m->ring_ev[q]));
@@ -1164,7 +1200,7 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
             // mapped cloud ring and k_obs_points fetches it over the bus with the parameter block -- the graph launch below is
             // the only thing queued for the frame
             if (!m->cring_host) {
-                m->cring_cap = m->pt_cap;
+                m->cring_cap = std::max(1, std::min(m->pt_cap, m->ve.cap));   // (this path only carries clouds the device estimator takes: <= ve.cap points; 64 slots x 12 B each)
                 HIPCHK(m, hipHostMalloc((void**)&m->cring_host, sizeof(float) * 3 * (size_t)m->cring_cap * DSPMAP_CLOUD_RING, hipHostMallocMapped));
                 void* dp2 = nullptr;
                 HIPCHK(m, hipHostGetDevicePointer(&dp2, m->cring_host, 0));
@@ -1207,10 +1243,9 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
             // another entry point -- a pre-processed cloud, an import, new cursors, a frame of another kind --, or on a stream the caller
             // owns and may have queued the cloud's producer on).  The frame's first birth kernel waits for k_ve_clusters' word.  Every wait
             // is for work queued EARLIER, whatever hardware queues the two streams share: nothing to deadlock on.
-            { const int rs = ensure_estimator_stream(m, c); if (rs != DSPMAP_OK) return rs; }
             LaunchCtx c2 = c;
             c2.stream = m->stream3;
-            if (getenv("DSPMAP_XQ_TEST_BREAK")) m->xq_break = true;
+            if (m->xq_test_break) m->xq_break = true;
             const bool chained = m->own_stream && !m->xq_break && m->xq_chain_api + 1 == m->api_seq;
             m->xq_break = false;
             if (!chained) {
@@ -1290,6 +1325,7 @@ extern "C" int dspmap_update_device(dspmap_t* m, int n_points, const float* poin
                                     const float q[4]) {
     READY(m);
     if (n_points < 0 || (n_points > 0 && !points_dev) || !pos || !q) return dspmap_fail(m, DSPMAP_E_ARG, "bad arguments");
+    { const int rq = dspmap_check_estimator_queue(m); if (rq != DSPMAP_OK) return rq; }
     float dp[3], dt;
     if (!dspmap_gate_and_delta(m, pos, stamp, q, dp, &dt)) return DSPMAP_REJECTED;
     return device_frame(m, n_points, points_dev, n_birth, birth_dev, dp, dt, q);
@@ -1361,6 +1397,7 @@ extern "C" int dspmap_update(dspmap_t* m, int n, int stride, const float* pts, f
                              double stamp, float qw, float qx, float qy, float qz) {
     READY(m);
     if (n > 0 && (!pts || stride < 3)) return dspmap_fail(m, DSPMAP_E_ARG, "bad point cloud arguments");
+    { const int rq = dspmap_check_estimator_queue(m); if (rq != DSPMAP_OK) return rq; }
     const float pos[3] = {sx, sy, sz};
     const float q[4] = {qw, qx, qy, qz};
     float dp[3], dt;
@@ -1567,6 +1604,9 @@ extern "C" int dspmap_clear_state(dspmap_t* m) {
     HIPCHK(m, hipMemsetAsync(m->s.pyr_cnt, 0, sizeof(int) * d.np, m->stream));
     HIPCHK(m, hipMemsetAsync(&m->s.fs->vmax_bits, 0, sizeof(int), m->stream));   // (no particle, no speed)
     HIPCHK(m, hipStreamSynchronize(m->stream));
+    if (m->stream3) HIPCHK(m, hipStreamSynchronize(m->stream3));
+    if (m->hint_host) m->hint_host[3] = 0;   // a new state: an earlier frame's give-up on the estimator's queue is history (also: dspmap_load_checkpoint)
+    m->xq_failed = false;
     m->have_last = false;
     if (m->nb_dirty) { m->nb_dirty = false; m->graph_epoch++; }
     return DSPMAP_OK;
@@ -1852,6 +1892,10 @@ extern "C" int dspmap_debug_estimator_queue(dspmap_t* m, long long out[6]) {
     out[0] = m->xq_frames; out[1] = w[0]; out[2] = w[1]; out[3] = m->hint_host ? m->hint_host[3] : 0; out[4] = w[6]; out[5] = w[7];
     return DSPMAP_OK;
 }
+extern "C" int dspmap_debug_estimator_path(dspmap_t* m) {
+    if (!m) return DSPMAP_E_ARG;
+    return m->est_path;
+}
 extern "C" int dspmap_debug_rollout_paths(dspmap_t* m, long long out[3]) {
     READY(m);
     if (!out) return DSPMAP_E_ARG;
@@ -1859,7 +1903,7 @@ extern "C" int dspmap_debug_rollout_paths(dspmap_t* m, long long out[3]) {
     out[0] = m->last_resample_variant; out[1] = 0; out[2] = 0;
     const int ro = m->last_resample_variant >> 1;
     if (ro == 1 || ro == 2) {   // k_rollout ran: its groups' counts
-        const size_t ng = ((size_t)m->k.ntiles + 7) / 8;
+        const size_t ng = (size_t)rollout_groups(m->d, m->k.ntiles) * ((m->d.tiling && ro == 2) ? 4 : 1);   // workgroups of that launch
         std::vector<int> st(2 * ng);
         HIPCHK(m, hipMemcpy(st.data(), m->k.ro_stat, sizeof(int) * 2 * ng, hipMemcpyDeviceToHost));
         for (size_t g = 0; g < ng; ++g) { out[1] += st[2 * g]; out[2] += st[2 * g + 1]; }

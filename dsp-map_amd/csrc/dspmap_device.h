@@ -471,6 +471,11 @@ __device__ __forceinline__ void xq_wait(int* word, int want, int* gave_up) {
             if (wall_clock64() - t0 > 20000000ll) { *gave_up = want; break; }
             __builtin_amdgcn_s_sleep(4);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
+    // ALWAYS an acquire (one lane: it invalidates this CU's L1, nothing is written back -- the cost that mattered was the release's): a
+    // workgroup that finds the word set at its first look may still hold lines of the other queue's data from before they were written
+    // (the word can arrive between this kernel's launch-time invalidate and the look), ADVICE r5
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
+// the same for a workgroup that only LOOKS (no wait): call after a look that found the word ready, before reading the other queue's data
+__device__ __forceinline__ void xq_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }

@@ -88,6 +88,7 @@ struct dspmap_dist {
     volatile int* pub = nullptr;        // host view [4][4]
     int* pub_dev = nullptr;             // device view
     unsigned frame_no = 0;              // frames begun
+    unsigned pub_seen = 0;         // frame index + 1 of the published slot phase_begin consumed last (each slot counts once)
     int xsend_hist[4] = {0, 0, 0, 0};   // message size of the last frames
     float dz_hist[4] = {0.f, 0.f, 0.f, 0.f};   // |vertical step| of the last frames
     int nb_hi = 0;                      // longest birth cloud so far (span of the n_static all-reduce)
@@ -166,13 +167,13 @@ __global__ void __launch_bounds__(256) k_dist_import(MapDims d, const float* __r
     bool gone = false;
     if (i < n) {
         const float* r = msg + 8 * (size_t)(i + 1);
-        const int nlv = __float_as_int(r[0]) - d.v_base;
+        const int nlv = __float_as_int(r[0]) - d.v_base;   // (slabs keep index-order storage: the local index IS the storage index)
         if (nlv >= 0 && nlv < d.v_loc) {
             const int tile = nlv >> 6, cap = 64 * d.slots;
             const int pos = atomicAdd(&in_cnt[tile], 1);   // beyond cap: k_place counts it as "voxel full"
             if (pos < cap) {
                 const size_t o = ((size_t)tile * cap + pos) * 2;
-                in_rec[o] = make_float4(r[0], r[1], r[2], r[3]);
+                in_rec[o] = make_float4(__int_as_float(nlv), r[1], r[2], r[3]);   // (.x of an inbox record: the destination's STORAGE index, like k_predict's own)
                 in_rec[o + 1] = make_float4(r[4], r[5], r[6], r[7]);
             }
         } else if (fwd) {
@@ -448,13 +449,17 @@ static int phase_begin(dspmap* m, int n_points, const float* points_dev, int n_b
         }
         const int g = sl[0];
         x->gcnt_max = sl[1];
-        if (g > x->xsend_hist[f & 3u]) ++x->overflow_frames;   // that frame's messages were too small: particles were lost
+        // (a frame that the gate rejects returns below without advancing frame_no: the same slot is looked at again by the next call --
+        // its overflow and its crossing ratio are taken into account ONCE)
+        const bool fresh = x->pub_seen != f + 1u;
+        x->pub_seen = f + 1u;
+        if (fresh && g > x->xsend_hist[f & 3u]) ++x->overflow_frames;   // that frame's messages were too small: particles were lost
         // what crossed a face per unit of vertical step in THAT frame: vz == 0, so a frame's exports follow its own |dz| -- the size of
         // this frame's message is derived from ITS step below, not from that count (round 5: a message sized from the last frame's exports
         // alone shrank to its floor after a frame without vertical motion and lost the particles of the next frame that had one)
         const double steps = (double)x->dz_hist[f & 3u] / m->d.res;
         const double layer_cells = (double)m->d.nx * m->d.ny * m->d.slots;
-        if (steps * layer_cells >= 1.0) x->xratio = std::max((double)g / (steps * layer_cells), 0.9 * x->xratio);
+        if (fresh && steps * layer_cells >= 1.0) x->xratio = std::max((double)g / (steps * layer_cells), 0.9 * x->xratio);
     }
     {   // room for the cloud and for the two extra slots of the n_static all-reduce
         const int rcap = dspmap_ensure_point_cap(m, std::max(n_points, n_birth) + 3);

@@ -94,6 +94,13 @@ struct dspmap {
     int xq_last_seq = 0;
     bool xq_break = false;           // this call has queued work on the handle's stream that the frame's estimator depends on (a staged cloud, the
                                      // estimator's state handed over from the host): its kernels are ordered behind the stream with an event
+    bool xq_test_break = false;      // DSPMAP_XQ_TEST_BREAK (test hook, read at dspmap_create): every frame's estimator is ordered behind the stream with an event
+    int xq_force = 0;                // DSPMAP_XQ_FORCE (test hook, read at dspmap_create): 1 "shared" = every candidate stream counts as sharing the main stream's
+                                     // hardware queue, 2 "apart" = fail instead of falling back when none is apart
+    bool xq_shared = false;          // no stream apart from the main stream's hardware queue was found (ensure_estimator_stream): frames keep the forked branch
+    bool xq_failed = false;          // a cross-queue wait gave up (dspmap_check_estimator_queue): frames keep the forked branch
+    int est_path = 0;                // the last device-estimator frame: 1 on its own stream, 2 forked branch because the stream would share the queue,
+                                     // 3 forked branch (switched off / the map splits its placement / after a give-up); 0 none yet
     int xq_test_delay_us = 0;        // DSPMAP_XQ_TEST_DELAY_US (test hook): every third frame's estimator is held back this long, so that the
                                      // frame's first birth kernel finds its word missing and takes the deferral path
     long long xq_frames = 0;         // frames whose estimator ran that way (dspmap_debug_estimator_queue)
@@ -177,6 +184,7 @@ void dspmap_prof_collect(dspmap* m);
 LaunchCtx dspmap_ctx_of(dspmap* m);
 void dspmap_resample(dspmap* m, const LaunchCtx& c);   // launch_resample + bookkeeping of the variant it ran
 int dspmap_gate_and_delta(dspmap* m, const float pos[3], double stamp, const float q[4], float dp[3], float* dt);
+int dspmap_check_estimator_queue(dspmap* m);   // first thing in every frame entry point: fails once if an earlier frame's cross-queue wait gave up
 void dspmap_freeze_birth_statics(dspmap* m);
 int dspmap_ensure_point_cap(dspmap* m, int n);
 int dspmap_push_frame_params(dspmap* m);

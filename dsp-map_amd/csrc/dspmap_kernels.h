@@ -117,6 +117,7 @@ void launch_birth_plan_insert(const LaunchCtx& c, int n_birth, bool in_frame, bo
 void launch_birth_materialize(const LaunchCtx& c, BirthSrc* out, int cap, int* n_out);   // the frame's synthesised birth cloud, for host readback
 // mapOccupancyCalculationAndResample (:924-1057)
 void launch_resample(const LaunchCtx& c, int cls = 0, bool with_rollout = true);   // + the future rollout of the moving particles (k_rollout)
+int rollout_groups(const MapDims& d, int ntiles);   // workgroup groups of k_rollout (KernelScratch::ro_stat holds 2 ints per workgroup: x 4 with cube storage and windows)
 void launch_rollout(const LaunchCtx& c);    // the rollout alone (a two-branch frame: once, behind both branches' resampling)
 int resample_variant(const LaunchCtx& c);   // bit 0: k_resample_wg; bits 1-2: rollout 0 inline, 1 k_rollout light, 2 k_rollout windows, 3 none
 void kernels_init_device();                 // function attributes of the current device (dynamic LDS of k_rollout)

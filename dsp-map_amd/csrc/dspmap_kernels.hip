@@ -1284,6 +1284,12 @@ template <bool FUSED>
 __global__ void __launch_bounds__(256) k_birth_insert(MapDims d, DevState s, FilterParams fp, const float4* __restrict__ child,
                                const int* __restrict__ vb_cnt, const int* __restrict__ vb_idx, int* __restrict__ part_birth,
                                const u64* __restrict__ nbsnap, int wg_off) {
+    // (DSPMAP_P_ESTIMATOR_QUEUE) the frame's first birth kernel gave up waiting for the estimator's queue: the birth cloud is not complete
+    // and nothing of it is inserted -- the frame ends without a birth stage, the host fails its next call (dspmap_check_estimator_queue)
+    if (s.xq && s.fpar->from_ring && __hip_atomic_load(s.xq + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)(s.fpar->ring_pos + 1u)) {
+        if (threadIdx.x < 2) part_birth[blockIdx.x * 2 + threadIdx.x] = 0;
+        return;
+    }
     const BirthView bv = birth_view(s);
     const int n_birth = bv.n;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1637,11 +1643,21 @@ __global__ void __launch_bounds__(1024) k_birth_split_cksum_cvr(MapDims d, DevSt
                 __hip_atomic_fetch_add(s.xq + XQ_DEC + ((int)blockIdx.x & (XQ_NDEC - 1)) * 64, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (!ready) return;
+            // found ready at the first look: the word may have arrived after this kernel's launch-time invalidate -- one lane's acquire
+            // (L1 invalidate, no write-back) before anybody of the workgroup reads what the other queue wrote
+            if (threadIdx.x == 0) xq_acquire();
+            __syncthreads();
         } else {
             // workgroup 0: waits if it has to, does its own share, and then -- ALWAYS: another workgroup may have looked before the word
             // arrived although this one looked after -- makes sure every workgroup has decided and does the listed shares
             __syncthreads();
-            if (threadIdx.x == 0 && !ready) xq_wait(s.xq + 1, want, s.hint_out + 3);
+            if (threadIdx.x == 0 && !ready) {
+                xq_wait(s.xq + 1, want, s.hint_out + 3);
+                // gave up: the birth cloud is NOT complete -- this frame's insertion is called off (k_birth_insert looks at the word), the
+                // host fails its next call and goes on without the estimator's queue (dspmap_check_estimator_queue)
+                if (__hip_atomic_load(s.xq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0)
+                    __hip_atomic_store(s.xq + 8, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             __syncthreads();
             birth_split_cvr_block<CHILDREN>(d, s, fp, wg_off, child, vb_cnt, vb_idx, 0, s_c, s_red);
             __syncthreads();

@@ -1710,12 +1710,24 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
     // seen) takes the single-atomic path for every particle -- same result.
     // ro_stat[2 * group + {0, 1}] = contributions this group sent through its windows / straight to the accumulators (diagnostics:
     // which path ran; summed on request, no atomics here)
+    // CUBE storage (MapDims::tiling): a group is up to RO_G cubes of ONE row of cubes -- 32 x 4 voxels, four layers deep; a particle stays
+    // in its layer (vz == 0), so the windows are planar: with the LDS windows, FOUR workgroups share a group, one per layer (blockIdx & 3;
+    // each reads the group's records and keeps its layer's), and horizon t's window is the rectangle of (32 + 2 h) x (4 + 2 h) voxels
+    // around the group in that layer.  Without windows (LIGHT) one workgroup per group takes every record.
     extern __shared__ unsigned s_win[];
     __shared__ int s_cnt[RO_G + 1];
     __shared__ float s_wtot;
     __shared__ int s_stat[2];
-    const int G0 = (int)blockIdx.x * RO_G;
-    const int ng = min(RO_G, ntiles - G0);
+    const bool cubes = d.tiling != 0;
+    const bool split = cubes && !LIGHT;
+    const int gpr = (d.ncx + RO_G - 1) / RO_G;                       // groups per row of cubes
+    const int grp = split ? (int)blockIdx.x >> 2 : (int)blockIdx.x;
+    const int sub = split ? (int)blockIdx.x & 3 : -1;                // this workgroup's layer inside the cubes
+    const int crow = cubes ? grp / gpr : 0, gx = cubes ? grp - crow * gpr : 0;   // row of cubes (cz * ncy + cy), group inside it
+    const int G0 = cubes ? crow * d.ncx + gx * RO_G : grp * RO_G;
+    const int ng = cubes ? min(RO_G, d.ncx - gx * RO_G) : min(RO_G, ntiles - G0);
+    const int wx0 = gx * RO_G * 4, wy0 = cubes ? (crow % d.ncy) * 4 : 0;   // the group's first voxel column / row
+    const int wzl = cubes ? (crow / d.ncy) * 4 + max(sub, 0) : 0;          // this workgroup's layer (relative to the slab)
     const int tid = threadIdx.x;
     if (tid < RO_G) s_cnt[tid] = tid < ng ? ro_cnt[G0 + tid] : 0;
     __syncthreads();
@@ -1744,7 +1756,7 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
         a = ro_rec[o]; b = ro_rec[o + 1];
     };
     // (a window cell is 32 bits wide and can receive at most the group's whole moving weight: windows only while that fits)
-    const bool dense = !LIGHT && !d.tiling && total >= RO_DENSE && s_wtot < FUT_WINDOW_MAX_W;   // (the windows are runs of voxel indices: index-order storage only)
+    const bool dense = !LIGHT && total >= RO_DENSE && s_wtot < FUT_WINDOW_MAX_W;
     const int ncell = pl.woff[T];
     if (dense) for (int i = tid; i < ncell; i += TPB) s_win[i] = 0u;
     __syncthreads();
@@ -1759,6 +1771,7 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             if (it0 + u * TPB >= total) continue;
+            if (split && ((__float_as_int(b[u].y) >> 4) & 3) != sub) continue;   // another layer's workgroup takes this record
             const int zl = layer_of_lv(d, __float_as_int(b[u].y));   // the particle's layer: it never changes (vz == 0)
             wq[u] = (unsigned)fut_quantum(b[u].x);   // (dense: below 2^32 because the group's sum is)
             for (int t = 0; t < T; ++t) {
@@ -1770,7 +1783,11 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
                 const int yi = (int)div_res(d, fy + d.half_y);
                 const int dl = lv_of_xyz(d, xi, yi, zl);
                 if (dl < 0 || dl >= d.v_loc) continue;
-                const int off = dl - (G0 * 64 - pl.halo[t] * d.nx);
+                int off;
+                if (cubes) {   // the rectangle of (32 + 2 h) x (4 + 2 h) voxels around the group, row-major
+                    const int h = pl.halo[t], ww = RO_G * 4 + 2 * h, wx = xi - (wx0 - h), wy = yi - (wy0 - h);
+                    off = ((unsigned)wx < (unsigned)ww && (unsigned)wy < (unsigned)(4 + 2 * h)) ? wy * ww + wx : -1;
+                } else off = dl - (G0 * 64 - pl.halo[t] * d.nx);
                 if (dense && off >= 0 && off < pl.woff[t + 1] - pl.woff[t]) { atomicAdd(&s_win[pl.woff[t] + off], wq[u]); ++n_win; }
                 else { fut_add(&s.fut[(size_t)t * V + dl], fut_quantum(b[u].x)); s.fut_dirty[dl >> 6] = 1; ++n_dir; }
             }
@@ -1783,6 +1800,18 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
     if (!dense) return;
     for (int t = 0; t < T; ++t) {
         const int w0 = pl.woff[t], wn = pl.woff[t + 1] - w0;
+        if (cubes) {
+            const int h = pl.halo[t], ww = RO_G * 4 + 2 * h;
+            for (int i = tid; i < wn; i += TPB) {
+                const unsigned q = s_win[w0 + i];
+                if (q) {   // (only cells of voxels inside the map ever receive anything)
+                    const int wy = i / ww, wx = i - wy * ww;
+                    const int dl = lv_of_xyz(d, wx0 - h + wx, wy0 - h + wy, wzl);
+                    fut_add(&s.fut[(size_t)t * V + dl], (u64)q); s.fut_dirty[dl >> 6] = 1;
+                }
+            }
+            continue;
+        }
         const int g0 = G0 * 64 - pl.halo[t] * d.nx;   // local voxel index of the window's first cell (cells outside the slab stay zero)
         for (int i = tid; i < wn; i += TPB) {
             const unsigned q = s_win[w0 + i];
@@ -2271,7 +2300,7 @@ int resample_variant(const LaunchCtx& c) {
     // empty: what is left is a few thousand tiles of a few hundred particles each, the metric's regime; 132x132x60 filled by the depth
     // stream, alternating inside one process: frame 0.2226 -> 0.2065 ms).  A limit of 0 keeps every map on the one-wave variant.
     const bool wg = (c.k.ntiles < c.resample_wg_tiles || (c.sparse && c.resample_wg_tiles > 0)) && c.d.mw == 1 && c.d.slots <= 4 * RWB;
-    int ro = c.d.T <= 0 ? 3 : (c.ro_inline ? (wg ? 0 : 1) : (c.d.tiling ? 1 : 2));   // (k_rollout's LDS windows are runs of voxel indices: index-order storage only)
+    int ro = c.d.T <= 0 ? 3 : (c.ro_inline ? (wg ? 0 : 1) : 2);
     return (wg ? 1 : 0) | (ro << 1);
 }
 void kernels_init_device() {   // per device, once (dspmap_init_device)
@@ -2302,6 +2331,9 @@ void launch_resample(const LaunchCtx& c, int cls, bool with_rollout) {
     }
     if (with_rollout) launch_rollout(c);
 }
+int rollout_groups(const MapDims& d, int ntiles) {   // groups of k_rollout: runs of RO_G tiles; cube storage: inside one row of cubes
+    return d.tiling ? d.ncy * d.ncz * ((d.ncx + RO_G - 1) / RO_G) : (ntiles + RO_G - 1) / RO_G;
+}
 void launch_rollout(const LaunchCtx& c) {
     const KernelScratch* k = &c.k;
     const int ro = resample_variant(c) >> 1;
@@ -2314,7 +2346,9 @@ void launch_rollout(const LaunchCtx& c) {
             for (int t = 0; t < c.d.T; ++t) {
                 pl.halo[t] = (int)ceilf(vdes * fabsf(c.d.pred_t[t]) / c.d.res) + 1;
                 pl.woff[t] = tot;
-                tot += RO_G * 64 + 2 * pl.halo[t] * c.d.nx;
+                // index-order storage: the group's 512 voxel indices and halo rows of the grid either side; cubes: the rectangle of voxels
+                // around the group's 32 x 4 in one layer (one workgroup per layer)
+                tot += c.d.tiling ? (RO_G * 4 + 2 * pl.halo[t]) * (4 + 2 * pl.halo[t]) : RO_G * 64 + 2 * pl.halo[t] * c.d.nx;
             }
             pl.woff[c.d.T] = tot;
             if (tot <= RO_LDS_CELLS || vdes < 0.02f) break;
@@ -2322,12 +2356,13 @@ void launch_rollout(const LaunchCtx& c) {
         }
         if (pl.woff[c.d.T] > RO_LDS_CELLS) {   // (a grid too wide even for one-row halos: every window collapses to the group itself)
             int tot = 0;
-            for (int t = 0; t < c.d.T; ++t) { pl.halo[t] = 0; pl.woff[t] = tot; tot += RO_G * 64; }
+            for (int t = 0; t < c.d.T; ++t) { pl.halo[t] = 0; pl.woff[t] = tot; tot += c.d.tiling ? RO_G * 4 * 4 : RO_G * 64; }
             pl.woff[c.d.T] = tot;
         }
-        if (ro == 1) hipLaunchKernelGGL((k_rollout<256, true>), dim3((k->ntiles + RO_G - 1) / RO_G), dim3(256), 0, c.stream, c.d, c.s, k->ro_rec, k->ro_cnt,
+        const unsigned ngrp = (unsigned)rollout_groups(c.d, k->ntiles);
+        if (ro == 1) hipLaunchKernelGGL((k_rollout<256, true>), dim3(ngrp), dim3(256), 0, c.stream, c.d, c.s, k->ro_rec, k->ro_cnt,
                                         k->ntiles, pl, k->ro_stat);
-        else hipLaunchKernelGGL((k_rollout<RO_TPB, false>), dim3((k->ntiles + RO_G - 1) / RO_G), dim3(RO_TPB), (size_t)pl.woff[c.d.T] * 4, c.stream, c.d, c.s, k->ro_rec, k->ro_cnt,
+        else hipLaunchKernelGGL((k_rollout<RO_TPB, false>), dim3(ngrp * (c.d.tiling ? 4u : 1u)), dim3(RO_TPB), (size_t)pl.woff[c.d.T] * 4, c.stream, c.d, c.s, k->ro_rec, k->ro_cnt,
                                 k->ntiles, pl, k->ro_stat);
     }
 }

@@ -157,11 +157,16 @@ enum dspmap_param {
     /* 24: early registration of the voxel-changing particles by the prediction sweep (round 5) -- measured slower on the maps it was
        built for and removed in round 6 (LOG.md); the value is not reused */
     DSPMAP_P_ESTIMATOR_QUEUE = 25,  /* captured frames with the device velocity estimator (DSPMAP_P_VELOCITY_ESTIMATOR = 2) on maps that do not split their
-                                       placement: 1 (default) = the estimator's kernels are launched on a hardware queue of their own and meet the
-                                       frame through two words in device memory (the prediction's first workgroup says "the binned view is complete",
-                                       the frame's first birth kernel waits for "the birth cloud is complete") -- the reference's helper thread
-                                       (:297,311) without a fork / join inside the graph, which costs ~8 us of a 147-us frame on this runtime
-                                       (tools/micro/fork_join.hip); 0 = a forked branch of the captured graph (rounds 2-5).  Same result either way */
+                                       placement: 1 (default) = the estimator's kernels are launched on a stream of their own, BEFORE the frame, and meet it
+                                       through two words in device memory: the estimator makes its own picture of the view from the frame's slot of the
+                                       parameter ring (k_ve_view) and waits only for "the PREVIOUS frame's birth stage has ended" (published by that frame's
+                                       resampling kernel: the rand() cursor and the birth buffers are the estimator's from then on); the frame's first birth
+                                       kernel waits for "the birth cloud is complete" (published by the estimator's last kernel behind a release fence).  The
+                                       reference's helper thread (:297,311) without a fork / join inside the graph, which costs ~8 us of a 147-us frame on
+                                       this runtime (tools/micro/fork_join.hip).  Every wait is for work submitted earlier and is bounded (200 ms): a wait
+                                       that gives up calls the frame's birth stage off, the next call fails once and the handle goes on with 0.  The stream
+                                       is tested not to share the main stream's hardware queue; if none is found the handle keeps 0's path
+                                       (dspmap_debug_estimator_path).  0 = a forked branch of the captured graph (rounds 2-5).  Same result either way */
     DSPMAP_P_FRAME_BRANCHES = 26,   /* whole frames of dense large maps run as TWO BRANCHES (round 6): the part of the map the sensor can see this frame -- grown by
                                        the reach of a newborn (:871-873) and by the frame's largest displacement (:665-667) -- goes through prediction,
                                        placement, mapUpdate, births and resampling on the main stream, the rest of the map (most of it: prediction,
@@ -294,10 +299,15 @@ int dspmap_debug_tile_moving(dspmap_t* m, int* out, int cap);
  * 2 k_rollout with LDS windows, 3 none; out[1] / out[2] = contributions k_rollout sent through its windows / as single atomics */
 int dspmap_debug_rollout_paths(dspmap_t* m, long long out[3]);
 /* diagnostics of DSPMAP_P_ESTIMATOR_QUEUE: out[0] = frames of this handle whose velocity estimator ran on a queue of its own, out[1] / out[2] = the
- * two hand-over words (ring position + 1 of the last frame whose prediction has started / whose birth cloud the estimator has finished),
+ * two hand-over words (ring position + 1 of the last frame whose birth stage has ended / whose birth cloud the estimator has finished),
  * out[3] = nonzero if a cross-queue wait ever gave up, out[4] = frames whose first birth kernel found the birth cloud unfinished (its workgroup 0
  * waited, the other workgroups left their shares to it), out[5] = shares it did for them */
 int dspmap_debug_estimator_queue(dspmap_t* m, long long out[6]);
+/* where the last frame with the device velocity estimator ran it: 1 = on a stream of its own (DSPMAP_P_ESTIMATOR_QUEUE), 2 = as a forked branch of the
+ * captured frame because no stream apart from the main stream's hardware queue was found (the fallback), 3 = as a forked branch (switched off, a map
+ * that splits its placement, or after a cross-queue wait gave up), 0 = no such frame yet.  Test hooks, read at dspmap_create: DSPMAP_XQ_FORCE=shared
+ * (every candidate stream counts as sharing the queue: the fallback runs), DSPMAP_XQ_FORCE=apart (fail instead of falling back) */
+int dspmap_debug_estimator_path(dspmap_t* m);
 /* diagnostics of DSPMAP_P_FRAME_BRANCHES: out[0] = frames of this handle that ran as two branches, out[1] / out[2] = tiles of class Q (a newborn of
  * the last such frame could land there) / P (a particle could reach a Q tile), out[3] = tiles of the map, out[4] = the largest speed any particle
  * of the map was ever given, mm/s (what sizes P) */

@@ -330,8 +330,8 @@ def _equal_maps(a, b, f):
     return sa, ca
 
 
-@pytest.mark.parametrize("delay_us", [0, 2000])
-def test_estimator_on_a_queue_of_its_own_changes_nothing(dsp, delay_us, monkeypatch):
+@pytest.mark.parametrize("force,delay_us", [("apart", 0), ("apart", 2000), ("shared", 0)])
+def test_estimator_on_a_queue_of_its_own_changes_nothing(dsp, force, delay_us, monkeypatch):
     """DSPMAP_P_ESTIMATOR_QUEUE (round 5): the reference forks velocityEstimationThread before the prediction and joins it before the
     birth stage (:297,311).  As a forked branch of the captured graph that costs ~8 us of the metric's 147-us frame on this runtime
     (tools/micro/fork_join.hip); with the switch on (the default) the estimator's kernels are launched on a stream of their own and
@@ -347,7 +347,12 @@ def test_estimator_on_a_queue_of_its_own_changes_nothing(dsp, delay_us, monkeypa
     off map never to have used it), both hand-over words stand at the last frame's ring position + 1, no wait gave up.
     delay_us = 2000 (test hook DSPMAP_XQ_TEST_DELAY_US): every third frame's estimator is held back 2 ms, longer than a round of the six maps' frames: the
     first birth kernel finds the cloud unfinished, only its workgroup 0 waits, the others leave their shares to it (the path that
-    keeps the machine free for the estimator's own kernels) -- verified to have run, same result."""
+    keeps the machine free for the estimator's own kernels) -- verified to have run, same result.
+    force (test hook DSPMAP_XQ_FORCE, round 6): "apart" = a handle that finds no stream apart from its main stream's hardware queue FAILS instead of
+    falling back (16 candidates are tried), so the own-stream path and, with the delay, its waiting path are asserted unconditionally;
+    "shared" = every candidate counts as sharing the queue: the handles keep the estimator as a forked branch of the captured frame (the
+    fallback a long-lived process can end up in) -- verified to be what ran, same bits."""
+    monkeypatch.setenv("DSPMAP_XQ_FORCE", force)
     if delay_us:
         monkeypatch.setenv("DSPMAP_XQ_TEST_DELAY_US", str(delay_us))
     scene_mod = __import__("dsp-map_amd.scene", fromlist=["CorridorScene"])
@@ -357,6 +362,11 @@ def test_estimator_on_a_queue_of_its_own_changes_nothing(dsp, delay_us, monkeypa
     torch.cuda.synchronize()
     maps = []
     for k in range(6):
+        # (the hooks are read when a handle is created) only the FIRST map's estimator is held back: six maps are a dozen streams on four
+        # hardware queues -- with every map spinning in the same frames, every main stream would sit behind somebody's spinner and nobody
+        # would ever be seen waiting
+        if k == 1:
+            monkeypatch.delenv("DSPMAP_XQ_TEST_DELAY_US", raising=False)
         m = dsp.DSPMap(dsp.make_config(seed=4321, **cfg))
         m.L.dspmap_init_device(m.h)
         m.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, 2)
@@ -401,15 +411,19 @@ def test_estimator_on_a_queue_of_its_own_changes_nothing(dsp, delay_us, monkeypa
             m.clearOccupancyMapPrediction()
     q_on, q_off, q_flip = on.estimator_queue(), off.estimator_queue(), flip.estimator_queue()
     print("estimator queue diagnostics (on / off / flip):", q_on, q_off, q_flip)
-    assert q_on[0] == 220 and q_on[1] == 220 and q_on[2] == 220 and q_on[3] == 0, q_on
-    assert q_off[0] == 0 and q_off[2] == 0 and q_off[3] == 0 and q_off[4] == 0, q_off
-    assert q_flip[0] == 100 and q_flip[3] == 0, q_flip            # frames 40-79, 120-159, 200-219 ran with the switch on
-    if delay_us and q_on[4] == 0:
-        # (seen once in a full-suite run, after ~140 tests had created and destroyed streams: every candidate of ensure_estimator_stream shared the
-        # main stream's hardware queue, so the held-back estimator held the frame back with it and nobody ever had to wait -- correct, slower,
-        # and nothing of the waiting path to verify in such a process)
-        print("the estimator's stream shares the main stream's hardware queue in this process: the waiting path did not run")
-    elif delay_us:
-        assert q_on[5] >= q_on[4] * 50, q_on                     # the held-back frames waited: workgroup 0 did most of the 386 shares of such a frame
+    paths = [m.estimator_path() for m in maps]
+    print("estimator paths:", paths)
+    assert q_off[0] == 0 and q_off[2] == 0 and q_off[3] == 0 and q_off[4] == 0 and paths[1] == "forked", (q_off, paths)
+    if force == "shared":
+        # the fallback: no frame of any map used a queue of its own, and the handles say why
+        assert q_on[0] == 0 and q_flip[0] == 0 and q_on[3] == 0, (q_on, q_flip)
+        assert paths[0] == paths[3] == paths[4] == paths[5] == "forked_shared_queue", paths
+    else:
+        assert q_on[0] == 220 and q_on[1] == 220 and q_on[2] == 220 and q_on[3] == 0, q_on
+        assert q_flip[0] == 100 and q_flip[3] == 0, q_flip        # frames 40-79, 120-159, 200-219 ran with the switch on
+        assert paths[0] == paths[3] == paths[4] == paths[5] == "own_stream", paths
+        if delay_us:
+            assert q_on[4] >= 50, q_on                            # every third frame's first birth kernel found the cloud unfinished ...
+            assert q_on[5] >= q_on[4] * 50, q_on                  # ... and its workgroup 0 did most of the 386 shares of such a frame
     for m in maps:
         m.close()
