@@ -388,6 +388,7 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, hipMemset(m->s.ring_seq, 0, sizeof(int)));
     HIPCHK(m, hipMalloc((void**)&m->xq_dev, (XQ_LIST + DSPMAP_XQ_LIST) * sizeof(int)));
     HIPCHK(m, hipMemset(m->xq_dev, 0, (XQ_LIST + DSPMAP_XQ_LIST) * sizeof(int)));
+    if (m->xq_test_delay_us > 0) { const int one = 1; HIPCHK(m, hipMemcpy(m->xq_dev + 10, &one, sizeof(int), hipMemcpyHostToDevice)); }   // (test hook, see queue_estimator)
     m->ring_head = 0;
     { int dev = 0, cu = 0; if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) m->n_cu = cu; }
     HIPCHK(m, hipEventCreate(&m->ev0));
@@ -1253,6 +1254,9 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
                 HIPCHK(m, hipStreamWaitEvent(m->stream3, m->ev_fork, 0));
             }
             const int seq = (int)(m->hp.ring_pos + 1u);
+            // (test hook: every third frame's estimator is held back by the clock; in the same handles the frame's first birth kernel takes
+            // every third frame's cloud for unfinished at its first look whatever the clock says -- DevState::xq[10] -- so that the
+            // one-waiting-workgroup / deferred-shares path runs in a known set of frames whichever hardware queues the streams share)
             if (m->xq_test_delay_us > 0 && m->xq_frames % 3 == 1) launch_spin(c2, m->xq_test_delay_us);
             launch_velocity_estimator_xq(c2, true, m->ring_dev + (m->ring_head % DSPMAP_RING), m->xq_dev, m->s.hint_out + 3, chained ? m->xq_last_seq : 0, seq);
             m->xq_last_seq = seq;

@@ -208,15 +208,18 @@ __device__ __forceinline__ void pyr_sort_block(const MapDims& d, const DevState&
                     const unsigned k = k_u[u];
                     if (ps == npass - 1 || (k >> (shift + 13)) == (prefix >> (shift + 13))) bin = (int)((k >> shift) & 8191u);
                 }
-                // the keys of a pyramid share their high bits: one LDS atomic per distinct bin of a wavefront, not one per lane
-                u64 todo = __ballot(bin >= 0);
-                while (todo) {
-                    const int leader = __ffsll((long long)todo) - 1;
-                    const int bk = __shfl(bin, leader, WAVE);
-                    const u64 grp = __ballot(bin == bk);
-                    if (lane_id() == leader) atomicAdd(&s_sel[bk], (int)__popcll(grp));
-                    todo &= ~grp;
-                }
+                // the keys of a pyramid share their HIGH bits: in the first pass one LDS atomic per distinct bin of a wavefront, not one
+                // per lane; the lower digits scatter over the 8192 bins -- there the grouping loop would run once per lane (round 6)
+                if (ps == npass - 1) {
+                    u64 todo = __ballot(bin >= 0);
+                    while (todo) {
+                        const int leader = __ffsll((long long)todo) - 1;
+                        const int bk = __shfl(bin, leader, WAVE);
+                        const u64 grp = __ballot(bin == bk);
+                        if (lane_id() == leader) atomicAdd(&s_sel[bk], (int)__popcll(grp));
+                        todo &= ~grp;
+                    }
+                } else if (bin >= 0) atomicAdd(&s_sel[bin], 1);
                 }
             }
             __syncthreads();
@@ -343,7 +346,11 @@ __device__ __forceinline__ void pyr_items_block(const MapDims& d, const DevState
                                                 int* __restrict__ n_items, int* __restrict__ nb_tab);
 // k_pyr_prepare: what the pair kernels need once per frame, in one launch: workgroups 0 .. np-1 order the pyramid lists,
 // the last workgroup expands the work-item lists and neighbourhood tables (the two are independent of each other).
-__global__ void __launch_bounds__(1024) k_pyr_prepare(MapDims d, DevState s, int* __restrict__ ck_items, int* __restrict__ wu_items,
+// (two workgroups per CU -- 64 registers: the 448 pyramids + 1 are ONE round of workgroups on 256 CUs; measured -2.4 us at 132x132x60
+// saturated, round 6.  Also tried in round 6 and dropped: the list's keys and range buckets held in registers across the passes -- one
+// read of the list instead of one per pass -- needs 2 x 14 registers per thread at that size on top of the passes' own: one workgroup
+// per CU and spills, 37.8 against 13 us on lists that need no selection, LOG.md)
+__global__ void __launch_bounds__(1024, 8) k_pyr_prepare(MapDims d, DevState s, int* __restrict__ ck_items, int* __restrict__ wu_items,
                                                       int* __restrict__ n_items, int* __restrict__ nb_tab) {
     if ((int)blockIdx.x == d.np) pyr_items_block(d, s, ck_items, wu_items, n_items, nb_tab);
     else pyr_sort_block(d, s, (int)blockIdx.x);
@@ -1520,7 +1527,7 @@ void launch_pyr_prepare(const LaunchCtx& c) {
     hipLaunchKernelGGL(k_pyr_prepare, dim3(c.d.np + 1), dim3(1024), 0, c.stream, c.d, c.s, c.k.ck_items, c.k.wu_items, c.k.n_items, c.k.nb_tab);
 }
 void launch_ck_partial(const LaunchCtx& c, bool prepared, bool with_fix) {
-    if (!prepared) hipLaunchKernelGGL(k_pyr_prepare, dim3(c.d.np + 1), dim3(1024), 0, c.stream, c.d, c.s, c.k.ck_items, c.k.wu_items, c.k.n_items, c.k.nb_tab);
+    if (!prepared) launch_pyr_prepare(c);
     hipLaunchKernelGGL(k_ck_partial, dim3(4096 + PF_WG), dim3(CK_TPB), (sizeof(float4) + sizeof(int)) * (size_t)c.d.nbins * DSP_OBS_CAP, c.stream, c.d, c.s, c.fp, c.k.ck_items, c.k.n_items, c.k.nb_tab,
                        c.k.in_rec, c.k.omask, reinterpret_cast<const int*>(c.k.mv_rec), with_fix ? 1 : 0);
 }
@@ -1628,7 +1635,9 @@ __global__ void __launch_bounds__(1024) k_birth_split_cksum_cvr(MapDims d, DevSt
     __shared__ int s_flag;
     if (s.xq) {
         const int want = (int)(s.fpar->ring_pos + 1u);
-        if (threadIdx.x == 0) s_flag = __hip_atomic_load(s.xq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want >= 0 ? 1 : 0;
+        // (xq[10], test hook DSPMAP_XQ_TEST_DELAY_US: in every third frame every workgroup takes the cloud for unfinished at this first look --
+        // the deferral path below then runs in a known set of frames, whatever the two streams' timing; workgroup 0's wait finds the truth)
+        if (threadIdx.x == 0) s_flag = (__hip_atomic_load(s.xq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want >= 0 && !(s.xq[10] != 0 && want % 3 == 2)) ? 1 : 0;
         __syncthreads();
         const bool ready = s_flag != 0;
         if (blockIdx.x != 0) {

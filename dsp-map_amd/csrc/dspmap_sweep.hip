@@ -1683,6 +1683,8 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
 //     Destinations outside the window take the single-atomic path.
 // --------------------------------------------------------------------------
 #define RO_G 8           // tiles per workgroup: their particles share the LDS windows
+#define RO_GC 4          // cube storage: a group is RO_GC x RO_GC cubes of one layer of cubes
+#define RO_GT (RO_GC * RO_GC)   // ... = 16 tiles (>= RO_G: the group tables are sized with it)
 #define RO_DENSE 384     // moving particles in a GROUP of tiles from which the LDS windows pay
 #define RO_TPB 1024
 #define RO_LDS_CELLS 30000   // fp32 cells of all windows together (120 kB: one workgroup per CU)
@@ -1710,37 +1712,46 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
     // seen) takes the single-atomic path for every particle -- same result.
     // ro_stat[2 * group + {0, 1}] = contributions this group sent through its windows / straight to the accumulators (diagnostics:
     // which path ran; summed on request, no atomics here)
-    // CUBE storage (MapDims::tiling): a group is up to RO_G cubes of ONE row of cubes -- 32 x 4 voxels, four layers deep; a particle stays
-    // in its layer (vz == 0), so the windows are planar: with the LDS windows, FOUR workgroups share a group, one per layer (blockIdx & 3;
-    // each reads the group's records and keeps its layer's), and horizon t's window is the rectangle of (32 + 2 h) x (4 + 2 h) voxels
-    // around the group in that layer.  Without windows (LIGHT) one workgroup per group takes every record.
+    // CUBE storage (MapDims::tiling): a group is a block of RO_GC x RO_GC cubes of one layer of cubes -- 16 x 16 voxels, four layers deep
+    // (square: the least window per particle); a particle stays in its layer (vz == 0), so the windows are planar: with the LDS windows,
+    // FOUR workgroups share a group, one per layer (blockIdx & 3; each reads the group's records and keeps its layer's), and horizon t's
+    // window is the square of (16 + 2 h)^2 voxels around the group in that layer.  Without windows (LIGHT) one workgroup per group takes
+    // every record.
     extern __shared__ unsigned s_win[];
-    __shared__ int s_cnt[RO_G + 1];
+    __shared__ int s_cnt[RO_GT + 1];
+    __shared__ int s_tile[RO_GT];
     __shared__ float s_wtot;
     __shared__ int s_stat[2];
     const bool cubes = d.tiling != 0;
     const bool split = cubes && !LIGHT;
-    const int gpr = (d.ncx + RO_G - 1) / RO_G;                       // groups per row of cubes
+    const int gxn = (d.ncx + RO_GC - 1) / RO_GC, gyn = (d.ncy + RO_GC - 1) / RO_GC;   // groups per row / column of a layer of cubes
     const int grp = split ? (int)blockIdx.x >> 2 : (int)blockIdx.x;
     const int sub = split ? (int)blockIdx.x & 3 : -1;                // this workgroup's layer inside the cubes
-    const int crow = cubes ? grp / gpr : 0, gx = cubes ? grp - crow * gpr : 0;   // row of cubes (cz * ncy + cy), group inside it
-    const int G0 = cubes ? crow * d.ncx + gx * RO_G : grp * RO_G;
-    const int ng = cubes ? min(RO_G, d.ncx - gx * RO_G) : min(RO_G, ntiles - G0);
-    const int wx0 = gx * RO_G * 4, wy0 = cubes ? (crow % d.ncy) * 4 : 0;   // the group's first voxel column / row
-    const int wzl = cubes ? (crow / d.ncy) * 4 + max(sub, 0) : 0;          // this workgroup's layer (relative to the slab)
+    const int gcz = cubes ? grp / (gxn * gyn) : 0, grem = cubes ? grp - gcz * gxn * gyn : 0, gy = grem / gxn, gx = grem - gy * gxn;
+    const int G0 = cubes ? 0 : grp * RO_G;
+    const int nt_g = cubes ? RO_GT : RO_G;                           // tiles of a group (some may lie outside the map: count 0)
+    const int wx0 = gx * RO_GC * 4, wy0 = gy * RO_GC * 4;            // the group's first voxel column / row (cube storage)
+    const int wzl = gcz * 4 + max(sub, 0);                           // this workgroup's layer (relative to the slab)
     const int tid = threadIdx.x;
-    if (tid < RO_G) s_cnt[tid] = tid < ng ? ro_cnt[G0 + tid] : 0;
+    if (tid < nt_g) {
+        int bx = G0 + tid;
+        if (cubes) { const int cxk = gx * RO_GC + (tid & (RO_GC - 1)), cyk = gy * RO_GC + tid / RO_GC; bx = (cxk < d.ncx && cyk < d.ncy) ? (gcz * d.ncy + cyk) * d.ncx + cxk : -1; }
+        else if (bx >= ntiles) bx = -1;
+        s_tile[tid] = bx;
+        s_cnt[tid] = bx >= 0 ? ro_cnt[bx] : 0;
+    }
     __syncthreads();
     if (tid == 0) {
         int t = 0; float w = 0.f;
-        for (int k = 0; k < RO_G; ++k) {   // exclusive prefix of the counts; the weights in tile order
+        for (int k = 0; k < nt_g; ++k) {   // exclusive prefix of the counts; the weights in tile order
             const int c = s_cnt[k]; s_cnt[k] = t; t += c;
-            if (c > 0) w += __int_as_float(ro_cnt[ntiles + G0 + k]);
+            if (c > 0) w += __int_as_float(ro_cnt[ntiles + s_tile[k]]);
         }
-        s_cnt[RO_G] = t; s_wtot = w;
+        for (int k = nt_g; k <= RO_GT; ++k) s_cnt[k] = t;
+        s_wtot = w;
     }
     __syncthreads();
-    const int total = s_cnt[RO_G];
+    const int total = s_cnt[RO_GT];
     if (total == 0) { if (tid < 2) ro_stat[blockIdx.x * 2 + tid] = 0; return; }
     if (tid < 2) s_stat[tid] = 0;
     int n_win = 0, n_dir = 0;
@@ -1751,8 +1762,8 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
     auto rec_of = [&](int it, float4& a, float4& b) {
         int g = 0;
 #pragma unroll
-        for (int k = 1; k < RO_G; ++k) g += it >= s_cnt[k] ? 1 : 0;
-        const size_t o = ((size_t)(G0 + g) * cap + (it - s_cnt[g])) * 2;
+        for (int k = 1; k < RO_GT; ++k) g += it >= s_cnt[k] ? 1 : 0;   // (the tile whose run holds `it`: prefixes are non-decreasing; empty tiles share a value and are skipped)
+        const size_t o = ((size_t)s_tile[g] * cap + (it - s_cnt[g])) * 2;
         a = ro_rec[o]; b = ro_rec[o + 1];
     };
     // (a window cell is 32 bits wide and can receive at most the group's whole moving weight: windows only while that fits)
@@ -1784,9 +1795,9 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
                 const int dl = lv_of_xyz(d, xi, yi, zl);
                 if (dl < 0 || dl >= d.v_loc) continue;
                 int off;
-                if (cubes) {   // the rectangle of (32 + 2 h) x (4 + 2 h) voxels around the group, row-major
-                    const int h = pl.halo[t], ww = RO_G * 4 + 2 * h, wx = xi - (wx0 - h), wy = yi - (wy0 - h);
-                    off = ((unsigned)wx < (unsigned)ww && (unsigned)wy < (unsigned)(4 + 2 * h)) ? wy * ww + wx : -1;
+                if (cubes) {   // the square of (16 + 2 h)^2 voxels around the group, row-major
+                    const int h = pl.halo[t], ww = RO_GC * 4 + 2 * h, wx = xi - (wx0 - h), wy = yi - (wy0 - h);
+                    off = ((unsigned)wx < (unsigned)ww && (unsigned)wy < (unsigned)ww) ? wy * ww + wx : -1;
                 } else off = dl - (G0 * 64 - pl.halo[t] * d.nx);
                 if (dense && off >= 0 && off < pl.woff[t + 1] - pl.woff[t]) { atomicAdd(&s_win[pl.woff[t] + off], wq[u]); ++n_win; }
                 else { fut_add(&s.fut[(size_t)t * V + dl], fut_quantum(b[u].x)); s.fut_dirty[dl >> 6] = 1; ++n_dir; }
@@ -1801,7 +1812,7 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
     for (int t = 0; t < T; ++t) {
         const int w0 = pl.woff[t], wn = pl.woff[t + 1] - w0;
         if (cubes) {
-            const int h = pl.halo[t], ww = RO_G * 4 + 2 * h;
+            const int h = pl.halo[t], ww = RO_GC * 4 + 2 * h;
             for (int i = tid; i < wn; i += TPB) {
                 const unsigned q = s_win[w0 + i];
                 if (q) {   // (only cells of voxels inside the map ever receive anything)
@@ -2332,7 +2343,7 @@ void launch_resample(const LaunchCtx& c, int cls, bool with_rollout) {
     if (with_rollout) launch_rollout(c);
 }
 int rollout_groups(const MapDims& d, int ntiles) {   // groups of k_rollout: runs of RO_G tiles; cube storage: inside one row of cubes
-    return d.tiling ? d.ncy * d.ncz * ((d.ncx + RO_G - 1) / RO_G) : (ntiles + RO_G - 1) / RO_G;
+    return d.tiling ? d.ncz * ((d.ncy + RO_GC - 1) / RO_GC) * ((d.ncx + RO_GC - 1) / RO_GC) : (ntiles + RO_G - 1) / RO_G;
 }
 void launch_rollout(const LaunchCtx& c) {
     const KernelScratch* k = &c.k;
@@ -2348,7 +2359,7 @@ void launch_rollout(const LaunchCtx& c) {
                 pl.woff[t] = tot;
                 // index-order storage: the group's 512 voxel indices and halo rows of the grid either side; cubes: the rectangle of voxels
                 // around the group's 32 x 4 in one layer (one workgroup per layer)
-                tot += c.d.tiling ? (RO_G * 4 + 2 * pl.halo[t]) * (4 + 2 * pl.halo[t]) : RO_G * 64 + 2 * pl.halo[t] * c.d.nx;
+                tot += c.d.tiling ? (RO_GC * 4 + 2 * pl.halo[t]) * (RO_GC * 4 + 2 * pl.halo[t]) : RO_G * 64 + 2 * pl.halo[t] * c.d.nx;
             }
             pl.woff[c.d.T] = tot;
             if (tot <= RO_LDS_CELLS || vdes < 0.02f) break;
@@ -2356,7 +2367,7 @@ void launch_rollout(const LaunchCtx& c) {
         }
         if (pl.woff[c.d.T] > RO_LDS_CELLS) {   // (a grid too wide even for one-row halos: every window collapses to the group itself)
             int tot = 0;
-            for (int t = 0; t < c.d.T; ++t) { pl.halo[t] = 0; pl.woff[t] = tot; tot += c.d.tiling ? RO_G * 4 * 4 : RO_G * 64; }
+            for (int t = 0; t < c.d.T; ++t) { pl.halo[t] = 0; pl.woff[t] = tot; tot += c.d.tiling ? RO_GC * 4 * RO_GC * 4 : RO_G * 64; }
             pl.woff[c.d.T] = tot;
         }
         const unsigned ngrp = (unsigned)rollout_groups(c.d, k->ntiles);

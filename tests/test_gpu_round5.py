@@ -345,9 +345,11 @@ def test_estimator_on_a_queue_of_its_own_changes_nothing(dsp, force, delay_us, m
     and not waited for (the estimator's stream is ordered behind the caller's with an event then):
     every slot, every float, results and future status equal at 8 checkpoints; the on-queue path is verified to have run (and the
     off map never to have used it), both hand-over words stand at the last frame's ring position + 1, no wait gave up.
-    delay_us = 2000 (test hook DSPMAP_XQ_TEST_DELAY_US): every third frame's estimator is held back 2 ms, longer than a round of the six maps' frames: the
-    first birth kernel finds the cloud unfinished, only its workgroup 0 waits, the others leave their shares to it (the path that
-    keeps the machine free for the estimator's own kernels) -- verified to have run, same result.
+    delay_us = 2000 (test hook DSPMAP_XQ_TEST_DELAY_US, the first map only): every third frame's estimator is held back 2 ms, and -- because a
+    dozen streams on four hardware queues may well put that map's two streams behind each other, where nobody is ever seen waiting
+    (seen in full-suite runs of rounds 5 and 6) -- its first birth kernel takes every third frame's cloud for unfinished at the first
+    look whatever the clock says: only its workgroup 0 waits (for the truth), the others leave their shares to it (the path that
+    keeps the machine free for the estimator's own kernels) -- asserted to have run in at least 70 frames, same result.
     force (test hook DSPMAP_XQ_FORCE, round 6): "apart" = a handle that finds no stream apart from its main stream's hardware queue FAILS instead of
     falling back (16 candidates are tried), so the own-stream path and, with the delay, its waiting path are asserted unconditionally;
     "shared" = every candidate counts as sharing the queue: the handles keep the estimator as a forked branch of the captured frame (the
@@ -423,7 +425,7 @@ def test_estimator_on_a_queue_of_its_own_changes_nothing(dsp, force, delay_us, m
         assert q_flip[0] == 100 and q_flip[3] == 0, q_flip        # frames 40-79, 120-159, 200-219 ran with the switch on
         assert paths[0] == paths[3] == paths[4] == paths[5] == "own_stream", paths
         if delay_us:
-            assert q_on[4] >= 50, q_on                            # every third frame's first birth kernel found the cloud unfinished ...
+            assert q_on[4] >= 70, q_on                            # every third frame's first birth kernel took the cloud for unfinished ...
             assert q_on[5] >= q_on[4] * 50, q_on                  # ... and its workgroup 0 did most of the 386 shares of such a frame
     for m in maps:
         m.close()
