@@ -774,6 +774,14 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
 #ifndef PLACE_SIDE_WG
 #define PLACE_SIDE_WG 3   // workgroups per CU of the side-stream placement
 #endif
+#ifdef PLACE_PROF
+// build with DSPMAP_EXTRA_FLAGS=-DPLACE_PROF: cycle stamps of a tile's phases in k_place (tools/prof/place_prof.py)
+__device__ long long g_plprof[8 * 131072];
+extern "C" int dspmap_debug_place_prof(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_plprof), sizeof(long long) * (size_t)n); }
+#define PLSTAMP(k) do { if (threadIdx.x == 0 && BX < 131072) g_plprof[BX * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define PLSTAMP(k) do { } while (0)
+#endif
 #define PLACE_MAX 1024   // arrivals of one tile whose bucketed keys fit the LDS table; a tile that receives more (up to its
                          // capacity of 64 * slots records) keeps them in its own staging area of k_predict, which is dead by now
 template <int MW>
@@ -799,6 +807,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
     // the first 256 records stay in registers across the phases (most tiles receive fewer): requested together with the
     // occupancy words, one memory round trip
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), b0 = a0;
+    PLSTAMP(0);
     if (tid < n) { a0 = in_rec[(base + tid) * 2]; b0 = in_rec[(base + tid) * 2 + 1]; }
     for (int i = tid; i < (d.np_h + 1) * 3; i += blockDim.x) s_ph[i] = s.planes_h[i];
     for (int i = tid; i < (d.np_v + 1) * 3; i += blockDim.x) s_pv[i] = s.planes_v[i];
@@ -823,6 +832,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
     if (tid < 2) s_cnt[tid] = 0;
     int c_vf = tid == 0 ? n_all - n : 0, c_pf = 0;
     __syncthreads();
+    PLSTAMP(1);
     // bucket the arrivals' source keys by destination lane: counts, offsets, then every key into its lane's run
     for (int i = tid; i < n; i += NT) {
         const int gv = __float_as_int(i == tid ? a0.x : in_rec[(base + i) * 2].x);   // (the destination voxel's storage index)
@@ -846,6 +856,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
         else __hip_atomic_store(&gbk[o], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    PLSTAMP(2);
     for (int i0 = 0; i0 < n; i0 += NT) {
         const int i = i0 + tid;
         int key[1] = {-1}, pos[1];
@@ -942,12 +953,14 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
             if (keep) atomicOr(&s_new[(nsl >> 6) * 64 + ln], 1ull << (nsl & 63));
         }
     }
+    PLSTAMP(3);
     c_vf = wave_sum_i(c_vf); c_pf = wave_sum_i(c_pf);
     if (lane_id() == 0) {
         if (c_vf) atomicAdd(&s_cnt[0], c_vf);
         if (c_pf) atomicAdd(&s_cnt[1], c_pf);
     }
     __syncthreads();
+    PLSTAMP(4);
     if (tid < 64) {
         const int lv = BX * 64 + tid;
 #pragma unroll
@@ -959,6 +972,10 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
         if (s_cnt[0]) atomicAdd(&s.fs->n_place_vf, s_cnt[0]);   // (rare events: the frame's counts, reset with the pyramid lists)
         if (s_cnt[1]) atomicAdd(&s.fs->n_place_pf, s_cnt[1]);
     }
+    PLSTAMP(5);
+#ifdef PLACE_PROF
+    if (threadIdx.x == 0 && BX < 131072) g_plprof[BX * 8 + 6] = n;
+#endif
 }
 
 #ifndef PLACE_LB
@@ -1382,11 +1399,22 @@ __device__ __forceinline__ void rollout_direct(const MapDims& d, const DevState&
 __device__ long long g_rprof[4 * 65536];
 extern "C" int dspmap_debug_resample_prof(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rprof), sizeof(long long) * (size_t)n); }
 #endif
-#define RWB 12  // rows per wave: 4 x 12 = 48 slots, the whole tile in one batch
+#define RWB 12  // rows per wave, one occupancy word: 4 x 12 = 48 slots, the whole tile in one batch
+#define RWB2 18 // ... two occupancy words (72 slots, config E's 36 particles per voxel): 4 x 18
+// MW occupancy words per voxel (round 6: the two-word instantiation -- the depth-stream fill of the 264x264x80 map ran the one-wave
+// k_resample<2, 8> for want of it: 77 us for 0.5 M particles, profiles/r06_*).  Bit r of a voxel's words = slot r.
+template <int MW> __device__ __forceinline__ bool wbit(const u64 (&w)[MW], int r) { return ((w[MW == 1 ? 0 : (r >> 6)] >> (r & 63)) & 1ull) != 0ull; }
+template <int MW> __device__ __forceinline__ int wbelow(const u64 (&w)[MW], int r) {   // set bits below slot r
+    if (MW == 1) return (int)__popcll(w[0] & ((1ull << r) - 1ull));
+    return r < 64 ? (int)__popcll(w[0] & ((1ull << r) - 1ull)) : (int)__popcll(w[0]) + (int)__popcll(w[MW - 1] & ((1ull << (r & 63)) - 1ull));
+}
+template <int MW> __device__ __forceinline__ int wcount(const u64 (&w)[MW]) { int n = 0; for (int e = 0; e < MW; ++e) n += (int)__popcll(w[e]); return n; }
+template <int MW>
 __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int* __restrict__ part_live, int* __restrict__ vb_cnt,
                                                      float4* __restrict__ ro_rec, int* __restrict__ ro_cnt, int inline_ro) {
+    constexpr int RW = MW == 1 ? RWB : RWB2;
     extern __shared__ float s_dyn[];
-    __shared__ u64 s_surv[64], s_oldc[64];
+    __shared__ u64 s_surv[MW * 64], s_oldc[MW * 64];
     __shared__ int s_ncp[64];
     __shared__ float s_wcp[64];
     __shared__ int s_nmv;
@@ -1406,10 +1434,16 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
     const int lv = BX * 64 + l;
     const bool inr = lv < d.v_loc;
     const int t_live = s.tile_live[BX];   // (requested together with the occupancy words: one round trip)
-    u64 nb = 0ull, m = 0ull;
-    if (inr) {
-        nb = s.nbmask[lv];
-        m = s.mask[lv] | nb;  // newborns live only in nbmask until now
+    u64 nb[MW], m[MW];
+    bool any_m = false, any_nb = false;
+#pragma unroll
+    for (int e = 0; e < MW; ++e) {
+        nb[e] = 0ull; m[e] = 0ull;
+        if (inr) {
+            nb[e] = s.nbmask[(size_t)lv * MW + e];
+            m[e] = s.mask[(size_t)lv * MW + e] | nb[e];  // newborns live only in nbmask until now
+        }
+        any_m |= m[e] != 0ull; any_nb |= nb[e] != 0ull;
     }
     if (!t_live) return;   // empty since its last visit: result, buckets and lists are already zero
 #ifdef RESAMPLE_PROF
@@ -1417,8 +1451,11 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
 #endif
     if (wave == 0 && inr) vb_cnt[lv] = 0;    // birth buckets of this frame are consumed: leave them empty for the next one
     if (tid == 0) s_nmv = 0;
-    if (tid < 64) { s_surv[tid] = 0ull; s_oldc[tid] = 0ull; }
-    if (!__ballot(m != 0ull)) {  // whole tile empty (the same answer in every wave)
+    if (tid < 64) {
+#pragma unroll
+        for (int e = 0; e < MW; ++e) { s_surv[e * 64 + tid] = 0ull; s_oldc[e * 64 + tid] = 0ull; }
+    }
+    if (!__ballot(any_m)) {  // whole tile empty (the same answer in every wave)
         if (wave == 0) {
             if (inr) s.res4[lv] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (l == 0) { part_live[BX] = 0; ro_cnt[BX] = 0; s.tile_live[BX] = 0; }
@@ -1430,22 +1467,36 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
     const brsrc rs_vel = __builtin_amdgcn_make_buffer_rsrc((void*)(s.vel + 2 * tcell), 0, cells * 8, 0x00020000);
     const brsrc rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(s.w + tcell), 0, cells * 4, 0x00020000);
     // ---- phase 1: this wave's rows, all in flight together
-    const unsigned m_lo = (unsigned)m, m_hi = (unsigned)(m >> 32), nb_lo = (unsigned)nb, nb_hi = (unsigned)(nb >> 32);
-    int row[RWB];
-    V2 vv[RWB];
-    float wr[RWB];
-    float2 pq[RWB];
+    int row[RW];
+    V2 vv[RW];
+    float wr[RW];
+    float2 pq[RW];
     {
-        u64 tor = rows_of_wave<4>(wave_or_u64(m), wave);   // (at most 12 of the 48 rows)
+        // every fourth live row of the tile, starting at `wave`, counted across the occupancy words
+        u64 tor[MW];
+        int kk = 0;
 #pragma unroll
-        for (int r = 0; r < RWB; ++r) {
-            row[r] = tor ? __ffsll((long long)tor) - 1 : -1;
-            if (tor) tor &= tor - 1ull;
+        for (int e = 0; e < MW; ++e) {
+            u64 t = wave_or_u64(m[e]), mine = 0ull;
+            while (t) {
+                const u64 low = t & (~t + 1ull);
+                if ((kk & 3) == wave) mine |= low;
+                t ^= low;
+                ++kk;
+            }
+            tor[e] = mine;
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            row[r] = -1;
+#pragma unroll
+            for (int e = 0; e < MW; ++e)
+                if (row[r] < 0 && tor[e]) { row[r] = e * 64 + (__ffsll((long long)tor[e]) - 1); tor[e] &= tor[e] - 1ull; }
             const int srow = (row[r] < 0 ? 0 : row[r]) * 64;
             // only the voxel's LIVE cells are fetched: a lane whose cell is empty asks for an offset beyond the tile's descriptor --
             // the buffer unit returns 0 for it without touching memory and without a branch (a predicated load would make the
             // compiler wait before it issues the next row's).  A tile of the metric's map is 8 % full: its rows were 37 MB per launch
-            const bool cell = row[r] >= 0 && (((row[r] < 32 ? m_lo : m_hi) >> (row[r] & 31)) & 1u) != 0u;
+            const bool cell = row[r] >= 0 && wbit<MW>(m, row[r]);
             const int ln = cell ? l : (1 << 24);
             wr[r] = bl_w(rs_w, ln, srow);
             vv[r] = bl_vel(rs_vel, ln, srow);
@@ -1457,37 +1508,41 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
     }
     __syncthreads();   // (s_surv / s_oldc / s_nmv are zero)
     // which cells survive the cull (:941), per voxel
-    unsigned sv_lo = 0u, sv_hi = 0u;
+    u64 sv_mine[MW];
 #pragma unroll
-    for (int r = 0; r < RWB; ++r) {
+    for (int e = 0; e < MW; ++e) sv_mine[e] = 0ull;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
         if (row[r] < 0) continue;
-        const int rw = row[r], sh = rw & 31;
-        const bool act = (((rw < 32 ? m_lo : m_hi) >> sh) & 1u) != 0u;
-        const unsigned b = (act && !(wr[r] < 1e-3f)) ? (1u << sh) : 0u;
-        if (rw < 32) sv_lo |= b; else sv_hi |= b;
+        const int rw = row[r];
+        if (wbit<MW>(m, rw) && !(wr[r] < 1e-3f)) sv_mine[MW == 1 ? 0 : (rw >> 6)] |= 1ull << (rw & 63);
     }
-    const u64 sv_mine = ((u64)sv_hi << 32) | sv_lo;
-    if (sv_mine) atomicOr(&s_surv[l], sv_mine);
+#pragma unroll
+    for (int e = 0; e < MW; ++e) if (sv_mine[e]) atomicOr(&s_surv[e * 64 + l], sv_mine[e]);
     __syncthreads();
 #ifdef RESAMPLE_PROF2
     const long long t_sa = __builtin_readcyclecounter();
 #endif
-    const u64 surv = s_surv[l];   // the voxel's survivors, all rows
+    u64 surv[MW];   // the voxel's survivors, all rows
+#pragma unroll
+    for (int e = 0; e < MW; ++e) surv[e] = s_surv[e * 64 + l];
     const size_t ro_base = (size_t)BX * cells;
-    u64 oldc_mine = 0ull;
+    u64 oldc_mine[MW];
+#pragma unroll
+    for (int e = 0; e < MW; ++e) oldc_mine[e] = 0ull;
     float mvw = 0.f;
 #pragma unroll
-    for (int r = 0; r < RWB; ++r) {
+    for (int r = 0; r < RW; ++r) {
         if (row[r] < 0) continue;
-        const int rw = row[r], sh = rw & 31;
-        const bool on = (((rw < 32 ? sv_lo : sv_hi) >> sh) & 1u) != 0u;
-        const bool old = on && (((rw < 32 ? nb_lo : nb_hi) >> sh) & 1u) == 0u;
+        const int rw = row[r];
+        const bool on = wbit<MW>(sv_mine, rw);
+        const bool old = on && !wbit<MW>(nb, rw);
         const float vx = old ? vv[r].x : 0.f, vy = old ? vv[r].y : 0.f;
         if (on) {
-            const int j = (int)__popcll(surv & ((1ull << rw) - 1ull));   // survivors of this voxel in lower slots
+            const int j = wbelow<MW>(surv, rw);   // survivors of this voxel in lower slots
             const int c = j * 64 + l;
             cw[c] = wr[r]; cs[c] = (unsigned char)rw;
-            if (old) oldc_mine |= 1ull << j;
+            if (old) oldc_mine[MW == 1 ? 0 : (j >> 6)] |= 1ull << (j & 63);
         }
         // the rollout (:950-964) needs the MOVING old survivors: noted here, their future positions are k_rollout's job
         const bool mv = vx != 0.f || vy != 0.f;
@@ -1501,7 +1556,8 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
     }
     mvw = wave_sum_f(mvw);
     if (l == 0) s_mvw[wave] = mvw;
-    if (oldc_mine) atomicOr(&s_oldc[l], oldc_mine);
+#pragma unroll
+    for (int e = 0; e < MW; ++e) if (oldc_mine[e]) atomicOr(&s_oldc[e * 64 + l], oldc_mine[e]);
     __syncthreads();
 #ifdef RESAMPLE_PROF
     t_s1 = __builtin_readcyclecounter();
@@ -1514,7 +1570,7 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
         }
         // (the voxel's mass only: the walk needs it; mean velocity, static future mass and the result record are wave 1's job below --
         // the same sums in the same order, off this wave's chain)
-        const int n = (int)__popcll(surv);
+        const int n = wcount<MW>(surv);
         int nmax = n;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, WAVE));
@@ -1533,8 +1589,9 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
         // systematic resampling :986-1053
         int ncp = 0;
         float w_copy = 0.f;
-        u64 mfin = surv;
-        const u64 valid = valid_bits(d, 0);
+        u64 mfin[MW];
+#pragma unroll
+        for (int e = 0; e < MW; ++e) mfin[e] = surv[e];
         if (n >= 5) {
             const int n_after = n > d.M ? d.M : n;                  // :992-997
             const float w_after = __fdiv_rn(wsum, (float)n_after);  // :1000
@@ -1555,10 +1612,15 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
                         acc_new += w_after;
                         bool full = false;
                         while (acc_ori > acc_new) {                 // copy heavy particles :1021
-                            const u64 fr = ~mfin & valid;
-                            if (!full && fr) {
-                                const int fslot = __ffsll((long long)fr) - 1;
-                                mfin |= fr & (~fr + 1ull);
+                            int fslot = -1;
+                            if (!full) {
+#pragma unroll
+                                for (int e = 0; e < MW; ++e) {
+                                    const u64 fr = ~mfin[e] & valid_bits(d, e);
+                                    if (fslot < 0 && fr) { fslot = e * 64 + (__ffsll((long long)fr) - 1); mfin[e] |= fr & (~fr + 1ull); }
+                                }
+                            }
+                            if (fslot >= 0) {
                                 // the copy itself is deferred: only (source, destination) is noted here
                                 if (ncp < cpmax) s_cp[l * cpmax + ncp] = (unsigned short)((sl4[q] << 8) | fslot);
                                 ++ncp;
@@ -1570,7 +1632,7 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
                         }
                         s.w[tcell + (size_t)sl4[q] * 64 + l] = wn;   // (a store the walk does not wait for; the panels stay as wave 1 reads them)
                     } else {
-                        mfin &= ~(1ull << sl4[q]);                  // remove :1046-1049
+                        mfin[MW == 1 ? 0 : (sl4[q] >> 6)] &= ~(1ull << (sl4[q] & 63));   // remove :1046-1049
                     }
                 }
             }
@@ -1579,10 +1641,13 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
         s_ncp[l] = ncp;
         s_wcp[l] = w_copy;
         if (inr) {
-            s.mask[lv] = mfin;
-            if (nb) s.nbmask[lv] = 0ull;  // newborn flag -> 1 (:968)
+#pragma unroll
+            for (int e = 0; e < MW; ++e) {
+                s.mask[(size_t)lv * MW + e] = mfin[e];
+                if (nb[e]) s.nbmask[(size_t)lv * MW + e] = 0ull;  // newborn flag -> 1 (:968)
+            }
         }
-        const int live_out = wave_sum_i(inr ? (int)__popcll(mfin) : 0);
+        const int live_out = wave_sum_i(inr ? wcount<MW>(mfin) : 0);
         if (l == 0) {
             part_live[BX] = live_out; s.tile_live[BX] = live_out > 0 ? 1 : 0;
             if ((BX & 63) == 0 && live_out > 0) atomicAdd(&s.fs->live_acc, 1);   // (a 1-in-64 sample of the non-empty tiles: k_predict's hint)
@@ -1593,8 +1658,10 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
             // panel untouched: it stores the new weights straight to their cells).  The velocities of the entries are re-read from
             // their cells (eight at a time, warm in the L2 since phase 1; nobody writes them before phase 3): keeping them in LDS
             // beside the weights made the panels 42 kB per tile, three tiles per CU; 18 kB lets the registers decide (five)
-            const u64 oldc = s_oldc[l];
-            const int n = (int)__popcll(surv);
+            u64 oldc[MW];
+#pragma unroll
+            for (int e = 0; e < MW; ++e) oldc[e] = s_oldc[e * 64 + l];
+            const int n = wcount<MW>(surv);
             int nmax = n;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, WAVE));
@@ -1614,7 +1681,7 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     if (j0 + q < n) {
-                        if ((oldc >> (j0 + q)) & 1ull) {          // flag < 10 :944
+                        if (wbit<MW>(oldc, j0 + q)) {             // flag < 10 :944
                             ++n_old;
                             vxs += v8[q].x; vys += v8[q].y;
                             if (v8[q].x == 0.f && v8[q].y == 0.f) stat_w += w8[q];   // p + 0*t stays in this voxel for every horizon
@@ -2310,7 +2377,9 @@ int resample_variant(const LaunchCtx& c) {
     // four waves per tile: maps below the handle's tile limit -- and, whatever their size, maps the handle takes for sparse (most tiles
     // empty: what is left is a few thousand tiles of a few hundred particles each, the metric's regime; 132x132x60 filled by the depth
     // stream, alternating inside one process: frame 0.2226 -> 0.2065 ms).  A limit of 0 keeps every map on the one-wave variant.
-    const bool wg = (c.k.ntiles < c.resample_wg_tiles || (c.sparse && c.resample_wg_tiles > 0)) && c.d.mw == 1 && c.d.slots <= 4 * RWB;
+    const bool wg = (c.k.ntiles < c.resample_wg_tiles || (c.sparse && c.resample_wg_tiles > 0)) && ((c.d.mw == 1 && c.d.slots <= 4 * RWB) || (c.d.mw == 2 && c.d.slots <= 4 * RWB2 && c.k.ntiles < 32768));
+    // (two words: 139 registers, three workgroups per CU -- on the 87 120 mostly empty tiles of a depth-stream-filled 264x264x80 map the
+    // launch of four waves per EMPTY tile alone outlasts the one-wave k_resample<2, 8>: 0.441 against 0.374 ms per frame, round 6)
     int ro = c.d.T <= 0 ? 3 : (c.ro_inline ? (wg ? 0 : 1) : 2);
     return (wg ? 1 : 0) | (ro << 1);
 }
@@ -2333,7 +2402,8 @@ void launch_resample(const LaunchCtx& c, int cls, bool with_rollout) {
         // the sequential walk anyway): no k_rollout launch
         // -- unless many tiles hold hundreds of moving particles (c.ro_inline, the handle's choice from last frame's count):
         // then k_rollout's LDS windows are worth their launch (66x66x40 saturated, every particle moving: 0.11 vs 0.27 ms)
-        hipLaunchKernelGGL(k_resample_wg, dim3(k->ntiles), dim3(256), lds4, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, ro == 0 ? 1 : 0);
+        if (c.d.mw == 1) hipLaunchKernelGGL(k_resample_wg<1>, dim3(k->ntiles), dim3(256), lds4, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, ro == 0 ? 1 : 0);
+        else hipLaunchKernelGGL(k_resample_wg<2>, dim3(k->ntiles), dim3(256), lds4, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, ro == 0 ? 1 : 0);
     } else {
 #define RS_LAUNCH(MWV, RB) hipLaunchKernelGGL((k_resample<MWV, RB>), dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, c.resample_rev ? 1 : 0, cls ? k->tile_cls : nullptr, cls)
         if (c.d.mw == 1) { if (c.sparse) RS_LAUNCH(1, 8); else RS_LAUNCH(1, 4); }

@@ -98,9 +98,10 @@ def test_resample_every_one_word_variant_against_oracle(dsp, orc, name, variant)
     o.close(); m.close()
 
 
-@pytest.mark.parametrize("variant", ["wave+light", "wave+windows"])
+@pytest.mark.parametrize("variant", ["wave+light", "wave+windows", "wg+inline", "wg+windows"])
 def test_resample_two_word_variants_against_oracle(dsp, orc, variant):
-    """config E's shape (72 slots = two occupancy words: k_resample<2>) with both k_rollout variants against the oracle"""
+    """config E's shape (72 slots = two occupancy words) against the oracle: k_resample<2> with both k_rollout variants, and (round 6) the
+    four-waves-per-tile k_resample_wg<2> -- what a depth-stream-filled 264x264x80 map runs -- with its inline rollout and with k_rollout"""
     cfgkw, n_part = CONFIGS["E_80x80x12_res010_36ppv"]
     o, m = make_pair(dsp, orc, seed=5, **cfgkw)
     want = _force(m, dsp, variant)
