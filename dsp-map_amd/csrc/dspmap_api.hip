@@ -212,7 +212,7 @@ static void free_dev(dspmap* m) {
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, s.fov_rec, s.fov_slot, s.fov_key, s.fov_spos, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt, s.in_n, s.pmask, s.ta, s.dflag, s.dirty,
                     s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.ro_cnt, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
-                    s.tile_moving, m->k.ro_stat, m->k.part_predict, m->k.tile_fov, m->k.view_list, m->k.tile_cls, s.tile_live, s.fut_dirty, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf, s.birth_cvr};
+                    s.tile_moving, m->k.ro_stat, m->k.ro_sub, m->k.part_predict, m->k.tile_fov, m->k.view_list, m->k.tile_cls, s.tile_live, s.fut_dirty, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf, s.birth_cvr};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
     if (m->res_true) chk(hipFree(m->res_true), "hipFree");
     if (m->nbsnap_buf) chk(hipFree(m->nbsnap_buf), "hipFree");
@@ -439,6 +439,8 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     k.ro_rec = k.mv_rec;   // k_predict's staging area is dead once k_predict has ended: k_resample -> k_rollout reuse it
     HIPCHK(m, dalloc(&k.ro_cnt, 2 * ntiles));   // [ntiles] counts, then [ntiles] the float bits of the tiles' moving weight
     HIPCHK(m, hipMemset(k.ro_cnt, 0, sizeof(int) * 2 * ntiles));
+    HIPCHK(m, dalloc(&k.ro_sub, 4 * ntiles));
+    HIPCHK(m, hipMemset(k.ro_sub, 0, sizeof(int) * 4 * ntiles));
     const size_t n_ro_wg = (size_t)rollout_groups(d, (int)ntiles) * (d.tiling ? 4 : 1);   // workgroups of k_rollout
     HIPCHK(m, dalloc(&k.ro_stat, 2 * n_ro_wg));
     HIPCHK(m, hipMemset(k.ro_stat, 0, sizeof(int) * 2 * n_ro_wg));

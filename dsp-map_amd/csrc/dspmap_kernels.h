@@ -37,6 +37,8 @@ struct KernelScratch {
                         // flag-15 records / a second birth stage without resampling: addAParticle (:1184-1185) skips those slots
     float4* ro_rec;     // [ntiles][64*slots][2] the tile's MOVING old particles {px, py, vx, vy}, {w, local voxel} (k_resample -> k_rollout)
     int* ro_cnt;        // [2 * ntiles] per tile: records in ro_rec; then the float bits of their summed weight
+    int* ro_sub;        // [4 * ntiles] (cube storage) lengths of the four runs -- one per layer of the cube -- k_resample writes a tile's records
+                        // in; [4 t] = -1: ONE mixed run of ro_cnt[t] records (k_resample_wg)
     int* ro_stat;       // [2 * ceil(ntiles / 8)] per group of k_rollout: contributions through its LDS windows / straight to the accumulators
     int* work_list;     // [v_loc] scratch: per-voxel prefix of the constructor-seeded particles' noise ranks (k_vz_count)
     int ntiles;         // tiles of 64 voxels; k_predict / k_place run one workgroup per tile

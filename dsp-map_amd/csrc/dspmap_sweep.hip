@@ -1074,7 +1074,10 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
 // --------------------------------------------------------------------------
 template <int MW, int RBK_>
 __global__ void __launch_bounds__(256, RBK_ >= 8 ? 3 : 5) k_resample(MapDims d, DevState s, int* __restrict__ part_live, int* __restrict__ vb_cnt,
-                                                  float4* __restrict__ ro_rec, int* __restrict__ ro_cnt, int rev, const int* __restrict__ tcls, int cls) {
+                                                  float4* __restrict__ ro_rec, int* __restrict__ ro_cnt, int rev, const int* __restrict__ tcls, int cls,
+                                                  int* __restrict__ ro_sub) {
+    // ro_sub (cube storage): the tile's rollout records are written in FOUR runs, one per layer of the cube (lanes 16 s .. 16 s + 15 = layer
+    // s; run s starts at record s * 16 * slots), ro_sub[4 * tile + s] = its length: k_rollout's workgroup of layer s reads its run only
     extern __shared__ float s_dyn[];
     // (DSPMAP_P_ESTIMATOR_QUEUE) the frame's birth stage ended where this launch began: the next frame's estimator may have the rand() cursor
     // and the birth buffers
@@ -1085,6 +1088,7 @@ __global__ void __launch_bounds__(256, RBK_ >= 8 ? 3 : 5) k_resample(MapDims d, 
     unsigned short* s_cp = (unsigned short*)(s_dyn + (size_t)wave * ((64 * cpmax + 1) / 2));
     const int wq = blockIdx.x * (blockDim.x >> 6) + wave;
     const int wave_g = rev ? ((d.v_loc + 63) >> 6) - 1 - wq : wq;   // (tiles from the last one down: see k_predict)
+    const bool cubes = d.tiling != 0;
     const int lv = wave_g * 64 + l;
     if (wave_g < 0 || wave_g * 64 >= d.v_loc) return;
     int t_live, t_mov, tc;
@@ -1109,9 +1113,12 @@ __global__ void __launch_bounds__(256, RBK_ >= 8 ? 3 : 5) k_resample(MapDims d, 
     if (!__ballot(nonempty)) {  // whole tile empty
         if (inr) s.res4[lv] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (l == 0 && wave_g * 64 < d.v_loc + 63) { part_live[wave_g] = 0; ro_cnt[wave_g] = 0; s.tile_live[wave_g] = 0; }
+        if (cubes && l < 4) ro_sub[4 * wave_g + l] = 0;
         return;
     }
     int nmv = 0;   // moving old particles of the tile noted for k_rollout so far (wave-uniform)
+    int nmv_s[4] = {0, 0, 0, 0};   // (cube storage) ... per layer of the cube
+    const int sub_l = l >> 4, run_len = 16 * d.slots;
     float mvw = 0.f;   // ... and this lane's share of their weight (k_rollout scales its fixed-point windows with the total)
     const size_t ro_base = (size_t)wave_g * 64 * d.slots;
     int n = 0, n_old = 0;
@@ -1190,12 +1197,22 @@ __global__ void __launch_bounds__(256, RBK_ >= 8 ? 3 : 5) k_resample(MapDims d, 
                 for (int r = 0; r < RBK_; ++r) {
                     const u64 mb = __ballot(mv_now[r]);
                     if (mv_now[r]) {
-                        const size_t o = (ro_base + nmv + (int)__popcll(mb & lanemask_lt())) * 2;
+                        int at = nmv + (int)__popcll(mb & lanemask_lt());
+                        if (cubes) {
+                            const u64 ms = 0xffffull << (16 * sub_l);
+                            const int before = sub_l == 0 ? nmv_s[0] : (sub_l == 1 ? nmv_s[1] : (sub_l == 2 ? nmv_s[2] : nmv_s[3]));
+                            at = sub_l * run_len + before + (int)__popcll(mb & ms & lanemask_lt());
+                        }
+                        const size_t o = (ro_base + at) * 2;
                         ro_rec[o] = make_float4(mpx[r], mpy[r], vx[r], vy[r]);
                         ro_rec[o + 1] = make_float4(B.wr[r], __int_as_float(lv), 0.f, 0.f);
                         mvw += B.wr[r];
                     }
                     nmv += (int)__popcll(mb);
+                    if (cubes) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) nmv_s[q] += (int)__popcll(mb & (0xffffull << (16 * q)));
+                    }
                 }
             }
         };
@@ -1216,6 +1233,7 @@ __global__ void __launch_bounds__(256, RBK_ >= 8 ? 3 : 5) k_resample(MapDims d, 
     if (nmv) mvw = wave_sum_f(mvw);
     if (l == 0) {
         ro_cnt[wave_g] = nmv; ro_cnt[((d.v_loc + 63) >> 6) + wave_g] = __float_as_int(mvw);
+        if (cubes) { ro_sub[4 * wave_g] = nmv_s[0]; ro_sub[4 * wave_g + 1] = nmv_s[1]; ro_sub[4 * wave_g + 2] = nmv_s[2]; ro_sub[4 * wave_g + 3] = nmv_s[3]; }
         if (nmv > RO_INLINE_MAX && (wave_g & 15) == 0) atomicAdd(&s.fs->mv_acc, 16);   // (the caller's hint, from every 16th tile: with many such tiles k_rollout's LDS windows pay)
     }
     if (inr) {
@@ -1411,7 +1429,7 @@ template <int MW> __device__ __forceinline__ int wbelow(const u64 (&w)[MW], int 
 template <int MW> __device__ __forceinline__ int wcount(const u64 (&w)[MW]) { int n = 0; for (int e = 0; e < MW; ++e) n += (int)__popcll(w[e]); return n; }
 template <int MW>
 __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int* __restrict__ part_live, int* __restrict__ vb_cnt,
-                                                     float4* __restrict__ ro_rec, int* __restrict__ ro_cnt, int inline_ro) {
+                                                     float4* __restrict__ ro_rec, int* __restrict__ ro_cnt, int inline_ro, int* __restrict__ ro_sub) {
     constexpr int RW = MW == 1 ? RWB : RWB2;
     extern __shared__ float s_dyn[];
     __shared__ u64 s_surv[MW * 64], s_oldc[MW * 64];
@@ -1458,7 +1476,7 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
     if (!__ballot(any_m)) {  // whole tile empty (the same answer in every wave)
         if (wave == 0) {
             if (inr) s.res4[lv] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (l == 0) { part_live[BX] = 0; ro_cnt[BX] = 0; s.tile_live[BX] = 0; }
+            if (l == 0) { part_live[BX] = 0; ro_cnt[BX] = 0; s.tile_live[BX] = 0; if (d.tiling) ro_sub[4 * BX] = -1; }
         }
         return;
     }
@@ -1566,6 +1584,7 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
     if (wave == 0) {
         if (l == 0) {
             ro_cnt[BX] = inline_ro ? 0 : s_nmv; ro_cnt[((d.v_loc + 63) >> 6) + BX] = __float_as_int((s_mvw[0] + s_mvw[1]) + (s_mvw[2] + s_mvw[3]));
+            if (d.tiling) ro_sub[4 * BX] = -1;   // (cube storage) ONE run of records, layers mixed: k_rollout's layer workgroups pick theirs out
             if (s_nmv > RO_INLINE_MAX && (BX & 15) == 0) atomicAdd(&s.fs->mv_acc, 16);   // (the caller's hint, from every 16th tile: with many such tiles k_rollout's LDS windows pay)
         }
         // (the voxel's mass only: the walk needs it; mean velocity, static future mass and the result record are wave 1's job below --
@@ -1751,7 +1770,8 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
 // --------------------------------------------------------------------------
 #define RO_G 8           // tiles per workgroup: their particles share the LDS windows
 #define RO_GC 4          // cube storage: a group is RO_GC x RO_GC cubes of one layer of cubes
-#define RO_GT (RO_GC * RO_GC)   // ... = 16 tiles (>= RO_G: the group tables are sized with it)
+#define RO_GT (RO_GC * RO_GC)   // ... = 16 tiles
+#define RO_NE 64         // runs of records a workgroup's table holds (a power of two >= RO_G, RO_GT, 4 * RO_GT)
 #define RO_DENSE 384     // moving particles in a GROUP of tiles from which the LDS windows pay
 #define RO_TPB 1024
 #define RO_LDS_CELLS 30000   // fp32 cells of all windows together (120 kB: one workgroup per CU)
@@ -1765,7 +1785,7 @@ struct RolloutPlan {
 // The handle launches this variant while last frame's count of tiles with hundreds of moving particles is low (c.ro_inline).
 template <int TPB, bool LIGHT>
 __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const float4* __restrict__ ro_rec, const int* __restrict__ ro_cnt, int ntiles,
-                                                    RolloutPlan pl, int* __restrict__ ro_stat) {
+                                                    RolloutPlan pl, int* __restrict__ ro_stat, const int* __restrict__ ro_sub) {
     // One workgroup per group of RO_G consecutive tiles (512 voxels: a few rows of a layer).  EVERY particle is read once and
     // adds its weight to its future voxel at all T horizons (reading the particles once per horizon was what bound this kernel
     // with every particle moving: 10 x 0.5 GB at 132x132x60).  Horizon t has its own LDS window over the voxel-index range the
@@ -1781,12 +1801,15 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
     // which path ran; summed on request, no atomics here)
     // CUBE storage (MapDims::tiling): a group is a block of RO_GC x RO_GC cubes of one layer of cubes -- 16 x 16 voxels, four layers deep
     // (square: the least window per particle); a particle stays in its layer (vz == 0), so the windows are planar: with the LDS windows,
-    // FOUR workgroups share a group, one per layer (blockIdx & 3; each reads the group's records and keeps its layer's), and horizon t's
-    // window is the square of (16 + 2 h)^2 voxels around the group in that layer.  Without windows (LIGHT) one workgroup per group takes
-    // every record.
+    // FOUR workgroups share a group, one per layer (blockIdx & 3), and horizon t's window is the square of (16 + 2 h)^2 voxels around the
+    // group in that layer.  k_resample writes a tile's records in four runs, one per layer (ro_sub: their lengths), so a layer's workgroup
+    // reads ITS records only; a tile whose records came as one mixed run (k_resample_wg: ro_sub[4 t] = -1) is read whole and filtered.
+    // Without windows (LIGHT) one workgroup per group takes every record.
+    // The group's records as a table of RUNS: (first record, length); at most 64 (16 tiles x 4 layers, LIGHT on cubes)
     extern __shared__ unsigned s_win[];
-    __shared__ int s_cnt[RO_GT + 1];
-    __shared__ int s_tile[RO_GT];
+    __shared__ int s_cnt[RO_NE + 1];
+    __shared__ int s_rbase[RO_NE];
+    __shared__ u64 s_mixed;
     __shared__ float s_wtot;
     __shared__ int s_stat[2];
     const bool cubes = d.tiling != 0;
@@ -1800,38 +1823,54 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
     const int wx0 = gx * RO_GC * 4, wy0 = gy * RO_GC * 4;            // the group's first voxel column / row (cube storage)
     const int wzl = gcz * 4 + max(sub, 0);                           // this workgroup's layer (relative to the slab)
     const int tid = threadIdx.x;
-    if (tid < nt_g) {
-        int bx = G0 + tid;
-        if (cubes) { const int cxk = gx * RO_GC + (tid & (RO_GC - 1)), cyk = gy * RO_GC + tid / RO_GC; bx = (cxk < d.ncx && cyk < d.ncy) ? (gcz * d.ncy + cyk) * d.ncx + cxk : -1; }
-        else if (bx >= ntiles) bx = -1;
-        s_tile[tid] = bx;
-        s_cnt[tid] = bx >= 0 ? ro_cnt[bx] : 0;
+    const int cap = 64 * d.slots;
+    const int ne = cubes ? (split ? RO_GT : RO_NE) : RO_G;           // runs of this workgroup
+    if (tid == 0) s_mixed = 0ull;
+    __syncthreads();
+    if (tid < RO_NE) {
+        int cnt = 0, rb = 0;
+        if (tid < ne) {
+            const int k = cubes && !split ? tid >> 2 : tid, sq = cubes && !split ? tid & 3 : max(sub, 0);   // tile of the group, layer
+            int bx = G0 + k;
+            if (cubes) { const int cxk = gx * RO_GC + (k & (RO_GC - 1)), cyk = gy * RO_GC + k / RO_GC; bx = (cxk < d.ncx && cyk < d.ncy) ? (gcz * d.ncy + cyk) * d.ncx + cxk : -1; }
+            else if (bx >= ntiles) bx = -1;
+            if (bx >= 0) {
+                rb = bx * cap;
+                if (!cubes) cnt = ro_cnt[bx];
+                else if (ro_sub[4 * bx] < 0) {   // one mixed run: the layer workgroups filter it; LIGHT takes it once (as layer 0's)
+                    if (split || sq == 0) { cnt = ro_cnt[bx]; if (split && cnt > 0) atomicOr(&s_mixed, 1ull << tid); }
+                } else { cnt = ro_sub[4 * bx + sq]; rb += sq * (cap >> 2); }
+            }
+        }
+        s_cnt[tid] = cnt; s_rbase[tid] = rb;
     }
     __syncthreads();
     if (tid == 0) {
         int t = 0; float w = 0.f;
-        for (int k = 0; k < nt_g; ++k) {   // exclusive prefix of the counts; the weights in tile order
+        for (int k = 0; k < RO_NE; ++k) {   // exclusive prefix of the lengths; the weights in run order (an upper bound for a layer's share)
             const int c = s_cnt[k]; s_cnt[k] = t; t += c;
-            if (c > 0) w += __int_as_float(ro_cnt[ntiles + s_tile[k]]);
+            if (c > 0) w += __int_as_float(ro_cnt[ntiles + s_rbase[k] / cap]);
         }
-        for (int k = nt_g; k <= RO_GT; ++k) s_cnt[k] = t;
+        s_cnt[RO_NE] = t;
         s_wtot = w;
     }
     __syncthreads();
-    const int total = s_cnt[RO_GT];
+    const int total = s_cnt[RO_NE];
+    const u64 mixed = s_mixed;
     if (total == 0) { if (tid < 2) ro_stat[blockIdx.x * 2 + tid] = 0; return; }
     if (tid < 2) s_stat[tid] = 0;
     int n_win = 0, n_dir = 0;
     const int T = d.T;
-    const int cap = 64 * d.slots;
     const size_t V = (size_t)d.v_loc;
-    // particle `it` of the group -> its record
+    // particle `it` of the group -> its record (the run whose prefix interval holds `it`: the last k with s_cnt[k] <= it; prefixes are
+    // non-decreasing, empty runs share a value with their successor and are skipped); returns the run
     auto rec_of = [&](int it, float4& a, float4& b) {
         int g = 0;
 #pragma unroll
-        for (int k = 1; k < RO_GT; ++k) g += it >= s_cnt[k] ? 1 : 0;   // (the tile whose run holds `it`: prefixes are non-decreasing; empty tiles share a value and are skipped)
-        const size_t o = ((size_t)s_tile[g] * cap + (it - s_cnt[g])) * 2;
+        for (int st = RO_NE / 2; st > 0; st >>= 1) g += (s_cnt[g + st] <= it) ? st : 0;
+        const size_t o = ((size_t)s_rbase[g] + (size_t)(it - s_cnt[g])) * 2;
         a = ro_rec[o]; b = ro_rec[o + 1];
+        return g;
     };
     // (a window cell is 32 bits wide and can receive at most the group's whole moving weight: windows only while that fits)
     const bool dense = !LIGHT && total >= RO_DENSE && s_wtot < FUT_WINDOW_MAX_W;
@@ -1841,15 +1880,16 @@ __global__ void __launch_bounds__(TPB) k_rollout(MapDims d, DevState s, const fl
     for (int it0 = tid; it0 < total; it0 += TPB * 3) {   // three particles per step: their records are requested together
         float4 a[3], b[3];
         unsigned wq[3];
+        int run[3];
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-            a[u] = make_float4(0.f, 0.f, 0.f, 0.f); b[u] = a[u];
-            if (it0 + u * TPB < total) rec_of(it0 + u * TPB, a[u], b[u]);
+            a[u] = make_float4(0.f, 0.f, 0.f, 0.f); b[u] = a[u]; run[u] = 0;
+            if (it0 + u * TPB < total) run[u] = rec_of(it0 + u * TPB, a[u], b[u]);
         }
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             if (it0 + u * TPB >= total) continue;
-            if (split && ((__float_as_int(b[u].y) >> 4) & 3) != sub) continue;   // another layer's workgroup takes this record
+            if (split && ((mixed >> run[u]) & 1ull) && ((__float_as_int(b[u].y) >> 4) & 3) != sub) continue;   // (a mixed run) another layer's workgroup takes this record
             const int zl = layer_of_lv(d, __float_as_int(b[u].y));   // the particle's layer: it never changes (vz == 0)
             wq[u] = (unsigned)fut_quantum(b[u].x);   // (dense: below 2^32 because the group's sum is)
             for (int t = 0; t < T; ++t) {
@@ -2402,10 +2442,10 @@ void launch_resample(const LaunchCtx& c, int cls, bool with_rollout) {
         // the sequential walk anyway): no k_rollout launch
         // -- unless many tiles hold hundreds of moving particles (c.ro_inline, the handle's choice from last frame's count):
         // then k_rollout's LDS windows are worth their launch (66x66x40 saturated, every particle moving: 0.11 vs 0.27 ms)
-        if (c.d.mw == 1) hipLaunchKernelGGL(k_resample_wg<1>, dim3(k->ntiles), dim3(256), lds4, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, ro == 0 ? 1 : 0);
-        else hipLaunchKernelGGL(k_resample_wg<2>, dim3(k->ntiles), dim3(256), lds4, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, ro == 0 ? 1 : 0);
+        if (c.d.mw == 1) hipLaunchKernelGGL(k_resample_wg<1>, dim3(k->ntiles), dim3(256), lds4, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, ro == 0 ? 1 : 0, k->ro_sub);
+        else hipLaunchKernelGGL(k_resample_wg<2>, dim3(k->ntiles), dim3(256), lds4, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, ro == 0 ? 1 : 0, k->ro_sub);
     } else {
-#define RS_LAUNCH(MWV, RB) hipLaunchKernelGGL((k_resample<MWV, RB>), dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, c.resample_rev ? 1 : 0, cls ? k->tile_cls : nullptr, cls)
+#define RS_LAUNCH(MWV, RB) hipLaunchKernelGGL((k_resample<MWV, RB>), dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, c.resample_rev ? 1 : 0, cls ? k->tile_cls : nullptr, cls, k->ro_sub)
         if (c.d.mw == 1) { if (c.sparse) RS_LAUNCH(1, 8); else RS_LAUNCH(1, 4); }
         else { if (c.sparse) RS_LAUNCH(2, 8); else RS_LAUNCH(2, 4); }
 #undef RS_LAUNCH
@@ -2442,9 +2482,9 @@ void launch_rollout(const LaunchCtx& c) {
         }
         const unsigned ngrp = (unsigned)rollout_groups(c.d, k->ntiles);
         if (ro == 1) hipLaunchKernelGGL((k_rollout<256, true>), dim3(ngrp), dim3(256), 0, c.stream, c.d, c.s, k->ro_rec, k->ro_cnt,
-                                        k->ntiles, pl, k->ro_stat);
+                                        k->ntiles, pl, k->ro_stat, k->ro_sub);
         else hipLaunchKernelGGL((k_rollout<RO_TPB, false>), dim3(ngrp * (c.d.tiling ? 4u : 1u)), dim3(RO_TPB), (size_t)pl.woff[c.d.T] * 4, c.stream, c.d, c.s, k->ro_rec, k->ro_cnt,
-                                k->ntiles, pl, k->ro_stat);
+                                k->ntiles, pl, k->ro_stat, k->ro_sub);
     }
 }
 __global__ void k_set_live_sample(DevState s, int v) { s.fs->live_acc = v; }
