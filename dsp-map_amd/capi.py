@@ -20,7 +20,7 @@ OK, REJECTED = 1, 0
 P_POSITION_STDDEV, P_VELOCITY_STDDEV, P_OBSERVATION_STDDEV, P_NEWBORN_WEIGHT, P_NEWBORN_NUMBER, \
     P_VOXEL_FILTER_RES, P_KAPPA, P_DETECTION, P_VELOCITY_ESTIMATOR, P_REGENERATE_TABLES, P_USE_GRAPH, P_OCCLUSION_MARGIN, \
     P_PAIR_CULL_SIGMAS, P_UPDATE_TIME, P_UPDATE_COUNTER, P_PLACE_SPLIT_TILES, P_FAST_DIVISION, P_SPARSE_SWEEP, P_ROLLOUT_INLINE, \
-    P_RESAMPLE_WG_TILES, P_SWEEP_ALTERNATE, P_STATIC_TILE_SKIP, P_HOST_CLOUD_DIRECT, _P_REMOVED_24, P_ESTIMATOR_QUEUE, P_FRAME_BRANCHES, P_TILING = range(1, 28)
+    P_RESAMPLE_WG_TILES, P_SWEEP_ALTERNATE, P_STATIC_TILE_SKIP, P_HOST_CLOUD_DIRECT, _P_REMOVED_24, P_ESTIMATOR_QUEUE, P_FRAME_BRANCHES, P_TILING, P_SIDE_PLACEMENT, P_RESAMPLE_SPLIT = range(1, 30)
 
 
 class Config(C.Structure):
@@ -100,6 +100,7 @@ SIGNATURES = {
     "dspmap_debug_rollout_paths": (_i, [_P, C.POINTER(C.c_longlong)]),
     "dspmap_debug_estimator_queue": (_i, [_P, C.POINTER(C.c_longlong)]),
     "dspmap_debug_frame_branches": (_i, [_P, C.POINTER(C.c_longlong)]),
+    "dspmap_debug_resample_split_frames": (C.c_longlong, [_P]),
     "dspmap_debug_estimator_path": (_i, [_P]),
     "dspmap_debug_tile_count": (_i, [_P]),
     "dspmap_debug_tile_of_voxels": (_i, [_P, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -275,6 +276,10 @@ class DSPMap:
         out = (C.c_longlong * 5)()
         self._chk(self.L.dspmap_debug_frame_branches(self.h, out))
         return tuple(int(v) for v in out)
+
+    def resample_split_frames(self):
+        """frames whose resampling stage ran as two launches -- DSPMAP_P_RESAMPLE_SPLIT"""
+        return int(self.L.dspmap_debug_resample_split_frames(self.h))
 
     def estimator_path(self):
         """where the last device-estimator frame ran the estimator: 'own_stream', 'forked_shared_queue' (the fallback), 'forked', or None"""

@@ -74,6 +74,7 @@ LaunchCtx dspmap_ctx_of(dspmap* m) {
     }
     c.ro_inline = !m->ro_kernel;
     c.resample_wg_tiles = m->resample_wg_tiles;
+    c.side_wg = m->side_wg;
     c.sweep_rev = (m->sweep_alt < 0 ? m->k.ntiles >= 4096 : m->sweep_alt == 1) && (m->frame_parity & 1u);
     c.resample_rev = m->sweep_alt == 2 ? true : c.sweep_rev;   // 2: k_predict up, k_place down, k_resample down -- and the next k_predict starts where it ended
     return c;
@@ -186,6 +187,8 @@ extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
     if (const char* e = getenv("DSPMAP_XQ_FORCE")) m->xq_force = !strcmp(e, "shared") ? 1 : (!strcmp(e, "apart") ? 2 : 0);
     if (const char* e = getenv("DSPMAP_TILING")) m->tiling_req = atoi(e) < 0 ? -1 : (atoi(e) != 0 ? 1 : 0);
     if (const char* e = getenv("DSPMAP_FRAME_BRANCHES")) m->frame_branches = atoi(e) < 0 ? -1 : (atoi(e) != 0 ? 1 : 0);
+    if (const char* e = getenv("DSPMAP_RESAMPLE_SPLIT")) m->resample_split = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("DSPMAP_SIDE_PLACEMENT")) { const int iv = atoi(e); if (iv > 0 && (iv >> 4) <= 2 && (iv & 15)) { m->side_fork = iv >> 4; m->side_wg = iv & 15; } }
     if (const char* e = getenv("DSPMAP_RESAMPLE_WG_TILES")) { const long v = atol(e); if (v >= 0) m->resample_wg_tiles = (int)std::min(v, 2000000000l); }
     derive_dims(m);   // (the storage order follows DSPMAP_TILING / DSPMAP_PLACE_SPLIT_TILES)
     return m;
@@ -597,6 +600,14 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
             if (m->hint_host) m->hint_host[3] = 0;
             break;
         case DSPMAP_P_FRAME_BRANCHES: m->frame_branches = v < 0 ? -1 : (v != 0 ? 1 : 0); m->graph_epoch++; break;
+        case DSPMAP_P_RESAMPLE_SPLIT: m->resample_split = v != 0 ? 1 : 0; m->graph_epoch++; break;
+        case DSPMAP_P_SIDE_PLACEMENT: {
+            const int iv = v < 0 ? 3 : (int)v;
+            m->side_fork = (iv >> 4) > 2 ? 0 : (iv >> 4);
+            m->side_wg = (iv & 15) ? (iv & 15) : 3;
+            m->graph_epoch++;
+            break;
+        }
         case DSPMAP_P_TILING:
             if (m->device_ready) return dspmap_fail(m, DSPMAP_E_STATE, "DSPMAP_P_TILING must be set before the device state is allocated");
             m->tiling_req = v < 0 ? -1 : (v != 0 ? 1 : 0);
@@ -651,6 +662,8 @@ extern "C" double dspmap_get_param(const dspmap_t* m, int key) {
         case DSPMAP_P_HOST_CLOUD_DIRECT: return m->host_direct ? 1 : 0;
         case DSPMAP_P_ESTIMATOR_QUEUE: return m->est_queue ? 1 : 0;
         case DSPMAP_P_FRAME_BRANCHES: return m->frame_branches;
+        case DSPMAP_P_SIDE_PLACEMENT: return m->side_fork * 16 + m->side_wg;
+        case DSPMAP_P_RESAMPLE_SPLIT: return m->resample_split;
         case DSPMAP_P_TILING: return m->d.tiling;
         case DSPMAP_P_USE_GRAPH: return m->use_graph ? 1 : (m->direct_ring ? 2 : 0);
         default: return 0;
@@ -810,6 +823,15 @@ static bool frame_runs_two_branches(const dspmap* m, const LaunchCtx& c, bool fo
     return m->frame_branches == 1 || frame_splits_placement(m, c, fork);
 }
 
+// does this frame resample the tiles no newborn can reach BESIDE the weight update and the births (DSPMAP_P_RESAMPLE_SPLIT)?  A frame that
+// splits its placement (the side stream exists and ends with the placement of exactly such tiles), cube storage (k_tile_class), the
+// one-wave-per-tile resampler (class filter), no velocity noise pending, and a birth cloud made on the device from THIS frame's view
+// (every point in view a static source, or the device estimator's: a caller-supplied cloud may hold points anywhere)
+static bool frame_splits_resampling(const dspmap* m, const LaunchCtx& c, bool split, bool device_cloud) {
+    if (!split || m->resample_split == 0 || !device_cloud || c.s.vz0 || !c.k.tile_cls || !c.d.tiling) return false;
+    return !(resample_variant(c) & 1);
+}
+
 // enqueue one whole device-resident frame (setup .. resample); every per-frame value is read from s.fpar.
 // When `fork` is set (graph capture) the observation binning runs on a second stream concurrently with
 // prediction + re-binning: the two only share the rotated planes written by k_reset and meet again at
@@ -828,6 +850,7 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
         // run beside each other.  Same kernels, same per-tile work, same result slot for slot (tests/test_gpu_round6.py).
         c.place_split = false;
         c.branches = true;
+        m->rsplit_enq = false;
         if (!m->stream4) {
             // the bulk branch's stream, created at the first frame that needs it, with the LOWEST priority the device offers: its sweeps would
             // otherwise keep every CU's wave slots and LDS filled and the in-view chain's kernels -- the frame's critical path -- would wait
@@ -851,7 +874,8 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
         (void)hipEventRecord(m->ev_br[2], m->stream4);                // predict(not P) has ended: every tile's pending clear is done
         (void)hipStreamWaitEvent(m->stream4, m->ev_br[1], 0);
         launch_claim(cb, 0, 0, 0, 0, -1, -TILE_Q);
-        launch_resample(cb, -TILE_Q, false);
+        (void)hipEventRecord(m->ev_br[4], m->stream4);                // place(not Q) has ended
+        launch_resample(cb, -TILE_Q, false, 2);                       // (the early launch: leaves a frame with an empty view alone, see k_resample)
         (void)hipEventRecord(m->ev_br[3], m->stream4);
         if (with_est) {   // the estimator's branch (the reference's helper thread, :297,311): a third one, from the binning to the birth stage
             (void)hipStreamWaitEvent(m->stream2, m->ev_br[0], 0);
@@ -874,7 +898,10 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
             else launch_birth(c, birth_grid, true, all_static);
         }
         (void)hipStreamWaitEvent(m->stream, m->ev_br[2], 0);          // (the rollout of the Q tiles adds to accumulators anywhere: after every clear)
-        launch_resample(c, TILE_Q, false);
+        // a frame with an empty view re-uses the birth cloud of the last non-empty one (:1379-1381): its newborns land where THAT frame's
+        // field of view was, Q says nothing about them -- this launch then takes every tile, so every tile's placement must have ended
+        (void)hipStreamWaitEvent(m->stream, m->ev_br[4], 0);
+        launch_resample(c, TILE_Q, false, 4);
         (void)hipStreamWaitEvent(m->stream, m->ev_br[3], 0);
         launch_rollout(c);
         m->last_resample_variant = resample_variant(c);
@@ -884,6 +911,35 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     const bool split0 = frame_splits_placement(m, c, fork);
     const bool split = split0;
     c.place_split = split;
+    // (DSPMAP_P_RESAMPLE_SPLIT) Q = the tiles a newborn of this frame can reach (k_tile_class: the field of view grown by the position
+    // table's largest value; every tile with a view is one).  Weights, births and the list re-slotting only touch Q tiles, and the side
+    // stream's placement serves exactly the tiles without a view: once it is done the tiles outside Q are final for this frame, and the
+    // side stream resamples them while the main chain is still in its weight update and birth stage; the main chain resamples Q behind
+    // the births, the rollout follows both.  Same per-tile work, same result slot for slot.
+    const bool rsplit = frame_splits_resampling(m, c, split, all_static || est);
+    m->rsplit_enq = rsplit;
+    auto side_place = [&]() {   // (queued behind the main chain's next kernel: the branch whose node comes first after the fork stays on the parent's hardware queue)
+        (void)hipStreamWaitEvent(m->stream2, m->ev_fork2, 0);
+        LaunchCtx c2 = c;
+        c2.stream = m->stream2;
+        if (rsplit) launch_tile_class(c2);
+        launch_claim(c2, 0, 0, 0, 0, 0);
+        (void)hipEventRecord(m->ev_join, m->stream2);
+        if (rsplit) {
+            launch_resample(c2, -TILE_Q, false, 2);
+            (void)hipEventRecord(m->ev_br[3], m->stream2);
+        }
+    };
+    auto final_resample = [&]() {
+        if (!rsplit) { dspmap_resample(m, c); return; }
+        m->last_resample_variant = resample_variant(c);
+        launch_resample(c, TILE_Q, false, 4);
+        (void)hipStreamWaitEvent(m->stream, m->ev_br[3], 0);
+        launch_rollout(c);
+    };
+    // where the side placement leaves the main chain (DSPMAP_P_SIDE_PLACEMENT): 0 behind the list preparation, 1 behind the placement of
+    // the tiles with a view, 2 behind the prediction
+    const int side_fork = m->side_fork;
     dspmap_prof_mark(m, 0);
     if (!fork) {
         launch_setup_and_bin(c, pts_grid, false, m->frame_ring ? m->ring_dev : nullptr, DSPMAP_RING - 1);   // the gather rides on k_predict's launch
@@ -921,15 +977,13 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
         }
         dspmap_prof_mark(m, 2);
         launch_claim(c, 0, 0, 0, 0, split ? 1 : -1);
+        if (split && side_fork == 1) (void)hipEventRecord(m->ev_fork2, m->stream);
         if (split) launch_pyr_prepare(c);
+        if (split && side_fork == 1) side_place();   // (behind the estimator's kernels on that stream)
         dspmap_prof_mark(m, 3);
-        if (split) (void)hipEventRecord(m->ev_fork2, m->stream);
+        if (split && side_fork != 1) (void)hipEventRecord(m->ev_fork2, m->stream);
         launch_ck_partial(c, split);
-        if (split) {   // the side stream places the arrivals of the tiles outside the field of view (behind the estimator's kernels)
-            (void)hipStreamWaitEvent(m->stream2, m->ev_fork2, 0);
-            launch_claim(c2, 0, 0, 0, 0, 0);
-            (void)hipEventRecord(m->ev_join, m->stream2);
-        }
+        if (split && side_fork != 1) side_place();   // the side stream places the arrivals of the tiles outside the field of view (behind the estimator's kernels)
         dspmap_prof_mark(m, 4);
         launch_weight_update(c);
         dspmap_prof_mark(m, 5);
@@ -937,7 +991,7 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
         dspmap_prof_mark(m, 6);
         launch_birth_late(c, birth_grid, false, !split);
         dspmap_prof_mark(m, 7);
-        dspmap_resample(m, c);
+        final_resample();
         dspmap_prof_mark(m, 8);
         if (m->prof) m->prof_pending = true;
         return;
@@ -947,24 +1001,22 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     const bool early_birth = !fork && birth_grid > 0;
     launch_predict_only(c, !fork, early_birth);
     dspmap_prof_mark(m, 2);
+    if (split && side_fork == 2) (void)hipEventRecord(m->ev_fork2, m->stream);
     launch_claim(c, early_birth ? birth_grid : 0, 0, 0, 0, split ? 1 : -1);
+    if (split && side_fork == 2) side_place();
     if (split) {
         // Only the arrivals of tiles that can see the field of view are registered in pyramids, so only their placement
         // has to precede the weight update: the others get their slots on the side stream WHILE the pair kernels run
         // (VALU-bound; the list preparation before them is itself a scatter and would only share the memory system).
+        if (side_fork == 1) (void)hipEventRecord(m->ev_fork2, m->stream);
         launch_pyr_prepare(c);
-        (void)hipEventRecord(m->ev_fork2, m->stream);
+        if (side_fork == 1) side_place();
+        if (side_fork != 1 && side_fork != 2) (void)hipEventRecord(m->ev_fork2, m->stream);
     }
     if (fork) (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
     dspmap_prof_mark(m, 3);
     launch_ck_partial(c, split);
-    if (split) {   // (queued behind the main chain's next kernel, see the estimator's fork above)
-        (void)hipStreamWaitEvent(m->stream2, m->ev_fork2, 0);
-        LaunchCtx c2 = c;
-        c2.stream = m->stream2;
-        launch_claim(c2, 0, 0, 0, 0, 0);
-        (void)hipEventRecord(m->ev_join, m->stream2);
-    }
+    if (split && side_fork != 1 && side_fork != 2) side_place();
     dspmap_prof_mark(m, 4);
     launch_weight_update(c);
     if (split) (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
@@ -974,7 +1026,7 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
     if (early_birth) launch_birth_late(c, birth_grid, all_static);
     else launch_birth(c, birth_grid, true, all_static);
     dspmap_prof_mark(m, 7);
-    dspmap_resample(m, c);
+    final_resample();
     dspmap_prof_mark(m, 8);
     if (m->prof) m->prof_pending = true;
 }
@@ -1282,8 +1334,10 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
             }
             if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
             HIPCHK(m, hipStreamBeginCapture(m->stream, hipStreamCaptureModeRelaxed));
+            m->graph_rsplit[gi] = false;
             enqueue_frame(m, c, m->pt_cap, m->birth_cap, false, mode == 1, mode == 2);  // (fork=true measured slower: HIP replays multi-branch graphs with a much higher launch cost) grids sized for the capacity; kernels bound-check against fpar
             HIPCHK(m, hipStreamEndCapture(m->stream, &m->graph));
+            m->graph_rsplit[gi] = m->rsplit_enq;
             if (const char* dot = getenv("DSPMAP_GRAPH_DOT")) (void)hipGraphDebugDotPrint(m->graph, dot, 0);   // diagnostics: the frame's nodes and edges
             HIPCHK(m, hipGraphInstantiate(&m->graph_exec[gi], m->graph, nullptr, nullptr, 0));
             (void)hipGraphDestroy(m->graph);   // the executable graph keeps its own copy of the topology
@@ -1294,6 +1348,7 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
         rc = queue_estimator();
         if (rc != DSPMAP_OK) return rc;
         HIPCHK(m, hipGraphLaunch(m->graph_exec[gi], m->stream));
+        if (m->graph_rsplit[gi]) ++m->rsplit_frames;
         if (m->frame_ring) {
             if (m->ring_head % (DSPMAP_RING / 4) == DSPMAP_RING / 4 - 1) {
                 const unsigned q = (m->ring_head / (DSPMAP_RING / 4)) % 4;
@@ -1307,6 +1362,7 @@ static int device_frame(dspmap* m, int n_points, const float* points_dev, int n_
         m->branch_pending = false;
         enqueue_frame(m, c, n_points, nb_grid, false, mode == 1, mode == 2);
         if (m->branch_pending) ++m->branch_frames;
+        if (m->rsplit_enq) ++m->rsplit_frames;
         if (m->frame_ring) {
             if (m->ring_head % (DSPMAP_RING / 4) == DSPMAP_RING / 4 - 1) {
                 const unsigned q = (m->ring_head / (DSPMAP_RING / 4)) % 4;
@@ -1931,6 +1987,7 @@ extern "C" int dspmap_debug_frame_branches(dspmap_t* m, long long out[5]) {
     out[4] = (long long)(vf * 1000.f);
     return DSPMAP_OK;
 }
+extern "C" long long dspmap_debug_resample_split_frames(dspmap_t* m) { return m ? m->rsplit_frames : 0; }
 extern "C" int dspmap_get_pyramid_counts(dspmap_t* m, int* out) {
     READY(m);
     if (!out) return DSPMAP_E_ARG;

@@ -109,7 +109,7 @@ struct dspmap {
     bool fut_clear_pending = false;   // clearOccupancyMapPrediction is lazy: done by the next frame's k_predict, or by the next reader
     hipStream_t stream2 = nullptr;   // fork/join branch inside the captured frame
     hipStream_t stream4 = nullptr;   // the bulk branch of a two-branch frame (DSPMAP_P_FRAME_BRANCHES)
-    hipEvent_t ev_br[4] = {nullptr, nullptr, nullptr, nullptr};   // its fork, "predict(P) ended", "predict(not P) ended", its join
+    hipEvent_t ev_br[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // its fork, "predict(P) ended", "predict(not P) ended", its join, "place(not Q) ended"
     int tiling_req = -1;             // DSPMAP_P_TILING: -1 by size (derive_dims), 0 runs of 64 voxel indices, 1 cubes of 4 x 4 x 4
     int frame_branches = 0;          // DSPMAP_P_FRAME_BRANCHES: 0 never (default: measured slower), -1 the maps that would split their placement (cube storage), 1 whenever possible
     long long branch_frames = 0;     // frames that ran as two branches (dspmap_debug_frame_branches)
@@ -134,6 +134,11 @@ struct dspmap {
     int ro_force = -1;               // DSPMAP_P_ROLLOUT_INLINE: -1 from the hint, 0 / 1 forced
     bool sparse_mode = false;        // launch k_predict's SPARSE variant (dspmap_pick_sweep_mode: from the hint, with hysteresis)
     int sparse_force = -1;           // DSPMAP_P_SPARSE_SWEEP: -1 from the hint, 0 / 1 forced
+    int resample_split = 0;          // DSPMAP_P_RESAMPLE_SPLIT: the tiles no newborn can reach are resampled on the side stream, beside the weight update and the births
+    bool rsplit_enq = false;         // the frame enqueue_frame queued / captured last does so
+    bool graph_rsplit[2] = {false, false};   // ... per captured graph
+    long long rsplit_frames = 0;     // frames that ran that way (dspmap_debug_resample_split_frames)
+    int side_fork = 0, side_wg = 3;  // split placement: where the side launch leaves the main chain / its workgroups per CU (DSPMAP_P_SIDE_PLACEMENT)
     int place_split_tiles = 8192;    // maps with at least this many tiles place the arrivals of the tiles outside the field of view
                                      // on the side stream, beside the pair kernels (DSPMAP_P_PLACE_SPLIT_TILES)
     int resample_wg_tiles = 8192;    // one-word maps with fewer tiles (and sparse ones of any size) run the four-waves-per-tile resampler (DSPMAP_P_RESAMPLE_WG_TILES)

@@ -61,6 +61,7 @@ struct LaunchCtx {
     bool resample_rev = false;   // k_resample walks the tiles from the last one down (after a k_place that ended there)
     bool place_split = false; // this frame places the arrivals of the tiles with a view first (launch_claim sel = 1) and the others beside the pair
                               // kernels (sel = 0): k_predict leaves the list of the tiles with a view (KernelScratch::view_list)
+    int side_wg = 3;          // workgroups per CU of the side-stream placement (sel = 0; DSPMAP_P_SIDE_PLACEMENT)
     bool branches = false;   // this frame runs as two branches (DSPMAP_P_FRAME_BRANCHES; see KernelScratch::tile_cls)
     bool sparse = false; // most tiles hold nothing (dspmap::sparse_mode): k_predict's variant that leaves such tiles first
 };
@@ -118,7 +119,7 @@ void launch_birth_late(const LaunchCtx& c, int n_birth, bool all_static, bool wi
 void launch_birth_plan_insert(const LaunchCtx& c, int n_birth, bool in_frame, bool all_static);
 void launch_birth_materialize(const LaunchCtx& c, BirthSrc* out, int cap, int* n_out);   // the frame's synthesised birth cloud, for host readback
 // mapOccupancyCalculationAndResample (:924-1057)
-void launch_resample(const LaunchCtx& c, int cls = 0, bool with_rollout = true);   // + the future rollout of the moving particles (k_rollout)
+void launch_resample(const LaunchCtx& c, int cls = 0, bool with_rollout = true, int part = 0);   // + the future rollout of the moving particles (k_rollout)
 int rollout_groups(const MapDims& d, int ntiles);   // workgroup groups of k_rollout (KernelScratch::ro_stat holds 2 ints per workgroup: x 4 with cube storage and windows)
 void launch_rollout(const LaunchCtx& c);    // the rollout alone (a two-branch frame: once, behind both branches' resampling)
 int resample_variant(const LaunchCtx& c);   // bit 0: k_resample_wg; bits 1-2: rollout 0 inline, 1 k_rollout light, 2 k_rollout windows, 3 none

@@ -771,9 +771,6 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
 // on the occupancy words and no sequential loop.  Pyramid registration :1233-1259.
 // FrameScalars::n_place_vf / n_place_pf += {voxel full, pyramid full}
 // --------------------------------------------------------------------------
-#ifndef PLACE_SIDE_WG
-#define PLACE_SIDE_WG 3   // workgroups per CU of the side-stream placement
-#endif
 #ifdef PLACE_PROF
 // build with DSPMAP_EXTRA_FLAGS=-DPLACE_PROF: cycle stamps of a tile's phases in k_place (tools/prof/place_prof.py)
 __device__ long long g_plprof[8 * 131072];
@@ -1087,13 +1084,24 @@ __global__ void __launch_bounds__(256, RBK_ >= 8 ? 3 : 5) k_resample(MapDims d, 
     const int cpmax = d.M;   // a voxel makes at most M copies
     unsigned short* s_cp = (unsigned short*)(s_dyn + (size_t)wave * ((64 * cpmax + 1) / 2));
     const int wq = blockIdx.x * (blockDim.x >> 6) + wave;
-    const int wave_g = rev ? ((d.v_loc + 63) >> 6) - 1 - wq : wq;   // (tiles from the last one down: see k_predict)
+    const int wave_g = (rev & 1) ? ((d.v_loc + 63) >> 6) - 1 - wq : wq;   // (tiles from the last one down: see k_predict)
     const bool cubes = d.tiling != 0;
     const int lv = wave_g * 64 + l;
     if (wave_g < 0 || wave_g * 64 >= d.v_loc) return;
     int t_live, t_mov, tc;
+    if (rev & 6) {
+        // (DSPMAP_P_RESAMPLE_SPLIT) the stage in two launches: the tiles no newborn can reach (not Q) BESIDE the weight update and the births
+        // (rev & 2), the others behind the births (rev & 4).  Q is cut around THIS frame's field of view; a frame whose view is empty
+        // re-uses the birth cloud of the last non-empty one (:1379-1381), whose newborns may land anywhere: the early launch leaves
+        // such a frame alone and the late one takes every tile.  (n_valid: final since k_predict's gather.)
+        int nval;
+        sload_i4(s.tile_live + wave_g, s.tile_moving + wave_g, tcls + wave_g, &s.fs->n_valid, t_live, t_mov, tc, nval);
+        if (nval == 0) { if (rev & 2) return; }
+        else if (!cls_mine(tc, cls)) return;
+    } else {
     sload_i3(s.tile_live + wave_g, s.tile_moving + wave_g, tcls ? tcls + wave_g : s.tile_live + wave_g, t_live, t_mov, tc);   // (one scalar round trip)
     if (tcls && !cls_mine(tc, cls)) return;   // (two-branch frame) the other branch's tile
+    }
     if (!t_live) return;   // empty since its last visit: result, buckets and lists are already zero
     if (!d.tile_skip) t_mov = 1;
     const bool inr = lv < d.v_loc;
@@ -2388,11 +2396,11 @@ void launch_claim(const LaunchCtx& c, int n_birth_grid, int part, int tile_lo, i
     if (part == 2) { n0 = tile_lo; t1 = tile_hi; n1 = nt - tile_hi; }   // part 2: the rest
     if (n0 + n1 <= 0 && xb == 0) return;
     const KernelScratch* k = &c.k;
-    // sel == 0 runs beside the pair kernels with a small footprint: PLACE_SIDE_WG workgroups per CU walk the tiles -- the
+    // sel == 0 runs beside the pair kernels with a small footprint: LaunchCtx::side_wg (default 3) workgroups per CU walk the tiles -- the
     // scattered stores that bound this kernel are saturated from there (measured: 7 -> 3 resident workgroups, same time),
     // and the wave slots, registers and LDS it leaves free are what the pair kernels run in
     unsigned grid = (unsigned)(n0 + n1) + xb;
-    if (sel == 0) grid = std::min(grid, (unsigned)(PLACE_SIDE_WG * c.n_cu));
+    if (sel == 0) grid = std::min(grid, (unsigned)(std::max(1, c.side_wg) * c.n_cu));
     const int* vlist = (sel == 1 && c.place_split && part == 0) ? k->view_list : nullptr;   // (k_predict listed the tiles with a view)
     if (vlist) grid = std::min((unsigned)(n0 + n1), (unsigned)(PLACE_LB * c.n_cu)) + xb;    // one round of workgroups walks the list
     if (cls) grid = std::min((unsigned)(n0 + n1), (unsigned)(PLACE_LB * c.n_cu)) + xb;      // (two-branch frame) one round of workgroups walks the tiles: a workgroup
@@ -2426,7 +2434,7 @@ int resample_variant(const LaunchCtx& c) {
 void kernels_init_device() {   // per device, once (dspmap_init_device)
     (void)hipFuncSetAttribute((const void*)k_rollout<RO_TPB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RO_LDS_CELLS * 4);
 }
-void launch_resample(const LaunchCtx& c, int cls, bool with_rollout) {
+void launch_resample(const LaunchCtx& c, int cls, bool with_rollout, int part) {   // part (DSPMAP_P_RESAMPLE_SPLIT; needs cls): 2 the early launch, 4 the late one
     const KernelScratch* k = &c.k;
     const int nw = 1;   // waves (= tiles) per workgroup (2 / 4 measured in round 4: -3 % on the realistic 264x264x80 fill, +2 % at saturation)
     const size_t lds = (size_t)nw * ((64 * c.d.M + 1) / 2) * sizeof(float);   // the copy notes; the weights are re-read (no LDS panel)
@@ -2445,7 +2453,7 @@ void launch_resample(const LaunchCtx& c, int cls, bool with_rollout) {
         if (c.d.mw == 1) hipLaunchKernelGGL(k_resample_wg<1>, dim3(k->ntiles), dim3(256), lds4, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, ro == 0 ? 1 : 0, k->ro_sub);
         else hipLaunchKernelGGL(k_resample_wg<2>, dim3(k->ntiles), dim3(256), lds4, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, ro == 0 ? 1 : 0, k->ro_sub);
     } else {
-#define RS_LAUNCH(MWV, RB) hipLaunchKernelGGL((k_resample<MWV, RB>), dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, c.resample_rev ? 1 : 0, cls ? k->tile_cls : nullptr, cls, k->ro_sub)
+#define RS_LAUNCH(MWV, RB) hipLaunchKernelGGL((k_resample<MWV, RB>), dim3(grid), dim3(64 * nw), lds, c.stream, c.d, c.s, k->part_resample, k->vb_cnt, k->ro_rec, k->ro_cnt, (c.resample_rev ? 1 : 0) | (cls ? part : 0), cls ? k->tile_cls : nullptr, cls, k->ro_sub)
         if (c.d.mw == 1) { if (c.sparse) RS_LAUNCH(1, 8); else RS_LAUNCH(1, 4); }
         else { if (c.sparse) RS_LAUNCH(2, 8); else RS_LAUNCH(2, 4); }
 #undef RS_LAUNCH

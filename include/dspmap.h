@@ -180,6 +180,17 @@ enum dspmap_param {
                                        of the 132x132x60 map's runs have a view, 19 % of its cubes).  Settable only before the handle's first use (read: the
                                        order in use); sharded handles (Z-slabs) keep index order.  Results, state records and sweep order are the reference's
                                        whatever the storage: the same result slot for slot.  The environment variable DSPMAP_TILING presets it */
+    DSPMAP_P_SIDE_PLACEMENT = 28,   /* frames that split their placement (DSPMAP_P_PLACE_SPLIT_TILES): value = 16 * fork + footprint.  fork: where the launch that
+                                       places the arrivals of the tiles without a view leaves the main chain -- 0 (default) behind the list preparation, 1 behind
+                                       the placement of the tiles with a view, 2 behind the prediction; footprint: its workgroups per compute unit (1 .. 15,
+                                       default 3).  A scheduling knob: same result slot for slot */
+    DSPMAP_P_RESAMPLE_SPLIT = 29,   /* frames that split their placement on cube storage, with a birth cloud made on the device from the frame's own view
+                                       (DSPMAP_P_VELOCITY_ESTIMATOR 2, or every point in view a static source): 1 = the resampling stage (:924-1057) runs as two
+                                       launches -- the tiles no newborn of this frame can reach (outside the field of view grown by the position table's
+                                       largest value) on the side stream, right behind the placement it carries, BESIDE the weight update and the birth
+                                       stage of the main chain; the others behind the births; the rollout behind both.  A frame with an empty view (stale
+                                       birth cloud, :1379-1381) resamples every tile behind the births.  0 = one launch behind the births.  Same result
+                                       slot for slot.  The environment variable DSPMAP_RESAMPLE_SPLIT presets it */
     DSPMAP_P_PAIR_CULL_SIGMAS = 13  /* mapUpdate evaluates a (particle, observation) pair only if their ranges differ by at most this many
                                        sigma_ob (default 9: the dropped terms are < 1e-19 and zero on the fixed-point Ck grid);
                                        a huge value evaluates every pair of the neighbourhood like the reference's loops */
@@ -312,6 +323,8 @@ int dspmap_debug_estimator_path(dspmap_t* m);
  * the last such frame could land there) / P (a particle could reach a Q tile), out[3] = tiles of the map, out[4] = the largest speed any particle
  * of the map was ever given, mm/s (what sizes P) */
 int dspmap_debug_frame_branches(dspmap_t* m, long long out[5]);
+/* frames of this handle whose resampling stage ran as two launches (DSPMAP_P_RESAMPLE_SPLIT) */
+long long dspmap_debug_resample_split_frames(dspmap_t* m);
 /* test hooks of dspmap_mgpu_comm_init_from_env's rendezvous file (no device, no RCCL): what rank 0 publishes / what a rank != 0
  * waits for (this launch's nonce: DSPMAP_RDZV_NONCE or TORCHELASTIC_RUN_ID + the parent's pid).  1 = written / found, 0 = not */
 int dspmap_debug_rdzv_publish(const char* path, const char id[128]);

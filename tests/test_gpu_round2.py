@@ -432,10 +432,15 @@ def test_split_placement_changes_nothing(dsp, est, quat):
     cfg = dict(nx=56, ny=88, nz=12, res=0.15, ppv=24)   # tiles straddle two rows; rows beyond the view's width exist
     tables = common.tables(5)
     maps = []
-    for split in (1, 2_000_000_000):
+    # (DSPMAP_P_SIDE_PLACEMENT: the side launch leaving the main chain behind the list preparation (default), behind the placement of the
+    # tiles with a view, behind the prediction; with one and with five workgroups per compute unit)
+    for split, side in ((1, None), (2_000_000_000, None), (1, 16 + 5), (1, 32 + 1)):
         m = dsp.DSPMap(dsp.make_config(**cfg)); m.set_tables(*tables)
         m.L.dspmap_init_device(m.h)
         m.set_param(dsp.capi.P_PLACE_SPLIT_TILES, split)
+        if side is not None:
+            m.set_param(dsp.capi.P_SIDE_PLACEMENT, side)
+            assert m.get_param(dsp.capi.P_SIDE_PLACEMENT) == side
         if est:
             m.set_param(dsp.capi.P_VELOCITY_ESTIMATOR, est)
         maps.append(m)
@@ -452,14 +457,16 @@ def test_split_placement_changes_nothing(dsp, est, quat):
         for m in maps:
             assert m.update_device(pts.data_ptr(), len(base), pos, t, quat) == 1
             m.clearOccupancyMapPrediction()
-        ca, cb = maps[0].counters(), maps[1].counters()
-        ca.pop("update_ms"); cb.pop("update_ms")
-        assert ca == cb, (f, ca, cb)
+        ca = maps[0].counters(); ca.pop("update_ms")
+        for mb in maps[1:]:
+            cb = mb.counters(); cb.pop("update_ms")
+            assert ca == cb, (f, ca, cb)
         moved += ca["n_moved"]
     assert moved > 20000
-    for a, b in zip(maps[0].export_state(), maps[1].export_state()):
-        assert np.array_equal(a, b)
-    assert np.array_equal(maps[0].results(), maps[1].results())
+    for mb in maps[1:]:
+        for a, b in zip(maps[0].export_state(), mb.export_state()):
+            assert np.array_equal(a, b)
+        assert np.array_equal(maps[0].results(), mb.results())
     got = maps[0].debug_tile_fov()
     assert 0 < got.sum() < len(got), got.sum()      # both launches had tiles to place
     for m in maps:

@@ -34,12 +34,23 @@ def _trio(dsp, cfg, estimator=0, extra=None):
     [2] index-order storage (rounds 1-5), the serial frame.  All on the one-wave-per-tile resampler (the four-waves-per-tile variant
     of small maps has no class filter: a map that runs it keeps the serial frame)"""
     maps = []
-    for tiling, br in ((1, 1), (1, 0), (0, 0)):
+    # ... and [3] cube storage, the serial frame with its placement split (forced: DSPMAP_P_PLACE_SPLIT_TILES = 1), the side launch
+    # leaving the main chain behind the placement of the tiles with a view, and the RESAMPLING split (DSPMAP_P_RESAMPLE_SPLIT: the tiles
+    # no newborn can reach are resampled on the side stream beside the weight update and the births)
+    for tiling, br in ((1, 1), (1, 0), (0, 0), (1, 2)):
         m = dsp.DSPMap(dsp.make_config(seed=1234, **cfg))
         m.set_param(dsp.capi.P_TILING, tiling)            # (before the device state exists)
         m.L.dspmap_init_device(m.h)
         assert m.get_param(dsp.capi.P_TILING) == tiling
         m.set_param(dsp.capi.P_RESAMPLE_WG_TILES, 0)
+        if br == 2:
+            br = 0
+            m.set_param(dsp.capi.P_PLACE_SPLIT_TILES, 1)
+            m.set_param(dsp.capi.P_SIDE_PLACEMENT, 16 + 3)
+            m.set_param(dsp.capi.P_RESAMPLE_SPLIT, 1)
+            assert m.get_param(dsp.capi.P_RESAMPLE_SPLIT) == 1
+        else:
+            m.set_param(dsp.capi.P_RESAMPLE_SPLIT, 0)
         m.set_param(dsp.capi.P_FRAME_BRANCHES, br)
         assert m.get_param(dsp.capi.P_FRAME_BRANCHES) == br
         if estimator:
@@ -51,7 +62,7 @@ def _trio(dsp, cfg, estimator=0, extra=None):
 
 
 @pytest.mark.parametrize("case", ["saturated_step", "nearly_full_voxels", "depth_stream_estimator", "two_words_overfull_lists",
-                                  "moving_fill_turning", "depth_stream_static_tags", "sparse_sweep_variant"])
+                                  "moving_fill_turning", "depth_stream_static_tags", "sparse_sweep_variant", "empty_view_frames"])
 def test_cube_storage_and_two_branch_frame_change_nothing(dsp, case):
     """DSPMAP_P_TILING + DSPMAP_P_FRAME_BRANCHES (round 6).  Storage: the device arrays are indexed tile by tile; with cubes for tiles the
     voxel -> (tile, lane) map changes, the reference's voxel index (:1081) stays what orders sweeps (source keys) and what every result
@@ -70,7 +81,11 @@ def test_cube_storage_and_two_branch_frame_change_nothing(dsp, case):
       moving_fill_turning   every voxel seeded with particles at up to 2 m/s, the sensor advances, climbs and turns: movers cross the
                             Q / P borders in every direction, P is several rows wide
       depth_stream_static_tags  the stream with every point in view a static source (the saturated benchmark's birth mode)
-      sparse_sweep_variant  the same with the prediction's SPARSE variant and the resampler's 8-row batches forced."""
+      sparse_sweep_variant  the same with the prediction's SPARSE variant and the resampler's 8-row batches forced
+      empty_view_frames     the stream, but in every third frame all points lie BEHIND the sensor while it turns: the view is empty, the
+                            birth stage re-uses the cloud of the last non-empty view (:1379-1381) and its newborns land where that
+                            frame's field of view was -- outside this frame's Q: the split resampling takes every tile behind the births
+    A FOURTH map runs the serial frame with its placement split and the resampling stage split (DSPMAP_P_RESAMPLE_SPLIT) in every case."""
     scene_mod = __import__("dsp-map_amd.scene", fromlist=["CorridorScene"])
     quat = (1.0, 0.0, 0.0, 0.0)
     extra = {}
@@ -89,6 +104,17 @@ def test_cube_storage_and_two_branch_frame_change_nothing(dsp, case):
         sc = scene_mod.CorridorScene(66 * 0.15, 66 * 0.15, 40 * 0.15, seed=1234, device="cuda")
         frames = [sc.frame(f / 30.0) for f in range(90)]
         every = 15
+    elif case == "empty_view_frames":
+        sc = scene_mod.CorridorScene(66 * 0.15, 66 * 0.15, 40 * 0.15, seed=1234, device="cuda")
+        frames = []
+        for f in range(18):
+            pts, pos, _ = sc.frame(f / 30.0)
+            yaw = 0.5 * f                                   # (29 degrees per frame: the stale cloud's newborns land far outside the new view)
+            q = (float(np.cos(yaw / 2)), 0.0, 0.0, float(np.sin(yaw / 2)))
+            if f % 3 == 2:
+                pts = pts.clone(); pts[:, 0] = -pts[:, 0].abs() - 0.5   # every point behind the sensor (sensor frame): an empty view
+            frames.append((pts, pos, q))
+        every = 1
     elif case == "moving_fill_turning":
         for m in maps:
             m.seed_uniform(10, 0.02, 77, 2.0)
@@ -151,6 +177,9 @@ def test_cube_storage_and_two_branch_frame_change_nothing(dsp, case):
             snaps = [_snapshot(m) for m in maps]
             _same(snaps[1], snaps[2], (f, "cube storage against index-order storage"))
             _same(snaps[0], snaps[2], (f, "... and the two-branch frame on top of it"))
+            _same(snaps[3], snaps[2], (f, "... and the serial frame with its placement and its resampling split"))
+            if case == "empty_view_frames" and f % 3 == 2:
+                assert snaps[2][4]["n_obs"] == 0 and snaps[2][4]["n_born"] > 0, (f, snaps[2][4])   # an empty view, births from the stale cloud
             ca = snaps[0][4]
             for k in tot:
                 tot[k] += ca[k]
@@ -159,7 +188,9 @@ def test_cube_storage_and_two_branch_frame_change_nothing(dsp, case):
                 m.clearOccupancyMapPrediction()
     br = [m.frame_branches() for m in maps]
     print(case, tot, "branches", br)
-    assert br[0][0] == len(frames) and br[1][0] == 0 and br[2][0] == 0, br   # every frame of map 0 ran as two branches, none of the others
+    assert br[0][0] == len(frames) and br[1][0] == 0 and br[2][0] == 0 and br[3][0] == 0, br   # every frame of map 0 ran as two branches, none of the others
+    rs = [m.resample_split_frames() for m in maps]
+    assert rs[3] == len(frames) and rs[0] == 0 and rs[1] == 0 and rs[2] == 0, rs   # every frame of map 3 split its resampling
     assert 0 < br[0][1] <= br[0][2] <= br[0][3], br                # Q inside P inside the map
     assert tot["n_moved"] > 2000 and tot["n_born"] > 100, tot
     if case == "saturated_step":
@@ -187,11 +218,16 @@ def test_two_branch_frame_changes_nothing_at_config_c_full_size(dsp):
     scene_mod = __import__("dsp-map_amd.scene", fromlist=["CorridorScene"])
     cfg = dict(nx=132, ny=132, nz=60, res=0.15, ppv=24)
     maps = []
-    for tiling, br in ((-1, -1), (0, 0)):
+    # (map 2: what the handle runs by default since the split resampling exists -- cube storage, the serial frame with its placement split,
+    # the side launch behind the placement of the tiles with a view, the tiles no newborn can reach resampled on the side stream)
+    for tiling, br, rs in ((-1, -1, 0), (0, 0, 0), (-1, 0, 1)):
         m = dsp.DSPMap(dsp.make_config(seed=1234, **cfg))
         m.set_param(dsp.capi.P_TILING, tiling)
         m.L.dspmap_init_device(m.h)
         m.set_param(dsp.capi.P_FRAME_BRANCHES, br)
+        m.set_param(dsp.capi.P_RESAMPLE_SPLIT, rs)
+        if rs:
+            m.set_param(dsp.capi.P_SIDE_PLACEMENT, 16 + 3)
         m.seed_uniform(24, 0.01, 99)
         maps.append(m)
     assert maps[0].get_param(dsp.capi.P_TILING) == 1 and maps[1].get_param(dsp.capi.P_TILING) == 0
@@ -201,11 +237,13 @@ def test_two_branch_frame_changes_nothing_at_config_c_full_size(dsp):
     for f, (pts, pos, q) in enumerate(frames):
         for m in maps:
             assert m.update_device(pts.data_ptr(), pts.shape[0], pos, f / 30.0, q) == 1
-        assert np.array_equal(maps[0].results(), maps[1].results()), f
-        assert np.array_equal(maps[0].getFutureStatus(), maps[1].getFutureStatus()), f
-        ca, cb = maps[0].counters(), maps[1].counters()
-        for k in ("n_live_in", "n_moved", "n_out_of_map", "n_voxel_full", "n_pyramid_full", "n_born", "n_live_out", "n_reslotted", "n_fov"):
-            assert ca[k] == cb[k], (f, k, ca[k], cb[k])
+        r1, f1, cb = maps[1].results(), maps[1].getFutureStatus(), maps[1].counters()
+        for mi in (0, 2):
+            assert np.array_equal(maps[mi].results(), r1), (f, mi)
+            assert np.array_equal(maps[mi].getFutureStatus(), f1), (f, mi)
+            ca = maps[mi].counters()
+            for k in ("n_live_in", "n_moved", "n_out_of_map", "n_voxel_full", "n_pyramid_full", "n_born", "n_live_out", "n_reslotted", "n_fov"):
+                assert ca[k] == cb[k], (f, mi, k, ca[k], cb[k])
         for m in maps:
             m.clearOccupancyMapPrediction()
     br = [m.frame_branches() for m in maps]
@@ -213,9 +251,12 @@ def test_two_branch_frame_changes_nothing_at_config_c_full_size(dsp):
     assert br[0][0] == len(frames) and br[1][0] == 0, br
     assert 0 < br[0][1] <= br[0][2] < br[0][3] // 2, br            # the in-view branch is the smaller part of the map
     assert ca["n_moved"] > 100000 and ca["n_fov"] > 100000 and ca["n_born"] > 10000, ca
-    sa, sb = maps[0].export_state(), maps[1].export_state()
-    for x, y in zip(sa, sb):
-        assert np.array_equal(x, y)
+    assert maps[2].resample_split_frames() == len(frames) and maps[0].resample_split_frames() == 0 and maps[1].resample_split_frames() == 0
+    sb = maps[1].export_state()
+    for mi in (0, 2):
+        sa = maps[mi].export_state()
+        for x, y in zip(sa, sb):
+            assert np.array_equal(x, y), mi
     assert len(sa[0]) > 15_000_000
     for m in maps:
         m.close()

@@ -23,8 +23,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="C_sat")
     ap.add_argument("--param", required=True, help="name without the P_ prefix, e.g. SWEEP_ALTERNATE")
-    ap.add_argument("--a", type=float, required=True)
-    ap.add_argument("--b", type=float, required=True)
+    ap.add_argument("--a", type=float, default=None)
+    ap.add_argument("--b", type=float, default=None)
+    ap.add_argument("--values", default="", help="comma list of more than two values (instead of --a / --b): every round runs one block of each, rotated")
     ap.add_argument("--rounds", type=int, default=10)
     ap.add_argument("--block", type=int, default=20)
     ap.add_argument("--prefill", type=int, default=3)
@@ -43,7 +44,8 @@ def main():
     if est:
         m.set_param(D.capi.P_VELOCITY_ESTIMATOR, est)
     key = getattr(D.capi, "P_" + args.param)
-    n_frames = args.prefill + 2 * args.rounds * (args.block + 4) + 8
+    vals = [float(x) for x in args.values.split(",") if x] or [args.a, args.b]
+    n_frames = args.prefill + len(vals) * args.rounds * (args.block + 4) + 8
     sc = scene_mod.CorridorScene(w["nx"] * w["res"], w["ny"] * w["res"], w["nz"] * w["res"], seed=1234, device=dev,
                                  scale=1.0 if w["res"] >= 0.15 else 1.33)
     frames = []
@@ -61,10 +63,10 @@ def main():
             assert m.update_device(pts.data_ptr(), pts.shape[0], pos, t, quat) == 1
             m.clearOccupancyMapPrediction()
     run(args.prefill)
-    ms = {args.a: [], args.b: []}
+    ms = {v: [] for v in vals}
     gc.collect(); gc.disable()
     for r in range(args.rounds):
-        for v in ((args.a, args.b) if r % 2 == 0 else (args.b, args.a)):
+        for v in (vals[r % len(vals):] + vals[:r % len(vals)]):
             m.set_param(key, v)
             run(4)                      # (re-capture of the frame's graph + warm-up, untimed)
             m.sync()
@@ -77,8 +79,9 @@ def main():
     for v, xs in ms.items():
         out[v] = (statistics.median(xs), min(xs), max(xs))
         print("%s = %g : median %.4f ms  (min %.4f, max %.4f, %d blocks of %d frames)" % (args.param, v, *out[v], len(xs), args.block))
-    a, b = out[args.a][0], out[args.b][0]
-    print("b / a = %.4f  (%+.2f %%)" % (b / a, (b / a - 1) * 100))
+    a = out[vals[0]][0]
+    for v in vals[1:]:
+        print("%g / %g = %.4f  (%+.2f %%)" % (v, vals[0], out[v][0] / a, (out[v][0] / a - 1) * 100))
     m.close()
 
 
