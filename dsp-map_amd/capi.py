@@ -20,7 +20,7 @@ OK, REJECTED = 1, 0
 P_POSITION_STDDEV, P_VELOCITY_STDDEV, P_OBSERVATION_STDDEV, P_NEWBORN_WEIGHT, P_NEWBORN_NUMBER, \
     P_VOXEL_FILTER_RES, P_KAPPA, P_DETECTION, P_VELOCITY_ESTIMATOR, P_REGENERATE_TABLES, P_USE_GRAPH, P_OCCLUSION_MARGIN, \
     P_PAIR_CULL_SIGMAS, P_UPDATE_TIME, P_UPDATE_COUNTER, P_PLACE_SPLIT_TILES, P_FAST_DIVISION, P_SPARSE_SWEEP, P_ROLLOUT_INLINE, \
-    P_RESAMPLE_WG_TILES, P_SWEEP_ALTERNATE, P_STATIC_TILE_SKIP, P_HOST_CLOUD_DIRECT, _P_REMOVED_24, P_ESTIMATOR_QUEUE, P_FRAME_BRANCHES, P_TILING, P_SIDE_PLACEMENT, P_RESAMPLE_SPLIT = range(1, 30)
+    P_RESAMPLE_WG_TILES, P_SWEEP_ALTERNATE, P_STATIC_TILE_SKIP, P_HOST_CLOUD_DIRECT, _P_REMOVED_24, P_ESTIMATOR_QUEUE, P_FRAME_BRANCHES, P_TILING, P_SIDE_PLACEMENT, P_RESAMPLE_SPLIT, P_TILE_BITMAPS = range(1, 31)
 
 
 class Config(C.Structure):

@@ -188,6 +188,7 @@ extern "C" dspmap_t* dspmap_create(const dspmap_config* cfg) {
     if (const char* e = getenv("DSPMAP_TILING")) m->tiling_req = atoi(e) < 0 ? -1 : (atoi(e) != 0 ? 1 : 0);
     if (const char* e = getenv("DSPMAP_FRAME_BRANCHES")) m->frame_branches = atoi(e) < 0 ? -1 : (atoi(e) != 0 ? 1 : 0);
     if (const char* e = getenv("DSPMAP_RESAMPLE_SPLIT")) m->resample_split = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("DSPMAP_TILE_BITMAPS")) m->tile_bitmaps = atoi(e) != 0;
     if (const char* e = getenv("DSPMAP_SIDE_PLACEMENT")) { const int iv = atoi(e); if (iv > 0 && (iv >> 4) <= 2 && (iv & 15)) { m->side_fork = iv >> 4; m->side_wg = iv & 15; } }
     if (const char* e = getenv("DSPMAP_RESAMPLE_WG_TILES")) { const long v = atol(e); if (v >= 0) m->resample_wg_tiles = (int)std::min(v, 2000000000l); }
     derive_dims(m);   // (the storage order follows DSPMAP_TILING / DSPMAP_PLACE_SPLIT_TILES)
@@ -214,7 +215,7 @@ static void free_dev(dspmap* m) {
     void* ptrs[] = {s.fpar, s.obs_ckf, s.part_inv, s.fut_stat, s.mask, s.nbmask, s.pos, s.vel, s.w, s.vz0, s.res4, s.fut, s.fut_out, s.obs, s.obs_ck,
                     s.obs_cnt, s.obs_maxlen, s.planes_h, s.planes_v, s.planes_h0, s.planes_v0, s.pt_rot, s.pt_pyr,
                     s.birth, s.plan, s.plan_pbase, s.plan_inside, s.nstatic, s.fov_rec, s.fov_slot, s.fov_key, s.fov_spos, s.fov_rec_s, s.fov_slot_s, s.pyr_cnt, s.in_n, s.pmask, s.ta, s.dflag, s.dirty,
-                    s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.ro_cnt, m->k.in_rec, m->k.in_cnt, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
+                    s.blk_cnt, s.occ_xyz, s.p_tab, s.v_tab, s.r_tab, s.fs, m->k.mv_rec, m->k.ro_cnt, m->k.in_rec, m->k.in_cnt, m->k.tile_bits, m->k.omask, m->k.ck_items, m->k.wu_items, m->k.n_items, m->k.nb_tab, m->k.expmask,
                     s.tile_moving, m->k.ro_stat, m->k.ro_sub, m->k.part_predict, m->k.tile_fov, m->k.view_list, m->k.tile_cls, s.tile_live, s.fut_dirty, m->k.part_resample, m->k.vb_cnt, m->k.vb_idx, m->k.work_list, m->k.child, m->k.part_birth, m->k.vz_q, m->pts_dev, s.birth_ovf, s.birth_cvr};
     for (void* p : ptrs) if (p) chk(hipFree(p), "hipFree");
     if (m->res_true) chk(hipFree(m->res_true), "hipFree");
@@ -435,6 +436,11 @@ extern "C" int dspmap_init_device(dspmap_t* m) {
     HIPCHK(m, dalloc(&k.mv_rec, ntiles * 64 * d.slots * 2));
     HIPCHK(m, dalloc(&k.in_rec, ntiles * 64 * d.slots * 2));
     HIPCHK(m, dalloc(&k.in_cnt, ntiles));
+    {   // the tile bitmaps (DevState::vis_bits): three tables of one bit per tile, whole 64-bit words
+        const size_t nw = (ntiles + 63) / 64 * 2;
+        HIPCHK(m, dalloc(&k.tile_bits, 3 * nw));
+        HIPCHK(m, hipMemset(k.tile_bits, 0, sizeof(unsigned) * 3 * nw));
+    }
     HIPCHK(m, dalloc(&s.in_n, 2 * ntiles));
     HIPCHK(m, hipMemset(s.in_n, 0xff, sizeof(int) * 2 * ntiles));   // (no prediction's stamp)
     HIPCHK(m, dalloc(&s.pmask, W)); HIPCHK(m, dalloc(&s.ta, W)); HIPCHK(m, dalloc(&s.dflag, (size_t)d.v_loc)); HIPCHK(m, dalloc(&s.dirty, (size_t)DSP_DIRTY_CAP));
@@ -601,8 +607,9 @@ extern "C" int dspmap_set_param(dspmap_t* m, int key, double v) {
             break;
         case DSPMAP_P_FRAME_BRANCHES: m->frame_branches = v < 0 ? -1 : (v != 0 ? 1 : 0); m->graph_epoch++; break;
         case DSPMAP_P_RESAMPLE_SPLIT: m->resample_split = v != 0 ? 1 : 0; m->graph_epoch++; break;
+        case DSPMAP_P_TILE_BITMAPS: m->tile_bitmaps = v != 0; m->graph_epoch++; break;
         case DSPMAP_P_SIDE_PLACEMENT: {
-            const int iv = v < 0 ? 3 : (int)v;
+            const int iv = v < 0 ? 16 + 3 : (int)v;
             m->side_fork = (iv >> 4) > 2 ? 0 : (iv >> 4);
             m->side_wg = (iv & 15) ? (iv & 15) : 3;
             m->graph_epoch++;
@@ -664,6 +671,7 @@ extern "C" double dspmap_get_param(const dspmap_t* m, int key) {
         case DSPMAP_P_FRAME_BRANCHES: return m->frame_branches;
         case DSPMAP_P_SIDE_PLACEMENT: return m->side_fork * 16 + m->side_wg;
         case DSPMAP_P_RESAMPLE_SPLIT: return m->resample_split;
+        case DSPMAP_P_TILE_BITMAPS: return m->tile_bitmaps ? 1 : 0;
         case DSPMAP_P_TILING: return m->d.tiling;
         case DSPMAP_P_USE_GRAPH: return m->use_graph ? 1 : (m->direct_ring ? 2 : 0);
         default: return 0;
@@ -907,6 +915,12 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
         m->last_resample_variant = resample_variant(c);
         m->branch_pending = true;
         return;
+    }
+    // (DSPMAP_P_TILE_BITMAPS) a sparse unsharded map: the sweeps of this frame find their empty tiles in the bitmaps k_obs_points rebuilds
+    c.tile_bits = !fork && c.sparse && m->tile_bitmaps && c.k.tile_bits && m->d.v_true == m->d.v_glob && !m->mgpu_bound;
+    if (c.tile_bits) {
+        const size_t nw = ((size_t)c.k.ntiles + 63) / 64 * 2;
+        c.s.vis_bits = c.k.tile_bits; c.s.pred_bits = c.k.tile_bits + nw; c.s.arr_bits = c.k.tile_bits + 2 * nw;
     }
     const bool split0 = frame_splits_placement(m, c, fork);
     const bool split = split0;

@@ -134,11 +134,12 @@ struct dspmap {
     int ro_force = -1;               // DSPMAP_P_ROLLOUT_INLINE: -1 from the hint, 0 / 1 forced
     bool sparse_mode = false;        // launch k_predict's SPARSE variant (dspmap_pick_sweep_mode: from the hint, with hysteresis)
     int sparse_force = -1;           // DSPMAP_P_SPARSE_SWEEP: -1 from the hint, 0 / 1 forced
+    bool tile_bitmaps = true;        // DSPMAP_P_TILE_BITMAPS: the sweeps of a sparse unsharded map's whole frames find their empty tiles in bitmaps (DevState::vis_bits)
     int resample_split = 0;          // DSPMAP_P_RESAMPLE_SPLIT: the tiles no newborn can reach are resampled on the side stream, beside the weight update and the births
     bool rsplit_enq = false;         // the frame enqueue_frame queued / captured last does so
     bool graph_rsplit[2] = {false, false};   // ... per captured graph
     long long rsplit_frames = 0;     // frames that ran that way (dspmap_debug_resample_split_frames)
-    int side_fork = 0, side_wg = 3;  // split placement: where the side launch leaves the main chain / its workgroups per CU (DSPMAP_P_SIDE_PLACEMENT)
+    int side_fork = 1, side_wg = 3;  // split placement: where the side launch leaves the main chain / its workgroups per CU (DSPMAP_P_SIDE_PLACEMENT)
     int place_split_tiles = 8192;    // maps with at least this many tiles place the arrivals of the tiles outside the field of view
                                      // on the side stream, beside the pair kernels (DSPMAP_P_PLACE_SPLIT_TILES)
     int resample_wg_tiles = 8192;    // one-word maps with fewer tiles (and sparse ones of any size) run the four-waves-per-tile resampler (DSPMAP_P_RESAMPLE_WG_TILES)

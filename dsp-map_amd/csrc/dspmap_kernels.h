@@ -10,6 +10,7 @@ struct KernelScratch {
     unsigned long long* omask;      // [v_loc*mw] occupancy (mask | nbmask) before the frame's prediction (k_predict -> k_place)
     float4* in_rec;     // [ntiles][64*slots][2] per-destination-tile inbox of movers (k_predict tail -> k_place)
     int* in_cnt;        // [ntiles] inbox fill; zeroed again by k_place
+    unsigned* tile_bits;  // [3][(ntiles + 63) / 64 * 2] the tile bitmaps (DevState::vis_bits / pred_bits / arr_bits point into it while they are in use)
     u64* expmask;       // [v_loc*mw] particles that left the slab (multi-GPU), or nullptr
     int* part_predict;  // [ntiles*4]
     int* tile_fov;      // [ntiles] 1 = a particle inside this tile may lie in the field of view (k_predict, conservative box test):
@@ -61,6 +62,7 @@ struct LaunchCtx {
     bool resample_rev = false;   // k_resample walks the tiles from the last one down (after a k_place that ended there)
     bool place_split = false; // this frame places the arrivals of the tiles with a view first (launch_claim sel = 1) and the others beside the pair
                               // kernels (sel = 0): k_predict leaves the list of the tiles with a view (KernelScratch::view_list)
+    bool tile_bits = false;   // this frame's sweeps go by the tile bitmaps (sparse whole frames of an unsharded map; DSPMAP_P_TILE_BITMAPS)
     int side_wg = 3;          // workgroups per CU of the side-stream placement (sel = 0; DSPMAP_P_SIDE_PLACEMENT)
     bool branches = false;   // this frame runs as two branches (DSPMAP_P_FRAME_BRANCHES; see KernelScratch::tile_cls)
     bool sparse = false; // most tiles hold nothing (dspmap::sparse_mode): k_predict's variant that leaves such tiles first

@@ -52,7 +52,7 @@ __global__ void k_reset(MapDims d, DevState s, int flags) {
     if (flags & RESET_OBS) {
         for (int i = gt; i < d.np; i += gn) { s.obs_cnt[i] = 0; s.obs_maxlen[i] = -1.f; }
         for (int i = gt; i < d.np * DSP_OBS_CAP; i += gn) s.obs_ck[i] = 0;
-        if (gt == 0) { s.fs->n_valid = 0; s.fs->n_obs = 0; s.fs->has_expected_override = 0; }
+        if (gt == 0) { s.fs->n_valid = 0; s.fs->n_obs = 0; s.fs->has_expected_override = 0; s.fs->bits_on = 0; }
     }
     if (flags & RESET_PRED) {
         for (int i = gt; i < d.np; i += gn) s.pyr_cnt[i] = 0;
@@ -68,7 +68,22 @@ __global__ void k_reset(MapDims d, DevState s, int flags) {
 // sensor-centred frame (:247), FOV test (:250), pyramid cell (:260-263), range (:266).
 // --------------------------------------------------------------------------
 template <bool FUSED>
-__global__ void __launch_bounds__(256) k_obs_points(MapDims d, DevState s, const FrameParams* __restrict__ ring, int ring_mask) {
+__global__ void __launch_bounds__(256) k_obs_points(MapDims d, DevState s, const FrameParams* __restrict__ ring, int ring_mask, int bits_blk0) {
+    // bits_blk0 >= 0 (sparse whole frames): the workgroups from that index on rebuild the tile bitmaps from the per-tile flags, 256 tiles
+    // each (DevState::vis_bits): whatever wrote the flags since the last frame -- a frame, an import, a restored checkpoint -- is in them
+    if (FUSED && bits_blk0 >= 0 && (int)blockIdx.x >= bits_blk0) {
+        const int ntl = (d.v_loc + 63) >> 6;
+        const int t = ((int)blockIdx.x - bits_blk0) * 256 + (int)threadIdx.x;
+        const bool on = t < ntl && (s.tile_live[t] != 0 || s.fut_dirty[t] != 0);
+        const u64 b = __ballot(on);
+        const int w0 = t >> 5;   // (lane 0's tile: a multiple of 64)
+        if (lane_id() == 0 && t < ntl) {
+            s.vis_bits[w0] = (unsigned)b; s.vis_bits[w0 + 1] = (unsigned)(b >> 32);
+            s.pred_bits[w0] = (unsigned)b; s.pred_bits[w0 + 1] = (unsigned)(b >> 32);
+            s.arr_bits[w0] = 0u; s.arr_bits[w0 + 1] = 0u;
+        }
+        return;
+    }
     // A captured frame takes its parameter block straight from the pinned host ring the caller filled (no copy node in
     // front of the graph): every workgroup of this -- the frame's first -- kernel reads the slot over the bus, workgroup 0
     // also stores it in HBM for the kernels that follow.  The ring's read position is advanced by k_predict, after every
@@ -105,12 +120,13 @@ __global__ void __launch_bounds__(256) k_obs_points(MapDims d, DevState s, const
                 if (blockIdx.x == 0) { s.planes_v[3 * j] = o[0]; s.planes_v[3 * j + 1] = o[1]; s.planes_v[3 * j + 2] = o[2]; }
             }
         }
-        const int gt = blockIdx.x * blockDim.x + threadIdx.x, gn = gridDim.x * blockDim.x;
+        const int gt = blockIdx.x * blockDim.x + threadIdx.x, gn = (bits_blk0 >= 0 ? bits_blk0 : (int)gridDim.x) * blockDim.x;   // (the bitmap workgroups have left)
         for (int i = gt; i < d.np * DSP_OBS_CAP; i += gn) s.obs_ck[i] = 0;         // Ck = 0 (:235-238)
         for (int i = gt; i < d.np; i += gn) s.pyr_cnt[i] = 0;                       // pyramids are rebuilt by prediction (:638-642)
         if (gt == 0) {
             s.fs->cur_pos[0] = cpx; s.fs->cur_pos[1] = cpy; s.fs->cur_pos[2] = cpz;
             s.fs->n_valid = 0; s.fs->n_obs = 0; s.fs->has_expected_override = 0;   // k_obs_gather accumulates the first two
+            s.fs->bits_on = bits_blk0 >= 0 ? 1 : 0;
             s.fs->n_voxel_full_import = 0; s.fs->n_exp_up = 0; s.fs->n_exp_down = 0; s.fs->n_pyr_removed = 0; s.fs->n_dirty = 0; s.fs->n_overflow_inexact = 0; s.fs->n_place_vf = 0; s.fs->n_place_pf = 0; s.fs->n_view_tiles = 0; s.fs->pred_epoch = s.fs->pred_epoch + 1; s.fs->live_hint = s.fs->live_acc; s.hint_out[0] = s.fs->live_acc; s.fs->live_acc = 0; s.hint_out[1] = s.fs->mv_acc; s.fs->mv_acc = 0;
         }
     } else {
@@ -1419,6 +1435,10 @@ __global__ void __launch_bounds__(256) k_birth_insert(MapDims d, DevState s, Fil
                     s.w[idx] = newborn_w;
                     atomicOr(&s.nbmask[(size_t)lv * d.mw + (sl >> 6)], 1ull << (sl & 63));  // flag 15
                     s.tile_live[lv >> 6] = 1;   // (the tile may have been empty: the sweeps must visit it again)
+                    if (s.vis_bits) {   // ... this frame's resampling too (one atomic per tile and frame, not per newborn: the others find the bit)
+                        const int tl = lv >> 6;
+                        if (!((__hip_atomic_load(&s.vis_bits[tl >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (tl & 31)) & 1u)) atomicOr(&s.vis_bits[tl >> 5], 1u << (tl & 31));
+                    }
                     born = true;
                 } else {
                     dropped = true;
@@ -1510,11 +1530,12 @@ void launch_frame_setup(const LaunchCtx& c, bool reset_obs) {
 
 void launch_setup_and_bin(const LaunchCtx& c, int n_pts_grid, bool gather, const FrameParams* ring, int ring_mask) {   // whole frame: launch_frame_setup(c, true) + launch_obs_bin
     const int grid = n_pts_grid > 0 ? (n_pts_grid + 255) / 256 : 1;
-    hipLaunchKernelGGL(k_obs_points<true>, dim3(grid), dim3(256), 0, c.stream, c.d, c.s, ring, ring_mask);
+    const int nbits = c.tile_bits ? (c.k.ntiles + 255) / 256 : 0;   // the bitmap rebuild rides along (sparse whole frames)
+    hipLaunchKernelGGL(k_obs_points<true>, dim3(grid + nbits), dim3(256), 0, c.stream, c.d, c.s, ring, ring_mask, c.tile_bits ? grid : -1);
     if (gather) hipLaunchKernelGGL(k_obs_gather, dim3(c.d.np), dim3(WAVE), 0, c.stream, c.d, c.s);
 }
 void launch_obs_bin(const LaunchCtx& c, int n_pts_grid) {
-    if (n_pts_grid > 0) hipLaunchKernelGGL(k_obs_points<false>, dim3((n_pts_grid + 255) / 256), dim3(256), 0, c.stream, c.d, c.s, (const FrameParams*)nullptr, 0);
+    if (n_pts_grid > 0) hipLaunchKernelGGL(k_obs_points<false>, dim3((n_pts_grid + 255) / 256), dim3(256), 0, c.stream, c.d, c.s, (const FrameParams*)nullptr, 0, -1);
     hipLaunchKernelGGL(k_obs_gather, dim3(c.d.np), dim3(WAVE), 0, c.stream, c.d, c.s);
 }
 

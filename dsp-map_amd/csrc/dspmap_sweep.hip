@@ -351,6 +351,9 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
         if ((int)blockIdx.x >= nextra0) {
             const int bq0 = (int)blockIdx.x - nextra0;
             const int bx0 = rev ? (int)gridDim.x - nextra0 - 1 - bq0 : bq0;
+            // (tile bitmaps: one cached word says that the tile holds nothing and has nothing to zero -- no per-tile count is written,
+            // k_reduce_counters adds up the visited tiles' only)
+            if (s.vis_bits && !((sload_i(reinterpret_cast<const int*>(s.vis_bits) + (bx0 >> 5)) >> (bx0 & 31)) & 1)) return;
             int t_live, f_dirty, f_clear;
             sload_i3(s.tile_live + bx0, s.fut_dirty + bx0, &s.fpar->clear_fut, t_live, f_dirty, f_clear);
             tflags = (t_live ? 1 : 0) | ((f_clear && f_dirty) ? 2 : 0);
@@ -716,6 +719,7 @@ __global__ void __launch_bounds__(NW * 64, PRED_LB) k_predict(MapDims d, DevStat
         batch_append<TB>(in_cnt, key, pos);
 #pragma unroll
         for (int j = 0; j < TB; ++j) {
+            if (SPARSE && s.arr_bits && key[j] >= 0 && pos[j] == 0) atomicOr(&s.arr_bits[key[j] >> 5], 1u << (key[j] & 31));   // the inbox's first record this frame
             // beyond the inbox: more arrivals than the tile has slots; k_place counts them as dropped
             if (key[j] < 0 || pos[j] >= cap) continue;
             float4 ra, rb;
@@ -966,6 +970,7 @@ __device__ __forceinline__ void place_tile(const MapDims& d, const DevState& s, 
     }
     if (tid == 0) {
         in_cnt[BX] = 0; s.in_n[2 * BX] = n; s.in_n[2 * BX + 1] = s.fs->pred_epoch; s.tile_live[BX] = 1;   // ready for the next frame; the tile holds particles now
+        if (s.vis_bits && !was_live) atomicOr(&s.vis_bits[BX >> 5], 1u << (BX & 31));   // (tile bitmaps) ... this frame's resampling has to visit it
         if (s_cnt[0]) atomicAdd(&s.fs->n_place_vf, s_cnt[0]);   // (rare events: the frame's counts, reset with the pyramid lists)
         if (s_cnt[1]) atomicAdd(&s.fs->n_place_pf, s_cnt[1]);
     }
@@ -1019,12 +1024,16 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
     }
     if (bq0 >= nt) return;
     const int epoch = sel >= 0 ? sload_i(&s.fpar->epoch) : 0;
+    // (tile bitmaps) has the tile arrivals at all?  One cached word instead of a round trip to the tile's own count
+    auto has_arrivals = [&](int BX) -> bool { return !s.arr_bits || ((sload_i(reinterpret_cast<const int*>(s.arr_bits) + (BX >> 5)) >> (BX & 31)) & 1); };
     int n_in, tf = 0;
     {   // the first tile's words; a workgroup whose ONLY tile has nothing for it leaves HERE, before the loop below is set up: the
         // invariants the compiler hoists in front of it (~100 vector instructions with the scalar registers it parks in lanes) were
         // what a sparse map's placement spent its time on -- 87 120 workgroups, 12 k with arrivals
         const int bqr = rev ? nt - 1 - bq0 : bq0;
         const int BX = bqr < n0 ? t0 + bqr : t1 + (bqr - n0);
+        if (!has_arrivals(BX)) { if (bq0 + stride >= nt && !(has_vz && BX == 0)) return; n_in = 0; }
+        else
         if (sel >= 0) sload_i2(in_cnt + BX, tile_fov + BX, n_in, tf); else if (tcls) sload_i2(in_cnt + BX, tcls + BX, n_in, tf); else n_in = sload_i(in_cnt + BX);
         if (bq0 + stride >= nt && !(has_vz && BX == 0)) {
             if (n_in == 0) return;
@@ -1037,7 +1046,7 @@ __global__ void __launch_bounds__(256, PLACE_LB) k_place(MapDims d, DevState s, 
         const int BX = bqr < n0 ? t0 + bqr : t1 + (bqr - n0);   // tile index
         if (has_vz && BX == 0 && sel != 0 && threadIdx.x == 0)   // k_predict drew 3 table values per ranked particle (:655-657)
             s.fs->v_cur = (int)(((long long)s.fs->v_cur + 3ll * (long long)s.fs->occupied_count) % tab_n);
-        if (bq != bq0) { if (sel >= 0) sload_i2(in_cnt + BX, tile_fov + BX, n_in, tf); else if (tcls) sload_i2(in_cnt + BX, tcls + BX, n_in, tf); else n_in = sload_i(in_cnt + BX); }
+        if (bq != bq0) { if (!has_arrivals(BX)) n_in = 0; else if (sel >= 0) sload_i2(in_cnt + BX, tile_fov + BX, n_in, tf); else if (tcls) sload_i2(in_cnt + BX, tcls + BX, n_in, tf); else n_in = sload_i(in_cnt + BX); }
         if (n_in == 0) continue;   // (no arrivals -- or the tile's owner is done with them)
         if (tcls && !cls_mine(tf, cls)) continue;   // (sel < 0 with tcls: tf holds the tile's class)
         if (sel >= 0) {   // a split placement: the other launch owns the tiles of the other kind
@@ -1088,6 +1097,7 @@ __global__ void __launch_bounds__(256, RBK_ >= 8 ? 3 : 5) k_resample(MapDims d, 
     const bool cubes = d.tiling != 0;
     const int lv = wave_g * 64 + l;
     if (wave_g < 0 || wave_g * 64 >= d.v_loc) return;
+    if (s.vis_bits && !((sload_i(reinterpret_cast<const int*>(s.vis_bits) + (wave_g >> 5)) >> (wave_g & 31)) & 1)) return;   // (tile bitmaps) empty, and nothing arrived or was born
     int t_live, t_mov, tc;
     if (rev & 6) {
         // (DSPMAP_P_RESAMPLE_SPLIT) the stage in two launches: the tiles no newborn can reach (not Q) BESIDE the weight update and the births
@@ -1459,6 +1469,7 @@ __global__ void __launch_bounds__(256) k_resample_wg(MapDims d, DevState s, int*
     unsigned short* s_cp = (unsigned short*)(cs + cells);
     const int lv = BX * 64 + l;
     const bool inr = lv < d.v_loc;
+    if (s.vis_bits && !((sload_i(reinterpret_cast<const int*>(s.vis_bits) + (BX >> 5)) >> (BX & 31)) & 1)) return;   // (tile bitmaps) empty, and nothing arrived or was born
     const int t_live = s.tile_live[BX];   // (requested together with the occupancy words: one round trip)
     u64 nb[MW], m[MW];
     bool any_m = false, any_nb = false;
@@ -2320,7 +2331,9 @@ __global__ void __launch_bounds__(1024) k_reduce_counters(DevState s, KernelScra
     __shared__ int s_red[1024];
     const int tid = threadIdx.x;
     int acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    const unsigned* pb = s.fs->bits_on ? k.tile_bits + (size_t)((k.ntiles + 63) / 64 * 2) : nullptr;   // (the last frame's k_predict visited these tiles only)
     for (int i = tid; i < k.ntiles; i += 1024) {
+        if (pb && !((pb[i >> 5] >> (i & 31)) & 1u)) continue;
         acc[0] += k.part_predict[i * 4]; acc[1] += k.part_predict[i * 4 + 1];
         acc[2] += k.part_predict[i * 4 + 2]; acc[3] += k.part_predict[i * 4 + 3];
     }

@@ -97,6 +97,7 @@ struct FrameScalars {
     int occupied_count; // readout
     int n_voxel_full_import; // multi-GPU: movers received from a neighbour that found their voxel full
     int n_dirty;            // entries of DevState::dirty
+    int bits_on;            // the last frame's sweeps went by the tile bitmaps (DevState::vis_bits): k_reduce_counters gates k_predict's per-tile counts with pred_bits
     int n_overflow_inexact; // diagnostics: voxels / arrivals the re-slotting pass could not treat exactly (see k_place_fix)
     int mv_acc;                // tiles in which k_resample_wg noted more than RO_INLINE_MAX moving particles (moved to hint_out[1] like live_acc)
     int live_acc, live_hint;   // every 64th tile that k_resample leaves non-empty counts itself in live_acc; the next frame's first kernel
@@ -230,6 +231,18 @@ struct DevState {
                         // the range-sorted list the pair kernels read (without a global cut: min(pyr_cnt, capp))
     long long* pyr_gcnt; // [np] or nullptr: this rank's list lengths before the cut, summed over the ranks by the Ck all-reduce they ride on
     int* in_n;          // [2 * tiles] {arrivals the last placement served in the tile, FrameScalars::pred_epoch of that placement}
+    // TILE BITMAPS of a sparse map's whole frames (round 6; nullptr: not in use).  A sparse map's sweeps launch a workgroup per tile to find
+    // most of them empty (87 120 tiles at 264x264x80, ~12 k with particles): what an empty tile costs is the round trip of the scalar loads
+    // that tell -- three words at three addresses per tile.  One BIT per tile instead, 32 tiles a word: the whole table (11 kB at that size)
+    // sits in the scalar cache, and an empty tile's workgroup is gone as fast as the dispatcher can start the next one.
+    //   vis_bits   tiles k_predict / k_resample visit: live or with dirty future accumulators when the frame began (k_obs_points' extra
+    //              workgroups rebuild it from tile_live / fut_dirty every frame -- the flags stay the truth, whoever wrote them), plus the
+    //              tiles that received their first particle during the frame (k_place, k_birth_insert set the bit with the flag)
+    //   pred_bits  the same table as the frame began: the tiles k_predict visited (k_reduce_counters adds up THEIR counts only)
+    //   arr_bits   tiles with arrivals: set by k_predict's tail for the first record of an inbox, zeroed with the rebuild
+    unsigned* vis_bits;
+    unsigned* pred_bits;
+    unsigned* arr_bits;
     int* fut_dirty;     // [tiles] 1 = something was added to the tile's future accumulators (fut, fut_stat) since they were zeroed
     int* tile_moving;   // [tiles] 0 = every LIVE particle of the tile has velocity (0, 0): rewritten by k_predict for every tile it visits (it reads
                         // the velocities anyway), set by whoever puts a moving particle there afterwards (k_place: arrivals, k_birth_insert:

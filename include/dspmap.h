@@ -181,9 +181,11 @@ enum dspmap_param {
                                        order in use); sharded handles (Z-slabs) keep index order.  Results, state records and sweep order are the reference's
                                        whatever the storage: the same result slot for slot.  The environment variable DSPMAP_TILING presets it */
     DSPMAP_P_SIDE_PLACEMENT = 28,   /* frames that split their placement (DSPMAP_P_PLACE_SPLIT_TILES): value = 16 * fork + footprint.  fork: where the launch that
-                                       places the arrivals of the tiles without a view leaves the main chain -- 0 (default) behind the list preparation, 1 behind
-                                       the placement of the tiles with a view, 2 behind the prediction; footprint: its workgroups per compute unit (1 .. 15,
-                                       default 3).  A scheduling knob: same result slot for slot */
+                                       places the arrivals of the tiles without a view leaves the main chain -- 0 behind the list preparation (rounds 3-5), 1
+                                       (default) behind the placement of the tiles with a view, 2 behind the prediction; footprint: its workgroups per compute
+                                       unit (1 .. 15, default 3); a negative value restores the default (19).  Measured on identical maps in one process
+                                       (tools/ab_maps.py): 132x132x60 saturated 19 against 3: -2.9 %, 35: +8 %; 264x264x80 saturated: -1.4 %.  A scheduling knob:
+                                       same result slot for slot */
     DSPMAP_P_RESAMPLE_SPLIT = 29,   /* frames that split their placement on cube storage, with a birth cloud made on the device from the frame's own view
                                        (DSPMAP_P_VELOCITY_ESTIMATOR 2, or every point in view a static source): 1 = the resampling stage (:924-1057) runs as two
                                        launches -- the tiles no newborn of this frame can reach (outside the field of view grown by the position table's
@@ -191,6 +193,12 @@ enum dspmap_param {
                                        stage of the main chain; the others behind the births; the rollout behind both.  A frame with an empty view (stale
                                        birth cloud, :1379-1381) resamples every tile behind the births.  0 = one launch behind the births.  Same result
                                        slot for slot.  The environment variable DSPMAP_RESAMPLE_SPLIT presets it */
+    DSPMAP_P_TILE_BITMAPS = 30,     /* whole frames of an unsharded map the handle sweeps as a sparse one (most 64-voxel tiles empty, DSPMAP_P_SPARSE_SWEEP): 1
+                                       (default) = the three sweeps (prediction, placement, resampling) learn that a tile has nothing for them from one BIT per
+                                       tile -- tables of a few kB that stay in the scalar cache, rebuilt from the per-tile flags by the frame's first kernel
+                                       and extended by whoever puts the first particle into an empty tile -- instead of from the tile's own words in
+                                       memory: an empty tile's workgroup leaves as fast as the next one can be started (264x264x80 filled by the depth
+                                       stream: 87 120 tiles, ~12 k with particles); 0 = every workgroup loads its tile's flags (rounds 3-5).  Same result */
     DSPMAP_P_PAIR_CULL_SIGMAS = 13  /* mapUpdate evaluates a (particle, observation) pair only if their ranges differ by at most this many
                                        sigma_ob (default 9: the dropped terms are < 1e-19 and zero on the fixed-point Ck grid);
                                        a huge value evaluates every pair of the neighbourhood like the reference's loops */

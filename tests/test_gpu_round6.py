@@ -51,6 +51,10 @@ def _trio(dsp, cfg, estimator=0, extra=None):
             assert m.get_param(dsp.capi.P_RESAMPLE_SPLIT) == 1
         else:
             m.set_param(dsp.capi.P_RESAMPLE_SPLIT, 0)
+        # the index-order map is the frame of rounds 1-5 in this respect too: every workgroup of a sparse sweep loads its tile's own flags;
+        # the others find their empty tiles in the tile bitmaps (DSPMAP_P_TILE_BITMAPS, in use where the sparse sweep is)
+        m.set_param(dsp.capi.P_TILE_BITMAPS, 0 if tiling == 0 else 1)
+        assert m.get_param(dsp.capi.P_TILE_BITMAPS) == (0 if tiling == 0 else 1)
         m.set_param(dsp.capi.P_FRAME_BRANCHES, br)
         assert m.get_param(dsp.capi.P_FRAME_BRANCHES) == br
         if estimator:
@@ -62,7 +66,7 @@ def _trio(dsp, cfg, estimator=0, extra=None):
 
 
 @pytest.mark.parametrize("case", ["saturated_step", "nearly_full_voxels", "depth_stream_estimator", "two_words_overfull_lists",
-                                  "moving_fill_turning", "depth_stream_static_tags", "sparse_sweep_variant", "empty_view_frames"])
+                                  "moving_fill_turning", "depth_stream_static_tags", "sparse_sweep_variant", "empty_view_frames", "sparse_bitmaps_moving"])
 def test_cube_storage_and_two_branch_frame_change_nothing(dsp, case):
     """DSPMAP_P_TILING + DSPMAP_P_FRAME_BRANCHES (round 6).  Storage: the device arrays are indexed tile by tile; with cubes for tiles the
     voxel -> (tile, lane) map changes, the reference's voxel index (:1081) stays what orders sweeps (source keys) and what every result
@@ -85,6 +89,9 @@ def test_cube_storage_and_two_branch_frame_change_nothing(dsp, case):
       empty_view_frames     the stream, but in every third frame all points lie BEHIND the sensor while it turns: the view is empty, the
                             birth stage re-uses the cloud of the last non-empty view (:1379-1381) and its newborns land where that
                             frame's field of view was -- outside this frame's Q: the split resampling takes every tile behind the births
+      sparse_bitmaps_moving the stream with the device estimator (newborns with velocities: their rollout dirties the accumulators of EMPTY tiles,
+                            tiles fill and empty as the sensor turns), sparse sweeps forced, the future status read in some frames, cleared in
+                            others and left to accumulate in the rest: maps 1 and 3 sweep by the tile bitmaps, map 2 by the tiles' own flags
     A FOURTH map runs the serial frame with its placement split and the resampling stage split (DSPMAP_P_RESAMPLE_SPLIT) in every case."""
     scene_mod = __import__("dsp-map_amd.scene", fromlist=["CorridorScene"])
     quat = (1.0, 0.0, 0.0, 0.0)
@@ -96,14 +103,22 @@ def test_cube_storage_and_two_branch_frame_change_nothing(dsp, case):
         quat = UP
     else:
         cfg = dict(nx=66, ny=66, nz=40, res=0.15, ppv=24)
-    if case == "sparse_sweep_variant":
+    if case in ("sparse_sweep_variant", "sparse_bitmaps_moving"):
         extra[dsp.capi.P_SPARSE_SWEEP] = 1
-    maps = _trio(dsp, cfg, estimator=2 if case == "depth_stream_estimator" else 0, extra=extra)
+    maps = _trio(dsp, cfg, estimator=2 if case in ("depth_stream_estimator", "sparse_bitmaps_moving") else 0, extra=extra)
     res = cfg["res"]
     if case in ("depth_stream_estimator", "depth_stream_static_tags", "sparse_sweep_variant"):
         sc = scene_mod.CorridorScene(66 * 0.15, 66 * 0.15, 40 * 0.15, seed=1234, device="cuda")
         frames = [sc.frame(f / 30.0) for f in range(90)]
         every = 15
+    elif case == "sparse_bitmaps_moving":
+        sc = scene_mod.CorridorScene(66 * 0.15, 66 * 0.15, 40 * 0.15, seed=1234, device="cuda")
+        frames = []
+        for f in range(60):
+            pts, pos, _ = sc.frame(f / 30.0)
+            yaw = 0.06 * f                                  # a steady turn: tiles enter and leave the view, fill and empty
+            frames.append((pts, pos, (float(np.cos(yaw / 2)), 0.0, 0.0, float(np.sin(yaw / 2)))))
+        every = 5
     elif case == "empty_view_frames":
         sc = scene_mod.CorridorScene(66 * 0.15, 66 * 0.15, 40 * 0.15, seed=1234, device="cuda")
         frames = []
@@ -183,7 +198,7 @@ def test_cube_storage_and_two_branch_frame_change_nothing(dsp, case):
             ca = snaps[0][4]
             for k in tot:
                 tot[k] += ca[k]
-        if f % every != every - 1:
+        if f % every != every - 1 and not (case == "sparse_bitmaps_moving" and f % 5 in (1, 2)):   # (that case: two frames in five leave the accumulators alone)
             for m in maps:
                 m.clearOccupancyMapPrediction()
     br = [m.frame_branches() for m in maps]
@@ -205,8 +220,10 @@ def test_cube_storage_and_two_branch_frame_change_nothing(dsp, case):
         assert 1900 <= br[0][4] <= 2000 and tot["n_moved"] > 100000, (br, tot)
     if case == "depth_stream_estimator":
         assert br[0][4] > 0, br                                     # newborns of matched clusters / random velocities were noted
-    if case == "sparse_sweep_variant":
+    if case in ("sparse_sweep_variant", "sparse_bitmaps_moving"):
         assert all(m.get_param(dsp.capi.P_SPARSE_SWEEP) == 1 for m in maps)
+    if case == "sparse_bitmaps_moving":
+        assert br[0][4] > 0, br                                     # velocities were given: the rollout ran
     for m in maps:
         m.close()
 
