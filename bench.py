@@ -843,6 +843,12 @@ def main():
                 tab, nf = g.phase_ms()
                 sel = tab[len(ranges)][3] > 0
                 cnts = [mm.counters() for mm in g.maps]
+                try:   # the longest pyramid list of the whole map (the slabs' lists added up) against the reference's capacity (:66): what decides
+                    # whether a frame has to select the lists' cut over all ranks
+                    pc = np.sum([np.asarray(mm.pyramid_counts(), np.int64) for mm in g.maps], axis=0)
+                    cnts[0]["longest_list_over_capp"] = round(float(pc.max()) / float(g.maps[0].capp), 4)
+                except Exception:
+                    pass
                 g.close()
                 return tab, sel, cnts
 
@@ -928,6 +934,7 @@ def main():
                 "one_gpu_ms": one, "projected_speedup": round(one / proj, 2) if one else None,
                 "projected_efficiency_8": round(one / proj / NW, 3) if one else None,
                 "in_view_particles_per_slab": [int(c["n_fov"]) for c in cnts],
+                "longest_list_over_capp": cnts[0].get("longest_list_over_capp"),
                 "block_cyclic_emulation": cyc}
             del fre, fr8
         except Exception as e:

@@ -208,14 +208,23 @@ int dspmap_mgpu_ck_phase(dspmap* m) {
         m->mgpu_placed = false;
         if (m->vz_frames_at_begin <= 0) c.s.vz0 = nullptr;
         if (m->mgpu_split) {
+            // (DSPMAP_P_SIDE_PLACEMENT: the side launch leaves the main chain behind the placement of the tiles with a view -- the default --
+            // or behind the list preparation; the next kernel of the main chain is queued before the side launch either way)
+            const bool early = m->side_fork >= 1;
+            if (early) HIPCHK(m, hipEventRecord(m->ev_fork2, m->stream));
             launch_pyr_prepare(c);
-            HIPCHK(m, hipEventRecord(m->ev_fork2, m->stream));
+            if (!early) HIPCHK(m, hipEventRecord(m->ev_fork2, m->stream));
+            auto side = [&]() -> int {
+                HIPCHK(m, hipStreamWaitEvent(m->stream2, m->ev_fork2, 0));
+                LaunchCtx c2 = c;
+                c2.stream = m->stream2;
+                launch_claim(c2, 0, 0, 0, 0, 0);
+                HIPCHK(m, hipEventRecord(m->ev_join, m->stream2));
+                return DSPMAP_OK;
+            };
+            if (early) { const int rs = side(); if (rs != DSPMAP_OK) return rs; }
             launch_ck_partial(c, true);
-            HIPCHK(m, hipStreamWaitEvent(m->stream2, m->ev_fork2, 0));
-            LaunchCtx c2 = c;
-            c2.stream = m->stream2;
-            launch_claim(c2, 0, 0, 0, 0, 0);
-            HIPCHK(m, hipEventRecord(m->ev_join, m->stream2));
+            if (!early) { const int rs = side(); if (rs != DSPMAP_OK) return rs; }
             m->mgpu_side_pending = true;
             HIPCHK(m, hipGetLastError());
             return DSPMAP_OK;
