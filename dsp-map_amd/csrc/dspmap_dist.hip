@@ -490,7 +490,7 @@ static int phase_begin(dspmap* m, int n_points, const float* points_dev, int n_b
     LaunchCtx c = dspmap_ctx_of(m);
     launch_export_slab(c, 0, x->buf[0][0] + 8, x->xsend, x->cnt2, x->buf[1][0] + 8);   // both faces in one pass
     hipLaunchKernelGGL(k_dist_headers, dim3(1), dim3(64), 0, m->stream, x->buf[0][0], x->buf[1][0], x->cnt2, m->s.nstatic, x->nb_hi);
-    launch_birth_early(c, m->last_n_birth, false);   // newborn children: they only need the birth cloud (the rank rode on k_predict)
+    dspmap_mgpu_birth_early(m, c);   // newborn children: they only need the birth cloud (the rank rode on k_predict / on the estimator, beside it)
     m->mgpu_birth_early = true;
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
@@ -668,6 +668,8 @@ extern "C" int dspmap_mgpu_group_update(dspmap_t** hs, int n, int n_points, cons
     for (int i = 0; i < n; ++i) {
         mark(i, 0, 0);
         const int rc = phase_begin(hs[i], n_points, points_dev, n_birth, birth_dev, pos, stamp, q);
+        // (profiled: the estimator's side branch is joined inside the slab's own window, see the Ck phase below)
+        if (prof && rc == DSPMAP_OK && hs[i]->mgpu_side_pending) { (void)hipStreamWaitEvent(st, hs[i]->ev_join, 0); hs[i]->mgpu_side_pending = false; }
         mark(i, 0, 1);
         if (rc < 0) return rc;
         accepted += rc == DSPMAP_OK ? 1 : 0;
@@ -708,7 +710,20 @@ extern "C" int dspmap_mgpu_group_update(dspmap_t** hs, int n, int n_points, cons
         for (int i = 0; i < n; ++i) { LaunchCtx c = dspmap_ctx_of(hs[i]); launch_pyr_kept(c, hs[i]->dist->kstar, hs[i]->dist->kept); ++hs[i]->dist->exact_frames; }
         mark(n, 3, 1);   // (the whole selection, all slabs: 4 x (histogram, sum, pick) -- per rank a 1 / n share of the kernels + 4 all-reduces)
     }
-    for (int i = 0; i < n; ++i) { mark(i, 4, 0); const int rc = phase_ck(hs[i]); mark(i, 4, 1); if (rc != DSPMAP_OK) return rc; l.p[i] = hs[i]->s.obs_ck; }
+    for (int i = 0; i < n; ++i) {
+        mark(i, 4, 0);
+        const int rc = phase_ck(hs[i]);
+        // a slab that places the arrivals of its tiles without a view on the side stream (large slabs) joins that launch in its weight phase --
+        // which, in a group, comes after EVERY slab's Ck phase: unprofiled that is all the same (one GPU does all the work either way),
+        // but a profiled group charges each slab its own time, and the side launches of the slabs before would run inside the windows of
+        // the slabs behind (round 6: the Ck phases of slabs without a view measured 0.28 - 0.32 ms beside 0.02 - 0.03 for their
+        // neighbours).  Profiled, a slab's side launch is joined inside its own window -- on its own GPU it overlaps its own Ck pass,
+        // the all-reduce and the weight update, so this charges it in full rather than not at all
+        if (prof && rc == DSPMAP_OK && hs[i]->mgpu_side_pending) { (void)hipStreamWaitEvent(st, hs[i]->ev_join, 0); hs[i]->mgpu_side_pending = false; }
+        mark(i, 4, 1);
+        if (rc != DSPMAP_OK) return rc;
+        l.p[i] = hs[i]->s.obs_ck;
+    }
     const int n_ck = hs[0]->d.np * DSP_OBS_CAP + hs[0]->d.np;
     mark(n, 4, 0);
     hipLaunchKernelGGL(k_group_sum_i64, dim3((n_ck + 255) / 256), dim3(256), 0, st, l, n_ck);

@@ -164,6 +164,7 @@ struct dspmap {
     bool mgpu_exact_lists = false;     // this frame selects the pyramid lists' cut over all ranks (dspmap_dist.hip)
     bool mgpu_split = false, mgpu_placed = false;   // between dspmap_mgpu_place_phase and dspmap_mgpu_ck_phase
     unsigned state_epoch = 0;          // bumped whenever particles are written outside a frame (seed / import / clear / checkpoint)
+    bool mgpu_est_side = false;        // this frame's estimator (and the newborn children behind it) run on the side stream, beside the prediction
     bool mgpu_side_pending = false;    // the placement of the tiles without a view runs on the side stream (joined before the birth split)
     int vz_frames_at_begin = 0;
     int mgpu_nstatic_cap = 0;
@@ -188,6 +189,7 @@ int dspmap_fail(dspmap* m, int code, const char* fmt, ...);
 void dspmap_prof_mark(dspmap* m, int i);
 void dspmap_prof_collect(dspmap* m);
 LaunchCtx dspmap_ctx_of(dspmap* m);
+void dspmap_mgpu_birth_early(dspmap* m, const LaunchCtx& c);   // the newborn children of a split-phase frame, on the stream the estimator ran on
 void dspmap_resample(dspmap* m, const LaunchCtx& c);   // launch_resample + bookkeeping of the variant it ran
 int dspmap_gate_and_delta(dspmap* m, const float pos[3], double stamp, const float q[4], float dp[3], float* dt);
 int dspmap_check_estimator_queue(dspmap* m);   // first thing in every frame entry point: fails once if an earlier frame's cross-queue wait gave up

@@ -98,10 +98,25 @@ extern "C" int dspmap_mgpu_begin(dspmap_t* m, int n_points, const float* points_
     dspmap_prof_collect(m);
     HIPCHK(m, hipEventRecord(m->ev0, m->stream));
     launch_setup_and_bin(c, n_points, false, ring, DSPMAP_RING - 1);
+    // the estimator runs BESIDE the prediction, like the reference's helper thread (:297,311) and like the unsharded frame's side branch: it
+    // needs the binned view only; whoever needs its cloud (newborn children, the birth split) joins the side stream first (mgpu_side_pending)
+    const bool est_side = mode == 2 && nb > 0 && m->stream2 && m->stream2 != m->stream;
+    if (est_side) HIPCHK(m, hipEventRecord(m->ev_fork, m->stream));
     // + gather + (static tags) the birth rank; k_place follows the exchange: imported movers take part in the sweep-order placement
     launch_predict_only(c, true, nb > 0 && mode != 2);
     if (ring) dspmap_ring_pushed(m);
-    if (mode == 2 && nb > 0) { launch_velocity_estimator(c, true); m->ve_last_at = 2; }   // ... with the estimator the rank rides on k_ve_clusters
+    m->mgpu_est_side = false;
+    if (mode == 2 && nb > 0) {   // ... with the estimator the rank rides on k_ve_clusters
+        if (est_side) {
+            HIPCHK(m, hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
+            LaunchCtx c2 = c;
+            c2.stream = m->stream2;
+            launch_velocity_estimator(c2, true);
+            HIPCHK(m, hipEventRecord(m->ev_join, m->stream2));
+            m->mgpu_est_side = true; m->mgpu_side_pending = true;
+        } else launch_velocity_estimator(c, true);
+        m->ve_last_at = 2;
+    }
     m->mgpu_all_static = mode == 1;
     m->mgpu_place_pending = true;
     m->mgpu_interior_done = false;
@@ -140,7 +155,7 @@ extern "C" int dspmap_mgpu_export_both(dspmap_t* m, float* up_dev_out, float* do
     launch_export_slab(c, 0, up_dev_out, cap, counts_dev, down_dev_out);   // one pass over the slab's occupancy words for both faces
     // the caller now synchronises with the host to size the exchange: the birth rank and the newborn children only need
     // the frame's birth cloud, so they fill that gap instead of sitting in dspmap_mgpu_finish
-    launch_birth_early(c, m->last_n_birth, false);   // (the rank rode on k_predict's launch)
+    dspmap_mgpu_birth_early(m, c);   // (the rank rode on k_predict's launch / on the estimator's)
     m->mgpu_birth_early = true;
     HIPCHK(m, hipGetLastError());
     return DSPMAP_OK;
@@ -183,6 +198,17 @@ extern "C" int dspmap_mgpu_import(dspmap_t* m, int n, const float* rec_dev) {
     return DSPMAP_OK;
 }
 
+// the newborn children (they need the frame's birth cloud only): behind the estimator on the side stream when it runs there, so that
+// the main chain never waits for it before the birth split
+void dspmap_mgpu_birth_early(dspmap* m, const LaunchCtx& c) {
+    if (m->mgpu_est_side) {
+        LaunchCtx c2 = c;
+        c2.stream = m->stream2;
+        launch_birth_early(c2, m->last_n_birth, false);
+        (void)hipEventRecord(m->ev_join, m->stream2);
+        m->mgpu_side_pending = true;
+    } else launch_birth_early(c, m->last_n_birth, false);
+}
 // the phase in two halves, so that the C++ driver (dspmap_dist.hip) can select the pyramid lists' GLOBAL cut between them
 int dspmap_mgpu_place_phase(dspmap* m) {
     READY(m);
@@ -254,6 +280,7 @@ extern "C" int dspmap_mgpu_finish(dspmap_t* m) {
     READY(m);
     LaunchCtx c = dspmap_ctx_of(m);
     if (m->vz_frames <= 0) c.s.vz0 = nullptr;
+    if (m->mgpu_side_pending) { HIPCHK(m, hipStreamWaitEvent(m->stream, m->ev_join, 0)); m->mgpu_side_pending = false; }   // (a caller that skipped the weight phase)
     if (!m->mgpu_birth_early) launch_birth_early(c, m->last_n_birth, false);   // caller used the per-direction exports
     launch_birth_finish(c, m->last_n_birth, m->mgpu_all_static);
     m->mgpu_birth_early = false;
