@@ -991,13 +991,14 @@ static void enqueue_frame(dspmap* m, LaunchCtx& c, int pts_grid, int birth_grid,
         }
         dspmap_prof_mark(m, 2);
         launch_claim(c, 0, 0, 0, 0, split ? 1 : -1);
-        if (split && side_fork == 1) (void)hipEventRecord(m->ev_fork2, m->stream);
+        // (the side stream carries the estimator first: "behind the prediction" -- fork 2 -- is "behind the placement of the tiles with a view" here)
+        if (split && side_fork >= 1) (void)hipEventRecord(m->ev_fork2, m->stream);
         if (split) launch_pyr_prepare(c);
-        if (split && side_fork == 1) side_place();   // (behind the estimator's kernels on that stream)
+        if (split && side_fork >= 1) side_place();   // (behind the estimator's kernels on that stream)
         dspmap_prof_mark(m, 3);
-        if (split && side_fork != 1) (void)hipEventRecord(m->ev_fork2, m->stream);
+        if (split && side_fork < 1) (void)hipEventRecord(m->ev_fork2, m->stream);
         launch_ck_partial(c, split);
-        if (split && side_fork != 1) side_place();   // the side stream places the arrivals of the tiles outside the field of view (behind the estimator's kernels)
+        if (split && side_fork < 1) side_place();   // the side stream places the arrivals of the tiles outside the field of view (behind the estimator's kernels)
         dspmap_prof_mark(m, 4);
         launch_weight_update(c);
         dspmap_prof_mark(m, 5);
